@@ -1,0 +1,249 @@
+"""ctypes binding of the CPU oracle (oracle/pvs_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by bench.py's ``cpu_baseline``
+leg and by ``__graft_entry__.smoke()`` as the checker.  Nothing under
+``panoptikon_amd/`` imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libpvs_oracle.so")
+
+F32, F16, I8 = 0, 1, 2
+COSINE, L2 = 0, 1
+AGG_NONE, AGG_MIN, AGG_MAX, AGG_AVG = 0, 1, 2, 3
+_NP = {F32: np.float32, F16: np.float16, I8: np.int8}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "pvs_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-B", "libpvs_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, sz, f, d, i32, u32, i64p = C.c_void_p, C.c_size_t, C.c_float, C.c_double, C.c_int, C.c_uint32, C.c_void_p
+        L.orc_scale_from_absmax.restype = f
+        L.orc_scale_from_absmax.argtypes = [f]
+        L.orc_blob_absmax.restype = f
+        L.orc_blob_absmax.argtypes = [vp, sz]
+        L.orc_scale_artifact.argtypes = [f, vp]
+        L.orc_artifact_scale.restype = i32
+        L.orc_artifact_scale.argtypes = [vp, sz, C.POINTER(f)]
+        L.orc_quantize_int8.argtypes = [vp, sz, f, vp]
+        L.orc_compute_int8_scale.restype = i32
+        L.orc_compute_int8_scale.argtypes = [vp, sz, sz, C.POINTER(f)]
+        L.orc_f16_to_f32.restype = f
+        L.orc_f16_to_f32.argtypes = [C.c_uint16]
+        L.orc_npy_f16_to_f32.restype = f
+        L.orc_npy_f16_to_f32.argtypes = [C.c_uint16]
+        L.orc_f32_to_f16.restype = C.c_uint16
+        L.orc_f32_to_f16.argtypes = [f]
+        for name in ("l2_f32", "cosine_f32", "l2_i8", "cosine_i8"):
+            fn = getattr(L, "orc_vec_distance_" + name)
+            fn.restype = d
+            fn.argtypes = [vp, vp, sz]
+        L.orc_i8_l2_from_sums.restype = d
+        L.orc_i8_l2_from_sums.argtypes = [C.c_int64]
+        L.orc_i8_cosine_from_sums.restype = d
+        L.orc_i8_cosine_from_sums.argtypes = [C.c_int64] * 3
+        L.orc_score_all.argtypes = [i32, i32, vp, sz, sz, vp, vp, i32]
+        L.orc_topk.restype = u32
+        L.orc_topk.argtypes = [vp, i64p, sz, u32, vp, vp]
+        L.orc_search.restype = u32
+        L.orc_search.argtypes = [i32, i32, vp, sz, sz, vp, i64p, u32, vp, vp, i32]
+        L.orc_aggregate.restype = sz
+        L.orc_aggregate.argtypes = [vp, vp, vp, sz, i32, vp, vp]
+        L.orc_row_number.argtypes = [vp, vp, sz, vp]
+        L.orc_rrf_score.restype = d
+        L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
+        L.orc_synth_gauss.restype = f
+        L.orc_synth_gauss.argtypes = [C.c_uint64, C.c_uint64, u32]
+        L.orc_synth_rows.argtypes = [C.c_uint64, C.c_uint64, sz, u32, vp]
+        L.orc_max_threads.restype = i32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ----------------------------------------------------------------- codec
+def scale_from_absmax(absmax: float) -> float:
+    return float(lib().orc_scale_from_absmax(np.float32(absmax)))
+
+
+def blob_absmax(x) -> float:
+    x = _c(x, np.float32)
+    return float(lib().orc_blob_absmax(_p(x), x.size))
+
+
+def scale_artifact(scale: float) -> bytes:
+    out = np.zeros(4, np.uint8)
+    lib().orc_scale_artifact(np.float32(scale), _p(out))
+    return out.tobytes()
+
+
+def artifact_scale(artifact: bytes):
+    buf = np.frombuffer(bytes(artifact), np.uint8).copy() if len(artifact) else np.zeros(1, np.uint8)
+    s = C.c_float()
+    ok = lib().orc_artifact_scale(_p(buf), len(artifact), C.byref(s))
+    return float(s.value) if ok else None
+
+
+def quantize_int8(x, scale: float) -> np.ndarray:
+    x = _c(x, np.float32)
+    out = np.empty(x.shape, np.int8)
+    lib().orc_quantize_int8(_p(x), x.size, np.float32(scale), _p(out))
+    return out
+
+
+def compute_int8_scale(rows):
+    rows = _c(rows, np.float32)
+    if rows.ndim != 2:
+        raise ValueError("rows must be [n][dim]")
+    s = C.c_float()
+    ok = lib().orc_compute_int8_scale(_p(rows), rows.shape[0], rows.shape[1], C.byref(s))
+    return float(s.value) if ok else None
+
+
+def f32_to_f16_bits(x) -> np.ndarray:
+    x = _c(x, np.float32)
+    L = lib()
+    return np.array([L.orc_f32_to_f16(v) for v in x.ravel()], np.uint16).reshape(x.shape)
+
+
+def f16_bits_to_f32(b) -> np.ndarray:
+    b = _c(b, np.uint16)
+    L = lib()
+    return np.array([L.orc_f16_to_f32(int(v)) for v in b.ravel()], np.float32).reshape(b.shape)
+
+
+def npy_f16_bits_to_f32(b) -> np.ndarray:
+    """The reference's own f16 widening (halves subnormals; embedding_utils.rs:323-350)."""
+    b = _c(b, np.uint16)
+    L = lib()
+    return np.array([L.orc_npy_f16_to_f32(int(v)) for v in b.ravel()], np.float32).reshape(b.shape)
+
+
+# ------------------------------------------------------------- distances
+def vec_distance(metric: int, a, b) -> float:
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.dtype == np.int8:
+        assert b.dtype == np.int8 and a.size == b.size
+        fn = lib().orc_vec_distance_l2_i8 if metric == L2 else lib().orc_vec_distance_cosine_i8
+    else:
+        a = _c(a, np.float32)
+        b = _c(b, np.float32)
+        assert a.size == b.size
+        fn = lib().orc_vec_distance_l2_f32 if metric == L2 else lib().orc_vec_distance_cosine_f32
+    return float(fn(_p(a), _p(b), a.size))
+
+
+def _corpus(dtype: int, corpus):
+    c = np.ascontiguousarray(corpus)
+    if c.dtype != _NP[dtype]:
+        raise TypeError(f"corpus dtype {c.dtype} != {_NP[dtype]}")
+    if c.ndim != 2:
+        raise ValueError("corpus must be [n][dim]")
+    return c
+
+
+def _query(dtype: int, q, dim: int):
+    q = _c(q, np.int8 if dtype == I8 else np.float32)
+    if q.size != dim:
+        raise ValueError("query dimension mismatch")
+    return q
+
+
+def score_all(dtype: int, metric: int, corpus, query, threads: int = 1) -> np.ndarray:
+    c = _corpus(dtype, corpus)
+    q = _query(dtype, query, c.shape[1])
+    out = np.empty(c.shape[0], np.float32)
+    lib().orc_score_all(dtype, metric, _p(c), c.shape[0], c.shape[1], _p(q), _p(out), threads)
+    return out
+
+
+def topk(dist, k: int, ids=None):
+    dist = _c(dist, np.float32)
+    ids_a = None if ids is None else _c(ids, np.int64)
+    m = min(k, dist.size)
+    oi = np.empty(max(m, 1), np.int64)
+    od = np.empty(max(m, 1), np.float32)
+    cnt = lib().orc_topk(_p(dist), _p(ids_a), dist.size, k, _p(oi), _p(od))
+    return oi[:cnt].copy(), od[:cnt].copy()
+
+
+def search(dtype: int, metric: int, corpus, queries, k: int, ids=None, threads: int = 1):
+    """Batch of queries -> (ids[B][k'], dist[B][k']), k' = min(k, n)."""
+    c = _corpus(dtype, corpus)
+    queries = np.ascontiguousarray(queries)
+    if queries.ndim == 1:
+        queries = queries[None, :]
+    ids_a = None if ids is None else _c(ids, np.int64)
+    m = min(k, c.shape[0])
+    oi = np.empty((queries.shape[0], max(m, 1)), np.int64)
+    od = np.empty((queries.shape[0], max(m, 1)), np.float32)
+    for b in range(queries.shape[0]):
+        q = _query(dtype, queries[b], c.shape[1])
+        lib().orc_search(dtype, metric, _p(c), c.shape[0], c.shape[1], _p(q), _p(ids_a), k,
+                         _p(oi[b]), _p(od[b]), threads)
+    return oi[:, :m], od[:, :m]
+
+
+# ------------------------------------------------- aggregate / rank / RRF
+def aggregate(dist, group, agg: int, w=None):
+    dist = _c(dist, np.float32)
+    group = _c(group, np.int64)
+    w_a = None if w is None else _c(w, np.float32)
+    og = np.empty(max(dist.size, 1), np.int64)
+    ov = np.empty(max(dist.size, 1), np.float64)
+    g = lib().orc_aggregate(_p(dist), _p(w_a), _p(group), dist.size, agg, _p(og), _p(ov))
+    return og[:g].copy(), ov[:g].copy()
+
+
+def row_number(val, ids=None) -> np.ndarray:
+    val = _c(val, np.float64)
+    ids_a = None if ids is None else _c(ids, np.int64)
+    out = np.empty(max(val.size, 1), np.int64)
+    lib().orc_row_number(_p(val), _p(ids_a), val.size, _p(out))
+    return out[: val.size]
+
+
+def rrf_score(ranks, ks, weights) -> float:
+    """ranks < 0 encode SQL NULL (branch did not return the row)."""
+    r = _c(ranks, np.int64)
+    k = _c(ks, np.int32)
+    w = _c(weights, np.float64)
+    return float(lib().orc_rrf_score(_p(r), _p(k), _p(w), r.size))
+
+
+# -------------------------------------------------------------- synthetic
+def synth_rows(seed: int, row0: int, n: int, dim: int) -> np.ndarray:
+    out = np.empty((n, dim), np.float32)
+    lib().orc_synth_rows(seed, row0, n, dim, _p(out))
+    return out
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
