@@ -1,0 +1,266 @@
+/*
+ * pvs.h — C ABI of the MI355X-native vector-similarity scan for Panoptikon
+ * ("Panoptikon Vector Scan").  This is the drop-in boundary:
+ * plain pointers and sizes, no C++ or torch types, no exceptions across it.
+ * A Rust host binds it with an `extern "C"` block.
+ *
+ * What each entry point replaces in the reference (paths under
+ * reasv/panoptikon, panoptikon/src/...):
+ *
+ *   pvs_search / pvs_score_all   the per-row `vec_distance_cosine` / `vec_distance_L2`
+ *                                scalar SQL functions of sqlite-vec 0.1.9, registered at
+ *                                db/sql_functions.rs:105-128 and emitted by
+ *                                pql/builder/filters/image_embeddings.rs:321-362,
+ *                                text_embeddings.rs:386-418, item_similarity.rs:503-521,
+ *                                i.e. the `d` column of the MATERIALIZED dist_{cte}
+ *                                (filters/exact.rs:106-165) and, for pvs_search, everything
+ *                                down to `ORDER BY order_rank ASC ... LIMIT k`
+ *                                (pql/builder.rs:578-582, 1043-1223).
+ *   pvs_quantize_i8              quantize_int8 / compute_query_quant, db/vector_quants.rs:1489-1503
+ *   pvs_absmax / pvs_scale_from_absmax
+ *                                blob_absmax / scale_from_absmax / compute_int8_scale_artifact,
+ *                                db/vector_quants.rs:1465-1483, 1513-1554
+ *   pvs_artifact_scale / pvs_scale_artifact
+ *                                artifact_scale / scale_artifact, db/vector_quants.rs:1449-1460
+ *   pvs_aggregate                rank_aggregate + GROUP BY file_id, filters/exact.rs:67-80,
+ *                                pql/builder.rs:829-835
+ *   pvs_row_number / pvs_rrf_fuse
+ *                                add_rank_column_expr pql/builder.rs:757-771 and
+ *                                build_coalesced_expr pql/builder.rs:1284-1317
+ *   pvs_npy_to_f32               embedding_from_npy_bytes, pql/embedding_utils.rs:10-76,229-350
+ *   pvs_resolve_vector_quant     resolve_vector_quant policy, pql/preprocess.rs:314-446
+ *
+ * Conventions
+ *   - every function returns pvs_status (0 = OK); pvs_last_error() returns a
+ *     thread-local message for the last failing call on this thread.
+ *   - all buffers are caller-owned; `*_space` says whether a pointer is host or
+ *     device (HBM) memory.  Device pointers must belong to the index's device.
+ *   - vectors are dense little-endian arrays in component order: f32 (the
+ *     reference's storage format, extraction_write.rs:574-616), IEEE f16, or int8
+ *     codes (db/vector_quants.rs:1489-1497).
+ *   - ordering: (distance ascending, row id ascending); NaN distances (SQL NULL in
+ *     the reference) sort last.  The id tie-break is the build's addition
+ *     (SURVEY.md §8c); the reference leaves ties unspecified.
+ *   - threading: pvs_search* / pvs_score_all may be called concurrently from many
+ *     host threads on one index (the reference runs up to 16 read connections,
+ *     db/connection.rs:235); pvs_index_add / set_scale / destroy are exclusive.
+ */
+#ifndef PVS_H
+#define PVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVS_ABI_VERSION 1
+
+typedef int32_t pvs_status;
+enum {
+    PVS_OK = 0,
+    PVS_ERR_INVALID_ARG = 1,  /* null pointer, bad enum, k < 1 (preprocess.rs:436-446) ... */
+    PVS_ERR_DIM_MISMATCH = 2, /* the reference's sqlite-vec SQL error -> 500 (db/pql.rs:18-21) */
+    PVS_ERR_DEVICE = 3,       /* HIP runtime failure or no gfx950 device */
+    PVS_ERR_OOM = 4,
+    PVS_ERR_STATE = 5,        /* e.g. f32 query on an int8 index whose scale is not set */
+    PVS_ERR_UNSUPPORTED = 6,
+    PVS_ERR_PARSE = 7,        /* malformed .npy (embedding_utils.rs error strings) */
+    PVS_ERR_NOT_READY = 8,    /* strict quant selection that cannot be served (preprocess.rs:327-383) */
+    PVS_ERR_COMM = 9          /* RCCL failure */
+};
+
+typedef enum { PVS_F32 = 0, PVS_F16 = 1, PVS_I8 = 2 } pvs_dtype;
+typedef enum { PVS_COSINE = 0, PVS_L2 = 1 } pvs_metric;
+/* embedding_types.rs:4-18 DistanceAggregation (+ NONE = per-row results) */
+typedef enum { PVS_AGG_NONE = 0, PVS_AGG_MIN = 1, PVS_AGG_MAX = 2, PVS_AGG_AVG = 3 } pvs_agg;
+typedef enum { PVS_HOST = 0, PVS_DEVICE = 1 } pvs_space;
+
+typedef struct pvs_index pvs_index;
+
+typedef struct pvs_index_desc {
+    uint32_t struct_size;   /* sizeof(pvs_index_desc) */
+    int32_t device;         /* HIP device ordinal, -1 = current device */
+    uint32_t dtype;         /* pvs_dtype of the rows resident in HBM */
+    uint32_t dim;           /* components per vector (dim = blob_len/4 in the reference) */
+    uint64_t capacity_rows; /* rows to reserve up front (0 = grow on demand) */
+    int64_t id_base;        /* row id of row 0 when pvs_index_add is given row_ids == NULL */
+} pvs_index_desc;
+
+typedef struct pvs_stats {
+    uint32_t struct_size;
+    uint32_t dtype, dim;
+    uint64_t rows, capacity_rows;
+    uint64_t row_stride_bytes;  /* padded row pitch in HBM */
+    uint64_t hbm_bytes;         /* bytes resident for this index */
+    float scale;                /* int8 scale artifact (0 when unset) */
+    uint64_t searches;          /* pvs_search* calls served */
+    uint64_t fast_queries;      /* queries answered by the filter-scan path */
+    uint64_t dense_queries;     /* queries answered by the dense score+sort path */
+    uint64_t last_candidates;   /* candidates emitted by the last filter scan (all queries) */
+} pvs_stats;
+
+/* ------------------------------------------------------------------ library */
+uint32_t pvs_abi_version(void);
+const char *pvs_last_error(void);
+/* number of visible gfx950 devices (0 when there is no usable GPU) */
+int32_t pvs_device_count(void);
+
+/* -------------------------------------------------------------------- index */
+pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **out);
+void pvs_index_destroy(pvs_index *idx);
+
+/* Appends n rows of the index dtype (f32 / f16 / int8 codes).  row_ids are the
+ * reference's item_data.id (embeddings.id); they must be strictly increasing
+ * across the whole index (the reference streams rows ORDER BY item_data.id,
+ * db/vector_quants.rs:1085-1099) so that "row id ascending" and "row order"
+ * coincide.  row_ids == NULL assigns id_base + row index.  group_ids (file_id /
+ * item_id, optional) feed pvs_aggregate; rows of one group need not be adjacent. */
+pvs_status pvs_index_add(pvs_index *idx, const void *rows, uint64_t n, const int64_t *row_ids,
+                         const int64_t *group_ids, pvs_space rows_space);
+
+/* Write side of the codec (backfill_chunk, db/vector_quants.rs:1119-1163): rows
+ * arrive as f32 and are converted on the device to the index dtype — int8 via
+ * quantize_int8 with the index scale (which must be set), f16 via round-to-
+ * nearest-even, f32 unchanged. */
+pvs_status pvs_index_add_f32(pvs_index *idx, const float *rows, uint64_t n, const int64_t *row_ids,
+                             const int64_t *group_ids, pvs_space rows_space);
+
+/* int8 only: the 4-byte scale artifact.  Same rejections as artifact_scale
+ * (db/vector_quants.rs:1456-1460): len != 4, non-finite, <= 0 -> INVALID_ARG. */
+pvs_status pvs_index_set_scale_artifact(pvs_index *idx, const uint8_t *artifact, size_t len);
+pvs_status pvs_index_set_scale(pvs_index *idx, float scale);
+
+pvs_status pvs_index_stats(pvs_index *idx, pvs_stats *out);
+
+/* ------------------------------------------------------------------- search */
+
+/* Page 1 of size k of the reference ordering, for `batch` queries.
+ *   queries: [batch][dim] of query_dtype.  f32 queries are accepted by every index
+ *     (an int8 index quantizes them with its scale, like compute_query_quant; an
+ *     f16/f32 index scores them as f32).  int8 queries (QuantResolved.query_quant)
+ *     are accepted by int8 indexes only.  f16 queries are not accepted.
+ *   out_ids / out_dist: [batch][k]; out_count[batch] = rows written (min(k, rows)).
+ *     Unwritten tail slots are set to id -1 / distance NaN.
+ * Distances are the f32 value sqlite-vec would return (bit-exact for int8; for
+ * f32/f16 the build reproduces the scalar sequential-f32 evaluation). */
+pvs_status pvs_search(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch,
+                      uint32_t k, pvs_metric metric, int64_t *out_ids, float *out_dist,
+                      uint32_t *out_count);
+
+/* Same, with every buffer resident in HBM (queries, out_*).  Enqueues on one of
+ * the index's streams and returns without synchronising; *out_ticket identifies
+ * the stream to wait on with pvs_wait (or pvs_sync for all of them). */
+pvs_status pvs_search_device(pvs_index *idx, const void *d_queries, pvs_dtype query_dtype,
+                             uint32_t batch, uint32_t k, pvs_metric metric, int64_t *d_out_ids,
+                             float *d_out_dist, uint32_t *d_out_count, uint32_t *out_ticket);
+pvs_status pvs_wait(pvs_index *idx, uint32_t ticket);
+pvs_status pvs_sync(pvs_index *idx);
+
+/* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort
+ * (every row scored exactly, full device sort), 2 = filter scan only (error
+ * instead of falling back).  For tests and profiling. */
+pvs_status pvs_index_set_path(pvs_index *idx, uint32_t path);
+
+/* The `d` column of dist_{cte}: one distance per row, in row order. */
+pvs_status pvs_score_all(pvs_index *idx, const void *query, pvs_dtype query_dtype, pvs_metric metric,
+                         float *out_dist, pvs_space out_space);
+
+/* Per-group aggregate of per-row distances (GROUP BY file_id; MIN/MAX/AVG, or
+ * SUM(d*w)/SUM(w) when weights != NULL — `agg` is ignored then, exact.rs:67-80).
+ * dist / weights / group_ids: [n] host arrays, group_ids non-decreasing.
+ * Outputs one (group, f64 aggregate) per distinct group; NaN distance = SQL NULL. */
+pvs_status pvs_aggregate(const float *dist, const float *weights, const int64_t *group_ids, uint64_t n,
+                         pvs_agg agg, int64_t *out_groups, double *out_values, uint64_t *out_n);
+
+/* ------------------------------------------------------- codec (device side) */
+/* max |x_i| over n floats, NaN ignored (blob_absmax).  Runs on the GPU. */
+pvs_status pvs_absmax(const float *x, uint64_t n, pvs_space space, int32_t device, float *out_absmax);
+/* clamp(round_ties_even(x / scale), -128, 127) as i8, NaN -> 0.  Runs on the GPU. */
+pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, int8_t *out, pvs_space space,
+                           int32_t device);
+
+/* ------------------------------------------------------- codec (host scalars) */
+float pvs_scale_from_absmax(float absmax);
+void pvs_scale_artifact(float scale, uint8_t out[4]);
+/* returns PVS_OK and *scale, or PVS_ERR_INVALID_ARG for an unusable artifact */
+pvs_status pvs_artifact_scale(const uint8_t *artifact, size_t len, float *scale);
+
+/* ------------------------------------------------------------- rank and RRF */
+/* row_number() OVER (ORDER BY value ASC), ties by id ascending, NaN (NULL) last. */
+pvs_status pvs_row_number(const double *values, const int64_t *ids, uint64_t n, int64_t *out_rank);
+/* fused[i] = sum_b weight_b * 1.0 / (k_b + coalesce(rank[b][i], 9223372036854775805));
+ * ranks: [n_branches][n], rank < 0 = NULL (branch did not return the row). */
+pvs_status pvs_rrf_fuse(const int64_t *ranks, uint32_t n_branches, uint64_t n, const int32_t *ks,
+                        const double *weights, double *out_fused);
+
+/* -------------------------------------------------- query ingestion / policy */
+/* .npy (v1/2/3; f2 f4 f8 i1-8 u1-8 bool; LE/BE; C/Fortran; 1-D or first row of
+ * 2-D) -> f32.  Returns the component count in *out_n; when out == NULL only
+ * reports the count.  Error strings match embedding_utils.rs. */
+pvs_status pvs_npy_to_f32(const uint8_t *npy, size_t len, float *out, size_t out_cap, size_t *out_n);
+
+typedef enum { PVS_INDEX_AUTO = 0, PVS_INDEX_EXACT = 1, PVS_INDEX_QUANT = 2, PVS_INDEX_ANN = 3 } pvs_index_mode;
+
+/* The state resolve_ready_pair (db/vector_quants.rs:1795-1869) would return for
+ * (profile, setters), supplied by the caller that owns the database. */
+typedef struct pvs_ready_pair {
+    int32_t have_db_context;     /* 0: no quant connection available */
+    int32_t have_default_profile;/* 0: no default profile configured and no variant named */
+    int32_t pair_ready;          /* 0: profile missing / setter not ready / unusable scale */
+    int64_t profile_id;
+    float scale;
+    int64_t dim;
+} pvs_ready_pair;
+
+typedef struct pvs_quant_resolved {
+    int32_t use_quant;   /* 0 = search exact (Ok(None) in the reference) */
+    int64_t profile_id;
+    uint64_t query_quant_len; /* 0 when no embedding was given */
+} pvs_quant_resolved;
+
+/* resolve_vector_quant (pql/preprocess.rs:314-393).  embedding: f32 LE query bytes
+ * (may be NULL); query_quant_out receives dim int8 codes when use_quant and an
+ * embedding was given.  Strict selections (index=quant or a non-blank variant)
+ * turn every fallback condition into PVS_ERR_NOT_READY / PVS_ERR_DIM_MISMATCH. */
+pvs_status pvs_resolve_vector_quant(pvs_index_mode index, const char *variant, int64_t k,
+                                    const pvs_ready_pair *pair, const uint8_t *embedding,
+                                    size_t embedding_len, int8_t *query_quant_out,
+                                    size_t query_quant_cap, pvs_quant_resolved *out);
+
+/* ------------------------------------------------------------- multi-GPU (RCCL) */
+typedef struct pvs_comm pvs_comm;
+#define PVS_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id and ships the 128 bytes to the other ranks out of band */
+pvs_status pvs_comm_unique_id(uint8_t id[PVS_UNIQUE_ID_BYTES]);
+pvs_status pvs_comm_create(const uint8_t id[PVS_UNIQUE_ID_BYTES], int32_t world, int32_t rank,
+                           int32_t device, pvs_comm **out);
+void pvs_comm_destroy(pvs_comm *comm);
+/* Row-sharded search: idx holds this rank's shard (its row ids are global).
+ * Each rank scores its shard, one ncclAllGather moves the per-shard top-k
+ * (batch*k*(f32,i64)) over xGMI, every rank merges.  Outputs are device buffers
+ * [batch][k] valid on every rank. */
+pvs_status pvs_search_sharded(pvs_index *idx, pvs_comm *comm, const void *d_queries,
+                              pvs_dtype query_dtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+/* k-way merge of `world` per-shard pages (host buffers, [world][batch][k] with
+ * counts [world][batch]) under the shared ordering; the same routine the device
+ * merge kernel implements, exposed for hosts that gather by other means. */
+pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t *counts,
+                          uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
+                          float *out_dist, uint32_t *out_count);
+
+/* ------------------------------------------------- device memory + synthetic */
+pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out);
+pvs_status pvs_device_free(int32_t device, void *ptr);
+pvs_status pvs_memcpy(void *dst, const void *src, size_t bytes, int32_t device);
+/* Unit-normalised pseudo-Gaussian rows, generated in HBM:
+ * row r, component c is a pure function of (seed, row0 + r, c). */
+pvs_status pvs_synth_rows_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
+                              float *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVS_H */

@@ -528,26 +528,32 @@ static uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
     return x ^ (x >> 31);
 }
-ORC_API float orc_synth_gauss(uint64_t seed, uint64_t row, uint32_t col) {
+static int32_t synth_raw(uint64_t seed, uint64_t row, uint32_t col) {
     uint64_t key = seed * 0xD1342543DE82EF95ULL + row * 0x9E3779B97F4A7C15ULL + (uint64_t)col * 0xC2B2AE3D27D4EB4FULL;
     uint64_t a = splitmix64(key), b = splitmix64(key ^ 0xA5A5A5A5A5A5A5A5ULL), c = splitmix64(key + 0x1234567ULL);
     uint32_t s = 0;
     for (int i = 0; i < 4; i++) s += (uint32_t)((a >> (16 * i)) & 0xffff);
     for (int i = 0; i < 4; i++) s += (uint32_t)((b >> (16 * i)) & 0xffff);
     for (int i = 0; i < 4; i++) s += (uint32_t)((c >> (16 * i)) & 0xffff);
-    /* mean 12*32767.5 = 393210, sd = 65536*sqrt(12/12)=~65536*1.0 (var of U16 ~ 65536^2/12) */
-    return (float)((int32_t)s - 393210) * (1.0f / 65536.0f);
+    /* sum of 12 U16: mean 12*32767.5 = 393210, variance 12*(65536^2-1)/12 ~ 65536^2 */
+    return (int32_t)s - 393210;
 }
+ORC_API float orc_synth_gauss(uint64_t seed, uint64_t row, uint32_t col) {
+    return (float)synth_raw(seed, row, col) * (1.0f / 65536.0f); /* exact: |raw| < 2^19 */
+}
+/* The squared norm is an exact integer sum (|raw|^2 < 2^38, dim <= 2^14 keeps the
+ * sum < 2^53), so it is order independent and the device may reduce it in
+ * parallel and still produce identical bytes. */
 ORC_API void orc_synth_rows(uint64_t seed, uint64_t row0, size_t n, uint32_t dim, float *out) {
     for (size_t r = 0; r < n; r++) {
-        double ss = 0.0;
+        int64_t ss = 0;
         float *o = out + r * dim;
         for (uint32_t c = 0; c < dim; c++) {
-            float g = orc_synth_gauss(seed, row0 + r, c);
-            o[c] = g;
-            ss = fma((double)g, (double)g, ss);
+            int32_t v = synth_raw(seed, row0 + r, c);
+            o[c] = (float)v * (1.0f / 65536.0f);
+            ss += (int64_t)v * (int64_t)v;
         }
-        float nrm = (float)sqrt(ss);
+        float nrm = (float)sqrt((double)ss * (1.0 / 4294967296.0));
         if (!(nrm > 0.0f)) nrm = 1.0f;
         for (uint32_t c = 0; c < dim; c++) o[c] = o[c] / nrm;
     }

@@ -1,0 +1,13 @@
+"""panoptikon_amd — MI355X-native vector-similarity scan for Panoptikon.
+
+The product is libpvs.so (hand-written HIP for gfx950 behind the C ABI of
+include/pvs.h).  This package is the thin Python host mirror used by the tests,
+bench.py and smoke(): it only marshals buffers; nothing here computes a distance.
+"""
+from ._lib import (AGG_AVG, AGG_MAX, AGG_MIN, AGG_NONE, COSINE, DEVICE, F16, F32, HOST, I8, INDEX_ANN, INDEX_AUTO,
+                   INDEX_EXACT, INDEX_QUANT, L2, PvsError, lib)
+from .index import DeviceBuffer, VectorIndex, absmax, device_count, quantize_int8
+from .host import (aggregate, artifact_scale, embedding_from_npy_bytes, extract_embeddings, merge_topk,
+                   resolve_vector_quant, row_number, rrf_fuse, scale_artifact, scale_from_absmax)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

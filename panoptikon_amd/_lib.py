@@ -1,0 +1,115 @@
+"""ctypes binding of libpvs.so (the C ABI in include/pvs.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises — there is no Python or CPU fallback for any distance computation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpvs.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_DIM_MISMATCH, ERR_DEVICE, ERR_OOM, ERR_STATE, ERR_UNSUPPORTED, ERR_PARSE, ERR_NOT_READY, ERR_COMM = range(1, 10)
+F32, F16, I8 = 0, 1, 2
+COSINE, L2 = 0, 1
+AGG_NONE, AGG_MIN, AGG_MAX, AGG_AVG = 0, 1, 2, 3
+HOST, DEVICE = 0, 1
+INDEX_AUTO, INDEX_EXACT, INDEX_QUANT, INDEX_ANN = 0, 1, 2, 3
+UNIQUE_ID_BYTES = 128
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("dtype", C.c_uint32), ("dim", C.c_uint32),
+                ("capacity_rows", C.c_uint64), ("id_base", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_uint32), ("dim", C.c_uint32), ("rows", C.c_uint64),
+                ("capacity_rows", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("hbm_bytes", C.c_uint64),
+                ("scale", C.c_float), ("searches", C.c_uint64), ("fast_queries", C.c_uint64),
+                ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64)]
+
+
+class ReadyPair(C.Structure):
+    _fields_ = [("have_db_context", C.c_int32), ("have_default_profile", C.c_int32), ("pair_ready", C.c_int32),
+                ("profile_id", C.c_int64), ("scale", C.c_float), ("dim", C.c_int64)]
+
+
+class QuantResolved(C.Structure):
+    _fields_ = [("use_quant", C.c_int32), ("profile_id", C.c_int64), ("query_quant_len", C.c_uint64)]
+
+
+class PvsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"pvs status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+# every symbol include/pvs.h declares: name -> (restype, argtypes)
+_vp, _sz, _u32, _u64, _i32, _i64, _f = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "pvs_abi_version": (_u32, []),
+    "pvs_last_error": (C.c_char_p, []),
+    "pvs_device_count": (_i32, []),
+    "pvs_index_create": (_i32, [C.POINTER(IndexDesc), C.POINTER(_vp)]),
+    "pvs_index_destroy": (None, [_vp]),
+    "pvs_index_add": (_i32, [_vp, _vp, _u64, _vp, _vp, _i32]),
+    "pvs_index_add_f32": (_i32, [_vp, _vp, _u64, _vp, _vp, _i32]),
+    "pvs_index_set_scale_artifact": (_i32, [_vp, _vp, _sz]),
+    "pvs_index_set_scale": (_i32, [_vp, _f]),
+    "pvs_index_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "pvs_search": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_search_device": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "pvs_wait": (_i32, [_vp, _u32]),
+    "pvs_sync": (_i32, [_vp]),
+    "pvs_index_set_path": (_i32, [_vp, _u32]),
+    "pvs_score_all": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),
+    "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
+    "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),
+    "pvs_quantize_i8": (_i32, [_vp, _u64, _f, _vp, _i32, _i32]),
+    "pvs_scale_from_absmax": (_f, [_f]),
+    "pvs_scale_artifact": (None, [_f, _vp]),
+    "pvs_artifact_scale": (_i32, [_vp, _sz, C.POINTER(_f)]),
+    "pvs_row_number": (_i32, [_vp, _vp, _u64, _vp]),
+    "pvs_rrf_fuse": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp]),
+    "pvs_npy_to_f32": (_i32, [_vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    "pvs_resolve_vector_quant": (_i32, [_i32, C.c_char_p, _i64, C.POINTER(ReadyPair), _vp, _sz, _vp, _sz,
+                                        C.POINTER(QuantResolved)]),
+    "pvs_comm_unique_id": (_i32, [_vp]),
+    "pvs_comm_create": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "pvs_comm_destroy": (None, [_vp]),
+    "pvs_search_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_merge_topk": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_device_malloc": (_i32, [_i32, _sz, C.POINTER(_vp)]),
+    "pvs_device_free": (_i32, [_i32, _vp]),
+    "pvs_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
+    "pvs_synth_rows_f32": (_i32, [_i32, _u64, _u64, _u64, _u32, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libpvs.so; raises if it was not built (run `python -m panoptikon_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m panoptikon_amd.build` "
+                              "(there is no fallback implementation)")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        msg = lib().pvs_last_error()
+        raise PvsError(status, msg.decode("utf-8", "replace") if msg else "")

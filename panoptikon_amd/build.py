@@ -1,0 +1,79 @@
+"""Builds libpvs.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m panoptikon_amd.build [--force] [-j N]
+
+hipcc cross-compiles without a GPU.  Objects go to panoptikon_amd/csrc/build/,
+the library to panoptikon_amd/libpvs.so (git-ignored; it travels to the GPU box).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libpvs.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = [
+    "pvs_api.hip",
+    "pvs_kernels_util.hip",
+    "pvs_kernels_scan.hip",
+    "pvs_dense.hip",
+    "pvs_comm.hip",
+    "pvs_host.cpp",
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+HIPFLAGS = ["--offload-arch=gfx950", "-ffp-contract=off"]
+HOSTFLAGS = ["-ffp-contract=off"]
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith((".hip", ".cpp", ".hpp", ".h")):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    path = os.path.join(CSRC, src)
+    if src.endswith(".hip"):
+        cmd = [HIPCC, *COMMON, *HIPFLAGS, "-c", path, "-o", obj]
+    else:
+        cmd = [HIPCC, *COMMON, *HOSTFLAGS, "-x", "c++", "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"compile failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, jobs: int | None = None) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
+        return LIB
+    jobs = jobs or min(len(SOURCES), os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    jobs = None
+    if "-j" in sys.argv:
+        jobs = int(sys.argv[sys.argv.index("-j") + 1])
+    print(build(force=force, jobs=jobs))

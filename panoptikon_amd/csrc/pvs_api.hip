@@ -1,0 +1,794 @@
+// pvs_api.hip — C ABI of libpvs: index residency in HBM, search orchestration over HIP
+// streams, device codec entry points.  No torch, no CPU compute path: every distance
+// is produced by a HIP kernel or the call fails (PVS_ERR_DEVICE).
+#include <sched.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "pvs_kernels.hpp"
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+pvs_status pvs_fail(pvs_status code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+PVS_EXPORT const char *pvs_last_error(void) { return g_last_error.c_str(); }
+PVS_EXPORT uint32_t pvs_abi_version(void) { return PVS_ABI_VERSION; }
+
+PVS_EXPORT int32_t pvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int d = 0; d < n; d++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+static pvs_status use_device(int32_t device, int *resolved) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return pvs_fail(PVS_ERR_DEVICE, "no HIP device available (%s): libpvs has no CPU path",
+                        e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    int d = device;
+    if (d < 0) HIP_TRY(hipGetDevice(&d));
+    if (d >= n) return pvs_fail(PVS_ERR_INVALID_ARG, "device %d out of range (%d visible)", d, n);
+    HIP_TRY(hipSetDevice(d));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, d));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return pvs_fail(PVS_ERR_DEVICE, "device %d is %s; libpvs is built for gfx950 (MI355X) only", d, p.gcnArchName);
+    if (resolved) *resolved = d;
+    return PVS_OK;
+}
+
+// ------------------------------------------------------------------- index
+struct PendingChunk {
+    uint32_t qoff, nb;
+};
+
+struct SearchCtx {
+    hipStream_t stream = nullptr;
+    bool busy = false;
+    uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
+    uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
+    uint8_t *d_qexact = nullptr;  // [MAX_BATCH][dim*4]
+    QInfo *d_qinfo = nullptr;     // [MAX_BATCH]
+    float *d_thr = nullptr;       // [MAX_BATCH]
+    float *d_gmin = nullptr;      // [MAX_BATCH][GMAX]
+    uint32_t *d_cand_cnt = nullptr;
+    uint2 *d_cand = nullptr;      // [MAX_BATCH][CAND_CAP]
+    uint32_t *d_need_dense = nullptr;  // [total batch capacity]
+    uint32_t *h_need_dense = nullptr;  // pinned
+    uint32_t flags_cap = 0;
+    // host-variant output staging
+    int64_t *d_out_ids = nullptr;
+    float *d_out_dist = nullptr;
+    uint32_t *d_out_count = nullptr;
+    uint64_t out_cap = 0;  // elements (batch*k)
+    uint32_t out_batch_cap = 0;
+    DenseWork dense;
+    // deferred fallback bookkeeping (device variant)
+    bool pending = false;
+    const void *p_queries = nullptr;
+    int p_qdtype = 0, p_metric = 0;
+    uint32_t p_batch = 0, p_k = 0;
+    int64_t *p_out_ids = nullptr;
+    float *p_out_dist = nullptr;
+    uint32_t *p_out_count = nullptr;
+    bool p_fast = false;
+};
+
+constexpr uint32_t GMAX = 256 * 4 * 32;  // group minima per query (pass A grid <= 256)
+constexpr uint32_t NCTX = 4;
+
+struct pvs_index {
+    int device = 0;
+    uint32_t dtype = 0, dim = 0, esz = 0, stride = 0;
+    uint64_t n = 0, cap = 0;
+    int64_t id_base = 0, last_id = INT64_MIN;
+    uint8_t *d_rows = nullptr;
+    float *d_norm2 = nullptr;
+    int64_t *d_ids = nullptr;
+    std::vector<int64_t> h_groups;  // optional group ids (host copy, for pvs_aggregate callers)
+    float scale = 0.f;
+    bool scale_set = false;
+    uint32_t forced_path = 0;
+    int n_cu = 256;
+    std::mutex mu;
+    SearchCtx ctx[NCTX];
+    hipStream_t admin_stream = nullptr;
+    std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
+};
+
+static void ctx_release(SearchCtx &c) {
+    hipFree(c.d_qin);
+    hipFree(c.d_qmat);
+    hipFree(c.d_qexact);
+    hipFree(c.d_qinfo);
+    hipFree(c.d_thr);
+    hipFree(c.d_gmin);
+    hipFree(c.d_cand_cnt);
+    hipFree(c.d_cand);
+    hipFree(c.d_need_dense);
+    if (c.h_need_dense) hipHostFree(c.h_need_dense);
+    hipFree(c.d_out_ids);
+    hipFree(c.d_out_dist);
+    hipFree(c.d_out_count);
+    pvs_dense_release(c.dense);
+    if (c.stream) hipStreamDestroy(c.stream);
+    c = SearchCtx();
+}
+
+static pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs) {
+    if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (!c.d_qmat) {
+        HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_MAX_BATCH * ix->stride));
+        HIP_TRY(hipMalloc((void **)&c.d_qexact, (size_t)PVS_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_MAX_BATCH * GMAX));
+        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_MAX_BATCH * PVS_CAND_CAP));
+    }
+    if (batch > c.flags_cap) {
+        hipFree(c.d_need_dense);
+        if (c.h_need_dense) hipHostFree(c.h_need_dense);
+        c.d_need_dense = nullptr;
+        c.h_need_dense = nullptr;
+        uint32_t cap = (uint32_t)pvs_round_up(batch, 256);
+        HIP_TRY(hipMalloc((void **)&c.d_need_dense, 4 * (size_t)cap));
+        HIP_TRY(hipHostMalloc((void **)&c.h_need_dense, 4 * (size_t)cap, hipHostMallocDefault));
+        c.flags_cap = cap;
+    }
+    if (host_outputs) {
+        uint64_t need = (uint64_t)batch * k;
+        if (need > c.out_cap || batch > c.out_batch_cap) {
+            hipFree(c.d_out_ids);
+            hipFree(c.d_out_dist);
+            hipFree(c.d_out_count);
+            c.d_out_ids = nullptr;
+            c.d_out_dist = nullptr;
+            c.d_out_count = nullptr;
+            HIP_TRY(hipMalloc((void **)&c.d_out_ids, 8 * need));
+            HIP_TRY(hipMalloc((void **)&c.d_out_dist, 4 * need));
+            HIP_TRY(hipMalloc((void **)&c.d_out_count, 4 * (size_t)batch));
+            c.out_cap = need;
+            c.out_batch_cap = batch;
+        }
+    }
+    return PVS_OK;
+}
+
+pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows);
+
+PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **out) {
+    if (!desc || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (desc->struct_size < sizeof(pvs_index_desc)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_index_desc.struct_size too small");
+    if (desc->dtype > PVS_I8) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown dtype %u", desc->dtype);
+    if (desc->dim == 0 || desc->dim > 16384) return pvs_fail(PVS_ERR_INVALID_ARG, "dim %u out of range [1, 16384]", desc->dim);
+    int dev = 0;
+    PVS_TRY(use_device(desc->device, &dev));
+    pvs_index *ix = new (std::nothrow) pvs_index();
+    if (!ix) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
+    ix->device = dev;
+    ix->dtype = desc->dtype;
+    ix->dim = desc->dim;
+    ix->esz = pvs_esz(desc->dtype);
+    ix->stride = (uint32_t)pvs_round_up((uint64_t)desc->dim * ix->esz, PVS_KSLAB_BYTES);
+    ix->id_base = desc->id_base;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) ix->n_cu = p.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ix->admin_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ix;
+        return pvs_fail(PVS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    if (desc->capacity_rows) {
+        pvs_status s = pvs_index_reserve_(ix, desc->capacity_rows);
+        if (s != PVS_OK) {
+            pvs_index_destroy(ix);
+            *out = nullptr;
+            return s;
+        }
+    }
+    return PVS_OK;
+}
+
+pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
+    const uint64_t cap = pvs_round_up(std::max<uint64_t>(rows, 1), PVS_ROW_ALIGN);
+    if (cap <= ix->cap) return PVS_OK;
+    if (cap > 0xfffffff0ull) return pvs_fail(PVS_ERR_UNSUPPORTED, "a shard holds at most 2^32-16 rows");
+    uint8_t *rows_new = nullptr;
+    float *norm_new = nullptr;
+    int64_t *ids_new = nullptr;
+    HIP_TRY(hipMalloc((void **)&rows_new, cap * (uint64_t)ix->stride));
+    hipError_t e = hipMalloc((void **)&norm_new, cap * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ids_new, cap * 8);
+    if (e != hipSuccess) {
+        hipFree(rows_new);
+        hipFree(norm_new);
+        return pvs_fail(PVS_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    hipStream_t s = ix->admin_stream;
+    // padding rows: zero payload, NaN norm (a NaN norm makes every scan compare fail)
+    HIP_TRY(hipMemsetAsync(rows_new + ix->n * (uint64_t)ix->stride, 0, (cap - ix->n) * (uint64_t)ix->stride, s));
+    HIP_TRY(pvs_launch_fill_f32(norm_new + ix->n, cap - ix->n, __builtin_nanf(""), s));
+    HIP_TRY(hipMemsetAsync(ids_new + ix->n, 0xff, (cap - ix->n) * 8, s));
+    if (ix->n) {
+        HIP_TRY(hipMemcpyAsync(rows_new, ix->d_rows, ix->n * (uint64_t)ix->stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(norm_new, ix->d_norm2, ix->n * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ids_new, ix->d_ids, ix->n * 8, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    hipFree(ix->d_rows);
+    hipFree(ix->d_norm2);
+    hipFree(ix->d_ids);
+    ix->d_rows = rows_new;
+    ix->d_norm2 = norm_new;
+    ix->d_ids = ids_new;
+    ix->cap = cap;
+    return PVS_OK;
+}
+
+PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (auto &c : ix->ctx) ctx_release(c);
+    hipFree(ix->d_rows);
+    hipFree(ix->d_norm2);
+    hipFree(ix->d_ids);
+    if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
+    delete ix;
+}
+
+static pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, int64_t *last) {
+    int64_t prev = ix->last_id;
+    if (!row_ids) {
+        int64_t first = ix->id_base + (int64_t)ix->n;
+        if (ix->n && first <= prev) return pvs_fail(PVS_ERR_INVALID_ARG, "implicit row ids would not be increasing");
+        *last = first + (int64_t)n - 1;
+        return PVS_OK;
+    }
+    for (uint64_t i = 0; i < n; i++) {
+        if (row_ids[i] <= prev && !(ix->n == 0 && i == 0 && prev == INT64_MIN))
+            return pvs_fail(PVS_ERR_INVALID_ARG, "row_ids must be strictly increasing (row %llu: %lld after %lld)",
+                            (unsigned long long)i, (long long)row_ids[i], (long long)prev);
+        prev = row_ids[i];
+    }
+    *last = prev;
+    return PVS_OK;
+}
+
+// rows_dev: [n][dim] dense device array of src_dtype (f32 when converting)
+static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool from_f32, uint64_t n, const int64_t *row_ids,
+                                     const int64_t *group_ids, int64_t last_id) {
+    if (ix->n + n > ix->cap) PVS_TRY(pvs_index_reserve_(ix, std::max<uint64_t>(ix->n + n, ix->cap * 2)));
+    hipStream_t s = ix->admin_stream;
+    uint8_t *dst = ix->d_rows + ix->n * (uint64_t)ix->stride;
+    if (from_f32 && ix->dtype == PVS_I8) {
+        HIP_TRY(pvs_launch_rows_quantize((const float *)rows_dev, ix->dim, n, ix->scale, dst, ix->stride, s));
+    } else if (from_f32 && ix->dtype == PVS_F16) {
+        HIP_TRY(pvs_launch_rows_f32_to_f16((const float *)rows_dev, ix->dim, n, dst, ix->stride, s));
+    } else {
+        const size_t w = (size_t)ix->dim * ix->esz;
+        HIP_TRY(hipMemcpy2DAsync(dst, ix->stride, rows_dev, w, w, n, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(pvs_launch_norm2((int)ix->dtype, dst, ix->stride, ix->dim, n, ix->d_norm2 + ix->n, s));
+    if (row_ids)
+        HIP_TRY(hipMemcpyAsync(ix->d_ids + ix->n, row_ids, n * 8, hipMemcpyHostToDevice, s));
+    else
+        HIP_TRY(pvs_launch_iota_ids(ix->d_ids + ix->n, n, ix->id_base + (int64_t)ix->n, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (group_ids) {
+        if (ix->h_groups.size() != ix->n) ix->h_groups.resize(ix->n, -1);
+        ix->h_groups.insert(ix->h_groups.end(), group_ids, group_ids + n);
+    } else if (!ix->h_groups.empty()) {
+        ix->h_groups.resize(ix->n + n, -1);
+    }
+    ix->n += n;
+    ix->last_id = last_id;
+    return PVS_OK;
+}
+
+static pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids,
+                           const int64_t *group_ids, pvs_space space) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (n == 0) return PVS_OK;
+    if (!rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null rows");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set)
+        return pvs_fail(PVS_ERR_STATE, "int8 index has no scale artifact: set it before adding f32 rows");
+    int64_t last = 0;
+    PVS_TRY(check_ids(ix, row_ids, n, &last));
+    const size_t src_esz = from_f32 ? 4 : ix->esz;
+    if (space == PVS_DEVICE) return append_device_rows(ix, rows, from_f32, n, row_ids, group_ids, last);
+    // host rows: stage through HBM in chunks of <= 256 MiB
+    const uint64_t row_bytes = (uint64_t)ix->dim * src_esz;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+    void *stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, std::min(chunk, n) * row_bytes));
+    pvs_status st = PVS_OK;
+    if (ix->n + n > ix->cap) st = pvs_index_reserve_(ix, std::max<uint64_t>(ix->n + n, ix->cap * 2));
+    for (uint64_t off = 0; off < n && st == PVS_OK; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        hipError_t e = hipMemcpy(stage, (const uint8_t *)rows + off * row_bytes, m * row_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            st = pvs_fail(PVS_ERR_DEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
+            break;
+        }
+        int64_t chunk_last = row_ids ? row_ids[off + m - 1] : ix->id_base + (int64_t)(ix->n + m) - 1;
+        st = append_device_rows(ix, stage, from_f32, m, row_ids ? row_ids + off : nullptr, group_ids ? group_ids + off : nullptr,
+                                chunk_last);
+    }
+    hipFree(stage);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_index_add(pvs_index *ix, const void *rows, uint64_t n, const int64_t *row_ids,
+                                    const int64_t *group_ids, pvs_space space) {
+    return add_impl(ix, rows, false, n, row_ids, group_ids, space);
+}
+PVS_EXPORT pvs_status pvs_index_add_f32(pvs_index *ix, const float *rows, uint64_t n, const int64_t *row_ids,
+                                        const int64_t *group_ids, pvs_space space) {
+    return add_impl(ix, rows, true, n, row_ids, group_ids, space);
+}
+
+PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (ix->dtype != PVS_I8) return pvs_fail(PVS_ERR_INVALID_ARG, "only int8 indexes carry a scale artifact");
+    // artifact_scale (db/vector_quants.rs:1456-1460): finite and > 0, nothing else
+    if (!(std::isfinite(scale) && scale > 0.0f)) return pvs_fail(PVS_ERR_INVALID_ARG, "unusable scale artifact");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->n && ix->scale_set && ix->scale != scale)
+        return pvs_fail(PVS_ERR_STATE, "scale is frozen once rows exist (artifact_rev semantics): rebuild the index");
+    ix->scale = scale;
+    ix->scale_set = true;
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t *artifact, size_t len) {
+    float s = 0.f;
+    PVS_TRY(pvs_artifact_scale(artifact, len, &s));
+    return pvs_index_set_scale(ix, s);
+}
+
+PVS_EXPORT pvs_status pvs_index_set_path(pvs_index *ix, uint32_t path) {
+    if (!ix || path > 2) return pvs_fail(PVS_ERR_INVALID_ARG, "bad path selector");
+    ix->forced_path = path;
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
+    if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    pvs_stats s;
+    memset(&s, 0, sizeof s);
+    s.struct_size = sizeof s;
+    s.dtype = ix->dtype;
+    s.dim = ix->dim;
+    s.rows = ix->n;
+    s.capacity_rows = ix->cap;
+    s.row_stride_bytes = ix->stride;
+    s.hbm_bytes = ix->cap * ((uint64_t)ix->stride + 12);
+    s.scale = ix->scale_set ? ix->scale : 0.f;
+    s.searches = ix->searches.load();
+    s.fast_queries = ix->fast_queries.load();
+    s.dense_queries = ix->dense_queries.load();
+    s.last_candidates = ix->last_candidates.load();
+    *out = s;
+    return PVS_OK;
+}
+
+// ------------------------------------------------------------------- search
+static pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                  pvs_metric metric) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (batch && !queries) return pvs_fail(PVS_ERR_INVALID_ARG, "null queries");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");  // preprocess.rs:441-444
+    if (k > (1u << 20)) return pvs_fail(PVS_ERR_INVALID_ARG, "k too large");
+    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
+    if (qdtype == PVS_I8) {
+        if (ix->dtype != PVS_I8) return pvs_fail(PVS_ERR_DIM_MISMATCH, "int8 query against a float index (element type mismatch)");
+    } else if (qdtype == PVS_F32) {
+        if (ix->dtype == PVS_I8 && !ix->scale_set)
+            return pvs_fail(PVS_ERR_STATE, "f32 query on an int8 index needs the scale artifact");
+    } else {
+        return pvs_fail(PVS_ERR_INVALID_ARG, "queries must be f32 or int8");
+    }
+    return PVS_OK;
+}
+
+static bool fast_path_ok(const pvs_index *ix, uint32_t k) {
+    if (ix->forced_path == 1) return false;
+    if (ix->dtype == PVS_F32) return false;
+    if (!pvs_scan_supported((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES)) return false;
+    if (k > PVS_MAX_K) return false;
+    return ix->n > 0;
+}
+
+// one query through the dense path; q is the query's index inside the current chunk
+static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k, int metric, int64_t *out_ids, float *out_dist,
+                            uint32_t *out_count) {
+    PVS_TRY(pvs_dense_reserve(c.dense, ix->n));
+    const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
+    HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q,
+                                 c.dense.d_dist, c.stream));
+    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream));
+    ix->dense_queries++;
+    return PVS_OK;
+}
+
+static pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb,
+                             uint32_t batch_pad, int metric) {
+    const size_t qesz = qdtype == PVS_I8 ? 1 : 4;
+    const uint8_t *qsrc = (const uint8_t *)d_queries + (size_t)qoff * ix->dim * qesz;
+    HIP_TRY(pvs_launch_prep_queries((int)ix->dtype, qdtype, qsrc, nb, batch_pad, ix->dim, ix->stride, ix->scale, metric, c.d_qmat,
+                                    c.d_qexact, c.d_qinfo, c.stream));
+    return PVS_OK;
+}
+
+// Enqueues the whole search on c.stream.  Outputs are device buffers.
+static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+                                 int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast) {
+    const bool fast = fast_path_ok(ix, k);
+    *used_fast = fast;
+    if (!fast && ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "filter-scan path not available for this index / k");
+    if (ix->n == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_count, 0, 4 * (size_t)batch, c.stream));
+        HIP_TRY(hipMemsetAsync(d_out_ids, 0xff, 8 * (size_t)batch * k, c.stream));
+        HIP_TRY(pvs_launch_fill_f32(d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c.stream));
+        return PVS_OK;
+    }
+    HIP_TRY(hipMemsetAsync(c.d_need_dense, 0, 4 * (size_t)batch, c.stream));
+    for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
+        const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
+        const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));
+        int64_t *oid = d_out_ids + (size_t)qoff * k;
+        float *od = d_out_dist + (size_t)qoff * k;
+        uint32_t *oc = d_out_count + qoff;
+        if (!fast) {
+            for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
+            continue;
+        }
+        ScanArgs a;
+        a.dtype = (int)ix->dtype;
+        a.metric = metric;
+        a.kslabs = ix->stride / PVS_KSLAB_BYTES;
+        a.qgroups = batch_pad / 32;
+        a.rows = ix->d_rows;
+        a.norm2 = ix->d_norm2;
+        a.stride = ix->stride;
+        a.n_rows = ix->n;
+        a.qmat = c.d_qmat;
+        a.qinfo = c.d_qinfo;
+        a.thr = c.d_thr;
+        a.cand_cnt = c.d_cand_cnt;
+        a.cand = c.d_cand;
+        a.cand_cap = PVS_CAND_CAP;
+        a.gmin = c.d_gmin;
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+        // pass A: strided sample of row tiles -> group minima -> threshold
+        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>(ix->n / 64, 32768));
+        const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
+        a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
+        const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
+        a.grid = std::min<uint32_t>(n_samp, 256);
+        a.mode = 0;
+        a.groups_per_query = a.grid * (4 / a.qgroups) * 32;
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
+        // pass B: every row once
+        HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4 * PVS_MAX_BATCH, c.stream));
+        a.mode = 1;
+        a.tile_step = 1;
+        const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        // pass C
+        FinalizeArgs f;
+        f.dtype = (int)ix->dtype;
+        f.metric = metric;
+        f.rows = ix->d_rows;
+        f.norm2 = ix->d_norm2;
+        f.ids = ix->d_ids;
+        f.stride = ix->stride;
+        f.dim = ix->dim;
+        f.n_rows = ix->n;
+        f.qexact = c.d_qexact;
+        f.qinfo = c.d_qinfo;
+        f.cand_cnt = c.d_cand_cnt;
+        f.cand = c.d_cand;
+        f.cand_cap = PVS_CAND_CAP;
+        f.batch = nb;
+        f.k = k;
+        f.out_ids = oid;
+        f.out_dist = od;
+        f.out_count = oc;
+        f.need_dense = c.d_need_dense + qoff;
+        HIP_TRY(pvs_launch_finalize(f, c.stream));
+    }
+    if (fast) HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+    return PVS_OK;
+}
+
+// After the stream drained: answer the queries the filter path handed back.
+static pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+                                   int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    uint32_t n_dense = 0;
+    for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
+    ix->fast_queries += batch - n_dense;
+    if (!n_dense) return PVS_OK;
+    if (ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "%u queries need the dense path but path=2 forbids it", n_dense);
+    for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
+        const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
+        bool any = false;
+        for (uint32_t q = 0; q < nb; q++) any |= c.h_need_dense[qoff + q] != 0;
+        if (!any) continue;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, 32 * ((nb + 31) / 32), metric));
+        for (uint32_t q = 0; q < nb; q++) {
+            if (!c.h_need_dense[qoff + q]) continue;
+            PVS_TRY(dense_one(ix, c, q, k, metric, d_out_ids + (size_t)(qoff + q) * k, d_out_dist + (size_t)(qoff + q) * k,
+                              d_out_count + qoff + q));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return PVS_OK;
+}
+
+static SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket) {
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            for (uint32_t i = 0; i < NCTX; i++)
+                if (!ix->ctx[i].busy) {
+                    ix->ctx[i].busy = true;
+                    *ticket = i;
+                    return &ix->ctx[i];
+                }
+        }
+        sched_yield();
+    }
+}
+static void ctx_done(pvs_index *ix, SearchCtx *c) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    c->pending = false;
+    c->busy = false;
+}
+
+PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                 pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, batch, k, true);
+    const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+    void *d_q = nullptr;
+    if (st == PVS_OK) {
+        hipError_t e = hipMalloc(&d_q, qbytes * batch);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_OOM, "hipMalloc queries: %s", hipGetErrorString(e));
+    }
+    bool fast = false;
+    if (st == PVS_OK) {
+        hipError_t e = hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "H2D queries: %s", hipGetErrorString(e));
+    }
+    if (st == PVS_OK) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
+    if (st == PVS_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    }
+    if (st == PVS_OK && fast && ix->n)
+        st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count);
+    if (st == PVS_OK) {
+        hipError_t e = hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
+    }
+    hipFree(d_q);
+    ix->searches++;
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                        pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                                        uint32_t *out_ticket) {
+    PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
+    if (!d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, batch, k, false);
+    bool fast = false;
+    if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast);
+    if (st != PVS_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        ctx_done(ix, c);
+        return st;
+    }
+    c->pending = true;
+    c->p_queries = d_queries;
+    c->p_qdtype = qdtype;
+    c->p_metric = metric;
+    c->p_batch = batch;
+    c->p_k = k;
+    c->p_out_ids = d_out_ids;
+    c->p_out_dist = d_out_dist;
+    c->p_out_count = d_out_count;
+    c->p_fast = fast;
+    ix->searches++;
+    *out_ticket = t;
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
+    if (!ix || ticket >= NCTX) return pvs_fail(PVS_ERR_INVALID_ARG, "bad ticket");
+    SearchCtx *c = &ix->ctx[ticket];
+    if (!c->busy || !c->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+    HIP_TRY(hipSetDevice(ix->device));
+    pvs_status st = PVS_OK;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    if (st == PVS_OK && c->p_fast && ix->n)
+        st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->p_out_ids, c->p_out_dist,
+                              c->p_out_count);
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_sync(pvs_index *ix) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    pvs_status st = PVS_OK;
+    for (uint32_t i = 0; i < NCTX; i++)
+        if (ix->ctx[i].busy && ix->ctx[i].pending) {
+            pvs_status s = pvs_wait(ix, i);
+            if (s != PVS_OK) st = s;
+        }
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist,
+                                    pvs_space out_space) {
+    PVS_TRY(validate_search(ix, query, qdtype, 1, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (ix->n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, 1, 1, false);
+    auto body = [&]() -> pvs_status {
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMemcpyAsync(c->d_qin, query, qbytes, hipMemcpyHostToDevice, c->stream));
+        PVS_TRY(prep_chunk(ix, *c, c->d_qin, qdtype, 0, 1, 32, metric));
+        float *dst = out_dist;
+        if (out_space == PVS_HOST) {
+            PVS_TRY(pvs_dense_reserve(c->dense, ix->n));
+            dst = c->dense.d_dist;
+        }
+        HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
+                                     c->d_qinfo, dst, c->stream));
+        if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PVS_OK;
+    };
+    if (st == PVS_OK) st = body();
+    ctx_done(ix, c);
+    return st;
+}
+
+// ------------------------------------------------------- codec on the device
+template <typename Fn>
+static pvs_status with_device_chunks(const float *x, uint64_t n, pvs_space space, Fn &&fn) {
+    if (space == PVS_DEVICE) return fn(x, n, (uint64_t)0);
+    const uint64_t chunk = 64ull << 20;  // elements (256 MiB)
+    float *stage = nullptr;
+    HIP_TRY(hipMalloc((void **)&stage, std::min(chunk, n) * 4));
+    pvs_status st = PVS_OK;
+    for (uint64_t off = 0; off < n && st == PVS_OK; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        hipError_t e = hipMemcpy(stage, x + off, m * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            st = pvs_fail(PVS_ERR_DEVICE, "H2D: %s", hipGetErrorString(e));
+            break;
+        }
+        st = fn(stage, m, off);
+    }
+    hipFree(stage);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_absmax(const float *x, uint64_t n, pvs_space space, int32_t device, float *out_absmax) {
+    if (!out_absmax || (n && !x)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(use_device(device, nullptr));
+    float *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, 4));
+    float result = 0.f;
+    pvs_status st = with_device_chunks(x, n, space, [&](const float *d, uint64_t m, uint64_t) -> pvs_status {
+        HIP_TRY(pvs_launch_absmax(d, m, d_out, nullptr));
+        float part = 0.f;
+        HIP_TRY(hipMemcpy(&part, d_out, 4, hipMemcpyDeviceToHost));
+        if (part > result) result = part;  // non-negative, NaN never stored
+        return PVS_OK;
+    });
+    hipFree(d_out);
+    if (st == PVS_OK) *out_absmax = result;
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, int8_t *out, pvs_space space, int32_t device) {
+    if (n && (!x || !out)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(use_device(device, nullptr));
+    if (space == PVS_DEVICE) {
+        HIP_TRY(pvs_launch_quantize_flat(x, n, scale, out, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return PVS_OK;
+    }
+    int8_t *d_out = nullptr;
+    const uint64_t chunk = 64ull << 20;
+    HIP_TRY(hipMalloc((void **)&d_out, std::min(chunk, std::max<uint64_t>(n, 1))));
+    pvs_status st = with_device_chunks(x, n, space, [&](const float *d, uint64_t m, uint64_t off) -> pvs_status {
+        HIP_TRY(pvs_launch_quantize_flat(d, m, scale, d_out, nullptr));
+        HIP_TRY(hipMemcpy(out + off, d_out, m, hipMemcpyDeviceToHost));
+        return PVS_OK;
+    });
+    hipFree(d_out);
+    return st;
+}
+
+// ------------------------------------------------ device memory + synthetic
+PVS_EXPORT pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out) {
+    if (!out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_device_free(int32_t device, void *ptr) {
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(hipFree(ptr));
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_memcpy(void *dst, const void *src, size_t bytes, int32_t device) {
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_synth_rows_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *d_out) {
+    if (!d_out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(pvs_launch_synth(seed, row0, n, dim, d_out, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return PVS_OK;
+}
+
+// exposed to pvs_comm.hip
+pvs_status pvs_index_internal_(pvs_index *ix, int *device) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    *device = ix->device;
+    return PVS_OK;
+}

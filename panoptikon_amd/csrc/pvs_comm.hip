@@ -1,0 +1,177 @@
+// pvs_comm.hip — multi-GPU: one process per GPU, the corpus row-sharded across ranks,
+// per-shard pages exchanged by ONE RCCL all-gather over xGMI and merged on every rank
+// (SURVEY.md §8e).  The reference has no distributed code at all; this is the build's
+// only collective.  The payload is tiny (batch*k*16 B per rank, <= 410 KB at 256x100), so
+// the step is latency-bound, not the per-link 153 GB/s ring bound.
+//
+// RCCL is bound at run time with dlopen so that (a) libpvs.so loads on machines
+// without RCCL and (b) a host process that already carries an RCCL (e.g. a PyTorch
+// build) shares that one copy instead of initialising a second.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "pvs_kernels.hpp"
+
+pvs_status pvs_index_internal_(pvs_index *ix, int *device);
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+pvs_status load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return PVS_OK;
+    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return pvs_fail(PVS_ERR_COMM, "cannot load RCCL: %s", dlerror());
+    Rccl r;
+    r.lib = h;
+#define SYM(field, name)                                                        \
+    r.field = (decltype(r.field))dlsym(h, name);                                \
+    if (!r.field) return pvs_fail(PVS_ERR_COMM, "RCCL symbol %s missing", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = r;
+    return PVS_OK;
+}
+}  // namespace
+
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t _r = (expr);                                                                       \
+        if (_r != ncclSuccess) return pvs_fail(PVS_ERR_COMM, "%s: %s", #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+struct pvs_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    hipStream_t stream = nullptr;
+    int64_t *d_loc_ids = nullptr, *d_all_ids = nullptr;
+    float *d_loc_dist = nullptr, *d_all_dist = nullptr;
+    uint32_t *d_loc_cnt = nullptr, *d_all_cnt = nullptr;
+    uint64_t cap_elems = 0;
+    uint32_t cap_batch = 0;
+};
+
+static_assert(sizeof(ncclUniqueId) == PVS_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+PVS_EXPORT pvs_status pvs_comm_unique_id(uint8_t id[PVS_UNIQUE_ID_BYTES]) {
+    if (!id) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(load_rccl());
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, PVS_UNIQUE_ID_BYTES);
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_comm_create(const uint8_t id[PVS_UNIQUE_ID_BYTES], int32_t world, int32_t rank, int32_t device,
+                                      pvs_comm **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return pvs_fail(PVS_ERR_INVALID_ARG, "bad communicator arguments");
+    PVS_TRY(load_rccl());
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= n) return pvs_fail(PVS_ERR_INVALID_ARG, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    pvs_comm *c = new (std::nothrow) pvs_comm();
+    if (!c) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    ncclUniqueId u;
+    memcpy(&u, id, PVS_UNIQUE_ID_BYTES);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return pvs_fail(PVS_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return pvs_fail(PVS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PVS_OK;
+}
+
+static void comm_free_buffers(pvs_comm *c) {
+    hipFree(c->d_loc_ids);
+    hipFree(c->d_all_ids);
+    hipFree(c->d_loc_dist);
+    hipFree(c->d_all_dist);
+    hipFree(c->d_loc_cnt);
+    hipFree(c->d_all_cnt);
+    c->d_loc_ids = c->d_all_ids = nullptr;
+    c->d_loc_dist = c->d_all_dist = nullptr;
+    c->d_loc_cnt = c->d_all_cnt = nullptr;
+    c->cap_elems = 0;
+    c->cap_batch = 0;
+}
+
+PVS_EXPORT void pvs_comm_destroy(pvs_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_free_buffers(c);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+PVS_EXPORT pvs_status pvs_search_sharded(pvs_index *ix, pvs_comm *c, const void *d_queries, pvs_dtype qdtype, uint32_t batch,
+                                         uint32_t k, pvs_metric metric, int64_t *d_out_ids, float *d_out_dist,
+                                         uint32_t *d_out_count) {
+    if (!ix || !c) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    int dev = 0;
+    PVS_TRY(pvs_index_internal_(ix, &dev));
+    if (dev != c->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
+    HIP_TRY(hipSetDevice(dev));
+    const uint64_t elems = (uint64_t)batch * k;
+    if (elems > c->cap_elems || batch > c->cap_batch) {
+        comm_free_buffers(c);
+        HIP_TRY(hipMalloc((void **)&c->d_loc_ids, elems * 8));
+        HIP_TRY(hipMalloc((void **)&c->d_loc_dist, elems * 4));
+        HIP_TRY(hipMalloc((void **)&c->d_loc_cnt, (size_t)batch * 4));
+        HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * c->world));
+        HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * c->world));
+        HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * c->world));
+        c->cap_elems = elems;
+        c->cap_batch = batch;
+    }
+    // 1. this shard's page (row ids in the index are global ids)
+    uint32_t ticket = 0;
+    PVS_TRY(pvs_search_device(ix, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &ticket));
+    PVS_TRY(pvs_wait(ix, ticket));
+    // 2. one grouped all-gather of (ids, distances, counts) over xGMI
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllGather(c->d_loc_ids, c->d_all_ids, elems, ncclInt64, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllGather(c->d_loc_dist, c->d_all_dist, elems, ncclFloat32, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllGather(c->d_loc_cnt, c->d_all_cnt, batch, ncclUint32, c->comm, c->stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    // 3. merge on every rank
+    HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, (uint32_t)c->world, batch, k, d_out_ids, d_out_dist,
+                             d_out_count, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PVS_OK;
+}

@@ -1,0 +1,97 @@
+// pvs_kernels.hpp — host-callable launchers of the HIP kernels (gfx950).
+#pragma once
+#include "pvs_common.hpp"
+
+// ---- utility kernels (pvs_kernels_util.hip)
+hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
+                            float *norm2, hipStream_t s);
+hipError_t pvs_launch_fill_f32(float *p, uint64_t n, float v, hipStream_t s);
+hipError_t pvs_launch_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst,
+                                      uint32_t stride, hipStream_t s);
+hipError_t pvs_launch_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale, uint8_t *dst,
+                                    uint32_t stride, hipStream_t s);
+hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s);
+hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s);
+hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s);
+hipError_t pvs_launch_iota_ids(int64_t *ids, uint64_t n, int64_t base, hipStream_t s);
+
+// queries: [batch][dim] of qdtype (PVS_F32 or PVS_I8).  Produces, per query:
+//   qmat  [batch_pad][stride] scan operand in the index dtype (zero padded),
+//   qexact[batch][dim]        what the exact rerank reads (i8 codes or f32),
+//   qinfo [batch_pad]         per-query constants (padding queries get NaN-proof zeros).
+hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *queries, uint32_t batch,
+                                   uint32_t batch_pad, uint32_t dim, uint32_t stride, float scale,
+                                   int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, hipStream_t s);
+
+// exact per-row distance (the reference's dist_{cte}.d), one lane per row
+hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
+                                uint64_t n, const float *norm2, const void *qexact, const QInfo *qinfo,
+                                float *out, hipStream_t s);
+
+// ---- filter scan (pvs_kernels_scan.hip)
+struct ScanArgs {
+    int dtype, metric;
+    uint32_t kslabs;        // stride / 256
+    uint32_t qgroups;       // batch_pad / 32 in {1,2,4}
+    const uint8_t *rows;
+    const float *norm2;
+    uint32_t stride;
+    uint64_t n_rows;        // valid rows
+    const uint8_t *qmat;
+    const QInfo *qinfo;
+    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter
+    uint32_t tile_step;     // process WG tiles 0, step, 2*step, ...
+    uint32_t grid;          // workgroups
+    float *gmin;            // mode 0: [batch_pad][groups_per_query]
+    uint32_t groups_per_query;
+    const float *thr;       // mode 1: [batch_pad]
+    uint32_t *cand_cnt;     // [batch_pad]
+    uint2 *cand;            // [batch_pad][cand_cap] = (row, key bits)
+    uint32_t cand_cap;
+};
+bool pvs_scan_supported(int dtype, uint32_t kslabs);
+uint32_t pvs_scan_wg_rows(uint32_t qgroups);  // rows per workgroup tile
+hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
+
+// k-th smallest (1-based) of vals[q][0..per_query), +inf when fewer than k finite values
+hipError_t pvs_launch_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out,
+                          hipStream_t s);
+
+struct FinalizeArgs {
+    int dtype, metric;
+    const uint8_t *rows;
+    const float *norm2;
+    const int64_t *ids;
+    uint32_t stride, dim;
+    uint64_t n_rows;
+    const void *qexact;     // [batch][dim] i8 or f32
+    const QInfo *qinfo;
+    const uint32_t *cand_cnt;
+    const uint2 *cand;
+    uint32_t cand_cap;
+    uint32_t batch, k;
+    int64_t *out_ids;       // [batch][k]
+    float *out_dist;        // [batch][k]
+    uint32_t *out_count;    // [batch]
+    uint32_t *need_dense;   // [batch] 1 = this query must be answered by the dense path
+};
+hipError_t pvs_launch_finalize(const FinalizeArgs &a, hipStream_t s);
+
+// ---- dense score + sort (pvs_dense.hip)
+struct DenseWork {
+    float *d_dist = nullptr;       // [n]
+    uint32_t *d_keys_in = nullptr, *d_keys_out = nullptr, *d_vals_in = nullptr, *d_vals_out = nullptr;
+    void *d_temp = nullptr;
+    size_t temp_bytes = 0;
+    uint64_t cap_rows = 0;
+};
+pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n);
+void pvs_dense_release(DenseWork &w);
+// sorts d_dist[0..n) by (distance, row) and writes the first k (ids via ids[]) for one query
+pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids,
+                          float *out_dist, uint32_t *out_count, hipStream_t s);
+
+// merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
+hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
+                            uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
+                            uint32_t *out_count, hipStream_t s);

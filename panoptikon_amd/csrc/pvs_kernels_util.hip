@@ -1,0 +1,353 @@
+// pvs_kernels_util.hip — codec, norms, query preparation, exact per-row scoring,
+// synthetic rows.  gfx950.
+#include "pvs_kernels.hpp"
+
+// ------------------------------------------------------------------ norms
+// norm2[r] = the reference's aMag for row r: sum a_i^2 accumulated sequentially in
+// f32 (oracle: orc_vec_distance_cosine_*).  One lane per row; runs once per add.
+template <int DT>
+__global__ __launch_bounds__(256) void k_norm2(const uint8_t *rows, uint32_t stride, int dim, uint64_t n,
+                                               float *norm2) {
+    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    norm2[r] = seq_sumsq<DT>(rows + r * (uint64_t)stride, dim);
+}
+
+hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
+                            float *norm2, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (dtype == PVS_I8)
+        hipLaunchKernelGGL(k_norm2<PVS_I8>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+    else if (dtype == PVS_F16)
+        hipLaunchKernelGGL(k_norm2<PVS_F16>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+    else
+        hipLaunchKernelGGL(k_norm2<PVS_F32>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+    return hipGetLastError();
+}
+
+__global__ void k_fill_f32(float *p, uint64_t n, float v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+hipError_t pvs_launch_fill_f32(float *p, uint64_t n, float v, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_fill_f32, dim3(g), dim3(256), 0, s, p, n, v);
+    return hipGetLastError();
+}
+
+__global__ void k_iota_ids(int64_t *ids, uint64_t n, int64_t base) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        ids[i] = base + (int64_t)i;
+}
+hipError_t pvs_launch_iota_ids(int64_t *ids, uint64_t n, int64_t base, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_iota_ids, dim3(g), dim3(256), 0, s, ids, n, base);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ codec
+// quantize_int8 (db/vector_quants.rs:1489-1497): IEEE f32 division (never a
+// reciprocal multiply), round-half-to-even (v_rndne_f32), clamp, NaN -> 0.
+__device__ static inline int8_t quant_one(float x, float scale) {
+    float q = rintf(__fdiv_rn(x, scale));
+    q = fminf(fmaxf(q, -128.0f), 127.0f);  // fmin/fmax drop NaN, so test it explicitly
+    float raw = __fdiv_rn(x, scale);
+    return (raw != raw) ? (int8_t)0 : (int8_t)(int)q;
+}
+
+// strided destination (index rows): one thread per (row, 4 components)
+__global__ __launch_bounds__(256) void k_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale,
+                                                       uint8_t *dst, uint32_t stride) {
+    const uint64_t total = n * (uint64_t)dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        uint64_t r = i / dim;
+        uint32_t c = (uint32_t)(i - r * dim);
+        dst[r * stride + c] = (uint8_t)quant_one(src[i], scale);
+    }
+}
+hipError_t pvs_launch_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale, uint8_t *dst,
+                                    uint32_t stride, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t total = n * (uint64_t)dim;
+    unsigned g = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rows_quantize, dim3(g), dim3(256), 0, s, src, dim, n, scale, dst, stride);
+    return hipGetLastError();
+}
+
+// flat: 4 components per thread per step, 16-byte loads, 4-byte stores
+__global__ __launch_bounds__(256) void k_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst) {
+    const uint64_t n4 = n / 4;
+    const bool aligned = (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 3) == 0);
+    uint64_t start = 0;
+    if (aligned) {
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+            float4 v = ((const float4 *)src)[i];
+            uint32_t o = (uint32_t)(uint8_t)quant_one(v.x, scale) | ((uint32_t)(uint8_t)quant_one(v.y, scale) << 8) |
+                         ((uint32_t)(uint8_t)quant_one(v.z, scale) << 16) |
+                         ((uint32_t)(uint8_t)quant_one(v.w, scale) << 24);
+            ((uint32_t *)dst)[i] = o;
+        }
+        start = n4 * 4;
+    }
+    for (uint64_t i = start + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        dst[i] = quant_one(src[i], scale);
+}
+hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t w = (n + 1023) / 1024;
+    unsigned g = (unsigned)(w > 8192 ? 8192 : (w ? w : 1));
+    hipLaunchKernelGGL(k_quantize_flat, dim3(g), dim3(256), 0, s, src, n, scale, dst);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst,
+                                                         uint32_t stride) {
+    const uint64_t total = n * (uint64_t)dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        uint64_t r = i / dim;
+        uint32_t c = (uint32_t)(i - r * dim);
+        _Float16 h = (_Float16)src[i];  // v_cvt_f16_f32: round-to-nearest-even
+        *(uint16_t *)(dst + r * stride + 2 * (uint64_t)c) = __builtin_bit_cast(uint16_t, h);
+    }
+}
+hipError_t pvs_launch_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst, uint32_t stride,
+                                      hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t total = n * (uint64_t)dim;
+    unsigned g = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rows_f32_to_f16, dim3(g), dim3(256), 0, s, src, dim, n, dst, stride);
+    return hipGetLastError();
+}
+
+// blob_absmax over a flat array: `v > absmax` keeps NaN out, +-inf wins.  Non-
+// negative floats order like their bit patterns, so the cross-workgroup reduce is
+// one atomicMax on the u32 view.
+__global__ __launch_bounds__(256) void k_absmax(const float *src, uint64_t n, uint32_t *out_bits) {
+    float m = 0.0f;
+    const uint64_t n4 = (((uintptr_t)src & 15) == 0) ? n / 4 : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+        float4 v = ((const float4 *)src)[i];
+        float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), d = fabsf(v.w);
+        if (a > m) m = a;
+        if (b > m) m = b;
+        if (c > m) m = c;
+        if (d > m) m = d;
+    }
+    for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        float a = fabsf(src[i]);
+        if (a > m) m = a;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        float o = __shfl_xor(m, off);
+        if (o > m) m = o;
+    }
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (part[w] > m) m = part[w];
+        atomicMax(out_bits, __builtin_bit_cast(uint32_t, m));
+    }
+}
+hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_out_bits, 0, 4, s);
+    if (e != hipSuccess || n == 0) return e;
+    uint64_t w = (n + 4095) / 4096;
+    unsigned g = (unsigned)(w > 2048 ? 2048 : (w ? w : 1));
+    hipLaunchKernelGGL(k_absmax, dim3(g), dim3(256), 0, s, src, n, (uint32_t *)d_out_bits);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- synthetic
+__device__ static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+__device__ static inline int32_t synth_raw(uint64_t seed, uint64_t row, uint32_t col) {
+    uint64_t key = seed * 0xD1342543DE82EF95ULL + row * 0x9E3779B97F4A7C15ULL + (uint64_t)col * 0xC2B2AE3D27D4EB4FULL;
+    uint64_t a = splitmix64(key), b = splitmix64(key ^ 0xA5A5A5A5A5A5A5A5ULL), c = splitmix64(key + 0x1234567ULL);
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += (uint32_t)((a >> (16 * i)) & 0xffff);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += (uint32_t)((b >> (16 * i)) & 0xffff);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += (uint32_t)((c >> (16 * i)) & 0xffff);
+    return (int32_t)s - 393210;
+}
+// One wave per row: exact integer sum of squares (order independent), so the
+// bytes equal oracle/pvs_oracle.c orc_synth_rows.
+__global__ __launch_bounds__(256) void k_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (uint64_t)gridDim.x * 4) {
+        long long ss = 0;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            long long v = synth_raw(seed, row0 + r, c);
+            ss += v * v;
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        float nrm = (float)__dsqrt_rn((double)ss * (1.0 / 4294967296.0));
+        if (!(nrm > 0.0f)) nrm = 1.0f;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            float g = (float)synth_raw(seed, row0 + r, c) * (1.0f / 65536.0f);
+            out[r * dim + c] = __fdiv_rn(g, nrm);
+        }
+    }
+}
+hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t w = (n + 3) / 4;
+    unsigned g = (unsigned)(w > 65536 ? 65536 : w);
+    hipLaunchKernelGGL(k_synth, dim3(g), dim3(256), 0, s, seed, row0, n, dim, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------ query prep
+// One workgroup per (padded) query.
+__global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtype, const void *queries,
+                                                      uint32_t batch, uint32_t dim, uint32_t stride, float scale,
+                                                      int metric, uint8_t *qmat, void *qexact, QInfo *qinfo) {
+    const uint32_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint8_t *mrow = qmat + (uint64_t)b * stride;
+    // zero the scan operand row (padding bytes and padding queries contribute 0 to every dot)
+    for (uint32_t i = tid * 16; i < stride; i += 256 * 16) *(uint4 *)(mrow + i) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (b >= batch) {
+        if (tid == 0) {
+            QInfo z;
+            z.bb = 0.f; z.qn = 0.f; z.dscale = 0.f; z.eA = 0.f; z.eC = 0.f; z.eR = 0.f; z.pad0 = 0.f; z.pad1 = 0.f;
+            qinfo[b] = z;
+        }
+        return;
+    }
+    __shared__ float red[4];
+    __shared__ float s_amax;
+    float dscale = 1.0f;
+    if (index_dtype == PVS_I8) {
+        int8_t *qe = (int8_t *)qexact + (uint64_t)b * dim;
+        if (qdtype == PVS_I8) {
+            const int8_t *q = (const int8_t *)queries + (uint64_t)b * dim;
+            for (uint32_t i = tid; i < dim; i += 256) {
+                qe[i] = q[i];
+                mrow[i] = (uint8_t)q[i];
+            }
+        } else {
+            const float *q = (const float *)queries + (uint64_t)b * dim;
+            for (uint32_t i = tid; i < dim; i += 256) {
+                int8_t c = quant_one(q[i], scale);  // compute_query_quant: the write-side codec
+                qe[i] = c;
+                mrow[i] = (uint8_t)c;
+            }
+        }
+    } else {
+        const float *q = (const float *)queries + (uint64_t)b * dim;
+        float *qe = (float *)qexact + (uint64_t)b * dim;
+        float m = 0.f;
+        for (uint32_t i = tid; i < dim; i += 256) {
+            float v = q[i];
+            qe[i] = v;
+            float a = fabsf(v);
+            if (a > m && a < __builtin_inff()) m = a;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            float o = __shfl_xor(m, off);
+            if (o > m) m = o;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (red[w] > m) m = red[w];
+            s_amax = m;
+        }
+        __syncthreads();
+        if (index_dtype == PVS_F16) {
+            // exact power-of-two prescale so the largest |q_i| lands in [2^13, 2^14): keeps the
+            // f16 image of the query away from overflow and from the subnormal range
+            int e = 0;
+            if (s_amax > 0.f) {
+                int x;
+                (void)frexpf(s_amax, &x);
+                e = 14 - x;
+                if (e > 100) e = 100;
+                if (e < -100) e = -100;
+            }
+            dscale = ldexpf(1.0f, -e);
+            for (uint32_t i = tid; i < dim; i += 256) {
+                _Float16 h = (_Float16)ldexpf(q[i], e);
+                *(uint16_t *)(mrow + 2 * (uint64_t)i) = __builtin_bit_cast(uint16_t, h);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the reference's bMag: sequential f32 sum of squares of what it scores
+        float bb;
+        if (index_dtype == PVS_I8)
+            bb = seq_sumsq<PVS_I8>((const uint8_t *)((const int8_t *)qexact + (uint64_t)b * dim), (int)dim);
+        else
+            bb = seq_sumsq<PVS_F32>((const uint8_t *)((const float *)qexact + (uint64_t)b * dim), (int)dim);
+        QInfo qi;
+        qi.bb = bb;
+        qi.qn = sqrtf(bb);
+        qi.dscale = dscale;
+        qi.pad0 = 0.f;
+        qi.pad1 = 0.f;
+        // Error budget of the scan key: f32 accumulation of K terms is within
+        // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|.
+        const float acc = (float)dim * 6.0e-8f;
+        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : 0.0f;
+        if (metric == PVS_COSINE) {
+            qi.eA = (qround + 2.0f * acc + 4.0e-6f) * qi.qn;
+            qi.eC = 0.f;
+            qi.eR = 0.f;
+        } else {
+            const float coef = qround + 4.0f * acc + 1.0e-6f;
+            qi.eA = coef * bb + (index_dtype == PVS_I8 ? 2.0f : 0.0f);
+            qi.eC = 0.f;
+            qi.eR = coef;
+        }
+        qinfo[b] = qi;
+    }
+}
+
+hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *queries, uint32_t batch,
+                                   uint32_t batch_pad, uint32_t dim, uint32_t stride, float scale, int metric,
+                                   uint8_t *qmat, void *qexact, QInfo *qinfo, hipStream_t s) {
+    hipLaunchKernelGGL(k_prep_queries, dim3(batch_pad), dim3(256), 0, s, index_dtype, qdtype, queries, batch, dim,
+                       stride, scale, metric, qmat, qexact, qinfo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------- score_all
+template <int DT>
+__global__ __launch_bounds__(256) void k_score_all(int metric, const uint8_t *rows, uint32_t stride, int dim,
+                                                   uint64_t n, const float *norm2, const void *qexact,
+                                                   const QInfo *qinfo, float *out) {
+    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    out[r] = exact_distance<DT>(rows + r * (uint64_t)stride, qexact, dim, metric, norm2[r], qinfo->bb);
+}
+
+hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
+                                uint64_t n, const float *norm2, const void *qexact, const QInfo *qinfo, float *out,
+                                hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (dtype == PVS_I8)
+        hipLaunchKernelGGL(k_score_all<PVS_I8>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out);
+    else if (dtype == PVS_F16)
+        hipLaunchKernelGGL(k_score_all<PVS_F16>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out);
+    else
+        hipLaunchKernelGGL(k_score_all<PVS_F32>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out);
+    return hipGetLastError();
+}

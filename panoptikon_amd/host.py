@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference's operator helpers (names follow the Rust).
+
+Thin wrappers over the C ABI's host entry points: scale artifact
+(db/vector_quants.rs:1449-1471), per-item aggregation (filters/exact.rs:67-80),
+rank / RRF (pql/builder.rs:757-771, 1284-1317), query ingestion
+(pql/embedding_utils.rs) and quant resolution (pql/preprocess.rs:314-446).
+"""
+from __future__ import annotations
+
+import base64
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def scale_from_absmax(absmax: float) -> float:
+    return float(L.lib().pvs_scale_from_absmax(np.float32(absmax)))
+
+
+def scale_artifact(scale: float) -> bytes:
+    out = (C.c_uint8 * 4)()
+    L.lib().pvs_scale_artifact(np.float32(scale), out)
+    return bytes(out)
+
+
+def artifact_scale(artifact: bytes):
+    """Some(scale) / None, like the reference."""
+    s = C.c_float()
+    buf = (C.c_uint8 * max(len(artifact), 1)).from_buffer_copy(bytes(artifact) or b"\0")
+    st = L.lib().pvs_artifact_scale(buf, len(artifact), C.byref(s))
+    return float(s.value) if st == L.OK else None
+
+
+def aggregate(dist, group_ids, agg: int, weights=None):
+    dist = np.ascontiguousarray(dist, np.float32)
+    grp = np.ascontiguousarray(group_ids, np.int64)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    og = np.empty(max(dist.size, 1), np.int64)
+    ov = np.empty(max(dist.size, 1), np.float64)
+    n = C.c_uint64()
+    L.check(L.lib().pvs_aggregate(_ptr(dist), _ptr(w), _ptr(grp), dist.size, agg, _ptr(og), _ptr(ov), C.byref(n)))
+    return og[: n.value].copy(), ov[: n.value].copy()
+
+
+def row_number(values, ids=None) -> np.ndarray:
+    v = np.ascontiguousarray(values, np.float64)
+    i = None if ids is None else np.ascontiguousarray(ids, np.int64)
+    out = np.empty(max(v.size, 1), np.int64)
+    L.check(L.lib().pvs_row_number(_ptr(v), _ptr(i), v.size, _ptr(out)))
+    return out[: v.size]
+
+
+def rrf_fuse(ranks, ks, weights) -> np.ndarray:
+    """ranks: [n_branches][n] int64, < 0 = NULL."""
+    r = np.ascontiguousarray(ranks, np.int64)
+    if r.ndim == 1:
+        r = r[:, None]
+    k = np.ascontiguousarray(ks, np.int32)
+    w = np.ascontiguousarray(weights, np.float64)
+    out = np.empty(max(r.shape[1], 1), np.float64)
+    L.check(L.lib().pvs_rrf_fuse(_ptr(r), r.shape[0], r.shape[1], _ptr(k), _ptr(w), _ptr(out)))
+    return out[: r.shape[1]]
+
+
+def merge_topk(ids, dist, counts, k: int):
+    """ids/dist: [world][batch][k]; counts: [world][batch] -> merged ([batch][k], ...)."""
+    ids = np.ascontiguousarray(ids, np.int64)
+    dist = np.ascontiguousarray(dist, np.float32)
+    counts = np.ascontiguousarray(counts, np.uint32)
+    world, batch = counts.shape
+    oi = np.empty((batch, k), np.int64)
+    od = np.empty((batch, k), np.float32)
+    oc = np.empty(batch, np.uint32)
+    L.check(L.lib().pvs_merge_topk(_ptr(ids), _ptr(dist), _ptr(counts), world, batch, k, _ptr(oi), _ptr(od), _ptr(oc)))
+    return oi, od, oc
+
+
+def embedding_from_npy_bytes(buffer: bytes) -> bytes:
+    """pql/embedding_utils.rs:10-13: .npy -> f32 little-endian bytes (Err -> PvsError(ERR_PARSE))."""
+    buf = np.frombuffer(bytes(buffer), np.uint8)
+    n = C.c_size_t()
+    L.check(L.lib().pvs_npy_to_f32(_ptr(buf) if buf.size else None, buf.size, None, 0, C.byref(n)))
+    out = np.empty(max(n.value, 1), np.float32)
+    L.check(L.lib().pvs_npy_to_f32(_ptr(buf), buf.size, _ptr(out), out.size, C.byref(n)))
+    return out[: n.value].astype("<f4").tobytes()
+
+
+def extract_embeddings(encoded: str) -> bytes:
+    """pql/embedding_utils.rs:3-8: base64 -> .npy -> f32 LE bytes."""
+    try:
+        decoded = base64.b64decode(encoded.encode("ascii"), validate=True)
+    except Exception as err:  # noqa: BLE001
+        raise L.PvsError(L.ERR_PARSE, f"Invalid base64 embeddings: {err}") from None
+    return embedding_from_npy_bytes(decoded)
+
+
+def resolve_vector_quant(index: int, variant, k: int, pair: L.ReadyPair | None, embedding: bytes | None):
+    """pql/preprocess.rs:314-393.  Returns None (search exact) or (profile_id, query_quant | None)."""
+    emb = None if embedding is None else np.frombuffer(bytes(embedding), np.uint8)
+    cap = 0 if pair is None else max(int(pair.dim), 0)
+    qq = np.empty(max(cap, 1), np.int8)
+    out = L.QuantResolved()
+    var = None if variant is None else variant.encode("utf-8")
+    L.check(L.lib().pvs_resolve_vector_quant(index, var, k, None if pair is None else C.byref(pair), _ptr(emb),
+                                             0 if emb is None else emb.size, _ptr(qq), cap, C.byref(out)))
+    if not out.use_quant:
+        return None
+    return int(out.profile_id), (qq[: out.query_quant_len].copy() if out.query_quant_len else None)

@@ -1,0 +1,178 @@
+"""VectorIndex: Python handle over pvs_index (HBM-resident corpus shard)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_NP = {L.F32: np.float32, L.F16: np.float16, L.I8: np.int8}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return int(L.lib().pvs_device_count())
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through the C ABI (pvs_device_malloc)."""
+
+    def __init__(self, nbytes: int, device: int = -1):
+        self.device = device
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        L.check(L.lib().pvs_device_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, device: int = -1) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(max(a.nbytes, 16), device)
+        if a.nbytes:
+            L.check(L.lib().pvs_memcpy(b.ptr, _ptr(a), a.nbytes, device))
+        return b
+
+    def to_numpy(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            L.check(L.lib().pvs_memcpy(_ptr(out), self.ptr, out.nbytes, self.device))
+        return out
+
+    def free(self):
+        if self.ptr:
+            L.lib().pvs_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def absmax(x, device: int = -1) -> float:
+    """blob_absmax over all components, on the GPU (db/vector_quants.rs:1474-1483)."""
+    out = C.c_float()
+    if isinstance(x, DeviceBuffer):
+        L.check(L.lib().pvs_absmax(x.ptr, x.nbytes // 4, L.DEVICE, device, C.byref(out)))
+    else:
+        x = np.ascontiguousarray(x, np.float32)
+        L.check(L.lib().pvs_absmax(_ptr(x), x.size, L.HOST, device, C.byref(out)))
+    return float(out.value)
+
+
+def quantize_int8(x, scale: float, device: int = -1) -> np.ndarray:
+    """quantize_int8 on the GPU (db/vector_quants.rs:1489-1497)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.int8)
+    L.check(L.lib().pvs_quantize_i8(_ptr(x), x.size, np.float32(scale), _ptr(out), L.HOST, device))
+    return out
+
+
+class VectorIndex:
+    def __init__(self, dtype: int, dim: int, device: int = -1, capacity_rows: int = 0, id_base: int = 0):
+        self.dtype, self.dim, self.device = dtype, dim, device
+        d = L.IndexDesc(C.sizeof(L.IndexDesc), device, dtype, dim, capacity_rows, id_base)
+        h = C.c_void_p()
+        L.check(L.lib().pvs_index_create(C.byref(d), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            L.lib().pvs_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ build side
+    def set_scale(self, scale: float):
+        L.check(L.lib().pvs_index_set_scale(self._h, np.float32(scale)))
+
+    def set_scale_artifact(self, artifact: bytes):
+        buf = (C.c_uint8 * max(len(artifact), 1)).from_buffer_copy(bytes(artifact) or b"\0")
+        L.check(L.lib().pvs_index_set_scale_artifact(self._h, buf, len(artifact)))
+
+    def add(self, rows, row_ids=None, group_ids=None):
+        """rows: [n][dim] in the index dtype (numpy) or a DeviceBuffer of that layout."""
+        ids = None if row_ids is None else np.ascontiguousarray(row_ids, np.int64)
+        grp = None if group_ids is None else np.ascontiguousarray(group_ids, np.int64)
+        if isinstance(rows, tuple):  # (DeviceBuffer, n)
+            buf, n = rows
+            L.check(L.lib().pvs_index_add(self._h, buf.ptr, n, _ptr(ids), _ptr(grp), L.DEVICE))
+            return
+        rows = np.ascontiguousarray(rows)
+        if rows.dtype != _NP[self.dtype] or rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [{self.dim}]-wide {_NP[self.dtype]}")
+        L.check(L.lib().pvs_index_add(self._h, _ptr(rows), rows.shape[0], _ptr(ids), _ptr(grp), L.HOST))
+
+    def add_f32(self, rows, row_ids=None, group_ids=None):
+        """f32 rows converted on the device to the index dtype (backfill_chunk's codec)."""
+        ids = None if row_ids is None else np.ascontiguousarray(row_ids, np.int64)
+        grp = None if group_ids is None else np.ascontiguousarray(group_ids, np.int64)
+        if isinstance(rows, tuple):
+            buf, n = rows
+            L.check(L.lib().pvs_index_add_f32(self._h, buf.ptr, n, _ptr(ids), _ptr(grp), L.DEVICE))
+            return
+        rows = np.ascontiguousarray(rows, np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError("rows must be [n][dim]")
+        L.check(L.lib().pvs_index_add_f32(self._h, _ptr(rows), rows.shape[0], _ptr(ids), _ptr(grp), L.HOST))
+
+    # ----------------------------------------------------------- query side
+    def _queries(self, queries):
+        q = np.ascontiguousarray(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.dtype == np.int8:
+            qd = L.I8
+        else:
+            q = np.ascontiguousarray(q, np.float32)
+            qd = L.F32
+        if q.shape[1] != self.dim:
+            # the reference's sqlite-vec raises a SQL error for mismatched lengths (db/pql.rs:18-21)
+            raise L.PvsError(L.ERR_DIM_MISMATCH, f"query dimension {q.shape[1]} != index dimension {self.dim}")
+        return q, qd
+
+    def search(self, queries, k: int, metric: int = L.COSINE):
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        ids = np.empty((b, max(k, 1)), np.int64)
+        dist = np.empty((b, max(k, 1)), np.float32)
+        cnt = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search(self._h, _ptr(q), qd, b, k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
+    def search_device(self, d_queries: DeviceBuffer, qdtype: int, batch: int, k: int, metric: int,
+                      d_ids: DeviceBuffer, d_dist: DeviceBuffer, d_cnt: DeviceBuffer) -> int:
+        t = C.c_uint32()
+        L.check(L.lib().pvs_search_device(self._h, d_queries.ptr, qdtype, batch, k, metric, d_ids.ptr, d_dist.ptr,
+                                          d_cnt.ptr, C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket: int):
+        L.check(L.lib().pvs_wait(self._h, ticket))
+
+    def sync(self):
+        L.check(L.lib().pvs_sync(self._h))
+
+    def set_path(self, path: int):
+        L.check(L.lib().pvs_index_set_path(self._h, path))
+
+    def score_all(self, query, metric: int = L.COSINE) -> np.ndarray:
+        q, qd = self._queries(query)
+        out = np.empty(self.stats().rows, np.float32)
+        L.check(L.lib().pvs_score_all(self._h, _ptr(q), qd, metric, _ptr(out), L.HOST))
+        return out
+
+    def stats(self) -> L.Stats:
+        s = L.Stats()
+        L.check(L.lib().pvs_index_stats(self._h, C.byref(s)))
+        return s

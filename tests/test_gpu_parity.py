@@ -1,0 +1,238 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bit-exact for int8 distances and ids; the float paths reproduce the
+oracle's sequential-f32 evaluation, so they are compared bit-exact as well (the
+north-star tolerance of 1e-5 relative is asserted as the fallback bar)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # BASELINE.json north_star: fp32/fp16 cosine within 1e-5 relative
+
+
+@pytest.fixture(scope="module")
+def pvs():
+    import panoptikon_amd as p
+
+    if p.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the gpu tests need an MI355X")
+    return p
+
+
+def unit_rows(seed, n, dim):
+    return orc.synth_rows(seed, 0, n, dim)
+
+
+def make_index(pvs, dtype, rows_f32, scale=None):
+    n, dim = rows_f32.shape
+    ix = pvs.VectorIndex(dtype, dim)
+    if dtype == pvs.I8:
+        ix.set_scale(scale)
+    ix.add_f32(rows_f32)
+    return ix
+
+
+def host_corpus(dtype, rows_f32, scale=None):
+    if dtype == orc.I8:
+        return orc.quantize_int8(rows_f32, scale)
+    if dtype == orc.F16:
+        return rows_f32.astype(np.float16)
+    return rows_f32
+
+
+def assert_same_page(got, exp, exact=True):
+    gi, gd, gc = got
+    ei, ed = exp
+    assert gc.tolist() == [ei.shape[1]] * ei.shape[0]
+    assert np.array_equal(gi[:, : ei.shape[1]], ei), "returned item indices differ from the reference ordering"
+    g = gd[:, : ei.shape[1]]
+    if exact:
+        assert np.array_equal(g.view(np.uint32), ed.view(np.uint32)), "distances are not bit-identical"
+    else:
+        assert np.all(np.abs(g - ed) <= REL_TOL * np.abs(ed) + 1e-7)
+
+
+# ------------------------------------------------------------------- codec
+def test_codec_on_device_matches_reference_kats(pvs):
+    q = pvs.quantize_int8(np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 2.4999, -2.4999], np.float32), 1.0)
+    assert q.tolist() == [0, 2, 2, 0, -2, -2, 2, -2]
+    s = pvs.scale_from_absmax(11.0)
+    assert pvs.quantize_int8(np.array([11.0, -11.0, 1000.0, -1000.0], np.float32), s).tolist() == [127, -127, 127, -128]
+    assert pvs.quantize_int8(np.array([np.nan, np.inf, -np.inf], np.float32), 0.5).tolist() == [0, 127, -128]
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(100_003) * 0.05).astype(np.float32)
+    x[17] = np.nan
+    am = pvs.absmax(x)
+    assert am == orc.blob_absmax(x)
+    sc = pvs.scale_from_absmax(am)
+    assert np.array_equal(pvs.quantize_int8(x, sc), orc.quantize_int8(x, sc))
+    assert pvs.absmax(np.array([1.0, -np.inf], np.float32)) == np.inf
+    assert pvs.absmax(np.zeros(0, np.float32)) == 0.0
+
+
+def test_synth_rows_device_bytes_equal_oracle(pvs):
+    n, dim = 257, 768
+    buf = pvs.DeviceBuffer(n * dim * 4)
+    pvs._lib.check(pvs.lib().pvs_synth_rows_f32(-1, 20260928, 1000, n, dim, buf.ptr))
+    dev = buf.to_numpy(np.float32, (n, dim))
+    assert np.array_equal(dev.view(np.uint32), orc.synth_rows(20260928, 1000, n, dim).view(np.uint32))
+
+
+# --------------------------------------------------------------- score_all
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+@pytest.mark.parametrize("dim", [8, 100, 768])
+def test_score_all_bit_exact(pvs, dtype, metric, dim):
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    m = pvs.COSINE if metric == "cosine" else pvs.L2
+    rows = unit_rows(11, 1500, dim)
+    rows[7] = 0.0  # zero-norm row: cosine NaN (SQL NULL)
+    q = unit_rows(99, 1, dim)[0]
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    exp = orc.score_all(dt, m, hc, hq)
+    got = ix.score_all(hq, m)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+    if dt == pvs.I8:  # f32 query quantized on the device == host-side compute_query_quant
+        got2 = ix.score_all(q, m)
+        assert np.array_equal(got2[ok].view(np.uint32), exp[ok].view(np.uint32))
+    ix.close()
+
+
+# ------------------------------------------------------------------ search
+CASES = [
+    # dtype, metric, n, dim, batch, k
+    ("i8", "cosine", 20000, 768, 5, 10),
+    ("i8", "cosine", 30011, 768, 128, 100),
+    ("i8", "l2", 20000, 768, 40, 100),
+    ("i8", "cosine", 9000, 512, 64, 10),
+    ("i8", "l2", 5000, 1024, 33, 50),
+    ("f16", "cosine", 20000, 768, 32, 100),
+    ("f16", "l2", 12000, 768, 7, 10),
+    ("f16", "cosine", 8000, 512, 70, 100),
+    ("f16", "cosine", 6000, 1024, 128, 20),
+    ("f32", "cosine", 10000, 512, 1, 10),  # BASELINE configs[0]
+    ("f32", "l2", 4000, 768, 3, 100),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,n,dim,batch,k", CASES)
+@pytest.mark.parametrize("path", ["auto", "dense"])
+def test_search_matches_oracle(pvs, dtype, metric, n, dim, batch, k, path):
+    if path == "dense" and (n > 12000 or batch > 8):
+        pytest.skip("dense path covered on the smaller cases")
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    m = pvs.COSINE if metric == "cosine" else pvs.L2
+    rows = unit_rows(3, n, dim)
+    queries = orc.synth_rows(0x5EED0000, 0, batch, dim)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    ix.set_path(1 if path == "dense" else 0)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    exp = orc.search(dt, m, hc, hq, k, threads=8)
+    got = ix.search(queries, k, m)  # f32 queries: the int8 index quantizes them on the device
+    assert_same_page(got, exp)
+    st = ix.stats()
+    if path == "auto" and dt != pvs.F32:
+        assert st.fast_queries == batch and st.dense_queries == 0, "filter-scan path must serve these shapes"
+    if dt == pvs.I8:  # pre-quantized codes (QuantResolved.query_quant) give the same page
+        assert_same_page(ix.search(hq, k, m), exp)
+    ix.close()
+
+
+def test_disagreeing_vectors_fixture_order(pvs):
+    # db/vector_quants.rs:3254-3276, :3324-3382: int8 reproduces the exact ordering
+    vs = []
+    for idx in range(6):
+        v = [0.02] * 8
+        v[idx] = 11.0
+        v[(idx + 1) % 8] = 0.6 + 0.5 * idx
+        vs.append(v)
+    for idx in range(6):
+        v = [4.0] * 8
+        for flip in range(idx % 3 + 1):
+            v[7 - flip] = -0.5 - 0.2 * idx
+        vs.append(v)
+    vecs = np.array(vs, np.float32)
+    query = np.ones(8, np.float32)
+    scale = pvs.scale_from_absmax(pvs.absmax(vecs))
+    assert scale == orc.compute_int8_scale(vecs)
+    exact = make_index(pvs, pvs.F32, vecs)
+    quant = make_index(pvs, pvs.I8, vecs, scale)
+    ei, ed, ec = exact.search(query, 100, pvs.COSINE)
+    qi, qd, qc = quant.search(query, 100, pvs.COSINE)
+    assert ec[0] == 12 and qc[0] == 12
+    assert ei[0, :12].tolist() == qi[0, :12].tolist()
+    oi, od = orc.search(orc.F32, orc.COSINE, vecs, query, 100)
+    assert ei[0, :12].tolist() == oi[0].tolist()
+    assert np.array_equal(ed[0, :12].view(np.uint32), od[0].view(np.uint32))
+    assert (qi[0, 12:] == -1).all() and np.isnan(qd[0, 12:]).all()
+    # page walk (:3386-3415): k = 4, 8, 12 are prefixes of the single shot
+    for k in (1, 4, 8, 12):
+        ki, _, kc = quant.search(query, k, pvs.COSINE)
+        assert kc[0] == k and ki[0, :k].tolist() == qi[0, :k].tolist()
+    exact.close()
+    quant.close()
+
+
+def test_ties_duplicates_and_null_rows(pvs):
+    # heavy ties (duplicated rows) and zero-norm rows (NULL distance, sorted last)
+    base = unit_rows(21, 300, 768)
+    rows = np.concatenate([base, base[:150], np.zeros((5, 768), np.float32), base[:50]])
+    q = base[10] * 0.5 + base[11] * 0.5
+    scale = orc.compute_int8_scale(rows)
+    for dt in (pvs.I8, pvs.F16, pvs.F32):
+        hc = host_corpus(dt, rows, scale)
+        hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+        ix = make_index(pvs, dt, rows, scale)
+        for metric in (pvs.COSINE, pvs.L2):
+            for k in (10, 505):
+                exp = orc.search(dt, metric, hc, hq, k)
+                gi, gd, gc = ix.search(hq, k, metric)
+                assert gc[0] == exp[0].shape[1]
+                assert np.array_equal(gi[0, : gc[0]], exp[0][0])
+                a, b = gd[0, : gc[0]], exp[1][0]
+                assert np.array_equal(np.isnan(a), np.isnan(b))
+                assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+        ix.close()
+
+
+def test_row_ids_groups_and_errors(pvs):
+    rows = unit_rows(5, 2000, 512)
+    ids = np.arange(2000, dtype=np.int64) * 7 + 1000
+    ix = pvs.VectorIndex(pvs.F16, 512)
+    ix.add(rows[:1200].astype(np.float16), row_ids=ids[:1200])
+    ix.add(rows[1200:].astype(np.float16), row_ids=ids[1200:])
+    q = unit_rows(6, 2, 512)
+    exp = orc.search(orc.F16, orc.COSINE, rows.astype(np.float16), q, 25, ids=ids)
+    assert_same_page(ix.search(q, 25, pvs.COSINE), exp)
+    with pytest.raises(pvs.PvsError) as e:
+        ix.add(rows[:3].astype(np.float16), row_ids=[5, 6, 7])  # not increasing
+    assert e.value.status == pvs._lib.ERR_INVALID_ARG
+    with pytest.raises(pvs.PvsError) as e:
+        ix.search(np.zeros(100, np.float32), 5)
+    assert e.value.status == pvs._lib.ERR_DIM_MISMATCH
+    with pytest.raises(pvs.PvsError) as e:
+        ix.search(np.zeros((1, 512), np.int8), 5)  # element type mismatch
+    assert e.value.status == pvs._lib.ERR_DIM_MISMATCH
+    with pytest.raises(pvs.PvsError):
+        ix.search(q, 0)  # k must be a positive integer (preprocess.rs:441-444)
+    ix.close()
+    i8 = pvs.VectorIndex(pvs.I8, 512)
+    with pytest.raises(pvs.PvsError) as e:
+        i8.add_f32(rows[:10])
+    assert e.value.status == pvs._lib.ERR_STATE
+    for bad in (b"", bytes(5), np.float32(0).tobytes(), np.float32(-1).tobytes(), np.float32("nan").tobytes()):
+        with pytest.raises(pvs.PvsError):
+            i8.set_scale_artifact(bad)
+    i8.set_scale_artifact(pvs.scale_artifact(0.01))
+    gi, gd, gc = i8.search(q, 5)  # empty index
+    assert gc.tolist() == [0, 0] and (gi == -1).all()
+    i8.close()
