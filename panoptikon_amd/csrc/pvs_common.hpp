@@ -160,10 +160,8 @@ __device__ static inline float seq_sumsq(const uint8_t *row, int dim) {
     return aa;
 }
 
-// return sqrt(res): sqrt in double, narrowed to f32.  For an f32 argument this
-// equals the correctly rounded f32 square root (double rounding is innocuous for
-// sqrt when the wide format has >= 2p+2 bits), so the f32 IEEE sqrt is used.
-__device__ static inline float ref_l2_finish(float res) { return __fsqrt_rn(res); }
+// return sqrt(res): sqrt evaluated in double (IEEE, correctly rounded), narrowed to f32.
+__device__ static inline float ref_l2_finish(float res) { return (float)__dsqrt_rn((double)res); }
 
 // return (f32)(1 - dot / (sqrt(aa) * sqrt(bb))) evaluated in double.
 __device__ static inline float ref_cosine_finish(float dot, float aa, float bb) {
