@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""bench.py — k-NN queries/sec on the BASELINE.json headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`, configs[2]): 10,000,000 x 768 int8-quantized
+embeddings, batches of 128 queries, cosine, k = 100.  One "step" = one batch of
+128 queries answered over the whole corpus (page 1 of the reference ordering).
+Synthetic data: unit-normalised pseudo-Gaussian rows generated
+in HBM, absmax -> scale -> quantize_int8 on the device.  Inputs are resident in
+HBM when the timed region starts.
+
+N > 1: launched by torch.distributed.run, one process per GPU; the corpus is
+row-sharded (strong scaling: the corpus is fixed at --rows), every rank answers
+the same batch over its shard, the per-shard pages are exchanged by one RCCL
+all-gather over xGMI and merged on every rank.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA (~2x the 2.5 PF bf16 dense peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0
+SEED_CORPUS = 20260928
+SEED_QUERY = 0x5EED0000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dtype", choices=["i8", "f16"], default="i8")
+    ap.add_argument("--metric", choices=["cosine", "l2"], default="cosine")
+    ap.add_argument("--inflight", type=int, default=2, help="search batches in flight (HIP streams)")
+    ap.add_argument("--check-queries", type=int, default=2, help="queries verified against the CPU oracle over the full corpus")
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--chunk-rows", type=int, default=1_000_000)
+    return ap.parse_args()
+
+
+class Dist:
+    """Control plane for N > 1 (rendezvous, barrier, tiny host reductions): torch.distributed
+    over gloo.  The data path (top-k exchange) is RCCL inside libpvs."""
+
+    def __init__(self, gpus: int):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.td = None
+        if self.world > 1:
+            import torch  # noqa: F401  (plumbing only)
+            import torch.distributed as td
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self.td = td
+        if gpus != self.world and self.rank == 0:
+            print(f"[bench] note: --gpus {gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE", file=sys.stderr)
+
+    def barrier(self):
+        if self.td:
+            self.td.barrier()
+
+    def max_float(self, v: float) -> float:
+        if not self.td:
+            return v
+        import torch
+
+        t = torch.tensor([v], dtype=torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, b: bytes | None, n: int) -> bytes:
+        if not self.td:
+            return b
+        import torch
+
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == 0:
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8).clone()
+        self.td.broadcast(t, src=0)
+        return bytes(t.numpy().tobytes())
+
+    def all_gather_np(self, a: np.ndarray) -> np.ndarray:
+        import torch
+
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.td.all_gather(outs, t)
+        return np.stack([o.numpy() for o in outs])
+
+    def close(self):
+        if self.td:
+            self.td.destroy_process_group()
+
+
+def device_sync(pvs, device):
+    # hipDeviceSynchronize through the library's own runtime; torch.cuda.synchronize too when torch is here
+    if "torch" in sys.modules:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+
+def main():
+    args = parse()
+    dist = Dist(args.gpus)
+    import panoptikon_amd as pvs
+    from panoptikon_amd import _lib as L
+
+    rank, world = dist.rank, dist.world
+    device = dist.local_rank if world > 1 else 0
+    if pvs.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X (gfx950); libpvs has no CPU path")
+    dtype = pvs.I8 if args.dtype == "i8" else pvs.F16
+    metric = pvs.COSINE if args.metric == "cosine" else pvs.L2
+    esz = 1 if dtype == pvs.I8 else 2
+    N, D, B, K = args.rows, args.dim, args.batch, args.k
+    per = (N + world - 1) // world
+    r0, r1 = min(rank * per, N), min((rank + 1) * per, N)
+    n_local = r1 - r0
+    lib = pvs.lib()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    # ------------------------------------------------------------ build shard
+    t_build = time.time()
+    chunk = min(args.chunk_rows, max(n_local, 1))
+    stage = pvs.DeviceBuffer(chunk * D * 4, device)
+    scale = None
+    if dtype == pvs.I8:
+        amax = 0.0
+        for off in range(0, n_local, chunk):
+            m = min(chunk, n_local - off)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, r0 + off, m, D, stage.ptr))
+            out = L.C.c_float()
+            L.check(lib.pvs_absmax(stage.ptr, m * D, L.DEVICE, device, L.C.byref(out)))
+            amax = max(amax, float(out.value))
+        amax = dist.max_float(amax)  # one scale per embedding space, global over all shards
+        scale = pvs.scale_from_absmax(amax)
+    ix = pvs.VectorIndex(dtype, D, device=device, capacity_rows=n_local, id_base=r0)
+    if scale is not None:
+        ix.set_scale(scale)
+    for off in range(0, n_local, chunk):
+        m = min(chunk, n_local - off)
+        L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, r0 + off, m, D, stage.ptr))
+        ix.add_f32((stage, m))
+    stage.free()
+    log(f"shard rows [{r0}, {r1}) resident in HBM as {args.dtype} in {time.time() - t_build:.1f}s (scale={scale})")
+
+    # ---------------------------------------------------------------- queries
+    NQB = 4
+    qbufs = []
+    for i in range(NQB):
+        qb = pvs.DeviceBuffer(B * D * 4, device)
+        L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, i * B, B, D, qb.ptr))
+        qbufs.append(qb)
+    slots = max(1, min(args.inflight, 4))
+    outs = [(pvs.DeviceBuffer(B * K * 8, device), pvs.DeviceBuffer(B * K * 4, device), pvs.DeviceBuffer(B * 4, device))
+            for _ in range(slots)]
+
+    comm = None
+    gather_mode = "single-gpu"
+    if world > 1:
+        try:
+            idb = None
+            if rank == 0:
+                buf = (L.C.c_uint8 * L.UNIQUE_ID_BYTES)()
+                L.check(lib.pvs_comm_unique_id(buf))
+                idb = bytes(buf)
+            idb = dist.bcast_bytes(idb, L.UNIQUE_ID_BYTES)
+            h = L.C.c_void_p()
+            idarr = (L.C.c_uint8 * L.UNIQUE_ID_BYTES).from_buffer_copy(idb)
+            L.check(lib.pvs_comm_create(idarr, world, rank, device, L.C.byref(h)))
+            comm = h
+            gather_mode = "rccl-allgather"
+        except Exception as e:  # noqa: BLE001
+            log(f"in-library RCCL unavailable ({e}); falling back to a host gather over gloo")
+            gather_mode = "gloo-host-gather"
+
+    def step_sharded(i):
+        q = qbufs[i % NQB]
+        oi, od, oc = outs[0]
+        if comm is not None:
+            L.check(lib.pvs_search_sharded(ix._h, comm, q.ptr, L.F32, B, K, metric, oi.ptr, od.ptr, oc.ptr))
+        else:
+            t = ix.search_device(q, L.F32, B, K, metric, oi, od, oc)
+            ix.wait(t)
+            ids = dist.all_gather_np(oi.to_numpy(np.int64, (B, K)))
+            dd = dist.all_gather_np(od.to_numpy(np.float32, (B, K)))
+            cc = dist.all_gather_np(oc.to_numpy(np.uint32, (B,)))
+            return pvs.merge_topk(ids, dd, cc, K)
+        return None
+
+    pending = []
+
+    def step_single(i):
+        q = qbufs[i % NQB]
+        oi, od, oc = outs[i % slots]
+        if len(pending) >= slots:
+            ix.wait(pending.pop(0))
+        pending.append(ix.search_device(q, L.F32, B, K, metric, oi, od, oc))
+
+    def drain():
+        while pending:
+            ix.wait(pending.pop(0))
+
+    step = step_single if world == 1 else step_sharded
+
+    # ----------------------------------------------------------------- timing
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    device_sync(pvs, device)
+    dist.barrier()
+    ix.set_profiling(True)
+    ix.profile(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    drain()
+    device_sync(pvs, device)
+    dist.barrier()
+    elapsed = dist.max_float(time.perf_counter() - t0)
+    ix.set_profiling(False)
+    prof = ix.profile()
+    st = ix.stats()
+    qps = args.steps * B / elapsed
+
+    # ---------------------------------------------------------------- roofline
+    scan_ms = prof.scan_ms / max(prof.scan_launches, 1)
+    bytes_per_launch = n_local * D * esz  # algorithmic bytes: each corpus component read once per batch
+    achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if prof.scan_launches else 0.0
+    ops_per_launch = 2.0 * n_local * D * B
+    mfma_peak = I8_MFMA_PEAK_TOPS if dtype == pvs.I8 else F16_MFMA_PEAK_TFLOPS
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("rows") == n_local and tj.get("dim") == D and tj.get("dtype") == args.dtype and tj.get("batch") == B:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "kernel": "k_scan (pass B, filter scan)", "launches": int(prof.scan_launches),
+        "avg_launch_ms": round(scan_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+        "mfma": {"achieved": round(ops_per_launch / (scan_ms * 1e-3) / 1e12, 1) if prof.scan_launches else 0.0,
+                 "peak": mfma_peak, "unit": "TOP/s" if dtype == pvs.I8 else "TFLOP/s",
+                 "frac": round(ops_per_launch / (scan_ms * 1e-3) / 1e12 / mfma_peak, 4) if prof.scan_launches else 0.0},
+        "sample_pass_avg_ms": round(prof.sample_ms / max(prof.sample_launches, 1), 4),
+        "finalize_avg_ms": round(prof.finalize_ms / max(prof.finalize_launches, 1), 4),
+    }
+
+    result = {
+        "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} (BASELINE configs[2])",
+                   "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
+                   "parallelism": f"row-shard x{world}", "exchange": gather_mode, "inflight": slots if world == 1 else 1},
+        "roofline": roofline,
+        "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries)},
+    }
+
+    # ------------------------------------------------- verification (untimed)
+    if rank == 0 and not args.no_verify:
+        import oracle as orc
+
+        odt = orc.I8 if dtype == pvs.I8 else orc.F16
+        omet = orc.COSINE if metric == pvs.COSINE else orc.L2
+        nq = max(1, min(args.check_queries, B))
+        # the batch the GPU answers, as the oracle sees it
+        qf32 = qbufs[0].to_numpy(np.float32, (B, D))[:nq]
+        qh = orc.quantize_int8(qf32, scale) if dtype == pvs.I8 else qf32
+        if world == 1:
+            gi, gd, gc = ix.search(qf32, K, metric)
+            threads = orc.max_threads()
+            best_i = [np.empty(0, np.int64) for _ in range(nq)]
+            best_d = [np.empty(0, np.float32) for _ in range(nq)]
+            t_or = time.time()
+            for off in range(0, n_local, args.chunk_rows):
+                m = min(args.chunk_rows, n_local - off)
+                rows = ix.read_rows(off, m)
+                ids = np.arange(r0 + off, r0 + off + m, dtype=np.int64)
+                ci, cd = orc.search(odt, omet, rows, qh, K, ids=ids, threads=threads)
+                for q in range(nq):
+                    ai = np.concatenate([best_i[q], ci[q]])
+                    ad = np.concatenate([best_d[q], cd[q]])
+                    best_i[q], best_d[q] = orc.topk(ad, K, ids=ai)
+            hits = sum(len(set(gi[q, :K].tolist()) & set(best_i[q].tolist())) for q in range(nq))
+            exact = all(np.array_equal(gi[q, : len(best_i[q])], best_i[q]) and
+                        np.array_equal(gd[q, : len(best_d[q])].view(np.uint32), best_d[q].view(np.uint32)) for q in range(nq))
+            result["recall_at_k"] = round(hits / (nq * min(K, n_local)), 6)
+            result["parity"] = {"checked_queries": nq, "oracle_rows": n_local, "ids_and_distances_bit_exact": bool(exact),
+                                "oracle_threads": threads, "oracle_seconds": round(time.time() - t_or, 1)}
+        else:
+            result["parity"] = {"note": "full-corpus oracle check runs at --gpus 1; N>1 relies on the merge tests"}
+
+        if not args.no_cpu_baseline and world == 1:
+            S = min(args.cpu_sample_rows, n_local)
+            Q = min(args.cpu_sample_queries, B)
+            rows = ix.read_rows(0, S)
+            qf = qbufs[0].to_numpy(np.float32, (B, D))[:Q]
+            qq = orc.quantize_int8(qf, scale) if dtype == pvs.I8 else qf
+            t1 = time.perf_counter()
+            orc.search(odt, omet, rows, qq, K, threads=1)
+            dt1 = time.perf_counter() - t1
+            allc = orc.max_threads()
+            t2 = time.perf_counter()
+            orc.search(odt, omet, rows, qq, K, threads=allc)
+            dt2 = time.perf_counter() - t2
+            result["cpu_baseline"] = {
+                "value": round(Q / dt1 * S / N, 4), "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": f"oracle scalar scan + top-{K} over the first {S} rows x {Q} queries of the same corpus "
+                          f"({dt1:.1f}s measured), extrapolated linearly to {N} rows",
+                "all_cores": {"value": round(Q / dt2 * S / N, 4), "cores": allc, "seconds": round(dt2, 2)},
+            }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if comm is not None:
+        lib.pvs_comm_destroy(comm)
+    ix.close()
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,25 @@ pvs_status pvs_index_set_scale(pvs_index *idx, float scale);
 
 pvs_status pvs_index_stats(pvs_index *idx, pvs_stats *out);
 
+/* Reads rows [row0, row0+n) back to the host as dense [n][dim] of the index dtype
+ * (the stored payload: embeddings.embedding / embedding_quants.quant). */
+pvs_status pvs_index_read_rows(pvs_index *idx, uint64_t row0, uint64_t n, void *out_host);
+
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched
+ * on (bench.py's roofline figure).  Off by default. */
+typedef struct pvs_profile {
+    uint32_t struct_size;
+    uint64_t scan_launches;     /* pass B: the full filter scan (dominant kernel) */
+    double scan_ms;
+    uint64_t scan_rows;         /* rows streamed by those launches */
+    uint64_t sample_launches;   /* pass A: threshold scan over the tile sample */
+    double sample_ms;
+    uint64_t finalize_launches; /* pass C */
+    double finalize_ms;
+} pvs_profile;
+pvs_status pvs_index_set_profiling(pvs_index *idx, int32_t enable);
+pvs_status pvs_index_get_profile(pvs_index *idx, pvs_profile *out, int32_t reset);
+
 /* ------------------------------------------------------------------- search */
 
 /* Page 1 of size k of the reference ordering, for `batch` queries.

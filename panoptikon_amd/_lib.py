@@ -33,6 +33,12 @@ class Stats(C.Structure):
                 ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("scan_launches", C.c_uint64), ("scan_ms", C.c_double),
+                ("scan_rows", C.c_uint64), ("sample_launches", C.c_uint64), ("sample_ms", C.c_double),
+                ("finalize_launches", C.c_uint64), ("finalize_ms", C.c_double)]
+
+
 class ReadyPair(C.Structure):
     _fields_ = [("have_db_context", C.c_int32), ("have_default_profile", C.c_int32), ("pair_ready", C.c_int32),
                 ("profile_id", C.c_int64), ("scale", C.c_float), ("dim", C.c_int64)]
@@ -62,6 +68,9 @@ SYMBOLS = {
     "pvs_index_set_scale_artifact": (_i32, [_vp, _vp, _sz]),
     "pvs_index_set_scale": (_i32, [_vp, _f]),
     "pvs_index_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "pvs_index_read_rows": (_i32, [_vp, _u64, _u64, _vp]),
+    "pvs_index_set_profiling": (_i32, [_vp, _i32]),
+    "pvs_index_get_profile": (_i32, [_vp, C.POINTER(Profile), _i32]),
     "pvs_search": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
     "pvs_search_device": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_wait": (_i32, [_vp, _u32]),

@@ -62,7 +62,15 @@ struct PendingChunk {
     uint32_t qoff, nb;
 };
 
+struct TimedSpan {
+    hipEvent_t a, b;
+    int kind;  // 0 = sample scan, 1 = full scan, 2 = finalize
+    uint64_t rows;
+};
+
 struct SearchCtx {
+    std::vector<TimedSpan> spans;       // recorded during the current search
+    std::vector<TimedSpan> span_pool;   // recycled events
     hipStream_t stream = nullptr;
     bool busy = false;
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
@@ -114,9 +122,61 @@ struct pvs_index {
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
+    bool profiling = false;
+    std::mutex prof_mu;
+    pvs_profile prof{};
 };
 
+static void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows) {
+    if (!ix->profiling) return;
+    TimedSpan t;
+    if (!c.span_pool.empty()) {
+        t = c.span_pool.back();
+        c.span_pool.pop_back();
+    } else if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) {
+        return;
+    }
+    t.kind = kind;
+    t.rows = rows;
+    (void)hipEventRecord(t.a, c.stream);
+    c.spans.push_back(t);
+}
+static void span_end(pvs_index *ix, SearchCtx &c) {
+    if (!ix->profiling || c.spans.empty()) return;
+    (void)hipEventRecord(c.spans.back().b, c.stream);
+}
+// after the stream drained
+static void spans_collect(pvs_index *ix, SearchCtx &c) {
+    if (c.spans.empty()) return;
+    std::lock_guard<std::mutex> lk(ix->prof_mu);
+    for (auto &t : c.spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            if (t.kind == 0) {
+                ix->prof.sample_launches++;
+                ix->prof.sample_ms += ms;
+            } else if (t.kind == 1) {
+                ix->prof.scan_launches++;
+                ix->prof.scan_ms += ms;
+                ix->prof.scan_rows += t.rows;
+            } else {
+                ix->prof.finalize_launches++;
+                ix->prof.finalize_ms += ms;
+            }
+        }
+        c.span_pool.push_back(t);
+    }
+    c.spans.clear();
+}
+
 static void ctx_release(SearchCtx &c) {
+    for (auto &t : c.spans) c.span_pool.push_back(t);
+    for (auto &t : c.span_pool) {
+        hipEventDestroy(t.a);
+        hipEventDestroy(t.b);
+    }
+    c.spans.clear();
+    c.span_pool.clear();
     hipFree(c.d_qin);
     hipFree(c.d_qmat);
     hipFree(c.d_qexact);
@@ -397,6 +457,31 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
+    if (!ix || (n && !out_host)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
+                                          (unsigned long long)(row0 + n), (unsigned long long)ix->n);
+    if (n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    const size_t w = (size_t)ix->dim * ix->esz;
+    HIP_TRY(hipMemcpy2D(out_host, w, ix->d_rows + row0 * (uint64_t)ix->stride, ix->stride, w, n, hipMemcpyDeviceToHost));
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_index_set_profiling(pvs_index *ix, int32_t enable) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    ix->profiling = enable != 0;
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_index_get_profile(pvs_index *ix, pvs_profile *out, int32_t reset) {
+    if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->prof_mu);
+    *out = ix->prof;
+    out->struct_size = sizeof(pvs_profile);
+    if (reset) ix->prof = pvs_profile{};
+    return PVS_OK;
+}
+
 // ------------------------------------------------------------------- search
 static pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                   pvs_metric metric) {
@@ -495,7 +580,9 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         a.grid = std::min<uint32_t>(n_samp, 256);
         a.mode = 0;
         a.groups_per_query = a.grid * (4 / a.qgroups) * 32;
+        span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
         HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
         HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
         // pass B: every row once
         HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4 * PVS_MAX_BATCH, c.stream));
@@ -503,7 +590,9 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         a.tile_step = 1;
         const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
         a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
         // pass C
         FinalizeArgs f;
         f.dtype = (int)ix->dtype;
@@ -525,7 +614,9 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         f.out_dist = od;
         f.out_count = oc;
         f.need_dense = c.d_need_dense + qoff;
+        span_begin(ix, c, 2, 0);
         HIP_TRY(pvs_launch_finalize(f, c.stream));
+        span_end(ix, c);
     }
     if (fast) HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
     return PVS_OK;
@@ -600,6 +691,7 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     }
+    if (st == PVS_OK) spans_collect(ix, *c);
     if (st == PVS_OK && fast && ix->n)
         st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count);
     if (st == PVS_OK) {
@@ -655,6 +747,7 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     pvs_status st = PVS_OK;
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    if (st == PVS_OK) spans_collect(ix, *c);
     if (st == PVS_OK && c->p_fast && ix->n)
         st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->p_out_ids, c->p_out_dist,
                               c->p_out_count);

@@ -172,6 +172,19 @@ class VectorIndex:
         L.check(L.lib().pvs_score_all(self._h, _ptr(q), qd, metric, _ptr(out), L.HOST))
         return out
 
+    def read_rows(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), _NP[self.dtype])
+        L.check(L.lib().pvs_index_read_rows(self._h, row0, n, _ptr(out)))
+        return out
+
+    def set_profiling(self, enable: bool):
+        L.check(L.lib().pvs_index_set_profiling(self._h, 1 if enable else 0))
+
+    def profile(self, reset: bool = False) -> L.Profile:
+        p = L.Profile()
+        L.check(L.lib().pvs_index_get_profile(self._h, C.byref(p), 1 if reset else 0))
+        return p
+
     def stats(self) -> L.Stats:
         s = L.Stats()
         L.check(L.lib().pvs_index_stats(self._h, C.byref(s)))
