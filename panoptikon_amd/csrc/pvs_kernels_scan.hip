@@ -27,6 +27,8 @@
 //   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16: A = 32 corpus rows, B = 32 queries,
 //   so each lane ends up with ONE query (lane & 31) and 16 rows: the per-query threshold
 //   is a lane-private register and the epilogue is branch-free until a row passes.
+#include <cstdlib>
+
 #include "pvs_kernels.hpp"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -100,6 +102,7 @@ struct ScanK {
     uint64_t n_rows;
     uint32_t stride, n_wgtiles, tile_step, groups_per_query, cand_cap;
     int metric, mode;
+    int debug;  // profiling ablations (PVS_SCAN_DEBUG): 1 = no MFMA, 2 = no epilogue, 4 = no DMA in the loop
 };
 
 template <int QG>
@@ -194,20 +197,26 @@ __global__ __launch_bounds__(256, (QG == 1 || KSLABS > 4) ? 1 : 2) void k_scan(S
             int norm_slot = 0;
 #pragma unroll
             for (int ks = 0; ks < KSLABS; ks++) {
-                wait_vm<(P - 1) * G::VM_PER_SLAB>();  // this wave's share of slab (tl,ks) has landed
+                if (!(a.debug & 4)) wait_vm<(P - 1) * G::VM_PER_SLAB>();  // this wave's share of slab (tl,ks) has landed
                 wg_barrier();                          // ... and everyone else's; slab g-1 is fully consumed
-                issue();                               // refill the slot slab g-1 occupied
+                if (!(a.debug & 4)) issue();           // refill the slot slab g-1 occupied
                 const uint8_t *sl = ring + c_slot * SLAB_BYTES + (rt * 32 + j) * 256;
+                if (!(a.debug & 1)) {
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const int c = (2 * t + h) ^ (j & 15);
-                    const v4i af = *(const v4i *)(sl + c * 16);
-                    acc = A::mfma(af, qf[ks * 8 + t], acc);
+                    for (int t = 0; t < 8; t++) {
+                        const int c = (2 * t + h) ^ (j & 15);
+                        const v4i af = *(const v4i *)(sl + c * 16);
+                        acc = A::mfma(af, qf[ks * 8 + t], acc);
+                    }
                 }
                 norm_slot = c_slot;
                 if (++c_slot == NS) c_slot = 0;
             }
 
+            if (a.debug & 2) {
+                asm volatile("" ::"v"(acc[0]), "v"(acc[15]));
+                continue;
+            }
             // ---- epilogue: lane = one query, 16 rows: i(reg) = (reg&3) + 8*(reg>>2) + 4*h
             const float *nl = (const float *)(normring + norm_slot * 1024 + wave * 256);
             float nr[16];
@@ -347,6 +356,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.cand_cap = a.cand_cap;
     k.metric = a.metric;
     k.mode = a.mode;
+    static const int dbg = getenv("PVS_SCAN_DEBUG") ? atoi(getenv("PVS_SCAN_DEBUG")) : 0;
+    k.debug = a.mode == 1 ? dbg : 0;
     if (a.dtype == PVS_I8) {
         switch (a.kslabs) {
             case 1: return launch_qg<PVS_I8, 1>(k, a.qgroups, a.grid, s);
