@@ -23,6 +23,9 @@ SOURCES = [
     "pvs_api.hip",
     "pvs_kernels_util.hip",
     "pvs_kernels_scan.hip",
+    "pvs_scan_i8.hip",
+    "pvs_scan_f16_small.hip",
+    "pvs_scan_f16_large.hip",
     "pvs_dense.hip",
     "pvs_comm.hip",
     "pvs_host.cpp",

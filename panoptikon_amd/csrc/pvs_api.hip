@@ -111,7 +111,8 @@ struct pvs_index {
     uint64_t n = 0, cap = 0;
     int64_t id_base = 0, last_id = INT64_MIN;
     uint8_t *d_rows = nullptr;
-    float *d_norm2 = nullptr;
+    float *d_norm2 = nullptr;   // |a|^2, the reference's aMag (sequential f32)
+    float *d_rnorm = nullptr;   // 1/|a|
     int64_t *d_ids = nullptr;
     std::vector<int64_t> h_groups;  // optional group ids (host copy, for pvs_aggregate callers)
     float scale = 0.f;
@@ -280,29 +281,36 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
     float *norm_new = nullptr;
     int64_t *ids_new = nullptr;
     HIP_TRY(hipMalloc((void **)&rows_new, cap * (uint64_t)ix->stride));
+    float *rnorm_new = nullptr;
     hipError_t e = hipMalloc((void **)&norm_new, cap * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&rnorm_new, cap * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ids_new, cap * 8);
     if (e != hipSuccess) {
         hipFree(rows_new);
         hipFree(norm_new);
+        hipFree(rnorm_new);
         return pvs_fail(PVS_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
     }
     hipStream_t s = ix->admin_stream;
     // padding rows: zero payload, NaN norm (a NaN norm makes every scan compare fail)
     HIP_TRY(hipMemsetAsync(rows_new + ix->n * (uint64_t)ix->stride, 0, (cap - ix->n) * (uint64_t)ix->stride, s));
     HIP_TRY(pvs_launch_fill_f32(norm_new + ix->n, cap - ix->n, __builtin_nanf(""), s));
+    HIP_TRY(pvs_launch_fill_f32(rnorm_new + ix->n, cap - ix->n, __builtin_nanf(""), s));
     HIP_TRY(hipMemsetAsync(ids_new + ix->n, 0xff, (cap - ix->n) * 8, s));
     if (ix->n) {
         HIP_TRY(hipMemcpyAsync(rows_new, ix->d_rows, ix->n * (uint64_t)ix->stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(norm_new, ix->d_norm2, ix->n * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(rnorm_new, ix->d_rnorm, ix->n * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(ids_new, ix->d_ids, ix->n * 8, hipMemcpyDeviceToDevice, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     hipFree(ix->d_rows);
     hipFree(ix->d_norm2);
+    hipFree(ix->d_rnorm);
     hipFree(ix->d_ids);
     ix->d_rows = rows_new;
     ix->d_norm2 = norm_new;
+    ix->d_rnorm = rnorm_new;
     ix->d_ids = ids_new;
     ix->cap = cap;
     return PVS_OK;
@@ -315,6 +323,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     for (auto &c : ix->ctx) ctx_release(c);
     hipFree(ix->d_rows);
     hipFree(ix->d_norm2);
+    hipFree(ix->d_rnorm);
     hipFree(ix->d_ids);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     delete ix;
@@ -352,7 +361,7 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
         const size_t w = (size_t)ix->dim * ix->esz;
         HIP_TRY(hipMemcpy2DAsync(dst, ix->stride, rows_dev, w, w, n, hipMemcpyDeviceToDevice, s));
     }
-    HIP_TRY(pvs_launch_norm2((int)ix->dtype, dst, ix->stride, ix->dim, n, ix->d_norm2 + ix->n, s));
+    HIP_TRY(pvs_launch_norm2((int)ix->dtype, dst, ix->stride, ix->dim, n, ix->d_norm2 + ix->n, ix->d_rnorm + ix->n, s));
     if (row_ids)
         HIP_TRY(hipMemcpyAsync(ix->d_ids + ix->n, row_ids, n * 8, hipMemcpyHostToDevice, s));
     else
@@ -447,7 +456,7 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     s.rows = ix->n;
     s.capacity_rows = ix->cap;
     s.row_stride_bytes = ix->stride;
-    s.hbm_bytes = ix->cap * ((uint64_t)ix->stride + 12);
+    s.hbm_bytes = ix->cap * ((uint64_t)ix->stride + 16);
     s.scale = ix->scale_set ? ix->scale : 0.f;
     s.searches = ix->searches.load();
     s.fast_queries = ix->fast_queries.load();
@@ -560,7 +569,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         a.kslabs = ix->stride / PVS_KSLAB_BYTES;
         a.qgroups = batch_pad / 32;
         a.rows = ix->d_rows;
-        a.norm2 = ix->d_norm2;
+        a.aux = metric == PVS_COSINE ? ix->d_rnorm : ix->d_norm2;
         a.stride = ix->stride;
         a.n_rows = ix->n;
         a.qmat = c.d_qmat;

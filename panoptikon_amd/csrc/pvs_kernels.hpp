@@ -4,7 +4,7 @@
 
 // ---- utility kernels (pvs_kernels_util.hip)
 hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
-                            float *norm2, hipStream_t s);
+                            float *norm2, float *rnorm, hipStream_t s);
 hipError_t pvs_launch_fill_f32(float *p, uint64_t n, float v, hipStream_t s);
 hipError_t pvs_launch_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst,
                                       uint32_t stride, hipStream_t s);
@@ -34,7 +34,7 @@ struct ScanArgs {
     uint32_t kslabs;        // stride / 256
     uint32_t qgroups;       // batch_pad / 32 in {1,2,4}
     const uint8_t *rows;
-    const float *norm2;
+    const float *aux;       // per-row scalar for the metric: 1/|a| (cosine) or |a|^2 (L2)
     uint32_t stride;
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;

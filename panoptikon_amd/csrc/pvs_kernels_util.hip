@@ -5,24 +5,27 @@
 // ------------------------------------------------------------------ norms
 // norm2[r] = the reference's aMag for row r: sum a_i^2 accumulated sequentially in
 // f32 (oracle: orc_vec_distance_cosine_*).  One lane per row; runs once per add.
+// rnorm[r] = 1/sqrt(norm2[r]) (two correctly rounded steps): the scan's cosine filter key.
 template <int DT>
 __global__ __launch_bounds__(256) void k_norm2(const uint8_t *rows, uint32_t stride, int dim, uint64_t n,
-                                               float *norm2) {
+                                               float *norm2, float *rnorm) {
     uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    norm2[r] = seq_sumsq<DT>(rows + r * (uint64_t)stride, dim);
+    const float aa = seq_sumsq<DT>(rows + r * (uint64_t)stride, dim);
+    norm2[r] = aa;
+    rnorm[r] = __frcp_rn(__fsqrt_rn(aa));
 }
 
 hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
-                            float *norm2, hipStream_t s) {
+                            float *norm2, float *rnorm, hipStream_t s) {
     if (n == 0) return hipSuccess;
     dim3 g((unsigned)((n + 255) / 256)), b(256);
     if (dtype == PVS_I8)
-        hipLaunchKernelGGL(k_norm2<PVS_I8>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+        hipLaunchKernelGGL(k_norm2<PVS_I8>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
     else if (dtype == PVS_F16)
-        hipLaunchKernelGGL(k_norm2<PVS_F16>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+        hipLaunchKernelGGL(k_norm2<PVS_F16>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
     else
-        hipLaunchKernelGGL(k_norm2<PVS_F32>, g, b, 0, s, rows, stride, (int)dim, n, norm2);
+        hipLaunchKernelGGL(k_norm2<PVS_F32>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
     return hipGetLastError();
 }
 

@@ -1,0 +1,20 @@
+// pvs_scan_dispatch.hpp — entry points of the scan-kernel translation units.
+#pragma once
+#include "pvs_kernels.hpp"
+struct ScanK {
+    const uint8_t *rows;
+    const float *aux;  // per-row scalar streamed with the tiles: 1/|a| (cosine) or |a|^2 (L2); NaN on padding rows
+    const uint8_t *qmat;
+    const QInfo *qinfo;
+    const float *thr;
+    float *gmin;
+    uint32_t *cand_cnt;
+    uint2 *cand;
+    uint64_t n_rows;
+    uint32_t stride, n_wgtiles, tile_step, groups_per_query, cand_cap, grid;
+    int debug;  // profiling ablations (PVS_SCAN_DEBUG): 1 = no MFMA, 2 = no epilogue, 4 = no DMA in the loop
+};
+
+hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
+hipError_t pvs_scan_dispatch_f16_small(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
+hipError_t pvs_scan_dispatch_f16_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

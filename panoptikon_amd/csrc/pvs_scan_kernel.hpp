@@ -1,0 +1,368 @@
+// pvs_scan_kernel.hpp — the hot kernel: a bandwidth-bound filter scan of the corpus on
+// the CDNA4 matrix cores (gfx950).  Included by the pvs_scan_*.hip translation units,
+// which instantiate it per (dtype, k-slabs, query groups, metric, mode).
+//
+// Replaces, for a batch of queries, the reference's per-row
+//   vec_distance_{cosine,L2}(payload, ?)          (image_embeddings.rs:321-362,
+//   ... ORDER BY order_rank ASC ... LIMIT k          text_embeddings.rs:386-418, builder.rs:578-582)
+// The reference scores every row and sorts everything.  Here:
+//   pass A (MODE 0)  scan a strided sample of row tiles, keep per-lane minima of an UPPER
+//           bound of the key -> the k-th smallest of those group minima is a valid upper
+//           bound T of the k-th best key of the whole corpus;
+//   pass B (MODE 1)  scan every row once, emit (row, key) for rows whose LOWER bound <= T;
+//   pass C  (pvs_kernels_scan.hip) exact rerank of the few survivors.
+//
+// Geometry (64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
+//   workgroup = 4 waves; wave (qg, rt) owns query group qg (32 queries, held in VGPRs for
+//   the whole kernel as MFMA B fragments) and row sub-tile rt (32 rows);
+//   QG = batch_pad/32 in {1,2,4}, RT = 4/QG, workgroup tile = 32*RT rows.
+//   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
+//   in "slabs" of (32*RT rows x 256 B), NS-deep ring, P = NS-1 slabs in flight, one
+//   s_barrier per slab, counted s_waitcnt vmcnt (never 0 in steady state).
+//   A fragments are ds_read_b128 from an XOR-swizzled slab image (chunk ^= row & 15, applied
+//   on the DMA *source* address; the LDS destination is lane-linear): conflict-free for the
+//   16-lane groups ds_read_b128 is serviced in.
+//   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 with A = 32 corpus rows, B = 32 queries:
+//   each lane ends up with ONE query (lane & 31) and 16 rows, so the per-query threshold is
+//   a lane-private register and the epilogue is 3-4 VALU per score until a row passes.
+#pragma once
+#include <cstdlib>
+
+#include "pvs_scan_dispatch.hpp"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+// LDS-DMA issued from inline asm: hipcc models the builtin form as an LDS store that may
+// alias every later ds_read and drains vmcnt(0) in front of them (two full pipeline drains
+// per tile in the first build of this kernel).  An asm statement is invisible to its waitcnt
+// insertion, so the counted s_waitcnt vmcnt(N) below are the only waits.  M0 carries the
+// wave-uniform LDS destination; each lane lands at M0 + lane*size.  Source address =
+// SGPR base (uniform: tile + k-slab) + 32-bit VGPR offset (lane's row/chunk inside the slab).
+__device__ static inline void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ static inline void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ static inline uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)p;
+}
+template <int N>
+__device__ static inline void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ static inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int LCAP = 384;      // LDS candidate staging entries per workgroup
+constexpr int FLUSH_AT = 128;  // flush to HBM at a checkpoint once this many are staged
+constexpr int FLUSH_EVERY = 16;  // tiles between flush checkpoints (one extra barrier each)
+
+template <int DT>
+struct Acc;
+template <>
+struct Acc<PVS_I8> {
+    using type = v16i;
+    __device__ static inline type mfma(v4i a, v4i b, type c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+    __device__ static inline float tof(int v) { return (float)v; }
+};
+template <>
+struct Acc<PVS_F16> {
+    using type = v16f;
+    __device__ static inline type mfma(v4i a, v4i b, type c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+    }
+    __device__ static inline float tof(float v) { return v; }
+};
+
+// Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
+// vmcnt wait + one s_barrier per chunk.  For the headline shape (768-B rows, 128 queries) a
+// chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
+template <int QG, int KSLABS>
+struct Geo {
+    static constexpr int RT = 4 / QG;
+    static constexpr int SLAB_ROWS = 32 * RT;
+    static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
+    static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
+    static constexpr int NC = RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8));  // chunks in the ring
+    static constexpr int NS = NC * SPB;                                            // slabs in the ring
+    static constexpr int PC = NC - 1;                                              // chunks in flight
+    static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
+    static constexpr int VM_PER_CHUNK = 2 * RT * SPB + 1;  // per wave: row DMAs + 1 norm DMA
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NC * 1024 + 16 + LCAP * 12;
+    static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
+};
+
+constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
+
+template <int DT, int KSLABS, int QG, int METRIC, int MODE>
+__global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
+    using G = Geo<QG, KSLABS>;
+    using A = Acc<DT>;
+    constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
+                  SPB = G::SPB, CPT = G::CPT;
+    constexpr bool COS = METRIC == PVS_COSINE;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *const ring = smem;
+    uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NC][4 waves][256 B]
+    uint32_t *const st_cnt = (uint32_t *)(normring + NC * 1024);
+    uint32_t *const st_row = st_cnt + 4;
+    uint32_t *const st_key = st_row + LCAP;
+    uint32_t *const st_q = st_key + LCAP;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave % QG, rt = wave / QG;
+    const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
+    const int myq = qg * 32 + j;
+
+    if (MODE == 1 && tid == 0) *st_cnt = 0;
+    const uint32_t ring_lds = lds_addr(ring), norm_lds = lds_addr(normring);
+
+    // tiles of this workgroup: (blockIdx.x + it*grid) * tile_step
+    const uint32_t n_samp = (a.n_wgtiles + a.tile_step - 1) / a.tile_step;
+    const int n_my = blockIdx.x < n_samp ? (int)((n_samp - blockIdx.x + a.grid - 1) / a.grid) : 0;
+    const uint64_t tile_bytes = (uint64_t)SLAB_ROWS * a.stride;
+
+    float mins[MODE == 0 ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[r] = __builtin_inff();
+
+    if (n_my > 0) {
+        // ---- query fragments: resident in registers for the whole kernel
+        v4i qf[KSLABS * 8];
+        {
+            const uint8_t *qrow = a.qmat + (size_t)myq * a.stride;
+#pragma unroll
+            for (int x = 0; x < KSLABS * 8; x++) qf[x] = *(const v4i *)(qrow + (x >> 3) * 256 + ((x & 7) * 2 + h) * 16);
+        }
+        QInfo qi = a.qinfo[myq];
+        float thr = MODE == 1 ? a.thr[myq] : 0.f;
+        // Pin every value loaded above as an asm operand: hipcc must retire its own loads HERE
+        // (it cannot see the asm waits), otherwise it re-emits partial vmcnt waits for them
+        // inside the main loop and throttles the DMA prefetch depth.
+#pragma unroll
+        for (int x = 0; x < KSLABS * 8; x++) asm volatile("" : "+v"(qf[x]));
+        asm volatile("" : "+v"(qi.bb), "+v"(qi.dscale), "+v"(qi.eA), "+v"(qi.eR), "+v"(thr));
+        wait_vm<0>();
+        // Filter tests folded into one per-lane constant (key/err algebra of DESIGN.md §5):
+        //   cosine  key = -dscale*acc/|a|, err = eA
+        //           pass: key-err <= thr  <=>  acc/|a| >= -(thr+eA)/dscale
+        //   L2      key = |a|^2 + bb - 2 dscale acc, err = eA + eR|a|^2
+        //           pass: (1-eR)|a|^2 - 2 dscale acc <= thr + eA - bb
+        const float c1 = 1.0f - qi.eR;
+        const float m2d = -2.0f * qi.dscale;
+        float tS;
+        if (COS)
+            tS = qi.dscale > 0.f ? -(thr + qi.eA) / qi.dscale : __builtin_inff();  // padding query: never passes
+        else
+            tS = qi.dscale > 0.f ? thr + qi.eA - qi.bb : -__builtin_inff();
+
+        // ---- per-lane DMA source offsets inside a slab (row/chunk swizzle), computed once
+        uint32_t voff[2 * RT];
+#pragma unroll
+        for (int e = 0; e < 2 * RT; e++) {
+            const int r = 4 * (wave * 2 * RT + e) + (lane >> 4);
+            const int c = (lane & 15) ^ (r & 15);
+            voff[e] = (uint32_t)r * a.stride + (uint32_t)c * 16u;
+        }
+        const uint32_t nvoff = (uint32_t)(rt * 32 + j) * 4u;
+        // A-fragment LDS byte offsets of this lane inside a slab
+        const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
+        const uint32_t jx = (uint32_t)(j & 15);
+
+        // ---- DMA issue state (runs PC chunks ahead of the consumer)
+        int i_tl = 0, i_ck = 0, i_slot = 0;  // tile, chunk within tile, ring chunk slot
+        auto issue = [&]() {
+            const int tl = i_tl < n_my ? i_tl : n_my - 1;  // past the end: harmless re-read keeps vmcnt uniform
+            const uint64_t wt = (uint64_t)(blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step;
+            const uint8_t *sbase = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 256u);
+            const uint32_t sl = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (2 * RT * 1024);
+#pragma unroll
+            for (int sb = 0; sb < SPB; sb++) {
+#pragma unroll
+                for (int e = 0; e < 2 * RT; e++) dma16(sbase + sb * 256, voff[e], sl + sb * SLAB_BYTES + e * 1024);
+            }
+            dma4(a.aux + wt * SLAB_ROWS, nvoff, norm_lds + (uint32_t)i_slot * 1024 + (uint32_t)wave * 256);
+            if (++i_ck == CPT) {
+                i_ck = 0;
+                i_tl++;
+            }
+            if (++i_slot == NC) i_slot = 0;
+        };
+#pragma unroll
+        for (int p = 0; p < PC; p++) issue();
+
+        int c_slot = 0;
+        for (int tl = 0; tl < n_my; tl++) {
+            typename A::type acc, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                acc[r] = 0;
+                acc1[r] = 0;
+            }
+            int norm_slot = 0;
+#pragma unroll
+            for (int ck = 0; ck < CPT; ck++) {
+                if (!(a.debug & 4)) wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
+                wg_barrier();                                             // ... and everyone else's; the previous chunk is consumed
+                if (!(a.debug & 4)) issue();                              // refill the slot the previous chunk occupied
+                const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
+                if (!(a.debug & 1)) {
+                    // all A fragments of the chunk are independent LDS reads; MFMAs alternate
+                    // between two accumulator chains so no MFMA waits on its predecessor
+                    v4i af[SPB * 8];
+#pragma unroll
+                    for (int t = 0; t < SPB * 8; t++)
+                        af[t] = (a.debug & 8) ? qf[t] : *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
+#pragma unroll
+                    for (int t = 0; t < SPB * 8; t += 2) {
+                        acc = A::mfma(af[t], qf[ck * SPB * 8 + t], acc);
+                        acc1 = A::mfma(af[t + 1], qf[ck * SPB * 8 + t + 1], acc1);
+                    }
+                }
+                norm_slot = c_slot;
+                if (++c_slot == NC) c_slot = 0;
+            }
+            if (a.debug & 2) {
+                asm volatile("" ::"v"(acc[0]), "v"(acc1[15]));
+                continue;
+            }
+            // ---- epilogue: lane = one query, 16 rows: i(reg) = (reg&3) + 8*(reg>>2) + 4*h
+            // x[r] = per-row scalar (1/|a| or |a|^2).  3-4 VALU per score and one wave-wide test;
+            // rows are only looked at individually when some lane passes.
+            const float *nl = (const float *)(normring + norm_slot * 1024 + wave * 256);
+            float x[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
+                x[4 * g4 + 0] = v.x;
+                x[4 * g4 + 1] = v.y;
+                x[4 * g4 + 2] = v.z;
+                x[4 * g4 + 3] = v.w;
+            }
+            // sv[r]: cosine  acc * (1/|a|)                 (pass iff sv >= tS)
+            //        L2      (1-eR)*|a|^2 - 2*dscale*acc   (pass iff sv <= tS)
+            float sv[16];
+            float best = COS ? -__builtin_inff() : __builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float d = A::tof(acc[r]) + A::tof(acc1[r]);  // i8: exact integers; f16: within the error budget
+                if (COS) {
+                    sv[r] = d * x[r];
+                    best = fmaxf(best, sv[r]);  // NaN (padding / zero-norm rows) never wins
+                } else {
+                    sv[r] = __builtin_fmaf(d, m2d, c1 * x[r]);
+                    best = fminf(best, sv[r]);
+                }
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    // upper bound of this row's key: key + err
+                    const float ub = COS ? __builtin_fmaf(-sv[r], qi.dscale, qi.eA) : sv[r] + (qi.bb + qi.eA) + 2.0f * qi.eR * x[r];
+                    mins[r] = fminf(mins[r], ub);
+                }
+            } else {
+                const bool lane_pass = COS ? (best >= tS) : (best <= tS);
+                if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) {
+                    const uint32_t row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
+                    bool direct = false;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
+                        if (p) {
+                            const float key = COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * x[r];
+                            const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
+                            const uint32_t pos = atomicAdd(st_cnt, 1u);
+                            if (pos < (uint32_t)LCAP) {
+                                st_row[pos] = row;
+                                st_key[pos] = __builtin_bit_cast(uint32_t, key);
+                                st_q[pos] = (uint32_t)myq;
+                            } else {  // staging full (very loose threshold): go to HBM directly
+                                const uint32_t gp = atomicAdd(&a.cand_cnt[myq], 1u);
+                                if (gp < a.cand_cap)
+                                    a.cand[(size_t)myq * a.cand_cap + gp] = make_uint2(row, __builtin_bit_cast(uint32_t, key));
+                                direct = true;
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(direct) != 0) wait_vm<0>();  // stores are unordered vs loads: drain
+                }
+                // flush checkpoint: uniform, because no wave appends between this barrier and its
+                // next epilogue
+                if ((tl % FLUSH_EVERY) == FLUSH_EVERY - 1) {
+                    wg_barrier();
+                    const uint32_t staged = *(volatile uint32_t *)st_cnt;
+                    if (staged >= (uint32_t)FLUSH_AT) {
+                        const uint32_t nst = staged < (uint32_t)LCAP ? staged : (uint32_t)LCAP;
+                        for (uint32_t e = tid; e < nst; e += 256) {
+                            const uint32_t q = st_q[e];
+                            const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
+                            if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[e], st_key[e]);
+                        }
+                        wg_barrier();
+                        if (tid == 0) *st_cnt = 0;
+                        wait_vm<0>();
+                    }
+                }
+            }
+        }
+        wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
+    }
+
+    if (MODE == 0) {
+        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * 16;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] = mins[r];
+    } else {
+        wg_barrier();
+        const uint32_t staged = *(volatile uint32_t *)st_cnt;
+        const uint32_t nst = staged < (uint32_t)LCAP ? staged : (uint32_t)LCAP;
+        for (uint32_t e = tid; e < nst; e += 256) {
+            const uint32_t q = st_q[e];
+            const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
+            if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[e], st_key[e]);
+        }
+    }
+}
+
+// ---- per-TU dispatch helpers
+template <int DT, int KS, int QG, int METRIC, int MODE>
+static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
+    static std::atomic<bool> configured{false};
+    constexpr int lds = Geo<QG, KS>::LDS_BYTES;
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_scan<DT, KS, QG, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(256), lds, s, k);
+    return hipGetLastError();
+}
+template <int DT, int KS, int QG>
+static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream_t s) {
+    if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
+    return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
+}
+template <int DT, int KS>
+static hipError_t scan_launch_qg(const ScanK &k, uint32_t qg, int metric, int mode, hipStream_t s) {
+    switch (qg) {
+        case 1: return scan_launch_mm<DT, KS, 1>(k, metric, mode, s);
+        case 2: return scan_launch_mm<DT, KS, 2>(k, metric, mode, s);
+        case 4: return scan_launch_mm<DT, KS, 4>(k, metric, mode, s);
+    }
+    return hipErrorInvalidValue;
+}
