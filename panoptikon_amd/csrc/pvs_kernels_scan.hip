@@ -33,12 +33,36 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.grid = a.grid;
     static const int dbg = getenv("PVS_SCAN_DEBUG") ? atoi(getenv("PVS_SCAN_DEBUG")) : 0;
     k.debug = a.mode == 1 ? dbg : 0;
-    if (a.dtype == PVS_I8) return pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
-    if (a.dtype == PVS_F16) {
-        if (a.kslabs <= 4) return pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
-        return pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+    k.dbg_out = nullptr;
+    static unsigned long long *d_dbg = nullptr;
+    if (k.debug & 16) {
+        if (!d_dbg && hipMalloc((void **)&d_dbg, (size_t)4096 * 4 * 6 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_dbg, 0, (size_t)4096 * 4 * 6 * 8, s);
+        k.dbg_out = d_dbg;
     }
-    return hipErrorInvalidValue;
+    struct DbgPrint {
+        static void run(unsigned long long *d, uint32_t grid, hipStream_t s) {
+            (void)hipStreamSynchronize(s);
+            std::vector<unsigned long long> h((size_t)grid * 24);
+            (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[6] = {0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < h.size(); i++) sum[i % 6] += (double)h[i];
+            const char *nm[6] = {"vmcnt-wait", "barrier", "dma-issue", "lds+mfma", "epilogue", "flush"};
+            double tot = 0;
+            for (int i = 0; i < 6; i++) tot += sum[i];
+            fprintf(stderr, "[pvs scan phases, mean cycles per wave]");
+            for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.0f (%.1f%%)", nm[i], sum[i] / (grid * 4.0), 100.0 * sum[i] / tot);
+            fprintf(stderr, " total=%.0f\n", tot / (grid * 4.0));
+        }
+    };
+    hipError_t e = hipErrorInvalidValue;
+    if (a.dtype == PVS_I8)
+        e = pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+    else if (a.dtype == PVS_F16)
+        e = a.kslabs <= 4 ? pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+                          : pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+    if (e == hipSuccess && k.dbg_out && a.grid <= 4096) DbgPrint::run(k.dbg_out, a.grid, s);
+    return e;
 }
 
 // ------------------------------------------------------------- k-th select

@@ -76,7 +76,7 @@ template <>
 struct Acc<PVS_I8> {
     using type = v16i;
     __device__ static inline type mfma(v4i a, v4i b, type c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-    __device__ static inline float tof(int v) { return (float)v; }
+    __device__ static inline int sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }  // exact
 };
 template <>
 struct Acc<PVS_F16> {
@@ -84,7 +84,7 @@ struct Acc<PVS_F16> {
     __device__ static inline type mfma(v4i a, v4i b, type c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
     }
-    __device__ static inline float tof(float v) { return v; }
+    __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
 };
 
 // Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
@@ -204,88 +204,56 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         };
 #pragma unroll
         for (int p = 0; p < PC; p++) issue();
-
+        // ---- main loop, software-pipelined inside each wave: the MFMAs of tile t are issued while
+        // the VALU works through the epilogue of tile t-1 (MFMA and VALU are separate pipes; a wave
+        // issues in order, so the two instruction streams must sit in one basic block for the
+        // scheduler to interleave them).  `hold` carries tile t-1's 16 dot products and `xh` its
+        // per-row scalars across the iteration boundary.
+        using acc_t = typename A::type;
         int c_slot = 0;
-        for (int tl = 0; tl < n_my; tl++) {
-            typename A::type acc, acc1;
+        float xh[16];
+        decltype(A::sum2(acc_t{}, acc_t{}, 0)) hold[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                acc[r] = 0;
-                acc1[r] = 0;
+        for (int r = 0; r < 16; r++) {
+            xh[r] = __builtin_nanf("");  // tile "-1": every test fails
+            hold[r] = 0;
+        }
+        uint32_t prev_row_base = 0;
+
+        // Fast part of an epilogue, cut into 24 micro-steps so the main loop can drop them between
+        // MFMAs:  m < 16: sv[m] = score of row m;  m >= 16: fold two scores into the running best.
+        //   sv[r]: cosine  dot * (1/|a|)                 (pass iff sv >= tS)
+        //          L2      (1-eR)*|a|^2 - 2*dscale*dot   (pass iff sv <= tS)
+        auto epi_micro = [&](int m, float(&sv)[16], float &best) {
+            if (m < 16) {
+                const float d = (float)hold[m];
+                sv[m] = COS ? d * xh[m] : __builtin_fmaf(d, m2d, c1 * xh[m]);
+            } else {
+                const int r = (m - 16) * 2;
+                // NaN (padding / zero-norm rows) never wins a fmax/fmin
+                best = COS ? fmaxf(best, fmaxf(sv[r], sv[r + 1])) : fminf(best, fminf(sv[r], sv[r + 1]));
             }
-            int norm_slot = 0;
-#pragma unroll
-            for (int ck = 0; ck < CPT; ck++) {
-                if (!(a.debug & 4)) wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
-                wg_barrier();                                             // ... and everyone else's; the previous chunk is consumed
-                if (!(a.debug & 4)) issue();                              // refill the slot the previous chunk occupied
-                const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
-                if (!(a.debug & 1)) {
-                    // all A fragments of the chunk are independent LDS reads; MFMAs alternate
-                    // between two accumulator chains so no MFMA waits on its predecessor
-                    v4i af[SPB * 8];
-#pragma unroll
-                    for (int t = 0; t < SPB * 8; t++)
-                        af[t] = (a.debug & 8) ? qf[t] : *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
-#pragma unroll
-                    for (int t = 0; t < SPB * 8; t += 2) {
-                        acc = A::mfma(af[t], qf[ck * SPB * 8 + t], acc);
-                        acc1 = A::mfma(af[t + 1], qf[ck * SPB * 8 + t + 1], acc1);
-                    }
-                }
-                norm_slot = c_slot;
-                if (++c_slot == NC) c_slot = 0;
-            }
-            if (a.debug & 2) {
-                asm volatile("" ::"v"(acc[0]), "v"(acc1[15]));
-                continue;
-            }
-            // ---- epilogue: lane = one query, 16 rows: i(reg) = (reg&3) + 8*(reg>>2) + 4*h
-            // x[r] = per-row scalar (1/|a| or |a|^2).  3-4 VALU per score and one wave-wide test;
-            // rows are only looked at individually when some lane passes.
-            const float *nl = (const float *)(normring + norm_slot * 1024 + wave * 256);
-            float x[16];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
-                x[4 * g4 + 0] = v.x;
-                x[4 * g4 + 1] = v.y;
-                x[4 * g4 + 2] = v.z;
-                x[4 * g4 + 3] = v.w;
-            }
-            // sv[r]: cosine  acc * (1/|a|)                 (pass iff sv >= tS)
-            //        L2      (1-eR)*|a|^2 - 2*dscale*acc   (pass iff sv <= tS)
-            float sv[16];
-            float best = COS ? -__builtin_inff() : __builtin_inff();
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float d = A::tof(acc[r]) + A::tof(acc1[r]);  // i8: exact integers; f16: within the error budget
-                if (COS) {
-                    sv[r] = d * x[r];
-                    best = fmaxf(best, sv[r]);  // NaN (padding / zero-norm rows) never wins
-                } else {
-                    sv[r] = __builtin_fmaf(d, m2d, c1 * x[r]);
-                    best = fminf(best, sv[r]);
-                }
-            }
+        };
+        constexpr int EPI_STEPS = 24;
+        // the rest: group minima (pass A) or candidate emission (pass B)
+        auto epi_rest = [&](const float(&sv)[16], float best) {
             if (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     // upper bound of this row's key: key + err
-                    const float ub = COS ? __builtin_fmaf(-sv[r], qi.dscale, qi.eA) : sv[r] + (qi.bb + qi.eA) + 2.0f * qi.eR * x[r];
+                    const float ub = COS ? __builtin_fmaf(-sv[r], qi.dscale, qi.eA) : sv[r] + (qi.bb + qi.eA) + 2.0f * qi.eR * xh[r];
                     mins[r] = fminf(mins[r], ub);
                 }
             } else {
                 const bool lane_pass = COS ? (best >= tS) : (best <= tS);
                 if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) {
-                    const uint32_t row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
                     bool direct = false;
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
                         if (p) {
-                            const float key = COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * x[r];
-                            const uint32_t row = row_base + (r & 3) + 8 * (r >> 2);
+                            const float key = COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r];
+                            const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
                             const uint32_t pos = atomicAdd(st_cnt, 1u);
                             if (pos < (uint32_t)LCAP) {
                                 st_row[pos] = row;
@@ -301,6 +269,70 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                     }
                     if (__builtin_amdgcn_ballot_w64(direct) != 0) wait_vm<0>();  // stores are unordered vs loads: drain
                 }
+            }
+        };
+
+        for (int tl = 0; tl < n_my; tl++) {
+            acc_t acc, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                acc[r] = 0;
+                acc1[r] = 0;
+            }
+            int norm_slot = 0;
+            float sv[16];
+            float best = COS ? -__builtin_inff() : __builtin_inff();
+#pragma unroll
+            for (int ck = 0; ck < CPT; ck++) {
+                wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
+                wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
+                issue();                                // refill the slot the previous chunk occupied
+                const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
+                // Explicit software pipeline, fenced with sched_barrier(0) so hipcc keeps the order:
+                //   step t:  LDS read of fragment t+PF | MFMA t | a slice of the previous tile's epilogue
+                // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
+                constexpr int NF = SPB * 8, PF = 4;
+                v4i af[NF];
+                auto frag = [&](int t) {
+                    return *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
+                };
+#pragma unroll
+                for (int t = 0; t < PF && t < NF; t++) af[t] = frag(t);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NF; t++) {
+                    if (t + PF < NF) af[t + PF] = frag(t + PF);
+                    if (t & 1)
+                        acc1 = A::mfma(af[t], qf[ck * NF + t], acc1);
+                    else
+                        acc = A::mfma(af[t], qf[ck * NF + t], acc);
+                    if (ck == 0) {
+#pragma unroll
+                        for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, sv, best);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                norm_slot = c_slot;
+                if (++c_slot == NC) c_slot = 0;
+            }
+            epi_rest(sv, best);
+            // ---- hand this tile's results to the next iteration (its row scalars leave LDS now: the
+            // slot is refilled by the DMA issued after the next barrier)
+            {
+                const float *nl = (const float *)(normring + norm_slot * 1024 + wave * 256);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
+                    xh[4 * g4 + 0] = v.x;
+                    xh[4 * g4 + 1] = v.y;
+                    xh[4 * g4 + 2] = v.z;
+                    xh[4 * g4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; f16: within the error budget
+                prev_row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
+            }
+            if (MODE == 1) {
                 // flush checkpoint: uniform, because no wave appends between this barrier and its
                 // next epilogue
                 if ((tl % FLUSH_EVERY) == FLUSH_EVERY - 1) {
@@ -319,6 +351,13 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                     }
                 }
             }
+        }
+        {  // drain: the last tile's epilogue
+            float sv[16];
+            float best = COS ? -__builtin_inff() : __builtin_inff();
+#pragma unroll
+            for (int m = 0; m < EPI_STEPS; m++) epi_micro(m, sv, best);
+            epi_rest(sv, best);
         }
         wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
     }
