@@ -105,10 +105,11 @@ class Dist:
     def all_gather_np(self, a: np.ndarray) -> np.ndarray:
         import torch
 
-        t = torch.from_numpy(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1))
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.td.all_gather(outs, t)
-        return np.stack([o.numpy() for o in outs])
+        return np.stack([o.numpy().view(a.dtype).reshape(a.shape) for o in outs])
 
     def close(self):
         if self.td:
@@ -138,8 +139,7 @@ def main():
     metric = pvs.COSINE if args.metric == "cosine" else pvs.L2
     esz = 1 if dtype == pvs.I8 else 2
     N, D, B, K = args.rows, args.dim, args.batch, args.k
-    per = (N + world - 1) // world
-    r0, r1 = min(rank * per, N), min((rank + 1) * per, N)
+    r0, r1 = pvs.shard_range(N, world, rank)
     n_local = r1 - r0
     lib = pvs.lib()
 
@@ -210,10 +210,8 @@ def main():
         else:
             t = ix.search_device(q, L.F32, B, K, metric, oi, od, oc)
             ix.wait(t)
-            ids = dist.all_gather_np(oi.to_numpy(np.int64, (B, K)))
-            dd = dist.all_gather_np(od.to_numpy(np.float32, (B, K)))
-            cc = dist.all_gather_np(oc.to_numpy(np.uint32, (B,)))
-            return pvs.merge_topk(ids, dd, cc, K)
+            return pvs.merge_shard_pages(oi.to_numpy(np.int64, (B, K)), od.to_numpy(np.float32, (B, K)),
+                                         oc.to_numpy(np.uint32, (B,)), dist.all_gather_np, K)
         return None
 
     pending = []

@@ -10,4 +10,6 @@ from .index import DeviceBuffer, VectorIndex, absmax, device_count, quantize_int
 from .host import (aggregate, artifact_scale, embedding_from_npy_bytes, extract_embeddings, merge_topk,
                    resolve_vector_quant, row_number, rrf_fuse, scale_artifact, scale_from_absmax)
 
+from .sharded import TorchDistGather, merge_shard_pages, shard_range
+
 __all__ = [n for n in dir() if not n.startswith("_")]

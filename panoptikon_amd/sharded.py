@@ -1,0 +1,46 @@
+"""Row-sharded search across ranks: contiguous row ranges per rank,
+queries replicated, per-shard pages exchanged once and merged on every rank.
+
+The GPU data path is pvs_search_sharded (RCCL all-gather + device merge inside
+libpvs).  This module holds the rank arithmetic and the host-side exchange used
+when the pages are gathered by other means (gloo on CPU tests, or as the bench's
+fallback when RCCL cannot be initialised)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .host import merge_topk
+
+
+def shard_range(n_rows: int, world: int, rank: int):
+    """Rows [r0, r1) owned by `rank`: ceil(n/world) contiguous rows each, so that
+    global row id = r0 + local row and ids stay increasing across ranks."""
+    per = (n_rows + world - 1) // world
+    return min(rank * per, n_rows), min((rank + 1) * per, n_rows)
+
+
+class TorchDistGather:
+    """all_gather of small numpy arrays through torch.distributed (any backend that
+    moves CPU tensors, i.e. gloo)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.world = dist.get_world_size()
+
+    def __call__(self, a: np.ndarray) -> np.ndarray:
+        import torch
+
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1))  # raw bytes: gloo has no u32 / i64-safe dtypes for all
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.stack([o.numpy().view(a.dtype).reshape(a.shape) for o in outs])
+
+
+def merge_shard_pages(local_ids, local_dist, local_cnt, gather, k: int):
+    """Gathers every rank's page ([batch][k] ids / distances, [batch] counts) and merges
+    them under the shared ordering (distance asc, id asc, NaN last)."""
+    ids = gather(np.ascontiguousarray(local_ids, np.int64))
+    dist = gather(np.ascontiguousarray(local_dist, np.float32))
+    cnt = gather(np.ascontiguousarray(local_cnt, np.uint32))
+    return merge_topk(ids, dist, cnt, k)

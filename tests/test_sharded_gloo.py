@@ -1,0 +1,60 @@
+"""N > 1 path on CPU: two ranks over gloo.  Each rank owns a contiguous row shard;
+its local page comes from the oracle here (there is no GPU in this test), the
+exchange and merge are the package's own (torch.distributed all_gather + the C
+ABI's pvs_merge_topk) and the merged page must equal the oracle's page over the
+whole corpus."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    import oracle as orc
+    import panoptikon_amd as pvs
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, dim, batch, k = 3001, 64, 5, 17
+    rows = orc.synth_rows(123, 0, n, dim)
+    rows[5] = rows[2000]          # a cross-shard tie: id order must decide
+    rows[1700] = 0.0              # a NULL-distance row on rank 1
+    queries = orc.synth_rows(77, 0, batch, dim)
+    scale = orc.compute_int8_scale(rows)
+    codes, qcodes = orc.quantize_int8(rows, scale), orc.quantize_int8(queries, scale)
+    r0, r1 = pvs.shard_range(n, world, rank)
+    for metric in (orc.COSINE, orc.L2):
+        li, ld = orc.search(orc.I8, metric, codes[r0:r1], qcodes, k, ids=np.arange(r0, r1))
+        cnt = np.full(batch, li.shape[1], np.uint32)
+        pi = np.full((batch, k), -1, np.int64); pd = np.full((batch, k), np.nan, np.float32)
+        pi[:, : li.shape[1]] = li; pd[:, : ld.shape[1]] = ld
+        mi, md, mc = pvs.merge_shard_pages(pi, pd, cnt, pvs.TorchDistGather(dist), k)
+        ei, ed = orc.search(orc.I8, metric, codes, qcodes, k)
+        assert (mc == k).all()
+        assert np.array_equal(mi, ei), (rank, metric)
+        assert np.array_equal(md.view(np.uint32), ed.view(np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_two_rank_gloo_merge(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    import socket
+
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
