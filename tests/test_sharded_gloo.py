@@ -40,7 +40,8 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(md.view(np.uint32), ed.view(np.uint32))
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok")
+    sys.stdout.write("rank%d-ok\n" % rank)
+    sys.stdout.flush()
 """) % ROOT
 
 
@@ -57,4 +58,4 @@ def test_two_rank_gloo_merge(tmp_path):
            "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert "rank0-ok" in out.stdout and "rank1-ok" in out.stdout
