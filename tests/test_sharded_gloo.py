@@ -40,7 +40,7 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(md.view(np.uint32), ed.view(np.uint32))
     dist.barrier()
     dist.destroy_process_group()
-    sys.stdout.write("rank" + str(rank) + "-ok\n")
+    sys.stdout.write("rank" + str(rank) + "-ok" + chr(10))
     sys.stdout.flush()
 """) % ROOT
 
