@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=1_000_000)
+    ap.add_argument("--force-comm", action="store_true", help="use the RCCL shard-merge path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -68,11 +69,12 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.td = None
-        if self.world > 1:
+        if self.world > 1 or "--force-comm" in sys.argv:
             import torch  # noqa: F401  (plumbing only)
             import torch.distributed as td
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
             td.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
             self.td = td
         if gpus != self.world and self.rank == 0:
@@ -185,7 +187,7 @@ def main():
 
     comm = None
     gather_mode = "single-gpu"
-    if world > 1:
+    if world > 1 or args.force_comm:
         try:
             idb = None
             if rank == 0:
@@ -227,7 +229,7 @@ def main():
         while pending:
             ix.wait(pending.pop(0))
 
-    step = step_single if world == 1 else step_sharded
+    step = step_single if (world == 1 and not args.force_comm) else step_sharded
 
     # ----------------------------------------------------------------- timing
     for i in range(args.warmup):
