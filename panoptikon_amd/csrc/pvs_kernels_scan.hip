@@ -66,7 +66,9 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------- k-th select
-// 4-pass MSB radix select on order-preserving keys.  One workgroup per query.
+// 4-pass MSB radix select on order-preserving u32 keys, one workgroup (256 threads) per query.
+// (Measured alternatives on MI355X: a bitonic sort in LDS was 4x slower, wave-aggregated LDS
+// atomics 1.7x slower; what matters is keeping the keys on chip across the four passes.)
 template <typename KeyAt>
 __device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hist, uint32_t *s_sel, KeyAt key_at) {
     const int tid = threadIdx.x;
@@ -80,14 +82,21 @@ __device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hi
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t cum = 0, b = 0;
-            for (; b < 256; b++) {
-                if (cum + hist[b] >= kk) break;
-                cum += hist[b];
-            }
-            s_sel[0] = b;          // 256 => fewer than kk keys match
-            s_sel[1] = kk - cum;
+        // inclusive prefix over the 256 bins (Hillis-Steele in LDS), then the bin holding rank kk
+        uint32_t v = hist[tid];
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t add = tid >= off ? hist[tid - off] : 0u;
+            __syncthreads();
+            v += add;
+            hist[tid] = v;
+            __syncthreads();
+        }
+        if (tid == 0) s_sel[0] = 256;  // 256 => fewer than kk keys match
+        __syncthreads();
+        const uint32_t before = tid ? hist[tid - 1] : 0u;
+        if (before < kk && v >= kk) {
+            s_sel[0] = (uint32_t)tid;
+            s_sel[1] = kk - before;
         }
         __syncthreads();
         const uint32_t b = s_sel[0];
@@ -110,7 +119,59 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
     }
     const float *v = vals + (size_t)q * per_query;
     uint32_t key = 0xffffffffu;
-    if (per_query >= k) key = radix_kth(per_query, k, hist, s_sel, [&](uint32_t i) { return f32_sort_key(v[i]); });
+    if (per_query >= k) {
+        if (per_query <= 8192) {
+            // keys live in registers across the four passes (the loads are the latency that matters)
+            uint32_t kreg[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const uint32_t i = threadIdx.x + 256u * j;
+                kreg[j] = i < per_query ? f32_sort_key(v[i]) : 0xffffffffu;
+            }
+            const int tid = threadIdx.x;
+            uint32_t prefix = 0, mask = 0, kk = k;
+            bool ok = true;
+            for (int pass = 0; pass < 4 && ok; pass++) {
+                const int shift = 24 - 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t i = threadIdx.x + 256u * j;
+                    if (i < per_query && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                uint32_t val = hist[tid];
+                for (int off = 1; off < 256; off <<= 1) {
+                    const uint32_t add = tid >= off ? hist[tid - off] : 0u;
+                    __syncthreads();
+                    val += add;
+                    hist[tid] = val;
+                    __syncthreads();
+                }
+                if (tid == 0) s_sel[0] = 256;
+                __syncthreads();
+                const uint32_t before = tid ? hist[tid - 1] : 0u;
+                if (before < kk && val >= kk) {
+                    s_sel[0] = (uint32_t)tid;
+                    s_sel[1] = kk - before;
+                }
+                __syncthreads();
+                const uint32_t b = s_sel[0];
+                if (b >= 256) {
+                    ok = false;
+                } else {
+                    kk = s_sel[1];
+                    prefix |= b << shift;
+                    mask |= 0xffu << shift;
+                }
+                __syncthreads();
+            }
+            key = ok ? prefix : 0xffffffffu;
+        } else {
+            key = radix_kth(per_query, k, hist, s_sel, [&](uint32_t i) { return f32_sort_key(v[i]); });
+        }
+    }
     if (threadIdx.x == 0) {
         float t = f32_from_sort_key(key);
         out[q] = (t != t) ? __builtin_inff() : t;  // too few finite minima: admit everything
@@ -145,6 +206,16 @@ constexpr int FIN_LDS = PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
 __device__ static inline float cand_err(const FinK &a, const QInfo &qi, float aa) {
     return a.metric == PVS_COSINE ? qi.eA : qi.eA + qi.eR * aa;
 }
+// scan key of a candidate.  int8 candidates carry the exact integer dot, f16 ones the key itself.
+template <int DT>
+__device__ static inline float cand_key(const FinK &a, const QInfo &qi, uint32_t payload, float aa) {
+    if constexpr (DT == PVS_I8) {
+        const float d = (float)(int)payload;
+        return a.metric == PVS_COSINE ? -d * __frcp_rn(__fsqrt_rn(aa)) : aa + (qi.bb - 2.0f * d);
+    } else {
+        return __builtin_bit_cast(float, payload);
+    }
+}
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_finalize(FinK a) {
@@ -172,8 +243,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     const uint2 *cand = a.cand + (size_t)q * a.cand_cap;
     for (uint32_t i = tid; i < cnt; i += 256) {
         const uint2 c = cand[i];
-        const float key = __builtin_bit_cast(float, c.y);
-        s_ub[i] = f32_sort_key(key + cand_err(a, qi, a.norm2[c.x]));
+        const float aa = a.norm2[c.x];
+        s_ub[i] = f32_sort_key(cand_key<DT>(a, qi, c.y, aa) + cand_err(a, qi, aa));
     }
     if (tid == 0) s_misc[0] = 0;
     __syncthreads();
@@ -184,10 +255,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     // survivors: lower bound <= k-th smallest upper bound
     for (uint32_t i = tid; i < cnt; i += 256) {
         const uint2 c = cand[i];
-        const float key = __builtin_bit_cast(float, c.y);
-        if (key - cand_err(a, qi, a.norm2[c.x]) <= kappa) {
+        const float aa = a.norm2[c.x];
+        if (cand_key<DT>(a, qi, c.y, aa) - cand_err(a, qi, aa) <= kappa) {
             const uint32_t p = atomicAdd(&s_misc[0], 1u);
-            if (p < PVS_SURV_CAP) s_surv[p] = c.x;
+            if (p < PVS_SURV_CAP) s_surv[p] = i;  // candidate slot
         }
     }
     __syncthreads();
@@ -206,8 +277,31 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     for (uint32_t i = tid; i < m2; i += 256) {
         unsigned long long v = ~0ull;
         if (i < m) {
-            const uint32_t row = s_surv[i];
-            const float d = exact_distance<DT>(a.rows + (size_t)row * a.stride, qe, (int)a.dim, a.metric, a.norm2[row], qi.bb);
+            const uint2 c = cand[s_surv[i]];
+            const uint32_t row = c.x;
+            const float aa = a.norm2[row];
+            float d;
+            bool closed = false;
+            if constexpr (DT == PVS_I8) {
+                // The reference accumulates integer-valued f32 terms; while every partial sum stays
+                // below 2^24 the result is a pure function of the exact integer sums (oracle:
+                // orc_i8_*_from_sums), which the MFMA already produced.  Otherwise recompute in order.
+                const int dot = (int)c.y;
+                const float lim = 16777216.0f;
+                if (a.metric == PVS_COSINE) {
+                    if (aa < lim && qi.bb < lim) {
+                        d = ref_cosine_finish((float)dot, aa, qi.bb);
+                        closed = true;
+                    }
+                } else {
+                    const double ss = (double)aa + (double)qi.bb - 2.0 * (double)dot;
+                    if (aa < lim && qi.bb < lim && ss < (double)lim) {
+                        d = ref_l2_finish((float)ss);
+                        closed = true;
+                    }
+                }
+            }
+            if (!closed) d = exact_distance<DT>(a.rows + (size_t)row * a.stride, qe, (int)a.dim, a.metric, aa, qi.bb);
             v = ((unsigned long long)f32_sort_key(d) << 32) | row;
         }
         s_sort[i] = v;

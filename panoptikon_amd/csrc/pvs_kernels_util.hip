@@ -292,13 +292,43 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         }
     }
     __syncthreads();
+    // the reference's bMag: sequential f32 sum of squares of what it scores.  int8 codes: integer
+    // terms, exact in any order while < 2^24 -> parallel integer sum; otherwise (and for floats)
+    // one lane walks the vector in order, from a coalesced LDS copy.
+    __shared__ float s_q[4096];
+    __shared__ long long s_isum[4];
+    float bb = 0.f;
+    bool have_bb = false;
+    if (index_dtype == PVS_I8) {
+        const int8_t *qe = (const int8_t *)qexact + (uint64_t)b * dim;
+        long long part = 0;
+        for (uint32_t i = tid; i < dim; i += 256) part += (long long)qe[i] * qe[i];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if ((tid & 63) == 0) s_isum[tid >> 6] = part;
+        __syncthreads();
+        const long long tot = s_isum[0] + s_isum[1] + s_isum[2] + s_isum[3];
+        if (tot < 16777216) {
+            bb = (float)tot;
+            have_bb = true;
+        }
+    } else if (dim <= 4096) {
+        const float *qe = (const float *)qexact + (uint64_t)b * dim;
+        for (uint32_t i = tid; i < dim; i += 256) s_q[i] = qe[i];
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (uint32_t i = 0; i < dim; i++) acc = __fadd_rn(acc, __fmul_rn(s_q[i], s_q[i]));
+            bb = acc;
+        }
+        have_bb = true;
+    }
     if (tid == 0) {
-        // the reference's bMag: sequential f32 sum of squares of what it scores
-        float bb;
-        if (index_dtype == PVS_I8)
-            bb = seq_sumsq<PVS_I8>((const uint8_t *)((const int8_t *)qexact + (uint64_t)b * dim), (int)dim);
-        else
-            bb = seq_sumsq<PVS_F32>((const uint8_t *)((const float *)qexact + (uint64_t)b * dim), (int)dim);
+        if (!have_bb) {
+            if (index_dtype == PVS_I8)
+                bb = seq_sumsq<PVS_I8>((const uint8_t *)((const int8_t *)qexact + (uint64_t)b * dim), (int)dim);
+            else
+                bb = seq_sumsq<PVS_F32>((const uint8_t *)((const float *)qexact + (uint64_t)b * dim), (int)dim);
+        }
         QInfo qi;
         qi.bb = bb;
         qi.qn = sqrtf(bb);

@@ -252,17 +252,23 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                     for (int r = 0; r < 16; r++) {
                         const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
                         if (p) {
-                            const float key = COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r];
+                            // payload: int8 -> the EXACT integer dot (pass C needs no row re-read);
+                            //          f16  -> the scan key
+                            uint32_t payload;
+                            if constexpr (DT == PVS_I8)
+                                payload = (uint32_t)hold[r];
+                            else
+                                payload = __builtin_bit_cast(uint32_t, COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r]);
                             const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
                             const uint32_t pos = atomicAdd(st_cnt, 1u);
                             if (pos < (uint32_t)LCAP) {
                                 st_row[pos] = row;
-                                st_key[pos] = __builtin_bit_cast(uint32_t, key);
+                                st_key[pos] = payload;
                                 st_q[pos] = (uint32_t)myq;
                             } else {  // staging full (very loose threshold): go to HBM directly
                                 const uint32_t gp = atomicAdd(&a.cand_cnt[myq], 1u);
                                 if (gp < a.cand_cap)
-                                    a.cand[(size_t)myq * a.cand_cap + gp] = make_uint2(row, __builtin_bit_cast(uint32_t, key));
+                                    a.cand[(size_t)myq * a.cand_cap + gp] = make_uint2(row, payload);
                                 direct = true;
                             }
                         }
