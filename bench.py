@@ -204,19 +204,24 @@ def main():
             log(f"in-library RCCL unavailable ({e}); falling back to a host gather over gloo")
             gather_mode = "gloo-host-gather"
 
+    pending = []
+
     def step_sharded(i):
         q = qbufs[i % NQB]
-        oi, od, oc = outs[0]
-        if comm is not None:
-            L.check(lib.pvs_search_sharded(ix._h, comm, q.ptr, L.F32, B, K, metric, oi.ptr, od.ptr, oc.ptr))
+        if comm is not None:  # stream-ordered: search -> RCCL all-gather -> merge, `slots` batches in flight
+            oi, od, oc = outs[i % slots]
+            if len(pending) >= slots:
+                ix.wait(pending.pop(0))
+            t = L.C.c_uint32()
+            L.check(lib.pvs_search_sharded_async(ix._h, comm, q.ptr, L.F32, B, K, metric, oi.ptr, od.ptr, oc.ptr, L.C.byref(t)))
+            pending.append(int(t.value))
         else:
+            oi, od, oc = outs[0]
             t = ix.search_device(q, L.F32, B, K, metric, oi, od, oc)
             ix.wait(t)
             return pvs.merge_shard_pages(oi.to_numpy(np.int64, (B, K)), od.to_numpy(np.float32, (B, K)),
                                          oc.to_numpy(np.uint32, (B,)), dist.all_gather_np, K)
         return None
-
-    pending = []
 
     def step_single(i):
         q = qbufs[i % NQB]
@@ -284,7 +289,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} (BASELINE configs[2])",
                    "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
-                   "parallelism": f"row-shard x{world}", "exchange": gather_mode, "inflight": slots if world == 1 else 1},
+                   "parallelism": f"row-shard x{world}", "exchange": gather_mode, "inflight": slots if (world == 1 or comm is not None) else 1},
         "roofline": roofline,
         "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries)},
     }

@@ -263,6 +263,13 @@ void pvs_comm_destroy(pvs_comm *comm);
 pvs_status pvs_search_sharded(pvs_index *idx, pvs_comm *comm, const void *d_queries,
                               pvs_dtype query_dtype, uint32_t batch, uint32_t k, pvs_metric metric,
                               int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+/* Stream-ordered form: local search, all-gather and merge are enqueued on one of the index's
+ * streams with no host synchronisation in between; pvs_wait(idx, ticket) completes it (and,
+ * when any shard handed a query to the dense path, redoes the exchange for the batch). */
+pvs_status pvs_search_sharded_async(pvs_index *idx, pvs_comm *comm, const void *d_queries,
+                                    pvs_dtype query_dtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                    int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                                    uint32_t *out_ticket);
 /* k-way merge of `world` per-shard pages (host buffers, [world][batch][k] with
  * counts [world][batch]) under the shared ordering; the same routine the device
  * merge kernel implements, exposed for hosts that gather by other means. */

@@ -92,6 +92,7 @@ SYMBOLS = {
     "pvs_comm_create": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
     "pvs_comm_destroy": (None, [_vp]),
     "pvs_search_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_search_sharded_async": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_merge_topk": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_device_malloc": (_i32, [_i32, _sz, C.POINTER(_vp)]),
     "pvs_device_free": (_i32, [_i32, _vp]),

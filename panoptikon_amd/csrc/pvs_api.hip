@@ -100,7 +100,24 @@ struct SearchCtx {
     float *p_out_dist = nullptr;
     uint32_t *p_out_count = nullptr;
     bool p_fast = false;
+    // sharded search: this rank's page, the gathered pages and flags
+    pvs_comm *p_comm = nullptr;
+    int64_t *d_loc_ids = nullptr, *d_all_ids = nullptr;
+    float *d_loc_dist = nullptr, *d_all_dist = nullptr;
+    uint32_t *d_loc_cnt = nullptr, *d_all_cnt = nullptr, *d_all_flags = nullptr, *h_all_flags = nullptr;
+    uint64_t sh_elems = 0;
+    uint32_t sh_batch = 0, sh_world = 0;
+    int64_t *p_final_ids = nullptr;
+    float *p_final_dist = nullptr;
+    uint32_t *p_final_count = nullptr;
 };
+
+struct pvs_comm;
+int pvs_comm_world_(pvs_comm *c);
+int pvs_comm_device_(pvs_comm *c);
+pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *dist, const uint32_t *cnt, const uint32_t *flags,
+                                  int64_t *all_ids, float *all_dist, uint32_t *all_cnt, uint32_t *all_flags, uint64_t elems,
+                                  uint32_t batch, hipStream_t s);
 
 constexpr uint32_t GMAX = 256 * 4 * 32;  // group minima per query (pass A grid <= 256)
 constexpr uint32_t NCTX = 4;
@@ -192,6 +209,14 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_out_dist);
     hipFree(c.d_out_count);
     pvs_dense_release(c.dense);
+    hipFree(c.d_loc_ids);
+    hipFree(c.d_all_ids);
+    hipFree(c.d_loc_dist);
+    hipFree(c.d_all_dist);
+    hipFree(c.d_loc_cnt);
+    hipFree(c.d_all_cnt);
+    hipFree(c.d_all_flags);
+    if (c.h_all_flags) hipHostFree(c.h_all_flags);
     if (c.stream) hipStreamDestroy(c.stream);
     c = SearchCtx();
 }
@@ -546,6 +571,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
     *used_fast = fast;
     if (!fast && ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "filter-scan path not available for this index / k");
     if (ix->n == 0) {
+        HIP_TRY(hipMemsetAsync(c.d_need_dense, 0, 4 * (size_t)batch, c.stream));
         HIP_TRY(hipMemsetAsync(d_out_count, 0, 4 * (size_t)batch, c.stream));
         HIP_TRY(hipMemsetAsync(d_out_ids, 0xff, 8 * (size_t)batch * k, c.stream));
         HIP_TRY(pvs_launch_fill_f32(d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c.stream));
@@ -757,11 +783,119 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     if (st == PVS_OK) spans_collect(ix, *c);
-    if (st == PVS_OK && c->p_fast && ix->n)
+    if (st == PVS_OK && c->p_comm) {
+        // every rank sees the same gathered flags, so they all agree on whether to redo
+        bool redo = false;
+        for (uint64_t i = 0; i < (uint64_t)c->sh_world * c->p_batch; i++) redo |= c->h_all_flags[i] != 0;
+        if (!redo) {
+            ix->fast_queries += c->p_fast ? c->p_batch : 0;
+        } else {
+            if (c->p_fast && ix->n)
+                st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->d_loc_ids, c->d_loc_dist,
+                                      c->d_loc_cnt);
+            if (st == PVS_OK) {
+                hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, c->stream);
+                if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
+            }
+            if (st == PVS_OK)
+                st = pvs_comm_gather_pages_(c->p_comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids,
+                                            c->d_all_dist, c->d_all_cnt, c->d_all_flags, (uint64_t)c->p_batch * c->p_k, c->p_batch,
+                                            c->stream);
+            if (st == PVS_OK) {
+                hipError_t e2 = pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, c->sh_world, c->p_batch, c->p_k,
+                                                 c->p_final_ids, c->p_final_dist, c->p_final_count, c->stream);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+                if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "sharded redo: %s", hipGetErrorString(e2));
+            }
+        }
+        c->p_comm = nullptr;
+    } else if (st == PVS_OK && c->p_fast && ix->n) {
         st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->p_out_ids, c->p_out_dist,
                               c->p_out_count);
+    }
     ctx_done(ix, c);
     return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, const void *d_queries, pvs_dtype qdtype, uint32_t batch,
+                                               uint32_t k, pvs_metric metric, int64_t *d_out_ids, float *d_out_dist,
+                                               uint32_t *d_out_count, uint32_t *out_ticket) {
+    PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
+    if (!comm || !d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    if (pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint32_t world = (uint32_t)pvs_comm_world_(comm);
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
+        const uint64_t elems = (uint64_t)batch * k;
+        if (elems > c->sh_elems || batch > c->sh_batch || world != c->sh_world) {
+            hipFree(c->d_loc_ids);
+            hipFree(c->d_all_ids);
+            hipFree(c->d_loc_dist);
+            hipFree(c->d_all_dist);
+            hipFree(c->d_loc_cnt);
+            hipFree(c->d_all_cnt);
+            hipFree(c->d_all_flags);
+            if (c->h_all_flags) hipHostFree(c->h_all_flags);
+            c->d_loc_ids = c->d_all_ids = nullptr;
+            c->d_loc_dist = c->d_all_dist = nullptr;
+            c->d_loc_cnt = c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
+            c->sh_elems = 0;
+            HIP_TRY(hipMalloc((void **)&c->d_loc_ids, elems * 8));
+            HIP_TRY(hipMalloc((void **)&c->d_loc_dist, elems * 4));
+            HIP_TRY(hipMalloc((void **)&c->d_loc_cnt, (size_t)batch * 4));
+            HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_flags, (size_t)batch * 4 * world));
+            HIP_TRY(hipHostMalloc((void **)&c->h_all_flags, (size_t)batch * 4 * world, hipHostMallocDefault));
+            c->sh_elems = elems;
+            c->sh_batch = batch;
+            c->sh_world = world;
+        }
+        bool fast = false;
+        // 1. this shard's page (row ids in the index are global ids)
+        PVS_TRY(search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &fast));
+        // 2. one grouped all-gather over xGMI, 3. merge on every rank — same stream, no host sync
+        PVS_TRY(pvs_comm_gather_pages_(comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids, c->d_all_dist,
+                                       c->d_all_cnt, c->d_all_flags, elems, batch, c->stream));
+        HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, c->stream));
+        c->pending = true;
+        c->p_comm = comm;
+        c->p_queries = d_queries;
+        c->p_qdtype = qdtype;
+        c->p_metric = metric;
+        c->p_batch = batch;
+        c->p_k = k;
+        c->p_out_ids = c->d_loc_ids;
+        c->p_out_dist = c->d_loc_dist;
+        c->p_out_count = c->d_loc_cnt;
+        c->p_final_ids = d_out_ids;
+        c->p_final_dist = d_out_dist;
+        c->p_final_count = d_out_count;
+        c->p_fast = fast;
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        ctx_done(ix, c);
+        return st;
+    }
+    ix->searches++;
+    *out_ticket = t;
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_search_sharded(pvs_index *ix, pvs_comm *comm, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                         pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    uint32_t t = 0;
+    PVS_TRY(pvs_search_sharded_async(ix, comm, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &t));
+    return pvs_wait(ix, t);
 }
 
 PVS_EXPORT pvs_status pvs_sync(pvs_index *ix) {

@@ -12,8 +12,6 @@
 
 #include "pvs_kernels.hpp"
 
-pvs_status pvs_index_internal_(pvs_index *ix, int *device);
-
 namespace {
 struct Rccl {
     void *lib = nullptr;
@@ -65,12 +63,6 @@ pvs_status load_rccl() {
 struct pvs_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
-    hipStream_t stream = nullptr;
-    int64_t *d_loc_ids = nullptr, *d_all_ids = nullptr;
-    float *d_loc_dist = nullptr, *d_all_dist = nullptr;
-    uint32_t *d_loc_cnt = nullptr, *d_all_cnt = nullptr;
-    uint64_t cap_elems = 0;
-    uint32_t cap_batch = 0;
 };
 
 static_assert(sizeof(ncclUniqueId) == PVS_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -105,73 +97,30 @@ PVS_EXPORT pvs_status pvs_comm_create(const uint8_t id[PVS_UNIQUE_ID_BYTES], int
         delete c;
         return pvs_fail(PVS_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        g_rccl.CommDestroy(c->comm);
-        delete c;
-        return pvs_fail(PVS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
-    }
     *out = c;
     return PVS_OK;
-}
-
-static void comm_free_buffers(pvs_comm *c) {
-    hipFree(c->d_loc_ids);
-    hipFree(c->d_all_ids);
-    hipFree(c->d_loc_dist);
-    hipFree(c->d_all_dist);
-    hipFree(c->d_loc_cnt);
-    hipFree(c->d_all_cnt);
-    c->d_loc_ids = c->d_all_ids = nullptr;
-    c->d_loc_dist = c->d_all_dist = nullptr;
-    c->d_loc_cnt = c->d_all_cnt = nullptr;
-    c->cap_elems = 0;
-    c->cap_batch = 0;
 }
 
 PVS_EXPORT void pvs_comm_destroy(pvs_comm *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    comm_free_buffers(c);
+    (void)hipDeviceSynchronize();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
-PVS_EXPORT pvs_status pvs_search_sharded(pvs_index *ix, pvs_comm *c, const void *d_queries, pvs_dtype qdtype, uint32_t batch,
-                                         uint32_t k, pvs_metric metric, int64_t *d_out_ids, float *d_out_dist,
-                                         uint32_t *d_out_count) {
-    if (!ix || !c) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
-    int dev = 0;
-    PVS_TRY(pvs_index_internal_(ix, &dev));
-    if (dev != c->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
-    HIP_TRY(hipSetDevice(dev));
-    const uint64_t elems = (uint64_t)batch * k;
-    if (elems > c->cap_elems || batch > c->cap_batch) {
-        comm_free_buffers(c);
-        HIP_TRY(hipMalloc((void **)&c->d_loc_ids, elems * 8));
-        HIP_TRY(hipMalloc((void **)&c->d_loc_dist, elems * 4));
-        HIP_TRY(hipMalloc((void **)&c->d_loc_cnt, (size_t)batch * 4));
-        HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * c->world));
-        HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * c->world));
-        HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * c->world));
-        c->cap_elems = elems;
-        c->cap_batch = batch;
-    }
-    // 1. this shard's page (row ids in the index are global ids)
-    uint32_t ticket = 0;
-    PVS_TRY(pvs_search_device(ix, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &ticket));
-    PVS_TRY(pvs_wait(ix, ticket));
-    // 2. one grouped all-gather of (ids, distances, counts) over xGMI
+// ---- internal interface used by pvs_api.hip (stream-ordered sharded search)
+int pvs_comm_world_(pvs_comm *c) { return c->world; }
+int pvs_comm_device_(pvs_comm *c) { return c->device; }
+// one grouped all-gather of (ids i64, dist f32, counts u32, flags u32) on `s`
+pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *dist, const uint32_t *cnt, const uint32_t *flags,
+                                  int64_t *all_ids, float *all_dist, uint32_t *all_cnt, uint32_t *all_flags, uint64_t elems,
+                                  uint32_t batch, hipStream_t s) {
     NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllGather(c->d_loc_ids, c->d_all_ids, elems, ncclInt64, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllGather(c->d_loc_dist, c->d_all_dist, elems, ncclFloat32, c->comm, c->stream));
-    NCCL_TRY(g_rccl.AllGather(c->d_loc_cnt, c->d_all_cnt, batch, ncclUint32, c->comm, c->stream));
+    NCCL_TRY(g_rccl.AllGather(ids, all_ids, elems, ncclInt64, c->comm, s));
+    NCCL_TRY(g_rccl.AllGather(dist, all_dist, elems, ncclFloat32, c->comm, s));
+    NCCL_TRY(g_rccl.AllGather(cnt, all_cnt, batch, ncclUint32, c->comm, s));
+    NCCL_TRY(g_rccl.AllGather(flags, all_flags, batch, ncclUint32, c->comm, s));
     NCCL_TRY(g_rccl.GroupEnd());
-    // 3. merge on every rank
-    HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, (uint32_t)c->world, batch, k, d_out_ids, d_out_dist,
-                             d_out_count, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return PVS_OK;
 }
