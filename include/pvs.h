@@ -277,6 +277,12 @@ pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t 
                           uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
                           float *out_dist, uint32_t *out_count);
 
+/* The device form of pvs_merge_topk (the kernel pvs_search_sharded runs after the all-gather):
+ * every pointer is an HBM buffer on `device`; synchronous. */
+pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist,
+                                 const uint32_t *d_counts, uint32_t world, uint32_t batch, uint32_t k,
+                                 int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+
 /* ------------------------------------------------- device memory + synthetic */
 pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out);
 pvs_status pvs_device_free(int32_t device, void *ptr);

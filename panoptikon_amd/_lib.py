@@ -94,6 +94,7 @@ SYMBOLS = {
     "pvs_search_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
     "pvs_search_sharded_async": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_merge_topk": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_merge_topk_device": (_i32, [_i32, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_device_malloc": (_i32, [_i32, _sz, C.POINTER(_vp)]),
     "pvs_device_free": (_i32, [_i32, _vp]),
     "pvs_memcpy": (_i32, [_vp, _vp, _sz, _i32]),

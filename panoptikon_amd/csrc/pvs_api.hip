@@ -997,6 +997,17 @@ PVS_EXPORT pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, i
     return st;
 }
 
+PVS_EXPORT pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist, const uint32_t *d_counts,
+                                            uint32_t world, uint32_t batch, uint32_t k, int64_t *d_out_ids, float *d_out_dist,
+                                            uint32_t *d_out_count) {
+    if (!d_ids || !d_dist || !d_counts || !d_out_ids || !d_out_dist || !d_out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (world == 0 || batch == 0 || k == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty merge");
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(pvs_launch_merge(d_ids, d_dist, d_counts, world, batch, k, d_out_ids, d_out_dist, d_out_count, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return PVS_OK;
+}
+
 // ------------------------------------------------ device memory + synthetic
 PVS_EXPORT pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out) {
     if (!out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");

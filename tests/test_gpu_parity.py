@@ -236,3 +236,52 @@ def test_row_ids_groups_and_errors(pvs):
     gi, gd, gc = i8.search(q, 5)  # empty index
     assert gc.tolist() == [0, 0] and (gi == -1).all()
     i8.close()
+
+
+def test_device_merge_and_sharded_search(pvs):
+    """The N>1 data path on one GPU: (a) the device merge kernel against the host merge and the
+    oracle on synthetic multi-shard pages with ties and NULLs; (b) pvs_search_sharded through a
+    1-rank RCCL communicator equals pvs_search."""
+    import ctypes as C
+
+    from panoptikon_amd import _lib as L
+
+    rng = np.random.default_rng(9)
+    world, batch, k = 8, 33, 100
+    ids = np.full((world, batch, k), -1, np.int64)
+    dist = np.full((world, batch, k), np.nan, np.float32)
+    cnt = np.zeros((world, batch), np.uint32)
+    for w in range(world):
+        for q in range(batch):
+            c = int(rng.integers(0, k + 1))
+            d = np.round(rng.random(c), 2).astype(np.float32)
+            if c > 3:
+                d[-2:] = np.nan
+            i = np.sort(rng.choice(50_000, c, replace=False)) + w * 50_000
+            pi, pd = orc.topk(d, k, ids=i)
+            ids[w, q, : len(pi)], dist[w, q, : len(pi)], cnt[w, q] = pi, pd, len(pi)
+    hi, hd, hc = pvs.merge_topk(ids, dist, cnt, k)
+    d_ids, d_dist, d_cnt = (pvs.DeviceBuffer.from_numpy(a) for a in (ids, dist, cnt))
+    o_ids, o_dist, o_cnt = pvs.DeviceBuffer(batch * k * 8), pvs.DeviceBuffer(batch * k * 4), pvs.DeviceBuffer(batch * 4)
+    L.check(pvs.lib().pvs_merge_topk_device(-1, d_ids.ptr, d_dist.ptr, d_cnt.ptr, world, batch, k, o_ids.ptr, o_dist.ptr, o_cnt.ptr))
+    gi, gd, gc = o_ids.to_numpy(np.int64, (batch, k)), o_dist.to_numpy(np.float32, (batch, k)), o_cnt.to_numpy(np.uint32, (batch,))
+    assert np.array_equal(gc, hc) and np.array_equal(gi, hi)
+    assert np.array_equal(np.isnan(gd), np.isnan(hd)) and np.array_equal(gd[~np.isnan(gd)], hd[~np.isnan(hd)])
+
+    rows = unit_rows(31, 9000, 768)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    queries = orc.synth_rows(0x5EED0000, 0, 40, 768)
+    exp = ix.search(queries, 50, pvs.COSINE)
+    uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+    L.check(pvs.lib().pvs_comm_unique_id(uid))
+    comm = C.c_void_p()
+    L.check(pvs.lib().pvs_comm_create(uid, 1, 0, -1, C.byref(comm)))
+    dq = pvs.DeviceBuffer.from_numpy(queries)
+    oi, od, oc = pvs.DeviceBuffer(40 * 50 * 8), pvs.DeviceBuffer(40 * 50 * 4), pvs.DeviceBuffer(40 * 4)
+    L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dq.ptr, L.F32, 40, 50, pvs.COSINE, oi.ptr, od.ptr, oc.ptr))
+    assert np.array_equal(oi.to_numpy(np.int64, (40, 50)), exp[0])
+    assert np.array_equal(od.to_numpy(np.float32, (40, 50)).view(np.uint32), exp[1].view(np.uint32))
+    assert np.array_equal(oc.to_numpy(np.uint32, (40,)), exp[2])
+    pvs.lib().pvs_comm_destroy(comm)
+    ix.close()
