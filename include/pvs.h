@@ -186,6 +186,31 @@ pvs_status pvs_index_set_path(pvs_index *idx, uint32_t path);
 pvs_status pvs_score_all(pvs_index *idx, const void *query, pvs_dtype query_dtype, pvs_metric metric,
                          float *out_dist, pvs_space out_space);
 
+/* Dense exact distances for a batch: out[row * batch + q] = the reference's
+ * vec_distance_*(row payload, query q) — the `d` column of dist_{cte} for `batch`
+ * queries at once (query-minor layout).  int8 indexes run on the matrix cores
+ * (exact closed form of the integer sums); float indexes score in order. */
+pvs_status pvs_score_batch(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch,
+                           pvs_metric metric, float *out_dist, pvs_space out_space);
+
+/* Per-item results, on the device: score every row, aggregate per group
+ * (GROUP BY file_id: MIN / MAX / AVG, or SUM(d*w)/SUM(w) when row_weights != NULL —
+ * filters/exact.rs:67-80), rank the groups (value asc, group id asc, NULL last) and
+ * return page 1 of size k.  Groups are the group_ids given to pvs_index_add (identity
+ * when none were given).  out_groups/out_values: [batch][k] host buffers; values are the
+ * f64 SQLite would produce (Kahan-Babuska-Neumaier sums in row order). */
+pvs_status pvs_search_groups(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch,
+                             uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights,
+                             int64_t *out_groups, double *out_values, uint32_t *out_count);
+
+/* similar_to (filters/item_similarity.rs:432-581): the target item's stored vectors
+ * (rows named by their row ids) against every other row; per group aggregate over the
+ * (target vector x group row) fan-out; the target's own rows are excluded
+ * (`other.sha256 != target`).  AVG is the reference's default aggregation. */
+pvs_status pvs_similar_to(pvs_index *idx, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
+                          pvs_metric metric, pvs_agg agg, int64_t *out_groups, double *out_values,
+                          uint32_t *out_count);
+
 /* Per-group aggregate of per-row distances (GROUP BY file_id; MIN/MAX/AVG, or
  * SUM(d*w)/SUM(w) when weights != NULL — `agg` is ignored then, exact.rs:67-80).
  * dist / weights / group_ids: [n] host arrays, group_ids non-decreasing.

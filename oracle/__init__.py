@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
         L.orc_search.argtypes = [i32, i32, vp, sz, sz, vp, i64p, u32, vp, vp, i32]
         L.orc_aggregate.restype = sz
         L.orc_aggregate.argtypes = [vp, vp, vp, sz, i32, vp, vp]
+        L.orc_aggregate_fanout.restype = sz
+        L.orc_aggregate_fanout.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
         L.orc_row_number.argtypes = [vp, vp, sz, vp]
         L.orc_rrf_score.restype = d
         L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
@@ -220,6 +222,43 @@ def aggregate(dist, group, agg: int, w=None):
     ov = np.empty(max(dist.size, 1), np.float64)
     g = lib().orc_aggregate(_p(dist), _p(w_a), _p(group), dist.size, agg, _p(og), _p(ov))
     return og[:g].copy(), ov[:g].copy()
+
+
+def _rank_groups(groups, values, k):
+    """(value asc, group id asc), NaN (NULL) last -> first k."""
+    ranks = row_number(values, groups)
+    order = np.argsort(ranks)[:k]
+    return groups[order], values[order]
+
+
+def search_groups(dtype: int, metric: int, corpus, query, group_ids, agg: int, k: int, weights=None):
+    """One query: score all rows, GROUP BY group id (rows of a group in row order), aggregate, rank."""
+    d = score_all(dtype, metric, corpus, query)
+    grp = _c(group_ids, np.int64)
+    order = np.argsort(grp, kind="stable")
+    w = None if weights is None else _c(weights, np.float32)[order]
+    g, v = aggregate(d[order], grp[order], agg, w=w)
+    return _rank_groups(g, v, k)
+
+
+def similar_to(dtype: int, metric: int, corpus, target_rows, group_ids, agg: int, k: int):
+    """filters/item_similarity.rs: target vectors x every other row, aggregate per group, rank."""
+    c = _corpus(dtype, corpus)
+    targets = list(target_rows)
+    cols = []
+    for t in targets:
+        q = c[t].astype(np.float32) if dtype == F16 else c[t]
+        cols.append(score_all(dtype, metric, c, q))
+    dist = np.ascontiguousarray(np.stack(cols, axis=1), np.float32)  # [n][m]
+    grp = _c(group_ids, np.int64)
+    order = np.argsort(grp, kind="stable")
+    excl = np.zeros(c.shape[0], np.uint8)
+    excl[targets] = 1
+    dist_o, grp_o, excl_o = np.ascontiguousarray(dist[order]), np.ascontiguousarray(grp[order]), np.ascontiguousarray(excl[order])
+    og = np.empty(max(grp.size, 1), np.int64)
+    ov = np.empty(max(grp.size, 1), np.float64)
+    n = lib().orc_aggregate_fanout(_p(dist_o), len(targets), _p(excl_o), _p(grp_o), grp.size, agg, _p(og), _p(ov))
+    return _rank_groups(og[:n].copy(), ov[:n].copy(), k)
 
 
 def row_number(val, ids=None) -> np.ndarray:

@@ -457,6 +457,40 @@ ORC_API size_t orc_aggregate(const float *dist, const float *w, const int64_t *g
     return g;
 }
 
+/* The similar_to self-join aggregate (filters/item_similarity.rs:432-581): dist is
+ * [n][m] (row-major: other row o, target vector i) = vec_distance(main_i, other_o);
+ * rows flagged in `exclude` (the target item's own rows, `other.sha256 != target`) are
+ * skipped; per group the aggregate runs over every remaining (o, i) pair, o ascending then
+ * i ascending.  group[] non-decreasing.  Returns the number of groups. */
+ORC_API size_t orc_aggregate_fanout(const float *dist, size_t m, const uint8_t *exclude, const int64_t *group,
+                                    size_t n, int agg, int64_t *out_group, double *out_val) {
+    size_t g = 0, i = 0;
+    while (i < n) {
+        size_t j = i;
+        kbn sum = {0, 0};
+        double mn = INFINITY, mx = -INFINITY;
+        size_t cnt = 0;
+        for (; j < n && group[j] == group[i]; j++) {
+            if (exclude && exclude[j]) continue;
+            for (size_t t = 0; t < m; t++) {
+                float df = dist[j * m + t];
+                if (isnan(df)) continue;
+                double d = (double)df;
+                kbn_step(&sum, d);
+                if (d < mn) mn = d;
+                if (d > mx) mx = d;
+                cnt++;
+            }
+        }
+        double v = cnt == 0 ? NAN : agg == ORC_AGG_MIN ? mn : agg == ORC_AGG_MAX ? mx : kbn_value(&sum) / (double)cnt;
+        out_group[g] = group[i];
+        out_val[g] = v;
+        g++;
+        i = j;
+    }
+    return g;
+}
+
 /* ------------------------------------------------------------ rank / RRF */
 
 typedef struct {

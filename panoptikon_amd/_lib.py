@@ -77,6 +77,9 @@ SYMBOLS = {
     "pvs_sync": (_i32, [_vp]),
     "pvs_index_set_path": (_i32, [_vp, _u32]),
     "pvs_score_all": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),
+    "pvs_score_batch": (_i32, [_vp, _vp, _i32, _u32, _i32, _vp, _i32]),
+    "pvs_search_groups": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),
     "pvs_quantize_i8": (_i32, [_vp, _u64, _f, _vp, _i32, _i32]),

@@ -27,6 +27,7 @@ SOURCES = [
     "pvs_scan_f16_small.hip",
     "pvs_scan_f16_large.hip",
     "pvs_dense.hip",
+    "pvs_groups.hip",
     "pvs_comm.hip",
     "pvs_host.cpp",
 ]

@@ -131,7 +131,14 @@ struct pvs_index {
     float *d_norm2 = nullptr;   // |a|^2, the reference's aMag (sequential f32)
     float *d_rnorm = nullptr;   // 1/|a|
     int64_t *d_ids = nullptr;
-    std::vector<int64_t> h_groups;  // optional group ids (host copy, for pvs_aggregate callers)
+    std::vector<int64_t> h_groups;  // optional group ids per row (host copy)
+    std::vector<int64_t> h_ids_cache;  // host copy of row ids (lazy; similar_to's id -> row lookup)
+    // group CSR on the device (built lazily, rebuilt after adds)
+    uint64_t groups_built_n = UINT64_MAX;
+    uint32_t n_groups = 0;
+    uint32_t *d_grp_off = nullptr, *d_grp_rows = nullptr;
+    int64_t *d_grp_ids = nullptr;
+    GroupWork gwork;
     float scale = 0.f;
     bool scale_set = false;
     uint32_t forced_path = 0;
@@ -350,6 +357,10 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_norm2);
     hipFree(ix->d_rnorm);
     hipFree(ix->d_ids);
+    hipFree(ix->d_grp_off);
+    hipFree(ix->d_grp_rows);
+    hipFree(ix->d_grp_ids);
+    pvs_group_work_release(ix->gwork);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     delete ix;
 }
@@ -400,6 +411,7 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
     }
     ix->n += n;
     ix->last_id = last_id;
+    ix->groups_built_n = UINT64_MAX;
     return PVS_OK;
 }
 
@@ -934,6 +946,291 @@ PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype 
         return PVS_OK;
     };
     if (st == PVS_OK) st = body();
+    ctx_done(ix, c);
+    return st;
+}
+
+// ------------------------------------------------- groups, dense scores, similar_to
+static pvs_status ensure_groups(pvs_index *ix) {
+    if (ix->groups_built_n == ix->n) return PVS_OK;
+    if (!ix->h_groups.empty() && ix->h_groups.size() != ix->n) return pvs_fail(PVS_ERR_STATE, "group ids missing for some rows");
+    hipFree(ix->d_grp_off);
+    hipFree(ix->d_grp_rows);
+    hipFree(ix->d_grp_ids);
+    ix->d_grp_off = ix->d_grp_rows = nullptr;
+    ix->d_grp_ids = nullptr;
+    const uint64_t n = ix->n;
+    std::vector<uint32_t> off, rows(n);
+    std::vector<int64_t> gids;
+    if (ix->h_groups.empty()) {  // identity: one group per row, the group id is the row id
+        gids.resize(n);
+        if (n) HIP_TRY(hipMemcpy(gids.data(), ix->d_ids, n * 8, hipMemcpyDeviceToHost));
+        off.resize(n + 1);
+        for (uint64_t i = 0; i <= n; i++) off[i] = (uint32_t)i;
+        for (uint64_t i = 0; i < n; i++) rows[i] = (uint32_t)i;
+    } else {
+        std::vector<uint32_t> order(n);
+        for (uint64_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        const int64_t *g = ix->h_groups.data();
+        std::stable_sort(order.begin(), order.end(), [g](uint32_t a, uint32_t b) { return g[a] < g[b]; });  // rows stay ascending inside a group
+        for (uint64_t i = 0; i < n; i++) {
+            if (i == 0 || g[order[i]] != g[order[i - 1]]) {
+                gids.push_back(g[order[i]]);
+                off.push_back((uint32_t)i);
+            }
+            rows[i] = order[i];
+        }
+        off.push_back((uint32_t)n);
+    }
+    ix->n_groups = (uint32_t)gids.size();
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_off, (off.size() + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_rows, (n + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_ids, (gids.size() + 1) * 8));
+    HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
+    if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
+    ix->groups_built_n = n;
+    return PVS_OK;
+}
+
+// d_out[row * nb + q], nb <= PVS_MAX_BATCH queries already prepared in ctx c (prep_chunk)
+static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
+    const uint32_t kslabs = ix->stride / PVS_KSLAB_BYTES;
+    if (ix->dtype == PVS_I8 && pvs_scan_supported(PVS_I8, kslabs) && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
+        // matrix-core path: exact integer dots, closed-form finish (valid below 2^24)
+        ScanArgs a;
+        a.dtype = PVS_I8;
+        a.metric = metric;
+        a.kslabs = kslabs;
+        a.qgroups = batch_pad / 32;
+        a.rows = ix->d_rows;
+        a.aux = ix->d_norm2;
+        a.stride = ix->stride;
+        a.n_rows = ix->n;
+        a.qmat = c.d_qmat;
+        a.qinfo = c.d_qinfo;
+        a.thr = c.d_thr;
+        a.gmin = c.d_gmin;
+        a.groups_per_query = 0;
+        a.cand_cnt = c.d_cand_cnt;
+        a.cand = c.d_cand;
+        a.cand_cap = PVS_CAND_CAP;
+        a.mode = 2;
+        a.tile_step = 1;
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+        const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        a.dense_out = d_out;
+        a.dense_ld = nb;
+        a.batch = nb;
+        a.dense_flag = c.d_cand_cnt;  // reused as the out-of-range flag word
+        HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (!flag) return PVS_OK;  // else: some L2 sum left the exact range -> score in order below
+    }
+    for (uint32_t q = 0; q < nb; q++) {
+        const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, d_out,
+                                     c.stream, nb, q));
+    }
+    return PVS_OK;
+}
+
+// queries per dense chunk so that the [n][nb] f32 matrix stays <= 2 GiB
+static uint32_t dense_chunk_queries(const pvs_index *ix, uint32_t batch) {
+    const uint64_t cap = (1ull << 31) / (4 * std::max<uint64_t>(ix->n, 1));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({cap, (uint64_t)PVS_MAX_BATCH, (uint64_t)batch}));
+}
+
+PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric,
+                                      float *out_dist, pvs_space out_space) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0 || ix->n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, 1, false));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        const uint32_t cq = dense_chunk_queries(ix, batch);
+        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * cq * 4));
+        for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
+            const uint32_t nb = std::min(cq, batch - q0);
+            const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+            PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+            PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
+            // scatter the chunk's columns into out[row * batch + q0 + j]
+            const hipMemcpyKind kind = out_space == PVS_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+            HIP_TRY(hipMemcpy2DAsync(out_dist + q0, (size_t)batch * 4, d_m, (size_t)nb * 4, (size_t)nb * 4, ix->n, kind, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    ctx_done(ix, c);
+    return st;
+}
+
+// shared tail: d_m [n][nb] (fanout == 0: nb output columns; else one) -> ranked groups on the host
+static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg,
+                                     const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
+                                     double *out_values, uint32_t *out_count) {
+    const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
+    double *d_vals = nullptr;
+    int64_t *d_og = nullptr;
+    double *d_ov = nullptr;
+    uint32_t *d_oc = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
+        HIP_TRY(hipMalloc((void **)&d_og, (size_t)k * 8));
+        HIP_TRY(hipMalloc((void **)&d_ov, (size_t)k * 8));
+        HIP_TRY(hipMalloc((void **)&d_oc, 4));
+        HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
+                                           c.stream));
+        for (uint32_t q = 0; q < ncol; q++) {
+            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, ix->gwork, d_og, d_ov, d_oc, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_values + (size_t)q * k, d_ov, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_count + q, d_oc, 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_vals);
+    hipFree(d_og);
+    hipFree(d_ov);
+    hipFree(d_oc);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                        pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
+                                        double *out_values, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (!row_weights && agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG)
+        return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+    }
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr, *d_w = nullptr;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        if (row_weights && ix->n) {
+            HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+            HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        const uint32_t cq = dense_chunk_queries(ix, batch);
+        HIP_TRY(hipMalloc((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
+        for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
+            const uint32_t nb = std::min(cq, batch - q0);
+            const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+            if (ix->n) {
+                PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+                PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
+            }
+            PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, nullptr, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
+                                       out_count + q0));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    hipFree(d_w);
+    ix->searches++;
+    ix->dense_queries += batch;
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                     pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
+    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
+    if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    HIP_TRY(hipSetDevice(ix->device));
+    std::vector<uint32_t> trow(n_targets);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+        if (ix->h_ids_cache.size() != ix->n) {
+            ix->h_ids_cache.resize(ix->n);
+            if (ix->n) HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
+        }
+        for (uint32_t i = 0; i < n_targets; i++) {  // ids are strictly increasing: binary search
+            auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), target_row_ids[i]);
+            if (it == ix->h_ids_cache.end() || *it != target_row_ids[i])
+                return pvs_fail(PVS_ERR_INVALID_ARG, "target row id %lld is not in the index", (long long)target_row_ids[i]);
+            trow[i] = (uint32_t)(it - ix->h_ids_cache.begin());
+        }
+    }
+    if (ix->n > (1ull << 31) / (4ull * n_targets)) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to fan-out matrix would exceed 2 GiB");
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr;
+    uint8_t *d_ex = nullptr;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
+        // the target's stored vectors become the query batch: int8 codes as they are, f16/f32 as f32
+        const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
+        std::vector<uint8_t> hq((size_t)n_targets * ix->dim * qesz);
+        std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
+        for (uint32_t i = 0; i < n_targets; i++) {
+            HIP_TRY(hipMemcpy(rowbuf.data(), ix->d_rows + (uint64_t)trow[i] * ix->stride, rowbuf.size(), hipMemcpyDeviceToHost));
+            uint8_t *dst = hq.data() + (size_t)i * ix->dim * qesz;
+            if (ix->dtype == PVS_F16) {
+                for (uint32_t e = 0; e < ix->dim; e++) {
+                    _Float16 hv;
+                    memcpy(&hv, rowbuf.data() + 2 * e, 2);
+                    const float f = (float)hv;
+                    memcpy(dst + 4 * e, &f, 4);
+                }
+            } else {
+                memcpy(dst, rowbuf.data(), rowbuf.size());
+            }
+        }
+        HIP_TRY(hipMalloc(&d_q, hq.size()));
+        HIP_TRY(hipMemcpy(d_q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&d_ex, ix->n + 1));
+        HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
+        for (uint32_t i = 0; i < n_targets; i++) HIP_TRY(hipMemsetAsync(d_ex + trow[i], 1, 1, c->stream));
+        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * n_targets * 4));
+        const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
+        PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
+        PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));
+        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, agg, nullptr, d_ex, k, out_groups, out_values, out_count));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    hipFree(d_ex);
+    ix->searches++;
     ctx_done(ix, c);
     return st;
 }

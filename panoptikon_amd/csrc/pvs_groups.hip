@@ -1,0 +1,151 @@
+// pvs_groups.hip — per-item aggregation and ranking on the device.
+// Replaces the reference's  `GROUP BY file_id` + rank_aggregate (MIN / MAX / AVG / SUM(d*w)/SUM(w))
+// over the materialised per-row distance (filters/exact.rs:67-134, pql/builder.rs:829-835) and the
+// ORDER BY over the groups; for `similar_to` the aggregate runs over the (target vector x
+// candidate vector) fan-out of the self-join (filters/item_similarity.rs:432-581).
+// SQLite's SUM/AVG are Kahan-Babuska-Neumaier compensated f64 sums taken in row order; one lane
+// walks one group in that fixed order, so the f64 results are bit-identical to the oracle.
+#include <hipcub/hipcub.hpp>
+
+#include "pvs_kernels.hpp"
+
+struct Kbn {
+    double s = 0.0, c = 0.0;
+    __device__ inline void step(double r) {
+        const double t = s + r;
+        if (fabs(s) > fabs(r))
+            c += (s - t) + r;
+        else
+            c += (r - t) + s;
+        s = t;
+    }
+    __device__ inline double value() const { return s + c; }
+};
+
+// dist: [n_rows][ld] (query-minor).  One lane per (group, output column).
+//   fanout == 0: column q aggregates dist[row][q] over the group's rows (semantic search)
+//   fanout == M: a single output column aggregates dist[row][0..M) over rows and targets
+//                (similar_to), skipping rows flagged in `exclude`.
+__global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout,
+                                                         const uint32_t *grp_off, const uint32_t *grp_rows, uint32_t n_groups,
+                                                         const float *weights, const uint8_t *exclude, int agg, double *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ncol_out = fanout ? 1u : n_cols;
+    if (gid >= (uint64_t)n_groups * ncol_out) return;
+    const uint32_t g = (uint32_t)(gid / ncol_out), q = (uint32_t)(gid % ncol_out);
+    Kbn sum, wsum;
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    uint64_t cnt = 0;
+    for (uint32_t e = grp_off[g]; e < grp_off[g + 1]; e++) {
+        const uint32_t row = grp_rows[e];
+        if (exclude && exclude[row]) continue;
+        const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
+        for (uint32_t c = c0; c < c1; c++) {
+            const float df = dist[(size_t)row * ld + c];
+            if (df != df) continue;  // SQL NULL: ignored by every aggregate
+            const double d = (double)df;
+            if (weights) {
+                const double w = (double)weights[row];
+                sum.step(d * w);
+                wsum.step(w);
+            } else {
+                sum.step(d);
+            }
+            mn = fmin(mn, d);
+            mx = fmax(mx, d);
+            cnt++;
+        }
+    }
+    double v;
+    if (cnt == 0)
+        v = __builtin_nan("");
+    else if (weights)
+        v = sum.value() / wsum.value();
+    else if (agg == PVS_AGG_MIN)
+        v = mn;
+    else if (agg == PVS_AGG_MAX)
+        v = mx;
+    else
+        v = sum.value() / (double)cnt;
+    out[(size_t)q * n_groups + g] = v;
+}
+
+hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
+                                      const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
+                                      int agg, double *out, hipStream_t s) {
+    if (n_groups == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)n_groups * (fanout ? 1u : n_cols);
+    hipLaunchKernelGGL(k_group_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dist, ld, n_cols, fanout, grp_off,
+                       grp_rows, n_groups, weights, exclude, agg, out);
+    return hipGetLastError();
+}
+
+// order-preserving f64 -> u64, NaN last
+__device__ static inline unsigned long long f64_sort_key(double d) {
+    unsigned long long b = __builtin_bit_cast(unsigned long long, d);
+    if ((b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) return ~0ull;
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ void k_group_keys(const double *vals, uint32_t n, unsigned long long *keys, uint32_t *idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        keys[i] = f64_sort_key(vals[i]);
+        idx[i] = i;
+    }
+}
+__global__ void k_group_emit(const uint32_t *idx_sorted, const double *vals, const int64_t *group_ids, uint32_t n, uint32_t k,
+                             int64_t *out_groups, double *out_vals, uint32_t *out_count) {
+    const uint32_t nout = n < k ? n : k;
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        if (i < nout) {
+            out_groups[i] = group_ids[idx_sorted[i]];
+            out_vals[i] = vals[idx_sorted[i]];
+        } else {
+            out_groups[i] = -1;
+            out_vals[i] = __builtin_nan("");
+        }
+    }
+    if (threadIdx.x == 0) *out_count = nout;
+}
+
+// ranks one column of group values: (value asc, group id asc — groups are stored in id order and
+// the radix sort is stable), NaN last; writes the first k.
+pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
+                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s) {
+    if (n_groups > w.cap) {
+        hipFree(w.keys_in);
+        hipFree(w.keys_out);
+        hipFree(w.idx_in);
+        hipFree(w.idx_out);
+        hipFree(w.temp);
+        w = GroupWork();
+        const uint32_t cap = (uint32_t)pvs_round_up(n_groups, 1024);
+        HIP_TRY(hipMalloc((void **)&w.keys_in, (size_t)cap * 8));
+        HIP_TRY(hipMalloc((void **)&w.keys_out, (size_t)cap * 8));
+        HIP_TRY(hipMalloc((void **)&w.idx_in, (size_t)cap * 4));
+        HIP_TRY(hipMalloc((void **)&w.idx_out, (size_t)cap * 4));
+        size_t tb = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (int)cap));
+        HIP_TRY(hipMalloc(&w.temp, tb ? tb : 16));
+        w.temp_bytes = tb;
+        w.cap = cap;
+    }
+    if (n_groups) {
+        hipLaunchKernelGGL(k_group_keys, dim3((n_groups + 255) / 256 > 4096 ? 4096 : (n_groups + 255) / 256), dim3(256), 0, s, d_vals,
+                           n_groups, w.keys_in, w.idx_in);
+        size_t tb = w.temp_bytes;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (int)n_groups, 0, 64, s));
+    }
+    hipLaunchKernelGGL(k_group_emit, dim3(1), dim3(256), 0, s, w.idx_out, d_vals, d_group_ids, n_groups, k, d_out_groups, d_out_vals,
+                       d_out_count);
+    HIP_TRY(hipGetLastError());
+    return PVS_OK;
+}
+
+void pvs_group_work_release(GroupWork &w) {
+    hipFree(w.keys_in);
+    hipFree(w.keys_out);
+    hipFree(w.idx_in);
+    hipFree(w.idx_out);
+    hipFree(w.temp);
+    w = GroupWork();
+}

@@ -26,7 +26,7 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
 // exact per-row distance (the reference's dist_{cte}.d), one lane per row
 hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
                                 uint64_t n, const float *norm2, const void *qexact, const QInfo *qinfo,
-                                float *out, hipStream_t s);
+                                float *out, hipStream_t s, uint32_t out_ld = 1, uint32_t out_col = 0);
 
 // ---- filter scan (pvs_kernels_scan.hip)
 struct ScanArgs {
@@ -39,7 +39,10 @@ struct ScanArgs {
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;
     const QInfo *qinfo;
-    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter
+    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8)
+    float *dense_out = nullptr;       // mode 2: [n_rows][dense_ld]
+    uint32_t *dense_flag = nullptr;   // mode 2
+    uint32_t dense_ld = 0, batch = 0;
     uint32_t tile_step;     // process WG tiles 0, step, 2*step, ...
     uint32_t grid;          // workgroups
     float *gmin;            // mode 0: [batch_pad][groups_per_query]
@@ -95,3 +98,18 @@ pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *i
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
                             uint32_t *out_count, hipStream_t s);
+
+// ---- per-item aggregation and ranking (pvs_groups.hip)
+struct GroupWork {
+    unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+    uint32_t *idx_in = nullptr, *idx_out = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    uint32_t cap = 0;
+};
+hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
+                                      const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
+                                      int agg, double *out, hipStream_t s);
+pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
+                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s);
+void pvs_group_work_release(GroupWork &w);

@@ -31,6 +31,10 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.groups_per_query = a.groups_per_query;
     k.cand_cap = a.cand_cap;
     k.grid = a.grid;
+    k.dense_out = a.dense_out;
+    k.dense_flag = a.dense_flag;
+    k.dense_ld = a.dense_ld;
+    k.batch = a.batch;
     static const int dbg = getenv("PVS_SCAN_DEBUG") ? atoi(getenv("PVS_SCAN_DEBUG")) : 0;
     k.debug = a.mode == 1 ? dbg : 0;
     k.dbg_out = nullptr;

@@ -12,6 +12,9 @@ struct ScanK {
     uint2 *cand;
     uint64_t n_rows;
     uint32_t stride, n_wgtiles, tile_step, groups_per_query, cand_cap, grid;
+    float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
+    uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
+    uint32_t dense_ld, batch;
     unsigned long long *dbg_out;  // PVS_SCAN_DEBUG & 16: per-wave phase cycle sums [grid][4][6]
     int debug;  // profiling ablations (PVS_SCAN_DEBUG): 1 = no MFMA, 2 = no epilogue, 4 = no DMA in the loop
 };

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             hold[r] = 0;
         }
         uint32_t prev_row_base = 0;
+        bool prev_valid = false;  // MODE 2: the dummy tile "-1" writes nothing
 
         // Fast part of an epilogue, cut into 24 micro-steps so the main loop can drop them between
         // MFMAs:  m < 16: sv[m] = score of row m;  m >= 16: fold two scores into the running best.
@@ -237,7 +238,28 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         constexpr int EPI_STEPS = 24;
         // the rest: group minima (pass A) or candidate emission (pass B)
         auto epi_rest = [&](const float(&sv)[16], float best) {
-            if (MODE == 0) {
+            if constexpr (MODE == 2) {
+                // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
+                // closed form of the exact integer sums, valid while they stay below 2^24
+                // (oracle: orc_i8_cosine_from_sums / orc_i8_l2_from_sums).  xh = |a|^2 here.
+                if (myq < (int)a.batch) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
+                        if (row < a.n_rows && prev_valid) {
+                            float d;
+                            if (COS) {
+                                d = ref_cosine_finish((float)hold[r], xh[r], qi.bb);
+                            } else {
+                                const double ss = (double)xh[r] + (double)qi.bb - 2.0 * (double)hold[r];
+                                if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
+                                d = ref_l2_finish((float)ss);
+                            }
+                            a.dense_out[(size_t)row * a.dense_ld + myq] = d;
+                        }
+                    }
+                }
+            } else if (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     // upper bound of this row's key: key + err
@@ -337,6 +359,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
 #pragma unroll
                 for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; f16: within the error budget
                 prev_row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
+                prev_valid = true;
             }
             if (MODE == 1) {
                 // flush checkpoint: uniform, because no wave appends between this barrier and its
@@ -368,7 +391,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
     }
 
-    if (MODE == 0) {
+    if (MODE == 2) {
+    } else if (MODE == 0) {
         float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * 16;
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = mins[r];
@@ -399,6 +423,12 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
 }
 template <int DT, int KS, int QG>
 static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream_t s) {
+    if constexpr (DT == PVS_I8) {
+        if (mode == 2)
+            return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 2>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 2>(k, s);
+    } else {
+        if (mode == 2) return hipErrorInvalidValue;  // float order matters: no closed form
+    }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
 }

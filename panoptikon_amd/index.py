@@ -172,6 +172,33 @@ class VectorIndex:
         L.check(L.lib().pvs_score_all(self._h, _ptr(q), qd, metric, _ptr(out), L.HOST))
         return out
 
+    def score_batch(self, queries, metric: int = L.COSINE) -> np.ndarray:
+        """[rows][batch] exact distances (the dist_{cte}.d column for every query of the batch)."""
+        q, qd = self._queries(queries)
+        out = np.empty((self.stats().rows, q.shape[0]), np.float32)
+        L.check(L.lib().pvs_score_batch(self._h, _ptr(q), qd, q.shape[0], metric, _ptr(out), L.HOST))
+        return out
+
+    def search_groups(self, queries, k: int, metric: int = L.COSINE, agg: int = L.AGG_MIN, row_weights=None):
+        """Per-item page: (group ids [b][k], f64 aggregate [b][k], counts [b])."""
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        w = None if row_weights is None else np.ascontiguousarray(row_weights, np.float32)
+        og = np.empty((b, k), np.int64)
+        ov = np.empty((b, k), np.float64)
+        oc = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_groups(self._h, _ptr(q), qd, b, k, metric, agg, _ptr(w), _ptr(og), _ptr(ov), _ptr(oc)))
+        return og, ov, oc
+
+    def similar_to(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG):
+        """filters/item_similarity.rs: the target item's stored vectors against everything else."""
+        t = np.ascontiguousarray(target_row_ids, np.int64)
+        og = np.empty(k, np.int64)
+        ov = np.empty(k, np.float64)
+        oc = C.c_uint32()
+        L.check(L.lib().pvs_similar_to(self._h, _ptr(t), t.size, k, metric, agg, _ptr(og), _ptr(ov), C.byref(oc)))
+        return og[: oc.value], ov[: oc.value]
+
     def read_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dim), _NP[self.dtype])
         L.check(L.lib().pvs_index_read_rows(self._h, row0, n, _ptr(out)))

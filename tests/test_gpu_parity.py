@@ -285,3 +285,97 @@ def test_device_merge_and_sharded_search(pvs):
     assert np.array_equal(oc.to_numpy(np.uint32, (40,)), exp[2])
     pvs.lib().pvs_comm_destroy(comm)
     ix.close()
+
+
+def _group_ids(rng, n, n_groups):
+    g = rng.integers(0, n_groups, n).astype(np.int64) * 3 + 100  # unsorted: rows of a group are scattered
+    return g
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_score_batch_dense_matrix(pvs, dtype):
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    n, dim, b = 3000, 768, 37
+    rows = unit_rows(41, n, dim)
+    rows[11] = 0.0
+    queries = orc.synth_rows(0x5EED0000, 0, b, dim)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    for metric in (pvs.COSINE, pvs.L2):
+        got = ix.score_batch(hq, metric)
+        assert got.shape == (n, b)
+        for q in (0, 5, b - 1):
+            exp = orc.score_all(dt, metric, hc, hq[q])
+            assert np.array_equal(np.isnan(got[:, q]), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok, q].view(np.uint32), exp[ok].view(np.uint32)), (dtype, metric, q)
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16"])
+def test_search_groups_matches_sqlite_aggregate_semantics(pvs, dtype):
+    # filters/exact.rs:67-80: MIN / MAX / AVG per file, weighted average when weights apply
+    dt = pvs.I8 if dtype == "i8" else pvs.F16
+    rng = np.random.default_rng(17)
+    n, dim, b, k = 4000, 512, 3, 60
+    rows = unit_rows(43, n, dim)
+    rows[100] = 0.0  # a NULL distance inside some group
+    groups = _group_ids(rng, n, 700)
+    queries = orc.synth_rows(0x5EED0000, 7, b, dim)
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(dt, dim)
+    if dt == pvs.I8:
+        ix.set_scale(scale)
+    ix.add_f32(rows, group_ids=groups)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    w = (rng.random(n) + 0.05).astype(np.float32)
+    for metric in (pvs.COSINE, pvs.L2):
+        for agg, oagg in ((pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_MAX, orc.AGG_MAX), (pvs.AGG_AVG, orc.AGG_AVG)):
+            gg, gv, gc = ix.search_groups(hq, k, metric, agg)
+            for q in range(b):
+                eg, ev = orc.search_groups(dt, metric, hc, hq[q], groups, oagg, k)
+                assert gc[q] == len(eg) and np.array_equal(gg[q, : len(eg)], eg)
+                assert np.array_equal(gv[q, : len(eg)].view(np.uint64), ev.view(np.uint64)), (dtype, metric, agg)
+        gg, gv, gc = ix.search_groups(hq, k, metric, pvs.AGG_MIN, row_weights=w)
+        for q in range(b):
+            eg, ev = orc.search_groups(dt, metric, hc, hq[q], groups, orc.AGG_MIN, k, weights=w)
+            assert np.array_equal(gg[q, : len(eg)], eg)
+            assert np.array_equal(gv[q, : len(eg)].view(np.uint64), ev.view(np.uint64))
+    ix.close()
+    # no group ids: identity grouping == row search
+    ix2 = make_index(pvs, dt, rows, scale)
+    gg, gv, gc = ix2.search_groups(hq[:1], 10, pvs.COSINE, pvs.AGG_MIN)
+    ri, rd, rc = ix2.search(hq[:1], 10, pvs.COSINE)
+    assert np.array_equal(gg[0], ri[0]) and np.array_equal(gv[0], rd[0].astype(np.float64))
+    ix2.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_similar_to_matches_self_join(pvs, dtype):
+    # filters/item_similarity.rs:432-581; :3532-3582 similar_to_quant_matches_exact is the ordering-level test
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    rng = np.random.default_rng(23)
+    n, dim, k = 2500, 512, 40
+    rows = unit_rows(47, n, dim)
+    groups = np.sort(_group_ids(rng, n, 600))  # files: a few vectors each
+    ids = np.arange(n, dtype=np.int64) * 2 + 5
+    targets = [int(t) for t in np.nonzero(groups == groups[1234])[0]]  # every vector of one item
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(dt, dim)
+    if dt == pvs.I8:
+        ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids, group_ids=groups)
+    hc = host_corpus(dt, rows, scale)
+    for metric in (pvs.L2, pvs.COSINE):
+        for agg, oagg in ((pvs.AGG_AVG, orc.AGG_AVG), (pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_MAX, orc.AGG_MAX)):
+            gg, gv = ix.similar_to(ids[targets], k, metric, agg)
+            eg, ev = orc.similar_to(dt, metric, hc, targets, groups, oagg, k)
+            assert np.array_equal(gg, eg), (dtype, metric, agg)
+            assert np.array_equal(gv.view(np.uint64), ev.view(np.uint64))
+    assert groups[1234] not in gg  # the target's own group has no non-target rows left
+    with pytest.raises(pvs.PvsError):
+        ix.similar_to([4], 5)  # not a row id of this index
+    ix.close()
