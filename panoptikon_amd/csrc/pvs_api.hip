@@ -324,13 +324,15 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
         return pvs_fail(PVS_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
     }
     hipStream_t s = ix->admin_stream;
-    // padding rows: zero payload, NaN norm (a NaN norm makes every scan compare fail)
-    HIP_TRY(hipMemsetAsync(rows_new + ix->n * (uint64_t)ix->stride, 0, (cap - ix->n) * (uint64_t)ix->stride, s));
+    // padding rows: zero payload, NaN norm (a NaN norm makes every scan compare fail).  The layout
+    // is tiled by 32 rows, so the copy below moves whole tiles and the memset starts at a tile edge.
+    const uint64_t n_tiled = pvs_round_up(ix->n, 32);
+    HIP_TRY(hipMemsetAsync(rows_new + n_tiled * (uint64_t)ix->stride, 0, (cap - n_tiled) * (uint64_t)ix->stride, s));
     HIP_TRY(pvs_launch_fill_f32(norm_new + ix->n, cap - ix->n, __builtin_nanf(""), s));
     HIP_TRY(pvs_launch_fill_f32(rnorm_new + ix->n, cap - ix->n, __builtin_nanf(""), s));
     HIP_TRY(hipMemsetAsync(ids_new + ix->n, 0xff, (cap - ix->n) * 8, s));
     if (ix->n) {
-        HIP_TRY(hipMemcpyAsync(rows_new, ix->d_rows, ix->n * (uint64_t)ix->stride, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(rows_new, ix->d_rows, n_tiled * (uint64_t)ix->stride, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(norm_new, ix->d_norm2, ix->n * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(rnorm_new, ix->d_rnorm, ix->n * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(ids_new, ix->d_ids, ix->n * 8, hipMemcpyDeviceToDevice, s));
@@ -388,16 +390,9 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
                                      const int64_t *group_ids, int64_t last_id) {
     if (ix->n + n > ix->cap) PVS_TRY(pvs_index_reserve_(ix, std::max<uint64_t>(ix->n + n, ix->cap * 2)));
     hipStream_t s = ix->admin_stream;
-    uint8_t *dst = ix->d_rows + ix->n * (uint64_t)ix->stride;
-    if (from_f32 && ix->dtype == PVS_I8) {
-        HIP_TRY(pvs_launch_rows_quantize((const float *)rows_dev, ix->dim, n, ix->scale, dst, ix->stride, s));
-    } else if (from_f32 && ix->dtype == PVS_F16) {
-        HIP_TRY(pvs_launch_rows_f32_to_f16((const float *)rows_dev, ix->dim, n, dst, ix->stride, s));
-    } else {
-        const size_t w = (size_t)ix->dim * ix->esz;
-        HIP_TRY(hipMemcpy2DAsync(dst, ix->stride, rows_dev, w, w, n, hipMemcpyDeviceToDevice, s));
-    }
-    HIP_TRY(pvs_launch_norm2((int)ix->dtype, dst, ix->stride, ix->dim, n, ix->d_norm2 + ix->n, ix->d_rnorm + ix->n, s));
+    const int mode = (from_f32 && ix->dtype == PVS_I8) ? 0 : (from_f32 && ix->dtype == PVS_F16) ? 1 : 2;
+    HIP_TRY(pvs_launch_rows_ingest(mode, rows_dev, ix->dim, ix->esz, ix->n, n, ix->scale, ix->d_rows, ix->stride, s));
+    HIP_TRY(pvs_launch_norm2((int)ix->dtype, ix->d_rows, ix->stride, ix->dim, ix->n, n, ix->d_norm2, ix->d_rnorm, s));
     if (row_ids)
         HIP_TRY(hipMemcpyAsync(ix->d_ids + ix->n, row_ids, n * 8, hipMemcpyHostToDevice, s));
     else
@@ -510,8 +505,21 @@ PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t
     if (n == 0) return PVS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     const size_t w = (size_t)ix->dim * ix->esz;
-    HIP_TRY(hipMemcpy2D(out_host, w, ix->d_rows + row0 * (uint64_t)ix->stride, ix->stride, w, n, hipMemcpyDeviceToHost));
-    return PVS_OK;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / w);
+    uint8_t *stage = nullptr;
+    HIP_TRY(hipMalloc((void **)&stage, std::min(chunk, n) * w));
+    pvs_status st = PVS_OK;
+    for (uint64_t off = 0; off < n; off += chunk) {
+        const uint64_t m = std::min(chunk, n - off);
+        hipError_t e = pvs_launch_rows_gather(ix->d_rows, ix->stride, (uint32_t)w, row0 + off, m, stage, nullptr);
+        if (e == hipSuccess) e = hipMemcpy((uint8_t *)out_host + off * w, stage, m * w, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            st = pvs_fail(PVS_ERR_DEVICE, "read_rows: %s", hipGetErrorString(e));
+            break;
+        }
+    }
+    hipFree(stage);
+    return st;
 }
 
 PVS_EXPORT pvs_status pvs_index_set_profiling(pvs_index *ix, int32_t enable) {
@@ -1201,7 +1209,9 @@ PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_id
         std::vector<uint8_t> hq((size_t)n_targets * ix->dim * qesz);
         std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
         for (uint32_t i = 0; i < n_targets; i++) {
-            HIP_TRY(hipMemcpy(rowbuf.data(), ix->d_rows + (uint64_t)trow[i] * ix->stride, rowbuf.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(pvs_launch_rows_gather(ix->d_rows, ix->stride, (uint32_t)rowbuf.size(), trow[i], 1, c->d_qin, c->stream));
+            HIP_TRY(hipMemcpyAsync(rowbuf.data(), c->d_qin, rowbuf.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
             uint8_t *dst = hq.data() + (size_t)i * ix->dim * qesz;
             if (ix->dtype == PVS_F16) {
                 for (uint32_t e = 0; e < ix->dim; e++) {

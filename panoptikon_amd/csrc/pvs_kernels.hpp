@@ -3,13 +3,14 @@
 #include "pvs_common.hpp"
 
 // ---- utility kernels (pvs_kernels_util.hip)
-hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
+hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t row0, uint64_t n,
                             float *norm2, float *rnorm, hipStream_t s);
 hipError_t pvs_launch_fill_f32(float *p, uint64_t n, float v, hipStream_t s);
-hipError_t pvs_launch_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst,
-                                      uint32_t stride, hipStream_t s);
-hipError_t pvs_launch_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale, uint8_t *dst,
-                                    uint32_t stride, hipStream_t s);
+// dense [n][dim] rows -> tiled index rows row0..: mode 0 = quantize_int8 from f32, 1 = f16 from f32, 2 = copy
+hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint32_t esz, uint64_t row0, uint64_t n, float scale,
+                                  uint8_t *rows, uint32_t stride, hipStream_t s);
+hipError_t pvs_launch_rows_gather(const uint8_t *rows, uint32_t stride, uint32_t row_bytes, uint64_t row0, uint64_t n, uint8_t *dst,
+                                  hipStream_t s);
 hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s);
 hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s);
 hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s);

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     }
                 }
             }
-            if (!closed) d = exact_distance<DT>(a.rows + (size_t)row * a.stride, qe, (int)a.dim, a.metric, aa, qi.bb);
+            if (!closed) d = exact_distance<DT>(a.rows, a.stride, row, qe, (int)a.dim, a.metric, aa, qi.bb);
             v = ((unsigned long long)f32_sort_key(d) << 32) | row;
         }
         s_sort[i] = v;

@@ -7,25 +7,25 @@
 // f32 (oracle: orc_vec_distance_cosine_*).  One lane per row; runs once per add.
 // rnorm[r] = 1/sqrt(norm2[r]) (two correctly rounded steps): the scan's cosine filter key.
 template <int DT>
-__global__ __launch_bounds__(256) void k_norm2(const uint8_t *rows, uint32_t stride, int dim, uint64_t n,
+__global__ __launch_bounds__(256) void k_norm2(const uint8_t *rows, uint32_t stride, int dim, uint64_t row0, uint64_t n,
                                                float *norm2, float *rnorm) {
     uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    const float aa = seq_sumsq<DT>(rows + r * (uint64_t)stride, dim);
-    norm2[r] = aa;
-    rnorm[r] = __frcp_rn(__fsqrt_rn(aa));
+    const float aa = seq_sumsq<DT>(rows, stride, row0 + r, dim);
+    norm2[row0 + r] = aa;
+    rnorm[row0 + r] = __frcp_rn(__fsqrt_rn(aa));
 }
 
-hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
+hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t row0, uint64_t n,
                             float *norm2, float *rnorm, hipStream_t s) {
     if (n == 0) return hipSuccess;
     dim3 g((unsigned)((n + 255) / 256)), b(256);
     if (dtype == PVS_I8)
-        hipLaunchKernelGGL(k_norm2<PVS_I8>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
+        hipLaunchKernelGGL(k_norm2<PVS_I8>, g, b, 0, s, rows, stride, (int)dim, row0, n, norm2, rnorm);
     else if (dtype == PVS_F16)
-        hipLaunchKernelGGL(k_norm2<PVS_F16>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
+        hipLaunchKernelGGL(k_norm2<PVS_F16>, g, b, 0, s, rows, stride, (int)dim, row0, n, norm2, rnorm);
     else
-        hipLaunchKernelGGL(k_norm2<PVS_F32>, g, b, 0, s, rows, stride, (int)dim, n, norm2, rnorm);
+        hipLaunchKernelGGL(k_norm2<PVS_F32>, g, b, 0, s, rows, stride, (int)dim, row0, n, norm2, rnorm);
     return hipGetLastError();
 }
 
@@ -64,21 +64,69 @@ __device__ static inline int8_t quant_one(float x, float scale) {
 }
 
 // strided destination (index rows): one thread per (row, 4 components)
-__global__ __launch_bounds__(256) void k_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale,
-                                                       uint8_t *dst, uint32_t stride) {
-    const uint64_t total = n * (uint64_t)dim;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
-        uint64_t r = i / dim;
-        uint32_t c = (uint32_t)(i - r * dim);
-        dst[r * stride + c] = (uint8_t)quant_one(src[i], scale);
+// Ingest kernels: dense [n][dim] source rows -> tiled index rows row0.. (one thread per 16-byte
+// destination chunk; source reads stay coalesced along the row).  MODE 0: int8 codes from f32
+// (quantize_int8), 1: f16 from f32 (round-to-nearest-even), 2: copy of rows already in the index dtype.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rows_ingest(const void *src, uint32_t dim, uint32_t esz, uint64_t row0, uint64_t n, float scale,
+                                                     uint8_t *rows, uint32_t stride) {
+    const uint32_t per = 16u / esz;                        // elements per destination chunk
+    const uint32_t cpr = (dim + per - 1) / per;            // chunks per row that hold data
+    const uint64_t total = n * (uint64_t)cpr;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = t / cpr;
+        const uint32_t c = (uint32_t)(t - r * cpr);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t e = c * per + j;
+            if (e >= dim) break;
+            if (MODE == 0) {
+                const uint32_t v = (uint8_t)quant_one(((const float *)src)[r * dim + e], scale);
+                w[j >> 2] |= v << ((j & 3) * 8);
+            } else if (MODE == 1) {
+                const _Float16 hv = (_Float16)((const float *)src)[r * dim + e];  // v_cvt_f16_f32: RNE
+                w[j >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, hv) << ((j & 1) * 16);
+            } else if (esz == 4) {
+                w[j] = ((const uint32_t *)src)[r * dim + e];
+            } else if (esz == 2) {
+                w[j >> 1] |= (uint32_t)((const uint16_t *)src)[r * dim + e] << ((j & 1) * 16);
+            } else {
+                w[j >> 2] |= (uint32_t)((const uint8_t *)src)[r * dim + e] << ((j & 3) * 8);
+            }
+        }
+        *(uint4 *)(rows + pvs_chunk_off(row0 + r, c, stride)) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
-hipError_t pvs_launch_rows_quantize(const float *src, uint32_t dim, uint64_t n, float scale, uint8_t *dst,
-                                    uint32_t stride, hipStream_t s) {
+hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint32_t esz, uint64_t row0, uint64_t n, float scale,
+                                  uint8_t *rows, uint32_t stride, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    uint64_t total = n * (uint64_t)dim;
-    unsigned g = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(k_rows_quantize, dim3(g), dim3(256), 0, s, src, dim, n, scale, dst, stride);
+    const uint32_t per = 16u / esz;
+    const uint64_t total = n * (uint64_t)((dim + per - 1) / per);
+    unsigned g = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_rows_ingest<0>, dim3(g), dim3(256), 0, s, src, dim, esz, row0, n, scale, rows, stride);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_rows_ingest<1>, dim3(g), dim3(256), 0, s, src, dim, esz, row0, n, scale, rows, stride);
+    else
+        hipLaunchKernelGGL(k_rows_ingest<2>, dim3(g), dim3(256), 0, s, src, dim, esz, row0, n, scale, rows, stride);
+    return hipGetLastError();
+}
+// tiled rows row0..row0+n -> dense [n][dim*esz] (pvs_index_read_rows)
+__global__ __launch_bounds__(256) void k_rows_gather(const uint8_t *rows, uint32_t stride, uint32_t row_bytes, uint64_t row0, uint64_t n,
+                                                     uint8_t *dst) {
+    const uint64_t total = n * (uint64_t)row_bytes;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = t / row_bytes;
+        const uint32_t b = (uint32_t)(t - r * row_bytes);
+        dst[t] = rows[pvs_chunk_off(row0 + r, b >> 4, stride) + (b & 15u)];
+    }
+}
+hipError_t pvs_launch_rows_gather(const uint8_t *rows, uint32_t stride, uint32_t row_bytes, uint64_t row0, uint64_t n, uint8_t *dst,
+                                  hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t total = n * (uint64_t)row_bytes;
+    unsigned g = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rows_gather, dim3(g), dim3(256), 0, s, rows, stride, row_bytes, row0, n, dst);
     return hipGetLastError();
 }
 
@@ -105,25 +153,6 @@ hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, i
     uint64_t w = (n + 1023) / 1024;
     unsigned g = (unsigned)(w > 8192 ? 8192 : (w ? w : 1));
     hipLaunchKernelGGL(k_quantize_flat, dim3(g), dim3(256), 0, s, src, n, scale, dst);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void k_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst,
-                                                         uint32_t stride) {
-    const uint64_t total = n * (uint64_t)dim;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
-        uint64_t r = i / dim;
-        uint32_t c = (uint32_t)(i - r * dim);
-        _Float16 h = (_Float16)src[i];  // v_cvt_f16_f32: round-to-nearest-even
-        *(uint16_t *)(dst + r * stride + 2 * (uint64_t)c) = __builtin_bit_cast(uint16_t, h);
-    }
-}
-hipError_t pvs_launch_rows_f32_to_f16(const float *src, uint32_t dim, uint64_t n, uint8_t *dst, uint32_t stride,
-                                      hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    uint64_t total = n * (uint64_t)dim;
-    unsigned g = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(k_rows_f32_to_f16, dim3(g), dim3(256), 0, s, src, dim, n, dst, stride);
     return hipGetLastError();
 }
 
@@ -325,9 +354,9 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
     if (tid == 0) {
         if (!have_bb) {
             if (index_dtype == PVS_I8)
-                bb = seq_sumsq<PVS_I8>((const uint8_t *)((const int8_t *)qexact + (uint64_t)b * dim), (int)dim);
+                bb = seq_sumsq_dense<PVS_I8>((const int8_t *)qexact + (uint64_t)b * dim, (int)dim);
             else
-                bb = seq_sumsq<PVS_F32>((const uint8_t *)((const float *)qexact + (uint64_t)b * dim), (int)dim);
+                bb = seq_sumsq_dense<PVS_F32>((const float *)qexact + (uint64_t)b * dim, (int)dim);
         }
         QInfo qi;
         qi.bb = bb;
@@ -368,7 +397,7 @@ __global__ __launch_bounds__(256) void k_score_all(int metric, const uint8_t *ro
                                                    const QInfo *qinfo, float *out, uint32_t out_ld, uint32_t out_col) {
     uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    out[r * out_ld + out_col] = exact_distance<DT>(rows + r * (uint64_t)stride, qexact, dim, metric, norm2[r], qinfo->bb);
+    out[r * out_ld + out_col] = exact_distance<DT>(rows, stride, r, qexact, dim, metric, norm2[r], qinfo->bb);
 }
 
 hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,

@@ -19,9 +19,9 @@
 //   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
 //   in "slabs" of (32*RT rows x 256 B), NS-deep ring, P = NS-1 slabs in flight, one
 //   s_barrier per slab, counted s_waitcnt vmcnt (never 0 in steady state).
-//   A fragments are ds_read_b128 from an XOR-swizzled slab image (chunk ^= row & 15, applied
-//   on the DMA *source* address; the LDS destination is lane-linear): conflict-free for the
-//   16-lane groups ds_read_b128 is serviced in.
+//   A fragments are ds_read_b128 from an XOR-swizzled slab image (chunk ^= row & 15).  The corpus
+//   is STORED in that image (tiled layout, pvs_common.hpp), so a DMA piece is one contiguous KiB
+//   of HBM landing lane-linear in LDS; reads are conflict-free for ds_read_b128's 16-lane groups.
 //   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 with A = 32 corpus rows, B = 32 queries:
 //   each lane ends up with ONE query (lane & 31) and 16 rows, so the per-query threshold is
 //   a lane-private register and the epilogue is 3-4 VALU per score until a row passes.
@@ -41,10 +41,11 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 // insertion, so the counted s_waitcnt vmcnt(N) below are the only waits.  M0 carries the
 // wave-uniform LDS destination; each lane lands at M0 + lane*size.  Source address =
 // SGPR base (uniform: tile + k-slab) + 32-bit VGPR offset (lane's row/chunk inside the slab).
+// `nt`: every corpus byte is read once per launch by exactly one CU (streaming policy).
 __device__ static inline void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         uint32_t voff[2 * RT];
 #pragma unroll
         for (int e = 0; e < 2 * RT; e++) {
-            const int r = 4 * (wave * 2 * RT + e) + (lane >> 4);
-            const int c = (lane & 15) ^ (r & 15);
-            voff[e] = (uint32_t)r * a.stride + (uint32_t)c * 16u;
+            // piece = 4 slab rows x 256 B = one contiguous KiB of the tiled HBM layout, already swizzled
+            const int r = 4 * (wave * 2 * RT + e);                       // first slab row of the piece
+            voff[e] = (uint32_t)(r >> 5) * (32u * a.stride) + (uint32_t)(r & 31) * 256u + (uint32_t)lane * 16u;
         }
         const uint32_t nvoff = (uint32_t)(rt * 32 + j) * 4u;
         // A-fragment LDS byte offsets of this lane inside a slab
@@ -185,22 +186,35 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
         int i_tl = 0, i_ck = 0, i_slot = 0;  // tile, chunk within tile, ring chunk slot
-        auto issue = [&]() {
+        constexpr int DMA_PARTS = SPB * 2 * RT + 1;  // row pieces + the per-row scalars
+        const uint8_t *is_base = nullptr;
+        const float *is_aux = nullptr;
+        uint32_t is_lds = 0, is_norm = 0;
+        auto issue_begin = [&]() {
             const int tl = i_tl < n_my ? i_tl : n_my - 1;  // past the end: harmless re-read keeps vmcnt uniform
             const uint64_t wt = (uint64_t)(blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step;
-            const uint8_t *sbase = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 256u);
-            const uint32_t sl = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (2 * RT * 1024);
-#pragma unroll
-            for (int sb = 0; sb < SPB; sb++) {
-#pragma unroll
-                for (int e = 0; e < 2 * RT; e++) dma16(sbase + sb * 256, voff[e], sl + sb * SLAB_BYTES + e * 1024);
-            }
-            dma4(a.aux + wt * SLAB_ROWS, nvoff, norm_lds + (uint32_t)i_slot * 1024 + (uint32_t)wave * 256);
+            is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
+            is_aux = a.aux + wt * SLAB_ROWS;
+            is_lds = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (2 * RT * 1024);
+            is_norm = norm_lds + (uint32_t)i_slot * 1024 + (uint32_t)wave * 256;
             if (++i_ck == CPT) {
                 i_ck = 0;
                 i_tl++;
             }
             if (++i_slot == NC) i_slot = 0;
+        };
+        auto issue_part = [&](int part) {  // part is a compile-time constant at every call site
+            if (part < DMA_PARTS - 1) {
+                const int sb = part / (2 * RT), e = part % (2 * RT);
+                dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
+            } else {
+                dma4(is_aux, nvoff, is_norm);
+            }
+        };
+        auto issue = [&]() {
+            issue_begin();
+#pragma unroll
+            for (int part = 0; part < DMA_PARTS; part++) issue_part(part);
         };
 #pragma unroll
         for (int p = 0; p < PC; p++) issue();
@@ -314,10 +328,11 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             for (int ck = 0; ck < CPT; ck++) {
                 wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
                 wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
-                issue();                                // refill the slot the previous chunk occupied
+                issue_begin();                          // the slot the previous chunk occupied is refilled below
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
                 // Explicit software pipeline, fenced with sched_barrier(0) so hipcc keeps the order:
-                //   step t:  LDS read of fragment t+PF | MFMA t | a slice of the previous tile's epilogue
+                //   step t:  LDS read of fragment t+PF | MFMA t | one DMA piece of the chunk PC ahead |
+                //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
                 constexpr int NF = SPB * 8, PF = 4;
                 v4i af[NF];
@@ -334,6 +349,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                         acc1 = A::mfma(af[t], qf[ck * NF + t], acc1);
                     else
                         acc = A::mfma(af[t], qf[ck * NF + t], acc);
+#pragma unroll
+                    for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
                     if (ck == 0) {
 #pragma unroll
                         for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, sv, best);
