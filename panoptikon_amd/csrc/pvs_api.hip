@@ -119,7 +119,7 @@ pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *
                                   int64_t *all_ids, float *all_dist, uint32_t *all_cnt, uint32_t *all_flags, uint64_t elems,
                                   uint32_t batch, hipStream_t s);
 
-constexpr uint32_t GMAX = 256 * 4 * 32;  // group minima per query (pass A grid <= 256)
+constexpr uint32_t GMAX = 16384;  // group minima per query (pass A grid * RT * 32 <= GMAX)
 constexpr uint32_t NCTX = 4;
 
 struct pvs_index {
@@ -628,11 +628,12 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         // pass A: strided sample of row tiles -> group minima -> threshold
-        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>(ix->n / 64, 32768));
+        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>(ix->n / 16, 32768));
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
         const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
-        a.grid = std::min<uint32_t>(n_samp, 256);
+        const uint32_t per_cu_a = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / ((4 / a.qgroups) * 32)});
         a.mode = 0;
         a.groups_per_query = a.grid * (4 / a.qgroups) * 32;
         span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);

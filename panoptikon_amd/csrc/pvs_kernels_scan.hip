@@ -124,11 +124,11 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
     const float *v = vals + (size_t)q * per_query;
     uint32_t key = 0xffffffffu;
     if (per_query >= k) {
-        if (per_query <= 8192) {
+        if (per_query <= 16384) {
             // keys live in registers across the four passes (the loads are the latency that matters)
-            uint32_t kreg[32];
+            uint32_t kreg[64];
 #pragma unroll
-            for (int j = 0; j < 32; j++) {
+            for (int j = 0; j < 64; j++) {
                 const uint32_t i = threadIdx.x + 256u * j;
                 kreg[j] = i < per_query ? f32_sort_key(v[i]) : 0xffffffffu;
             }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
                 hist[tid] = 0;
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < 32; j++) {
+                for (int j = 0; j < 64; j++) {
                     const uint32_t i = threadIdx.x + 256u * j;
                     if (i < per_query && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
                 }

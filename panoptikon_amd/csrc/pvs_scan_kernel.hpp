@@ -67,9 +67,8 @@ __device__ static inline void wait_vm() {
 }
 __device__ static inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int LCAP = 384;      // LDS candidate staging entries per workgroup
-constexpr int FLUSH_AT = 128;  // flush to HBM at a checkpoint once this many are staged
-constexpr int FLUSH_EVERY = 16;  // tiles between flush checkpoints (one extra barrier each)
+constexpr int WCAP = 96;          // candidate staging entries per WAVE (wave-private LDS region)
+constexpr int LCAP = 4 * WCAP;    // per workgroup
 
 template <int DT>
 struct Acc;
@@ -129,7 +128,6 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
     const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
     const int myq = qg * 32 + j;
 
-    if (MODE == 1 && tid == 0) *st_cnt = 0;
     const uint32_t ring_lds = lds_addr(ring), norm_lds = lds_addr(normring);
 
     // tiles of this workgroup: (blockIdx.x + it*grid) * tile_step
@@ -250,6 +248,20 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             }
         };
         constexpr int EPI_STEPS = 24;
+        // wave-private candidate staging: fill count (wave-uniform) and the flush to HBM.  The flush
+        // issues global atomics/stores, which are unordered against the DMA loads the counted
+        // vmcnt waits rely on, so it ends with a full drain of this wave's VMEM queue.
+        uint32_t wcnt = 0;
+        auto flush_wave = [&]() {
+            for (uint32_t e = (uint32_t)lane; e < wcnt; e += 64) {
+                const uint32_t slot = (uint32_t)wave * WCAP + e;
+                const uint32_t q = st_q[slot];
+                const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
+                if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[slot], st_key[slot]);
+            }
+            wcnt = 0;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        };
         // the rest: group minima (pass A) or candidate emission (pass B)
         auto epi_rest = [&](const float(&sv)[16], float best) {
             if constexpr (MODE == 2) {
@@ -283,33 +295,44 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             } else {
                 const bool lane_pass = COS ? (best >= tS) : (best <= tS);
                 if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) {
-                    bool direct = false;
+                    // Rare path.  Staging is wave-private and its fill count lives in a scalar
+                    // register: no LDS atomics, no barrier.  m16 = this lane's passing rows; each round
+                    // every lane with a bit left appends its lowest one at slot wcnt + (rank of the lane
+                    // in the ballot).  "reg r" is picked with a select chain (dynamic register indexing
+                    // would go through scratch).
+                    uint32_t m16 = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
-                        if (p) {
-                            // payload: int8 -> the EXACT integer dot (pass C needs no row re-read);
-                            //          f16  -> the scan key
-                            uint32_t payload;
-                            if constexpr (DT == PVS_I8)
-                                payload = (uint32_t)hold[r];
-                            else
-                                payload = __builtin_bit_cast(uint32_t, COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r]);
-                            const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
-                            const uint32_t pos = atomicAdd(st_cnt, 1u);
-                            if (pos < (uint32_t)LCAP) {
-                                st_row[pos] = row;
-                                st_key[pos] = payload;
-                                st_q[pos] = (uint32_t)myq;
-                            } else {  // staging full (very loose threshold): go to HBM directly
-                                const uint32_t gp = atomicAdd(&a.cand_cnt[myq], 1u);
-                                if (gp < a.cand_cap)
-                                    a.cand[(size_t)myq * a.cand_cap + gp] = make_uint2(row, payload);
-                                direct = true;
+                    for (int r = 0; r < 16; r++) m16 |= (COS ? (sv[r] >= tS) : (sv[r] <= tS)) ? (1u << r) : 0u;
+                    for (;;) {
+                        const bool has = m16 != 0;
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+                        if (bal == 0) break;
+                        const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
+                        if (wcnt + npass > (uint32_t)WCAP) flush_wave();
+                        const uint32_t r = has ? (uint32_t)__builtin_ctz(m16) : 0u;
+                        uint32_t payload = 0;
+                        if constexpr (DT == PVS_I8) {
+#pragma unroll
+                            for (uint32_t rr = 0; rr < 16; rr++) payload = (r == rr) ? (uint32_t)hold[rr] : payload;  // exact integer dot
+                        } else {
+                            float svr = 0.f, xr = 0.f;
+#pragma unroll
+                            for (uint32_t rr = 0; rr < 16; rr++) {
+                                svr = (r == rr) ? sv[rr] : svr;
+                                xr = (r == rr) ? xh[rr] : xr;
                             }
+                            payload = __builtin_bit_cast(uint32_t, COS ? -svr * qi.dscale : svr + qi.bb + qi.eR * xr);
                         }
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        if (has) {
+                            const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
+                            st_row[slot] = prev_row_base + (r & 3u) + 8u * (r >> 2);
+                            st_key[slot] = payload;
+                            st_q[slot] = (uint32_t)myq;
+                        }
+                        wcnt += npass;
+                        m16 &= m16 - 1u;
                     }
-                    if (__builtin_amdgcn_ballot_w64(direct) != 0) wait_vm<0>();  // stores are unordered vs loads: drain
                 }
             }
         };
@@ -378,25 +401,6 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                 prev_row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
                 prev_valid = true;
             }
-            if (MODE == 1) {
-                // flush checkpoint: uniform, because no wave appends between this barrier and its
-                // next epilogue
-                if ((tl % FLUSH_EVERY) == FLUSH_EVERY - 1) {
-                    wg_barrier();
-                    const uint32_t staged = *(volatile uint32_t *)st_cnt;
-                    if (staged >= (uint32_t)FLUSH_AT) {
-                        const uint32_t nst = staged < (uint32_t)LCAP ? staged : (uint32_t)LCAP;
-                        for (uint32_t e = tid; e < nst; e += 256) {
-                            const uint32_t q = st_q[e];
-                            const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
-                            if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[e], st_key[e]);
-                        }
-                        wg_barrier();
-                        if (tid == 0) *st_cnt = 0;
-                        wait_vm<0>();
-                    }
-                }
-            }
         }
         {  // drain: the last tile's epilogue
             float sv[16];
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             for (int m = 0; m < EPI_STEPS; m++) epi_micro(m, sv, best);
             epi_rest(sv, best);
         }
+        if (MODE == 1) flush_wave();
         wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
     }
 
@@ -413,15 +418,6 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * 16;
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = mins[r];
-    } else {
-        wg_barrier();
-        const uint32_t staged = *(volatile uint32_t *)st_cnt;
-        const uint32_t nst = staged < (uint32_t)LCAP ? staged : (uint32_t)LCAP;
-        for (uint32_t e = tid; e < nst; e += 256) {
-            const uint32_t q = st_q[e];
-            const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
-            if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[e], st_key[e]);
-        }
     }
 }
 
