@@ -628,7 +628,14 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         // pass A: strided sample of row tiles -> group minima -> threshold
-        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>(ix->n / 16, 32768));
+        // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
+        // candidates, and each emit costs a few hundred cycles, while pass A costs ~ n_sample/N of a
+        // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
+        // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
+        // holds ~k/frac rows: keep that 2.5x below its capacity.
+        double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
+        frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
+        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
         const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
