@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--dtype", choices=["i8", "f16"], default="i8")
     ap.add_argument("--metric", choices=["cosine", "l2"], default="cosine")
-    ap.add_argument("--inflight", type=int, default=2, help="search batches in flight (HIP streams)")
+    ap.add_argument("--inflight", type=int, default=2, help="search batches queued ahead of the one being waited for")
+    ap.add_argument("--streams", type=int, default=1, help="1: all batches on one HIP stream (default); >1: one stream per in-flight batch")
     ap.add_argument("--check-queries", type=int, default=2, help="queries verified against the CPU oracle over the full corpus")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=8)
@@ -174,6 +175,9 @@ def main():
     stage.free()
     log(f"shard rows [{r0}, {r1}) resident in HBM as {args.dtype} in {time.time() - t_build:.1f}s (scale={scale})")
 
+    if args.streams > 1:
+        ix.set_streams(args.streams)
+
     # ---------------------------------------------------------------- queries
     NQB = 4
     qbufs = []
@@ -289,7 +293,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} (BASELINE configs[2])",
                    "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
-                   "parallelism": f"row-shard x{world}", "exchange": gather_mode, "inflight": slots if (world == 1 or comm is not None) else 1},
+                   "parallelism": f"row-shard x{world}", "exchange": gather_mode, "streams": args.streams, "inflight": slots if (world == 1 or comm is not None) else 1},
         "roofline": roofline,
         "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries)},
     }

@@ -177,6 +177,10 @@ pvs_status pvs_search_device(pvs_index *idx, const void *d_queries, pvs_dtype qu
 pvs_status pvs_wait(pvs_index *idx, uint32_t ticket);
 pvs_status pvs_sync(pvs_index *idx);
 
+/* 1 (default): every search is queued on one HIP stream — batches run back to back, their
+ * scans never compete for CUs; > 1: each in-flight search gets its own stream. */
+pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
+
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort
  * (every row scored exactly, full device sort), 2 = filter scan only (error
  * instead of falling back).  For tests and profiling. */

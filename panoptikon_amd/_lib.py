@@ -75,6 +75,7 @@ SYMBOLS = {
     "pvs_search_device": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_wait": (_i32, [_vp, _u32]),
     "pvs_sync": (_i32, [_vp]),
+    "pvs_index_set_streams": (_i32, [_vp, _u32]),
     "pvs_index_set_path": (_i32, [_vp, _u32]),
     "pvs_score_all": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32]),
     "pvs_score_batch": (_i32, [_vp, _vp, _i32, _u32, _i32, _vp, _i32]),

@@ -71,7 +71,9 @@ struct TimedSpan {
 struct SearchCtx {
     std::vector<TimedSpan> spans;       // recorded during the current search
     std::vector<TimedSpan> span_pool;   // recycled events
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream this context launches on (shared or own)
+    hipStream_t own_stream = nullptr;
+    hipEvent_t done = nullptr;         // recorded after the last launch of a search
     bool busy = false;
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
@@ -146,6 +148,8 @@ struct pvs_index {
     std::mutex mu;
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
+    hipStream_t search_stream = nullptr;
+    bool multi_stream = false;
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     bool profiling = false;
     std::mutex prof_mu;
@@ -216,6 +220,7 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_out_dist);
     hipFree(c.d_out_count);
     pvs_dense_release(c.dense);
+    if (c.done) hipEventDestroy(c.done);
     hipFree(c.d_loc_ids);
     hipFree(c.d_all_ids);
     hipFree(c.d_loc_dist);
@@ -224,12 +229,21 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_all_cnt);
     hipFree(c.d_all_flags);
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
-    if (c.stream) hipStreamDestroy(c.stream);
+    if (c.own_stream) hipStreamDestroy(c.own_stream);
     c = SearchCtx();
 }
 
 static pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs) {
-    if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    // Searches are queued on ONE stream by default: consecutive batches run back to back with no
+    // host turnaround between them and their scan kernels never compete for the same CUs.
+    // pvs_index_set_streams(idx, n > 1) gives every context its own stream instead.
+    if (ix->multi_stream) {
+        if (!c.own_stream) HIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+        c.stream = c.own_stream;
+    } else {
+        c.stream = ix->search_stream;
+    }
+    if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     if (!c.d_qmat) {
         HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_MAX_BATCH * ix->dim * 4));
         HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_MAX_BATCH * ix->stride));
@@ -289,6 +303,7 @@ PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **o
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) ix->n_cu = p.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ix->admin_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->search_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ix;
         return pvs_fail(PVS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -364,6 +379,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_ids);
     pvs_group_work_release(ix->gwork);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
+    if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     delete ix;
 }
 
@@ -470,6 +486,13 @@ PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t 
     float s = 0.f;
     PVS_TRY(pvs_artifact_scale(artifact, len, &s));
     return pvs_index_set_scale(ix, s);
+}
+
+PVS_EXPORT pvs_status pvs_index_set_streams(pvs_index *ix, uint32_t n_streams) {
+    if (!ix || n_streams == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "bad stream count");
+    PVS_TRY(pvs_sync(ix));
+    ix->multi_stream = n_streams > 1;
+    return PVS_OK;
 }
 
 PVS_EXPORT pvs_status pvs_index_set_path(pvs_index *ix, uint32_t path) {
@@ -595,6 +618,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         HIP_TRY(hipMemsetAsync(d_out_count, 0, 4 * (size_t)batch, c.stream));
         HIP_TRY(hipMemsetAsync(d_out_ids, 0xff, 8 * (size_t)batch * k, c.stream));
         HIP_TRY(pvs_launch_fill_f32(d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c.stream));
+        HIP_TRY(hipEventRecord(c.done, c.stream));
         return PVS_OK;
     }
     HIP_TRY(hipMemsetAsync(c.d_need_dense, 0, 4 * (size_t)batch, c.stream));
@@ -682,6 +706,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         span_end(ix, c);
     }
     if (fast) HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipEventRecord(c.done, c.stream));
     return PVS_OK;
 }
 
@@ -751,7 +776,7 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
     }
     if (st == PVS_OK) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
     if (st == PVS_OK) {
-        hipError_t e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipEventSynchronize(c->done);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     }
     if (st == PVS_OK) spans_collect(ix, *c);
@@ -808,7 +833,7 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     if (!c->busy || !c->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
     HIP_TRY(hipSetDevice(ix->device));
     pvs_status st = PVS_OK;
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = hipEventSynchronize(c->done);
     if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     if (st == PVS_OK) spans_collect(ix, *c);
     if (st == PVS_OK && c->p_comm) {
@@ -892,6 +917,7 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
                                        c->d_all_cnt, c->d_all_flags, elems, batch, c->stream));
         HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, c->stream));
         HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->done, c->stream));
         c->pending = true;
         c->p_comm = comm;
         c->p_queries = d_queries;

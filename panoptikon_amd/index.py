@@ -163,6 +163,9 @@ class VectorIndex:
     def sync(self):
         L.check(L.lib().pvs_sync(self._h))
 
+    def set_streams(self, n: int):
+        L.check(L.lib().pvs_index_set_streams(self._h, n))
+
     def set_path(self, path: int):
         L.check(L.lib().pvs_index_set_path(self._h, path))
 
