@@ -603,7 +603,7 @@ static pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries,
     const size_t qesz = qdtype == PVS_I8 ? 1 : 4;
     const uint8_t *qsrc = (const uint8_t *)d_queries + (size_t)qoff * ix->dim * qesz;
     HIP_TRY(pvs_launch_prep_queries((int)ix->dtype, qdtype, qsrc, nb, batch_pad, ix->dim, ix->stride, ix->scale, metric, c.d_qmat,
-                                    c.d_qexact, c.d_qinfo, c.stream));
+                                    c.d_qexact, c.d_qinfo, c.d_cand_cnt, c.d_need_dense + qoff, c.stream));
     return PVS_OK;
 }
 
@@ -621,7 +621,6 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         HIP_TRY(hipEventRecord(c.done, c.stream));
         return PVS_OK;
     }
-    HIP_TRY(hipMemsetAsync(c.d_need_dense, 0, 4 * (size_t)batch, c.stream));
     for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
         const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
         const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
@@ -671,8 +670,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
         HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
-        // pass B: every row once
-        HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4 * PVS_MAX_BATCH, c.stream));
+        // pass B: every row once (candidate counters were zeroed by the prep kernel)
         a.mode = 1;
         a.tile_step = 1;
         const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;

@@ -22,7 +22,8 @@ hipError_t pvs_launch_iota_ids(int64_t *ids, uint64_t n, int64_t base, hipStream
 //   qinfo [batch_pad]         per-query constants (padding queries get NaN-proof zeros).
 hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *queries, uint32_t batch,
                                    uint32_t batch_pad, uint32_t dim, uint32_t stride, float scale,
-                                   int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, hipStream_t s);
+                                   int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *cand_cnt,
+                                   uint32_t *need_dense, hipStream_t s);
 
 // exact per-row distance (the reference's dist_{cte}.d), one lane per row
 hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
