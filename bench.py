@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the kernels with HIP events (roofline fields become 0)")
     ap.add_argument("--force-comm", action="store_true", help="use the RCCL shard-merge path even with one rank (testing)")
     return ap.parse_args()
 
@@ -130,6 +131,11 @@ def device_sync(pvs, device):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE JSON line, but gloo and RCCL print banners on fd 1 when they
+    # initialise: keep a private handle on the real stdout and point fd 1 at stderr for the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     dist = Dist(args.gpus)
     import panoptikon_amd as pvs
     from panoptikon_amd import _lib as L
@@ -208,6 +214,7 @@ def main():
             log(f"in-library RCCL unavailable ({e}); falling back to a host gather over gloo")
             gather_mode = "gloo-host-gather"
 
+
     pending = []
 
     def step_sharded(i):
@@ -246,7 +253,7 @@ def main():
     drain()
     device_sync(pvs, device)
     dist.barrier()
-    ix.set_profiling(True)
+    ix.set_profiling(not args.no_kernel_events)
     ix.profile(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -352,7 +359,8 @@ def main():
                 "all_cores": {"value": round(Q / dt2 * S / N, 4), "cores": allc, "seconds": round(dt2, 2)},
             }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
     if comm is not None:
         lib.pvs_comm_destroy(comm)
     ix.close()
