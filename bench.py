@@ -141,9 +141,9 @@ def main():
     from panoptikon_amd import _lib as L
 
     rank, world = dist.rank, dist.world
-    device = dist.local_rank if world > 1 else 0
     if pvs.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950); libpvs has no CPU path")
+    device = (dist.local_rank % pvs.device_count()) if world > 1 else 0
     dtype = pvs.I8 if args.dtype == "i8" else pvs.F16
     metric = pvs.COSINE if args.metric == "cosine" else pvs.L2
     esz = 1 if dtype == pvs.I8 else 2
@@ -306,7 +306,46 @@ def main():
     }
 
     # ------------------------------------------------- verification (untimed)
-    if rank == 0 and not args.no_verify:
+    if world > 1 and not args.no_verify:
+        # every rank: oracle page over ITS shard for a few queries -> gathered over gloo -> host merge
+        # = the oracle's page over the whole corpus; compared with what the GPUs returned.
+        import oracle as orc
+
+        odt = orc.I8 if dtype == pvs.I8 else orc.F16
+        omet = orc.COSINE if metric == pvs.COSINE else orc.L2
+        nq = max(1, min(args.check_queries, B))
+        qf32 = qbufs[0].to_numpy(np.float32, (B, D))
+        qh = (orc.quantize_int8(qf32, scale) if dtype == pvs.I8 else qf32)[:nq]
+        oi, od, oc = outs[0]
+        if comm is not None:
+            L.check(lib.pvs_search_sharded(ix._h, comm, qbufs[0].ptr, L.F32, B, K, metric, oi.ptr, od.ptr, oc.ptr))
+            gi, gd = oi.to_numpy(np.int64, (B, K))[:nq], od.to_numpy(np.float32, (B, K))[:nq]
+        else:
+            gi, gd, _ = step_sharded(0)
+            gi, gd = gi[:nq], gd[:nq]
+        threads = max(1, orc.max_threads() // world)
+        best_i = np.full((nq, K), -1, np.int64)
+        best_d = np.full((nq, K), np.nan, np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        acc_i = [np.empty(0, np.int64) for _ in range(nq)]
+        acc_d = [np.empty(0, np.float32) for _ in range(nq)]
+        for off in range(0, n_local, args.chunk_rows):
+            m = min(args.chunk_rows, n_local - off)
+            rows = ix.read_rows(off, m)
+            ci, cd = orc.search(odt, omet, rows, qh, K, ids=np.arange(r0 + off, r0 + off + m, dtype=np.int64), threads=threads)
+            for q in range(nq):
+                acc_i[q], acc_d[q] = orc.topk(np.concatenate([acc_d[q], cd[q]]), K, ids=np.concatenate([acc_i[q], ci[q]]))
+        for q in range(nq):
+            c = len(acc_i[q])
+            best_i[q, :c], best_d[q, :c], cnt[q] = acc_i[q], acc_d[q], c
+        ei, ed, ec = pvs.merge_shard_pages(best_i, best_d, cnt, dist.all_gather_np, K)
+        if rank == 0:
+            hits = sum(len(set(gi[q].tolist()) & set(ei[q, : ec[q]].tolist())) for q in range(nq))
+            exact = bool(np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32)))
+            result["recall_at_k"] = round(hits / (nq * min(K, N)), 6)
+            result["parity"] = {"checked_queries": nq, "oracle_rows": N, "ids_and_distances_bit_exact": exact,
+                                "how": "per-rank oracle pages over each shard, gathered over gloo and merged on the host"}
+    if rank == 0 and not args.no_verify and world == 1:
         import oracle as orc
 
         odt = orc.I8 if dtype == pvs.I8 else orc.F16
@@ -315,7 +354,7 @@ def main():
         # the batch the GPU answers, as the oracle sees it
         qf32 = qbufs[0].to_numpy(np.float32, (B, D))[:nq]
         qh = orc.quantize_int8(qf32, scale) if dtype == pvs.I8 else qf32
-        if world == 1:
+        if True:
             gi, gd, gc = ix.search(qf32, K, metric)
             threads = orc.max_threads()
             best_i = [np.empty(0, np.int64) for _ in range(nq)]
@@ -336,9 +375,6 @@ def main():
             result["recall_at_k"] = round(hits / (nq * min(K, n_local)), 6)
             result["parity"] = {"checked_queries": nq, "oracle_rows": n_local, "ids_and_distances_bit_exact": bool(exact),
                                 "oracle_threads": threads, "oracle_seconds": round(time.time() - t_or, 1)}
-        else:
-            result["parity"] = {"note": "full-corpus oracle check runs at --gpus 1; N>1 relies on the merge tests"}
-
         if not args.no_cpu_baseline and world == 1:
             S = min(args.cpu_sample_rows, n_local)
             Q = min(args.cpu_sample_queries, B)
