@@ -379,3 +379,108 @@ def test_similar_to_matches_self_join(pvs, dtype):
     with pytest.raises(pvs.PvsError):
         ix.similar_to([4], 5)  # not a row id of this index
     ix.close()
+
+
+# ------------------------------------------------------------ fallback / edge paths
+def _check(pvs, ix, dt, metric, hc, hq, k, ids=None):
+    exp = orc.search(dt, metric, hc, hq, k, ids=ids, threads=8)
+    gi, gd, gc = ix.search(hq, k, metric)
+    n = exp[0].shape[1]
+    assert gc.tolist() == [n] * exp[0].shape[0]
+    assert np.array_equal(gi[:, :n], exp[0])
+    a, b = gd[:, :n], exp[1]
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+
+
+def test_massive_ties_fall_back_to_dense(pvs):
+    # thousands of identical rows: more survivors than the exact-rerank stage holds -> dense path
+    base = unit_rows(51, 64, 768)
+    rows = np.concatenate([np.repeat(base[:1], 6000, axis=0), base, np.repeat(base[1:2], 3000, axis=0)])
+    scale = orc.compute_int8_scale(rows)
+    for dt in (pvs.I8, pvs.F16):
+        ix = make_index(pvs, dt, rows, scale)
+        hc = host_corpus(dt, rows, scale)
+        hq = orc.quantize_int8(base[:1] * 0.7 + base[2:3] * 0.3, scale) if dt == pvs.I8 else (base[:1] * 0.7 + base[2:3] * 0.3)
+        _check(pvs, ix, dt, pvs.COSINE, hc, hq, 10)
+        _check(pvs, ix, dt, pvs.L2, hc, hq, 100)
+        assert ix.stats().dense_queries >= 1, "ties beyond the survivor capacity must be answered by the dense path"
+        ix.close()
+
+
+def test_unrepresentative_sample_overflows_to_dense(pvs):
+    # pass A samples a strided subset of workgroup tiles (for one query: 128-row tiles, stride
+    # n_tiles // 256); put every near neighbour in the unsampled tiles so the threshold is far too
+    # loose and the candidate lists overflow -> dense path, still exact
+    n, dim = 700_000, 64
+    rows = orc.synth_rows(5, 0, n, dim)
+    q = orc.synth_rows(6, 0, 1, dim)[0]
+    n_wgtiles = (n + 127) // 128
+    step = max(1, n_wgtiles // 256)
+    near = ((np.arange(n) // 128) % step) != 0
+    noise = orc.synth_rows(7, 0, n, dim)
+    rows[near] = (q[None, :] + 0.05 * noise[near]).astype(np.float32)
+    rows[~near] = -rows[~near] * np.sign(rows[~near] @ q)[:, None]  # sampled tiles: anti-correlated rows
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    hc = orc.quantize_int8(rows, scale)
+    hq = orc.quantize_int8(q[None, :], scale)
+    _check(pvs, ix, pvs.I8, pvs.COSINE, hc, hq, 100)
+    st = ix.stats()
+    assert st.dense_queries == 1, "candidate overflow must hand the query to the dense path"
+    ix.close()
+
+
+def test_large_k_many_chunks_odd_shapes(pvs):
+    rng = np.random.default_rng(3)
+    # k beyond the filter path's page size -> dense path
+    rows = unit_rows(61, 5000, 512)
+    scale = orc.compute_int8_scale(rows)
+    q = orc.synth_rows(62, 0, 2, 512)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    _check(pvs, ix, pvs.I8, pvs.COSINE, orc.quantize_int8(rows, scale), orc.quantize_int8(q, scale), 3000)
+    _check(pvs, ix, pvs.I8, pvs.L2, orc.quantize_int8(rows, scale), orc.quantize_int8(q, scale), 1)
+    ix.close()
+    # 300 queries = three scan chunks (128 + 128 + 44)
+    rows = unit_rows(63, 6000, 768)
+    q = orc.synth_rows(64, 0, 300, 768)
+    ix = make_index(pvs, pvs.F16, rows)
+    _check(pvs, ix, pvs.F16, pvs.COSINE, rows.astype(np.float16), q, 20)
+    ix.close()
+    # dims that are not multiples of the k-slab / 16-byte chunk; tiny and ragged row counts
+    for dt, dim in ((pvs.I8, 100), (pvs.I8, 1000), (pvs.I8, 1024), (pvs.F16, 200), (pvs.F16, 384), (pvs.F16, 1024), (pvs.F32, 77)):
+        for n in (1, 31, 33, 2500):
+            rows = unit_rows(65 + dim, n, dim)
+            scale = orc.compute_int8_scale(rows)
+            q = orc.synth_rows(66, 0, 3, dim)
+            ix = make_index(pvs, dt, rows, scale)
+            hc = host_corpus(dt, rows, scale)
+            hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+            _check(pvs, ix, dt, pvs.COSINE, hc, hq, 7)
+            _check(pvs, ix, dt, pvs.L2, hc, hq, 50)
+            ix.close()
+
+
+def test_zero_query_and_saturated_codes(pvs):
+    # zero query: every cosine distance is NULL -> rows come back in id order, NaN distances
+    rows = unit_rows(71, 400, 768)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    gi, gd, gc = ix.search(np.zeros((1, 768), np.int8), 10, pvs.COSINE)
+    assert gc[0] == 10 and gi[0].tolist() == list(range(10)) and np.isnan(gd[0]).all()
+    ix.close()
+    # saturated +-127/-128 codes at dim 1024: the L2 sum of squares leaves the exactly representable
+    # range (> 2^24), so the reference's sequential f32 rounding matters -> in-order recompute
+    rng = np.random.default_rng(8)
+    codes = rng.choice(np.array([-128, -127, 127], np.int8), size=(3000, 1024))
+    qcodes = rng.choice(np.array([-128, 127], np.int8), size=(4, 1024))
+    ix = pvs.VectorIndex(pvs.I8, 1024)
+    ix.set_scale(1.0)
+    ix.add(codes)
+    assert int(((codes[0].astype(np.int64) - qcodes[0].astype(np.int64)) ** 2).sum()) > 2**24
+    _check(pvs, ix, pvs.I8, pvs.L2, codes, qcodes, 25)
+    _check(pvs, ix, pvs.I8, pvs.COSINE, codes, qcodes, 25)
+    got = ix.score_batch(qcodes, pvs.L2)
+    for qq in range(4):
+        assert np.array_equal(got[:, qq].view(np.uint32), orc.score_all(orc.I8, orc.L2, codes, qcodes[qq]).view(np.uint32))
+    ix.close()
