@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--dtype", choices=["i8", "f16"], default="i8")
+    ap.add_argument("--dtype", choices=["i8", "f16", "f32"], default="i8")
     ap.add_argument("--metric", choices=["cosine", "l2"], default="cosine")
     ap.add_argument("--inflight", type=int, default=2, help="search batches queued ahead of the one being waited for")
     ap.add_argument("--streams", type=int, default=1, help="1: all batches on one HIP stream (default); >1: one stream per in-flight batch")
@@ -144,9 +144,9 @@ def main():
     if pvs.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950); libpvs has no CPU path")
     device = (dist.local_rank % pvs.device_count()) if world > 1 else 0
-    dtype = pvs.I8 if args.dtype == "i8" else pvs.F16
+    dtype = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[args.dtype]
     metric = pvs.COSINE if args.metric == "cosine" else pvs.L2
-    esz = 1 if dtype == pvs.I8 else 2
+    esz = {pvs.I8: 1, pvs.F16: 2, pvs.F32: 4}[dtype]
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     r0, r1 = pvs.shard_range(N, world, rank)
     n_local = r1 - r0
@@ -272,7 +272,7 @@ def main():
     bytes_per_launch = n_local * D * esz  # algorithmic bytes: each corpus component read once per batch
     achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if prof.scan_launches else 0.0
     ops_per_launch = 2.0 * n_local * D * B
-    mfma_peak = I8_MFMA_PEAK_TOPS if dtype == pvs.I8 else F16_MFMA_PEAK_TFLOPS
+    mfma_peak = I8_MFMA_PEAK_TOPS if dtype == pvs.I8 else F16_MFMA_PEAK_TFLOPS  # f32 rows run as bf16 on the matrix core
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -311,7 +311,7 @@ def main():
         # = the oracle's page over the whole corpus; compared with what the GPUs returned.
         import oracle as orc
 
-        odt = orc.I8 if dtype == pvs.I8 else orc.F16
+        odt = {pvs.I8: orc.I8, pvs.F16: orc.F16, pvs.F32: orc.F32}[dtype]
         omet = orc.COSINE if metric == pvs.COSINE else orc.L2
         nq = max(1, min(args.check_queries, B))
         qf32 = qbufs[0].to_numpy(np.float32, (B, D))
@@ -348,7 +348,7 @@ def main():
     if rank == 0 and not args.no_verify and world == 1:
         import oracle as orc
 
-        odt = orc.I8 if dtype == pvs.I8 else orc.F16
+        odt = {pvs.I8: orc.I8, pvs.F16: orc.F16, pvs.F32: orc.F32}[dtype]
         omet = orc.COSINE if metric == pvs.COSINE else orc.L2
         nq = max(1, min(args.check_queries, B))
         # the batch the GPU answers, as the oracle sees it

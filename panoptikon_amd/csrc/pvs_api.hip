@@ -580,7 +580,6 @@ static pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype 
 
 static bool fast_path_ok(const pvs_index *ix, uint32_t k) {
     if (ix->forced_path == 1) return false;
-    if (ix->dtype == PVS_F32) return false;
     if (!pvs_scan_supported((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES)) return false;
     if (k > PVS_MAX_K) return false;
     return ix->n > 0;

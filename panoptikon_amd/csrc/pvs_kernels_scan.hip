@@ -9,6 +9,8 @@
 bool pvs_scan_supported(int dtype, uint32_t kslabs) {
     if (dtype == PVS_I8) return kslabs >= 1 && kslabs <= 4;
     if (dtype == PVS_F16) return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8;
+    if (dtype == PVS_F32)
+        return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 12 || kslabs == 16;
     return false;
 }
 uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return 32u * (4u / qgroups); }
@@ -65,6 +67,10 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     else if (a.dtype == PVS_F16)
         e = a.kslabs <= 4 ? pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                           : pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+    else if (a.dtype == PVS_F32)
+        e = a.kslabs <= 4   ? pvs_scan_dispatch_f32_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+            : a.kslabs <= 8 ? pvs_scan_dispatch_f32_mid(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+                            : pvs_scan_dispatch_f32_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     if (e == hipSuccess && k.dbg_out && a.grid <= 4096) DbgPrint::run(k.dbg_out, a.grid, s);
     return e;
 }
@@ -368,6 +374,8 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute((const void *)k_finalize<PVS_I8>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_finalize<PVS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_finalize<PVS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
@@ -376,7 +384,7 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     else if (f.dtype == PVS_F16)
         hipLaunchKernelGGL(k_finalize<PVS_F16>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
     else
-        return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_finalize<PVS_F32>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
     return hipGetLastError();
 }
 

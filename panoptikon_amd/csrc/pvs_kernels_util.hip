@@ -307,21 +307,28 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
             s_amax = m;
         }
         __syncthreads();
+        // exact power-of-two prescale of the scan operand: the largest |q_i| lands in [2^13, 2^14)
+        // for an f16 image (away from overflow and from the subnormal range), in [1/2, 1) for a
+        // bf16 image (f32 index; away from the subnormal range the matrix core may flush)
+        int e = 0;
+        if (s_amax > 0.f) {
+            int x;
+            (void)frexpf(s_amax, &x);
+            e = (index_dtype == PVS_F16 ? 14 : 0) - x;
+            if (e > 100) e = 100;
+            if (e < -100) e = -100;
+        }
+        dscale = ldexpf(1.0f, -e);
         if (index_dtype == PVS_F16) {
-            // exact power-of-two prescale so the largest |q_i| lands in [2^13, 2^14): keeps the
-            // f16 image of the query away from overflow and from the subnormal range
-            int e = 0;
-            if (s_amax > 0.f) {
-                int x;
-                (void)frexpf(s_amax, &x);
-                e = 14 - x;
-                if (e > 100) e = 100;
-                if (e < -100) e = -100;
-            }
-            dscale = ldexpf(1.0f, -e);
             for (uint32_t i = tid; i < dim; i += 256) {
                 _Float16 h = (_Float16)ldexpf(q[i], e);
                 *(uint16_t *)(mrow + 2 * (uint64_t)i) = __builtin_bit_cast(uint16_t, h);
+            }
+        } else {
+            for (uint32_t i = tid; i < dim; i += 256) {
+                uint32_t u = __builtin_bit_cast(uint32_t, ldexpf(q[i], e));
+                if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+                *(uint16_t *)(mrow + 2 * (uint64_t)i) = (uint16_t)(u >> 16);
             }
         }
     }
@@ -370,9 +377,10 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         qi.pad0 = 0.f;
         qi.pad1 = 0.f;
         // Error budget of the scan key: f32 accumulation of K terms is within
-        // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|.
+        // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|;
+        // bf16 images of both the row and the query (f32 index) add (2^-8 + 2^-18) |a||q|.
         const float acc = (float)dim * 6.0e-8f;
-        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : 0.0f;
+        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 3.92e-3f : 0.0f;
         if (metric == PVS_COSINE) {
             qi.eA = (qround + 2.0f * acc + 4.0e-6f) * qi.qn;
             qi.eC = 0.f;

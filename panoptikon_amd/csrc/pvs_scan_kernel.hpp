@@ -34,6 +34,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 // LDS-DMA issued from inline asm: hipcc models the builtin form as an LDS store that may
 // alias every later ds_read and drains vmcnt(0) in front of them (two full pipeline drains
@@ -86,6 +87,27 @@ struct Acc<PVS_F16> {
     }
     __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
 };
+
+// f32 rows are narrowed to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way from LDS to
+// the matrix core: the filter only needs an interval around the key (|dot error| <= 2^-8 |a||q|,
+// QInfo.eA/eR), the survivors are rescored from the f32 rows in the reference's order.
+template <>
+struct Acc<PVS_F32> {
+    using type = v16f;
+    __device__ static inline type mfma(v4i a, v4i b, type c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+    }
+    __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
+};
+__device__ static inline int cvt_pk_bf16(int lo, int hi) {
+    int r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// MFMA steps per 256-B row slab: 8 for 1- and 2-byte elements (32 B of k per step and half-wave),
+// 4 for f32 (two 16-B pieces per step and half-wave)
+template <int DT>
+constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 
 // Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
 // vmcnt wait + one s_barrier per chunk.  For the headline shape (768-B rows, 128 queries) a
@@ -141,11 +163,14 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
 
     if (n_my > 0) {
         // ---- query fragments: resident in registers for the whole kernel
-        v4i qf[KSLABS * 8];
+        // (f32 index: the operand row holds the bf16 image of the query in its first half)
+        constexpr int SPS = steps_per_slab<DT>();
+        constexpr int NQF = KSLABS * SPS;
+        v4i qf[NQF];
         {
             const uint8_t *qrow = a.qmat + (size_t)myq * a.stride;
 #pragma unroll
-            for (int x = 0; x < KSLABS * 8; x++) qf[x] = *(const v4i *)(qrow + (x >> 3) * 256 + ((x & 7) * 2 + h) * 16);
+            for (int x = 0; x < NQF; x++) qf[x] = *(const v4i *)(qrow + (x * 2 + h) * 16);
         }
         QInfo qi = a.qinfo[myq];
         float thr = MODE == 1 ? a.thr[myq] : 0.f;
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         // (it cannot see the asm waits), otherwise it re-emits partial vmcnt waits for them
         // inside the main loop and throttles the DMA prefetch depth.
 #pragma unroll
-        for (int x = 0; x < KSLABS * 8; x++) asm volatile("" : "+v"(qf[x]));
+        for (int x = 0; x < NQF; x++) asm volatile("" : "+v"(qf[x]));
         asm volatile("" : "+v"(qi.bb), "+v"(qi.dscale), "+v"(qi.eA), "+v"(qi.eR), "+v"(thr));
         wait_vm<0>();
         // Filter tests folded into one per-lane constant (key/err algebra of DESIGN.md §5):
@@ -193,6 +218,17 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             const uint64_t wt = (uint64_t)(blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step;
             is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
             is_aux = a.aux + wt * SLAB_ROWS;
+            if constexpr (DT == PVS_F32) {
+                // the 16-chunk unroll of the widest f32 instance makes hipcc lose track of the uniformity of
+                // these two and hand VGPRs to the asm's SGPR operands; pin them scalar
+                auto uni = [](const void *p) {
+                    const uint64_t v = (uint64_t)(uintptr_t)p;
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+                    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+                };
+                is_base = (const uint8_t *)uni(is_base);
+                is_aux = (const float *)uni(is_aux);
+            }
             is_lds = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (2 * RT * 1024);
             is_norm = norm_lds + (uint32_t)i_slot * 1024 + (uint32_t)wave * 256;
             if (++i_ck == CPT) {
@@ -357,21 +393,40 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                 //   step t:  LDS read of fragment t+PF | MFMA t | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
-                constexpr int NF = SPB * 8, PF = 4;
+                constexpr int NF = SPB * SPS, PF = 4;
                 v4i af[NF];
+                v4i raw[DT == PVS_F32 ? NF : 1][2];  // f32: the two 16-B pieces of a step, before narrowing
+                (void)raw;
                 auto frag = [&](int t) {
-                    return *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
+                    if constexpr (DT == PVS_F32) {
+                        const uint8_t *sb = cb + (t >> 2) * SLAB_BYTES;
+                        const uint32_t c0 = (uint32_t)(4 * (t & 3) + 2 * h);
+                        raw[t][0] = *(const v4i *)(sb + ((c0 ^ jx) << 4));
+                        raw[t][1] = *(const v4i *)(sb + (((c0 + 1) ^ jx) << 4));
+                    } else {
+                        af[t] = *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
+                    }
+                };
+                auto narrow = [&](int t) {  // VALU work placed behind MFMA t-1
+                    if constexpr (DT == PVS_F32) {
+                        af[t][0] = cvt_pk_bf16(raw[t][0][0], raw[t][0][1]);
+                        af[t][1] = cvt_pk_bf16(raw[t][0][2], raw[t][0][3]);
+                        af[t][2] = cvt_pk_bf16(raw[t][1][0], raw[t][1][1]);
+                        af[t][3] = cvt_pk_bf16(raw[t][1][2], raw[t][1][3]);
+                    }
                 };
 #pragma unroll
-                for (int t = 0; t < PF && t < NF; t++) af[t] = frag(t);
+                for (int t = 0; t < PF && t < NF; t++) frag(t);
+                narrow(0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NF; t++) {
-                    if (t + PF < NF) af[t + PF] = frag(t + PF);
+                    if (t + PF < NF) frag(t + PF);
                     if (t & 1)
                         acc1 = A::mfma(af[t], qf[ck * NF + t], acc1);
                     else
                         acc = A::mfma(af[t], qf[ck * NF + t], acc);
+                    if (t + 1 < NF) narrow(t + 1);
 #pragma unroll
                     for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
                     if (ck == 0) {

@@ -119,6 +119,11 @@ CASES = [
     ("f16", "cosine", 6000, 1024, 128, 20),
     ("f32", "cosine", 10000, 512, 1, 10),  # BASELINE configs[0]
     ("f32", "l2", 4000, 768, 3, 100),
+    ("f32", "cosine", 20000, 768, 128, 100),
+    ("f32", "l2", 9000, 1024, 40, 10),
+    ("f32", "cosine", 7000, 256, 64, 50),
+    ("f32", "l2", 6000, 384, 33, 20),
+    ("f32", "cosine", 5000, 128, 5, 10),
 ]
 
 
@@ -140,7 +145,7 @@ def test_search_matches_oracle(pvs, dtype, metric, n, dim, batch, k, path):
     got = ix.search(queries, k, m)  # f32 queries: the int8 index quantizes them on the device
     assert_same_page(got, exp)
     st = ix.stats()
-    if path == "auto" and dt != pvs.F32:
+    if path == "auto":
         assert st.fast_queries == batch and st.dense_queries == 0, "filter-scan path must serve these shapes"
     if dt == pvs.I8:  # pre-quantized codes (QuantResolved.query_quant) give the same page
         assert_same_page(ix.search(hq, k, m), exp)
@@ -448,7 +453,7 @@ def test_large_k_many_chunks_odd_shapes(pvs):
     _check(pvs, ix, pvs.F16, pvs.COSINE, rows.astype(np.float16), q, 20)
     ix.close()
     # dims that are not multiples of the k-slab / 16-byte chunk; tiny and ragged row counts
-    for dt, dim in ((pvs.I8, 100), (pvs.I8, 1000), (pvs.I8, 1024), (pvs.F16, 200), (pvs.F16, 384), (pvs.F16, 1024), (pvs.F32, 77)):
+    for dt, dim in ((pvs.I8, 100), (pvs.I8, 1000), (pvs.I8, 1024), (pvs.F16, 200), (pvs.F16, 384), (pvs.F16, 1024), (pvs.F32, 77), (pvs.F32, 200), (pvs.F32, 1000)):
         for n in (1, 31, 33, 2500):
             rows = unit_rows(65 + dim, n, dim)
             scale = orc.compute_int8_scale(rows)
