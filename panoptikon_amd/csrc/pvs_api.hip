@@ -149,6 +149,7 @@ struct pvs_index {
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
     hipStream_t search_stream = nullptr;
+    hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     bool profiling = false;
@@ -304,6 +305,7 @@ PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **o
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) ix->n_cu = p.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ix->admin_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->search_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ix;
         return pvs_fail(PVS_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -380,6 +382,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     pvs_group_work_release(ix->gwork);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
+    if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
     delete ix;
 }
 
@@ -843,18 +846,19 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
             if (c->p_fast && ix->n)
                 st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->d_loc_ids, c->d_loc_dist,
                                       c->d_loc_cnt);
+            // (search_fallbacks drained c->stream; the redo's collective goes where all the others go)
+            hipStream_t cs = ix->multi_stream ? ix->comm_stream : c->stream;
             if (st == PVS_OK) {
-                hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, c->stream);
+                hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
             }
             if (st == PVS_OK)
                 st = pvs_comm_gather_pages_(c->p_comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids,
-                                            c->d_all_dist, c->d_all_cnt, c->d_all_flags, (uint64_t)c->p_batch * c->p_k, c->p_batch,
-                                            c->stream);
+                                            c->d_all_dist, c->d_all_cnt, c->d_all_flags, (uint64_t)c->p_batch * c->p_k, c->p_batch, cs);
             if (st == PVS_OK) {
                 hipError_t e2 = pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, c->sh_world, c->p_batch, c->p_k,
-                                                 c->p_final_ids, c->p_final_dist, c->p_final_count, c->stream);
-                if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+                                                 c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "sharded redo: %s", hipGetErrorString(e2));
             }
         }
@@ -909,12 +913,20 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
         bool fast = false;
         // 1. this shard's page (row ids in the index are global ids)
         PVS_TRY(search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &fast));
-        // 2. one grouped all-gather over xGMI, 3. merge on every rank — same stream, no host sync
+        // 2. one grouped all-gather over xGMI, 3. merge on every rank — stream-ordered, no host sync.
+        // With one stream per context (pvs_index_set_streams) the local scans of several searches
+        // overlap, but their collectives still go out on ONE stream in program order: a communicator
+        // is never driven from two streams at once.
+        hipStream_t cs = c->stream;
+        if (ix->multi_stream) {
+            cs = ix->comm_stream;
+            HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
+        }
         PVS_TRY(pvs_comm_gather_pages_(comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids, c->d_all_dist,
-                                       c->d_all_cnt, c->d_all_flags, elems, batch, c->stream));
-        HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(c->done, c->stream));
+                                       c->d_all_cnt, c->d_all_flags, elems, batch, cs));
+        HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
+        HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipEventRecord(c->done, cs));
         c->pending = true;
         c->p_comm = comm;
         c->p_queries = d_queries;
