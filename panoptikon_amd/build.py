@@ -30,6 +30,7 @@ SOURCES = [
     "pvs_scan_f32_mid.hip",
     "pvs_scan_f32_large.hip",
     "pvs_dense.hip",
+    "pvs_dense_exact.hip",
     "pvs_groups.hip",
     "pvs_comm.hip",
     "pvs_host.cpp",

@@ -77,6 +77,7 @@ struct SearchCtx {
     bool busy = false;
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
+    float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
     uint8_t *d_qexact = nullptr;  // [MAX_BATCH][dim*4]
     QInfo *d_qinfo = nullptr;     // [MAX_BATCH]
     float *d_thr = nullptr;       // [MAX_BATCH]
@@ -209,6 +210,7 @@ static void ctx_release(SearchCtx &c) {
     c.span_pool.clear();
     hipFree(c.d_qin);
     hipFree(c.d_qmat);
+    hipFree(c.d_qpad);
     hipFree(c.d_qexact);
     hipFree(c.d_qinfo);
     hipFree(c.d_thr);
@@ -248,6 +250,7 @@ static pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint3
     if (!c.d_qmat) {
         HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_MAX_BATCH * ix->dim * 4));
         HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_MAX_BATCH * ix->stride));
+        HIP_TRY(hipMalloc((void **)&c.d_qpad, pvs_dense_exact_scratch_bytes(ix->stride, ix->esz)));
         HIP_TRY(hipMalloc((void **)&c.d_qexact, (size_t)PVS_MAX_BATCH * ix->dim * 4));
         HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_MAX_BATCH));
         HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_MAX_BATCH));
@@ -593,8 +596,8 @@ static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k,
                             uint32_t *out_count) {
     PVS_TRY(pvs_dense_reserve(c.dense, ix->n));
     const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
-    HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q,
-                                 c.dense.d_dist, c.stream));
+    HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, 1,
+                                   c.d_qpad, c.dense.d_dist, 1, 0, (uint32_t)ix->n_cu, c.stream));
     PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream));
     ix->dense_queries++;
     return PVS_OK;
@@ -990,8 +993,8 @@ PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype 
             PVS_TRY(pvs_dense_reserve(c->dense, ix->n));
             dst = c->dense.d_dist;
         }
-        HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
-                                     c->d_qinfo, dst, c->stream));
+        HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
+                                       c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
         if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return PVS_OK;
@@ -1083,11 +1086,8 @@ static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t
         HIP_TRY(hipStreamSynchronize(c.stream));
         if (!flag) return PVS_OK;  // else: some L2 sum left the exact range -> score in order below
     }
-    for (uint32_t q = 0; q < nb; q++) {
-        const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(pvs_launch_score_all((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, d_out,
-                                     c.stream, nb, q));
-    }
+    HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c.d_qexact, c.d_qinfo, nb,
+                                   c.d_qpad, d_out, nb, 0, (uint32_t)ix->n_cu, c.stream));
     return PVS_OK;
 }
 

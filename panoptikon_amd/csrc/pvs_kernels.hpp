@@ -25,10 +25,15 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
                                    int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *cand_cnt,
                                    uint32_t *need_dense, hipStream_t s);
 
-// exact per-row distance (the reference's dist_{cte}.d), one lane per row
-hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
-                                uint64_t n, const float *norm2, const void *qexact, const QInfo *qinfo,
-                                float *out, hipStream_t s, uint32_t out_ld = 1, uint32_t out_col = 0);
+// ---- exact per-row distances (pvs_dense_exact.hip): the reference's dist_{cte}.d for `nq` prepared
+// queries (qexact [nq][dim] int8 codes or f32, qinfo [nq]) -> out[row * out_ld + out_col + q].
+// Sequential f32 accumulation per row, rows streamed HBM -> LDS; up to PVS_DENSE_NQ queries share a pass.
+// qpad_scratch: pvs_dense_exact_scratch_bytes() of device memory, reused launch after launch on `s`.
+constexpr uint32_t PVS_DENSE_NQ = 4;
+uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz);
+hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
+                                  const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
+                                  float *out, uint32_t out_ld, uint32_t out_col, uint32_t n_cu, hipStream_t s);
 
 // ---- filter scan (pvs_kernels_scan.hip)
 struct ScanArgs {

@@ -403,27 +403,3 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
                        stride, scale, metric, qmat, qexact, qinfo, cand_cnt, need_dense);
     return hipGetLastError();
 }
-
-// ------------------------------------------------------------- score_all
-template <int DT>
-__global__ __launch_bounds__(256) void k_score_all(int metric, const uint8_t *rows, uint32_t stride, int dim,
-                                                   uint64_t n, const float *norm2, const void *qexact,
-                                                   const QInfo *qinfo, float *out, uint32_t out_ld, uint32_t out_col) {
-    uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    out[r * out_ld + out_col] = exact_distance<DT>(rows, stride, r, qexact, dim, metric, norm2[r], qinfo->bb);
-}
-
-hipError_t pvs_launch_score_all(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim,
-                                uint64_t n, const float *norm2, const void *qexact, const QInfo *qinfo, float *out,
-                                hipStream_t s, uint32_t out_ld, uint32_t out_col) {
-    if (n == 0) return hipSuccess;
-    dim3 g((unsigned)((n + 255) / 256)), b(256);
-    if (dtype == PVS_I8)
-        hipLaunchKernelGGL(k_score_all<PVS_I8>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out, out_ld, out_col);
-    else if (dtype == PVS_F16)
-        hipLaunchKernelGGL(k_score_all<PVS_F16>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out, out_ld, out_col);
-    else
-        hipLaunchKernelGGL(k_score_all<PVS_F32>, g, b, 0, s, metric, rows, stride, (int)dim, n, norm2, qexact, qinfo, out, out_ld, out_col);
-    return hipGetLastError();
-}

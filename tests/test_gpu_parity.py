@@ -288,6 +288,25 @@ def test_device_merge_and_sharded_search(pvs):
     assert np.array_equal(oi.to_numpy(np.int64, (40, 50)), exp[0])
     assert np.array_equal(od.to_numpy(np.float32, (40, 50)).view(np.uint32), exp[1].view(np.uint32))
     assert np.array_equal(oc.to_numpy(np.uint32, (40,)), exp[2])
+    # (c) four searches in flight on per-context streams, their collectives on the one comm stream;
+    ix.set_streams(2)
+    qsets = [orc.synth_rows(0x5EED0000 + 7 * i, 0, 40, 768) for i in range(4)]
+    exps = [ix.search(qs, 50, pvs.COSINE) for qs in qsets]
+    dqs = [pvs.DeviceBuffer.from_numpy(qs) for qs in qsets]
+    outs = [(pvs.DeviceBuffer(40 * 50 * 8), pvs.DeviceBuffer(40 * 50 * 4), pvs.DeviceBuffer(40 * 4)) for _ in range(4)]
+    for rep in range(3):
+        tickets = []
+        for i in range(4):
+            t = C.c_uint32()
+            L.check(pvs.lib().pvs_search_sharded_async(ix._h, comm, dqs[i].ptr, L.F32, 40, 50, pvs.COSINE, outs[i][0].ptr,
+                                                       outs[i][1].ptr, outs[i][2].ptr, C.byref(t)))
+            tickets.append(int(t.value))
+        for i in range(4):
+            ix.wait(tickets[i])
+            assert np.array_equal(outs[i][0].to_numpy(np.int64, (40, 50)), exps[i][0])
+            assert np.array_equal(outs[i][1].to_numpy(np.float32, (40, 50)).view(np.uint32), exps[i][1].view(np.uint32))
+            assert np.array_equal(outs[i][2].to_numpy(np.uint32, (40,)), exps[i][2])
+    ix.set_streams(1)
     pvs.lib().pvs_comm_destroy(comm)
     ix.close()
 
@@ -316,6 +335,40 @@ def test_score_batch_dense_matrix(pvs, dtype):
             assert np.array_equal(np.isnan(got[:, q]), np.isnan(exp))
             ok = ~np.isnan(exp)
             assert np.array_equal(got[ok, q].view(np.uint32), exp[ok].view(np.uint32)), (dtype, metric, q)
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype,dim,n,b", [("f32", 3000, 700, 7), ("f16", 1536, 1000, 3), ("i8", 1100, 900, 6), ("f32", 5, 65, 1),
+                                              ("f16", 4099, 129, 5)])
+def test_dense_exact_wide_rows_and_query_groups(pvs, dtype, dim, n, b):
+    """Every row against b queries through the streaming exact kernel: query groups of 4/2/1 per pass,
+    row pitches whose padded queries no longer fit four at a time beside the LDS ring, int8 rows whose
+    sums leave the closed-form range (dim * 127^2 >= 2^24), odd dims and a ragged last tile pair."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    rows = unit_rows(43 + dim, n, dim)
+    rows[n // 2] = 0.0
+    queries = orc.synth_rows(0x5EED0001, 0, b, dim)
+    if dt == pvs.I8:
+        rng = np.random.default_rng(dim)
+        hc = rng.choice(np.array([-128, -127, 126, 127], np.int8), size=(n, dim))
+        hq = rng.choice(np.array([-128, 127], np.int8), size=(b, dim))
+        ix = pvs.VectorIndex(pvs.I8, dim)
+        ix.set_scale(1.0)
+        ix.add(hc)
+    else:
+        ix = make_index(pvs, dt, rows, None)
+        hc, hq = host_corpus(dt, rows, None), queries
+    for metric in (pvs.COSINE, pvs.L2):
+        got = ix.score_batch(hq, metric)
+        assert got.shape == (n, b)
+        for q in range(b):
+            exp = orc.score_all(dt, metric, hc, hq[q])
+            assert np.array_equal(np.isnan(got[:, q]), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok, q].view(np.uint32), exp[ok].view(np.uint32)), (dtype, metric, q)
+        one = ix.score_all(hq[0], metric)
+        ok = ~np.isnan(one)
+        assert np.array_equal(one[ok].view(np.uint32), got[ok, 0].view(np.uint32))
     ix.close()
 
 
