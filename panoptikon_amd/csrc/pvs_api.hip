@@ -248,15 +248,15 @@ static pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint3
     }
     if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     if (!c.d_qmat) {
-        HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_MAX_BATCH * ix->dim * 4));
-        HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_MAX_BATCH * ix->stride));
+        HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_SCAN_MAX_BATCH * ix->stride));
         HIP_TRY(hipMalloc((void **)&c.d_qpad, pvs_dense_exact_scratch_bytes(ix->stride, ix->esz)));
-        HIP_TRY(hipMalloc((void **)&c.d_qexact, (size_t)PVS_MAX_BATCH * ix->dim * 4));
-        HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_MAX_BATCH));
-        HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_MAX_BATCH));
-        HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_MAX_BATCH * GMAX));
-        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_MAX_BATCH));
-        HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_MAX_BATCH * PVS_CAND_CAP));
+        HIP_TRY(hipMalloc((void **)&c.d_qexact, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
+        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
     }
     if (batch > c.flags_cap) {
         hipFree(c.d_need_dense);
@@ -626,9 +626,10 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         HIP_TRY(hipEventRecord(c.done, c.stream));
         return PVS_OK;
     }
-    for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
-        const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
-        const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+    const uint32_t pass_max = fast ? pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES) : PVS_MAX_BATCH;
+    for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
+        const uint32_t nb = std::min(pass_max, batch - qoff);
+        const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : nb <= 128 ? 128 : 256;
         PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));
         int64_t *oid = d_out_ids + (size_t)qoff * k;
         float *od = d_out_dist + (size_t)qoff * k;
@@ -667,10 +668,11 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
         const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
-        const uint32_t per_cu_a = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
-        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / ((4 / a.qgroups) * 32)});
+        const uint32_t per_cu_a = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
+        const uint32_t rt = a.qgroups >= 4 ? 1 : 4 / a.qgroups;  // row sub-tiles per workgroup
+        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (rt * 32)});
         a.mode = 0;
-        a.groups_per_query = a.grid * (4 / a.qgroups) * 32;
+        a.groups_per_query = a.grid * rt * 32;
         span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
@@ -678,7 +680,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         // pass B: every row once (candidate counters were zeroed by the prep kernel)
         a.mode = 1;
         a.tile_step = 1;
-        const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
         a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));

@@ -39,7 +39,7 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
 struct ScanArgs {
     int dtype, metric;
     uint32_t kslabs;        // stride / 256
-    uint32_t qgroups;       // batch_pad / 32 in {1,2,4}
+    uint32_t qgroups;       // batch_pad / 32 in {1,2,4} (and 8 where pvs_scan_max_batch() is 256)
     const uint8_t *rows;
     const float *aux;       // per-row scalar for the metric: 1/|a| (cosine) or |a|^2 (L2)
     uint32_t stride;
@@ -61,6 +61,7 @@ struct ScanArgs {
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 uint32_t pvs_scan_wg_rows(uint32_t qgroups);  // rows per workgroup tile
+uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
 
 // k-th smallest (1-based) of vals[q][0..per_query), +inf when fewer than k finite values

@@ -13,7 +13,8 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
         return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 12 || kslabs == 16;
     return false;
 }
-uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return 32u * (4u / qgroups); }
+uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
+uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }
 
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     ScanK k;
@@ -63,7 +64,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     };
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
-        e = pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+        e = a.qgroups == 8 ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
+                           : pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     else if (a.dtype == PVS_F16)
         e = a.kslabs <= 4 ? pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                           : pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);

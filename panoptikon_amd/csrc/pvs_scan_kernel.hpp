@@ -38,7 +38,6 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 constexpr int WCAP = 96;          // candidate staging entries per WAVE (wave-private LDS region)
-constexpr int LCAP = 4 * WCAP;    // per workgroup
 
 template <int DT>
 struct Acc;
@@ -81,34 +80,45 @@ constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 // Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
 // vmcnt wait + one s_barrier per chunk.  For the headline shape (768-B rows, 128 queries) a
 // chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
+// QG = 8 (256 queries per pass) runs EIGHT waves per workgroup, one query group each, all on the same
+// 32-row tile: every stored byte is used by twice as many queries per HBM read.  Its 8 waves fill the
+// CU's wave slots at this register budget (2 per SIMD), so there is one workgroup per CU and its ring
+// takes most of the LDS.
 template <int QG, int KSLABS>
 struct Geo {
-    static constexpr int RT = 4 / QG;
+    static constexpr int WAVES = QG == 8 ? 8 : 4;
+    static constexpr int RT = WAVES / QG;
     static constexpr int SLAB_ROWS = 32 * RT;
     static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
+    static constexpr int PPW = 8 * RT / WAVES;  // 1-KiB DMA pieces per wave and slab
     static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
-    static constexpr int NC = RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8));  // chunks in the ring
+    static constexpr int NC_FIT = 150000 / (SPB * SLAB_BYTES + WAVES * 256);  // ring + row scalars beside ~9 KiB of staging
+    static constexpr int NC_BIG = NC_FIT > 16 ? 16 : NC_FIT;
+    static constexpr int NC = QG == 8 ? NC_BIG : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8)));  // chunks in the ring
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
     static constexpr int PC = NC - 1;                                              // chunks in flight
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
-    static constexpr int VM_PER_CHUNK = 2 * RT * SPB + 1;  // per wave: row DMAs + 1 norm DMA
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NC * 1024 + 16 + LCAP * 12;
+    static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 norm DMA
+    static constexpr int LCAP = WAVES * WCAP;           // candidate staging entries per workgroup
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NC * WAVES * 256 + 16 + LCAP * 12;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
 
 constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
+constexpr int scan_threads(int QG) { return QG == 8 ? 512 : 256; }
 
 template <int DT, int KSLABS, int QG, int METRIC, int MODE>
-__global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
+__global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
     using G = Geo<QG, KSLABS>;
     using A = Acc<DT>;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
-                  SPB = G::SPB, CPT = G::CPT;
+                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, LCAP = G::LCAP;
     constexpr bool COS = METRIC == PVS_COSINE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
-    uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NC][4 waves][256 B]
-    uint32_t *const st_cnt = (uint32_t *)(normring + NC * 1024);
+    uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NC][WAVES][256 B]
+    uint32_t *const st_cnt = (uint32_t *)(normring + NC * WAVES * 256);
     uint32_t *const st_row = st_cnt + 4;
     uint32_t *const st_key = st_row + LCAP;
     uint32_t *const st_q = st_key + LCAP;
@@ -164,11 +174,11 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             tS = qi.dscale > 0.f ? thr + qi.eA - qi.bb : -__builtin_inff();
 
         // ---- per-lane DMA source offsets inside a slab (row/chunk swizzle), computed once
-        uint32_t voff[2 * RT];
+        uint32_t voff[PPW];
 #pragma unroll
-        for (int e = 0; e < 2 * RT; e++) {
+        for (int e = 0; e < PPW; e++) {
             // piece = 4 slab rows x 256 B = one contiguous KiB of the tiled HBM layout, already swizzled
-            const int r = 4 * (wave * 2 * RT + e);                       // first slab row of the piece
+            const int r = 4 * (wave * PPW + e);                          // first slab row of the piece
             voff[e] = (uint32_t)(r >> 5) * (32u * a.stride) + (uint32_t)(r & 31) * 256u + (uint32_t)lane * 16u;
         }
         const uint32_t nvoff = (uint32_t)(rt * 32 + j) * 4u;
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
         int i_tl = 0, i_ck = 0, i_slot = 0;  // tile, chunk within tile, ring chunk slot
-        constexpr int DMA_PARTS = SPB * 2 * RT + 1;  // row pieces + the per-row scalars
+        constexpr int DMA_PARTS = SPB * PPW + 1;  // row pieces + the per-row scalars
         const uint8_t *is_base = nullptr;
         const float *is_aux = nullptr;
         uint32_t is_lds = 0, is_norm = 0;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             const uint64_t wt = (uint64_t)(blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step;
             is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
             is_aux = a.aux + wt * SLAB_ROWS;
-            if constexpr (DT == PVS_F32) {
+            if constexpr (DT == PVS_F32 || QG == 8) {
                 // the 16-chunk unroll of the widest f32 instance makes hipcc lose track of the uniformity of
                 // these two and hand VGPRs to the asm's SGPR operands; pin them scalar
                 auto uni = [](const void *p) {
@@ -198,8 +208,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                 is_base = (const uint8_t *)uni(is_base);
                 is_aux = (const float *)uni(is_aux);
             }
-            is_lds = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (2 * RT * 1024);
-            is_norm = norm_lds + (uint32_t)i_slot * 1024 + (uint32_t)wave * 256;
+            is_lds = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (PPW * 1024);
+            is_norm = norm_lds + (uint32_t)i_slot * (WAVES * 256) + (uint32_t)wave * 256;
             if (++i_ck == CPT) {
                 i_ck = 0;
                 i_tl++;
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         };
         auto issue_part = [&](int part) {  // part is a compile-time constant at every call site
             if (part < DMA_PARTS - 1) {
-                const int sb = part / (2 * RT), e = part % (2 * RT);
+                const int sb = part / PPW, e = part % PPW;
                 dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
             } else {
                 dma4(is_aux, nvoff, is_norm);
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             // ---- hand this tile's results to the next iteration (its row scalars leave LDS now: the
             // slot is refilled by the DMA issued after the next barrier)
             {
-                const float *nl = (const float *)(normring + norm_slot * 1024 + wave * 256);
+                const float *nl = (const float *)(normring + norm_slot * (WAVES * 256) + wave * 256);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; g4++) {
                     const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
@@ -455,7 +465,7 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(256), lds, s, k);
+    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
     return hipGetLastError();
 }
 template <int DT, int KS, int QG>
@@ -468,6 +478,13 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
+}
+// 256 queries per pass: 8 waves x 32 queries (filter passes only)
+template <int DT, int KS>
+static hipError_t scan_launch_wide(const ScanK &k, int metric, int mode, hipStream_t s) {
+    if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+    if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, 8, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, 8, PVS_COSINE, 1>(k, s);
+    return mode == 0 ? scan_launch_one<DT, KS, 8, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, 8, PVS_L2, 1>(k, s);
 }
 template <int DT, int KS>
 static hipError_t scan_launch_qg(const ScanK &k, uint32_t qg, int metric, int mode, hipStream_t s) {

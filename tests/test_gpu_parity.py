@@ -113,6 +113,10 @@ CASES = [
     ("i8", "l2", 20000, 768, 40, 100),
     ("i8", "cosine", 9000, 512, 64, 10),
     ("i8", "l2", 5000, 1024, 33, 50),
+    ("i8", "cosine", 30011, 768, 256, 100),  # 256-query pass: two query groups per wave
+    ("i8", "l2", 9000, 1024, 200, 20),
+    ("i8", "cosine", 7000, 100, 129, 10),
+    ("i8", "l2", 6000, 512, 600, 5),  # 256 + 256 + 88
     ("f16", "cosine", 20000, 768, 32, 100),
     ("f16", "l2", 12000, 768, 7, 10),
     ("f16", "cosine", 8000, 512, 70, 100),
