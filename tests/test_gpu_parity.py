@@ -546,3 +546,88 @@ def test_zero_query_and_saturated_codes(pvs):
     for qq in range(4):
         assert np.array_equal(got[:, qq].view(np.uint32), orc.score_all(orc.I8, orc.L2, codes, qcodes[qq]).view(np.uint32))
     ix.close()
+
+
+def test_sixteen_host_threads_share_one_index(pvs):
+    """Boundary contract: pvs_search is callable concurrently from the 16 read-pool threads
+    of the reference (db/connection.rs:235,320-357).  Every thread must get its own query's page."""
+    import threading
+
+    rows = unit_rows(81, 20000, 768)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    hc = orc.quantize_int8(rows, scale)
+    nthreads, per = 16, 6
+    queries = orc.synth_rows(0x5EED0002, 0, nthreads * per, 768)
+    hq = orc.quantize_int8(queries, scale)
+    exp_i, exp_d = orc.search(orc.I8, orc.COSINE, hc, hq, 20, threads=8)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(per):
+                q = t * per + rep
+                nb = 1 + (q % 3)  # mixed batch sizes across threads
+                sel = [(q + i) % (nthreads * per) for i in range(nb)]
+                gi, gd, gc = ix.search(hq[sel], 20, pvs.COSINE)
+                for i, qq in enumerate(sel):
+                    if not (np.array_equal(gi[i], exp_i[qq]) and np.array_equal(gd[i].view(np.uint32), exp_d[qq].view(np.uint32))):
+                        errors.append((t, rep, qq))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors[:5]
+    ix.close()
+
+
+def test_or_composition_of_image_and_text_filters_rrf(pvs):
+    """BASELINE configs[4] in miniature: a 512-d image-embedding index (cosine) and a 1024-d text-embedding
+    index (L2, text_embeddings.rs:386-393) over the same files, each filter aggregated per file (MIN,
+    exact.rs:67-80) and ranked with row_number() (builder.rs:757-771); the OR arm is the UNION of the two
+    branches (builder.rs:638-661) ordered by the RRF score (builder.rs:1284-1317).  Device results per
+    branch + host fusion must equal the oracle's composition exactly (f64)."""
+    rng = np.random.default_rng(5)
+    n_files, k_page = 700, 50
+    # image branch: ~3 vectors per file; text branch: ~5 vectors, only 60 % of the files have text
+    img_files = np.sort(rng.integers(0, n_files, 2100)).astype(np.int64)
+    txt_files = np.sort(rng.choice(np.arange(0, n_files, dtype=np.int64)[rng.random(n_files) < 0.6], 3000))
+    img_rows, txt_rows = unit_rows(91, len(img_files), 512), unit_rows(92, len(txt_files), 1024)
+    s_img, s_txt = orc.compute_int8_scale(img_rows), orc.compute_int8_scale(txt_rows)
+    ix_img, ix_txt = pvs.VectorIndex(pvs.I8, 512), pvs.VectorIndex(pvs.I8, 1024)
+    ix_img.set_scale(s_img)
+    ix_txt.set_scale(s_txt)
+    ix_img.add_f32(img_rows, group_ids=img_files)
+    ix_txt.add_f32(txt_rows, group_ids=txt_files)
+    q_img = orc.quantize_int8(orc.synth_rows(93, 0, 1, 512), s_img)
+    q_txt = orc.quantize_int8(orc.synth_rows(94, 0, 1, 1024), s_txt)
+
+    # device: every file of each branch, ranked (k = all groups)
+    gi, vi, ci = ix_img.search_groups(q_img, n_files, pvs.COSINE, pvs.AGG_MIN)
+    gt, vt, ct = ix_txt.search_groups(q_txt, n_files, pvs.L2, pvs.AGG_MIN)
+    gi, vi, gt, vt = gi[0, : ci[0]], vi[0, : ci[0]], gt[0, : ct[0]], vt[0, : ct[0]]
+    # oracle branches
+    ogi, ovi = orc.search_groups(orc.I8, orc.COSINE, orc.quantize_int8(img_rows, s_img), q_img[0], img_files, orc.AGG_MIN, n_files)
+    ogt, ovt = orc.search_groups(orc.I8, orc.L2, orc.quantize_int8(txt_rows, s_txt), q_txt[0], txt_files, orc.AGG_MIN, n_files)
+    assert np.array_equal(gi, ogi) and np.array_equal(vi.view(np.uint64), ovi.view(np.uint64))
+    assert np.array_equal(gt, ogt) and np.array_equal(vt.view(np.uint64), ovt.view(np.uint64))
+
+    def fuse(rrf, rownum, g_a, v_a, g_b, v_b):
+        files = np.union1d(g_a, g_b)  # UNION of the branches' files
+        ranks = np.full((2, len(files)), -1, np.int64)  # NULL where a branch has no row for the file
+        for b, (g, v) in enumerate(((g_a, v_a), (g_b, v_b))):
+            ranks[b, np.searchsorted(files, g)] = rownum(v, g)
+        score = rrf(ranks)
+        order = np.lexsort((files, -score))  # ORDER BY score DESC (ties: file id, for determinism)
+        return files[order][:k_page], score[order][:k_page]
+
+    ks, ws = np.array([1, 60], np.int32), np.array([1.0, 0.5])
+    got_f, got_s = fuse(lambda r: pvs.rrf_fuse(r, ks, ws), pvs.row_number, gi, vi, gt, vt)
+    exp_f, exp_s = fuse(lambda r: np.array([orc.rrf_score(r[:, i], ks, ws) for i in range(r.shape[1])]), orc.row_number, ogi, ovi, ogt, ovt)
+    assert np.array_equal(got_f, exp_f) and np.array_equal(got_s.view(np.uint64), exp_s.view(np.uint64))
+    ix_img.close()
+    ix_txt.close()
