@@ -1,0 +1,227 @@
+"""Index lifecycle glue: from a Panoptikon index database (SQLite) to device-resident shards.
+
+Host-side only (stdlib ``sqlite3``; the image has no SQLite headers for a C++ twin and no Rust).
+It mirrors, for a host that is not the reference's Rust process:
+
+* readiness of a (profile, setters) pair — ``resolve_ready_pair`` / ``default_profile_name`` /
+  ``active_profile_id`` (reference ``db/vector_quants.rs:1795-1929``): active profile, every *existing*
+  setter ``state='ready'``, a usable scale artifact, equal scale and dim across xmodal siblings;
+* the row streams the device index is loaded from: ``embeddings`` (f32 LE blobs, dim =
+  len/4) and ``embedding_quants`` (int8 codes at the coverage row's ``artifact_rev``), both in
+  ``item_data.id`` order — the order ``BACKFILL_CHUNK_SQL`` streams (``db/vector_quants.rs:1085-1099``) and the
+  order ``pvs_index_add`` requires;
+* invalidation: a cached device index is keyed by (database, kind, setters, profile id, artifact rev)
+  and dropped when the caller's index epoch moves (``db/epochs.rs``: any index-DB write bumps it).
+
+Row id = ``item_data.id``; group id = ``item_data.item_id`` (files of an item expand on the host, as the
+reference's ``files`` join does).
+"""
+from __future__ import annotations
+
+import sqlite3
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .host import artifact_scale
+
+
+@dataclass(frozen=True)
+class ReadyPair:
+    """reference ``ReadyPair`` (db/vector_quants.rs:1784-1788)"""
+    profile_id: int
+    scale: float
+    dim: int
+
+
+def active_profile_id(conn: sqlite3.Connection, name: str) -> Optional[int]:
+    row = conn.execute("SELECT id FROM vector_quant_profiles WHERE name = ? AND state = 'active'", (name,)).fetchone()
+    return None if row is None else int(row[0])
+
+
+def default_profile_name(conn: sqlite3.Connection) -> Optional[str]:
+    row = conn.execute("SELECT name FROM vector_quant_profiles WHERE is_default = 1 AND state = 'active' LIMIT 1").fetchone()
+    return None if row is None else str(row[0])
+
+
+def _setter_id(conn: sqlite3.Connection, name: str) -> Optional[int]:
+    row = conn.execute("SELECT id FROM setters WHERE name = ?", (name,)).fetchone()
+    return None if row is None else int(row[0])
+
+
+def resolve_ready_pair(conn: sqlite3.Connection, profile_name: str, setter_names: Sequence[str]) -> Optional[ReadyPair]:
+    """None unless the profile is active and every existing involved setter's pair is ready with a usable
+    scale and the same (scale, dim) — the ``auto`` fallback contract (db/vector_quants.rs:1795-1869).
+    Setter names without a ``setters`` row are skipped."""
+    profile_id = active_profile_id(conn, profile_name)
+    if profile_id is None:
+        return None
+    result: Optional[ReadyPair] = None
+    for name in setter_names:
+        sid = _setter_id(conn, name)
+        if sid is None:
+            continue
+        row = conn.execute("SELECT artifact, dim FROM vector_quant_coverage WHERE profile_id = ? AND setter_id = ? AND state = 'ready'",
+                           (profile_id, sid)).fetchone()
+        if row is None:
+            return None
+        artifact, dim = row
+        scale = artifact_scale(bytes(artifact)) if artifact is not None else None
+        if dim is None or scale is None:
+            return None  # no dimension or no usable scale: not queryable whatever the state column says
+        if result is None:
+            result = ReadyPair(profile_id, float(scale), int(dim))
+        elif np.float32(result.scale) != np.float32(scale) or result.dim != int(dim):
+            return None  # xmodal siblings must share one artifact; a mismatch means a rebuild is pending
+    return result
+
+
+def _existing_setter_ids(conn: sqlite3.Connection, setter_names: Sequence[str]) -> List[int]:
+    return [sid for sid in (_setter_id(conn, n) for n in setter_names) if sid is not None]
+
+
+def iter_exact_rows(conn: sqlite3.Connection, setter_names: Sequence[str], chunk_rows: int = 65536
+                    ) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+    """(row ids, item ids, f32 [n][dim]) chunks of the setters' embeddings in ``item_data.id`` order.
+    dim is fixed by the first row; blobs of another length are skipped (the quant backfill applies the
+    same ``length(embedding) = dim*4`` guard)."""
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids:
+        return
+    marks = ",".join("?" * len(sids))
+    cur = conn.execute(f"SELECT d.id, d.item_id, e.embedding FROM item_data d JOIN embeddings e ON e.id = d.id "
+                       f"WHERE d.setter_id IN ({marks}) ORDER BY d.id", sids)
+    dim_bytes = None
+    while True:
+        rows = cur.fetchmany(chunk_rows)
+        if not rows:
+            return
+        if dim_bytes is None:
+            dim_bytes = len(rows[0][2])
+        keep = [r for r in rows if r[2] is not None and len(r[2]) == dim_bytes and dim_bytes % 4 == 0 and dim_bytes > 0]
+        if not keep:
+            continue
+        ids = np.fromiter((r[0] for r in keep), np.int64, len(keep))
+        items = np.fromiter((r[1] for r in keep), np.int64, len(keep))
+        mat = np.frombuffer(b"".join(r[2] for r in keep), dtype="<f4").reshape(len(keep), dim_bytes // 4)
+        yield ids, items, mat
+
+
+def iter_quant_rows(conn: sqlite3.Connection, profile_id: int, setter_names: Sequence[str], dim: int, chunk_rows: int = 65536
+                    ) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+    """(row ids, item ids, int8 [n][dim]) chunks of the profile's codes at each setter's current
+    ``artifact_rev``, in ``item_data.id`` order (embedding_quants schema: migrations/index/20260730150000)."""
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids:
+        return
+    marks = ",".join("?" * len(sids))
+    cur = conn.execute(
+        f"SELECT d.id, d.item_id, q.quant FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
+        f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
+        f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) ORDER BY d.id", [profile_id, *sids])
+    while True:
+        rows = cur.fetchmany(chunk_rows)
+        if not rows:
+            return
+        keep = [r for r in rows if len(r[2]) == dim]
+        if not keep:
+            continue
+        ids = np.fromiter((r[0] for r in keep), np.int64, len(keep))
+        items = np.fromiter((r[1] for r in keep), np.int64, len(keep))
+        mat = np.frombuffer(b"".join(r[2] for r in keep), dtype=np.int8).reshape(len(keep), dim)
+        yield ids, items, mat
+
+
+def coverage_revs(conn: sqlite3.Connection, profile_id: int, setter_names: Sequence[str]) -> Tuple[Tuple[int, int], ...]:
+    """((setter id, artifact_rev), ...) — part of the cache key of a quant index."""
+    out = []
+    for sid in _existing_setter_ids(conn, setter_names):
+        row = conn.execute("SELECT artifact_rev FROM vector_quant_coverage WHERE profile_id = ? AND setter_id = ?", (profile_id, sid)).fetchone()
+        out.append((sid, -1 if row is None else int(row[0])))
+    return tuple(out)
+
+
+@dataclass
+class LoadedIndex:
+    index: object  # VectorIndex
+    kind: str      # "exact" | "quant"
+    rows: int
+    dim: int
+    profile_id: Optional[int] = None
+    scale: Optional[float] = None
+    key: tuple = field(default_factory=tuple)
+
+
+def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtype: int = L.F32, device: int = 0,
+                     chunk_rows: int = 65536) -> Optional[LoadedIndex]:
+    """The reference's *exact* mode on the device: the setters' f32 embeddings as an f32 (or f16) index."""
+    from .index import VectorIndex
+
+    ix, n, dim = None, 0, 0
+    for ids, items, mat in iter_exact_rows(conn, setter_names, chunk_rows):
+        if ix is None:
+            dim = mat.shape[1]
+            ix = VectorIndex(dtype, dim, device=device)
+        ix.add_f32(mat, row_ids=ids, group_ids=items)
+        n += len(ids)
+    if ix is None:
+        return None
+    return LoadedIndex(ix, "exact", n, dim)
+
+
+def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: Sequence[str], device: int = 0,
+                     chunk_rows: int = 65536) -> Optional[LoadedIndex]:
+    """The *quant* mode: int8 codes of a ready pair with its frozen scale.  None when the pair is not ready
+    (the caller falls back to exact under ``auto``, or raises under strict selection — pql/preprocess.rs:327-383)."""
+    from .index import VectorIndex
+
+    pair = resolve_ready_pair(conn, profile_name, setter_names)
+    if pair is None:
+        return None
+    ix = VectorIndex(L.I8, pair.dim, device=device)
+    ix.set_scale(pair.scale)
+    n = 0
+    for ids, items, mat in iter_quant_rows(conn, pair.profile_id, setter_names, pair.dim, chunk_rows):
+        ix.add(mat, row_ids=ids, group_ids=items)
+        n += len(ids)
+    return LoadedIndex(ix, "quant", n, pair.dim, profile_id=pair.profile_id, scale=pair.scale)
+
+
+class IndexCache:
+    """Device indexes keyed by what makes them stale.  ``epoch`` is the host's index epoch for the database
+    (db/epochs.rs:38-46: bumped by every index-DB write); quant indexes additionally key on the coverage
+    rows' ``artifact_rev`` so a rebuilt scale never serves old codes."""
+
+    def __init__(self):
+        self._items: Dict[tuple, Tuple[int, LoadedIndex]] = {}
+
+    def get(self, conn: sqlite3.Connection, db_name: str, epoch: int, setter_names: Sequence[str],
+            profile_name: Optional[str] = None, dtype: int = L.F32, device: int = 0) -> Optional[LoadedIndex]:
+        names = tuple(setter_names)
+        if profile_name is None:
+            key = (db_name, "exact", names, int(dtype), device)
+        else:
+            pid = active_profile_id(conn, profile_name)
+            if pid is None:
+                return None
+            key = (db_name, "quant", names, pid, coverage_revs(conn, pid, names), device)
+        hit = self._items.get(key)
+        if hit is not None and hit[0] == epoch:
+            return hit[1]
+        # stale (epoch moved) or absent: drop every entry of this (database, kind, setters) and rebuild
+        for k in [k for k in self._items if k[:3] == key[:3]]:
+            self._items.pop(k)[1].index.close()
+        loaded = (load_exact_index(conn, names, dtype, device) if profile_name is None
+                  else load_quant_index(conn, profile_name, names, device))
+        if loaded is None:
+            return None
+        loaded.key = key
+        self._items[key] = (epoch, loaded)
+        return loaded
+
+    def clear(self):
+        for _, li in self._items.values():
+            li.index.close()
+        self._items.clear()

@@ -1,0 +1,158 @@
+"""Index lifecycle glue (panoptikon_amd/loader.py) against a miniature Panoptikon index database.
+
+The DDL below restates the columns of the reference's migrations that the path touches
+(migrations/index/20250117193000_init.sql: items, setters, item_data, embeddings;
+20260720130000_vector_quants.sql + 20260730150000_embedding_quants_rowid.sql: vector_quant_profiles,
+vector_quant_coverage, embedding_quants).  Readiness cases follow resolve_ready_pair
+(db/vector_quants.rs:1795-1869)."""
+import sqlite3
+import struct
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+DDL = """
+CREATE TABLE items (id INTEGER PRIMARY KEY, sha256 TEXT UNIQUE NOT NULL);
+CREATE TABLE setters (id INTEGER PRIMARY KEY, name TEXT NOT NULL UNIQUE);
+CREATE TABLE item_data (id INTEGER PRIMARY KEY, item_id INTEGER NOT NULL, setter_id INTEGER NOT NULL,
+                        data_type TEXT NOT NULL, idx INTEGER NOT NULL);
+CREATE TABLE embeddings (id INTEGER PRIMARY KEY, embedding float[]);
+CREATE TABLE vector_quant_profiles (id INTEGER PRIMARY KEY, name TEXT UNIQUE NOT NULL, quantizer TEXT NOT NULL, options TEXT,
+                                    state TEXT NOT NULL, is_default INTEGER NOT NULL DEFAULT 0);
+CREATE TABLE vector_quant_coverage (profile_id INTEGER NOT NULL, setter_id INTEGER NOT NULL, needs_artifact INTEGER NOT NULL DEFAULT 1,
+                                    artifact BLOB, artifact_rev INTEGER NOT NULL DEFAULT 0, n_at_artifact INTEGER, dim INTEGER,
+                                    metric TEXT, state TEXT NOT NULL DEFAULT 'pending', PRIMARY KEY (profile_id, setter_id));
+CREATE TABLE embedding_quants (id INTEGER NOT NULL, profile_id INTEGER NOT NULL, rev INTEGER NOT NULL, quant BLOB NOT NULL,
+                               UNIQUE (id, profile_id));
+"""
+
+
+def build_db(n_items=300, dim=96, seed=3, ragged=True):
+    """Two setters of one embedding space (an image model and its 't'-prefixed text sibling), interleaved
+    item_data ids, one active default int8 profile with a ready pair per setter at artifact_rev 2."""
+    rng = np.random.default_rng(seed)
+    conn = sqlite3.connect(":memory:")
+    conn.executescript(DDL)
+    conn.executemany("INSERT INTO setters (id, name) VALUES (?, ?)", [(1, "clip/m"), (2, "tclip/m"), (3, "other")])
+    conn.executemany("INSERT INTO items (id, sha256) VALUES (?, ?)", [(i, f"sha{i}") for i in range(1, n_items + 1)])
+    rows = orc.synth_rows(1234 + seed, 0, 2 * n_items, dim)
+    did, meta = 0, []
+    for i in range(1, n_items + 1):
+        for setter in (1, 2):
+            if setter == 2 and rng.random() < 0.3:
+                continue  # not every item has text
+            did += 1
+            conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (?, ?, ?, ?, 0)",
+                         (did, i, setter, "clip" if setter == 1 else "text-embedding"))
+            vec = rows[did - 1]
+            blob = vec.astype("<f4").tobytes()
+            if ragged and did == 7:
+                blob = blob[:-4]  # a stray row of another length: skipped by the loaders
+            conn.execute("INSERT INTO embeddings (id, embedding) VALUES (?, ?)", (did, blob))
+            meta.append((did, i, setter, vec, len(blob) == dim * 4))
+    good = [m for m in meta if m[4]]
+    scale = orc.compute_int8_scale(np.stack([m[3] for m in good]))
+    art = struct.pack("<f", scale)
+    conn.execute("INSERT INTO vector_quant_profiles (id, name, quantizer, state, is_default) VALUES (5, 'int8', 'int8', 'active', 1)")
+    for setter in (1, 2):
+        conn.execute("INSERT INTO vector_quant_coverage (profile_id, setter_id, artifact, artifact_rev, dim, state) VALUES (5, ?, ?, 2, ?, 'ready')",
+                     (setter, art, dim))
+    codes = orc.quantize_int8(np.stack([m[3] for m in good]), scale)
+    for m, c in zip(good, codes):
+        conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 2, ?)", (m[0], c.tobytes()))
+    conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 1, ?)", (10_000, codes[0].tobytes()))  # stale rev, no item_data
+    conn.commit()
+    return conn, good, scale, codes
+
+
+def test_resolve_ready_pair_matrix():
+    from panoptikon_amd import loader
+
+    conn, good, scale, _ = build_db()
+    names = ["clip/m", "tclip/m"]
+    p = loader.resolve_ready_pair(conn, "int8", names)
+    assert p is not None and p.profile_id == 5 and p.dim == 96 and np.float32(p.scale) == np.float32(scale)
+    assert loader.default_profile_name(conn) == "int8" and loader.active_profile_id(conn, "int8") == 5
+    # a setter name without a setters row is skipped; only unknown names -> None (nothing to query)
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m", "no-such-setter"]) is not None
+    assert loader.resolve_ready_pair(conn, "int8", ["no-such-setter"]) is None
+    # existing setter without a ready pair -> None
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m", "other"]) is None
+    assert loader.resolve_ready_pair(conn, "nope", names) is None
+    # sibling with a different artifact -> rebuild pending -> None
+    conn.execute("UPDATE vector_quant_coverage SET artifact = ? WHERE setter_id = 2", (struct.pack("<f", scale * 2),))
+    assert loader.resolve_ready_pair(conn, "int8", names) is None
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m"]) is not None
+    # unusable artifacts (artifact_scale rejections, db/vector_quants.rs:1456-1460) and missing dim
+    for bad in (b"", b"\x00\x00\x00", struct.pack("<f", 0.0), struct.pack("<f", -1.0), struct.pack("<f", float("nan")), struct.pack("<f", float("inf")), None):
+        conn.execute("UPDATE vector_quant_coverage SET artifact = ? WHERE setter_id = 1", (bad,))
+        assert loader.resolve_ready_pair(conn, "int8", ["clip/m"]) is None, bad
+    conn.execute("UPDATE vector_quant_coverage SET artifact = ?, dim = NULL WHERE setter_id = 1", (struct.pack("<f", scale),))
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m"]) is None
+    conn.execute("UPDATE vector_quant_coverage SET dim = 96, state = 'building' WHERE setter_id = 1")
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m"]) is None
+    conn.execute("UPDATE vector_quant_coverage SET state = 'ready' WHERE setter_id = 1")
+    conn.execute("UPDATE vector_quant_profiles SET state = 'removing'")
+    assert loader.resolve_ready_pair(conn, "int8", ["clip/m"]) is None and loader.default_profile_name(conn) is None
+
+
+def test_row_streams_are_in_item_data_id_order_and_skip_ragged_rows():
+    from panoptikon_amd import loader
+
+    conn, good, scale, codes = build_db()
+    ids, items, mats = zip(*loader.iter_exact_rows(conn, ["clip/m", "tclip/m"], chunk_rows=64))
+    ids, items, mat = np.concatenate(ids), np.concatenate(items), np.concatenate(mats)
+    assert np.all(np.diff(ids) > 0) and 7 not in ids
+    assert ids.tolist() == [m[0] for m in good] and items.tolist() == [m[1] for m in good]
+    assert np.array_equal(mat.view(np.uint32), np.stack([m[3] for m in good]).view(np.uint32))
+    only_img = np.concatenate([c[0] for c in loader.iter_exact_rows(conn, ["clip/m"])])
+    assert only_img.tolist() == [m[0] for m in good if m[2] == 1]
+    assert list(loader.iter_exact_rows(conn, ["no-such-setter"])) == []
+    qi, qit, qm = zip(*loader.iter_quant_rows(conn, 5, ["clip/m", "tclip/m"], 96, chunk_rows=50))
+    assert np.concatenate(qi).tolist() == [m[0] for m in good] and np.array_equal(np.concatenate(qm), codes)
+    # codes of another revision are not served
+    conn.execute("UPDATE vector_quant_coverage SET artifact_rev = 3 WHERE setter_id = 2")
+    qi2 = np.concatenate([c[0] for c in loader.iter_quant_rows(conn, 5, ["clip/m", "tclip/m"], 96)])
+    assert qi2.tolist() == [m[0] for m in good if m[2] == 1]
+    assert loader.coverage_revs(conn, 5, ["clip/m", "tclip/m", "zzz"]) == ((1, 2), (2, 3))
+
+
+@pytest.mark.gpu
+def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
+    import panoptikon_amd as pvs
+    from panoptikon_amd import loader
+
+    conn, good, scale, codes = build_db(n_items=900, dim=128, ragged=True)
+    names = ["clip/m", "tclip/m"]
+    rows = np.stack([m[3] for m in good])
+    ids = np.array([m[0] for m in good], np.int64)
+    q = orc.synth_rows(77, 0, 4, 128)
+    cache = loader.IndexCache()
+    ex = cache.get(conn, "idx", 0, names)  # exact mode: f32 rows
+    assert ex.kind == "exact" and ex.rows == len(good) and ex.dim == 128
+    gi, gd, gc = ex.index.search(q, 10, pvs.L2)  # text filters are always L2 (text_embeddings.rs:386-393)
+    ei, ed = orc.search(orc.F32, orc.L2, rows, q, 10, ids=ids)
+    assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+    qu = cache.get(conn, "idx", 0, names, profile_name="int8")
+    assert qu.kind == "quant" and qu.rows == len(good) and np.float32(qu.scale) == np.float32(scale)
+    gi, gd, gc = qu.index.search(q, 10, pvs.COSINE)  # f32 query quantized with the frozen scale on the device
+    ei, ed = orc.search(orc.I8, orc.COSINE, codes, orc.quantize_int8(q, scale), 10, ids=ids)
+    assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+    # per-item aggregation over the loaded group ids (item_id)
+    gg, gv, gn = qu.index.search_groups(q[:1], 5, pvs.COSINE, pvs.AGG_MIN)
+    eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, orc.quantize_int8(q, scale)[0], np.array([m[1] for m in good], np.int64), orc.AGG_MIN, 5)
+    assert np.array_equal(gg[0, : gn[0]], eg) and np.array_equal(gv[0, : gn[0]].view(np.uint64), ev.view(np.uint64))
+    # same epoch -> same object; bumped epoch (an index-DB write happened) -> rebuilt, sees the new row
+    assert cache.get(conn, "idx", 0, names) is ex
+    conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (99999, 1, 1, 'clip', 1)")
+    conn.execute("INSERT INTO embeddings (id, embedding) VALUES (99999, ?)", (q[0].astype('<f4').tobytes(),))
+    ex2 = cache.get(conn, "idx", 1, names)
+    assert ex2 is not ex and ex2.rows == len(good) + 1
+    gi, gd, gc = ex2.index.search(q[:1], 1, pvs.L2)
+    assert gi[0, 0] == 99999 and gd[0, 0] == 0.0
+    # not-ready pair -> None (caller falls back to exact / raises under strict selection)
+    conn.execute("UPDATE vector_quant_coverage SET state = 'building' WHERE setter_id = 2")
+    assert cache.get(conn, "idx", 2, names, profile_name="int8") is None
+    cache.clear()
