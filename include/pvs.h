@@ -215,8 +215,23 @@ pvs_status pvs_similar_to(pvs_index *idx, const int64_t *target_row_ids, uint32_
                           pvs_metric metric, pvs_agg agg, int64_t *out_groups, double *out_values,
                           uint32_t *out_count);
 
+/* similar_to with the text source's confidence weights (item_similarity.rs:503-581): per joined pair
+ *   w = pow(coalesce(conf_main,1)*coalesce(conf_other,1), confidence_weight)
+ *     * pow(coalesce(lang_other,1)*coalesce(lang_main,1), language_confidence_weight)
+ * (a factor is dropped when its exponent is 0) and the group value is SUM(d*w)/SUM(w); with both
+ * exponents 0 it is the plain `agg` of pvs_similar_to.  row_confidence / row_language_confidence:
+ * host arrays, one f64 per stored row in row order, NaN = SQL NULL, NULL pointer = all NULL.
+ * pow() is the device math library's (within 1 ulp of the C library SQLite calls): weighted
+ * values agree with the reference to ~1e-15 relative, not bit for bit. */
+pvs_status pvs_similar_to_weighted(pvs_index *idx, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
+                                   pvs_metric metric, pvs_agg agg, const double *row_confidence,
+                                   const double *row_language_confidence, double confidence_weight,
+                                   double language_confidence_weight, int64_t *out_groups, double *out_values,
+                                   uint32_t *out_count);
+
 /* Per-group aggregate of per-row distances (GROUP BY file_id; MIN/MAX/AVG, or
- * SUM(d*w)/SUM(w) when weights != NULL — `agg` is ignored then, exact.rs:67-80).
+ * SUM(d*w)/SUM(w) when weights != NULL — `agg` is ignored then, exact.rs:67-80; SUM(w) runs over
+ * every row of the group, rows with a NULL distance only drop out of SUM(d*w)).
  * dist / weights / group_ids: [n] host arrays, group_ids non-decreasing.
  * Outputs one (group, f64 aggregate) per distinct group; NaN distance = SQL NULL. */
 pvs_status pvs_aggregate(const float *dist, const float *weights, const int64_t *group_ids, uint64_t n,

@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
         L.orc_aggregate.argtypes = [vp, vp, vp, sz, i32, vp, vp]
         L.orc_aggregate_fanout.restype = sz
         L.orc_aggregate_fanout.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
+        L.orc_aggregate_fanout_weighted.restype = sz
+        L.orc_aggregate_fanout_weighted.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, d, d, vp, vp]
         L.orc_row_number.argtypes = [vp, vp, sz, vp]
         L.orc_rrf_score.restype = d
         L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
@@ -258,6 +260,32 @@ def similar_to(dtype: int, metric: int, corpus, target_rows, group_ids, agg: int
     og = np.empty(max(grp.size, 1), np.int64)
     ov = np.empty(max(grp.size, 1), np.float64)
     n = lib().orc_aggregate_fanout(_p(dist_o), len(targets), _p(excl_o), _p(grp_o), grp.size, agg, _p(og), _p(ov))
+    return _rank_groups(og[:n].copy(), ov[:n].copy(), k)
+
+
+def similar_to_weighted(dtype: int, metric: int, corpus, target_rows, group_ids, k: int, conf, lang, cw: float, lw: float):
+    """Confidence-weighted similar_to: SUM(d*w)/SUM(w) over the fan-out, w from the rows' confidences."""
+    c = _corpus(dtype, corpus)
+    targets = list(target_rows)
+    cols = []
+    for t in targets:
+        q = c[t].astype(np.float32) if dtype == F16 else c[t]
+        cols.append(score_all(dtype, metric, c, q))
+    dist = np.ascontiguousarray(np.stack(cols, axis=1), np.float32)
+    grp = _c(group_ids, np.int64)
+    order = np.argsort(grp, kind="stable")
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    excl = np.zeros(c.shape[0], np.uint8)
+    excl[targets] = 1
+    dist_o, grp_o, excl_o = np.ascontiguousarray(dist[order]), np.ascontiguousarray(grp[order]), np.ascontiguousarray(excl[order])
+    conf_o = np.ascontiguousarray(np.asarray(conf, np.float64)[order])
+    lang_o = np.ascontiguousarray(np.asarray(lang, np.float64)[order])
+    tgt = np.ascontiguousarray(inv[np.asarray(targets)], np.uint64)
+    og = np.empty(max(grp.size, 1), np.int64)
+    ov = np.empty(max(grp.size, 1), np.float64)
+    n = lib().orc_aggregate_fanout_weighted(_p(dist_o), len(targets), _p(excl_o), _p(grp_o), grp.size, _p(tgt), _p(conf_o), _p(lang_o),
+                                        float(cw), float(lw), _p(og), _p(ov))
     return _rank_groups(og[:n].copy(), ov[:n].copy(), k)
 
 

@@ -426,11 +426,11 @@ ORC_API size_t orc_aggregate(const float *dist, const float *w, const int64_t *g
         double mn = INFINITY, mx = -INFINITY;
         size_t cnt = 0;
         for (; j < n && group[j] == group[i]; j++) {
+            if (w) kbn_step(&wsum, (double)w[j]); /* SUM(w) runs over every row; only d*w is NULL for a NULL d */
             if (isnan(dist[j])) continue;
             double d = (double)dist[j];
             if (w) {
                 kbn_step(&sum, d * (double)w[j]);
-                kbn_step(&wsum, (double)w[j]);
             } else {
                 kbn_step(&sum, d);
             }
@@ -485,6 +485,45 @@ ORC_API size_t orc_aggregate_fanout(const float *dist, size_t m, const uint8_t *
         double v = cnt == 0 ? NAN : agg == ORC_AGG_MIN ? mn : agg == ORC_AGG_MAX ? mx : kbn_value(&sum) / (double)cnt;
         out_group[g] = group[i];
         out_val[g] = v;
+        g++;
+        i = j;
+    }
+    return g;
+}
+
+/* Confidence-weighted similar_to (filters/item_similarity.rs:503-581): per (main vector t, other row o)
+ *   w = pow(coalesce(conf_t,1) * coalesce(conf_o,1), cw)        [factor dropped when cw == 0]
+ *     * pow(coalesce(lang_o,1) * coalesce(lang_t,1), lw)        [factor dropped when lw == 0]
+ * and the rank is SUM(d*w) / SUM(w) over the group's fan-out (SUM(w) over every joined pair, d*w
+ * skipped where d is NULL).  conf/lang: per row, NaN = SQL NULL.  target[t] = row index of main vector t. */
+static double coalesce1(double v) { return isnan(v) ? 1.0 : v; }
+ORC_API size_t orc_aggregate_fanout_weighted(const float *dist, size_t m, const uint8_t *exclude, const int64_t *group, size_t n,
+                                             const size_t *target, const double *conf, const double *lang, double cw, double lw,
+                                             int64_t *out_group, double *out_val) {
+    size_t g = 0, i = 0;
+    while (i < n) {
+        size_t j = i;
+        kbn sum = {0, 0}, wsum = {0, 0};
+        size_t cnt = 0;
+        for (; j < n && group[j] == group[i]; j++) {
+            if (exclude && exclude[j]) continue;
+            for (size_t t = 0; t < m; t++) {
+                double w = 1.0;
+                if (cw != 0.0 && lw != 0.0)
+                    w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw) * pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
+                else if (cw != 0.0)
+                    w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw);
+                else if (lw != 0.0)
+                    w = pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
+                kbn_step(&wsum, w);
+                float df = dist[j * m + t];
+                if (isnan(df)) continue;
+                kbn_step(&sum, (double)df * w);
+                cnt++;
+            }
+        }
+        out_group[g] = group[i];
+        out_val[g] = cnt == 0 ? NAN : kbn_value(&sum) / kbn_value(&wsum);
         g++;
         i = j;
     }

@@ -81,6 +81,7 @@ SYMBOLS = {
     "pvs_score_batch": (_i32, [_vp, _vp, _i32, _u32, _i32, _vp, _i32]),
     "pvs_search_groups": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
+    "pvs_similar_to_weighted": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),
     "pvs_quantize_i8": (_i32, [_vp, _u64, _f, _vp, _i32, _i32]),

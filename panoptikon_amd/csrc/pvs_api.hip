@@ -1138,7 +1138,7 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
 // shared tail: d_m [n][nb] (fanout == 0: nb output columns; else one) -> ranked groups on the host
 static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg,
                                      const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
-                                     double *out_values, uint32_t *out_count) {
+                                     double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights()) {
     const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
     double *d_vals = nullptr;
     int64_t *d_og = nullptr;
@@ -1150,7 +1150,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         HIP_TRY(hipMalloc((void **)&d_ov, (size_t)k * 8));
         HIP_TRY(hipMalloc((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
-                                           c.stream));
+                                           c.stream, fw));
         for (uint32_t q = 0; q < ncol; q++) {
             PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, ix->gwork, d_og, d_ov, d_oc, c.stream));
             HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
@@ -1218,8 +1218,9 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
     return st;
 }
 
-PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
-                                     pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw, int64_t *out_groups,
+                                  double *out_values, uint32_t *out_count) {
     if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
     if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
@@ -1247,8 +1248,32 @@ PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_id
     void *d_q = nullptr;
     float *d_m = nullptr;
     uint8_t *d_ex = nullptr;
+    double *d_conf = nullptr, *d_lang = nullptr;
+    uint32_t *d_trows = nullptr;
+    const bool weighted = cw != 0.0 || lw != 0.0;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
+        FanoutWeights fw;
+        if (weighted) {
+            // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
+            auto upload = [&](const double *src, double **dst) -> pvs_status {
+                HIP_TRY(hipMalloc((void **)dst, std::max<uint64_t>(ix->n, 1) * 8));
+                if (src)
+                    HIP_TRY(hipMemcpy(*dst, src, ix->n * 8, hipMemcpyHostToDevice));
+                else
+                    HIP_TRY(hipMemset(*dst, 0xff, ix->n * 8));  // all-ones bits = NaN
+                return PVS_OK;
+            };
+            PVS_TRY(upload(row_conf, &d_conf));
+            PVS_TRY(upload(row_lang, &d_lang));
+            HIP_TRY(hipMalloc((void **)&d_trows, (size_t)n_targets * 4));
+            HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
+            fw.trows = d_trows;
+            fw.conf = d_conf;
+            fw.lang = d_lang;
+            fw.cw = cw;
+            fw.lw = lw;
+        }
         // the target's stored vectors become the query batch: int8 codes as they are, f16/f32 as f32
         const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
         std::vector<uint8_t> hq((size_t)n_targets * ix->dim * qesz);
@@ -1278,16 +1303,35 @@ PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_id
         const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
         PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));
-        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, agg, nullptr, d_ex, k, out_groups, out_values, out_count));
+        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
         return PVS_OK;
     };
     pvs_status st = body();
     hipFree(d_q);
     hipFree(d_m);
     hipFree(d_ex);
+    hipFree(d_conf);
+    hipFree(d_lang);
+    hipFree(d_trows);
     ix->searches++;
     ctx_done(ix, c);
     return st;
+}
+
+PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                     pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, nullptr, nullptr, 0.0, 0.0, out_groups, out_values, out_count);
+}
+
+PVS_EXPORT pvs_status pvs_similar_to_weighted(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
+                                              pvs_metric metric, pvs_agg agg, const double *row_confidence,
+                                              const double *row_language_confidence, double confidence_weight,
+                                              double language_confidence_weight, int64_t *out_groups, double *out_values,
+                                              uint32_t *out_count) {
+    if (confidence_weight != confidence_weight || language_confidence_weight != language_confidence_weight)
+        return pvs_fail(PVS_ERR_INVALID_ARG, "confidence weights must be numbers");
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, row_confidence, row_language_confidence, confidence_weight,
+                           language_confidence_weight, out_groups, out_values, out_count);
 }
 
 // ------------------------------------------------------- codec on the device

@@ -26,9 +26,14 @@ struct Kbn {
 //   fanout == 0: column q aggregates dist[row][q] over the group's rows (semantic search)
 //   fanout == M: a single output column aggregates dist[row][0..M) over rows and targets
 //                (similar_to), skipping rows flagged in `exclude`.
+//   fw.trows != nullptr (similar_to with confidence weights, item_similarity.rs:503-581): the pair weight
+//                w = pow(coalesce(conf_t,1)*coalesce(conf_o,1), cw) * pow(coalesce(lang_o,1)*coalesce(lang_t,1), lw)
+//                (a factor is dropped when its exponent is 0) and the value is SUM(d*w)/SUM(w).
+__device__ static inline double coalesce1(double v) { return v != v ? 1.0 : v; }
 __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout,
                                                          const uint32_t *grp_off, const uint32_t *grp_rows, uint32_t n_groups,
-                                                         const float *weights, const uint8_t *exclude, int agg, double *out) {
+                                                         const float *weights, const uint8_t *exclude, int agg, FanoutWeights fw,
+                                                         double *out) {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t ncol_out = fanout ? 1u : n_cols;
     if (gid >= (uint64_t)n_groups * ncol_out) return;
@@ -41,13 +46,24 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         if (exclude && exclude[row]) continue;
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
-            const float df = dist[(size_t)row * ld + c];
-            if (df != df) continue;  // SQL NULL: ignored by every aggregate
-            const double d = (double)df;
-            if (weights) {
-                const double w = (double)weights[row];
-                sum.step(d * w);
+            double w = 1.0;
+            if (fw.trows) {
+                const uint32_t t = fw.trows[c];
+                if (fw.cw != 0.0) w = pow(coalesce1(fw.conf[t]) * coalesce1(fw.conf[row]), fw.cw);
+                if (fw.lw != 0.0) {
+                    const double wl = pow(coalesce1(fw.lang[row]) * coalesce1(fw.lang[t]), fw.lw);
+                    w = fw.cw != 0.0 ? w * wl : wl;
+                }
+                wsum.step(w);  // SUM(w) runs over every joined pair
+            } else if (weights) {
+                w = (double)weights[row];
                 wsum.step(w);
+            }
+            const float df = dist[(size_t)row * ld + c];
+            if (df != df) continue;  // SQL NULL distance: d (and d*w) is ignored by the aggregates
+            const double d = (double)df;
+            if (weights || fw.trows) {
+                sum.step(d * w);
             } else {
                 sum.step(d);
             }
@@ -59,7 +75,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
     double v;
     if (cnt == 0)
         v = __builtin_nan("");
-    else if (weights)
+    else if (weights || fw.trows)
         v = sum.value() / wsum.value();
     else if (agg == PVS_AGG_MIN)
         v = mn;
@@ -72,11 +88,11 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
 
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s) {
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw) {
     if (n_groups == 0) return hipSuccess;
     const uint64_t total = (uint64_t)n_groups * (fanout ? 1u : n_cols);
     hipLaunchKernelGGL(k_group_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dist, ld, n_cols, fanout, grp_off,
-                       grp_rows, n_groups, weights, exclude, agg, out);
+                       grp_rows, n_groups, weights, exclude, agg, fw, out);
     return hipGetLastError();
 }
 

@@ -64,11 +64,11 @@ PVS_EXPORT pvs_status pvs_aggregate(const float *dist, const float *weights, con
         double mn = INFINITY, mx = -INFINITY;
         uint64_t cnt = 0;
         for (; j < n && group_ids[j] == group_ids[i]; j++) {
-            if (std::isnan(dist[j])) continue;  // SQL NULL: ignored by every aggregate
+            if (weights) wsum.step((double)weights[j]);  // SUM(w) runs over every row of the group
+            if (std::isnan(dist[j])) continue;           // SQL NULL distance: d (and d*w) is ignored by the aggregates
             const double d = (double)dist[j];
             if (weights) {
                 sum.step(d * (double)weights[j]);
-                wsum.step((double)weights[j]);
             } else {
                 sum.step(d);
             }

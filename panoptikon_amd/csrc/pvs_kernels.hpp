@@ -115,9 +115,16 @@ struct GroupWork {
     size_t temp_bytes = 0;
     uint32_t cap = 0;
 };
+// similar_to confidence weights (device pointers; trows == nullptr: unweighted fan-out)
+struct FanoutWeights {
+    const uint32_t *trows = nullptr;  // [fanout] row index of each target vector
+    const double *conf = nullptr;     // [rows] confidence, NaN = NULL
+    const double *lang = nullptr;     // [rows] language_confidence, NaN = NULL
+    double cw = 0.0, lw = 0.0;
+};
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s);
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights());
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);

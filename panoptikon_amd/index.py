@@ -202,6 +202,20 @@ class VectorIndex:
         L.check(L.lib().pvs_similar_to(self._h, _ptr(t), t.size, k, metric, agg, _ptr(og), _ptr(ov), C.byref(oc)))
         return og[: oc.value], ov[: oc.value]
 
+    def similar_to_weighted(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG, confidence=None,
+                            language_confidence=None, confidence_weight: float = 0.0, language_confidence_weight: float = 0.0):
+        """similar_to with the text source's confidence weights (item_similarity.rs:503-581); confidence arrays
+        are one f64 per stored row (NaN = NULL)."""
+        t = np.ascontiguousarray(target_row_ids, np.int64)
+        cf = None if confidence is None else np.ascontiguousarray(confidence, np.float64)
+        lg = None if language_confidence is None else np.ascontiguousarray(language_confidence, np.float64)
+        og = np.empty(k, np.int64)
+        ov = np.empty(k, np.float64)
+        oc = C.c_uint32()
+        L.check(L.lib().pvs_similar_to_weighted(self._h, _ptr(t), t.size, k, metric, agg, _ptr(cf), _ptr(lg), float(confidence_weight),
+                                                float(language_confidence_weight), _ptr(og), _ptr(ov), C.byref(oc)))
+        return og[: oc.value], ov[: oc.value]
+
     def read_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dim), _NP[self.dtype])
         L.check(L.lib().pvs_index_read_rows(self._h, row0, n, _ptr(out)))

@@ -443,6 +443,40 @@ def test_similar_to_matches_self_join(pvs, dtype):
     ix.close()
 
 
+def test_similar_to_confidence_weighted(pvs):
+    """item_similarity.rs:503-581: SUM(d*w)/SUM(w) over the fan-out with w from the two rows' confidences.
+    pow() runs in the device math library: values agree to 1e-13 relative, the ranking exactly."""
+    rng = np.random.default_rng(29)
+    n, dim, k = 1800, 384, 30
+    rows = unit_rows(53, n, dim)
+    rows[77] = 0.0  # a NULL cosine distance inside some group: drops out of SUM(d*w), stays in SUM(w)
+    groups = np.sort(_group_ids(rng, n, 400))
+    ids = np.arange(n, dtype=np.int64) + 10
+    targets = [int(t) for t in np.nonzero(groups == groups[900])[0]]
+    conf = rng.uniform(0.05, 1.0, n)
+    lang = rng.uniform(0.3, 1.0, n)
+    conf[rng.random(n) < 0.2] = np.nan  # NULL -> coalesce(…, 1)
+    lang[rng.random(n) < 0.2] = np.nan
+    ix = pvs.VectorIndex(pvs.F16, dim)
+    ix.add_f32(rows, row_ids=ids, group_ids=groups)
+    hc = rows.astype(np.float16)
+    for metric in (pvs.L2, pvs.COSINE):
+        for cw, lw in ((1.5, 0.0), (0.0, 2.0), (0.7, 1.3)):
+            gg, gv = ix.similar_to_weighted(ids[targets], k, metric, pvs.AGG_AVG, conf, lang, cw, lw)
+            eg, ev = orc.similar_to_weighted(orc.F16, metric, hc, targets, groups, k, conf, lang, cw, lw)
+            assert np.array_equal(gg, eg), (metric, cw, lw)
+            assert np.allclose(gv, ev, rtol=1e-13, atol=0.0), (metric, cw, lw, np.max(np.abs(gv - ev) / np.abs(ev)))
+    # both exponents zero: the plain aggregate, bit for bit
+    gg, gv = ix.similar_to_weighted(ids[targets], k, pvs.L2, pvs.AGG_MIN, conf, lang, 0.0, 0.0)
+    eg, ev = orc.similar_to(orc.F16, orc.L2, hc, targets, groups, orc.AGG_MIN, k)
+    assert np.array_equal(gg, eg) and np.array_equal(gv.view(np.uint64), ev.view(np.uint64))
+    # no confidence arrays at all: every weight is pow(1, x) = 1 -> the AVG
+    gg, gv = ix.similar_to_weighted(ids[targets], k, pvs.L2, pvs.AGG_MAX, None, None, 2.0, 0.5)
+    eg, ev = orc.similar_to(orc.F16, orc.L2, hc, targets, groups, orc.AGG_AVG, k)
+    assert np.array_equal(gg, eg) and np.allclose(gv, ev, rtol=1e-14)
+    ix.close()
+
+
 # ------------------------------------------------------------ fallback / edge paths
 def _check(pvs, ix, dt, metric, hc, hq, k, ids=None):
     exp = orc.search(dt, metric, hc, hq, k, ids=ids, threads=8)

@@ -222,6 +222,11 @@ def test_aggregate_rank_rrf_match_oracle():
     g, v = pvs.aggregate(dist, grp, pvs.AGG_MIN, weights=w)
     og, ov = orc.aggregate(dist, grp, orc.AGG_MIN, w=w)
     assert np.array_equal(v.view(np.uint64), ov.view(np.uint64))
+    # SQL semantics of SUM(d*w)/SUM(w) (exact.rs:67-80): a NULL distance drops out of SUM(d*w) only
+    g, v = pvs.aggregate([np.nan, 1.0, 3.0, np.nan], [7, 7, 8, 9], pvs.AGG_AVG, weights=[2.0, 1.0, 4.0, 5.0])
+    assert g.tolist() == [7, 8, 9] and v[0] == 1.0 / 3.0 and v[1] == 3.0 and np.isnan(v[2])
+    og, ov = orc.aggregate([np.nan, 1.0, 3.0, np.nan], [7, 7, 8, 9], orc.AGG_AVG, w=[2.0, 1.0, 4.0, 5.0])
+    assert np.array_equal(v.view(np.uint64), ov.view(np.uint64))
     with pytest.raises(pvs.PvsError):
         pvs.aggregate(dist[:3], [3, 2, 1], pvs.AGG_MIN)
     ids = rng.permutation(len(v)).astype(np.int64)
