@@ -1168,6 +1168,94 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
     return st;
 }
 
+// MIN aggregation (the reference's default, filters/embedding_types.rs:14-18) without scoring every row
+// into a dense matrix: a group's MIN is the distance of its best row, so the top-k groups are the
+// groups of the first rows of the row ranking.  Take a row page of kp rows through the filter scan,
+// keep each group's first occurrence, and accept iff the page provably contains the answer: it is the
+// whole corpus, or the k-th group's value is strictly below the last row's distance (rows tied with
+// the boundary could otherwise hide an unseen group).  Else grow kp; past PVS_MAX_K the caller runs
+// the dense path.  Values are the same f64(f32 distance) the dense path produces.
+static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                  int64_t *out_groups, double *out_values, uint32_t *out_count, bool *done) {
+    *done = false;
+    if (ix->n == 0 || ix->n_groups == 0 || ix->forced_path == 1) return PVS_OK;
+    const uint64_t n = ix->n;
+    const double per_group = (double)n / (double)ix->n_groups;
+    uint64_t kp = std::max<uint64_t>(64, (uint64_t)(2.0 * k * std::min(std::ceil(per_group), 8.0)));
+    kp = std::min<uint64_t>({kp, (uint64_t)PVS_MAX_K, n});
+    if (kp < std::min<uint64_t>(k, n) || !fast_path_ok(ix, (uint32_t)kp)) return PVS_OK;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_ids_cache.size() != n) {
+            ix->h_ids_cache.resize(n);
+            HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, n * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    std::vector<int64_t> ids;
+    std::vector<float> dist;
+    std::vector<uint32_t> cnt(batch);
+    struct GV {
+        double v;
+        int64_t g;
+    };
+    std::vector<GV> gv;
+    std::vector<int64_t> seen;
+    for (;;) {
+        ids.assign((size_t)batch * kp, -1);
+        dist.assign((size_t)batch * kp, 0.f);
+        PVS_TRY(pvs_search(ix, queries, qdtype, batch, (uint32_t)kp, metric, ids.data(), dist.data(), cnt.data()));
+        bool all_ok = true;
+        for (uint32_t q = 0; q < batch && all_ok; q++) {
+            const int64_t *qi = ids.data() + (size_t)q * kp;
+            const float *qd = dist.data() + (size_t)q * kp;
+            gv.clear();
+            seen.clear();
+            for (uint32_t i = 0; i < cnt[q]; i++) {
+                int64_t g = qi[i];  // identity groups: the group id is the row id
+                if (!ix->h_groups.empty()) {
+                    const auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), qi[i]);
+                    g = ix->h_groups[(size_t)(it - ix->h_ids_cache.begin())];
+                }
+                seen.push_back(g);
+            }
+            // first occurrence of each group, in page order
+            std::vector<uint32_t> order(seen.size());
+            for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seen[a] < seen[b]; });
+            for (size_t i = 0; i < order.size(); i++)
+                if (i == 0 || seen[order[i]] != seen[order[i - 1]]) gv.push_back({(double)qd[order[i]], seen[order[i]]});
+            std::sort(gv.begin(), gv.end(), [](const GV &a, const GV &b) {
+                const bool na = a.v != a.v, nb = b.v != b.v;  // NULL last, then value, then group id
+                if (na != nb) return nb;
+                if (!na && a.v != b.v) return a.v < b.v;
+                return a.g < b.g;
+            });
+            const bool complete = cnt[q] == n;  // the page is the whole corpus
+            const uint32_t want = (uint32_t)std::min<uint64_t>(k, complete ? gv.size() : (uint64_t)k);
+            bool ok = complete;
+            if (!ok && gv.size() >= k && cnt[q] > 0) {
+                const double last = (double)qd[cnt[q] - 1];
+                ok = gv[k - 1].v < last;  // false for NaN on either side
+            }
+            if (!ok) {
+                all_ok = false;
+                break;
+            }
+            for (uint32_t i = 0; i < k; i++) {
+                out_groups[(size_t)q * k + i] = i < want ? gv[i].g : -1;
+                out_values[(size_t)q * k + i] = i < want ? gv[i].v : __builtin_nan("");
+            }
+            out_count[q] = want;
+        }
+        if (all_ok) {
+            *done = true;
+            return PVS_OK;
+        }
+        if (kp >= std::min<uint64_t>(PVS_MAX_K, n)) return PVS_OK;  // give up: dense path
+        kp = std::min<uint64_t>({kp * 4, (uint64_t)PVS_MAX_K, n});
+    }
+}
+
 PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                         double *out_values, uint32_t *out_count) {
@@ -1180,6 +1268,11 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         PVS_TRY(ensure_groups(ix));
+    }
+    if (agg == PVS_AGG_MIN && !row_weights) {
+        bool done = false;
+        PVS_TRY(groups_min_fast(ix, queries, qdtype, batch, k, metric, out_groups, out_values, out_count, &done));
+        if (done) return PVS_OK;
     }
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);

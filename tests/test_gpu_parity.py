@@ -415,6 +415,42 @@ def test_search_groups_matches_sqlite_aggregate_semantics(pvs, dtype):
     ix2.close()
 
 
+def test_min_groups_through_the_filter_scan_equals_dense(pvs):
+    """MIN per group served from a row page of the filter scan (no dense matrix) must equal the dense
+    GROUP BY, including: distance ties across groups at the page boundary (duplicated vectors), groups
+    with many rows (page must grow), k >= number of groups, NULL-only groups."""
+    rng = np.random.default_rng(31)
+    n, dim = 6000, 256
+    rows = unit_rows(59, n, dim)
+    rows[2000:2400] = rows[1000:1400]  # 400 exact duplicates living in other groups: equal distances
+    rows[5000] = 0.0
+    groups = np.concatenate([np.repeat(np.arange(100, dtype=np.int64), 30),  # 100 groups x 30 rows
+                             3000 + rng.integers(0, 800, n - 3000)]).astype(np.int64)
+    groups[5000] = 99_999  # a group whose only row has a NULL cosine distance
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, group_ids=groups)
+    hq = orc.quantize_int8(np.concatenate([orc.synth_rows(0x5EED0003, 0, 5, dim), rows[1000:1002]]), scale)  # two queries ARE stored rows
+    n_groups = len(np.unique(groups))
+    for metric in (pvs.COSINE, pvs.L2):
+        for k in (1, 10, 150, n_groups, n_groups + 5):
+            ix.set_path(0)
+            fg, fv, fc = ix.search_groups(hq, k, metric, pvs.AGG_MIN)
+            ix.set_path(1)
+            dg, dv, dc = ix.search_groups(hq, k, metric, pvs.AGG_MIN)
+            assert np.array_equal(fc, dc), (metric, k)
+            for q in range(len(hq)):
+                assert np.array_equal(fg[q, : fc[q]], dg[q, : dc[q]]), (metric, k, q)
+                a, b = fv[q, : fc[q]], dv[q, : dc[q]]
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    ix.set_path(0)
+    before = ix.stats().dense_queries
+    ix.search_groups(hq, 10, pvs.COSINE, pvs.AGG_MIN)
+    assert ix.stats().dense_queries == before, "MIN over groups must not score the dense matrix"
+    ix.close()
+
+
 @pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
 def test_similar_to_matches_self_join(pvs, dtype):
     # filters/item_similarity.rs:432-581; :3532-3582 similar_to_quant_matches_exact is the ordering-level test
