@@ -310,43 +310,31 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             } else {
                 const bool lane_pass = COS ? (best >= tS) : (best <= tS);
                 if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) {
-                    // Rare path.  Staging is wave-private and its fill count lives in a scalar
-                    // register: no LDS atomics, no barrier.  m16 = this lane's passing rows; each round
-                    // every lane with a bit left appends its lowest one at slot wcnt + (rank of the lane
-                    // in the ballot).  "reg r" is picked with a select chain (dynamic register indexing
-                    // would go through scratch).
-                    uint32_t m16 = 0;
+                    // Rare path (some lane of the wave has a passing row).  Staging is wave-private and its
+                    // fill count lives in a scalar register: no LDS atomics, no barrier.  One ballot per
+                    // tile row r (compile-time r: no dynamic register indexing, no select chains); rows
+                    // nobody passes cost one compare and one not-taken scalar branch.
 #pragma unroll
-                    for (int r = 0; r < 16; r++) m16 |= (COS ? (sv[r] >= tS) : (sv[r] <= tS)) ? (1u << r) : 0u;
-                    for (;;) {
-                        const bool has = m16 != 0;
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
-                        if (bal == 0) break;
-                        const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
-                        if (wcnt + npass > (uint32_t)WCAP) flush_wave();
-                        const uint32_t r = has ? (uint32_t)__builtin_ctz(m16) : 0u;
-                        uint32_t payload = 0;
-                        if constexpr (DT == PVS_I8) {
-#pragma unroll
-                            for (uint32_t rr = 0; rr < 16; rr++) payload = (r == rr) ? (uint32_t)hold[rr] : payload;  // exact integer dot
-                        } else {
-                            float svr = 0.f, xr = 0.f;
-#pragma unroll
-                            for (uint32_t rr = 0; rr < 16; rr++) {
-                                svr = (r == rr) ? sv[rr] : svr;
-                                xr = (r == rr) ? xh[rr] : xr;
+                    for (int r = 0; r < 16; r++) {
+                        const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
+                        if (bal != 0) {
+                            const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
+                            if (__builtin_expect(wcnt + npass > (uint32_t)WCAP, 0)) flush_wave();
+                            uint32_t payload;
+                            if constexpr (DT == PVS_I8)
+                                payload = (uint32_t)hold[r];  // exact integer dot
+                            else
+                                payload = __builtin_bit_cast(uint32_t, COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r]);
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                            if (p) {
+                                const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
+                                st_row[slot] = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
+                                st_key[slot] = payload;
+                                st_q[slot] = (uint32_t)myq;
                             }
-                            payload = __builtin_bit_cast(uint32_t, COS ? -svr * qi.dscale : svr + qi.bb + qi.eR * xr);
+                            wcnt += npass;
                         }
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        if (has) {
-                            const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
-                            st_row[slot] = prev_row_base + (r & 3u) + 8u * (r >> 2);
-                            st_key[slot] = payload;
-                            st_q[slot] = (uint32_t)myq;
-                        }
-                        wcnt += npass;
-                        m16 &= m16 - 1u;
                     }
                 }
             }
