@@ -78,6 +78,8 @@ struct SearchCtx {
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
     float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
+    void *d_qstage = nullptr;     // pvs_search: the caller's host queries, staged (grown on demand, never freed per call)
+    size_t qstage_cap = 0;
     uint8_t *d_qexact = nullptr;  // [MAX_BATCH][dim*4]
     QInfo *d_qinfo = nullptr;     // [MAX_BATCH]
     float *d_thr = nullptr;       // [MAX_BATCH]
@@ -211,6 +213,7 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_qin);
     hipFree(c.d_qmat);
     hipFree(c.d_qpad);
+    hipFree(c.d_qstage);
     hipFree(c.d_qexact);
     hipFree(c.d_qinfo);
     hipFree(c.d_thr);
@@ -771,8 +774,20 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
     const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
     void *d_q = nullptr;
     if (st == PVS_OK) {
-        hipError_t e = hipMalloc(&d_q, qbytes * batch);
-        if (e != hipSuccess) st = pvs_fail(PVS_ERR_OOM, "hipMalloc queries: %s", hipGetErrorString(e));
+        // (hipMalloc/hipFree per call would cost ~0.1 ms and hipFree synchronises the whole device,
+        // stalling the other host threads' searches)
+        if (qbytes * batch > c->qstage_cap) {
+            hipFree(c->d_qstage);
+            c->d_qstage = nullptr;
+            c->qstage_cap = 0;
+            const size_t cap = pvs_round_up(qbytes * batch, 1 << 16);
+            hipError_t e = hipMalloc(&c->d_qstage, cap);
+            if (e != hipSuccess)
+                st = pvs_fail(PVS_ERR_OOM, "hipMalloc queries: %s", hipGetErrorString(e));
+            else
+                c->qstage_cap = cap;
+        }
+        d_q = c->d_qstage;
     }
     bool fast = false;
     if (st == PVS_OK) {
@@ -794,7 +809,6 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
     }
-    hipFree(d_q);
     ix->searches++;
     ctx_done(ix, c);
     return st;

@@ -102,9 +102,9 @@ __device__ static inline float h2f(uint16_t h) { return (float)__builtin_bit_cas
 template <int DT, typename F>
 __device__ static inline void row_foreach(const uint8_t *rows, uint32_t stride, uint64_t r, int dim, F &&f) {
     constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;
+    constexpr int UN = 8;  // loads in flight per lane: the visit is a dependent chain, the loads are not
     const int nchunks = (dim + PER - 1) / PER;
-    for (int c = 0; c < nchunks; c++) {
-        const uint4 v = *(const uint4 *)(rows + pvs_chunk_off(r, (uint32_t)c, stride));
+    auto visit = [&](int c, const uint4 &v) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < PER; j++) {
@@ -118,7 +118,16 @@ __device__ static inline void row_foreach(const uint8_t *rows, uint32_t stride, 
                     f(i, __builtin_bit_cast(float, w[j]));
             }
         }
+    };
+    int c = 0;
+    for (; c + UN <= nchunks; c += UN) {
+        uint4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) v[u] = *(const uint4 *)(rows + pvs_chunk_off(r, (uint32_t)(c + u), stride));
+#pragma unroll
+        for (int u = 0; u < UN; u++) visit(c + u, v[u]);
     }
+    for (; c < nchunks; c++) visit(c, *(const uint4 *)(rows + pvs_chunk_off(r, (uint32_t)c, stride)));
 }
 
 // Sequential-f32 restatement of sqlite-vec's scalar kernels (oracle/pvs_oracle.c):
