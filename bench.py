@@ -204,22 +204,36 @@ def main():
     comm = None
     gather_mode = "single-gpu"
     if world > 1 or args.force_comm:
-        try:
-            idb = None
-            if rank == 0:
+        # Every rank walks the same sequence of control-plane collectives whatever fails locally, and the
+        # ranks agree (gloo all-reduce) on whether the in-library RCCL path is usable: a rank that fell
+        # back alone would leave the others waiting in an all-gather.
+        idb, ok, err = bytes(L.UNIQUE_ID_BYTES), 1.0, ""
+        if rank == 0:
+            try:
                 buf = (L.C.c_uint8 * L.UNIQUE_ID_BYTES)()
                 L.check(lib.pvs_comm_unique_id(buf))
                 idb = bytes(buf)
-            idb = dist.bcast_bytes(idb, L.UNIQUE_ID_BYTES)
-            h = L.C.c_void_p()
-            idarr = (L.C.c_uint8 * L.UNIQUE_ID_BYTES).from_buffer_copy(idb)
-            L.check(lib.pvs_comm_create(idarr, world, rank, device, L.C.byref(h)))
+            except Exception as e:  # noqa: BLE001
+                ok, err = 0.0, str(e)
+        idb = dist.bcast_bytes(idb, L.UNIQUE_ID_BYTES)
+        ok = -dist.max_float(-ok)
+        h = None
+        if ok > 0:
+            try:
+                h = L.C.c_void_p()
+                idarr = (L.C.c_uint8 * L.UNIQUE_ID_BYTES).from_buffer_copy(idb)
+                L.check(lib.pvs_comm_create(idarr, world, rank, device, L.C.byref(h)))
+            except Exception as e:  # noqa: BLE001
+                ok, err, h = 0.0, str(e), None
+            ok = -dist.max_float(-ok)
+        if ok > 0:
             comm = h
             gather_mode = "rccl-allgather"
-        except Exception as e:  # noqa: BLE001
-            log(f"in-library RCCL unavailable ({e}); falling back to a host gather over gloo")
+        else:
+            if h is not None:
+                lib.pvs_comm_destroy(h)
+            log(f"in-library RCCL unavailable on some rank ({err or 'see other ranks'}); falling back to a host gather over gloo")
             gather_mode = "gloo-host-gather"
-
 
     pending = []
 
