@@ -36,6 +36,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int WCAP = 96;          // candidate staging entries per WAVE (wave-private LDS region)
 
@@ -127,13 +128,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qg = wave % QG, rt = wave / QG;
     const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
+    const uint32_t sid = blockIdx.x, nstreams = a.grid;  // this workgroup's tile stream
     const int myq = qg * 32 + j;
 
     const uint32_t ring_lds = lds_addr(ring), norm_lds = lds_addr(normring);
 
-    // tiles of this workgroup: (blockIdx.x + it*grid) * tile_step
+    // tiles of this workgroup: (sid + it*nstreams) * tile_step
     const uint32_t n_samp = (a.n_wgtiles + a.tile_step - 1) / a.tile_step;
-    const int n_my = blockIdx.x < n_samp ? (int)((n_samp - blockIdx.x + a.grid - 1) / a.grid) : 0;
+    const int n_my = sid < n_samp ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
     const uint64_t tile_bytes = (uint64_t)SLAB_ROWS * a.stride;
 
     float mins[MODE == 0 ? 16 : 1];
@@ -185,6 +187,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // A-fragment LDS byte offsets of this lane inside a slab
         const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
         const uint32_t jx = (uint32_t)(j & 15);
+        // the 8 swizzled 16-B chunk positions this lane reads in every slab (k order): one base address per
+        // position and chunk, the slab steps ride in the ds_read immediate offset
+        uint32_t swz[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t c = DT == PVS_F32 ? (uint32_t)(4 * (i >> 1) + 2 * h + (i & 1)) : (uint32_t)(2 * i + h);
+            swz[i] = (c ^ jx) << 4;
+        }
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
         int i_tl = 0, i_ck = 0, i_slot = 0;  // tile, chunk within tile, ring chunk slot
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         uint32_t is_lds = 0, is_norm = 0;
         auto issue_begin = [&]() {
             const int tl = i_tl < n_my ? i_tl : n_my - 1;  // past the end: harmless re-read keeps vmcnt uniform
-            const uint64_t wt = (uint64_t)(blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step;
+            const uint64_t wt = (uint64_t)(sid + (uint32_t)tl * nstreams) * a.tile_step;
             is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
             is_aux = a.aux + wt * SLAB_ROWS;
             if constexpr (DT == PVS_F32 || QG == 8) {
@@ -252,17 +262,21 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // MFMAs:  m < 16: sv[m] = score of row m;  m >= 16: fold two scores into the running best.
         //   sv[r]: cosine  dot * (1/|a|)                 (pass iff sv >= tS)
         //          L2      (1-eR)*|a|^2 - 2*dscale*dot   (pass iff sv <= tS)
+        // (two rows per step: v_pk_mul_f32 / v_pk_fma_f32)
         auto epi_micro = [&](int m, float(&sv)[16], float &best) {
-            if (m < 16) {
-                const float d = (float)hold[m];
-                sv[m] = COS ? d * xh[m] : __builtin_fmaf(d, m2d, c1 * xh[m]);
+            if (m < 8) {
+                const v2f d = {(float)hold[2 * m], (float)hold[2 * m + 1]};
+                const v2f x = {xh[2 * m], xh[2 * m + 1]};
+                const v2f r = COS ? d * x : __builtin_elementwise_fma(d, (v2f){m2d, m2d}, (v2f){c1, c1} * x);
+                sv[2 * m] = r[0];
+                sv[2 * m + 1] = r[1];
             } else {
-                const int r = (m - 16) * 2;
+                const int r = (m - 8) * 2;
                 // NaN (padding / zero-norm rows) never wins a fmax/fmin
                 best = COS ? fmaxf(best, fmaxf(sv[r], sv[r + 1])) : fminf(best, fminf(sv[r], sv[r + 1]));
             }
         };
-        constexpr int EPI_STEPS = 24;
+        constexpr int EPI_STEPS = 16;
         // wave-private candidate staging: fill count (wave-uniform) and the flush to HBM.  The flush
         // issues global atomics/stores, which are unordered against the DMA loads the counted
         // vmcnt waits rely on, so it ends with a full drain of this wave's VMEM queue.
@@ -356,6 +370,9 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
                 issue_begin();                          // the slot the previous chunk occupied is refilled below
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
+                const uint8_t *fb[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) fb[i] = cb + swz[i];
                 // Explicit software pipeline, fenced with sched_barrier(0) so hipcc keeps the order:
                 //   step t:  LDS read of fragment t+PF | MFMA t | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
@@ -366,12 +383,10 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 (void)raw;
                 auto frag = [&](int t) {
                     if constexpr (DT == PVS_F32) {
-                        const uint8_t *sb = cb + (t >> 2) * SLAB_BYTES;
-                        const uint32_t c0 = (uint32_t)(4 * (t & 3) + 2 * h);
-                        raw[t][0] = *(const v4i *)(sb + ((c0 ^ jx) << 4));
-                        raw[t][1] = *(const v4i *)(sb + (((c0 + 1) ^ jx) << 4));
+                        raw[t][0] = *(const v4i *)(fb[2 * (t & 3)] + (t >> 2) * SLAB_BYTES);
+                        raw[t][1] = *(const v4i *)(fb[2 * (t & 3) + 1] + (t >> 2) * SLAB_BYTES);
                     } else {
-                        af[t] = *(const v4i *)(cb + (t >> 3) * SLAB_BYTES + ((((uint32_t)(2 * (t & 7) + h)) ^ jx) << 4));
+                        af[t] = *(const v4i *)(fb[t & 7] + (t >> 3) * SLAB_BYTES);
                     }
                 };
                 auto narrow = [&](int t) {  // VALU work placed behind MFMA t-1
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; f16: within the error budget
-                prev_row_base = (uint32_t)((blockIdx.x + (uint32_t)tl * a.grid) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
+                prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
                 prev_valid = true;
             }
         }
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 
     if (MODE == 2) {
     } else if (MODE == 0) {
-        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * 16;
+        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((sid * RT + rt) * 2 + h) * 16;
 #pragma unroll
         for (int r = 0; r < 16; r++) o[r] = mins[r];
     }
