@@ -701,3 +701,43 @@ def test_or_composition_of_image_and_text_filters_rrf(pvs):
     assert np.array_equal(got_f, exp_f) and np.array_equal(got_s.view(np.uint64), exp_s.view(np.uint64))
     ix_img.close()
     ix_txt.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_clustered_and_skewed_corpora(pvs, dtype):
+    """Real embeddings are clustered and (before normalisation) of very different lengths; the sampled
+    threshold and the error intervals must stay valid there: tight clusters (many near-identical rows, a
+    query inside a cluster), a sample stride that resonates with the cluster layout, rows whose norms span
+    six orders of magnitude (L2 and cosine), and a query far outside the data.  Whatever path answers,
+    the page equals the oracle's."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    rng = np.random.default_rng(41)
+    n, dim, k = 24000, 256, 50
+    centers = rng.standard_normal((40, dim)).astype(np.float32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    assign = np.arange(n) % 40  # cluster id cycles with the row index: periodic in the tile order
+    rows = centers[assign] + 0.02 * rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    queries = np.concatenate([centers[:3] + 0.01 * rng.standard_normal((3, dim)).astype(np.float32),  # inside clusters
+                              rng.standard_normal((2, dim)).astype(np.float32),                        # generic
+                              -centers[5:6]]).astype(np.float32)                                       # opposite of a cluster
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    for metric in (pvs.COSINE, pvs.L2):
+        _check(pvs, ix, dt, metric, hc, hq, k)
+    ix.close()
+    if dt == pvs.I8:
+        return  # one scale per space: int8 spaces are built from normalised vectors
+    # wildly different row norms
+    lens = np.exp(rng.uniform(np.log(1e-3), np.log(1e3), n)).astype(np.float32)
+    if dt == pvs.F16:
+        lens = np.clip(lens, 1e-2, 1e2)  # stay inside binary16's range
+    rows2 = (rows * lens[:, None]).astype(np.float32)
+    q2 = np.concatenate([rows2[[11, 4097]], 1e2 * queries[:2], 1e-2 * queries[3:4]]).astype(np.float32)
+    ix = make_index(pvs, dt, rows2, None)
+    hc = host_corpus(dt, rows2, None)
+    for metric in (pvs.COSINE, pvs.L2):
+        _check(pvs, ix, dt, metric, hc, q2, k)
+    ix.close()
