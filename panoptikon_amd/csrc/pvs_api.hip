@@ -675,7 +675,11 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         const uint32_t rt = a.qgroups >= 4 ? 1 : 4 / a.qgroups;  // row sub-tiles per workgroup
         a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (rt * 32)});
         a.mode = 0;
-        a.groups_per_query = a.grid * rt * 32;
+        // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
+        // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
+        a.gmin_per_lane = 16;
+        while (a.gmin_per_lane > 1 && (uint64_t)a.grid * rt * 2 * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
+        a.groups_per_query = a.grid * rt * 2 * a.gmin_per_lane;
         span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);

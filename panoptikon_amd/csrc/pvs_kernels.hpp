@@ -54,6 +54,7 @@ struct ScanArgs {
     uint32_t grid;          // workgroups
     float *gmin;            // mode 0: [batch_pad][groups_per_query]
     uint32_t groups_per_query;
+    uint32_t gmin_per_lane = 16;  // mode 0: 1..16 (power of two); groups_per_query = grid * RT * 2 * gmin_per_lane
     const float *thr;       // mode 1: [batch_pad]
     uint32_t *cand_cnt;     // [batch_pad]
     uint2 *cand;            // [batch_pad][cand_cap] = (row, key bits)

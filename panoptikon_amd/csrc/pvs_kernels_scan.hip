@@ -32,6 +32,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.n_wgtiles = (uint32_t)((a.n_rows + wg_rows - 1) / wg_rows);
     k.tile_step = a.tile_step ? a.tile_step : 1;
     k.groups_per_query = a.groups_per_query;
+    k.gmin_per_lane = a.gmin_per_lane ? a.gmin_per_lane : 16;
     k.cand_cap = a.cand_cap;
     k.grid = a.grid;
     k.dense_out = a.dense_out;

@@ -452,9 +452,20 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 
     if (MODE == 2) {
     } else if (MODE == 0) {
-        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((sid * RT + rt) * 2 + h) * 16;
+        // Each lane holds 16 minima (one per accumulator row slot) = 16 disjoint row groups of its query.
+        // The threshold only needs a few times k groups per query; folding to a.gmin_per_lane (a power of two)
+        // keeps the k-th select that follows short.
+        const uint32_t gr = a.gmin_per_lane;
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[r] = mins[r];
+        for (int sft = 8; sft >= 1; sft >>= 1)
+            if (gr <= (uint32_t)sft) {
+#pragma unroll
+                for (int r = 0; r < sft; r++) mins[r] = fminf(mins[r], mins[r + sft]);
+            }
+        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * gr;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if ((uint32_t)r < gr) o[r] = mins[r];
     }
 }
 
