@@ -666,6 +666,8 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
         // holds ~k/frac rows: keep that 2.5x below its capacity.
         double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
+        static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
+        if (frac_env > 0.0) frac = frac_env;
         frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
         const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
