@@ -39,30 +39,6 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.dense_flag = a.dense_flag;
     k.dense_ld = a.dense_ld;
     k.batch = a.batch;
-    static const int dbg = getenv("PVS_SCAN_DEBUG") ? atoi(getenv("PVS_SCAN_DEBUG")) : 0;
-    k.debug = a.mode == 1 ? dbg : 0;
-    k.dbg_out = nullptr;
-    static unsigned long long *d_dbg = nullptr;
-    if (k.debug & 16) {
-        if (!d_dbg && hipMalloc((void **)&d_dbg, (size_t)4096 * 4 * 6 * 8) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(d_dbg, 0, (size_t)4096 * 4 * 6 * 8, s);
-        k.dbg_out = d_dbg;
-    }
-    struct DbgPrint {
-        static void run(unsigned long long *d, uint32_t grid, hipStream_t s) {
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> h((size_t)grid * 24);
-            (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
-            double sum[6] = {0, 0, 0, 0, 0, 0};
-            for (size_t i = 0; i < h.size(); i++) sum[i % 6] += (double)h[i];
-            const char *nm[6] = {"vmcnt-wait", "barrier", "dma-issue", "lds+mfma", "epilogue", "flush"};
-            double tot = 0;
-            for (int i = 0; i < 6; i++) tot += sum[i];
-            fprintf(stderr, "[pvs scan phases, mean cycles per wave]");
-            for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.0f (%.1f%%)", nm[i], sum[i] / (grid * 4.0), 100.0 * sum[i] / tot);
-            fprintf(stderr, " total=%.0f\n", tot / (grid * 4.0));
-        }
-    };
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
         e = a.qgroups == 8 ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
@@ -74,7 +50,6 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
         e = a.kslabs <= 4   ? pvs_scan_dispatch_f32_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
             : a.kslabs <= 8 ? pvs_scan_dispatch_f32_mid(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                             : pvs_scan_dispatch_f32_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
-    if (e == hipSuccess && k.dbg_out && a.grid <= 4096) DbgPrint::run(k.dbg_out, a.grid, s);
     return e;
 }
 
@@ -293,7 +268,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
             const uint2 c = cand[s_surv[i]];
             const uint32_t row = c.x;
             const float aa = a.norm2[row];
-            float d;
+            float d = 0.f;
             bool closed = false;
             if constexpr (DT == PVS_I8) {
                 // The reference accumulates integer-valued f32 terms; while every partial sum stays

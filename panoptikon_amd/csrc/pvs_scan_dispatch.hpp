@@ -16,8 +16,6 @@ struct ScanK {
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
     uint32_t dense_ld, batch;
-    unsigned long long *dbg_out;  // PVS_SCAN_DEBUG & 16: per-wave phase cycle sums [grid][4][6]
-    int debug;  // profiling ablations (PVS_SCAN_DEBUG): 1 = no MFMA, 2 = no epilogue, 4 = no DMA in the loop
 };
 
 hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
