@@ -741,3 +741,47 @@ def test_clustered_and_skewed_corpora(pvs, dtype):
     for metric in (pvs.COSINE, pvs.L2):
         _check(pvs, ix, dt, metric, hc, q2, k)
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_many_small_appends_keep_the_tiled_layout_consistent(pvs, dtype):
+    """The index grows by appends of arbitrary size (inline quantization writes one vector at a time,
+    write_inline_quants db/vector_quants.rs:1347-1438): capacity reallocations copy whole 32-row tiles and
+    appends start in the middle of a tile.  After every few appends rows read back, dense scores and the
+    search page must equal the oracle over the rows added so far."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    dim = 200
+    sizes = [1, 31, 33, 100, 7, 1000, 64, 5, 129, 2047, 3]
+    total = sum(sizes)
+    rows = unit_rows(97, total, dim)
+    scale = orc.compute_int8_scale(rows)
+    hc_all = host_corpus(dt, rows, scale)
+    ids_all = np.cumsum(np.random.default_rng(3).integers(1, 5, total)).astype(np.int64)
+    groups_all = (ids_all // 7).astype(np.int64)
+    q = orc.synth_rows(98, 0, 3, dim)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    ix = pvs.VectorIndex(dt, dim)  # no capacity hint: every growth step reallocates
+    if dt == pvs.I8:
+        ix.set_scale(scale)
+    done = 0
+    for step, m in enumerate(sizes):
+        if step % 2 == 0:
+            ix.add_f32(rows[done:done + m], row_ids=ids_all[done:done + m], group_ids=groups_all[done:done + m])
+        else:  # rows already in the index dtype
+            ix.add(hc_all[done:done + m], row_ids=ids_all[done:done + m], group_ids=groups_all[done:done + m])
+        done += m
+        assert ix.stats().rows == done
+        if step % 3 == 2 or step == len(sizes) - 1:
+            got = ix.read_rows(0, done)
+            assert np.array_equal(got.view(np.uint8), hc_all[:done].view(np.uint8)), (dtype, step)
+            for metric in (pvs.COSINE, pvs.L2):
+                _check(pvs, ix, dt, metric, hc_all[:done], hq, min(20, done), ids=ids_all[:done])
+                d = ix.score_all(hq[0], metric)
+                e = orc.score_all(dt, metric, hc_all[:done], hq[0])
+                assert np.array_equal(d.view(np.uint32), e.view(np.uint32))
+            gg, gv, gc = ix.search_groups(hq[:1], 5, pvs.L2, pvs.AGG_AVG)
+            eg, ev = orc.search_groups(dt, orc.L2, hc_all[:done], hq[0], groups_all[:done], orc.AGG_AVG, 5)
+            assert np.array_equal(gg[0, : gc[0]], eg) and np.array_equal(gv[0, : gc[0]].view(np.uint64), ev.view(np.uint64))
+    with pytest.raises(pvs.PvsError):
+        ix.add_f32(rows[:2], row_ids=[ids_all[-1], ids_all[-1] + 1])  # ids must keep increasing
+    ix.close()
