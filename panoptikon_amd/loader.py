@@ -82,8 +82,8 @@ def _existing_setter_ids(conn: sqlite3.Connection, setter_names: Sequence[str]) 
     return [sid for sid in (_setter_id(conn, n) for n in setter_names) if sid is not None]
 
 
-def iter_exact_rows(conn: sqlite3.Connection, setter_names: Sequence[str], chunk_rows: int = 65536
-                    ) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+def iter_exact_rows(conn: sqlite3.Connection, setter_names: Sequence[str], chunk_rows: int = 65536, after_id: int = -1,
+                    dim_bytes: Optional[int] = None) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
     """(row ids, item ids, f32 [n][dim]) chunks of the setters' embeddings in ``item_data.id`` order.
     dim is fixed by the first row; blobs of another length are skipped (the quant backfill applies the
     same ``length(embedding) = dim*4`` guard)."""
@@ -92,8 +92,7 @@ def iter_exact_rows(conn: sqlite3.Connection, setter_names: Sequence[str], chunk
         return
     marks = ",".join("?" * len(sids))
     cur = conn.execute(f"SELECT d.id, d.item_id, e.embedding FROM item_data d JOIN embeddings e ON e.id = d.id "
-                       f"WHERE d.setter_id IN ({marks}) ORDER BY d.id", sids)
-    dim_bytes = None
+                       f"WHERE d.setter_id IN ({marks}) AND d.id > ? ORDER BY d.id", [*sids, after_id])
     while True:
         rows = cur.fetchmany(chunk_rows)
         if not rows:
@@ -109,8 +108,8 @@ def iter_exact_rows(conn: sqlite3.Connection, setter_names: Sequence[str], chunk
         yield ids, items, mat
 
 
-def iter_quant_rows(conn: sqlite3.Connection, profile_id: int, setter_names: Sequence[str], dim: int, chunk_rows: int = 65536
-                    ) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+def iter_quant_rows(conn: sqlite3.Connection, profile_id: int, setter_names: Sequence[str], dim: int, chunk_rows: int = 65536,
+                    after_id: int = -1) -> Iterator[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
     """(row ids, item ids, int8 [n][dim]) chunks of the profile's codes at each setter's current
     ``artifact_rev``, in ``item_data.id`` order (embedding_quants schema: migrations/index/20260730150000)."""
     sids = _existing_setter_ids(conn, setter_names)
@@ -120,7 +119,7 @@ def iter_quant_rows(conn: sqlite3.Connection, profile_id: int, setter_names: Seq
     cur = conn.execute(
         f"SELECT d.id, d.item_id, q.quant FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
         f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
-        f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) ORDER BY d.id", [profile_id, *sids])
+        f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id > ? ORDER BY d.id", [profile_id, *sids, after_id])
     while True:
         rows = cur.fetchmany(chunk_rows)
         if not rows:
@@ -152,6 +151,7 @@ class LoadedIndex:
     profile_id: Optional[int] = None
     scale: Optional[float] = None
     key: tuple = field(default_factory=tuple)
+    last_id: int = -1  # largest item_data.id loaded (appends resume after it)
 
 
 def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtype: int = L.F32, device: int = 0,
@@ -159,16 +159,17 @@ def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtyp
     """The reference's *exact* mode on the device: the setters' f32 embeddings as an f32 (or f16) index."""
     from .index import VectorIndex
 
-    ix, n, dim = None, 0, 0
+    ix, n, dim, last = None, 0, 0, -1
     for ids, items, mat in iter_exact_rows(conn, setter_names, chunk_rows):
         if ix is None:
             dim = mat.shape[1]
             ix = VectorIndex(dtype, dim, device=device)
         ix.add_f32(mat, row_ids=ids, group_ids=items)
         n += len(ids)
+        last = int(ids[-1])
     if ix is None:
         return None
-    return LoadedIndex(ix, "exact", n, dim)
+    return LoadedIndex(ix, "exact", n, dim, last_id=last)
 
 
 def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: Sequence[str], device: int = 0,
@@ -182,11 +183,52 @@ def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: 
         return None
     ix = VectorIndex(L.I8, pair.dim, device=device)
     ix.set_scale(pair.scale)
-    n = 0
+    n, last = 0, -1
     for ids, items, mat in iter_quant_rows(conn, pair.profile_id, setter_names, pair.dim, chunk_rows):
         ix.add(mat, row_ids=ids, group_ids=items)
         n += len(ids)
-    return LoadedIndex(ix, "quant", n, pair.dim, profile_id=pair.profile_id, scale=pair.scale)
+        last = int(ids[-1])
+    return LoadedIndex(ix, "quant", n, pair.dim, profile_id=pair.profile_id, scale=pair.scale, last_id=last)
+
+
+def _count_prefix(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str]) -> int:
+    """Rows the loader would stream with id <= li.last_id — equals li.rows iff nothing the index holds was
+    deleted or replaced since it was loaded."""
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids:
+        return 0
+    marks = ",".join("?" * len(sids))
+    if li.kind == "exact":
+        row = conn.execute(f"SELECT COUNT(*) FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN ({marks}) "
+                           f"AND d.id <= ? AND length(e.embedding) = ?", [*sids, li.last_id, li.dim * 4]).fetchone()
+    else:
+        row = conn.execute(f"SELECT COUNT(*) FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
+                           f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
+                           f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id <= ? AND length(q.quant) = ?",
+                           [li.profile_id, *sids, li.last_id, li.dim]).fetchone()
+    return int(row[0])
+
+
+def append_new_rows(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str], chunk_rows: int = 65536) -> Optional[int]:
+    """After an epoch bump: if every row the index holds is still there (extractions are immutable; deletes
+    cascade), only rows with a larger item_data.id are new — append them.  Returns the number appended, or
+    None when the prefix changed and the caller must rebuild."""
+    if _count_prefix(conn, li, setter_names) != li.rows:
+        return None
+    added = 0
+    if li.kind == "exact":
+        stream = iter_exact_rows(conn, setter_names, chunk_rows, after_id=li.last_id, dim_bytes=li.dim * 4)
+        for ids, items, mat in stream:
+            li.index.add_f32(mat, row_ids=ids, group_ids=items)
+            added += len(ids)
+            li.last_id = int(ids[-1])
+    else:
+        for ids, items, mat in iter_quant_rows(conn, li.profile_id, setter_names, li.dim, chunk_rows, after_id=li.last_id):
+            li.index.add(mat, row_ids=ids, group_ids=items)
+            added += len(ids)
+            li.last_id = int(ids[-1])
+    li.rows += added
+    return added
 
 
 class IndexCache:
@@ -210,7 +252,15 @@ class IndexCache:
         hit = self._items.get(key)
         if hit is not None and hit[0] == epoch:
             return hit[1]
-        # stale (epoch moved) or absent: drop every entry of this (database, kind, setters) and rebuild
+        if hit is not None:  # the epoch moved under the same key (same artifact revs): try to append only
+            still_ok = True
+            if profile_name is not None:  # the pair must still be ready, with the scale the codes were made with
+                pair = resolve_ready_pair(conn, profile_name, names)
+                still_ok = pair is not None and np.float32(pair.scale) == np.float32(hit[1].scale) and pair.dim == hit[1].dim
+            if still_ok and append_new_rows(conn, hit[1], names) is not None:
+                self._items[key] = (epoch, hit[1])
+                return hit[1]
+        # absent, or the loaded prefix changed: drop every entry of this (database, kind, setters) and rebuild
         for k in [k for k in self._items if k[:3] == key[:3]]:
             self._items.pop(k)[1].index.close()
         loaded = (load_exact_index(conn, names, dtype, device) if profile_name is None

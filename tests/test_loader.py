@@ -149,10 +149,32 @@ def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
     conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (99999, 1, 1, 'clip', 1)")
     conn.execute("INSERT INTO embeddings (id, embedding) VALUES (99999, ?)", (q[0].astype('<f4').tobytes(),))
     ex2 = cache.get(conn, "idx", 1, names)
-    assert ex2 is not ex and ex2.rows == len(good) + 1
+    assert ex2 is ex and ex2.rows == len(good) + 1, "an intact prefix is appended to, not rebuilt"
     gi, gd, gc = ex2.index.search(q[:1], 1, pvs.L2)
     assert gi[0, 0] == 99999 and gd[0, 0] == 0.0
+    # a row the index holds disappears (ON DELETE CASCADE of an item): the prefix changed -> rebuild
+    victim = int(ids[5])
+    conn.execute("DELETE FROM embeddings WHERE id = ?", (victim,))
+    conn.execute("DELETE FROM item_data WHERE id = ?", (victim,))
+    ex3 = cache.get(conn, "idx", 2, names)
+    assert ex3 is not ex and ex3.rows == len(good)
+    gi, gd, gc = ex3.index.search(rows[5:6], 3, pvs.L2)
+    assert victim not in gi[0]
+    # the quant index follows: one more code row at the current revision is appended
+    conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (99999, 5, 2, ?)",
+                 (orc.quantize_int8(q[:1], scale)[0].tobytes(),))
+    conn.execute("DELETE FROM embedding_quants WHERE id = ?", (victim,))
+    qu2 = cache.get(conn, "idx", 2, names, profile_name="int8")
+    assert qu2 is not qu and qu2.rows == len(good)  # victim gone (rebuild), new row present
+    conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (100001, 2, 1, 'clip', 2)")
+    conn.execute("INSERT INTO embeddings (id, embedding) VALUES (100001, ?)", (q[1].astype('<f4').tobytes(),))
+    conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (100001, 5, 2, ?)",
+                 (orc.quantize_int8(q[1:2], scale)[0].tobytes(),))
+    qu3 = cache.get(conn, "idx", 3, names, profile_name="int8")
+    assert qu3 is qu2 and qu3.rows == len(good) + 1
+    gi, gd, gc = qu3.index.search(q[1:2], 1, pvs.COSINE)
+    assert gi[0, 0] == 100001
     # not-ready pair -> None (caller falls back to exact / raises under strict selection)
     conn.execute("UPDATE vector_quant_coverage SET state = 'building' WHERE setter_id = 2")
-    assert cache.get(conn, "idx", 2, names, profile_name="int8") is None
+    assert cache.get(conn, "idx", 4, names, profile_name="int8") is None
     cache.clear()
