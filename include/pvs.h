@@ -138,6 +138,11 @@ pvs_status pvs_index_stats(pvs_index *idx, pvs_stats *out);
  * (the stored payload: embeddings.embedding / embedding_quants.quant). */
 pvs_status pvs_index_read_rows(pvs_index *idx, uint64_t row0, uint64_t n, void *out_host);
 
+/* Row ids (item_data.id) and, when out_group_ids != NULL, group ids of rows [row0, row0+n), in row
+ * order — the key columns a host joins pvs_score_all's `d` column back to SQL with (dist_{cte}:
+ * filters/exact.rs:106-134).  Identity groups (no group ids were added) come back as the row ids. */
+pvs_status pvs_index_read_ids(pvs_index *idx, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids);
+
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched
  * on (bench.py's roofline figure).  Off by default. */
 typedef struct pvs_profile {

@@ -69,6 +69,7 @@ SYMBOLS = {
     "pvs_index_set_scale": (_i32, [_vp, _f]),
     "pvs_index_stats": (_i32, [_vp, C.POINTER(Stats)]),
     "pvs_index_read_rows": (_i32, [_vp, _u64, _u64, _vp]),
+    "pvs_index_read_ids": (_i32, [_vp, _u64, _u64, _vp, _vp]),
     "pvs_index_set_profiling": (_i32, [_vp, _i32]),
     "pvs_index_get_profile": (_i32, [_vp, C.POINTER(Profile), _i32]),
     "pvs_search": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),

@@ -530,6 +530,25 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
+    if (!ix || (n && !out_row_ids)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
+                                          (unsigned long long)(row0 + n), (unsigned long long)ix->n);
+    if (n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipMemcpy(out_row_ids, ix->d_ids + row0, n * 8, hipMemcpyDeviceToHost));
+    if (out_group_ids) {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_groups.empty())
+            memcpy(out_group_ids, out_row_ids, n * 8);
+        else if (ix->h_groups.size() < row0 + n)
+            return pvs_fail(PVS_ERR_STATE, "group ids missing for some rows");
+        else
+            memcpy(out_group_ids, ix->h_groups.data() + row0, n * 8);
+    }
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
     if (!ix || (n && !out_host)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,

@@ -216,6 +216,14 @@ class VectorIndex:
                                                 float(language_confidence_weight), _ptr(og), _ptr(ov), C.byref(oc)))
         return og[: oc.value], ov[: oc.value]
 
+    def read_ids(self, row0: int = 0, n: int | None = None, groups: bool = False):
+        """row ids (and group ids) of rows [row0, row0+n) in row order"""
+        n = self.stats().rows - row0 if n is None else n
+        ids = np.empty(n, np.int64)
+        grp = np.empty(n, np.int64) if groups else None
+        L.check(L.lib().pvs_index_read_ids(self._h, row0, n, _ptr(ids), _ptr(grp)))
+        return (ids, grp) if groups else ids
+
     def read_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.dim), _NP[self.dtype])
         L.check(L.lib().pvs_index_read_rows(self._h, row0, n, _ptr(out)))

@@ -178,3 +178,63 @@ def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
     conn.execute("UPDATE vector_quant_coverage SET state = 'building' WHERE setter_id = 2")
     assert cache.get(conn, "idx", 4, names, profile_name="int8") is None
     cache.clear()
+
+
+@pytest.mark.gpu
+def test_dist_cte_seam_sql_runs_unchanged_over_device_distances():
+    """The SQL shape the reference generates around the distance column — MATERIALIZED dist CTE, GROUP BY file_id
+    with MIN, row_number() rank, ORDER BY … NULLS LAST, LIMIT (filters/exact.rs:106-165, builder.rs:757-771,
+    578-582) — run twice on a miniature index DB: (A) with sqlite-vec's scalar functions emulated IN THE TEST by
+    the CPU oracle, as the reference runs it; (B) with the distance column read from a temp table filled by
+    pvs_score_all.  Same pages, same f64 values."""
+    import panoptikon_amd as pvs
+    from panoptikon_amd import loader, sqlite_seam
+
+    conn, good, scale, codes = build_db(n_items=700, dim=128, ragged=False)
+    conn.execute("CREATE TABLE files (id INTEGER PRIMARY KEY, item_id INTEGER NOT NULL, last_modified TEXT NOT NULL)")
+    fid = 0
+    for item in range(1, 701):  # one or two files per item
+        for rep in range(1 + item % 2):
+            fid += 1
+            conn.execute("INSERT INTO files (id, item_id, last_modified) VALUES (?, ?, ?)", (fid, item, f"2024-01-{1 + fid % 28:02d}"))
+    # one all-zero code row: its cosine distance is NULL in SQL
+    zero_id = good[10][0]
+    conn.execute("UPDATE embedding_quants SET quant = ? WHERE id = ? AND rev = 2", (bytes(128), zero_id))
+    q = orc.quantize_int8(orc.synth_rows(4242, 0, 1, 128), scale)[0]
+
+    conn.create_function("vec_int8", 1, lambda b: b, deterministic=True)
+
+    def vdc(a, b):
+        v = orc.vec_distance(orc.COSINE, np.frombuffer(a, np.int8), np.frombuffer(b, np.int8))
+        return None if v != v else float(v)
+
+    conn.create_function("vec_distance_cosine", 2, vdc, deterministic=True)
+    tail = """, agg AS (SELECT file_id, MIN(d) AS order_rank FROM dist GROUP BY file_id),
+              ranked AS (SELECT file_id, order_rank, row_number() OVER (ORDER BY order_rank ASC NULLS LAST, file_id) AS rn FROM agg)
+         SELECT r.file_id, r.order_rank, r.rn FROM ranked r JOIN files f ON f.id = r.file_id
+         ORDER BY r.order_rank ASC NULLS LAST, f.last_modified DESC, r.file_id LIMIT 40 OFFSET 20"""
+    sql_ref = """WITH dist AS MATERIALIZED (
+             SELECT d.item_id AS item_id, f.id AS file_id, vec_distance_cosine(vec_int8(qq.quant), vec_int8(?)) AS d
+             FROM item_data d JOIN setters s ON s.id = d.setter_id
+             JOIN embedding_quants qq ON qq.id = d.id AND qq.profile_id = 5 AND qq.rev = 2
+             JOIN files f ON f.item_id = d.item_id
+             WHERE s.name IN ('clip/m', 'tclip/m'))""" + tail
+    sql_dev = """WITH dist AS MATERIALIZED (
+             SELECT d.item_id AS item_id, f.id AS file_id, p.d AS d
+             FROM item_data d JOIN setters s ON s.id = d.setter_id
+             JOIN pvs_dist p ON p.id = d.id
+             JOIN files f ON f.item_id = d.item_id
+             WHERE s.name IN ('clip/m', 'tclip/m'))""" + tail
+    expected = conn.execute(sql_ref, (q.tobytes(),)).fetchall()
+    li = loader.load_quant_index(conn, "int8", ["clip/m", "tclip/m"])
+    n = sqlite_seam.fill_distance_table(conn, "pvs_dist", li.index, q, pvs.COSINE)
+    assert n == li.rows == len(good)
+    assert conn.execute("SELECT COUNT(*) FROM pvs_dist WHERE d IS NULL").fetchone()[0] == 1
+    got = conn.execute(sql_dev).fetchall()
+    assert len(got) == 40 and got == expected
+    # and without SQL at all: the same first page from pvs_search_groups (items) expanded to files on the host
+    gg, gv, gc = li.index.search_groups(q[None, :], 10, pvs.COSINE, pvs.AGG_MIN)
+    first_items = [r[0] for r in conn.execute(
+        "SELECT d.item_id, MIN(p.d) AS m FROM item_data d JOIN pvs_dist p ON p.id = d.id GROUP BY d.item_id ORDER BY m ASC NULLS LAST, d.item_id LIMIT 10")]
+    assert gg[0, : gc[0]].tolist() == first_items
+    li.index.close()
