@@ -44,9 +44,9 @@ constexpr uint32_t PVS_TILE_ROWS = 32;    // one MFMA 32x32 tile of rows
 constexpr uint32_t PVS_ROW_ALIGN = 128;   // capacity granularity (largest WG tile: 4 row tiles)
 constexpr uint32_t PVS_MAX_BATCH = 128;   // queries per dense / group pass (4 waves x 32)
 constexpr uint32_t PVS_SCAN_MAX_BATCH = 256;  // queries per filter-scan pass (int8: 4 waves x 2 groups x 32); sizes the per-search buffers
-constexpr uint32_t PVS_MAX_K = 2048;      // page size served by the filter path
+constexpr uint32_t PVS_MAX_K = 4096;      // page size served by the filter path (the reference prefetches up to 4096 rows, api/search.rs:51)
 constexpr uint32_t PVS_CAND_CAP = 16384;  // candidate slots per query
-constexpr uint32_t PVS_SURV_CAP = 4096;   // survivors reranked exactly per query
+constexpr uint32_t PVS_SURV_CAP = 8192;   // survivors reranked exactly per query (their sort records overlay the 64 KiB bound array)
 
 // Physical row layout in HBM ("tiled"): rows are grouped in tiles of 32; a tile is
 // stored k-slab major — [slab = byte/256][row in tile][256 B] — and inside each 256-B segment

@@ -117,6 +117,8 @@ CASES = [
     ("i8", "l2", 9000, 1024, 200, 20),
     ("i8", "cosine", 7000, 100, 129, 10),
     ("i8", "l2", 6000, 512, 600, 5),  # 256 + 256 + 88
+    ("i8", "cosine", 30011, 768, 3, 4096),  # the reference's largest prefetch (api/search.rs:51) on the filter path
+    ("f16", "l2", 20000, 512, 2, 2500),
     ("f16", "cosine", 20000, 768, 32, 100),
     ("f16", "l2", 12000, 768, 7, 10),
     ("f16", "cosine", 8000, 512, 70, 100),
@@ -528,7 +530,7 @@ def _check(pvs, ix, dt, metric, hc, hq, k, ids=None):
 def test_massive_ties_fall_back_to_dense(pvs):
     # thousands of identical rows: more survivors than the exact-rerank stage holds -> dense path
     base = unit_rows(51, 64, 768)
-    rows = np.concatenate([np.repeat(base[:1], 6000, axis=0), base, np.repeat(base[1:2], 3000, axis=0)])
+    rows = np.concatenate([np.repeat(base[:1], 9000, axis=0), base, np.repeat(base[1:2], 3000, axis=0)])  # > 8192 survivors
     scale = orc.compute_int8_scale(rows)
     for dt in (pvs.I8, pvs.F16):
         ix = make_index(pvs, dt, rows, scale)
@@ -565,12 +567,15 @@ def test_unrepresentative_sample_overflows_to_dense(pvs):
 
 def test_large_k_many_chunks_odd_shapes(pvs):
     rng = np.random.default_rng(3)
-    # k beyond the filter path's page size -> dense path
+    # k beyond the filter path's page size (4096) -> dense path; k = 3000 of 5000 rows: nearly every row is a survivor
     rows = unit_rows(61, 5000, 512)
     scale = orc.compute_int8_scale(rows)
     q = orc.synth_rows(62, 0, 2, 512)
     ix = make_index(pvs, pvs.I8, rows, scale)
     _check(pvs, ix, pvs.I8, pvs.COSINE, orc.quantize_int8(rows, scale), orc.quantize_int8(q, scale), 3000)
+    before = ix.stats().dense_queries
+    _check(pvs, ix, pvs.I8, pvs.COSINE, orc.quantize_int8(rows, scale), orc.quantize_int8(q, scale), 4500)
+    assert ix.stats().dense_queries == before + 2
     _check(pvs, ix, pvs.I8, pvs.L2, orc.quantize_int8(rows, scale), orc.quantize_int8(q, scale), 1)
     ix.close()
     # 300 queries = three scan chunks (128 + 128 + 44)
