@@ -220,19 +220,34 @@ pvs_status pvs_similar_to(pvs_index *idx, const int64_t *target_row_ids, uint32_
                           pvs_metric metric, pvs_agg agg, int64_t *out_groups, double *out_values,
                           uint32_t *out_count);
 
-/* similar_to with the text source's confidence weights (item_similarity.rs:503-581): per joined pair
- *   w = pow(coalesce(conf_main,1)*coalesce(conf_other,1), confidence_weight)
- *     * pow(coalesce(lang_other,1)*coalesce(lang_main,1), language_confidence_weight)
- * (a factor is dropped when its exponent is 0) and the group value is SUM(d*w)/SUM(w); with both
- * exponents 0 it is the plain `agg` of pvs_similar_to.  row_confidence / row_language_confidence:
- * host arrays, one f64 per stored row in row order, NaN = SQL NULL, NULL pointer = all NULL.
- * pow() is the device math library's (within 1 ulp of the C library SQLite calls): weighted
- * values agree with the reference to ~1e-15 relative, not bit for bit. */
-pvs_status pvs_similar_to_weighted(pvs_index *idx, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
-                                   pvs_metric metric, pvs_agg agg, const double *row_confidence,
-                                   const double *row_language_confidence, double confidence_weight,
-                                   double language_confidence_weight, int64_t *out_groups, double *out_values,
-                                   uint32_t *out_count);
+/* similar_to with everything the reference's filter takes (filters/item_similarity.rs:84-142, 432-581):
+ *  - the text source's confidence weights: per joined pair
+ *      w = pow(coalesce(conf_main,1)*coalesce(conf_other,1), confidence_weight)
+ *        * pow(coalesce(lang_other,1)*coalesce(lang_main,1), language_confidence_weight)
+ *    (a factor is dropped when its exponent is 0) and the group value is SUM(d*w)/SUM(w); with both
+ *    exponents 0 it is the plain `agg`.  row_confidence / row_language_confidence: host arrays, one f64
+ *    per stored row in row order, NaN = SQL NULL, NULL pointer = all NULL;
+ *  - the CLIP cross-modal gates (:473-489): row_kind[row] = PVS_KIND_CLIP or PVS_KIND_TEXT (data_type
+ *    'clip' / 'text-embedding'); with xmodal_i2i == 0 pairs of two clip rows are left out of the
+ *    join, with xmodal_t2t == 0 pairs of two text rows.  row_kind == NULL: no gating.
+ * pow() is the device math library's (within 1 ulp of the C library SQLite calls): weighted values
+ * agree with the reference to ~1e-15 relative, not bit for bit; unweighted ones are bit-exact. */
+#define PVS_KIND_CLIP 0
+#define PVS_KIND_TEXT 1
+typedef struct pvs_similar_opts {
+    uint32_t struct_size; /* sizeof(pvs_similar_opts) */
+    pvs_agg agg;          /* MIN / MAX / AVG (the reference's default for similar_to is AVG) */
+    const double *row_confidence;
+    const double *row_language_confidence;
+    double confidence_weight;
+    double language_confidence_weight;
+    const uint8_t *row_kind;
+    uint32_t xmodal_i2i; /* default 1 */
+    uint32_t xmodal_t2t; /* default 1 */
+} pvs_similar_opts;
+pvs_status pvs_similar_to_ex(pvs_index *idx, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
+                             pvs_metric metric, const pvs_similar_opts *opts, int64_t *out_groups,
+                             double *out_values, uint32_t *out_count);
 
 /* Per-group aggregate of per-row distances (GROUP BY file_id; MIN/MAX/AVG, or
  * SUM(d*w)/SUM(w) when weights != NULL — `agg` is ignored then, exact.rs:67-80; SUM(w) runs over

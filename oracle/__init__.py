@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
         L.orc_aggregate_fanout.argtypes = [vp, sz, vp, vp, sz, i32, vp, vp]
         L.orc_aggregate_fanout_weighted.restype = sz
         L.orc_aggregate_fanout_weighted.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, d, d, vp, vp]
+        L.orc_aggregate_fanout_ex.restype = sz
+        L.orc_aggregate_fanout_ex.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, d, d, vp, i32, i32, i32, vp, vp]
         L.orc_row_number.argtypes = [vp, vp, sz, vp]
         L.orc_rrf_score.restype = d
         L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
@@ -287,6 +289,36 @@ def similar_to_weighted(dtype: int, metric: int, corpus, target_rows, group_ids,
     n = lib().orc_aggregate_fanout_weighted(_p(dist_o), len(targets), _p(excl_o), _p(grp_o), grp.size, _p(tgt), _p(conf_o), _p(lang_o),
                                         float(cw), float(lw), _p(og), _p(ov))
     return _rank_groups(og[:n].copy(), ov[:n].copy(), k)
+
+
+def similar_to_ex(dtype: int, metric: int, corpus, target_rows, group_ids, agg: int, k: int, conf=None, lang=None, cw: float = 0.0,
+                  lw: float = 0.0, kind=None, xmodal_i2i: bool = True, xmodal_t2t: bool = True):
+    """similar_to with confidence weights and the CLIP cross-modal gates (orc_aggregate_fanout_ex)."""
+    c = _corpus(dtype, corpus)
+    targets = list(target_rows)
+    n = c.shape[0]
+    cols = []
+    for t in targets:
+        q = c[t].astype(np.float32) if dtype == F16 else c[t]
+        cols.append(score_all(dtype, metric, c, q))
+    dist = np.ascontiguousarray(np.stack(cols, axis=1), np.float32)
+    grp = _c(group_ids, np.int64)
+    order = np.argsort(grp, kind="stable")
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    excl = np.zeros(n, np.uint8)
+    excl[targets] = 1
+    conf = np.full(n, np.nan) if conf is None else np.asarray(conf, np.float64)
+    lang = np.full(n, np.nan) if lang is None else np.asarray(lang, np.float64)
+    kind_o = None if kind is None else np.ascontiguousarray(np.asarray(kind, np.uint8)[order])
+    dist_o, grp_o, excl_o = np.ascontiguousarray(dist[order]), np.ascontiguousarray(grp[order]), np.ascontiguousarray(excl[order])
+    conf_o, lang_o = np.ascontiguousarray(conf[order]), np.ascontiguousarray(lang[order])
+    tgt = np.ascontiguousarray(inv[np.asarray(targets)], np.uint64)
+    og = np.empty(max(grp.size, 1), np.int64)
+    ov = np.empty(max(grp.size, 1), np.float64)
+    g = lib().orc_aggregate_fanout_ex(_p(dist_o), len(targets), _p(excl_o), _p(grp_o), grp.size, _p(tgt), _p(conf_o), _p(lang_o),
+                                      float(cw), float(lw), _p(kind_o), int(not xmodal_i2i), int(not xmodal_t2t), agg, _p(og), _p(ov))
+    return _rank_groups(og[:g].copy(), ov[:g].copy(), k)
 
 
 def row_number(val, ids=None) -> np.ndarray:

@@ -530,6 +530,60 @@ ORC_API size_t orc_aggregate_fanout_weighted(const float *dist, size_t m, const 
     return g;
 }
 
+/* similar_to with every option of the reference's filter (item_similarity.rs:432-581): the weighted form above
+ * plus the CLIP cross-modal gates (:473-489) — kind[row] 0 = 'clip', 1 = 'text-embedding'; with skip_i2i pairs of
+ * two clip rows are not part of the join, with skip_t2t pairs of two text rows — and, when both exponents are 0,
+ * the plain MIN/MAX/AVG aggregate. */
+ORC_API size_t orc_aggregate_fanout_ex(const float *dist, size_t m, const uint8_t *exclude, const int64_t *group, size_t n,
+                                       const size_t *target, const double *conf, const double *lang, double cw, double lw,
+                                       const uint8_t *kind, int skip_i2i, int skip_t2t, int agg, int64_t *out_group,
+                                       double *out_val) {
+    const int weighted = cw != 0.0 || lw != 0.0;
+    size_t g = 0, i = 0;
+    while (i < n) {
+        size_t j = i;
+        kbn sum = {0, 0}, wsum = {0, 0};
+        double mn = INFINITY, mx = -INFINITY;
+        size_t cnt = 0;
+        for (; j < n && group[j] == group[i]; j++) {
+            if (exclude && exclude[j]) continue;
+            for (size_t t = 0; t < m; t++) {
+                if (kind) {
+                    const uint8_t km = kind[target[t]], ko = kind[j];
+                    if ((skip_i2i && km == 0 && ko == 0) || (skip_t2t && km == 1 && ko == 1)) continue;
+                }
+                double w = 1.0;
+                if (cw != 0.0 && lw != 0.0)
+                    w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw) * pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
+                else if (cw != 0.0)
+                    w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw);
+                else if (lw != 0.0)
+                    w = pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
+                if (weighted) kbn_step(&wsum, w);
+                float df = dist[j * m + t];
+                if (isnan(df)) continue;
+                double d = (double)df;
+                kbn_step(&sum, weighted ? d * w : d);
+                if (d < mn) mn = d;
+                if (d > mx) mx = d;
+                cnt++;
+            }
+        }
+        double v;
+        if (cnt == 0)
+            v = NAN;
+        else if (weighted)
+            v = kbn_value(&sum) / kbn_value(&wsum);
+        else
+            v = agg == ORC_AGG_MIN ? mn : agg == ORC_AGG_MAX ? mx : kbn_value(&sum) / (double)cnt;
+        out_group[g] = group[i];
+        out_val[g] = v;
+        g++;
+        i = j;
+    }
+    return g;
+}
+
 /* ------------------------------------------------------------ rank / RRF */
 
 typedef struct {

@@ -26,6 +26,12 @@ class IndexDesc(C.Structure):
                 ("capacity_rows", C.c_uint64), ("id_base", C.c_int64)]
 
 
+class SimilarOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("agg", C.c_int32), ("row_confidence", C.c_void_p), ("row_language_confidence", C.c_void_p),
+                ("confidence_weight", C.c_double), ("language_confidence_weight", C.c_double), ("row_kind", C.c_void_p),
+                ("xmodal_i2i", C.c_uint32), ("xmodal_t2t", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_uint32), ("dim", C.c_uint32), ("rows", C.c_uint64),
                 ("capacity_rows", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("hbm_bytes", C.c_uint64),
@@ -82,7 +88,7 @@ SYMBOLS = {
     "pvs_score_batch": (_i32, [_vp, _vp, _i32, _u32, _i32, _vp, _i32]),
     "pvs_search_groups": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
-    "pvs_similar_to_weighted": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp]),
+    "pvs_similar_to_ex": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),
     "pvs_quantize_i8": (_i32, [_vp, _u64, _f, _vp, _i32, _i32]),

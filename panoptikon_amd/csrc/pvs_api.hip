@@ -1351,8 +1351,9 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
 }
 
 static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
-                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw, int64_t *out_groups,
-                                  double *out_values, uint32_t *out_count) {
+                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
+                                  const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,
+                                  uint32_t *out_count) {
     if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
     if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
@@ -1382,10 +1383,24 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
     uint8_t *d_ex = nullptr;
     double *d_conf = nullptr, *d_lang = nullptr;
     uint32_t *d_trows = nullptr;
+    uint8_t *d_kind = nullptr;
     const bool weighted = cw != 0.0 || lw != 0.0;
+    const bool gated = row_kind && (skip_i2i || skip_t2t);
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
         FanoutWeights fw;
+        if (weighted || gated) {
+            HIP_TRY(hipMalloc((void **)&d_trows, (size_t)n_targets * 4));
+            HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
+            fw.trows = d_trows;
+        }
+        if (gated) {
+            HIP_TRY(hipMalloc((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
+            HIP_TRY(hipMemcpy(d_kind, row_kind, ix->n, hipMemcpyHostToDevice));
+            fw.kind = d_kind;
+            fw.skip_i2i = skip_i2i;
+            fw.skip_t2t = skip_t2t;
+        }
         if (weighted) {
             // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
             auto upload = [&](const double *src, double **dst) -> pvs_status {
@@ -1398,9 +1413,6 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
             };
             PVS_TRY(upload(row_conf, &d_conf));
             PVS_TRY(upload(row_lang, &d_lang));
-            HIP_TRY(hipMalloc((void **)&d_trows, (size_t)n_targets * 4));
-            HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
-            fw.trows = d_trows;
             fw.conf = d_conf;
             fw.lang = d_lang;
             fw.cw = cw;
@@ -1445,6 +1457,7 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
     hipFree(d_conf);
     hipFree(d_lang);
     hipFree(d_trows);
+    hipFree(d_kind);
     ix->searches++;
     ctx_done(ix, c);
     return st;
@@ -1452,18 +1465,18 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
 
 PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
                                      pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
-    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, nullptr, nullptr, 0.0, 0.0, out_groups, out_values, out_count);
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, nullptr, nullptr, 0.0, 0.0, nullptr, false, false, out_groups,
+                           out_values, out_count);
 }
 
-PVS_EXPORT pvs_status pvs_similar_to_weighted(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k,
-                                              pvs_metric metric, pvs_agg agg, const double *row_confidence,
-                                              const double *row_language_confidence, double confidence_weight,
-                                              double language_confidence_weight, int64_t *out_groups, double *out_values,
-                                              uint32_t *out_count) {
-    if (confidence_weight != confidence_weight || language_confidence_weight != language_confidence_weight)
+PVS_EXPORT pvs_status pvs_similar_to_ex(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                        const pvs_similar_opts *o, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (!o || o->struct_size < sizeof(pvs_similar_opts)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_similar_opts.struct_size too small");
+    if (o->confidence_weight != o->confidence_weight || o->language_confidence_weight != o->language_confidence_weight)
         return pvs_fail(PVS_ERR_INVALID_ARG, "confidence weights must be numbers");
-    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, row_confidence, row_language_confidence, confidence_weight,
-                           language_confidence_weight, out_groups, out_values, out_count);
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, o->agg, o->row_confidence, o->row_language_confidence,
+                           o->confidence_weight, o->language_confidence_weight, o->row_kind, o->xmodal_i2i == 0, o->xmodal_t2t == 0,
+                           out_groups, out_values, out_count);
 }
 
 // ------------------------------------------------------- codec on the device

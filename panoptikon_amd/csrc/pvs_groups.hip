@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
             double w = 1.0;
-            if (fw.trows) {
+            if (fw.trows && fw.kind) {  // cross-modal gates: the pair is not part of the join at all
+                const uint8_t km = fw.kind[fw.trows[c]], ko = fw.kind[row];
+                if ((fw.skip_i2i && km == 0 && ko == 0) || (fw.skip_t2t && km == 1 && ko == 1)) continue;
+            }
+            if (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)) {
                 const uint32_t t = fw.trows[c];
                 if (fw.cw != 0.0) w = pow(coalesce1(fw.conf[t]) * coalesce1(fw.conf[row]), fw.cw);
                 if (fw.lw != 0.0) {
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
             const float df = dist[(size_t)row * ld + c];
             if (df != df) continue;  // SQL NULL distance: d (and d*w) is ignored by the aggregates
             const double d = (double)df;
-            if (weights || fw.trows) {
+            if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0))) {
                 sum.step(d * w);
             } else {
                 sum.step(d);
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
     double v;
     if (cnt == 0)
         v = __builtin_nan("");
-    else if (weights || fw.trows)
+    else if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)))
         v = sum.value() / wsum.value();
     else if (agg == PVS_AGG_MIN)
         v = mn;

@@ -122,6 +122,8 @@ struct FanoutWeights {
     const double *conf = nullptr;     // [rows] confidence, NaN = NULL
     const double *lang = nullptr;     // [rows] language_confidence, NaN = NULL
     double cw = 0.0, lw = 0.0;
+    const uint8_t *kind = nullptr;    // [rows] PVS_KIND_*; gates below apply when set
+    uint32_t skip_i2i = 0, skip_t2t = 0;
 };
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,

@@ -202,19 +202,29 @@ class VectorIndex:
         L.check(L.lib().pvs_similar_to(self._h, _ptr(t), t.size, k, metric, agg, _ptr(og), _ptr(ov), C.byref(oc)))
         return og[: oc.value], ov[: oc.value]
 
-    def similar_to_weighted(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG, confidence=None,
-                            language_confidence=None, confidence_weight: float = 0.0, language_confidence_weight: float = 0.0):
-        """similar_to with the text source's confidence weights (item_similarity.rs:503-581); confidence arrays
-        are one f64 per stored row (NaN = NULL)."""
+    def similar_to_ex(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG, confidence=None,
+                      language_confidence=None, confidence_weight: float = 0.0, language_confidence_weight: float = 0.0,
+                      row_kind=None, xmodal_i2i: bool = True, xmodal_t2t: bool = True):
+        """similar_to with the text source's confidence weights and the CLIP cross-modal gates
+        (item_similarity.rs:473-581); confidence arrays: one f64 per stored row (NaN = NULL); row_kind: 0 = clip,
+        1 = text-embedding per stored row."""
         t = np.ascontiguousarray(target_row_ids, np.int64)
         cf = None if confidence is None else np.ascontiguousarray(confidence, np.float64)
         lg = None if language_confidence is None else np.ascontiguousarray(language_confidence, np.float64)
+        kd = None if row_kind is None else np.ascontiguousarray(row_kind, np.uint8)
+        addr = lambda a: None if a is None else a.ctypes.data  # noqa: E731
+        o = L.SimilarOpts(C.sizeof(L.SimilarOpts), agg, addr(cf), addr(lg), float(confidence_weight), float(language_confidence_weight),
+                          addr(kd), int(bool(xmodal_i2i)), int(bool(xmodal_t2t)))
         og = np.empty(k, np.int64)
         ov = np.empty(k, np.float64)
         oc = C.c_uint32()
-        L.check(L.lib().pvs_similar_to_weighted(self._h, _ptr(t), t.size, k, metric, agg, _ptr(cf), _ptr(lg), float(confidence_weight),
-                                                float(language_confidence_weight), _ptr(og), _ptr(ov), C.byref(oc)))
+        L.check(L.lib().pvs_similar_to_ex(self._h, _ptr(t), t.size, k, metric, C.byref(o), _ptr(og), _ptr(ov), C.byref(oc)))
         return og[: oc.value], ov[: oc.value]
+
+    def similar_to_weighted(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG, confidence=None,
+                            language_confidence=None, confidence_weight: float = 0.0, language_confidence_weight: float = 0.0):
+        return self.similar_to_ex(target_row_ids, k, metric, agg, confidence, language_confidence, confidence_weight,
+                                  language_confidence_weight)
 
     def read_ids(self, row0: int = 0, n: int | None = None, groups: bool = False):
         """row ids (and group ids) of rows [row0, row0+n) in row order"""

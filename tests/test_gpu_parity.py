@@ -515,6 +515,45 @@ def test_similar_to_confidence_weighted(pvs):
     ix.close()
 
 
+def test_similar_to_cross_modal_gates(pvs):
+    """item_similarity.rs:473-489: with clip_xmodal the collection holds image ('clip') and text
+    ('text-embedding') vectors of one CLIP space; xmodal_i2i = false drops clip x clip pairs from the self-join,
+    xmodal_t2t = false the text x text pairs.  Unweighted aggregates stay bit-exact."""
+    rng = np.random.default_rng(37)
+    n, dim, k = 2000, 256, 25
+    rows = unit_rows(67, n, dim)
+    groups = np.sort(_group_ids(rng, n, 450))
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    kind = (rng.random(n) < 0.4).astype(np.uint8)  # 1 = text-embedding
+    tg = groups[777]
+    targets = [int(t) for t in np.nonzero(groups == tg)[0]]
+    kind[targets[0]] = 0
+    if len(targets) > 1:
+        kind[targets[1]] = 1  # the target item has both modalities
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids, group_ids=groups)
+    hc = orc.quantize_int8(rows, scale)
+    conf = rng.uniform(0.1, 1.0, n)
+    for i2i, t2t in ((True, True), (False, True), (True, False), (False, False)):
+        for agg, oagg in ((pvs.AGG_AVG, orc.AGG_AVG), (pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_MAX, orc.AGG_MAX)):
+            gg, gv = ix.similar_to_ex(ids[targets], k, pvs.COSINE, agg, row_kind=kind, xmodal_i2i=i2i, xmodal_t2t=t2t)
+            eg, ev = orc.similar_to_ex(orc.I8, orc.COSINE, hc, targets, groups, oagg, k, kind=kind, xmodal_i2i=i2i, xmodal_t2t=t2t)
+            assert np.array_equal(gg, eg), (i2i, t2t, agg)
+            assert np.array_equal(gv.view(np.uint64), ev.view(np.uint64)), (i2i, t2t, agg)
+        gg, gv = ix.similar_to_ex(ids[targets], k, pvs.L2, pvs.AGG_AVG, confidence=conf, confidence_weight=1.25, row_kind=kind,
+                                  xmodal_i2i=i2i, xmodal_t2t=t2t)
+        eg, ev = orc.similar_to_ex(orc.I8, orc.L2, hc, targets, groups, orc.AGG_AVG, k, conf=conf, cw=1.25, kind=kind, xmodal_i2i=i2i,
+                                   xmodal_t2t=t2t)
+        assert np.array_equal(gg, eg) and np.allclose(gv, ev, rtol=1e-13, atol=0.0)
+    # gates off + no kinds == plain similar_to
+    a = ix.similar_to_ex(ids[targets], k, pvs.COSINE, pvs.AGG_AVG, row_kind=kind)
+    b = ix.similar_to(ids[targets], k, pvs.COSINE, pvs.AGG_AVG)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
+    ix.close()
+
+
 # ------------------------------------------------------------ fallback / edge paths
 def _check(pvs, ix, dt, metric, hc, hq, k, ids=None):
     exp = orc.search(dt, metric, hc, hq, k, ids=ids, threads=8)
