@@ -341,6 +341,21 @@ pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t 
                           uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
                           float *out_dist, uint32_t *out_count);
 
+/* Per-item search over row shards: shard BY GROUP — every row of a file/item on one rank —
+ * so MIN/MAX/AVG and the weighted average stay shard-local; each rank runs pvs_search_groups on its
+ * shard, the pages [batch][k] of (group id, f64 value) are exchanged with one grouped all-gather over
+ * the communicator and merged on every rank under the group ordering (value asc, group id asc, NULL
+ * last).  Host buffers in and out, like pvs_search_groups; row_weights indexes this rank's rows. */
+pvs_status pvs_search_groups_sharded(pvs_index *idx, pvs_comm *comm, const void *queries, pvs_dtype query_dtype,
+                                     uint32_t batch, uint32_t k, pvs_metric metric, pvs_agg agg,
+                                     const float *row_weights, int64_t *out_groups, double *out_values,
+                                     uint32_t *out_count);
+/* The merge step alone, for hosts that gather by other means: pages [world][batch][k], counts
+ * [world][batch] (host buffers).  Groups must not repeat across shards. */
+pvs_status pvs_merge_group_pages(const int64_t *groups, const double *values, const uint32_t *counts,
+                                 uint32_t world, uint32_t batch, uint32_t k, int64_t *out_groups,
+                                 double *out_values, uint32_t *out_count);
+
 /* The device form of pvs_merge_topk (the kernel pvs_search_sharded runs after the all-gather):
  * every pointer is an HBM buffer on `device`; synchronous. */
 pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist,

@@ -88,6 +88,8 @@ SYMBOLS = {
     "pvs_score_batch": (_i32, [_vp, _vp, _i32, _u32, _i32, _vp, _i32]),
     "pvs_search_groups": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
+    "pvs_search_groups_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pvs_merge_group_pages": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_similar_to_ex": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),

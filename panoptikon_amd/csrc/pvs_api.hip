@@ -1350,6 +1350,59 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
     return st;
 }
 
+pvs_status pvs_comm_gather_group_pages_(pvs_comm *c, const int64_t *groups, const double *values, const uint32_t *cnt, int64_t *all_groups,
+                                        double *all_values, uint32_t *all_cnt, uint64_t elems, uint32_t batch, hipStream_t s);
+
+PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, const void *queries, pvs_dtype qdtype, uint32_t batch,
+                                                uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
+                                                double *out_values, uint32_t *out_count) {
+    if (!comm) return pvs_fail(PVS_ERR_INVALID_ARG, "null communicator");
+    if (ix && pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
+    // 1. this shard's page (every rank must take part in the exchange below, whatever its shard holds)
+    std::vector<int64_t> lg((size_t)batch * k, -1);
+    std::vector<double> lv((size_t)batch * k, __builtin_nan(""));
+    std::vector<uint32_t> lc(batch, 0);
+    PVS_TRY(pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, lg.data(), lv.data(), lc.data()));
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint32_t world = (uint32_t)pvs_comm_world_(comm);
+    const uint64_t elems = (uint64_t)batch * k;
+    int64_t *d_g = nullptr, *d_ag = nullptr;
+    double *d_v = nullptr, *d_av = nullptr;
+    uint32_t *d_c = nullptr, *d_ac = nullptr;
+    std::vector<int64_t> ag((size_t)world * elems);
+    std::vector<double> av((size_t)world * elems);
+    std::vector<uint32_t> ac((size_t)world * batch);
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_g, elems * 8));
+        HIP_TRY(hipMalloc((void **)&d_v, elems * 8));
+        HIP_TRY(hipMalloc((void **)&d_c, (size_t)batch * 4));
+        HIP_TRY(hipMalloc((void **)&d_ag, elems * 8 * world));
+        HIP_TRY(hipMalloc((void **)&d_av, elems * 8 * world));
+        HIP_TRY(hipMalloc((void **)&d_ac, (size_t)batch * 4 * world));
+        hipStream_t s = ix->comm_stream;  // every collective of this index goes out on this one stream
+        HIP_TRY(hipMemcpyAsync(d_g, lg.data(), elems * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_v, lv.data(), elems * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_c, lc.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
+        // 2. one grouped all-gather over xGMI
+        PVS_TRY(pvs_comm_gather_group_pages_(comm, d_g, d_v, d_c, d_ag, d_av, d_ac, elems, batch, s));
+        HIP_TRY(hipMemcpyAsync(ag.data(), d_ag, ag.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(av.data(), d_av, av.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ac.data(), d_ac, ac.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // 3. merge on every rank (tiny: world * k entries per query)
+        return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
+    };
+    pvs_status st = body();
+    hipFree(d_g);
+    hipFree(d_v);
+    hipFree(d_c);
+    hipFree(d_ag);
+    hipFree(d_av);
+    hipFree(d_ac);
+    return st;
+}
+
 static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
                                   pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
                                   const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,

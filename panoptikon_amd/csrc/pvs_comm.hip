@@ -124,3 +124,14 @@ pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *
     NCCL_TRY(g_rccl.GroupEnd());
     return PVS_OK;
 }
+
+// (group id i64, value f64, count u32) pages of a per-item search
+pvs_status pvs_comm_gather_group_pages_(pvs_comm *c, const int64_t *groups, const double *values, const uint32_t *cnt, int64_t *all_groups,
+                                        double *all_values, uint32_t *all_cnt, uint64_t elems, uint32_t batch, hipStream_t s) {
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.AllGather(groups, all_groups, elems, ncclInt64, c->comm, s));
+    NCCL_TRY(g_rccl.AllGather(values, all_values, elems, ncclFloat64, c->comm, s));
+    NCCL_TRY(g_rccl.AllGather(cnt, all_cnt, batch, ncclUint32, c->comm, s));
+    NCCL_TRY(g_rccl.GroupEnd());
+    return PVS_OK;
+}

@@ -68,6 +68,19 @@ def rrf_fuse(ranks, ks, weights) -> np.ndarray:
     return out[: r.shape[1]]
 
 
+def merge_group_pages(groups, values, counts, k: int):
+    """groups/values: [world][batch][k] (i64 / f64); counts: [world][batch] -> merged per-item pages."""
+    groups = np.ascontiguousarray(groups, np.int64)
+    values = np.ascontiguousarray(values, np.float64)
+    counts = np.ascontiguousarray(counts, np.uint32)
+    world, batch = counts.shape
+    og = np.empty((batch, k), np.int64)
+    ov = np.empty((batch, k), np.float64)
+    oc = np.empty(batch, np.uint32)
+    L.check(L.lib().pvs_merge_group_pages(_ptr(groups), _ptr(values), _ptr(counts), world, batch, k, _ptr(og), _ptr(ov), _ptr(oc)))
+    return og, ov, oc
+
+
 def merge_topk(ids, dist, counts, k: int):
     """ids/dist: [world][batch][k]; counts: [world][batch] -> merged ([batch][k], ...)."""
     ids = np.ascontiguousarray(ids, np.int64)

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .host import merge_topk
+from .host import merge_group_pages, merge_topk
 
 
 def shard_range(n_rows: int, world: int, rank: int):
@@ -44,3 +44,28 @@ def merge_shard_pages(local_ids, local_dist, local_cnt, gather, k: int):
     dist = gather(np.ascontiguousarray(local_dist, np.float32))
     cnt = gather(np.ascontiguousarray(local_cnt, np.uint32))
     return merge_topk(ids, dist, cnt, k)
+
+
+def shard_ranges_by_group(group_ids, world: int):
+    """Row ranges [r0, r1) per rank for a corpus whose rows are clustered by group (non-decreasing group
+    ids): cuts fall on group boundaries nearest to the even split, so every group lives on one rank
+    and per-item aggregates stay shard-local."""
+    g = np.asarray(group_ids)
+    n = len(g)
+    cuts = [0]
+    for r in range(1, world):
+        c = min(max((n * r) // world, cuts[-1]), n)
+        while 0 < c < n and g[c] == g[c - 1]:
+            c += 1
+        cuts.append(c)
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def merge_shard_group_pages(local_groups, local_values, local_cnt, gather, k: int):
+    """Gathers every rank's per-item page ([batch][k] group ids / f64 values, [batch] counts) and merges them
+    under the group ordering (value asc, group id asc, NULL last)."""
+    grp = gather(np.ascontiguousarray(local_groups, np.int64))
+    val = gather(np.ascontiguousarray(local_values, np.float64))
+    cnt = gather(np.ascontiguousarray(local_cnt, np.uint32))
+    return merge_group_pages(grp, val, cnt, k)

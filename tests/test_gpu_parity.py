@@ -313,6 +313,21 @@ def test_device_merge_and_sharded_search(pvs):
             assert np.array_equal(outs[i][1].to_numpy(np.float32, (40, 50)).view(np.uint32), exps[i][1].view(np.uint32))
             assert np.array_equal(outs[i][2].to_numpy(np.uint32, (40,)), exps[i][2])
     ix.set_streams(1)
+    # (d) per-item search through the communicator (1 rank): gather + merge must be the identity
+    grp = np.sort(rng.integers(0, 2000, len(rows))).astype(np.int64)
+    ixg = pvs.VectorIndex(pvs.I8, 768)
+    ixg.set_scale(scale)
+    ixg.add_f32(rows, group_ids=grp)
+    hq8 = orc.quantize_int8(queries[:6], scale)
+    for agg in (pvs.AGG_MIN, pvs.AGG_AVG):
+        eg, ev, ec = ixg.search_groups(hq8, 30, pvs.COSINE, agg)
+        og, ov, ocn = np.empty((6, 30), np.int64), np.empty((6, 30), np.float64), np.empty(6, np.uint32)
+        L.check(pvs.lib().pvs_search_groups_sharded(ixg._h, comm, hq8.ctypes.data_as(C.c_void_p), L.I8, 6, 30, pvs.COSINE, agg, None,
+                                                    og.ctypes.data_as(C.c_void_p), ov.ctypes.data_as(C.c_void_p),
+                                                    ocn.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(ocn, ec) and np.array_equal(og, eg)
+        assert np.array_equal(np.isnan(ov), np.isnan(ev)) and np.array_equal(ov[~np.isnan(ov)], ev[~np.isnan(ev)])
+    ixg.close()
     pvs.lib().pvs_comm_destroy(comm)
     ix.close()
 

@@ -38,6 +38,21 @@ WORKER = textwrap.dedent("""
         assert (mc == k).all()
         assert np.array_equal(mi, ei), (rank, metric)
         assert np.array_equal(md.view(np.uint32), ed.view(np.uint32))
+    # per-item search: shard BY GROUP, local aggregate per rank (oracle here), merge of (group, f64) pages
+    groups = np.sort(np.random.default_rng(5).integers(0, 400, n)).astype(np.int64)
+    ranges = pvs.shard_ranges_by_group(groups, world)
+    g0, g1 = ranges[rank]
+    assert g0 == 0 or groups[g0] != groups[g0 - 1]
+    for agg in (orc.AGG_MIN, orc.AGG_AVG, orc.AGG_MAX):
+        pg = np.full((batch, k), -1, np.int64); pv = np.full((batch, k), np.nan); pc = np.zeros(batch, np.uint32)
+        for q in range(batch):
+            lg, lv = orc.search_groups(orc.I8, orc.COSINE, codes[g0:g1], qcodes[q], groups[g0:g1], agg, k)
+            pg[q, : len(lg)], pv[q, : len(lv)], pc[q] = lg, lv, len(lg)
+        mg, mv, mc = pvs.merge_shard_group_pages(pg, pv, pc, pvs.TorchDistGather(dist), k)
+        for q in range(batch):
+            eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, qcodes[q], groups, agg, k)
+            assert mc[q] == len(eg) and np.array_equal(mg[q, : len(eg)], eg), (rank, agg, q)
+            assert np.array_equal(mv[q, : len(eg)].view(np.uint64), ev.view(np.uint64))
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.write("rank" + str(rank) + "-ok" + chr(10))
