@@ -271,8 +271,12 @@ void pvs_scale_artifact(float scale, uint8_t out[4]);
 pvs_status pvs_artifact_scale(const uint8_t *artifact, size_t len, float *scale);
 
 /* ------------------------------------------------------------- rank and RRF */
-/* row_number() OVER (ORDER BY value ASC), ties by id ascending, NaN (NULL) last. */
+/* row_number() OVER (ORDER BY value <row_n_direction>) — pql/builder.rs:757-771.  The reference's window has no
+ * NULLS clause, so SQLite's default holds: NaN (NULL) ranks FIRST ascending and LAST descending; ties by
+ * id ascending (the build's deterministic tie-break).  pvs_row_number = ascending (the default direction,
+ * pql/model.rs:233). */
 pvs_status pvs_row_number(const double *values, const int64_t *ids, uint64_t n, int64_t *out_rank);
+pvs_status pvs_row_number_dir(const double *values, const int64_t *ids, uint64_t n, int32_t descending, int64_t *out_rank);
 /* fused[i] = sum_b weight_b * 1.0 / (k_b + coalesce(rank[b][i], 9223372036854775805));
  * ranks: [n_branches][n], rank < 0 = NULL (branch did not return the row). */
 pvs_status pvs_rrf_fuse(const int64_t *ranks, uint32_t n_branches, uint64_t n, const int32_t *ks,

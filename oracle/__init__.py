@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         L.orc_aggregate_fanout_ex.restype = sz
         L.orc_aggregate_fanout_ex.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, d, d, vp, i32, i32, i32, vp, vp]
         L.orc_row_number.argtypes = [vp, vp, sz, vp]
+        L.orc_row_number_dir.argtypes = [vp, vp, sz, i32, vp]
         L.orc_rrf_score.restype = d
         L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
         L.orc_synth_gauss.restype = f
@@ -229,9 +230,12 @@ def aggregate(dist, group, agg: int, w=None):
 
 
 def _rank_groups(groups, values, k):
-    """(value asc, group id asc), NaN (NULL) last -> first k."""
-    ranks = row_number(values, groups)
-    order = np.argsort(ranks)[:k]
+    """Page order of a raw aggregate (`ORDER BY order_rank ASC NULLS LAST`, model.rs:547-553): value asc, NaN
+    (NULL) last, ties by group id asc -> first k."""
+    groups = np.asarray(groups)
+    values = np.asarray(values, np.float64)
+    isn = np.isnan(values)
+    order = np.lexsort((groups, np.where(isn, 0.0, values), isn))[:k]
     return groups[order], values[order]
 
 
@@ -321,11 +325,12 @@ def similar_to_ex(dtype: int, metric: int, corpus, target_rows, group_ids, agg: 
     return _rank_groups(og[:g].copy(), ov[:g].copy(), k)
 
 
-def row_number(val, ids=None) -> np.ndarray:
+def row_number(val, ids=None, descending: bool = False) -> np.ndarray:
+    """row_number() OVER (ORDER BY val ASC|DESC) with SQLite's NULL placement (first ascending, last descending)."""
     val = _c(val, np.float64)
     ids_a = None if ids is None else _c(ids, np.int64)
     out = np.empty(max(val.size, 1), np.int64)
-    lib().orc_row_number(_p(val), _p(ids_a), val.size, _p(out))
+    lib().orc_row_number_dir(_p(val), _p(ids_a), val.size, int(descending), _p(out))
     return out[: val.size]
 
 

@@ -590,31 +590,42 @@ typedef struct {
     double v;
     int64_t id;
 } orc_dpair;
-static int dpair_cmp(const void *p, const void *q) {
+
+/* builder.rs:757-771: `row_number() OVER (ORDER BY agg <row_n_direction>)` — 1-based ranks.  The window has no
+ * NULLS clause, so SQLite's default applies: NULL sorts as the smallest value — FIRST ascending, LAST
+ * descending.  Ties (SQLite leaves them to the scan order) are broken by id ascending: the build's
+ * deterministic tie-break.  rank_out[i] is the rank of element i. */
+typedef struct {
+    orc_dpair k; /* must stay first: the comparators read it */
+    size_t pos;
+} orc_rank_rec;
+static int rank_cmp_asc(const void *p, const void *q) {
     const orc_dpair *x = (const orc_dpair *)p, *y = (const orc_dpair *)q;
     int nx = isnan(x->v), ny = isnan(y->v);
-    if (nx != ny) return nx - ny;
+    if (nx != ny) return ny - nx; /* NULL first */
     if (!nx && x->v != y->v) return x->v < y->v ? -1 : 1;
     return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
 }
-
-/* builder.rs:757-771: row_number() OVER (ORDER BY agg ASC) — 1-based ranks,
- * ties broken by id (the build's tie-break), NULLs last.  rank_out[i] is the
- * rank of element i. */
-ORC_API void orc_row_number(const double *val, const int64_t *ids, size_t n, int64_t *rank_out) {
-    typedef struct {
-        orc_dpair k; /* must stay first: dpair_cmp reads it */
-        size_t pos;
-    } rec;
-    rec *r = (rec *)malloc((n ? n : 1) * sizeof(rec));
+static int rank_cmp_desc(const void *p, const void *q) {
+    const orc_dpair *x = (const orc_dpair *)p, *y = (const orc_dpair *)q;
+    int nx = isnan(x->v), ny = isnan(y->v);
+    if (nx != ny) return nx - ny; /* NULL last */
+    if (!nx && x->v != y->v) return x->v > y->v ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+ORC_API void orc_row_number_dir(const double *val, const int64_t *ids, size_t n, int descending, int64_t *rank_out) {
+    orc_rank_rec *r = (orc_rank_rec *)malloc((n ? n : 1) * sizeof(orc_rank_rec));
     for (size_t i = 0; i < n; i++) {
         r[i].k.v = val[i];
         r[i].k.id = ids ? ids[i] : (int64_t)i;
         r[i].pos = i;
     }
-    qsort(r, n, sizeof(rec), dpair_cmp);
+    qsort(r, n, sizeof(orc_rank_rec), descending ? rank_cmp_desc : rank_cmp_asc);
     for (size_t i = 0; i < n; i++) rank_out[r[i].pos] = (int64_t)(i + 1);
     free(r);
+}
+ORC_API void orc_row_number(const double *val, const int64_t *ids, size_t n, int64_t *rank_out) {
+    orc_row_number_dir(val, ids, n, 0, rank_out);
 }
 
 /* builder.rs:17-18 */

@@ -98,6 +98,7 @@ SYMBOLS = {
     "pvs_scale_artifact": (None, [_f, _vp]),
     "pvs_artifact_scale": (_i32, [_vp, _sz, C.POINTER(_f)]),
     "pvs_row_number": (_i32, [_vp, _vp, _u64, _vp]),
+    "pvs_row_number_dir": (_i32, [_vp, _vp, _u64, _i32, _vp]),
     "pvs_rrf_fuse": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp]),
     "pvs_npy_to_f32": (_i32, [_vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "pvs_resolve_vector_quant": (_i32, [_i32, C.c_char_p, _i64, C.POINTER(ReadyPair), _vp, _sz, _vp, _sz,

@@ -99,19 +99,24 @@ PVS_EXPORT pvs_status pvs_aggregate(const float *dist, const float *weights, con
 
 // ------------------------------------------------------------- rank / RRF
 // builder.rs:757-771: row_number() OVER (ORDER BY value ASC); NULLs last; ties by id
-PVS_EXPORT pvs_status pvs_row_number(const double *values, const int64_t *ids, uint64_t n, int64_t *out_rank) {
+PVS_EXPORT pvs_status pvs_row_number_dir(const double *values, const int64_t *ids, uint64_t n, int32_t descending, int64_t *out_rank) {
     if (n && (!values || !out_rank)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     std::vector<uint64_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
+    // The reference's window carries no NULLS clause, so SQLite's default holds: NULL is the smallest value —
+    // first ascending, last descending.  Ties by id ascending (the build's deterministic tie-break).
     std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
         const bool na = std::isnan(values[a]), nb = std::isnan(values[b]);
-        if (na != nb) return nb;
-        if (!na && values[a] != values[b]) return values[a] < values[b];
+        if (na != nb) return descending ? nb : na;
+        if (!na && values[a] != values[b]) return descending ? values[a] > values[b] : values[a] < values[b];
         const int64_t ia = ids ? ids[a] : (int64_t)a, ib = ids ? ids[b] : (int64_t)b;
         return ia < ib;
     });
     for (uint64_t r = 0; r < n; r++) out_rank[idx[r]] = (int64_t)r + 1;
     return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_row_number(const double *values, const int64_t *ids, uint64_t n, int64_t *out_rank) {
+    return pvs_row_number_dir(values, ids, n, 0, out_rank);
 }
 
 // builder.rs:17-18, 1284-1301

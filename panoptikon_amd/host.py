@@ -48,11 +48,12 @@ def aggregate(dist, group_ids, agg: int, weights=None):
     return og[: n.value].copy(), ov[: n.value].copy()
 
 
-def row_number(values, ids=None) -> np.ndarray:
+def row_number(values, ids=None, descending: bool = False) -> np.ndarray:
+    """row_number() OVER (ORDER BY value ASC|DESC) with SQLite's NULL placement (first ascending, last descending)."""
     v = np.ascontiguousarray(values, np.float64)
     i = None if ids is None else np.ascontiguousarray(ids, np.int64)
     out = np.empty(max(v.size, 1), np.int64)
-    L.check(L.lib().pvs_row_number(_ptr(v), _ptr(i), v.size, _ptr(out)))
+    L.check(L.lib().pvs_row_number_dir(_ptr(v), _ptr(i), v.size, int(descending), _ptr(out)))
     return out[: v.size]
 
 

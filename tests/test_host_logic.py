@@ -231,7 +231,10 @@ def test_aggregate_rank_rrf_match_oracle():
         pvs.aggregate(dist[:3], [3, 2, 1], pvs.AGG_MIN)
     ids = rng.permutation(len(v)).astype(np.int64)
     assert np.array_equal(pvs.row_number(v, ids), orc.row_number(v, ids))
-    assert pvs.row_number([0.5, 0.1, np.nan, 0.1], ids=[4, 9, 1, 3]).tolist() == [3, 2, 4, 1]
+    # SQLite: NULL is the smallest value in a window ORDER BY — first ascending, last descending
+    assert pvs.row_number([0.5, 0.1, np.nan, 0.1], ids=[4, 9, 1, 3]).tolist() == [4, 3, 1, 2]
+    assert pvs.row_number([0.5, 0.1, np.nan, 0.1], ids=[4, 9, 1, 3], descending=True).tolist() == [1, 3, 4, 2]
+    assert np.array_equal(pvs.row_number(v, ids, descending=True), orc.row_number(v, ids, descending=True))
     # RRF with the production weights (quant_ab.rs:233-246): 5/1.0, 5/1.0, 10/0.7
     ranks = rng.integers(-1, 2000, (3, 400)).astype(np.int64)
     ks, ws = [5, 5, 10], [1.0, 1.0, 0.7]

@@ -216,8 +216,24 @@ def test_aggregate_min_max_avg_weighted():
 
 # builder.rs:757-771 row_number; builder.rs:1284-1301 RRF; weights of quant_ab.rs:233-246
 def test_row_number_and_rrf():
+    # the window has no NULLS clause (builder.rs:757-771): SQLite sorts NULL first ascending, last descending
     ranks = orc.row_number([0.5, 0.1, float("nan"), 0.1], ids=[4, 9, 1, 3])
-    assert ranks.tolist() == [3, 2, 4, 1]
+    assert ranks.tolist() == [4, 3, 1, 2]
+    assert orc.row_number([0.5, 0.1, float("nan"), 0.1], ids=[4, 9, 1, 3], descending=True).tolist() == [1, 3, 4, 2]
+    # pinned against SQLite itself (the stdlib module IS the engine whose window semantics the reference relies on)
+    import sqlite3
+
+    rng = np.random.default_rng(12)
+    vals = np.round(rng.random(300), 2)  # many ties
+    vals[rng.integers(0, 300, 25)] = np.nan
+    ids = rng.permutation(300).astype(np.int64)
+    conn = sqlite3.connect(":memory:")
+    conn.execute("CREATE TABLE t (pos INTEGER, id INTEGER, v REAL)")
+    conn.executemany("INSERT INTO t VALUES (?, ?, ?)", [(i, int(ids[i]), None if np.isnan(vals[i]) else float(vals[i])) for i in range(300)])
+    for desc in (False, True):
+        direction = "DESC" if desc else "ASC"
+        sql = conn.execute(f"SELECT pos, row_number() OVER (ORDER BY v {direction}, id ASC) FROM t ORDER BY pos").fetchall()
+        assert orc.row_number(vals, ids, descending=desc).tolist() == [r for _, r in sql]
     ks, ws = [5, 5, 10], [1.0, 1.0, 0.7]
     got = orc.rrf_score([1, 3, -1], ks, ws)
     big = 9223372036854775805
@@ -227,6 +243,35 @@ def test_row_number_and_rrf():
     assert orc.rrf_score([-1], [1], [1.0]) == 1.0 / float(big + 1)
     # default Rrf{k=1, weight=1.0} (pql/model.rs:129-133)
     assert orc.rrf_score([1], [1], [1.0]) == 0.5
+
+
+def test_rrf_expression_and_aggregate_null_semantics_pinned_against_sqlite():
+    """The SQL the reference emits around the distance column, evaluated by SQLite itself (stdlib module) on
+    small inputs: the RRF term `1.0/(k + coalesce(rank, 9223372036854775805)) * weight` incl. the integer
+    overflow of k + BIG (builder.rs:17-18,1284-1301), and MIN/MAX/AVG/SUM(d*w)/SUM(w) with NULL distances
+    (exact.rs:67-80).  Values are dyadic, so summation order and compensation do not matter."""
+    import sqlite3
+
+    conn = sqlite3.connect(":memory:")
+    for ranks, ks, ws in (([1, 3, None], [5, 5, 10], [1.0, 1.0, 0.7]), ([None], [1], [1.0]), ([None, 7], [3, 60], [0.25, 2.0]),
+                          ([2, None], [1, 2], [1.0, 1.0])):
+        expr = " + ".join(f"1.0 / ({k} + coalesce(?, 9223372036854775805)) * {w!r}" for k, w in zip(ks, ws))
+        sql = conn.execute(f"SELECT {expr}", ranks).fetchone()[0]
+        assert orc.rrf_score([-1 if r is None else r for r in ranks], ks, ws) == sql, (ranks, ks, ws)
+    conn.execute("CREATE TABLE d (g INTEGER, d REAL, w REAL)")
+    rows = [(1, 0.5, 2.0), (1, None, 4.0), (1, 0.25, 0.5), (2, None, 1.0), (2, None, 3.0), (3, 1.5, 1.0), (3, 0.75, 1.0), (3, 0.125, 2.0)]
+    conn.executemany("INSERT INTO d VALUES (?, ?, ?)", rows)
+    dist = np.array([np.nan if r[1] is None else r[1] for r in rows], np.float32)
+    grp = np.array([r[0] for r in rows], np.int64)
+    w = np.array([r[2] for r in rows], np.float32)
+    for agg, fn in ((orc.AGG_MIN, "MIN(d)"), (orc.AGG_MAX, "MAX(d)"), (orc.AGG_AVG, "AVG(d)")):
+        sql = conn.execute(f"SELECT g, {fn} FROM d GROUP BY g ORDER BY g").fetchall()
+        g, v = orc.aggregate(dist, grp, agg)
+        assert g.tolist() == [r[0] for r in sql]
+        assert [None if np.isnan(x) else float(x) for x in v] == [r[1] for r in sql], fn
+    sql = conn.execute("SELECT g, SUM(d * w) / SUM(w) FROM d GROUP BY g ORDER BY g").fetchall()
+    g, v = orc.aggregate(dist, grp, orc.AGG_AVG, w=w)
+    assert [None if np.isnan(x) else float(x) for x in v] == [r[1] for r in sql]
 
 
 def test_synth_rows_are_unit_vectors_and_deterministic():
