@@ -264,6 +264,28 @@ pvs_status pvs_absmax(const float *x, uint64_t n, pvs_space space, int32_t devic
 pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, int8_t *out, pvs_space space,
                            int32_t device);
 
+/* OR-composition of vector filters ranked by reciprocal-rank fusion, entirely on the device
+ * (pql/builder.rs:638-661 UNION of the branches' groups; :757-771 per-branch
+ * `row_number() OVER (ORDER BY agg <row_n_direction>)` over EVERY group of the branch — NULL aggregates
+ * first ascending, last descending; :1284-1301 score = sum_b 1.0/(k_b + coalesce(rank_b, 9223372036854775805)) * weight_b,
+ * a branch that does not hold the group contributing its NULL term; ORDER BY score DESC, ties by group id
+ * ascending — the reference breaks them by last_modified, which the index does not hold).
+ * Each branch: one index (all on the same device), one query, its metric and per-group aggregate (row_weights as in
+ * pvs_search_groups).  1..8 branches.  Outputs: host buffers [k]; scores are the f64 SQLite would produce. */
+typedef struct pvs_rrf_branch {
+    pvs_index *idx;
+    const void *query;
+    pvs_dtype query_dtype;
+    pvs_metric metric;
+    pvs_agg agg;
+    const float *row_weights; /* NULL, or one weight per row of idx: SUM(d*w)/SUM(w) */
+    int32_t row_n_descending; /* row_n_direction: 0 = asc (default, pql/model.rs:233) */
+    int32_t rrf_k;            /* Rrf.k, default 1 (pql/model.rs:112-133) */
+    double weight;            /* Rrf.weight, default 1.0 */
+} pvs_rrf_branch;
+pvs_status pvs_rrf_search(const pvs_rrf_branch *branches, uint32_t n_branches, uint32_t k, int64_t *out_groups,
+                          double *out_scores, uint32_t *out_count);
+
 /* ------------------------------------------------------- codec (host scalars) */
 float pvs_scale_from_absmax(float absmax);
 void pvs_scale_artifact(float scale, uint8_t out[4]);

@@ -325,6 +325,30 @@ def similar_to_ex(dtype: int, metric: int, corpus, target_rows, group_ids, agg: 
     return _rank_groups(og[:g].copy(), ov[:g].copy(), k)
 
 
+def rrf_search(branches, k: int):
+    """The reference's OR-composition with RRF, literally: per branch score every row, aggregate per group, rank
+    ALL groups with row_number() (SQLite NULL placement), UNION the groups, fuse, ORDER BY score DESC (ties:
+    group id), LIMIT k.  branches: dicts {dtype, metric, corpus, query, groups, agg, weights=None, descending=False,
+    rrf_k=1, weight=1.0}."""
+    per = []
+    for b in branches:
+        grp = _c(b["groups"], np.int64)
+        d = score_all(b["dtype"], b["metric"], b["corpus"], b["query"])
+        order = np.argsort(grp, kind="stable")
+        w = None if b.get("weights") is None else _c(b["weights"], np.float32)[order]
+        g, v = aggregate(d[order], grp[order], b.get("agg", AGG_MIN), w=w)
+        per.append((g, row_number(v, g, descending=b.get("descending", False))))
+    allg = np.unique(np.concatenate([g for g, _ in per])) if per else np.empty(0, np.int64)
+    ranks = np.full((len(per), len(allg)), -1, np.int64)
+    for i, (g, r) in enumerate(per):
+        ranks[i, np.searchsorted(allg, g)] = r
+    ks = [int(b.get("rrf_k", 1)) for b in branches]
+    ws = [float(b.get("weight", 1.0)) for b in branches]
+    score = np.array([rrf_score(ranks[:, i], ks, ws) for i in range(len(allg))])
+    order = np.lexsort((allg, -score))[:k]
+    return allg[order], score[order]
+
+
 def row_number(val, ids=None, descending: bool = False) -> np.ndarray:
     """row_number() OVER (ORDER BY val ASC|DESC) with SQLite's NULL placement (first ascending, last descending)."""
     val = _c(val, np.float64)

@@ -26,6 +26,11 @@ class IndexDesc(C.Structure):
                 ("capacity_rows", C.c_uint64), ("id_base", C.c_int64)]
 
 
+class RrfBranch(C.Structure):
+    _fields_ = [("idx", C.c_void_p), ("query", C.c_void_p), ("query_dtype", C.c_int32), ("metric", C.c_int32), ("agg", C.c_int32),
+                ("row_weights", C.c_void_p), ("row_n_descending", C.c_int32), ("rrf_k", C.c_int32), ("weight", C.c_double)]
+
+
 class SimilarOpts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("agg", C.c_int32), ("row_confidence", C.c_void_p), ("row_language_confidence", C.c_void_p),
                 ("confidence_weight", C.c_double), ("language_confidence_weight", C.c_double), ("row_kind", C.c_void_p),
@@ -90,6 +95,7 @@ SYMBOLS = {
     "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     "pvs_search_groups_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_merge_group_pages": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_rrf_search": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "pvs_similar_to_ex": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),

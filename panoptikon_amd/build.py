@@ -32,6 +32,7 @@ SOURCES = [
     "pvs_dense.hip",
     "pvs_dense_exact.hip",
     "pvs_groups.hip",
+    "pvs_rrf.hip",
     "pvs_comm.hip",
     "pvs_host.cpp",
 ]

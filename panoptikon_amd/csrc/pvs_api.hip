@@ -1403,6 +1403,88 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     return st;
 }
 
+PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
+                                     uint32_t *out_count) {
+    if (!br || !out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (nb < 1 || nb > (uint32_t)PVS_RRF_MAX_BRANCHES) return pvs_fail(PVS_ERR_INVALID_ARG, "1..%d branches", PVS_RRF_MAX_BRANCHES);
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    PvsRrfParams p;
+    memset(&p, 0, sizeof p);
+    p.n_branches = nb;
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        pvs_index *ix = br[b].idx;
+        PVS_TRY(validate_search(ix, br[b].query, br[b].query_dtype, 1, 1, br[b].metric));
+        if (ix->device != br[0].idx->device) return pvs_fail(PVS_ERR_INVALID_ARG, "all branches must live on one device");
+        if (!br[b].row_weights && br[b].agg != PVS_AGG_MIN && br[b].agg != PVS_AGG_MAX && br[b].agg != PVS_AGG_AVG)
+            return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+        p.k[b] = br[b].rrf_k;
+        p.w[b] = br[b].weight;
+        HIP_TRY(hipSetDevice(ix->device));
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+        total += ix->n_groups;
+    }
+    unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
+    void *d_q = nullptr;
+    float *d_m = nullptr, *d_w = nullptr;
+    double *d_vals = nullptr;
+    auto free_branch = [&]() {
+        hipFree(d_q);
+        hipFree(d_m);
+        hipFree(d_w);
+        hipFree(d_vals);
+        d_q = nullptr;
+        d_m = d_w = nullptr;
+        d_vals = nullptr;
+    };
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&cat_key, std::max<uint64_t>(total, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&cat_pay, std::max<uint64_t>(total, 1) * 8));
+        uint64_t off = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+            pvs_index *ix = br[b].idx;
+            if (ix->n == 0) continue;
+            if (ix->n > (1ull << 31) / 4) return pvs_fail(PVS_ERR_UNSUPPORTED, "branch %u: more than 2^29 rows in one dense column", b);
+            uint32_t t;
+            SearchCtx *c = ctx_acquire(ix, &t);
+            auto one = [&]() -> pvs_status {
+                PVS_TRY(ctx_prepare(ix, *c, 1, 1, false));
+                const size_t qbytes = (size_t)ix->dim * (br[b].query_dtype == PVS_I8 ? 1 : 4);
+                HIP_TRY(hipMalloc(&d_q, qbytes));
+                HIP_TRY(hipMemcpyAsync(d_q, br[b].query, qbytes, hipMemcpyHostToDevice, c->stream));
+                if (br[b].row_weights) {
+                    HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+                    HIP_TRY(hipMemcpyAsync(d_w, br[b].row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+                }
+                HIP_TRY(hipMalloc((void **)&d_m, ix->n * 4));
+                HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+                // every row's exact distance (the dist_{cte} column), aggregated per group in row order ...
+                PVS_TRY(prep_chunk(ix, *c, d_q, br[b].query_dtype, 0, 1, 32, br[b].metric));
+                PVS_TRY(dense_chunk(ix, *c, 1, 32, br[b].metric, d_m));
+                HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, br[b].agg, d_vals,
+                                                   c->stream));
+                // ... ranked over ALL groups of the branch, entries appended in branch order
+                PVS_TRY(pvs_rrf_rank_branch(d_vals, ix->d_grp_ids, ix->n_groups, br[b].row_n_descending != 0, b, cat_key + off, cat_pay + off,
+                                            c->stream));
+                return PVS_OK;
+            };
+            pvs_status st = one();
+            free_branch();
+            ix->searches++;
+            ix->dense_queries++;
+            ctx_done(ix, c);
+            if (st != PVS_OK) return st;
+            off += ix->n_groups;
+        }
+        return pvs_rrf_fuse_device(cat_key, cat_pay, off, p, k, out_groups, out_scores, out_count, br[0].idx->search_stream);
+    };
+    pvs_status st = body();
+    hipFree(cat_key);
+    hipFree(cat_pay);
+    return st;
+}
+
 static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
                                   pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
                                   const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,

@@ -131,3 +131,15 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);
+
+// ---- reciprocal-rank fusion of several ranked branches (pvs_rrf.hip)
+constexpr int PVS_RRF_MAX_BRANCHES = 8;
+struct PvsRrfParams {
+    uint32_t n_branches;
+    int32_t k[PVS_RRF_MAX_BRANCHES];
+    double w[PVS_RRF_MAX_BRANCHES];
+};
+pvs_status pvs_rrf_rank_branch(const double *d_vals, const int64_t *d_gids, uint32_t n, int descending, uint32_t branch,
+                               unsigned long long *cat_key, unsigned long long *cat_pay, hipStream_t s);
+pvs_status pvs_rrf_fuse_device(unsigned long long *cat_key, unsigned long long *cat_pay, uint64_t total, const PvsRrfParams &p, uint32_t k,
+                               int64_t *out_groups, double *out_scores, uint32_t *out_count, hipStream_t s);

@@ -69,6 +69,26 @@ def rrf_fuse(ranks, ks, weights) -> np.ndarray:
     return out[: r.shape[1]]
 
 
+def rrf_search(branches, k: int):
+    """branches: dicts {index, query, metric, agg=AGG_MIN, row_weights=None, descending=False, rrf_k=1, weight=1.0}.
+    OR-composition ranked by reciprocal-rank fusion on the device (pvs_rrf_search) -> (groups[k'], scores[k'])."""
+    arr = (L.RrfBranch * len(branches))()
+    keep = []
+    for i, b in enumerate(branches):
+        ix = b["index"]
+        q, qd = ix._queries(b["query"])
+        w = None if b.get("row_weights") is None else np.ascontiguousarray(b["row_weights"], np.float32)
+        keep += [q, w]
+        arr[i] = L.RrfBranch(ix._h.value if hasattr(ix._h, "value") else ix._h, q.ctypes.data, qd, b["metric"], b.get("agg", L.AGG_MIN),
+                             None if w is None else w.ctypes.data, int(bool(b.get("descending", False))), int(b.get("rrf_k", 1)),
+                             float(b.get("weight", 1.0)))
+    og = np.empty(k, np.int64)
+    ov = np.empty(k, np.float64)
+    oc = C.c_uint32()
+    L.check(L.lib().pvs_rrf_search(C.byref(arr), len(branches), k, _ptr(og), _ptr(ov), C.byref(oc)))
+    return og[: oc.value], ov[: oc.value]
+
+
 def merge_group_pages(groups, values, counts, k: int):
     """groups/values: [world][batch][k] (i64 / f64); counts: [world][batch] -> merged per-item pages."""
     groups = np.ascontiguousarray(groups, np.int64)

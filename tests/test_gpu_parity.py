@@ -844,3 +844,44 @@ def test_many_small_appends_keep_the_tiled_layout_consistent(pvs, dtype):
     with pytest.raises(pvs.PvsError):
         ix.add_f32(rows[:2], row_ids=[ids_all[-1], ids_all[-1] + 1])  # ids must keep increasing
     ix.close()
+
+
+def test_rrf_search_on_device_equals_the_sql_composition(pvs):
+    """pvs_rrf_search: three branches over different indexes (512-d int8 cosine MIN, 1024-d f16 L2 AVG, 256-d f32
+    cosine weighted, descending window) whose group sets only partly overlap; NULL aggregates (zero rows under
+    cosine) rank FIRST in an ascending window; production RRF weights.  Groups, order and f64 scores equal the
+    oracle's literal composition."""
+    rng = np.random.default_rng(43)
+    n_files = 900
+    specs = [(pvs.I8, orc.I8, 512, 2600, pvs.COSINE, orc.COSINE), (pvs.F16, orc.F16, 1024, 1900, pvs.L2, orc.L2),
+             (pvs.F32, orc.F32, 256, 1500, pvs.COSINE, orc.COSINE)]
+    dev, ora = [], []
+    for i, (dt, odt, dim, n, m, om) in enumerate(specs):
+        rows = unit_rows(101 + i, n, dim)
+        pool = np.arange(0, n_files, dtype=np.int64)[rng.random(n_files) < (0.9, 0.6, 0.4)[i]]
+        groups = np.sort(rng.choice(pool, n)).astype(np.int64)
+        if m == pvs.COSINE:
+            z = np.nonzero(groups == groups[n // 3])[0]
+            rows[z] = 0.0  # a whole file of zero vectors: NULL aggregate
+        scale = orc.compute_int8_scale(rows)
+        ix = pvs.VectorIndex(dt, dim)
+        if dt == pvs.I8:
+            ix.set_scale(scale)
+        ix.add_f32(rows, group_ids=groups)
+        q = orc.synth_rows(200 + i, 0, 1, dim)[0]
+        hq = orc.quantize_int8(q[None, :], scale)[0] if dt == pvs.I8 else q
+        w = (rng.random(n) + 0.1).astype(np.float32) if i == 2 else None
+        agg = (pvs.AGG_MIN, pvs.AGG_AVG, pvs.AGG_MAX)[i]
+        desc = i == 2
+        rk, wt = ((5, 1.0), (5, 1.0), (10, 0.7))[i]  # quant_ab.rs:233-246
+        dev.append(dict(index=ix, query=hq, metric=m, agg=agg, row_weights=w, descending=desc, rrf_k=rk, weight=wt))
+        ora.append(dict(dtype=odt, metric=om, corpus=host_corpus(dt, rows, scale), query=hq, groups=groups, agg=agg, weights=w,
+                        descending=desc, rrf_k=rk, weight=wt))
+    for k in (1, 40, 2000):
+        for nb in (1, 2, 3):
+            gg, gs = pvs.rrf_search(dev[:nb], k)
+            eg, es = orc.rrf_search(ora[:nb], k)
+            assert np.array_equal(gg, eg), (k, nb)
+            assert np.array_equal(gs.view(np.uint64), es.view(np.uint64)), (k, nb)
+    for b in dev:
+        b["index"].close()
