@@ -24,9 +24,21 @@
  *                                artifact_scale / scale_artifact, db/vector_quants.rs:1449-1460
  *   pvs_aggregate                rank_aggregate + GROUP BY file_id, filters/exact.rs:67-80,
  *                                pql/builder.rs:829-835
- *   pvs_row_number / pvs_rrf_fuse
+ *   pvs_search_groups[_sharded]  `GROUP BY file_id` + rank_aggregate over dist_{cte} and the page order,
+ *                                filters/exact.rs:67-165, pql/builder.rs:578-582
+ *   pvs_similar_to[_ex]          SimilarTo: self-join fan-out, confidence weights, CLIP cross-modal gates,
+ *                                filters/item_similarity.rs:84-142, 432-581
+ *   pvs_row_number[_dir] / pvs_rrf_fuse
  *                                add_rank_column_expr pql/builder.rs:757-771 and
  *                                build_coalesced_expr pql/builder.rs:1284-1317
+ *   pvs_rrf_search               the OR arm over vector filters: UNION of the branches (pql/builder.rs:638-661),
+ *                                per-branch row_number(), RRF score, ORDER BY ... LIMIT k
+ *   pvs_index_read_ids / pvs_index_read_rows
+ *                                the key / payload columns of dist_{cte} (item_data.id, embeddings.embedding,
+ *                                embedding_quants.quant: migrations/index/20250117193000_init.sql:29-33,
+ *                                20260730150000_embedding_quants_rowid.sql:32-49)
+ *   pvs_search_sharded / pvs_merge_topk / pvs_merge_group_pages
+ *                                no reference counterpart (the reference is single-process): SURVEY.md §8e
  *   pvs_npy_to_f32               embedding_from_npy_bytes, pql/embedding_utils.rs:10-76,229-350
  *   pvs_resolve_vector_quant     resolve_vector_quant policy, pql/preprocess.rs:314-446
  *
