@@ -885,3 +885,37 @@ def test_rrf_search_on_device_equals_the_sql_composition(pvs):
             assert np.array_equal(gs.view(np.uint64), es.view(np.uint64)), (k, nb)
     for b in dev:
         b["index"].close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_shapes_against_the_oracle(pvs, seed):
+    """Seeded sweep over dtype / metric / rows / dim / batch / k (dims that are not multiples of any tile size,
+    single rows, k > rows, batches across the 128/256 pass boundaries), with a sprinkling of duplicated rows,
+    zero rows and, for float indexes, huge and tiny components."""
+    rng = np.random.default_rng(1000 + seed)
+    dt = [pvs.I8, pvs.F16, pvs.F32][seed % 3]
+    metric = [pvs.COSINE, pvs.L2][(seed // 3) % 2]
+    n = int(rng.choice([1, 2, 31, 32, 33, 127, 129, 500, 1999, 4097, 9000]))
+    dim = int(rng.choice([1, 3, 16, 17, 63, 64, 65, 100, 255, 257, 384, 511, 768, 1000, 1024, 1100]))
+    batch = int(rng.choice([1, 2, 31, 33, 127, 129, 257]))
+    k = int(rng.choice([1, 2, 10, 100, 333]))
+    rows = orc.synth_rows(5000 + seed, 0, n, dim) if dim > 1 else rng.standard_normal((n, 1)).astype(np.float32)
+    if n > 8:
+        rows[rng.integers(0, n, 3)] = rows[rng.integers(0, n, 3)]  # duplicates
+        rows[int(rng.integers(0, n))] = 0.0                         # NULL cosine distance
+    if dt != pvs.I8 and n > 4:
+        rows[int(rng.integers(0, n))] *= np.float32(300.0 if dt == pvs.F16 else 1e18)
+        rows[int(rng.integers(0, n))] *= np.float32(1e-3 if dt == pvs.F16 else 1e-18)
+    queries = orc.synth_rows(6000 + seed, 0, batch, dim) if dim > 1 else rng.standard_normal((batch, 1)).astype(np.float32)
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    _check(pvs, ix, dt, metric, hc, hq, k)
+    got = ix.score_batch(hq[:3], metric)
+    for qq in range(min(3, batch)):
+        exp = orc.score_all(dt, metric, hc, hq[qq])
+        assert np.array_equal(np.isnan(got[:, qq]), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[ok, qq].view(np.uint32), exp[ok].view(np.uint32))
+    ix.close()
