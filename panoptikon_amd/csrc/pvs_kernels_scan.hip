@@ -312,6 +312,15 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         }
     }
     const uint32_t nout = m < a.k ? m : a.k;
+    // A NULL distance inside the page (non-finite components) or a short page: NULL rows are ordered by id over
+    // the WHOLE corpus and the candidate list only holds rows whose scan key was comparable -> dense path.
+    if (nout < want || (nout > 0 && (uint32_t)(s_sort[nout - 1] >> 32) == 0xffffffffu)) {
+        if (tid == 0) {
+            a.need_dense[q] = 1;
+            a.out_count[q] = 0;
+        }
+        return;
+    }
     for (uint32_t i = tid; i < a.k; i += 256) {
         if (i < nout) {
             const unsigned long long v = s_sort[i];

@@ -919,3 +919,25 @@ def test_randomized_shapes_against_the_oracle(pvs, seed):
         ok = ~np.isnan(exp)
         assert np.array_equal(got[ok, qq].view(np.uint32), exp[ok].view(np.uint32))
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_non_finite_components(pvs, dtype):
+    """NaN and infinite components in stored rows and in queries: whatever IEEE arithmetic makes of them in the
+    reference's loops (NaN distances = SQL NULL sort last) must come out of the device path too."""
+    dt = pvs.F16 if dtype == "f16" else pvs.F32
+    n, dim = 3000, 96
+    rows = unit_rows(111, n, dim)
+    rows[5, 7] = np.nan
+    rows[17, 0] = np.inf
+    rows[33, 95] = -np.inf
+    rows[40, :] = np.inf
+    q = orc.synth_rows(112, 0, 4, dim)
+    q[1, 3] = np.inf
+    q[2, 10] = np.nan
+    ix = make_index(pvs, dt, rows, None)
+    hc = host_corpus(dt, rows, None)
+    for metric in (pvs.COSINE, pvs.L2):
+        _check(pvs, ix, dt, metric, hc, q, 20)
+        _check(pvs, ix, dt, metric, hc, q[:1], n)  # the whole corpus: NULL rows fill the tail in id order
+    ix.close()
