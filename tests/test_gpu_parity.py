@@ -312,6 +312,19 @@ def test_device_merge_and_sharded_search(pvs):
             assert np.array_equal(outs[i][0].to_numpy(np.int64, (40, 50)), exps[i][0])
             assert np.array_equal(outs[i][1].to_numpy(np.float32, (40, 50)).view(np.uint32), exps[i][1].view(np.uint32))
             assert np.array_equal(outs[i][2].to_numpy(np.uint32, (40,)), exps[i][2])
+    # a batch in which some queries are handed to the dense path (zero query: every cosine distance is NULL): the
+    # sharded search redoes the exchange for that batch after the fallback
+    qz = qsets[0].copy()
+    qz[3] = 0.0
+    qz[17] = 0.0
+    expz = ix.search(qz, 50, pvs.COSINE)
+    assert np.isnan(expz[1][3]).all() and expz[0][3].tolist() == list(range(50))
+    dqz = pvs.DeviceBuffer.from_numpy(qz)
+    for _ in range(2):
+        L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dqz.ptr, L.F32, 40, 50, pvs.COSINE, outs[0][0].ptr, outs[0][1].ptr, outs[0][2].ptr))
+        assert np.array_equal(outs[0][0].to_numpy(np.int64, (40, 50)), expz[0])
+        gdz = outs[0][1].to_numpy(np.float32, (40, 50))
+        assert np.array_equal(np.isnan(gdz), np.isnan(expz[1])) and np.array_equal(gdz[~np.isnan(gdz)], expz[1][~np.isnan(expz[1])])
     ix.set_streams(1)
     # (d) per-item search through the communicator (1 rank): gather + merge must be the identity
     grp = np.sort(rng.integers(0, 2000, len(rows))).astype(np.int64)
