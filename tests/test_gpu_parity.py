@@ -954,3 +954,61 @@ def test_non_finite_components(pvs, dtype):
         _check(pvs, ix, dt, metric, hc, q, 20)
         _check(pvs, ix, dt, metric, hc, q[:1], n)  # the whole corpus: NULL rows fill the tail in id order
     ix.close()
+
+
+def test_full_size_properties_10m_x_768_int8(pvs):
+    """BASELINE configs[2] at full size (10M x 768 int8, 128 queries, k = 100), checked through size-independent
+    properties: pages sorted by (distance, id), ids unique and in range, full pages, two runs bit-identical, the
+    filter path and the dense path (two different algorithms on the device) agree on a few queries, the page is a
+    prefix of the k = 400 page, every returned distance equals the dense `d` column at that row, and row shards
+    merged with pvs_merge_topk reproduce the whole-corpus page."""
+    from panoptikon_amd import _lib as L
+
+    lib = pvs.lib()
+    n, dim, b, k = 10_000_000, 768, 128, 100
+    ix = pvs.VectorIndex(pvs.I8, dim, capacity_rows=n)
+    stage = pvs.DeviceBuffer(1_000_000 * dim * 4)
+    L.check(lib.pvs_synth_rows_f32(0, 20260928, 0, 1_000_000, dim, stage.ptr))
+    amax = L.C.c_float()
+    L.check(lib.pvs_absmax(stage.ptr, 1_000_000 * dim, L.DEVICE, 0, L.C.byref(amax)))
+    ix.set_scale(pvs.scale_from_absmax(float(amax.value) * 1.05))
+    for off in range(0, n, 1_000_000):
+        L.check(lib.pvs_synth_rows_f32(0, 20260928, off, 1_000_000, dim, stage.ptr))
+        ix.add_f32((stage, 1_000_000))
+    stage.free()
+    q = orc.synth_rows(0x5EED0000, 0, b, dim)
+    for metric in (pvs.COSINE, pvs.L2):
+        dense_before = ix.stats().dense_queries
+        gi, gd, gc = ix.search(q, k, metric)
+        assert (gc == k).all() and gi.min() >= 0 and gi.max() < n
+        for r in range(b):
+            assert len(set(gi[r].tolist())) == k
+            key = list(zip(gd[r].tolist(), gi[r].tolist()))
+            assert key == sorted(key), r
+        gi2, gd2, _ = ix.search(q, k, metric)
+        assert np.array_equal(gi, gi2) and np.array_equal(gd.view(np.uint32), gd2.view(np.uint32))
+        wi, wd, _ = ix.search(q[:8], 400, metric)
+        assert np.array_equal(wi[:, :k], gi[:8]) and np.array_equal(wd[:, :k].view(np.uint32), gd[:8].view(np.uint32))
+        assert ix.stats().dense_queries == dense_before, "the filter path must serve this shape"
+        ix.set_path(1)
+        di, dd, _ = ix.search(q[:3], k, metric)
+        ix.set_path(0)
+        assert np.array_equal(di, gi[:3]) and np.array_equal(dd.view(np.uint32), gd[:3].view(np.uint32))
+        col = ix.score_all(q[0], metric)
+        assert np.array_equal(col[gi[0]].view(np.uint32), gd[0].view(np.uint32))
+        assert (col >= gd[0, -1]).sum() >= n - k  # nothing outside the page beats its last entry
+    # row shards of the same corpus, merged: equals the whole-corpus page (ids are global row indexes)
+    gi, gd, gc = ix.search(q[:16], k, pvs.COSINE)
+    pages_i, pages_d, pages_c = [], [], []
+    for r0, r1 in (pvs.shard_range(n, 4, r) for r in range(4)):
+        sh = pvs.VectorIndex(pvs.I8, dim, capacity_rows=r1 - r0, id_base=r0)
+        sh.set_scale(ix.stats().scale)
+        for off in range(r0, r1, 500_000):
+            m = min(500_000, r1 - off)
+            sh.add(ix.read_rows(off, m))
+        si, sd, sc = sh.search(q[:16], k, pvs.COSINE)
+        pages_i.append(si), pages_d.append(sd), pages_c.append(sc)
+        sh.close()
+    mi, md, mc = pvs.merge_topk(np.stack(pages_i), np.stack(pages_d), np.stack(pages_c), k)
+    assert np.array_equal(mi, gi) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
+    ix.close()
