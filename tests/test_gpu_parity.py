@@ -956,8 +956,10 @@ def test_non_finite_components(pvs, dtype):
     ix.close()
 
 
-def test_full_size_properties_10m_x_768_int8(pvs):
-    """BASELINE configs[2] at full size (10M x 768 int8, 128 queries, k = 100), checked through size-independent
+@pytest.mark.parametrize("dtype,n,b", [("i8", 10_000_000, 128), ("f16", 1_000_000, 32), ("f32", 1_000_000, 8)])
+def test_full_size_properties(pvs, dtype, n, b):
+    """BASELINE configs[2] (10M x 768 int8, 128 queries) and configs[1] (1M x 768 f16, 32 queries; also as f32, the
+    reference's exact mode) at full size, k = 100, checked through size-independent
     properties: pages sorted by (distance, id), ids unique and in range, full pages, two runs bit-identical, the
     filter path and the dense path (two different algorithms on the device) agree on a few queries, the page is a
     prefix of the k = 400 page, every returned distance equals the dense `d` column at that row, and row shards
@@ -965,13 +967,15 @@ def test_full_size_properties_10m_x_768_int8(pvs):
     from panoptikon_amd import _lib as L
 
     lib = pvs.lib()
-    n, dim, b, k = 10_000_000, 768, 128, 100
-    ix = pvs.VectorIndex(pvs.I8, dim, capacity_rows=n)
+    dim, k = 768, 100
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    ix = pvs.VectorIndex(dt, dim, capacity_rows=n)
     stage = pvs.DeviceBuffer(1_000_000 * dim * 4)
-    L.check(lib.pvs_synth_rows_f32(0, 20260928, 0, 1_000_000, dim, stage.ptr))
-    amax = L.C.c_float()
-    L.check(lib.pvs_absmax(stage.ptr, 1_000_000 * dim, L.DEVICE, 0, L.C.byref(amax)))
-    ix.set_scale(pvs.scale_from_absmax(float(amax.value) * 1.05))
+    if dt == pvs.I8:
+        L.check(lib.pvs_synth_rows_f32(0, 20260928, 0, 1_000_000, dim, stage.ptr))
+        amax = L.C.c_float()
+        L.check(lib.pvs_absmax(stage.ptr, 1_000_000 * dim, L.DEVICE, 0, L.C.byref(amax)))
+        ix.set_scale(pvs.scale_from_absmax(float(amax.value) * 1.05))
     for off in range(0, n, 1_000_000):
         L.check(lib.pvs_synth_rows_f32(0, 20260928, off, 1_000_000, dim, stage.ptr))
         ix.add_f32((stage, 1_000_000))
@@ -998,15 +1002,17 @@ def test_full_size_properties_10m_x_768_int8(pvs):
         assert np.array_equal(col[gi[0]].view(np.uint32), gd[0].view(np.uint32))
         assert (col >= gd[0, -1]).sum() >= n - k  # nothing outside the page beats its last entry
     # row shards of the same corpus, merged: equals the whole-corpus page (ids are global row indexes)
-    gi, gd, gc = ix.search(q[:16], k, pvs.COSINE)
+    nq = min(16, b)
+    gi, gd, gc = ix.search(q[:nq], k, pvs.COSINE)
     pages_i, pages_d, pages_c = [], [], []
     for r0, r1 in (pvs.shard_range(n, 4, r) for r in range(4)):
-        sh = pvs.VectorIndex(pvs.I8, dim, capacity_rows=r1 - r0, id_base=r0)
-        sh.set_scale(ix.stats().scale)
+        sh = pvs.VectorIndex(dt, dim, capacity_rows=r1 - r0, id_base=r0)
+        if dt == pvs.I8:
+            sh.set_scale(ix.stats().scale)
         for off in range(r0, r1, 500_000):
             m = min(500_000, r1 - off)
             sh.add(ix.read_rows(off, m))
-        si, sd, sc = sh.search(q[:16], k, pvs.COSINE)
+        si, sd, sc = sh.search(q[:nq], k, pvs.COSINE)
         pages_i.append(si), pages_d.append(sd), pages_c.append(sc)
         sh.close()
     mi, md, mc = pvs.merge_topk(np.stack(pages_i), np.stack(pages_d), np.stack(pages_c), k)
