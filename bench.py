@@ -125,6 +125,9 @@ class Dist:
 
 def device_sync(pvs, device):
     # hipDeviceSynchronize through the library's own runtime; torch.cuda.synchronize too when torch is here
+    from panoptikon_amd import _lib as L
+
+    L.check(pvs.lib().pvs_device_synchronize(device))
     if "torch" in sys.modules:
         import torch
 
@@ -182,6 +185,8 @@ def main():
         L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, r0 + off, m, D, stage.ptr))
         ix.add_f32((stage, m))
     stage.free()
+    ix.sync()
+    device_sync(pvs, device)
     log(f"shard rows [{r0}, {r1}) resident in HBM as {args.dtype} in {time.time() - t_build:.1f}s (scale={scale})")
 
     multi = world > 1 or args.force_comm

@@ -401,6 +401,8 @@ pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const flo
                                  int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 
 /* ------------------------------------------------- device memory + synthetic */
+/* hipDeviceSynchronize on `device` (-1: current): every stream of the process, the library's included. */
+pvs_status pvs_device_synchronize(int32_t device);
 pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out);
 pvs_status pvs_device_free(int32_t device, void *ptr);
 pvs_status pvs_memcpy(void *dst, const void *src, size_t bytes, int32_t device);

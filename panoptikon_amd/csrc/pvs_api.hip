@@ -530,6 +530,13 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_device_synchronize(int32_t device) {
+    int dev = 0;
+    PVS_TRY(use_device(device, &dev));
+    HIP_TRY(hipDeviceSynchronize());
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
     if (!ix || (n && !out_row_ids)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
