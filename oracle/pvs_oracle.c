@@ -37,6 +37,9 @@
  *       numeric test for them (only tools/pql-equivalence at rtol 1e-4/atol 1e-6,
  *       which cannot run here).  The scalar two-rounding (mul, then add) x86-64
  *       baseline evaluation order is assumed.
+ *   aggregate / row_number / RRF : pinned against SQLite itself (python's stdlib sqlite3 is the engine) for the
+ *       SQL-level semantics — NULL placement in the window, the RRF term incl. the k + BIG integer overflow,
+ *       MIN/MAX/AVG/SUM(d*w)/SUM(w) over NULL distances (tests/test_oracle_golden.py).
  *
  * Tie-break added by the build (not in the reference):
  *   (distance ascending, row id ascending); NaN distances (SQL NULL) sort last.
