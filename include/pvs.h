@@ -185,6 +185,15 @@ pvs_status pvs_search(pvs_index *idx, const void *queries, pvs_dtype query_dtype
                       uint32_t k, pvs_metric metric, int64_t *out_ids, float *out_dist,
                       uint32_t *out_count);
 
+/* pvs_search over a subset of the rows: the candidate skeleton after the query's other filters (the context
+ * CTE every vector filter is joined to, `WHERE begin_cte.item_id IS NOT NULL`,
+ * filters/image_embeddings.rs:140-199).  allowed_rows: one byte per stored row in row order (host or
+ * device memory), 0 = the row is not a candidate.  Rows outside the mask are never returned, not even as
+ * NULL-distance filler; out_count[q] = min(k, allowed rows). */
+pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
+                               pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space,
+                               int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
 /* Same, with every buffer resident in HBM (queries, out_*).  Enqueues on one of
  * the index's streams and returns without synchronising; *out_ticket identifies
  * the stream to wait on with pvs_wait (or pvs_sync for all of them). */

@@ -78,6 +78,10 @@ struct SearchCtx {
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
     float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
+    const uint8_t *cur_mask = nullptr;  // pvs_search_filtered: candidate mask of the search in flight (device, [rows])
+    uint8_t *d_mask = nullptr;          // its staging copy when the caller's mask is in host memory
+    float *d_aux_masked = nullptr;      // [cap] per-row scalar stream with NaN on rows outside the mask
+    uint64_t mask_cap = 0;
     void *d_qstage = nullptr;     // pvs_search: the caller's host queries, staged (grown on demand, never freed per call)
     size_t qstage_cap = 0;
     uint8_t *d_qexact = nullptr;  // [MAX_BATCH][dim*4]
@@ -214,6 +218,8 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_qmat);
     hipFree(c.d_qpad);
     hipFree(c.d_qstage);
+    hipFree(c.d_mask);
+    hipFree(c.d_aux_masked);
     hipFree(c.d_qexact);
     hipFree(c.d_qinfo);
     hipFree(c.d_thr);
@@ -249,6 +255,7 @@ static pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint3
     } else {
         c.stream = ix->search_stream;
     }
+    c.cur_mask = nullptr;
     if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     if (!c.d_qmat) {
         HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
@@ -627,7 +634,7 @@ static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k,
     const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
     HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, 1,
                                    c.d_qpad, c.dense.d_dist, 1, 0, (uint32_t)ix->n_cu, c.stream));
-    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream));
+    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask));
     ix->dense_queries++;
     return PVS_OK;
 }
@@ -674,6 +681,10 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         a.qgroups = batch_pad / 32;
         a.rows = ix->d_rows;
         a.aux = metric == PVS_COSINE ? ix->d_rnorm : ix->d_norm2;
+        if (c.cur_mask) {  // filtered search: rows outside the mask stream a NaN scalar and never pass
+            HIP_TRY(pvs_launch_mask_aux(a.aux, c.cur_mask, ix->n, ix->cap, c.d_aux_masked, c.stream));
+            a.aux = c.d_aux_masked;
+        }
         a.stride = ix->stride;
         a.n_rows = ix->n;
         a.qmat = c.d_qmat;
@@ -794,8 +805,23 @@ static void ctx_done(pvs_index *ix, SearchCtx *c) {
     c->busy = false;
 }
 
+static pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
 PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                  pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
+}
+
+PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                          pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
+                                          float *out_dist, uint32_t *out_count) {
+    if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
+    return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
+}
+
+static pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0) return PVS_OK;
@@ -825,6 +851,28 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
     if (st == PVS_OK) {
         hipError_t e = hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "H2D queries: %s", hipGetErrorString(e));
+    }
+    if (st == PVS_OK && mask && ix->n) {
+        auto setup = [&]() -> pvs_status {
+            if (ix->cap > c->mask_cap) {
+                hipFree(c->d_mask);
+                hipFree(c->d_aux_masked);
+                c->d_mask = nullptr;
+                c->d_aux_masked = nullptr;
+                c->mask_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_mask, ix->cap));
+                HIP_TRY(hipMalloc((void **)&c->d_aux_masked, ix->cap * 4));
+                c->mask_cap = ix->cap;
+            }
+            if (mask_space == PVS_HOST) {
+                HIP_TRY(hipMemcpyAsync(c->d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
+                c->cur_mask = c->d_mask;
+            } else {
+                c->cur_mask = mask;
+            }
+            return PVS_OK;
+        };
+        st = setup();
     }
     if (st == PVS_OK) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
     if (st == PVS_OK) {

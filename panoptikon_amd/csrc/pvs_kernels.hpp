@@ -100,8 +100,12 @@ struct DenseWork {
 pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n);
 void pvs_dense_release(DenseWork &w);
 // sorts d_dist[0..n) by (distance, row) and writes the first k (ids via ids[]) for one query
+// mask (optional, [n] bytes on the device): rows with mask == 0 are not candidates at all
 pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids,
-                          float *out_dist, uint32_t *out_count, hipStream_t s);
+                          float *out_dist, uint32_t *out_count, hipStream_t s, const uint8_t *mask = nullptr);
+// out[r] = r < n && mask[r] ? aux[r] : NaN for r < cap: the per-row scalar stream of a filtered scan (a NaN
+// scalar makes every filter comparison of the row false)
+hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s);
 
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,

@@ -403,3 +403,15 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
                        stride, scale, metric, qmat, qexact, qinfo, cand_cnt, need_dense);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------ candidate mask
+__global__ __launch_bounds__(256) void k_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out) {
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < cap; r += (uint64_t)gridDim.x * 256)
+        out[r] = (r < n && mask[r]) ? aux[r] : __builtin_nanf("");
+}
+hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s) {
+    if (cap == 0) return hipSuccess;
+    const unsigned g = (unsigned)std::min<uint64_t>((cap + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_mask_aux, dim3(g), dim3(256), 0, s, aux, mask, n, cap, out);
+    return hipGetLastError();
+}

@@ -150,6 +150,19 @@ class VectorIndex:
         L.check(L.lib().pvs_search(self._h, _ptr(q), qd, b, k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
 
+    def search_filtered(self, queries, k: int, allowed_rows, metric: int = L.COSINE):
+        """pvs_search over the rows whose byte in `allowed_rows` ([rows] uint8/bool, row order) is non-zero."""
+        q, qd = self._queries(queries)
+        m = np.ascontiguousarray(allowed_rows).astype(np.uint8, copy=False)
+        if m.shape != (self.stats().rows,):
+            raise ValueError("allowed_rows must have one entry per stored row")
+        b = q.shape[0]
+        ids = np.full((b, k), -1, np.int64)
+        dist = np.full((b, k), np.nan, np.float32)
+        cnt = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_filtered(self._h, _ptr(q), qd, b, k, metric, _ptr(m), L.HOST, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
     def search_device(self, d_queries: DeviceBuffer, qdtype: int, batch: int, k: int, metric: int,
                       d_ids: DeviceBuffer, d_dist: DeviceBuffer, d_cnt: DeviceBuffer) -> int:
         t = C.c_uint32()

@@ -1018,3 +1018,46 @@ def test_full_size_properties(pvs, dtype, n, b):
     mi, md, mc = pvs.merge_topk(np.stack(pages_i), np.stack(pages_d), np.stack(pages_c), k)
     assert np.array_equal(mi, gi) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_search_filtered_by_a_candidate_mask(pvs, dtype):
+    """pvs_search_filtered = the vector filter joined to a context CTE (`WHERE begin_cte.item_id IS NOT NULL`,
+    image_embeddings.rs:140-199): only rows the query's other filters left are candidates.  Dense masks, sparse
+    masks (fewer candidates than k: the page is short and never padded with rows outside the mask), an empty mask,
+    masks that exclude the true nearest neighbours; pages equal the oracle's over the allowed rows only."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    rng = np.random.default_rng(47)
+    n, dim, k = 30000, 384, 50
+    rows = unit_rows(121, n, dim)
+    rows[123] = 0.0  # a NULL cosine distance among the candidates
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(dt, rows, scale)
+    q = orc.synth_rows(122, 0, 6, dim)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    full = orc.search(dt, pvs.COSINE, hc, hq, k)
+    masks = {"half": rng.random(n) < 0.5, "1pct": rng.random(n) < 0.01, "30rows": np.zeros(n, bool), "none": np.zeros(n, bool),
+             "all": np.ones(n, bool), "no_top": np.ones(n, bool), "tile": (np.arange(n) // 32) % 7 == 3}
+    masks["30rows"][rng.choice(n, 30, replace=False)] = True
+    masks["30rows"][123] = True
+    masks["half"][123] = True
+    masks["no_top"][full[0][:, :10].ravel()] = False  # every query loses its 10 best rows
+    for name, m in masks.items():
+        allowed = np.nonzero(m)[0]
+        for metric in (pvs.COSINE, pvs.L2):
+            gi, gd, gc = ix.search_filtered(hq, k, m, metric)
+            if len(allowed) == 0:
+                assert (gc == 0).all() and (gi == -1).all()
+                continue
+            ei, ed = orc.search(dt, metric, hc[allowed], hq, k, ids=allowed.astype(np.int64))
+            w = ei.shape[1]
+            assert gc.tolist() == [w] * len(hq), (name, metric)
+            assert np.array_equal(gi[:, :w], ei), (name, metric)
+            a, b = gd[:, :w], ed
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+            assert (gi[:, w:] == -1).all()
+    # the unfiltered entry point is untouched by a previous filtered search on the same context
+    gi, gd, gc = ix.search(hq, k, pvs.COSINE)
+    assert np.array_equal(gi, full[0])
+    ix.close()
