@@ -263,9 +263,9 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         //   sv[r]: cosine  dot * (1/|a|)                 (pass iff sv >= tS)
         //          L2      (1-eR)*|a|^2 - 2*dscale*dot   (pass iff sv <= tS)
         // (two rows per step: v_pk_mul_f32 / v_pk_fma_f32)
-        auto epi_micro = [&](int m, float(&sv)[16], float &best) {
+        auto epi_micro = [&](int m, float(&sv)[16], float &best, auto &&pv) {
             if (m < 8) {
-                const v2f d = {(float)hold[2 * m], (float)hold[2 * m + 1]};
+                const v2f d = {(float)pv(2 * m), (float)pv(2 * m + 1)};
                 const v2f x = {xh[2 * m], xh[2 * m + 1]};
                 const v2f r = COS ? d * x : __builtin_elementwise_fma(d, (v2f){m2d, m2d}, (v2f){c1, c1} * x);
                 sv[2 * m] = r[0];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         };
         // the rest: group minima (pass A) or candidate emission (pass B)
-        auto epi_rest = [&](const float(&sv)[16], float best) {
+        auto epi_rest = [&](const float(&sv)[16], float best, auto &&pv) {
             if constexpr (MODE == 2) {
                 // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
                 // closed form of the exact integer sums, valid while they stay below 2^24
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                         if (row < a.n_rows && prev_valid) {
                             float d;
                             if (COS) {
-                                d = ref_cosine_finish((float)hold[r], xh[r], qi.bb);
+                                d = ref_cosine_finish((float)pv(r), xh[r], qi.bb);
                             } else {
-                                const double ss = (double)xh[r] + (double)qi.bb - 2.0 * (double)hold[r];
+                                const double ss = (double)xh[r] + (double)qi.bb - 2.0 * (double)pv(r);
                                 if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
                                 d = ref_l2_finish((float)ss);
                             }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                             if (__builtin_expect(wcnt + npass > (uint32_t)WCAP, 0)) flush_wave();
                             uint32_t payload;
                             if constexpr (DT == PVS_I8)
-                                payload = (uint32_t)hold[r];  // exact integer dot
+                                payload = (uint32_t)pv(r);  // exact integer dot
                             else
                                 payload = __builtin_bit_cast(uint32_t, COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r]);
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -354,12 +354,16 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         };
 
-        for (int tl = 0; tl < n_my; tl++) {
-            acc_t acc, acc1;
+        // One tile: MFMA burst into (acc, acc1) with the previous tile's epilogue slices in its shadow; `pv(r)` = the
+        // previous tile's r-th dot product.  PARITY (the 8-wave geometry): accumulators alternate between two
+        // register sets, the previous tile's sums are read where the matrix core left them — no hand-off copy or
+        // add, and one accumulation chain is enough because the SIMD's second wave fills the dependent-issue gap.
+        constexpr bool PARITY = QG == 8;
+        auto run_tile = [&](int tl, acc_t &acc, acc_t &acc1, auto &&pv) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 acc[r] = 0;
-                acc1[r] = 0;
+                if (!PARITY) acc1[r] = 0;
             }
             int norm_slot = 0;
             float sv[16];
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
                 for (int t = 0; t < NF; t++) {
                     if (t + PF < NF) frag(t + PF);
-                    if (t & 1)
+                    if (!PARITY && (t & 1))
                         acc1 = A::mfma(af[t], qf[ck * NF + t], acc1);
                     else
                         acc = A::mfma(af[t], qf[ck * NF + t], acc);
@@ -413,14 +417,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
                     if (ck == 0) {
 #pragma unroll
-                        for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, sv, best);
+                        for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, sv, best, pv);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 norm_slot = c_slot;
                 if (++c_slot == NC) c_slot = 0;
             }
-            epi_rest(sv, best);
+            epi_rest(sv, best, pv);
             // ---- hand this tile's results to the next iteration (its row scalars leave LDS now: the
             // slot is refilled by the DMA issued after the next barrier)
             {
@@ -433,18 +437,45 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     xh[4 * g4 + 2] = v.z;
                     xh[4 * g4 + 3] = v.w;
                 }
+                if constexpr (!PARITY) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; f16: within the error budget
+                    for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; floats: within the error budget
+                }
                 prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
                 prev_valid = true;
             }
-        }
-        {  // drain: the last tile's epilogue
+        };
+        auto drain = [&](auto &&pv) {  // the last tile's epilogue
             float sv[16];
             float best = COS ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
-            for (int m = 0; m < EPI_STEPS; m++) epi_micro(m, sv, best);
-            epi_rest(sv, best);
+            for (int m = 0; m < EPI_STEPS; m++) epi_micro(m, sv, best, pv);
+            epi_rest(sv, best, pv);
+        };
+        if constexpr (PARITY) {
+            acc_t accA, accB, unused;
+#pragma unroll
+            for (int r = 0; r < 16; r++) accB[r] = 0;  // tile "-1"
+            auto pa = [&](int r) { return accA[r]; };
+            auto pb = [&](int r) { return accB[r]; };
+            int tl = 0;
+            for (; tl + 1 < n_my; tl += 2) {
+                run_tile(tl, accA, unused, pb);
+                run_tile(tl + 1, accB, unused, pa);
+            }
+            if (tl < n_my) {
+                run_tile(tl, accA, unused, pb);
+                drain(pa);
+            } else {
+                drain(pb);
+            }
+        } else {
+            auto ph = [&](int r) { return hold[r]; };
+            for (int tl = 0; tl < n_my; tl++) {
+                acc_t acc, acc1;
+                run_tile(tl, acc, acc1, ph);
+            }
+            drain(ph);
         }
         if (MODE == 1) flush_wave();
         wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
