@@ -21,6 +21,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [
     "pvs_api.hip",
+    "pvs_search.hip",
+    "pvs_items.hip",
     "pvs_kernels_util.hip",
     "pvs_kernels_scan.hip",
     "pvs_scan_i8.hip",

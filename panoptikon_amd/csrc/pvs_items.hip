@@ -1,0 +1,570 @@
+// pvs_items.hip — C ABI of libpvs, part 3: per-item results on the device — GROUP BY aggregates and their
+// ranking, dense score matrices, similar_to, reciprocal-rank fusion across indexes, sharded per-item search.
+#include "pvs_index.hpp"
+
+// ------------------------------------------------- groups, dense scores, similar_to
+pvs_status ensure_groups(pvs_index *ix) {
+    if (ix->groups_built_n == ix->n) return PVS_OK;
+    if (!ix->h_groups.empty() && ix->h_groups.size() != ix->n) return pvs_fail(PVS_ERR_STATE, "group ids missing for some rows");
+    hipFree(ix->d_grp_off);
+    hipFree(ix->d_grp_rows);
+    hipFree(ix->d_grp_ids);
+    ix->d_grp_off = ix->d_grp_rows = nullptr;
+    ix->d_grp_ids = nullptr;
+    const uint64_t n = ix->n;
+    std::vector<uint32_t> off, rows(n);
+    std::vector<int64_t> gids;
+    if (ix->h_groups.empty()) {  // identity: one group per row, the group id is the row id
+        gids.resize(n);
+        if (n) HIP_TRY(hipMemcpy(gids.data(), ix->d_ids, n * 8, hipMemcpyDeviceToHost));
+        off.resize(n + 1);
+        for (uint64_t i = 0; i <= n; i++) off[i] = (uint32_t)i;
+        for (uint64_t i = 0; i < n; i++) rows[i] = (uint32_t)i;
+    } else {
+        std::vector<uint32_t> order(n);
+        for (uint64_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        const int64_t *g = ix->h_groups.data();
+        std::stable_sort(order.begin(), order.end(), [g](uint32_t a, uint32_t b) { return g[a] < g[b]; });  // rows stay ascending inside a group
+        for (uint64_t i = 0; i < n; i++) {
+            if (i == 0 || g[order[i]] != g[order[i - 1]]) {
+                gids.push_back(g[order[i]]);
+                off.push_back((uint32_t)i);
+            }
+            rows[i] = order[i];
+        }
+        off.push_back((uint32_t)n);
+    }
+    ix->n_groups = (uint32_t)gids.size();
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_off, (off.size() + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_rows, (n + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&ix->d_grp_ids, (gids.size() + 1) * 8));
+    HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
+    if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
+    ix->groups_built_n = n;
+    return PVS_OK;
+}
+
+// d_out[row * nb + q], nb <= PVS_MAX_BATCH queries already prepared in ctx c (prep_chunk)
+static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
+    const uint32_t kslabs = ix->stride / PVS_KSLAB_BYTES;
+    if (ix->dtype == PVS_I8 && pvs_scan_supported(PVS_I8, kslabs) && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
+        // matrix-core path: exact integer dots, closed-form finish (valid below 2^24)
+        ScanArgs a;
+        a.dtype = PVS_I8;
+        a.metric = metric;
+        a.kslabs = kslabs;
+        a.qgroups = batch_pad / 32;
+        a.rows = ix->d_rows;
+        a.aux = ix->d_norm2;
+        a.stride = ix->stride;
+        a.n_rows = ix->n;
+        a.qmat = c.d_qmat;
+        a.qinfo = c.d_qinfo;
+        a.thr = c.d_thr;
+        a.gmin = c.d_gmin;
+        a.groups_per_query = 0;
+        a.cand_cnt = c.d_cand_cnt;
+        a.cand = c.d_cand;
+        a.cand_cap = PVS_CAND_CAP;
+        a.mode = 2;
+        a.tile_step = 1;
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+        const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        a.dense_out = d_out;
+        a.dense_ld = nb;
+        a.batch = nb;
+        a.dense_flag = c.d_cand_cnt;  // reused as the out-of-range flag word
+        HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (!flag) return PVS_OK;  // else: some L2 sum left the exact range -> score in order below
+    }
+    HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c.d_qexact, c.d_qinfo, nb,
+                                   c.d_qpad, d_out, nb, 0, (uint32_t)ix->n_cu, c.stream));
+    return PVS_OK;
+}
+
+// queries per dense chunk so that the [n][nb] f32 matrix stays <= 2 GiB
+static uint32_t dense_chunk_queries(const pvs_index *ix, uint32_t batch) {
+    const uint64_t cap = (1ull << 31) / (4 * std::max<uint64_t>(ix->n, 1));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({cap, (uint64_t)PVS_MAX_BATCH, (uint64_t)batch}));
+}
+
+PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric,
+                                      float *out_dist, pvs_space out_space) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0 || ix->n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, 1, false));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        const uint32_t cq = dense_chunk_queries(ix, batch);
+        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * cq * 4));
+        for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
+            const uint32_t nb = std::min(cq, batch - q0);
+            const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+            PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+            PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
+            // scatter the chunk's columns into out[row * batch + q0 + j]
+            const hipMemcpyKind kind = out_space == PVS_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+            HIP_TRY(hipMemcpy2DAsync(out_dist + q0, (size_t)batch * 4, d_m, (size_t)nb * 4, (size_t)nb * 4, ix->n, kind, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    ctx_done(ix, c);
+    return st;
+}
+
+// shared tail: d_m [n][nb] (fanout == 0: nb output columns; else one) -> ranked groups on the host
+static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg,
+                                     const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
+                                     double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights()) {
+    const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
+    double *d_vals = nullptr;
+    int64_t *d_og = nullptr;
+    double *d_ov = nullptr;
+    uint32_t *d_oc = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
+        HIP_TRY(hipMalloc((void **)&d_og, (size_t)k * 8));
+        HIP_TRY(hipMalloc((void **)&d_ov, (size_t)k * 8));
+        HIP_TRY(hipMalloc((void **)&d_oc, 4));
+        HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
+                                           c.stream, fw));
+        for (uint32_t q = 0; q < ncol; q++) {
+            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, ix->gwork, d_og, d_ov, d_oc, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_values + (size_t)q * k, d_ov, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(out_count + q, d_oc, 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_vals);
+    hipFree(d_og);
+    hipFree(d_ov);
+    hipFree(d_oc);
+    return st;
+}
+
+// MIN aggregation (the reference's default, filters/embedding_types.rs:14-18) without scoring every row
+// into a dense matrix: a group's MIN is the distance of its best row, so the top-k groups are the
+// groups of the first rows of the row ranking.  Take a row page of kp rows through the filter scan,
+// keep each group's first occurrence, and accept iff the page provably contains the answer: it is the
+// whole corpus, or the k-th group's value is strictly below the last row's distance (rows tied with
+// the boundary could otherwise hide an unseen group).  Else grow kp; past PVS_MAX_K the caller runs
+// the dense path.  Values are the same f64(f32 distance) the dense path produces.
+static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                  int64_t *out_groups, double *out_values, uint32_t *out_count, bool *done) {
+    *done = false;
+    if (ix->n == 0 || ix->n_groups == 0 || ix->forced_path == 1) return PVS_OK;
+    const uint64_t n = ix->n;
+    const double per_group = (double)n / (double)ix->n_groups;
+    uint64_t kp = std::max<uint64_t>(64, (uint64_t)(2.0 * k * std::min(std::ceil(per_group), 8.0)));
+    kp = std::min<uint64_t>({kp, (uint64_t)PVS_MAX_K, n});
+    if (kp < std::min<uint64_t>(k, n) || !fast_path_ok(ix, (uint32_t)kp)) return PVS_OK;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_ids_cache.size() != n) {
+            ix->h_ids_cache.resize(n);
+            HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, n * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    std::vector<int64_t> ids;
+    std::vector<float> dist;
+    std::vector<uint32_t> cnt(batch);
+    struct GV {
+        double v;
+        int64_t g;
+    };
+    std::vector<GV> gv;
+    std::vector<int64_t> seen;
+    for (;;) {
+        ids.assign((size_t)batch * kp, -1);
+        dist.assign((size_t)batch * kp, 0.f);
+        PVS_TRY(pvs_search(ix, queries, qdtype, batch, (uint32_t)kp, metric, ids.data(), dist.data(), cnt.data()));
+        bool all_ok = true;
+        for (uint32_t q = 0; q < batch && all_ok; q++) {
+            const int64_t *qi = ids.data() + (size_t)q * kp;
+            const float *qd = dist.data() + (size_t)q * kp;
+            gv.clear();
+            seen.clear();
+            for (uint32_t i = 0; i < cnt[q]; i++) {
+                int64_t g = qi[i];  // identity groups: the group id is the row id
+                if (!ix->h_groups.empty()) {
+                    const auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), qi[i]);
+                    g = ix->h_groups[(size_t)(it - ix->h_ids_cache.begin())];
+                }
+                seen.push_back(g);
+            }
+            // first occurrence of each group, in page order
+            std::vector<uint32_t> order(seen.size());
+            for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seen[a] < seen[b]; });
+            for (size_t i = 0; i < order.size(); i++)
+                if (i == 0 || seen[order[i]] != seen[order[i - 1]]) gv.push_back({(double)qd[order[i]], seen[order[i]]});
+            std::sort(gv.begin(), gv.end(), [](const GV &a, const GV &b) {
+                const bool na = a.v != a.v, nb = b.v != b.v;  // NULL last, then value, then group id
+                if (na != nb) return nb;
+                if (!na && a.v != b.v) return a.v < b.v;
+                return a.g < b.g;
+            });
+            const bool complete = cnt[q] == n;  // the page is the whole corpus
+            const uint32_t want = (uint32_t)std::min<uint64_t>(k, complete ? gv.size() : (uint64_t)k);
+            bool ok = complete;
+            if (!ok && gv.size() >= k && cnt[q] > 0) {
+                const double last = (double)qd[cnt[q] - 1];
+                ok = gv[k - 1].v < last;  // false for NaN on either side
+            }
+            if (!ok) {
+                all_ok = false;
+                break;
+            }
+            for (uint32_t i = 0; i < k; i++) {
+                out_groups[(size_t)q * k + i] = i < want ? gv[i].g : -1;
+                out_values[(size_t)q * k + i] = i < want ? gv[i].v : __builtin_nan("");
+            }
+            out_count[q] = want;
+        }
+        if (all_ok) {
+            *done = true;
+            return PVS_OK;
+        }
+        if (kp >= std::min<uint64_t>(PVS_MAX_K, n)) return PVS_OK;  // give up: dense path
+        kp = std::min<uint64_t>({kp * 4, (uint64_t)PVS_MAX_K, n});
+    }
+}
+
+PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                        pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
+                                        double *out_values, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (!row_weights && agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG)
+        return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+    }
+    if (agg == PVS_AGG_MIN && !row_weights) {
+        bool done = false;
+        PVS_TRY(groups_min_fast(ix, queries, qdtype, batch, k, metric, out_groups, out_values, out_count, &done));
+        if (done) return PVS_OK;
+    }
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr, *d_w = nullptr;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        if (row_weights && ix->n) {
+            HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+            HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        const uint32_t cq = dense_chunk_queries(ix, batch);
+        HIP_TRY(hipMalloc((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
+        for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
+            const uint32_t nb = std::min(cq, batch - q0);
+            const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+            if (ix->n) {
+                PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+                PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
+            }
+            PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, nullptr, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
+                                       out_count + q0));
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    hipFree(d_w);
+    ix->searches++;
+    ix->dense_queries += batch;
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, const void *queries, pvs_dtype qdtype, uint32_t batch,
+                                                uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
+                                                double *out_values, uint32_t *out_count) {
+    if (!comm) return pvs_fail(PVS_ERR_INVALID_ARG, "null communicator");
+    if (ix && pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
+    // 1. this shard's page (every rank must take part in the exchange below, whatever its shard holds)
+    std::vector<int64_t> lg((size_t)batch * k, -1);
+    std::vector<double> lv((size_t)batch * k, __builtin_nan(""));
+    std::vector<uint32_t> lc(batch, 0);
+    PVS_TRY(pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, lg.data(), lv.data(), lc.data()));
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint32_t world = (uint32_t)pvs_comm_world_(comm);
+    const uint64_t elems = (uint64_t)batch * k;
+    int64_t *d_g = nullptr, *d_ag = nullptr;
+    double *d_v = nullptr, *d_av = nullptr;
+    uint32_t *d_c = nullptr, *d_ac = nullptr;
+    std::vector<int64_t> ag((size_t)world * elems);
+    std::vector<double> av((size_t)world * elems);
+    std::vector<uint32_t> ac((size_t)world * batch);
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_g, elems * 8));
+        HIP_TRY(hipMalloc((void **)&d_v, elems * 8));
+        HIP_TRY(hipMalloc((void **)&d_c, (size_t)batch * 4));
+        HIP_TRY(hipMalloc((void **)&d_ag, elems * 8 * world));
+        HIP_TRY(hipMalloc((void **)&d_av, elems * 8 * world));
+        HIP_TRY(hipMalloc((void **)&d_ac, (size_t)batch * 4 * world));
+        hipStream_t s = ix->comm_stream;  // every collective of this index goes out on this one stream
+        HIP_TRY(hipMemcpyAsync(d_g, lg.data(), elems * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_v, lv.data(), elems * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_c, lc.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
+        // 2. one grouped all-gather over xGMI
+        PVS_TRY(pvs_comm_gather_group_pages_(comm, d_g, d_v, d_c, d_ag, d_av, d_ac, elems, batch, s));
+        HIP_TRY(hipMemcpyAsync(ag.data(), d_ag, ag.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(av.data(), d_av, av.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ac.data(), d_ac, ac.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // 3. merge on every rank (tiny: world * k entries per query)
+        return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
+    };
+    pvs_status st = body();
+    hipFree(d_g);
+    hipFree(d_v);
+    hipFree(d_c);
+    hipFree(d_ag);
+    hipFree(d_av);
+    hipFree(d_ac);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
+                                     uint32_t *out_count) {
+    if (!br || !out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (nb < 1 || nb > (uint32_t)PVS_RRF_MAX_BRANCHES) return pvs_fail(PVS_ERR_INVALID_ARG, "1..%d branches", PVS_RRF_MAX_BRANCHES);
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    PvsRrfParams p;
+    memset(&p, 0, sizeof p);
+    p.n_branches = nb;
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        pvs_index *ix = br[b].idx;
+        PVS_TRY(validate_search(ix, br[b].query, br[b].query_dtype, 1, 1, br[b].metric));
+        if (ix->device != br[0].idx->device) return pvs_fail(PVS_ERR_INVALID_ARG, "all branches must live on one device");
+        if (!br[b].row_weights && br[b].agg != PVS_AGG_MIN && br[b].agg != PVS_AGG_MAX && br[b].agg != PVS_AGG_AVG)
+            return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+        p.k[b] = br[b].rrf_k;
+        p.w[b] = br[b].weight;
+        HIP_TRY(hipSetDevice(ix->device));
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+        total += ix->n_groups;
+    }
+    unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
+    void *d_q = nullptr;
+    float *d_m = nullptr, *d_w = nullptr;
+    double *d_vals = nullptr;
+    auto free_branch = [&]() {
+        hipFree(d_q);
+        hipFree(d_m);
+        hipFree(d_w);
+        hipFree(d_vals);
+        d_q = nullptr;
+        d_m = d_w = nullptr;
+        d_vals = nullptr;
+    };
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&cat_key, std::max<uint64_t>(total, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&cat_pay, std::max<uint64_t>(total, 1) * 8));
+        uint64_t off = 0;
+        for (uint32_t b = 0; b < nb; b++) {
+            pvs_index *ix = br[b].idx;
+            if (ix->n == 0) continue;
+            if (ix->n > (1ull << 31) / 4) return pvs_fail(PVS_ERR_UNSUPPORTED, "branch %u: more than 2^29 rows in one dense column", b);
+            uint32_t t;
+            SearchCtx *c = ctx_acquire(ix, &t);
+            auto one = [&]() -> pvs_status {
+                PVS_TRY(ctx_prepare(ix, *c, 1, 1, false));
+                const size_t qbytes = (size_t)ix->dim * (br[b].query_dtype == PVS_I8 ? 1 : 4);
+                HIP_TRY(hipMalloc(&d_q, qbytes));
+                HIP_TRY(hipMemcpyAsync(d_q, br[b].query, qbytes, hipMemcpyHostToDevice, c->stream));
+                if (br[b].row_weights) {
+                    HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+                    HIP_TRY(hipMemcpyAsync(d_w, br[b].row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+                }
+                HIP_TRY(hipMalloc((void **)&d_m, ix->n * 4));
+                HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+                // every row's exact distance (the dist_{cte} column), aggregated per group in row order ...
+                PVS_TRY(prep_chunk(ix, *c, d_q, br[b].query_dtype, 0, 1, 32, br[b].metric));
+                PVS_TRY(dense_chunk(ix, *c, 1, 32, br[b].metric, d_m));
+                HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, br[b].agg, d_vals,
+                                                   c->stream));
+                // ... ranked over ALL groups of the branch, entries appended in branch order
+                PVS_TRY(pvs_rrf_rank_branch(d_vals, ix->d_grp_ids, ix->n_groups, br[b].row_n_descending != 0, b, cat_key + off, cat_pay + off,
+                                            c->stream));
+                return PVS_OK;
+            };
+            pvs_status st = one();
+            free_branch();
+            ix->searches++;
+            ix->dense_queries++;
+            ctx_done(ix, c);
+            if (st != PVS_OK) return st;
+            off += ix->n_groups;
+        }
+        return pvs_rrf_fuse_device(cat_key, cat_pay, off, p, k, out_groups, out_scores, out_count, br[0].idx->search_stream);
+    };
+    pvs_status st = body();
+    hipFree(cat_key);
+    hipFree(cat_pay);
+    return st;
+}
+
+static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
+                                  const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,
+                                  uint32_t *out_count) {
+    if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
+    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
+    if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    HIP_TRY(hipSetDevice(ix->device));
+    std::vector<uint32_t> trow(n_targets);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+        if (ix->h_ids_cache.size() != ix->n) {
+            ix->h_ids_cache.resize(ix->n);
+            if (ix->n) HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
+        }
+        for (uint32_t i = 0; i < n_targets; i++) {  // ids are strictly increasing: binary search
+            auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), target_row_ids[i]);
+            if (it == ix->h_ids_cache.end() || *it != target_row_ids[i])
+                return pvs_fail(PVS_ERR_INVALID_ARG, "target row id %lld is not in the index", (long long)target_row_ids[i]);
+            trow[i] = (uint32_t)(it - ix->h_ids_cache.begin());
+        }
+    }
+    if (ix->n > (1ull << 31) / (4ull * n_targets)) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to fan-out matrix would exceed 2 GiB");
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr;
+    uint8_t *d_ex = nullptr;
+    double *d_conf = nullptr, *d_lang = nullptr;
+    uint32_t *d_trows = nullptr;
+    uint8_t *d_kind = nullptr;
+    const bool weighted = cw != 0.0 || lw != 0.0;
+    const bool gated = row_kind && (skip_i2i || skip_t2t);
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
+        FanoutWeights fw;
+        if (weighted || gated) {
+            HIP_TRY(hipMalloc((void **)&d_trows, (size_t)n_targets * 4));
+            HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
+            fw.trows = d_trows;
+        }
+        if (gated) {
+            HIP_TRY(hipMalloc((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
+            HIP_TRY(hipMemcpy(d_kind, row_kind, ix->n, hipMemcpyHostToDevice));
+            fw.kind = d_kind;
+            fw.skip_i2i = skip_i2i;
+            fw.skip_t2t = skip_t2t;
+        }
+        if (weighted) {
+            // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
+            auto upload = [&](const double *src, double **dst) -> pvs_status {
+                HIP_TRY(hipMalloc((void **)dst, std::max<uint64_t>(ix->n, 1) * 8));
+                if (src)
+                    HIP_TRY(hipMemcpy(*dst, src, ix->n * 8, hipMemcpyHostToDevice));
+                else
+                    HIP_TRY(hipMemset(*dst, 0xff, ix->n * 8));  // all-ones bits = NaN
+                return PVS_OK;
+            };
+            PVS_TRY(upload(row_conf, &d_conf));
+            PVS_TRY(upload(row_lang, &d_lang));
+            fw.conf = d_conf;
+            fw.lang = d_lang;
+            fw.cw = cw;
+            fw.lw = lw;
+        }
+        // the target's stored vectors become the query batch: int8 codes as they are, f16/f32 as f32
+        const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
+        std::vector<uint8_t> hq((size_t)n_targets * ix->dim * qesz);
+        std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
+        for (uint32_t i = 0; i < n_targets; i++) {
+            HIP_TRY(pvs_launch_rows_gather(ix->d_rows, ix->stride, (uint32_t)rowbuf.size(), trow[i], 1, c->d_qin, c->stream));
+            HIP_TRY(hipMemcpyAsync(rowbuf.data(), c->d_qin, rowbuf.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            uint8_t *dst = hq.data() + (size_t)i * ix->dim * qesz;
+            if (ix->dtype == PVS_F16) {
+                for (uint32_t e = 0; e < ix->dim; e++) {
+                    _Float16 hv;
+                    memcpy(&hv, rowbuf.data() + 2 * e, 2);
+                    const float f = (float)hv;
+                    memcpy(dst + 4 * e, &f, 4);
+                }
+            } else {
+                memcpy(dst, rowbuf.data(), rowbuf.size());
+            }
+        }
+        HIP_TRY(hipMalloc(&d_q, hq.size()));
+        HIP_TRY(hipMemcpy(d_q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&d_ex, ix->n + 1));
+        HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
+        for (uint32_t i = 0; i < n_targets; i++) HIP_TRY(hipMemsetAsync(d_ex + trow[i], 1, 1, c->stream));
+        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * n_targets * 4));
+        const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
+        PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
+        PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));
+        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_q);
+    hipFree(d_m);
+    hipFree(d_ex);
+    hipFree(d_conf);
+    hipFree(d_lang);
+    hipFree(d_trows);
+    hipFree(d_kind);
+    ix->searches++;
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                     pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, nullptr, nullptr, 0.0, 0.0, nullptr, false, false, out_groups,
+                           out_values, out_count);
+}
+
+PVS_EXPORT pvs_status pvs_similar_to_ex(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                        const pvs_similar_opts *o, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (!o || o->struct_size < sizeof(pvs_similar_opts)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_similar_opts.struct_size too small");
+    if (o->confidence_weight != o->confidence_weight || o->language_confidence_weight != o->language_confidence_weight)
+        return pvs_fail(PVS_ERR_INVALID_ARG, "confidence weights must be numbers");
+    return similar_to_impl(ix, target_row_ids, n_targets, k, metric, o->agg, o->row_confidence, o->row_language_confidence,
+                           o->confidence_weight, o->language_confidence_weight, o->row_kind, o->xmodal_i2i == 0, o->xmodal_t2t == 0,
+                           out_groups, out_values, out_count);
+}
+

@@ -1,0 +1,503 @@
+// pvs_search.hip — C ABI of libpvs, part 2: search orchestration over HIP streams (filter scan passes A/B/C,
+// dense fallbacks, candidate masks), the stream-ordered and sharded entry points, the dense `d` column.
+#include "pvs_index.hpp"
+
+// ------------------------------------------------------------------- search
+pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                  pvs_metric metric) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (batch && !queries) return pvs_fail(PVS_ERR_INVALID_ARG, "null queries");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");  // preprocess.rs:441-444
+    if (k > (1u << 20)) return pvs_fail(PVS_ERR_INVALID_ARG, "k too large");
+    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
+    if (qdtype == PVS_I8) {
+        if (ix->dtype != PVS_I8) return pvs_fail(PVS_ERR_DIM_MISMATCH, "int8 query against a float index (element type mismatch)");
+    } else if (qdtype == PVS_F32) {
+        if (ix->dtype == PVS_I8 && !ix->scale_set)
+            return pvs_fail(PVS_ERR_STATE, "f32 query on an int8 index needs the scale artifact");
+    } else {
+        return pvs_fail(PVS_ERR_INVALID_ARG, "queries must be f32 or int8");
+    }
+    return PVS_OK;
+}
+
+bool fast_path_ok(const pvs_index *ix, uint32_t k) {
+    if (ix->forced_path == 1) return false;
+    if (!pvs_scan_supported((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES)) return false;
+    if (k > PVS_MAX_K) return false;
+    return ix->n > 0;
+}
+
+// one query through the dense path; q is the query's index inside the current chunk
+static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k, int metric, int64_t *out_ids, float *out_dist,
+                            uint32_t *out_count) {
+    PVS_TRY(pvs_dense_reserve(c.dense, ix->n));
+    const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
+    HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, 1,
+                                   c.d_qpad, c.dense.d_dist, 1, 0, (uint32_t)ix->n_cu, c.stream));
+    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask));
+    ix->dense_queries++;
+    return PVS_OK;
+}
+
+pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb,
+                             uint32_t batch_pad, int metric) {
+    const size_t qesz = qdtype == PVS_I8 ? 1 : 4;
+    const uint8_t *qsrc = (const uint8_t *)d_queries + (size_t)qoff * ix->dim * qesz;
+    HIP_TRY(pvs_launch_prep_queries((int)ix->dtype, qdtype, qsrc, nb, batch_pad, ix->dim, ix->stride, ix->scale, metric, c.d_qmat,
+                                    c.d_qexact, c.d_qinfo, c.d_cand_cnt, c.d_need_dense + qoff, c.stream));
+    return PVS_OK;
+}
+
+// Enqueues the whole search on c.stream.  Outputs are device buffers.
+static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+                                 int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast) {
+    const bool fast = fast_path_ok(ix, k);
+    *used_fast = fast;
+    if (!fast && ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "filter-scan path not available for this index / k");
+    if (ix->n == 0) {
+        HIP_TRY(hipMemsetAsync(c.d_need_dense, 0, 4 * (size_t)batch, c.stream));
+        HIP_TRY(hipMemsetAsync(d_out_count, 0, 4 * (size_t)batch, c.stream));
+        HIP_TRY(hipMemsetAsync(d_out_ids, 0xff, 8 * (size_t)batch * k, c.stream));
+        HIP_TRY(pvs_launch_fill_f32(d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c.stream));
+        HIP_TRY(hipEventRecord(c.done, c.stream));
+        return PVS_OK;
+    }
+    const uint32_t pass_max = fast ? pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES) : PVS_MAX_BATCH;
+    for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
+        const uint32_t nb = std::min(pass_max, batch - qoff);
+        const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : nb <= 128 ? 128 : 256;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));
+        int64_t *oid = d_out_ids + (size_t)qoff * k;
+        float *od = d_out_dist + (size_t)qoff * k;
+        uint32_t *oc = d_out_count + qoff;
+        if (!fast) {
+            for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
+            continue;
+        }
+        ScanArgs a;
+        a.dtype = (int)ix->dtype;
+        a.metric = metric;
+        a.kslabs = ix->stride / PVS_KSLAB_BYTES;
+        a.qgroups = batch_pad / 32;
+        a.rows = ix->d_rows;
+        a.aux = metric == PVS_COSINE ? ix->d_rnorm : ix->d_norm2;
+        if (c.cur_mask) {  // filtered search: rows outside the mask stream a NaN scalar and never pass
+            HIP_TRY(pvs_launch_mask_aux(a.aux, c.cur_mask, ix->n, ix->cap, c.d_aux_masked, c.stream));
+            a.aux = c.d_aux_masked;
+        }
+        a.stride = ix->stride;
+        a.n_rows = ix->n;
+        a.qmat = c.d_qmat;
+        a.qinfo = c.d_qinfo;
+        a.thr = c.d_thr;
+        a.cand_cnt = c.d_cand_cnt;
+        a.cand = c.d_cand;
+        a.cand_cap = PVS_CAND_CAP;
+        a.gmin = c.d_gmin;
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+        // pass A: strided sample of row tiles -> group minima -> threshold
+        // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
+        // candidates, and each emit costs a few hundred cycles, while pass A costs ~ n_sample/N of a
+        // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
+        // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
+        // holds ~k/frac rows: keep that 2.5x below its capacity.
+        double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
+        static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
+        if (frac_env > 0.0) frac = frac_env;
+        frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
+        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
+        const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
+        a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
+        const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
+        const uint32_t per_cu_a = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
+        const uint32_t rt = a.qgroups >= 4 ? 1 : 4 / a.qgroups;  // row sub-tiles per workgroup
+        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (rt * 32)});
+        a.mode = 0;
+        // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
+        // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
+        a.gmin_per_lane = 16;
+        while (a.gmin_per_lane > 1 && (uint64_t)a.grid * rt * 2 * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
+        a.groups_per_query = a.grid * rt * 2 * a.gmin_per_lane;
+        span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
+        HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
+        // pass B: every row once (candidate counters were zeroed by the prep kernel)
+        a.mode = 1;
+        a.tile_step = 1;
+        const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
+        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        span_begin(ix, c, 1, ix->n);
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
+        // pass C
+        FinalizeArgs f;
+        f.dtype = (int)ix->dtype;
+        f.metric = metric;
+        f.rows = ix->d_rows;
+        f.norm2 = ix->d_norm2;
+        f.ids = ix->d_ids;
+        f.stride = ix->stride;
+        f.dim = ix->dim;
+        f.n_rows = ix->n;
+        f.qexact = c.d_qexact;
+        f.qinfo = c.d_qinfo;
+        f.cand_cnt = c.d_cand_cnt;
+        f.cand = c.d_cand;
+        f.cand_cap = PVS_CAND_CAP;
+        f.batch = nb;
+        f.k = k;
+        f.out_ids = oid;
+        f.out_dist = od;
+        f.out_count = oc;
+        f.need_dense = c.d_need_dense + qoff;
+        span_begin(ix, c, 2, 0);
+        HIP_TRY(pvs_launch_finalize(f, c.stream));
+        span_end(ix, c);
+    }
+    if (fast) HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipEventRecord(c.done, c.stream));
+    return PVS_OK;
+}
+
+// After the stream drained: answer the queries the filter path handed back.
+static pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+                                   int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    uint32_t n_dense = 0;
+    for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
+    ix->fast_queries += batch - n_dense;
+    if (!n_dense) return PVS_OK;
+    if (ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "%u queries need the dense path but path=2 forbids it", n_dense);
+    for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
+        const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
+        bool any = false;
+        for (uint32_t q = 0; q < nb; q++) any |= c.h_need_dense[qoff + q] != 0;
+        if (!any) continue;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, 32 * ((nb + 31) / 32), metric));
+        for (uint32_t q = 0; q < nb; q++) {
+            if (!c.h_need_dense[qoff + q]) continue;
+            PVS_TRY(dense_one(ix, c, q, k, metric, d_out_ids + (size_t)(qoff + q) * k, d_out_dist + (size_t)(qoff + q) * k,
+                              d_out_count + qoff + q));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    return PVS_OK;
+}
+
+SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket) {
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            for (uint32_t i = 0; i < NCTX; i++)
+                if (!ix->ctx[i].busy) {
+                    ix->ctx[i].busy = true;
+                    *ticket = i;
+                    return &ix->ctx[i];
+                }
+        }
+        sched_yield();
+    }
+}
+void ctx_done(pvs_index *ix, SearchCtx *c) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    c->pending = false;
+    c->busy = false;
+}
+
+static pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                 pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
+}
+
+PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                          pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
+                                          float *out_dist, uint32_t *out_count) {
+    if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
+    return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
+}
+
+static pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, batch, k, true);
+    const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+    void *d_q = nullptr;
+    if (st == PVS_OK) {
+        // (hipMalloc/hipFree per call would cost ~0.1 ms and hipFree synchronises the whole device,
+        // stalling the other host threads' searches)
+        if (qbytes * batch > c->qstage_cap) {
+            hipFree(c->d_qstage);
+            c->d_qstage = nullptr;
+            c->qstage_cap = 0;
+            const size_t cap = pvs_round_up(qbytes * batch, 1 << 16);
+            hipError_t e = hipMalloc(&c->d_qstage, cap);
+            if (e != hipSuccess)
+                st = pvs_fail(PVS_ERR_OOM, "hipMalloc queries: %s", hipGetErrorString(e));
+            else
+                c->qstage_cap = cap;
+        }
+        d_q = c->d_qstage;
+    }
+    bool fast = false;
+    if (st == PVS_OK) {
+        hipError_t e = hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "H2D queries: %s", hipGetErrorString(e));
+    }
+    if (st == PVS_OK && mask && ix->n) {
+        auto setup = [&]() -> pvs_status {
+            if (ix->cap > c->mask_cap) {
+                hipFree(c->d_mask);
+                hipFree(c->d_aux_masked);
+                c->d_mask = nullptr;
+                c->d_aux_masked = nullptr;
+                c->mask_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_mask, ix->cap));
+                HIP_TRY(hipMalloc((void **)&c->d_aux_masked, ix->cap * 4));
+                c->mask_cap = ix->cap;
+            }
+            if (mask_space == PVS_HOST) {
+                HIP_TRY(hipMemcpyAsync(c->d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
+                c->cur_mask = c->d_mask;
+            } else {
+                c->cur_mask = mask;
+            }
+            return PVS_OK;
+        };
+        st = setup();
+    }
+    if (st == PVS_OK) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
+    if (st == PVS_OK) {
+        hipError_t e = hipEventSynchronize(c->done);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    }
+    if (st == PVS_OK) spans_collect(ix, *c);
+    if (st == PVS_OK && fast && ix->n)
+        st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count);
+    if (st == PVS_OK) {
+        hipError_t e = hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
+    }
+    ix->searches++;
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                        pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
+                                        uint32_t *out_ticket) {
+    PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
+    if (!d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, batch, k, false);
+    bool fast = false;
+    if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast);
+    if (st != PVS_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        ctx_done(ix, c);
+        return st;
+    }
+    c->pending = true;
+    c->p_queries = d_queries;
+    c->p_qdtype = qdtype;
+    c->p_metric = metric;
+    c->p_batch = batch;
+    c->p_k = k;
+    c->p_out_ids = d_out_ids;
+    c->p_out_dist = d_out_dist;
+    c->p_out_count = d_out_count;
+    c->p_fast = fast;
+    ix->searches++;
+    *out_ticket = t;
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
+    if (!ix || ticket >= NCTX) return pvs_fail(PVS_ERR_INVALID_ARG, "bad ticket");
+    SearchCtx *c = &ix->ctx[ticket];
+    if (!c->busy || !c->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+    HIP_TRY(hipSetDevice(ix->device));
+    pvs_status st = PVS_OK;
+    hipError_t e = hipEventSynchronize(c->done);
+    if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    if (st == PVS_OK) spans_collect(ix, *c);
+    if (st == PVS_OK && c->p_comm) {
+        // every rank sees the same gathered flags, so they all agree on whether to redo
+        bool redo = false;
+        for (uint64_t i = 0; i < (uint64_t)c->sh_world * c->p_batch; i++) redo |= c->h_all_flags[i] != 0;
+        if (!redo) {
+            ix->fast_queries += c->p_fast ? c->p_batch : 0;
+        } else {
+            if (c->p_fast && ix->n)
+                st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->d_loc_ids, c->d_loc_dist,
+                                      c->d_loc_cnt);
+            // (search_fallbacks drained c->stream; the redo's collective goes where all the others go)
+            hipStream_t cs = ix->multi_stream ? ix->comm_stream : c->stream;
+            if (st == PVS_OK) {
+                hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, cs);
+                if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
+            }
+            if (st == PVS_OK)
+                st = pvs_comm_gather_pages_(c->p_comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids,
+                                            c->d_all_dist, c->d_all_cnt, c->d_all_flags, (uint64_t)c->p_batch * c->p_k, c->p_batch, cs);
+            if (st == PVS_OK) {
+                hipError_t e2 = pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, c->sh_world, c->p_batch, c->p_k,
+                                                 c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(cs);
+                if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "sharded redo: %s", hipGetErrorString(e2));
+            }
+        }
+        c->p_comm = nullptr;
+    } else if (st == PVS_OK && c->p_fast && ix->n) {
+        st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->p_out_ids, c->p_out_dist,
+                              c->p_out_count);
+    }
+    ctx_done(ix, c);
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, const void *d_queries, pvs_dtype qdtype, uint32_t batch,
+                                               uint32_t k, pvs_metric metric, int64_t *d_out_ids, float *d_out_dist,
+                                               uint32_t *d_out_count, uint32_t *out_ticket) {
+    PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
+    if (!comm || !d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    if (pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint32_t world = (uint32_t)pvs_comm_world_(comm);
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
+        const uint64_t elems = (uint64_t)batch * k;
+        if (elems > c->sh_elems || batch > c->sh_batch || world != c->sh_world) {
+            hipFree(c->d_loc_ids);
+            hipFree(c->d_all_ids);
+            hipFree(c->d_loc_dist);
+            hipFree(c->d_all_dist);
+            hipFree(c->d_loc_cnt);
+            hipFree(c->d_all_cnt);
+            hipFree(c->d_all_flags);
+            if (c->h_all_flags) hipHostFree(c->h_all_flags);
+            c->d_loc_ids = c->d_all_ids = nullptr;
+            c->d_loc_dist = c->d_all_dist = nullptr;
+            c->d_loc_cnt = c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
+            c->sh_elems = 0;
+            HIP_TRY(hipMalloc((void **)&c->d_loc_ids, elems * 8));
+            HIP_TRY(hipMalloc((void **)&c->d_loc_dist, elems * 4));
+            HIP_TRY(hipMalloc((void **)&c->d_loc_cnt, (size_t)batch * 4));
+            HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
+            HIP_TRY(hipMalloc((void **)&c->d_all_flags, (size_t)batch * 4 * world));
+            HIP_TRY(hipHostMalloc((void **)&c->h_all_flags, (size_t)batch * 4 * world, hipHostMallocDefault));
+            c->sh_elems = elems;
+            c->sh_batch = batch;
+            c->sh_world = world;
+        }
+        bool fast = false;
+        // 1. this shard's page (row ids in the index are global ids)
+        PVS_TRY(search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &fast));
+        // 2. one grouped all-gather over xGMI, 3. merge on every rank — stream-ordered, no host sync.
+        // With one stream per context (pvs_index_set_streams) the local scans of several searches
+        // overlap, but their collectives still go out on ONE stream in program order: a communicator
+        // is never driven from two streams at once.
+        hipStream_t cs = c->stream;
+        if (ix->multi_stream) {
+            cs = ix->comm_stream;
+            HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
+        }
+        PVS_TRY(pvs_comm_gather_pages_(comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids, c->d_all_dist,
+                                       c->d_all_cnt, c->d_all_flags, elems, batch, cs));
+        HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
+        HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipEventRecord(c->done, cs));
+        c->pending = true;
+        c->p_comm = comm;
+        c->p_queries = d_queries;
+        c->p_qdtype = qdtype;
+        c->p_metric = metric;
+        c->p_batch = batch;
+        c->p_k = k;
+        c->p_out_ids = c->d_loc_ids;
+        c->p_out_dist = c->d_loc_dist;
+        c->p_out_count = c->d_loc_cnt;
+        c->p_final_ids = d_out_ids;
+        c->p_final_dist = d_out_dist;
+        c->p_final_count = d_out_count;
+        c->p_fast = fast;
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        ctx_done(ix, c);
+        return st;
+    }
+    ix->searches++;
+    *out_ticket = t;
+    return PVS_OK;
+}
+
+PVS_EXPORT pvs_status pvs_search_sharded(pvs_index *ix, pvs_comm *comm, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                         pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    uint32_t t = 0;
+    PVS_TRY(pvs_search_sharded_async(ix, comm, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &t));
+    return pvs_wait(ix, t);
+}
+
+PVS_EXPORT pvs_status pvs_sync(pvs_index *ix) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    pvs_status st = PVS_OK;
+    for (uint32_t i = 0; i < NCTX; i++)
+        if (ix->ctx[i].busy && ix->ctx[i].pending) {
+            pvs_status s = pvs_wait(ix, i);
+            if (s != PVS_OK) st = s;
+        }
+    return st;
+}
+
+PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist,
+                                    pvs_space out_space) {
+    PVS_TRY(validate_search(ix, query, qdtype, 1, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (ix->n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    pvs_status st = ctx_prepare(ix, *c, 1, 1, false);
+    auto body = [&]() -> pvs_status {
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMemcpyAsync(c->d_qin, query, qbytes, hipMemcpyHostToDevice, c->stream));
+        PVS_TRY(prep_chunk(ix, *c, c->d_qin, qdtype, 0, 1, 32, metric));
+        float *dst = out_dist;
+        if (out_space == PVS_HOST) {
+            PVS_TRY(pvs_dense_reserve(c->dense, ix->n));
+            dst = c->dense.d_dist;
+        }
+        HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
+                                       c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
+        if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PVS_OK;
+    };
+    if (st == PVS_OK) st = body();
+    ctx_done(ix, c);
+    return st;
+}
+
