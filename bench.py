@@ -123,6 +123,19 @@ class Dist:
             self.td.destroy_process_group()
 
 
+def which_config(n, d, dtype, b, k):
+    """BASELINE.json `configs` entry a workload corresponds to (the default run is configs[2])."""
+    if (n, d, dtype, b, k) == (10_000_000, 768, "i8", 128, 100):
+        return "BASELINE configs[2]"
+    if (n, d, dtype, b, k) == (1_000_000, 768, "f16", 32, 100):
+        return "BASELINE configs[1]"
+    if (n, d, dtype, b, k) == (10_000, 512, "f32", 1, 10):
+        return "BASELINE configs[0] shape, on the GPU"
+    if (n, d, dtype, b, k) == (100_000_000, 768, "i8", 256, 100):
+        return "BASELINE configs[3] corpus"
+    return "not a BASELINE config"
+
+
 def device_sync(pvs, device):
     # hipDeviceSynchronize through the library's own runtime; torch.cuda.synchronize too when torch is here
     from panoptikon_amd import _lib as L
@@ -341,7 +354,7 @@ def main():
         "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} (BASELINE configs[2])",
+        "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} ({which_config(N, D, args.dtype, B, K)})",
                    "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
                    "parallelism": f"row-shard x{world}", "exchange": gather_mode, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1},
         "roofline": roofline,
