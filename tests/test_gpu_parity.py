@@ -2,6 +2,8 @@
 seeded inputs.  Bit-exact for int8 distances and ids; the float paths reproduce the
 oracle's sequential-f32 evaluation, so they are compared bit-exact as well (the
 north-star tolerance of 1e-5 relative is asserted as the fallback bar)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -900,7 +902,7 @@ def test_rrf_search_on_device_equals_the_sql_composition(pvs):
         b["index"].close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PVS_FUZZ_SEEDS", "24"))))
 def test_randomized_shapes_against_the_oracle(pvs, seed):
     """Seeded sweep over dtype / metric / rows / dim / batch / k (dims that are not multiples of any tile size,
     single rows, k > rows, batches across the 128/256 pass boundaries), with a sprinkling of duplicated rows,
@@ -1060,4 +1062,66 @@ def test_search_filtered_by_a_candidate_mask(pvs, dtype):
     # the unfiltered entry point is untouched by a previous filtered search on the same context
     gi, gd, gc = ix.search(hq, k, pvs.COSINE)
     assert np.array_equal(gi, full[0])
+    ix.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PVS_FUZZ_SEEDS", "18"))))
+def test_randomized_item_level_operations(pvs, seed):
+    """Seeded sweep over the per-item entry points: GROUP BY aggregates (MIN through the filter scan, MAX / AVG /
+    weighted dense), filtered search, similar_to with random options, device RRF over two random branches."""
+    rng = np.random.default_rng(7000 + seed)
+    dt = [pvs.I8, pvs.F16, pvs.F32][seed % 3]
+    metric = [pvs.COSINE, pvs.L2][(seed // 3) % 2]
+    n = int(rng.choice([40, 333, 2049, 6000]))
+    dim = int(rng.choice([24, 100, 256, 513, 768]))
+    n_groups = int(rng.choice([1, 7, n // 3 + 1, n]))
+    k = int(rng.choice([1, 5, 60]))
+    rows = orc.synth_rows(8000 + seed, 0, n, dim)
+    rows[int(rng.integers(0, n))] = 0.0
+    groups = np.sort(rng.integers(0, n_groups, n)).astype(np.int64) * 5 + 2
+    ids = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(dt, dim)
+    if dt == pvs.I8:
+        ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids, group_ids=groups)
+    hc = host_corpus(dt, rows, scale)
+    q = orc.synth_rows(9000 + seed, 0, 3, dim)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    w = (rng.random(n) + 0.05).astype(np.float32)
+    for agg, oagg, ww in ((pvs.AGG_MIN, orc.AGG_MIN, None), (pvs.AGG_MAX, orc.AGG_MAX, None), (pvs.AGG_AVG, orc.AGG_AVG, None),
+                          (pvs.AGG_AVG, orc.AGG_AVG, w)):
+        gg, gv, gc = ix.search_groups(hq, k, metric, agg, row_weights=ww)
+        for b in range(3):
+            eg, ev = orc.search_groups(dt, metric, hc, hq[b], groups, oagg, k, weights=ww)
+            assert gc[b] == len(eg) and np.array_equal(gg[b, : len(eg)], eg), (seed, agg, b)
+            a, e = gv[b, : len(eg)], ev
+            assert np.array_equal(np.isnan(a), np.isnan(e)) and np.array_equal(a[~np.isnan(a)], e[~np.isnan(e)]), (seed, agg, b)
+    m = rng.random(n) < rng.choice([0.02, 0.3, 0.9])
+    gi, gd, gc = ix.search_filtered(hq, k, m, metric)
+    allowed = np.nonzero(m)[0]
+    if len(allowed):
+        ei, ed = orc.search(dt, metric, hc[allowed], hq, k, ids=ids[allowed])
+        wdt = ei.shape[1]
+        assert gc.tolist() == [wdt] * 3 and np.array_equal(gi[:, :wdt], ei)
+        assert np.array_equal(np.isnan(gd[:, :wdt]), np.isnan(ed))
+    else:
+        assert (gc == 0).all()
+    tg = groups[int(rng.integers(0, n))]
+    targets = [int(t) for t in np.nonzero(groups == tg)[0]][:8]
+    kind = (rng.random(n) < 0.5).astype(np.uint8)
+    i2i, t2t = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    oagg = [orc.AGG_MIN, orc.AGG_MAX, orc.AGG_AVG][seed % 3]
+    gg, gv = ix.similar_to_ex(ids[targets], k, metric, [pvs.AGG_MIN, pvs.AGG_MAX, pvs.AGG_AVG][seed % 3], row_kind=kind, xmodal_i2i=i2i, xmodal_t2t=t2t)
+    eg, ev = orc.similar_to_ex(dt, metric, hc, targets, groups, oagg, k, kind=kind, xmodal_i2i=i2i, xmodal_t2t=t2t)
+    assert np.array_equal(gg, eg), seed
+    assert np.array_equal(np.isnan(gv), np.isnan(ev)) and np.array_equal(gv[~np.isnan(gv)], ev[~np.isnan(ev)])
+    # RRF over this index under both metrics as two branches
+    br = [dict(index=ix, query=hq[0], metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=int(rng.integers(1, 70)), weight=1.0),
+          dict(index=ix, query=hq[1], metric=pvs.L2, agg=pvs.AGG_AVG, descending=bool(rng.integers(0, 2)), rrf_k=3, weight=0.5)]
+    ob = [dict(dtype=dt, metric=orc.COSINE, corpus=hc, query=hq[0], groups=groups, agg=orc.AGG_MIN, rrf_k=br[0]["rrf_k"], weight=1.0),
+          dict(dtype=dt, metric=orc.L2, corpus=hc, query=hq[1], groups=groups, agg=orc.AGG_AVG, descending=br[1]["descending"], rrf_k=3, weight=0.5)]
+    gg, gs = pvs.rrf_search(br, k)
+    eg, es = orc.rrf_search(ob, k)
+    assert np.array_equal(gg, eg) and np.array_equal(gs.view(np.uint64), es.view(np.uint64)), seed
     ix.close()
