@@ -233,6 +233,13 @@ pvs_status pvs_search_groups(pvs_index *idx, const void *queries, pvs_dtype quer
                              uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights,
                              int64_t *out_groups, double *out_values, uint32_t *out_count);
 
+/* pvs_search_groups over the rows a candidate mask allows (see pvs_search_filtered): rows outside the mask take no
+ * part in any aggregate, and a group without a single candidate row is not part of the result at all. */
+pvs_status pvs_search_groups_filtered(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch,
+                                      uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights,
+                                      const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_groups,
+                                      double *out_values, uint32_t *out_count);
+
 /* similar_to (filters/item_similarity.rs:432-581): the target item's stored vectors
  * (rows named by their row ids) against every other row; per group aggregate over the
  * (target vector x group row) fan-out; the target's own rows are excluded

@@ -33,17 +33,18 @@ __device__ static inline double coalesce1(double v) { return v != v ? 1.0 : v; }
 __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout,
                                                          const uint32_t *grp_off, const uint32_t *grp_rows, uint32_t n_groups,
                                                          const float *weights, const uint8_t *exclude, int agg, FanoutWeights fw,
-                                                         double *out) {
+                                                         double *out, uint32_t skip_when) {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t ncol_out = fanout ? 1u : n_cols;
     if (gid >= (uint64_t)n_groups * ncol_out) return;
     const uint32_t g = (uint32_t)(gid / ncol_out), q = (uint32_t)(gid % ncol_out);
     Kbn sum, wsum;
     double mn = __builtin_inf(), mx = -__builtin_inf();
-    uint64_t cnt = 0;
+    uint64_t cnt = 0, considered = 0;
     for (uint32_t e = grp_off[g]; e < grp_off[g + 1]; e++) {
         const uint32_t row = grp_rows[e];
-        if (exclude && exclude[row]) continue;
+        if (exclude && (uint32_t)(exclude[row] != 0) == skip_when) continue;  // similar_to: flagged rows; candidate mask: rows it leaves out
+        considered++;
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
             double w = 1.0;
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         }
     }
     double v;
-    if (cnt == 0)
+    if (considered == 0 && skip_when == 0)
+        v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);  // no candidate row at all: the group is not part of the result
+    else if (cnt == 0)
         v = __builtin_nan("");
     else if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)))
         v = sum.value() / wsum.value();
@@ -92,11 +95,11 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
 
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s, FanoutWeights fw) {
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when) {
     if (n_groups == 0) return hipSuccess;
     const uint64_t total = (uint64_t)n_groups * (fanout ? 1u : n_cols);
     hipLaunchKernelGGL(k_group_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dist, ld, n_cols, fanout, grp_off,
-                       grp_rows, n_groups, weights, exclude, agg, fw, out);
+                       grp_rows, n_groups, weights, exclude, agg, fw, out, skip_when);
     return hipGetLastError();
 }
 
@@ -108,13 +111,29 @@ __device__ static inline unsigned long long f64_sort_key(double d) {
 }
 __global__ void k_group_keys(const double *vals, uint32_t n, unsigned long long *keys, uint32_t *idx) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        keys[i] = f64_sort_key(vals[i]);
+        unsigned long long k = f64_sort_key(vals[i]);
+        if (k == ~0ull) k = ~0ull - 1;  // NULL aggregates: after every value ...
+        if (__builtin_bit_cast(unsigned long long, vals[i]) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
+        keys[i] = k;
         idx[i] = i;
     }
 }
 __global__ void k_group_emit(const uint32_t *idx_sorted, const double *vals, const int64_t *group_ids, uint32_t n, uint32_t k,
                              int64_t *out_groups, double *out_vals, uint32_t *out_count) {
-    const uint32_t nout = n < k ? n : k;
+    __shared__ uint32_t s_nout;
+    if (threadIdx.x == 0) {  // absent groups (no candidate row under the mask) sort last: the live ones are a prefix
+        uint32_t lo = 0, hi = n < k ? n : k;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (__builtin_bit_cast(unsigned long long, vals[idx_sorted[mid]]) != PVS_GROUP_ABSENT)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        s_nout = lo;
+    }
+    __syncthreads();
+    const uint32_t nout = s_nout;
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
         if (i < nout) {
             out_groups[i] = group_ids[idx_sorted[i]];

@@ -128,6 +128,8 @@ bool fast_path_ok(const pvs_index *ix, uint32_t k);
 pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb, uint32_t batch_pad,
                       int metric);
 SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket);
+pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                       const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 void ctx_done(pvs_index *ix, SearchCtx *c);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);

@@ -134,7 +134,7 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
 // shared tail: d_m [n][nb] (fanout == 0: nb output columns; else one) -> ranked groups on the host
 static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg,
                                      const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
-                                     double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights()) {
+                                     double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1) {
     const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
     double *d_vals = nullptr;
     int64_t *d_og = nullptr;
@@ -146,7 +146,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         HIP_TRY(hipMalloc((void **)&d_ov, (size_t)k * 8));
         HIP_TRY(hipMalloc((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
-                                           c.stream, fw));
+                                           c.stream, fw, skip_when));
         for (uint32_t q = 0; q < ncol; q++) {
             PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, ix->gwork, d_og, d_ov, d_oc, c.stream));
             HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
@@ -172,7 +172,8 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
 // the boundary could otherwise hide an unseen group).  Else grow kp; past PVS_MAX_K the caller runs
 // the dense path.  Values are the same f64(f32 distance) the dense path produces.
 static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                                  int64_t *out_groups, double *out_values, uint32_t *out_count, bool *done) {
+                                  const uint8_t *mask, pvs_space mask_space, int64_t *out_groups, double *out_values,
+                                  uint32_t *out_count, bool *done) {
     *done = false;
     if (ix->n == 0 || ix->n_groups == 0 || ix->forced_path == 1) return PVS_OK;
     const uint64_t n = ix->n;
@@ -199,7 +200,7 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     for (;;) {
         ids.assign((size_t)batch * kp, -1);
         dist.assign((size_t)batch * kp, 0.f);
-        PVS_TRY(pvs_search(ix, queries, qdtype, batch, (uint32_t)kp, metric, ids.data(), dist.data(), cnt.data()));
+        PVS_TRY(search_host(ix, queries, qdtype, batch, (uint32_t)kp, metric, mask, mask_space, ids.data(), dist.data(), cnt.data()));
         bool all_ok = true;
         for (uint32_t q = 0; q < batch && all_ok; q++) {
             const int64_t *qi = ids.data() + (size_t)q * kp;
@@ -226,7 +227,7 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
                 if (!na && a.v != b.v) return a.v < b.v;
                 return a.g < b.g;
             });
-            const bool complete = cnt[q] == n;  // the page is the whole corpus
+            const bool complete = cnt[q] == n || cnt[q] < kp;  // the page is the whole corpus / every candidate row
             const uint32_t want = (uint32_t)std::min<uint64_t>(k, complete ? gv.size() : (uint64_t)k);
             bool ok = complete;
             if (!ok && gv.size() >= k && cnt[q] > 0) {
@@ -252,9 +253,27 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     }
 }
 
+static pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                     pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                                     double *out_values, uint32_t *out_count);
+
 PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                         double *out_values, uint32_t *out_count) {
+    return search_groups_impl(ix, queries, qdtype, batch, k, metric, agg, row_weights, nullptr, PVS_HOST, out_groups, out_values, out_count);
+}
+
+PVS_EXPORT pvs_status pvs_search_groups_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                                                 pvs_metric metric, pvs_agg agg, const float *row_weights, const uint8_t *allowed_rows,
+                                                 pvs_space mask_space, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
+    return search_groups_impl(ix, queries, qdtype, batch, k, metric, agg, row_weights, allowed_rows, mask_space, out_groups, out_values,
+                              out_count);
+}
+
+static pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                     pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                                     double *out_values, uint32_t *out_count) {
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (!row_weights && agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG)
@@ -267,18 +286,29 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
     }
     if (agg == PVS_AGG_MIN && !row_weights) {
         bool done = false;
-        PVS_TRY(groups_min_fast(ix, queries, qdtype, batch, k, metric, out_groups, out_values, out_count, &done));
+        PVS_TRY(groups_min_fast(ix, queries, qdtype, batch, k, metric, mask, mask_space, out_groups, out_values, out_count, &done));
         if (done) return PVS_OK;
     }
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);
     void *d_q = nullptr;
     float *d_m = nullptr, *d_w = nullptr;
+    uint8_t *d_mask = nullptr;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
         HIP_TRY(hipMalloc(&d_q, qbytes * batch));
         HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        const uint8_t *dm = nullptr;  // candidate mask on the device
+        if (mask && ix->n) {
+            if (mask_space == PVS_HOST) {
+                HIP_TRY(hipMalloc((void **)&d_mask, ix->n));
+                HIP_TRY(hipMemcpyAsync(d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
+                dm = d_mask;
+            } else {
+                dm = mask;
+            }
+        }
         if (row_weights && ix->n) {
             HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
             HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
@@ -292,8 +322,8 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
                 PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
                 PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
             }
-            PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, nullptr, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
-                                       out_count + q0));
+            PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, dm, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
+                                       out_count + q0, FanoutWeights(), dm ? 0u : 1u));
         }
         return PVS_OK;
     };
@@ -301,6 +331,7 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
     hipFree(d_q);
     hipFree(d_m);
     hipFree(d_w);
+    hipFree(d_mask);
     ix->searches++;
     ix->dense_queries += batch;
     ctx_done(ix, c);

@@ -129,9 +129,13 @@ struct FanoutWeights {
     const uint8_t *kind = nullptr;    // [rows] PVS_KIND_*; gates below apply when set
     uint32_t skip_i2i = 0, skip_t2t = 0;
 };
+// `exclude` [rows] with skip_when == 1: rows whose byte is non-zero are left out (similar_to: the target's own rows);
+// with skip_when == 0 it is a candidate mask: rows whose byte is zero are left out, and a group without any candidate
+// row gets the value PVS_GROUP_ABSENT, which pvs_group_rank never emits.
+constexpr unsigned long long PVS_GROUP_ABSENT = 0x7ff8a5a5a5a5a5a5ull;  // a NaN payload no arithmetic produces
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights());
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1);
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);

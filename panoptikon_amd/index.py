@@ -206,6 +206,19 @@ class VectorIndex:
         L.check(L.lib().pvs_search_groups(self._h, _ptr(q), qd, b, k, metric, agg, _ptr(w), _ptr(og), _ptr(ov), _ptr(oc)))
         return og, ov, oc
 
+    def search_groups_filtered(self, queries, k: int, allowed_rows, metric: int = L.COSINE, agg: int = L.AGG_MIN, row_weights=None):
+        """search_groups over the rows whose byte in `allowed_rows` is non-zero; groups without such a row are absent."""
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        m = np.ascontiguousarray(allowed_rows).astype(np.uint8, copy=False)
+        w = None if row_weights is None else np.ascontiguousarray(row_weights, np.float32)
+        og = np.empty((b, k), np.int64)
+        ov = np.empty((b, k), np.float64)
+        oc = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_groups_filtered(self._h, _ptr(q), qd, b, k, metric, agg, _ptr(w), _ptr(m), L.HOST, _ptr(og), _ptr(ov),
+                                                   _ptr(oc)))
+        return og, ov, oc
+
     def similar_to(self, target_row_ids, k: int, metric: int = L.L2, agg: int = L.AGG_AVG):
         """filters/item_similarity.rs: the target item's stored vectors against everything else."""
         t = np.ascontiguousarray(target_row_ids, np.int64)

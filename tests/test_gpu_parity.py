@@ -1107,6 +1107,16 @@ def test_randomized_item_level_operations(pvs, seed):
         assert np.array_equal(np.isnan(gd[:, :wdt]), np.isnan(ed))
     else:
         assert (gc == 0).all()
+    # per-item pages under the same candidate mask: groups without a candidate row are absent, the others aggregate
+    # their candidate rows only
+    if len(allowed):
+        for agg, oagg, ww in ((pvs.AGG_MIN, orc.AGG_MIN, None), (pvs.AGG_AVG, orc.AGG_AVG, None), (pvs.AGG_MAX, orc.AGG_MAX, w)):
+            gg, gv, gc = ix.search_groups_filtered(hq, k, m, metric, agg, row_weights=ww)
+            for b in range(3):
+                eg, ev = orc.search_groups(dt, metric, hc[allowed], hq[b], groups[allowed], oagg, k, weights=None if ww is None else ww[allowed])
+                assert gc[b] == len(eg) and np.array_equal(gg[b, : len(eg)], eg), (seed, "filtered groups", agg, b)
+                a_, e_ = gv[b, : len(eg)], ev
+                assert np.array_equal(np.isnan(a_), np.isnan(e_)) and np.array_equal(a_[~np.isnan(a_)], e_[~np.isnan(e_)])
     tg = groups[int(rng.integers(0, n))]
     targets = [int(t) for t in np.nonzero(groups == tg)[0]][:8]
     kind = (rng.random(n) < 0.5).astype(np.uint8)
