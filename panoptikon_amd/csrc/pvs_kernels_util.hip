@@ -378,9 +378,10 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         qi.pad1 = 0.f;
         // Error budget of the scan key: f32 accumulation of K terms is within
         // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|;
-        // bf16 images of both the row and the query (f32 index) add (2^-8 + 2^-18) |a||q|.
+        // bf16 images of BOTH the row and the query (f32 index; 8 significand bits, round to nearest: 2^-8 each)
+        // add (2*2^-8 + 2^-16) sum|a_i||q_i| <= (2^-7 + 2^-16) |a||q|.
         const float acc = (float)dim * 6.0e-8f;
-        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 3.92e-3f : 0.0f;
+        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 7.83e-3f : 0.0f;
         if (metric == PVS_COSINE) {
             qi.eA = (qround + 2.0f * acc + 4.0e-6f) * qi.qn;
             qi.eC = 0.f;

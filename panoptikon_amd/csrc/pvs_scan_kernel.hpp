@@ -58,7 +58,7 @@ struct Acc<PVS_F16> {
 };
 
 // f32 rows are narrowed to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way from LDS to
-// the matrix core: the filter only needs an interval around the key (|dot error| <= 2^-8 |a||q|,
+// the matrix core: the filter only needs an interval around the key (|dot error| <= (2^-7 + 2^-16) |a||q|: both operands rounded,
 // QInfo.eA/eR), the survivors are rescored from the f32 rows in the reference's order.
 template <>
 struct Acc<PVS_F32> {
