@@ -307,29 +307,21 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
             s_amax = m;
         }
         __syncthreads();
-        // exact power-of-two prescale of the scan operand: the largest |q_i| lands in [2^13, 2^14)
-        // for an f16 image (away from overflow and from the subnormal range), in [1/2, 1) for a
-        // bf16 image (f32 index; away from the subnormal range the matrix core may flush)
+        // exact power-of-two prescale of the scan operand: the largest |q_i| lands in [2^13, 2^14) of its f16 image
+        // (away from overflow and from the subnormal range)
         int e = 0;
         if (s_amax > 0.f) {
             int x;
             (void)frexpf(s_amax, &x);
-            e = (index_dtype == PVS_F16 ? 14 : 0) - x;
+            e = 14 - x;
             if (e > 100) e = 100;
             if (e < -100) e = -100;
         }
         dscale = ldexpf(1.0f, -e);
-        if (index_dtype == PVS_F16) {
-            for (uint32_t i = tid; i < dim; i += 256) {
-                _Float16 h = (_Float16)ldexpf(q[i], e);
-                *(uint16_t *)(mrow + 2 * (uint64_t)i) = __builtin_bit_cast(uint16_t, h);
-            }
-        } else {
-            for (uint32_t i = tid; i < dim; i += 256) {
-                uint32_t u = __builtin_bit_cast(uint32_t, ldexpf(q[i], e));
-                if ((u & 0x7f800000u) != 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-                *(uint16_t *)(mrow + 2 * (uint64_t)i) = (uint16_t)(u >> 16);
-            }
+        // f16 and f32 indexes both take the f16 image of the prescaled query (f32 rows are narrowed to f16 in the kernel)
+        for (uint32_t i = tid; i < dim; i += 256) {
+            _Float16 h = (_Float16)ldexpf(q[i], e);
+            *(uint16_t *)(mrow + 2 * (uint64_t)i) = __builtin_bit_cast(uint16_t, h);
         }
     }
     __syncthreads();
@@ -378,10 +370,10 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         qi.pad1 = 0.f;
         // Error budget of the scan key: f32 accumulation of K terms is within
         // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|;
-        // bf16 images of BOTH the row and the query (f32 index; 8 significand bits, round to nearest: 2^-8 each)
-        // add (2*2^-8 + 2^-16) sum|a_i||q_i| <= (2^-7 + 2^-16) |a||q|.
+        // f32 index: rows narrowed to f16 toward zero after a per-row power-of-two scaling (2^-10, plus sqrt(D) 2^-26 for
+        // the components the scaling leaves below the f16 normal range) and the f16 query image (2^-11): 1.5e-3 |a||q|.
         const float acc = (float)dim * 6.0e-8f;
-        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 7.83e-3f : 0.0f;
+        const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 1.5e-3f : 0.0f;
         if (metric == PVS_COSINE) {
             qi.eA = (qround + 2.0f * acc + 4.0e-6f) * qi.qn;
             qi.eC = 0.f;

@@ -57,21 +57,32 @@ struct Acc<PVS_F16> {
     __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
 };
 
-// f32 rows are narrowed to bf16 (round to nearest even, v_cvt_pk_bf16_f32) on their way from LDS to
-// the matrix core: the filter only needs an interval around the key (|dot error| <= (2^-7 + 2^-16) |a||q|: both operands rounded,
-// QInfo.eA/eR), the survivors are rescored from the f32 rows in the reference's order.
+// f32 rows go to the matrix core as f16: on their way from LDS a lane scales its row by a power of two chosen from
+// the row's own norm (so the largest component lands below 2^13 whatever the row's magnitude: no overflow, nothing
+// above 2^-26 |a| is flushed) and narrows it with v_cvt_pkrtz_f16_f32 (round toward zero: 2^-10 relative).  The
+// filter only needs an interval around the key — |dot error| <= (2^-10 + 2^-11 + 2^-21 + sqrt(D) 2^-26) |a||q| with
+// the f16 image of the query, QInfo.eA/eR — and the survivors are rescored from the f32 rows in the reference's
+// order.  (bf16 needs no scaling but is 5x coarser: 2^-7 for the pair.)
 template <>
 struct Acc<PVS_F32> {
     using type = v16f;
     __device__ static inline type mfma(v4i a, v4i b, type c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
     }
     __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
 };
-__device__ static inline int cvt_pk_bf16(int lo, int hi) {
-    int r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+__device__ static inline int cvt_pkrtz_f16(float lo, float hi) {
+    return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+// power-of-two exponent a row is scaled by, from the per-row scalar the scan streams (cosine: 1/|a|, L2: |a|^2):
+// |a| * 2^e lies in (2^11, 2^13].  The same function serves the A side (scale) and the C side (undo).
+template <bool COSINE>
+__device__ static inline int f32_row_exp(float aux) {
+    const int x = __builtin_amdgcn_frexp_expf(aux);  // aux = m * 2^x, m in [0.5, 1)
+    int e = COSINE ? 12 + x : 13 - ((x + 1) >> 1);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);       // zero / non-finite norms: any value, those rows never pass
+    return e;
 }
 // MFMA steps per 256-B row slab: 8 for 1- and 2-byte elements (32 B of k per step and half-wave),
 // 4 for f32 (two 16-B pieces per step and half-wave)
@@ -265,7 +276,11 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // (two rows per step: v_pk_mul_f32 / v_pk_fma_f32)
         auto epi_micro = [&](int m, float(&sv)[16], float &best, auto &&pv) {
             if (m < 8) {
-                const v2f d = {(float)pv(2 * m), (float)pv(2 * m + 1)};
+                v2f d = {(float)pv(2 * m), (float)pv(2 * m + 1)};
+                if constexpr (DT == PVS_F32) {  // undo the per-row power-of-two scaling (exact)
+                    d[0] = __builtin_ldexpf(d[0], -f32_row_exp<COS>(xh[2 * m]));
+                    d[1] = __builtin_ldexpf(d[1], -f32_row_exp<COS>(xh[2 * m + 1]));
+                }
                 const v2f x = {xh[2 * m], xh[2 * m + 1]};
                 const v2f r = COS ? d * x : __builtin_elementwise_fma(d, (v2f){m2d, m2d}, (v2f){c1, c1} * x);
                 sv[2 * m] = r[0];
@@ -374,6 +389,12 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
                 issue_begin();                          // the slot the previous chunk occupied is refilled below
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
+                float row_scale = 1.0f;  // f32 rows: 2^e of this lane's A row (its scalar sits in this chunk's slot)
+                if constexpr (DT == PVS_F32) {
+                    const float ax = ((const float *)(normring + c_slot * (WAVES * 256) + wave * 256))[lane];
+                    row_scale = __builtin_ldexpf(1.0f, f32_row_exp<COS>(ax));
+                }
+                (void)row_scale;
                 const uint8_t *fb[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) fb[i] = cb + swz[i];
@@ -395,10 +416,16 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 };
                 auto narrow = [&](int t) {  // VALU work placed behind MFMA t-1
                     if constexpr (DT == PVS_F32) {
-                        af[t][0] = cvt_pk_bf16(raw[t][0][0], raw[t][0][1]);
-                        af[t][1] = cvt_pk_bf16(raw[t][0][2], raw[t][0][3]);
-                        af[t][2] = cvt_pk_bf16(raw[t][1][0], raw[t][1][1]);
-                        af[t][3] = cvt_pk_bf16(raw[t][1][2], raw[t][1][3]);
+                        // scale (v_pk_mul_f32 on register pairs) and narrow, two components at a time
+                        typedef float v4ff __attribute__((ext_vector_type(4)));
+                        const v4ff r0 = __builtin_bit_cast(v4ff, raw[t][0]), r1 = __builtin_bit_cast(v4ff, raw[t][1]);
+                        const v2f s2 = {row_scale, row_scale};
+                        const v2f p0 = __builtin_shufflevector(r0, r0, 0, 1) * s2, p1 = __builtin_shufflevector(r0, r0, 2, 3) * s2;
+                        const v2f p2 = __builtin_shufflevector(r1, r1, 0, 1) * s2, p3 = __builtin_shufflevector(r1, r1, 2, 3) * s2;
+                        af[t][0] = cvt_pkrtz_f16(p0[0], p0[1]);
+                        af[t][1] = cvt_pkrtz_f16(p1[0], p1[1]);
+                        af[t][2] = cvt_pkrtz_f16(p2[0], p2[1]);
+                        af[t][3] = cvt_pkrtz_f16(p3[0], p3[1]);
                     }
                 };
 #pragma unroll

@@ -103,13 +103,10 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
         // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
         // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
         // holds ~k/frac rows: keep that 2.5x below its capacity.
-        // f32 rows are filtered through bf16 images: the key interval is 2^-7 |a||q| wide and lets ~3x more rows
-        // through than the threshold rank suggests, so they get the denser sample even for a handful of queries
-        const bool wide_err = ix->dtype == PVS_F32;
-        double frac = (nb <= 4 && !wide_err) ? 1.0 / 64.0 : 1.0 / 16.0;
+        double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
         static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
         if (frac_env > 0.0) frac = frac_env;
-        frac = std::min(0.5, std::max(frac, (wide_err ? 6.0 : 2.5) * (double)k / (double)PVS_CAND_CAP));
+        frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
         const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
