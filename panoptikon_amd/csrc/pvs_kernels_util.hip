@@ -375,11 +375,11 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         const float acc = (float)dim * 6.0e-8f;
         const float qround = (index_dtype == PVS_F16) ? 4.9e-4f : (index_dtype == PVS_F32) ? 1.5e-3f : 0.0f;
         if (metric == PVS_COSINE) {
-            qi.eA = (qround + 2.0f * acc + 4.0e-6f) * qi.qn;
+            qi.eA = (qround + 4.0f * acc + 4.0e-6f) * qi.qn;  // (the matrix core's internal adds may chop: twice the IEEE budget)
             qi.eC = 0.f;
             qi.eR = 0.f;
         } else {
-            const float coef = qround + 4.0f * acc + 1.0e-6f;
+            const float coef = qround + 6.0f * acc + 1.0e-6f;
             qi.eA = coef * bb + (index_dtype == PVS_I8 ? 2.0f : 0.0f);
             qi.eC = 0.f;
             qi.eR = coef;
