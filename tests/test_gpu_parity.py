@@ -1135,3 +1135,34 @@ def test_randomized_item_level_operations(pvs, seed):
     eg, es = orc.rrf_search(ob, k)
     assert np.array_equal(gg, eg) and np.array_equal(gs.view(np.uint64), es.view(np.uint64)), seed
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_near_tied_scores_with_coherent_rounding(pvs, dtype):
+    """The filter scores float rows through narrowed images (f16 query image; f32 rows truncated to f16): here every
+    component and every query component is positive, so the narrowing errors of a row all push its dot product the
+    same way, and thousands of rows score within 1e-4 of each other — a page is exact only if the interval the
+    filter puts around its key really contains the error (checked by hand: with the f32 bound set 30x too small this
+    test fails; the factor-of-two questions are settled by the analysis in DESIGN.md, not by tests)."""
+    dt = pvs.F16 if dtype == "f16" else pvs.F32
+    rng = np.random.default_rng(53)
+    n, dim, k = 12000, 384, 60  # (a row pitch both dtypes have a scan instance for)
+    base = (np.abs(rng.standard_normal(dim)) + 0.5).astype(np.float32)
+    rows = np.abs(rng.standard_normal((n, dim))).astype(np.float32) + 0.1           # far from the queries ...
+    near = rng.choice(n, 2000, replace=False)                                        # ... except 2000 near-tied rows
+    rows[near] = base[None, :] * (1.0 + 2e-4 * rng.standard_normal((2000, dim))).astype(np.float32)
+    rows *= (2.0 ** rng.integers(-6, 7, n)).astype(np.float32)[:, None]  # norms over 12 octaves (cosine ignores them)
+    # odd rows: mantissas just below the next f16 grid point (truncation loses almost a full unit in the last place,
+    # their scan keys come out ~1e-3 pessimistic); even rows: exactly representable (no error at all).  The true
+    # neighbours are spread over both kinds, so rows must not be dropped for looking 1e-3 worse than their peers.
+    bits = rows.view(np.uint32).copy()
+    bits[1::2] |= np.uint32(0x1FFF)
+    bits[0::2] &= np.uint32(0xFFFFE000)
+    rows = bits.view(np.float32)
+    q = (base[None, :] * (1.0 + 1e-3 * rng.standard_normal((5, dim)))).astype(np.float32)
+    ix = make_index(pvs, dt, rows, None)
+    hc = host_corpus(dt, rows, None)
+    _check(pvs, ix, dt, pvs.COSINE, hc, q, k)
+    assert ix.stats().dense_queries == 0, "the filter path itself must get this right"
+    _check(pvs, ix, dt, pvs.L2, hc, q, k)
+    ix.close()
