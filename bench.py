@@ -156,6 +156,12 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     dist = Dist(args.gpus)
+    if not os.path.exists(os.path.join(ROOT, "panoptikon_amd", "libpvs.so")):  # fresh checkout: the library is git-ignored
+        if dist.rank == 0:
+            import subprocess
+
+            subprocess.check_call([sys.executable, "-m", "panoptikon_amd.build"], cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dist.barrier()
     import panoptikon_amd as pvs
     from panoptikon_amd import _lib as L
 
