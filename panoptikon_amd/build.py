@@ -28,6 +28,9 @@ SOURCES = [
     "pvs_scan_i8.hip",
     "pvs_scan_f16_small.hip",
     "pvs_scan_f16_large.hip",
+    "pvs_scan_f16_xl.hip",
+    "pvs_scan_i8_large.hip",
+    "pvs_scan_f32_xl.hip",
     "pvs_scan_f32_small.hip",
     "pvs_scan_f32_mid.hip",
     "pvs_scan_f32_large.hip",

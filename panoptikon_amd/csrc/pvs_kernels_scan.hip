@@ -7,14 +7,16 @@
 #include "pvs_scan_dispatch.hpp"
 
 bool pvs_scan_supported(int dtype, uint32_t kslabs) {
-    if (dtype == PVS_I8) return kslabs >= 1 && kslabs <= 4;
-    if (dtype == PVS_F16) return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8;
+    if (dtype == PVS_I8) return kslabs >= 1 && kslabs <= 6;
+    if (dtype == PVS_F16)
+        return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 9 || kslabs == 10 || kslabs == 12;
     if (dtype == PVS_F32)
-        return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 12 || kslabs == 16;
+        return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 12 || kslabs == 16 || kslabs == 18 ||
+               kslabs == 20 || kslabs == 24;
     return false;
 }
 uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
-uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }
+uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     ScanK k;
@@ -41,15 +43,18 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.batch = a.batch;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
-        e = a.qgroups == 8 ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
-                           : pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+        e = a.qgroups == 8   ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
+            : a.kslabs <= 4 ? pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+                            : pvs_scan_dispatch_i8_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     else if (a.dtype == PVS_F16)
-        e = a.kslabs <= 4 ? pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
-                          : pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+        e = a.kslabs <= 4   ? pvs_scan_dispatch_f16_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+            : a.kslabs <= 8 ? pvs_scan_dispatch_f16_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+                            : pvs_scan_dispatch_f16_xl(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     else if (a.dtype == PVS_F32)
         e = a.kslabs <= 4   ? pvs_scan_dispatch_f32_small(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
             : a.kslabs <= 8 ? pvs_scan_dispatch_f32_mid(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
-                            : pvs_scan_dispatch_f32_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
+            : a.kslabs <= 16 ? pvs_scan_dispatch_f32_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
+                             : pvs_scan_dispatch_f32_xl(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     return e;
 }
 

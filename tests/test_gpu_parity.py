@@ -132,6 +132,16 @@ CASES = [
     ("f32", "cosine", 7000, 256, 64, 50),
     ("f32", "l2", 6000, 384, 33, 20),
     ("f32", "cosine", 5000, 128, 5, 10),
+    # the wider models: SigLIP so400m (1152), OpenCLIP bigG (1280), 1536-d text embeddings
+    ("i8", "cosine", 9000, 1152, 128, 50),
+    ("i8", "l2", 7000, 1536, 33, 20),
+    ("i8", "cosine", 6000, 1280, 200, 10),
+    ("f16", "cosine", 8000, 1152, 32, 50),
+    ("f16", "l2", 6000, 1280, 128, 20),
+    ("f16", "cosine", 5000, 1536, 5, 10),
+    ("f32", "cosine", 6000, 1152, 32, 50),
+    ("f32", "l2", 5000, 1280, 8, 20),
+    ("f32", "cosine", 4000, 1536, 128, 10),
 ]
 
 
