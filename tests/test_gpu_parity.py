@@ -142,6 +142,10 @@ CASES = [
     ("f32", "cosine", 6000, 1152, 32, 50),
     ("f32", "l2", 5000, 1280, 8, 20),
     ("f32", "cosine", 4000, 1536, 128, 10),
+    # pitches without an instance of their own are padded up to the next one (640-d f16 -> 1536 B, 320-d f32 -> 1536 B)
+    ("f16", "cosine", 6000, 640, 16, 20),
+    ("f32", "l2", 5000, 320, 16, 20),
+    ("f16", "l2", 4000, 1100, 8, 10),
 ]
 
 
