@@ -7,7 +7,7 @@
 #include "pvs_scan_dispatch.hpp"
 
 bool pvs_scan_supported(int dtype, uint32_t kslabs) {
-    if (dtype == PVS_I8) return kslabs >= 1 && kslabs <= 6;
+    if (dtype == PVS_I8) return (kslabs >= 1 && kslabs <= 6) || kslabs == 8 || kslabs == 12;
     if (dtype == PVS_F16)
         return kslabs == 1 || kslabs == 2 || kslabs == 3 || kslabs == 4 || kslabs == 6 || kslabs == 8 || kslabs == 9 || kslabs == 10 || kslabs == 12;
     if (dtype == PVS_F32)

@@ -146,6 +146,9 @@ CASES = [
     ("f16", "cosine", 6000, 640, 16, 20),
     ("f32", "l2", 5000, 320, 16, 20),
     ("f16", "l2", 4000, 1100, 8, 10),
+    ("i8", "cosine", 5000, 2048, 64, 20),
+    ("i8", "l2", 4000, 3072, 16, 10),
+    ("i8", "cosine", 3000, 1700, 5, 10),  # 1792 B -> 2048 B
 ]
 
 
