@@ -5,7 +5,7 @@
 // Replaces, for a batch of queries, the reference's per-row
 //   vec_distance_{cosine,L2}(payload, ?)          (image_embeddings.rs:321-362,
 //   ... ORDER BY order_rank ASC ... LIMIT k          text_embeddings.rs:386-418, builder.rs:578-582)
-// The reference scores every row and sorts everything.  Here (DESIGN.md §5):
+// The reference scores every row and sorts everything.  Here (DESIGN.md §4.1-4.2):
 //   pass A (MODE 0)  scan a strided sample of row tiles, keep per-lane minima of an UPPER
 //           bound of the key -> the k-th smallest of those group minima is a valid upper
 //           bound T of the k-th best key of the whole corpus;
@@ -17,12 +17,15 @@
 //   the whole kernel as MFMA B fragments) and row sub-tile rt (32 rows);
 //   QG = batch_pad/32 in {1,2,4}, RT = 4/QG, workgroup tile = 32*RT rows.
 //   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
-//   in "slabs" of (32*RT rows x 256 B), NS-deep ring, P = NS-1 slabs in flight, one
-//   s_barrier per slab, counted s_waitcnt vmcnt (never 0 in steady state).
+//   in "slabs" of (32*RT rows x 256 B) grouped into chunks of SPB slabs (the whole 24 KiB tile for
+//   768-B rows and 128 queries): NC-chunk ring, NC-1 chunks in flight, one s_barrier and one counted
+//   s_waitcnt vmcnt per chunk (never 0 in steady state).  MODE 2 = dense exact int8 distances.
+//   QG = 8 (256 queries, int8): 8 waves, one query group each, on one 32-row tile (Geo below).
 //   A fragments are ds_read_b128 from an XOR-swizzled slab image (chunk ^= row & 15).  The corpus
 //   is STORED in that image (tiled layout, pvs_common.hpp), so a DMA piece is one contiguous KiB
 //   of HBM landing lane-linear in LDS; reads are conflict-free for ds_read_b128's 16-lane groups.
-//   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 with A = 32 corpus rows, B = 32 queries:
+//   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 (f32 rows: scaled per row and narrowed to f16 on the
+//   way from LDS, see Acc<PVS_F32>) with A = 32 corpus rows, B = 32 queries:
 //   each lane ends up with ONE query (lane & 31) and 16 rows, so the per-query threshold is
 //   a lane-private register and the epilogue is 3-4 VALU per score until a row passes.
 #pragma once
