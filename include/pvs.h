@@ -417,6 +417,8 @@ pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const flo
                                  int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 
 /* ------------------------------------------------- device memory + synthetic */
+/* Free and total HBM of `device` in bytes (hipMemGetInfo): capacity planning for shard sizes. */
+pvs_status pvs_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* hipDeviceSynchronize on `device` (-1: current): every stream of the process, the library's included. */
 pvs_status pvs_device_synchronize(int32_t device);
 pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out);

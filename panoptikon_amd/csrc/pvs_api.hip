@@ -433,6 +433,17 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_device_mem_info(int32_t device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    int dev = 0;
+    PVS_TRY(use_device(device, &dev));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_device_synchronize(int32_t device) {
     int dev = 0;
     PVS_TRY(use_device(device, &dev));
