@@ -67,7 +67,7 @@
 extern "C" {
 #endif
 
-#define PVS_ABI_VERSION 1
+#define PVS_ABI_VERSION 2
 
 typedef int32_t pvs_status;
 enum {
@@ -91,13 +91,25 @@ typedef enum { PVS_HOST = 0, PVS_DEVICE = 1 } pvs_space;
 
 typedef struct pvs_index pvs_index;
 
+#define PVS_MAX_DEVICES 16
 typedef struct pvs_index_desc {
-    uint32_t struct_size;   /* sizeof(pvs_index_desc) */
-    int32_t device;         /* HIP device ordinal, -1 = current device */
+    uint32_t struct_size;   /* sizeof(pvs_index_desc); the 32-byte ABI v1 prefix (up to id_base) is still accepted */
+    int32_t device;         /* HIP device ordinal, -1 = current device (ignored when n_devices > 1) */
     uint32_t dtype;         /* pvs_dtype of the rows resident in HBM */
     uint32_t dim;           /* components per vector (dim = blob_len/4 in the reference) */
-    uint64_t capacity_rows; /* rows to reserve up front (0 = grow on demand) */
+    uint64_t capacity_rows; /* rows to reserve up front, over all devices (0 = grow on demand) */
     int64_t id_base;        /* row id of row 0 when pvs_index_add is given row_ids == NULL */
+    /* ABI v2 — one host process, several GPUs (the reference host is ONE process with a pool of read
+     * connections, db/connection.rs:320-357): the rows shard across `devices`; every pvs_index_add call
+     * splits its rows into n_devices contiguous pieces (ids stay increasing inside every shard), searches fan
+     * out to all shards, per-shard pages travel to devices[0] by peer copies over xGMI and are merged there
+     * (SURVEY.md §8e).  n_devices 0 or 1 = single device.  An ordinal may repeat (several shards on one GPU:
+     * used by the tests on one-GPU machines).  Served on a multi-device index: add, scale, stats, read back,
+     * pvs_search / pvs_search_device + pvs_wait, pvs_score_all, pvs_search_groups with MIN (a group may span
+     * shards: the minimum of the shard minima), pvs_rrf_search over MIN branches; other per-item entry
+     * points return PVS_ERR_UNSUPPORTED (MAX/AVG need every row of a group on one device). */
+    uint32_t n_devices;
+    const int32_t *devices; /* [n_devices] HIP ordinals */
 } pvs_index_desc;
 
 typedef struct pvs_stats {
@@ -166,6 +178,8 @@ typedef struct pvs_profile {
     double sample_ms;
     uint64_t finalize_launches; /* pass C */
     double finalize_ms;
+    uint64_t exchange_launches; /* sharded search: the grouped RCCL all-gather + the merge kernel (ABI v2) */
+    double exchange_ms;
 } pvs_profile;
 pvs_status pvs_index_set_profiling(pvs_index *idx, int32_t enable);
 pvs_status pvs_index_get_profile(pvs_index *idx, pvs_profile *out, int32_t reset);
@@ -196,7 +210,10 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
 
 /* Same, with every buffer resident in HBM (queries, out_*).  Enqueues on one of
  * the index's streams and returns without synchronising; *out_ticket identifies
- * the stream to wait on with pvs_wait (or pvs_sync for all of them). */
+ * the stream to wait on with pvs_wait (or pvs_sync for all of them).  At most 16 searches (the size of the
+ * reference's read pool) can be in flight on one index: with none free the stream-ordered entry points
+ * (this one, pvs_search_sharded_async) return PVS_ERR_STATE — pvs_wait one first — while the synchronous
+ * ones block until a slot frees.  On a multi-device index the buffers live on devices[0]. */
 pvs_status pvs_search_device(pvs_index *idx, const void *d_queries, pvs_dtype query_dtype,
                              uint32_t batch, uint32_t k, pvs_metric metric, int64_t *d_out_ids,
                              float *d_out_dist, uint32_t *d_out_count, uint32_t *out_ticket);

@@ -472,10 +472,11 @@ ORC_API size_t orc_aggregate_fanout(const float *dist, size_t m, const uint8_t *
         size_t j = i;
         kbn sum = {0, 0};
         double mn = INFINITY, mx = -INFINITY;
-        size_t cnt = 0;
+        size_t cnt = 0, joined = 0;
         for (; j < n && group[j] == group[i]; j++) {
             if (exclude && exclude[j]) continue;
             for (size_t t = 0; t < m; t++) {
+                joined++;
                 float df = dist[j * m + t];
                 if (isnan(df)) continue;
                 double d = (double)df;
@@ -484,6 +485,10 @@ ORC_API size_t orc_aggregate_fanout(const float *dist, size_t m, const uint8_t *
                 if (d > mx) mx = d;
                 cnt++;
             }
+        }
+        if (joined == 0) { /* INNER JOIN + WHERE other.sha256 != target: no pair, no output row (item_similarity.rs:445-468) */
+            i = j;
+            continue;
         }
         double v = cnt == 0 ? NAN : agg == ORC_AGG_MIN ? mn : agg == ORC_AGG_MAX ? mx : kbn_value(&sum) / (double)cnt;
         out_group[g] = group[i];
@@ -507,10 +512,11 @@ ORC_API size_t orc_aggregate_fanout_weighted(const float *dist, size_t m, const 
     while (i < n) {
         size_t j = i;
         kbn sum = {0, 0}, wsum = {0, 0};
-        size_t cnt = 0;
+        size_t cnt = 0, joined = 0;
         for (; j < n && group[j] == group[i]; j++) {
             if (exclude && exclude[j]) continue;
             for (size_t t = 0; t < m; t++) {
+                joined++;
                 double w = 1.0;
                 if (cw != 0.0 && lw != 0.0)
                     w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw) * pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
@@ -524,6 +530,10 @@ ORC_API size_t orc_aggregate_fanout_weighted(const float *dist, size_t m, const 
                 kbn_step(&sum, (double)df * w);
                 cnt++;
             }
+        }
+        if (joined == 0) {
+            i = j;
+            continue;
         }
         out_group[g] = group[i];
         out_val[g] = cnt == 0 ? NAN : kbn_value(&sum) / kbn_value(&wsum);
@@ -547,7 +557,7 @@ ORC_API size_t orc_aggregate_fanout_ex(const float *dist, size_t m, const uint8_
         size_t j = i;
         kbn sum = {0, 0}, wsum = {0, 0};
         double mn = INFINITY, mx = -INFINITY;
-        size_t cnt = 0;
+        size_t cnt = 0, joined = 0;
         for (; j < n && group[j] == group[i]; j++) {
             if (exclude && exclude[j]) continue;
             for (size_t t = 0; t < m; t++) {
@@ -555,6 +565,7 @@ ORC_API size_t orc_aggregate_fanout_ex(const float *dist, size_t m, const uint8_
                     const uint8_t km = kind[target[t]], ko = kind[j];
                     if ((skip_i2i && km == 0 && ko == 0) || (skip_t2t && km == 1 && ko == 1)) continue;
                 }
+                joined++;
                 double w = 1.0;
                 if (cw != 0.0 && lw != 0.0)
                     w = pow(coalesce1(conf[target[t]]) * coalesce1(conf[j]), cw) * pow(coalesce1(lang[j]) * coalesce1(lang[target[t]]), lw);
@@ -571,6 +582,10 @@ ORC_API size_t orc_aggregate_fanout_ex(const float *dist, size_t m, const uint8_
                 if (d > mx) mx = d;
                 cnt++;
             }
+        }
+        if (joined == 0) { /* every pair gated away or excluded: the group is not in the join at all */
+            i = j;
+            continue;
         }
         double v;
         if (cnt == 0)

@@ -10,6 +10,7 @@ from .index import DeviceBuffer, VectorIndex, absmax, device_count, quantize_int
 from .host import (aggregate, artifact_scale, embedding_from_npy_bytes, extract_embeddings, merge_group_pages, merge_topk,
                    resolve_vector_quant, row_number, rrf_fuse, rrf_search, scale_artifact, scale_from_absmax)
 
-from .sharded import TorchDistGather, merge_shard_group_pages, merge_shard_pages, shard_range, shard_ranges_by_group
+from .rendezvous import LocalRendezvous
+from .sharded import merge_shard_group_pages, merge_shard_pages, shard_range, shard_ranges_by_group
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -23,7 +23,8 @@ UNIQUE_ID_BYTES = 128
 
 class IndexDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("dtype", C.c_uint32), ("dim", C.c_uint32),
-                ("capacity_rows", C.c_uint64), ("id_base", C.c_int64)]
+                ("capacity_rows", C.c_uint64), ("id_base", C.c_int64),
+                ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int32))]  # ABI v2: one process, several GPUs
 
 
 class RrfBranch(C.Structure):
@@ -47,7 +48,8 @@ class Stats(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("scan_launches", C.c_uint64), ("scan_ms", C.c_double),
                 ("scan_rows", C.c_uint64), ("sample_launches", C.c_uint64), ("sample_ms", C.c_double),
-                ("finalize_launches", C.c_uint64), ("finalize_ms", C.c_double)]
+                ("finalize_launches", C.c_uint64), ("finalize_ms", C.c_double),
+                ("exchange_launches", C.c_uint64), ("exchange_ms", C.c_double)]
 
 
 class ReadyPair(C.Structure):

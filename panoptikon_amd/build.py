@@ -39,6 +39,7 @@ SOURCES = [
     "pvs_groups.hip",
     "pvs_rrf.hip",
     "pvs_comm.hip",
+    "pvs_multi.hip",
     "pvs_host.cpp",
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
@@ -47,22 +48,35 @@ HIPFLAGS = ["--offload-arch=gfx950", "-ffp-contract=off"]
 HOSTFLAGS = ["-ffp-contract=off"]
 
 
-def _deps_mtime() -> float:
-    m = 0.0
-    for d in (CSRC, os.path.join(ROOT, "include")):
-        for f in os.listdir(d):
-            if f.endswith((".hip", ".cpp", ".hpp", ".h")):
-                m = max(m, os.path.getmtime(os.path.join(d, f)))
-    return max(m, os.path.getmtime(os.path.abspath(__file__)))
+def _stale(src: str, obj: str) -> bool:
+    """True when obj is older than the source, this script, or any header its depfile (-MD) names."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep) or os.path.getmtime(os.path.abspath(__file__)) > t:
+        return True
+    try:
+        txt = open(dep).read().replace("\\\n", " ")
+    except OSError:
+        return True
+    files = txt.split(":", 1)[1].split() if ":" in txt else []
+    for f in [os.path.join(CSRC, src), *files]:
+        if not f.startswith(("/opt/", "/usr/")) and (not os.path.exists(f) or os.path.getmtime(f) > t):
+            return True
+    return False
 
 
-def _compile(src: str) -> str:
+def _compile(src: str, force: bool = False) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
+    if not force and not _stale(src, obj):
+        return obj
+    dep = ["-MD", "-MF", obj[:-2] + ".d"]
     if src.endswith(".hip"):
-        cmd = [HIPCC, *COMMON, *HIPFLAGS, "-c", path, "-o", obj]
+        cmd = [HIPCC, *COMMON, *HIPFLAGS, *dep, "-c", path, "-o", obj]
     else:
-        cmd = [HIPCC, *COMMON, *HOSTFLAGS, "-x", "c++", "-c", path, "-o", obj]
+        cmd = [HIPCC, *COMMON, *HOSTFLAGS, *dep, "-x", "c++", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"compile failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
@@ -73,11 +87,13 @@ def _compile(src: str) -> str:
 
 def build(force: bool = False, jobs: int | None = None) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
-        return LIB
     jobs = jobs or min(len(SOURCES), os.cpu_count() or 4)
+    before = {s: os.path.getmtime(os.path.join(OBJ, os.path.splitext(s)[0] + ".o")) if os.path.exists(os.path.join(OBJ, os.path.splitext(s)[0] + ".o")) else 0 for s in SOURCES}
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    changed = any(os.path.getmtime(o) != before[s] for s, o in zip(SOURCES, objs))
+    if not changed and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
+        return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -53,8 +53,9 @@ pvs_status use_device(int32_t device, int *resolved) {
     return PVS_OK;
 }
 
-void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows) {
+void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipStream_t on) {
     if (!ix->profiling) return;
+    hipStream_t st = on ? on : c.stream;
     TimedSpan t;
     if (!c.span_pool.empty()) {
         t = c.span_pool.back();
@@ -64,12 +65,12 @@ void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows) {
     }
     t.kind = kind;
     t.rows = rows;
-    (void)hipEventRecord(t.a, c.stream);
+    (void)hipEventRecord(t.a, st);
     c.spans.push_back(t);
 }
-void span_end(pvs_index *ix, SearchCtx &c) {
+void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on) {
     if (!ix->profiling || c.spans.empty()) return;
-    (void)hipEventRecord(c.spans.back().b, c.stream);
+    (void)hipEventRecord(c.spans.back().b, on ? on : c.stream);
 }
 // after the stream drained
 void spans_collect(pvs_index *ix, SearchCtx &c) {
@@ -85,9 +86,12 @@ void spans_collect(pvs_index *ix, SearchCtx &c) {
                 ix->prof.scan_launches++;
                 ix->prof.scan_ms += ms;
                 ix->prof.scan_rows += t.rows;
-            } else {
+            } else if (t.kind == 2) {
                 ix->prof.finalize_launches++;
                 ix->prof.finalize_ms += ms;
+            } else {
+                ix->prof.exchange_launches++;
+                ix->prof.exchange_ms += ms;
             }
         }
         c.span_pool.push_back(t);
@@ -95,7 +99,7 @@ void spans_collect(pvs_index *ix, SearchCtx &c) {
     c.spans.clear();
 }
 
-static void ctx_release(SearchCtx &c) {
+void ctx_release(SearchCtx &c) {
     for (auto &t : c.spans) c.span_pool.push_back(t);
     for (auto &t : c.span_pool) {
         hipEventDestroy(t.a);
@@ -121,6 +125,7 @@ static void ctx_release(SearchCtx &c) {
     hipFree(c.d_out_dist);
     hipFree(c.d_out_count);
     pvs_dense_release(c.dense);
+    pvs_group_work_release(c.gwork);
     if (c.done) hipEventDestroy(c.done);
     hipFree(c.d_loc_ids);
     hipFree(c.d_all_ids);
@@ -190,11 +195,14 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows);
 
 PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **out) {
     if (!desc || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
-    if (desc->struct_size < sizeof(pvs_index_desc)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_index_desc.struct_size too small");
+    constexpr size_t V1_SIZE = offsetof(pvs_index_desc, n_devices);  // ABI v1: the fields up to id_base
+    if (desc->struct_size < V1_SIZE) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_index_desc.struct_size too small");
+    if (desc->struct_size >= sizeof(pvs_index_desc) && desc->n_devices > 1) return multi_create(desc, out);
     if (desc->dtype > PVS_I8) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown dtype %u", desc->dtype);
     if (desc->dim == 0 || desc->dim > 16384) return pvs_fail(PVS_ERR_INVALID_ARG, "dim %u out of range [1, 16384]", desc->dim);
     int dev = 0;
-    PVS_TRY(use_device(desc->device, &dev));
+    const int32_t want_dev = (desc->struct_size >= sizeof(pvs_index_desc) && desc->n_devices == 1 && desc->devices) ? desc->devices[0] : desc->device;
+    PVS_TRY(use_device(want_dev, &dev));
     pvs_index *ix = new (std::nothrow) pvs_index();
     if (!ix) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
     ix->device = dev;
@@ -278,6 +286,7 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
 
 PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     if (!ix) return;
+    if (is_multi(ix)) return multi_destroy(ix);
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     for (auto &c : ix->ctx) ctx_release(c);
@@ -288,17 +297,16 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
-    pvs_group_work_release(ix->gwork);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
     delete ix;
 }
 
-static pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, int64_t *last) {
+pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, int64_t *last, int64_t implicit_id0) {
     int64_t prev = ix->last_id;
     if (!row_ids) {
-        int64_t first = ix->id_base + (int64_t)ix->n;
+        int64_t first = implicit_id0 != INT64_MIN ? implicit_id0 : ix->id_base + (int64_t)ix->n;
         if (ix->n && first <= prev) return pvs_fail(PVS_ERR_INVALID_ARG, "implicit row ids would not be increasing");
         *last = first + (int64_t)n - 1;
         return PVS_OK;
@@ -315,7 +323,7 @@ static pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, i
 
 // rows_dev: [n][dim] dense device array of src_dtype (f32 when converting)
 static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool from_f32, uint64_t n, const int64_t *row_ids,
-                                     const int64_t *group_ids, int64_t last_id) {
+                                     const int64_t *group_ids, int64_t last_id, int64_t implicit_first) {
     if (ix->n + n > ix->cap) PVS_TRY(pvs_index_reserve_(ix, std::max<uint64_t>(ix->n + n, ix->cap * 2)));
     hipStream_t s = ix->admin_stream;
     const int mode = (from_f32 && ix->dtype == PVS_I8) ? 0 : (from_f32 && ix->dtype == PVS_F16) ? 1 : 2;
@@ -324,7 +332,7 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
     if (row_ids)
         HIP_TRY(hipMemcpyAsync(ix->d_ids + ix->n, row_ids, n * 8, hipMemcpyHostToDevice, s));
     else
-        HIP_TRY(pvs_launch_iota_ids(ix->d_ids + ix->n, n, ix->id_base + (int64_t)ix->n, s));
+        HIP_TRY(pvs_launch_iota_ids(ix->d_ids + ix->n, n, implicit_first, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (group_ids) {
         if (ix->h_groups.size() != ix->n) ix->h_groups.resize(ix->n, -1);
@@ -338,19 +346,21 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
     return PVS_OK;
 }
 
-static pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids,
-                           const int64_t *group_ids, pvs_space space) {
+pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
+                    pvs_space space, int64_t implicit_id0) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     if (n == 0) return PVS_OK;
     if (!rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null rows");
+    if (is_multi(ix)) return multi_add(ix, rows, from_f32, n, row_ids, group_ids, space);
     std::lock_guard<std::mutex> lk(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set)
         return pvs_fail(PVS_ERR_STATE, "int8 index has no scale artifact: set it before adding f32 rows");
     int64_t last = 0;
-    PVS_TRY(check_ids(ix, row_ids, n, &last));
+    PVS_TRY(check_ids(ix, row_ids, n, &last, implicit_id0));
     const size_t src_esz = from_f32 ? 4 : ix->esz;
-    if (space == PVS_DEVICE) return append_device_rows(ix, rows, from_f32, n, row_ids, group_ids, last);
+    const int64_t first_implicit = implicit_id0 != INT64_MIN ? implicit_id0 : ix->id_base + (int64_t)ix->n;
+    if (space == PVS_DEVICE) return append_device_rows(ix, rows, from_f32, n, row_ids, group_ids, last, first_implicit);
     // host rows: stage through HBM in chunks of <= 256 MiB
     const uint64_t row_bytes = (uint64_t)ix->dim * src_esz;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
@@ -365,9 +375,9 @@ static pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint6
             st = pvs_fail(PVS_ERR_DEVICE, "hipMemcpy H2D: %s", hipGetErrorString(e));
             break;
         }
-        int64_t chunk_last = row_ids ? row_ids[off + m - 1] : ix->id_base + (int64_t)(ix->n + m) - 1;
+        int64_t chunk_last = row_ids ? row_ids[off + m - 1] : first_implicit + (int64_t)(off + m) - 1;
         st = append_device_rows(ix, stage, from_f32, m, row_ids ? row_ids + off : nullptr, group_ids ? group_ids + off : nullptr,
-                                chunk_last);
+                                chunk_last, first_implicit + (int64_t)off);
     }
     hipFree(stage);
     return st;
@@ -387,6 +397,7 @@ PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
     if (ix->dtype != PVS_I8) return pvs_fail(PVS_ERR_INVALID_ARG, "only int8 indexes carry a scale artifact");
     // artifact_scale (db/vector_quants.rs:1456-1460): finite and > 0, nothing else
     if (!(std::isfinite(scale) && scale > 0.0f)) return pvs_fail(PVS_ERR_INVALID_ARG, "unusable scale artifact");
+    if (is_multi(ix)) return multi_set_scale(ix, scale);
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->n && ix->scale_set && ix->scale != scale)
         return pvs_fail(PVS_ERR_STATE, "scale is frozen once rows exist (artifact_rev semantics): rebuild the index");
@@ -403,18 +414,21 @@ PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t 
 PVS_EXPORT pvs_status pvs_index_set_streams(pvs_index *ix, uint32_t n_streams) {
     if (!ix || n_streams == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "bad stream count");
     PVS_TRY(pvs_sync(ix));
+    for (pvs_index *sh : ix->shards) sh->multi_stream = n_streams > 1;
     ix->multi_stream = n_streams > 1;
     return PVS_OK;
 }
 
 PVS_EXPORT pvs_status pvs_index_set_path(pvs_index *ix, uint32_t path) {
     if (!ix || path > 2) return pvs_fail(PVS_ERR_INVALID_ARG, "bad path selector");
+    for (pvs_index *sh : ix->shards) sh->forced_path = path;
     ix->forced_path = path;
     return PVS_OK;
 }
 
 PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (is_multi(ix)) return multi_stats(ix, out);
     pvs_stats s;
     memset(&s, 0, sizeof s);
     s.struct_size = sizeof s;
@@ -453,6 +467,7 @@ PVS_EXPORT pvs_status pvs_device_synchronize(int32_t device) {
 
 PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
     if (!ix || (n && !out_row_ids)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (is_multi(ix)) return multi_read_ids(ix, row0, n, out_row_ids, out_group_ids);
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);
     if (n == 0) return PVS_OK;
@@ -472,6 +487,7 @@ PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t 
 
 PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
     if (!ix || (n && !out_host)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (is_multi(ix)) return multi_read_rows(ix, row0, n, out_host);
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);
     if (n == 0) return PVS_OK;
@@ -496,11 +512,31 @@ PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t
 
 PVS_EXPORT pvs_status pvs_index_set_profiling(pvs_index *ix, int32_t enable) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    for (pvs_index *sh : ix->shards) sh->profiling = enable != 0;
     ix->profiling = enable != 0;
     return PVS_OK;
 }
 PVS_EXPORT pvs_status pvs_index_get_profile(pvs_index *ix, pvs_profile *out, int32_t reset) {
     if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (is_multi(ix)) {  // sums over the shards: launches / ms stay per-device averages
+        pvs_profile tot{};
+        for (pvs_index *sh : ix->shards) {
+            pvs_profile p;
+            PVS_TRY(pvs_index_get_profile(sh, &p, reset));
+            tot.scan_launches += p.scan_launches;
+            tot.scan_ms += p.scan_ms;
+            tot.scan_rows += p.scan_rows;
+            tot.sample_launches += p.sample_launches;
+            tot.sample_ms += p.sample_ms;
+            tot.finalize_launches += p.finalize_launches;
+            tot.finalize_ms += p.finalize_ms;
+            tot.exchange_launches += p.exchange_launches;
+            tot.exchange_ms += p.exchange_ms;
+        }
+        tot.struct_size = sizeof(pvs_profile);
+        *out = tot;
+        return PVS_OK;
+    }
     std::lock_guard<std::mutex> lk(ix->prof_mu);
     *out = ix->prof;
     out->struct_size = sizeof(pvs_profile);

@@ -4,9 +4,8 @@
 // only collective.  The payload is tiny (batch*k*16 B per rank, <= 410 KB at 256x100), so
 // the step is latency-bound, not the per-link 153 GB/s ring bound.
 //
-// RCCL is bound at run time with dlopen so that (a) libpvs.so loads on machines
-// without RCCL and (b) a host process that already carries an RCCL (e.g. a PyTorch
-// build) shares that one copy instead of initialising a second.
+// RCCL is bound at run time with dlopen so that libpvs.so loads on machines without RCCL
+// (single-GPU hosts never touch it).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -29,10 +28,14 @@ std::mutex g_rccl_mu;
 pvs_status load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return PVS_OK;
-    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // ROCm's own RCCL first, by absolute path: a host process that imported PyTorch carries torch/lib/librccl.so
+    // (another version), and a bare soname would resolve to that copy while libpvs runs on ROCm's HIP runtime.
+    // PVS_RCCL_PATH overrides.
+    const char *names[] = {getenv("PVS_RCCL_PATH"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void *h = nullptr;
     for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (h) break;
     }
     if (!h) return pvs_fail(PVS_ERR_COMM, "cannot load RCCL: %s", dlerror());

@@ -40,11 +40,10 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
     const uint32_t g = (uint32_t)(gid / ncol_out), q = (uint32_t)(gid % ncol_out);
     Kbn sum, wsum;
     double mn = __builtin_inf(), mx = -__builtin_inf();
-    uint64_t cnt = 0, considered = 0;
+    uint64_t cnt = 0, joined = 0;  // joined: (row, target) pairs that are part of the join at all
     for (uint32_t e = grp_off[g]; e < grp_off[g + 1]; e++) {
         const uint32_t row = grp_rows[e];
         if (exclude && (uint32_t)(exclude[row] != 0) == skip_when) continue;  // similar_to: flagged rows; candidate mask: rows it leaves out
-        considered++;
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
             double w = 1.0;
@@ -52,6 +51,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
                 const uint8_t km = fw.kind[fw.trows[c]], ko = fw.kind[row];
                 if ((fw.skip_i2i && km == 0 && ko == 0) || (fw.skip_t2t && km == 1 && ko == 1)) continue;
             }
+            joined++;
             if (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)) {
                 const uint32_t t = fw.trows[c];
                 if (fw.cw != 0.0) w = pow(coalesce1(fw.conf[t]) * coalesce1(fw.conf[row]), fw.cw);
@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         }
     }
     double v;
-    if (considered == 0 && skip_when == 0)
-        v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);  // no candidate row at all: the group is not part of the result
+    if (joined == 0)
+        // no candidate row under the mask / every pair of the similar_to join excluded or gated away (INNER JOIN +
+        // WHERE, item_similarity.rs:445-489): the group is not part of the result at all
+        v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);
     else if (cnt == 0)
         v = __builtin_nan("");
     else if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)))

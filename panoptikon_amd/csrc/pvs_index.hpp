@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 
 #include "pvs_kernels.hpp"
 
@@ -15,7 +16,7 @@ struct PendingChunk {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;  // 0 = sample scan, 1 = full scan, 2 = finalize
+    int kind;  // 0 = sample scan, 1 = full scan, 2 = finalize, 3 = exchange (all-gather + merge)
     uint64_t rows;
 };
 
@@ -51,6 +52,7 @@ struct SearchCtx {
     uint64_t out_cap = 0;  // elements (batch*k)
     uint32_t out_batch_cap = 0;
     DenseWork dense;
+    GroupWork gwork;              // per-context sort scratch of pvs_group_rank (searches in flight never share it)
     // deferred fallback bookkeeping (device variant)
     bool pending = false;
     const void *p_queries = nullptr;
@@ -65,7 +67,8 @@ struct SearchCtx {
     int64_t *d_loc_ids = nullptr, *d_all_ids = nullptr;
     float *d_loc_dist = nullptr, *d_all_dist = nullptr;
     uint32_t *d_loc_cnt = nullptr, *d_all_cnt = nullptr, *d_all_flags = nullptr, *h_all_flags = nullptr;
-    uint64_t sh_elems = 0;
+    uint64_t sh_elems = 0, loc_elems = 0;
+    uint32_t loc_batch = 0;
     uint32_t sh_batch = 0, sh_world = 0;
     int64_t *p_final_ids = nullptr;
     float *p_final_dist = nullptr;
@@ -80,9 +83,50 @@ pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *
                                   uint32_t batch, hipStream_t s);
 
 constexpr uint32_t GMAX = 16384;  // group minima per query (pass A grid * RT * 32 <= GMAX)
-constexpr uint32_t NCTX = 4;
+constexpr uint32_t NCTX = 16;  // searches in flight per index = the reference's read pool (db/connection.rs:235)
+
+// ---- one host process, several GPUs (pvs_multi.hip): a multi-device index owns one single-device index per
+// shard; a MultiCtx is one search in flight across all of them
+struct MultiCtx {
+    bool busy = false, pending = false;
+    hipStream_t stream = nullptr;  // on the root device (devices[0]): merge + result copies
+    hipEvent_t done = nullptr;
+    int64_t *d_all_ids = nullptr;  // root-side gather buffers [shards][batch][k]
+    float *d_all_dist = nullptr;
+    uint32_t *d_all_cnt = nullptr;
+    uint64_t elems_cap = 0;
+    uint32_t batch_cap = 0;
+    std::vector<uint32_t> tickets;       // the shard contexts this search holds
+    std::vector<void *> d_q;             // per shard: the queries copied to the shard's device (null on the root device)
+    std::vector<size_t> q_cap;
+    // host-buffer entry point staging (root device)
+    void *d_qroot = nullptr;
+    size_t qroot_cap = 0;
+    int64_t *d_out_ids = nullptr;
+    float *d_out_dist = nullptr;
+    uint32_t *d_out_cnt = nullptr;
+    uint64_t out_cap = 0;
+    uint32_t out_batch_cap = 0;
+    // the search in flight
+    const void *p_queries = nullptr;
+    int p_qdtype = 0, p_metric = 0;
+    uint32_t p_batch = 0, p_k = 0;
+    int64_t *p_out_ids = nullptr;
+    float *p_out_dist = nullptr;
+    uint32_t *p_out_count = nullptr;
+    std::vector<uint8_t> p_fast;
+};
+struct MultiSegment {
+    uint64_t row0, n;   // global rows [row0, row0 + n) ...
+    uint32_t shard;
+    uint64_t local0;    // ... are rows [local0, local0 + n) of this shard
+};
 
 struct pvs_index {
+    // multi-device index: shards non-empty, everything below `device` unused except the counters and mu
+    std::vector<pvs_index *> shards;
+    std::vector<MultiSegment> segs;
+    MultiCtx mctx[NCTX];
     int device = 0;
     uint32_t dtype = 0, dim = 0, esz = 0, stride = 0;
     uint64_t n = 0, cap = 0;
@@ -98,12 +142,12 @@ struct pvs_index {
     uint32_t n_groups = 0;
     uint32_t *d_grp_off = nullptr, *d_grp_rows = nullptr;
     int64_t *d_grp_ids = nullptr;
-    GroupWork gwork;
     float scale = 0.f;
     bool scale_set = false;
     uint32_t forced_path = 0;
     int n_cu = 256;
     std::mutex mu;
+    std::condition_variable ctx_cv;  // signalled when a context is released
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
     hipStream_t search_stream = nullptr;
@@ -116,23 +160,57 @@ struct pvs_index {
 };
 
 
+inline bool is_multi(const pvs_index *ix) { return !ix->shards.empty(); }
+
 // ---- pvs_api.hip
 pvs_status use_device(int32_t device, int *resolved);
-void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows);
-void span_end(pvs_index *ix, SearchCtx &c);
+// implicit_id0: first row id when row_ids == NULL (INT64_MIN: id_base + row index, the public behaviour)
+pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
+                    pvs_space space, int64_t implicit_id0 = INT64_MIN);
+pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, int64_t *last, int64_t implicit_id0 = INT64_MIN);
+void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipStream_t on = nullptr);
+void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on = nullptr);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
+void ctx_release(SearchCtx &c);
 // ---- pvs_search.hip
 pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric);
 bool fast_path_ok(const pvs_index *ix, uint32_t k);
 pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb, uint32_t batch_pad,
                       int metric);
-SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket);
+// block == false: returns nullptr (and sets the error) when every context is taken
+SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket, bool block = true);
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                        const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 void ctx_done(pvs_index *ix, SearchCtx *c);
+pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
+                          int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast);
+pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
+                            int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+pvs_status ctx_reserve_local_pages(SearchCtx &c, uint64_t elems, uint32_t batch);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
+pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                              double *out_values, uint32_t *out_count);
+// ---- pvs_multi.hip (entry points of a multi-device index; the public functions dispatch here when is_multi())
+pvs_status multi_create(const pvs_index_desc *desc, pvs_index **out);
+void multi_destroy(pvs_index *ix);
+pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
+                     pvs_space space);
+pvs_status multi_set_scale(pvs_index *ix, float scale);
+pvs_status multi_stats(pvs_index *ix, pvs_stats *out);
+pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host);
+pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids);
+pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                             int64_t *out_ids, float *out_dist, uint32_t *out_count);
+pvs_status multi_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, uint32_t *out_ticket);
+pvs_status multi_wait(pvs_index *ix, uint32_t ticket);
+pvs_status multi_sync(pvs_index *ix);
+pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist, pvs_space out_space);
+pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count);
 // ---- pvs_comm.hip
 pvs_status pvs_comm_gather_group_pages_(pvs_comm *c, const int64_t *groups, const double *values, const uint32_t *cnt, int64_t *all_groups,
                                         double *all_values, uint32_t *all_cnt, uint64_t elems, uint32_t batch, hipStream_t s);

@@ -97,6 +97,7 @@ static uint32_t dense_chunk_queries(const pvs_index *ix, uint32_t batch) {
 
 PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric,
                                       float *out_dist, pvs_space out_space) {
+    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_score_batch is not served on a multi-device index (pvs_score_all is)");
     PVS_TRY(validate_search(ix, queries, qdtype, batch, 1, metric));
     if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0 || ix->n == 0) return PVS_OK;
@@ -148,7 +149,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
                                            c.stream, fw, skip_when));
         for (uint32_t q = 0; q < ncol; q++) {
-            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, ix->gwork, d_og, d_ov, d_oc, c.stream));
+            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, c.gwork, d_og, d_ov, d_oc, c.stream));
             HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(out_values + (size_t)q * k, d_ov, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(out_count + q, d_oc, 4, hipMemcpyDeviceToHost, c.stream));
@@ -253,10 +254,6 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     }
 }
 
-static pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                                     pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
-                                     double *out_values, uint32_t *out_count);
-
 PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                         double *out_values, uint32_t *out_count) {
@@ -271,9 +268,13 @@ PVS_EXPORT pvs_status pvs_search_groups_filtered(pvs_index *ix, const void *quer
                               out_count);
 }
 
-static pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                                     pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
-                                     double *out_values, uint32_t *out_count) {
+pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                              pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                              double *out_values, uint32_t *out_count) {
+    if (ix && is_multi(ix)) {
+        if (mask) return pvs_fail(PVS_ERR_UNSUPPORTED, "candidate masks are not served on a multi-device index");
+        return multi_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, out_groups, out_values, out_count);
+    }
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (!row_weights && agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG)
@@ -342,13 +343,20 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
                                                 uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                                 double *out_values, uint32_t *out_count) {
     if (!comm) return pvs_fail(PVS_ERR_INVALID_ARG, "null communicator");
+    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "a multi-device index shards inside one process: use pvs_search_groups");
     if (ix && pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
-    // 1. this shard's page (every rank must take part in the exchange below, whatever its shard holds)
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (batch == 0) return PVS_OK;
+    // 1. this shard's page.  Every rank must take part in the exchange below whatever happened locally: a rank
+    // that returned early would leave the others inside the all-gather.  A local failure travels as a count of
+    // PVS_PAGE_FAILED and every rank fails after the exchange.
+    constexpr uint32_t PVS_PAGE_FAILED = 0xffffffffu;
     std::vector<int64_t> lg((size_t)batch * k, -1);
     std::vector<double> lv((size_t)batch * k, __builtin_nan(""));
     std::vector<uint32_t> lc(batch, 0);
-    PVS_TRY(pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, lg.data(), lv.data(), lc.data()));
-    if (batch == 0) return PVS_OK;
+    const pvs_status local_st = pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, lg.data(), lv.data(), lc.data());
+    const std::string local_err = local_st == PVS_OK ? std::string() : std::string(pvs_last_error());
+    if (local_st != PVS_OK) std::fill(lc.begin(), lc.end(), PVS_PAGE_FAILED);
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t world = (uint32_t)pvs_comm_world_(comm);
     const uint64_t elems = (uint64_t)batch * k;
@@ -375,6 +383,9 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         HIP_TRY(hipMemcpyAsync(av.data(), d_av, av.size() * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ac.data(), d_ac, ac.size() * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (local_st != PVS_OK) return pvs_fail(local_st, "%s", local_err.c_str());
+        for (uint32_t w = 0; w < world; w++)
+            if (ac[(size_t)w * batch] == PVS_PAGE_FAILED) return pvs_fail(PVS_ERR_COMM, "rank %u failed its shard of the per-item search", w);
         // 3. merge on every rank (tiny: world * k entries per query)
         return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
     };
@@ -476,6 +487,7 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
                                   uint32_t *out_count) {
     if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to needs every row of a group on one device: not served on a multi-device index");
     if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
     if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
     if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");

@@ -1,0 +1,588 @@
+// pvs_multi.hip — one host process, several GPUs (pvs_index_desc.n_devices > 1).
+//
+// The reference host is ONE process with a pool of read connections (db/connection.rs:235,320-357), so the natural
+// drop-in is one index object that owns every GPU of the node: the rows shard across the devices, a search fans
+// out to all shards from the calling thread (every enqueue is asynchronous, the shards scan concurrently), each
+// shard's page travels to devices[0] with peer copies over xGMI (hipMemcpyPeerAsync: <= 0.31 MB per shard at
+// 256 x 100, latency-bound like the RCCL all-gather of the one-process-per-GPU form in pvs_comm.hip) and the same
+// k_merge kernel merges them there.  Stream-ordered end to end: the root stream waits on one event per shard, no
+// host synchronisation until pvs_wait.  Exactness is the single-device argument per shard plus the merge under
+// the shared (distance, id) order; shards hold disjoint ids.
+//
+// Sharding rule: every pvs_index_add call splits its rows into n_devices contiguous pieces.  Row ids stay strictly
+// increasing inside every shard (all a shard needs); global "row order" (pvs_index_read_rows / read_ids /
+// pvs_score_all) is the order of the add calls, kept as a segment table.
+#include <thread>
+
+#include "pvs_index.hpp"
+
+namespace {
+int root_device(const pvs_index *ix) { return ix->shards[0]->device; }
+
+void mctx_release(MultiCtx &m) {
+    hipFree(m.d_all_ids);
+    hipFree(m.d_all_dist);
+    hipFree(m.d_all_cnt);
+    hipFree(m.d_qroot);
+    hipFree(m.d_out_ids);
+    hipFree(m.d_out_dist);
+    hipFree(m.d_out_cnt);
+    if (m.done) hipEventDestroy(m.done);
+    if (m.stream) hipStreamDestroy(m.stream);
+}
+
+MultiCtx *mctx_acquire(pvs_index *ix, uint32_t *ticket, bool block) {
+    std::unique_lock<std::mutex> lk(ix->mu);
+    for (;;) {
+        for (uint32_t i = 0; i < NCTX; i++)
+            if (!ix->mctx[i].busy) {
+                ix->mctx[i].busy = true;
+                *ticket = i;
+                return &ix->mctx[i];
+            }
+        if (!block) {
+            pvs_fail(PVS_ERR_STATE, "too many searches in flight on this index (limit %u): pvs_wait() one first", NCTX);
+            return nullptr;
+        }
+        ix->ctx_cv.wait(lk);
+    }
+}
+void mctx_done(pvs_index *ix, MultiCtx *m) {
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        m->pending = false;
+        m->busy = false;
+    }
+    ix->ctx_cv.notify_one();
+}
+
+// the shard contexts a multi search holds are released together with it
+void release_shard_ctxs(pvs_index *ix, MultiCtx &m) {
+    for (size_t s = 0; s < m.tickets.size(); s++) ctx_done(ix->shards[s], &ix->shards[s]->ctx[m.tickets[s]]);
+    m.tickets.clear();
+}
+
+pvs_status mctx_prepare(pvs_index *ix, MultiCtx &m, uint32_t batch, uint32_t k) {
+    const uint32_t S = (uint32_t)ix->shards.size();
+    HIP_TRY(hipSetDevice(root_device(ix)));
+    if (!m.stream) HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+    const uint64_t elems = (uint64_t)batch * k;
+    if (elems > m.elems_cap || batch > m.batch_cap) {
+        hipFree(m.d_all_ids);
+        hipFree(m.d_all_dist);
+        hipFree(m.d_all_cnt);
+        m.d_all_ids = nullptr;
+        m.d_all_dist = nullptr;
+        m.d_all_cnt = nullptr;
+        m.elems_cap = 0;
+        m.batch_cap = 0;
+        HIP_TRY(hipMalloc((void **)&m.d_all_ids, elems * 8 * S));
+        HIP_TRY(hipMalloc((void **)&m.d_all_dist, elems * 4 * S));
+        HIP_TRY(hipMalloc((void **)&m.d_all_cnt, (size_t)batch * 4 * S));
+        m.elems_cap = elems;
+        m.batch_cap = batch;
+    }
+    m.d_q.resize(S, nullptr);
+    m.q_cap.resize(S, 0);
+    return PVS_OK;
+}
+
+// shard s's page -> its slot of the root's gather buffers, on the shard's stream
+pvs_status ship_page(pvs_index *ix, MultiCtx &m, uint32_t s, SearchCtx &c, uint32_t batch, uint32_t k) {
+    pvs_index *sh = ix->shards[s];
+    const int root = root_device(ix);
+    const uint64_t elems = (uint64_t)batch * k;
+    HIP_TRY(hipMemcpyPeerAsync(m.d_all_ids + s * elems, root, c.d_loc_ids, sh->device, elems * 8, c.stream));
+    HIP_TRY(hipMemcpyPeerAsync(m.d_all_dist + s * elems, root, c.d_loc_dist, sh->device, elems * 4, c.stream));
+    HIP_TRY(hipMemcpyPeerAsync(m.d_all_cnt + (size_t)s * batch, root, c.d_loc_cnt, sh->device, (size_t)batch * 4, c.stream));
+    return PVS_OK;
+}
+
+// Enqueues one search over every shard plus the gather and the merge; outputs on the root device.
+pvs_status multi_enqueue(pvs_index *ix, MultiCtx &m, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
+                         pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const int root = root_device(ix);
+    const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4) * batch;
+    m.p_fast.assign(S, 0);
+    m.tickets.clear();
+    for (uint32_t s = 0; s < S; s++) {
+        pvs_index *sh = ix->shards[s];
+        HIP_TRY(hipSetDevice(sh->device));
+        uint32_t t;
+        SearchCtx *c = ctx_acquire(sh, &t, true);  // never blocks: a shard serves multi searches only, one context each
+        m.tickets.push_back(t);
+        PVS_TRY(ctx_prepare(sh, *c, batch, k, false));
+        PVS_TRY(ctx_reserve_local_pages(*c, (uint64_t)batch * k, batch));
+        const void *q_local = d_queries;
+        if (sh->device != root) {  // replicate the queries on the shard's device (<= 0.8 MB at 256 x 768 f32)
+            if (qbytes > m.q_cap[s]) {
+                hipFree(m.d_q[s]);
+                m.d_q[s] = nullptr;
+                m.q_cap[s] = 0;
+                const size_t cap = pvs_round_up(qbytes, 1 << 16);
+                HIP_TRY(hipMalloc(&m.d_q[s], cap));
+                m.q_cap[s] = cap;
+            }
+            HIP_TRY(hipMemcpyPeerAsync(m.d_q[s], sh->device, d_queries, root, qbytes, c->stream));
+            q_local = m.d_q[s];
+        }
+        bool fast = false;
+        PVS_TRY(search_enqueue(sh, *c, q_local, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &fast));
+        m.p_fast[s] = fast;
+        c->p_queries = q_local;
+        PVS_TRY(ship_page(ix, m, s, *c, batch, k));
+        HIP_TRY(hipEventRecord(c->done, c->stream));
+        HIP_TRY(hipSetDevice(root));
+        HIP_TRY(hipStreamWaitEvent(m.stream, c->done, 0));
+    }
+    HIP_TRY(hipSetDevice(root));
+    HIP_TRY(pvs_launch_merge(m.d_all_ids, m.d_all_dist, m.d_all_cnt, S, batch, k, d_out_ids, d_out_dist, d_out_count, m.stream));
+    HIP_TRY(hipEventRecord(m.done, m.stream));
+    m.p_queries = d_queries;
+    m.p_qdtype = qdtype;
+    m.p_metric = metric;
+    m.p_batch = batch;
+    m.p_k = k;
+    m.p_out_ids = d_out_ids;
+    m.p_out_dist = d_out_dist;
+    m.p_out_count = d_out_count;
+    return PVS_OK;
+}
+
+// After the merge drained: shards that handed queries to the dense path answer them, re-ship, and the root merges again.
+pvs_status multi_complete(pvs_index *ix, MultiCtx &m) {
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const int root = root_device(ix);
+    HIP_TRY(hipSetDevice(root));
+    hipError_t e = hipEventSynchronize(m.done);
+    if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+    bool redo = false;
+    std::vector<uint8_t> dense_q(m.p_batch, 0);
+    for (uint32_t s = 0; s < S; s++) {
+        pvs_index *sh = ix->shards[s];
+        SearchCtx &c = sh->ctx[m.tickets[s]];
+        spans_collect(sh, c);
+        if (!m.p_fast[s] || sh->n == 0) {
+            if (sh->n) std::fill(dense_q.begin(), dense_q.end(), 1);
+            continue;
+        }
+        bool any = false;
+        for (uint32_t q = 0; q < m.p_batch; q++)
+            if (c.h_need_dense[q]) {
+                any = true;
+                dense_q[q] = 1;
+            }
+        if (!any) continue;
+        HIP_TRY(hipSetDevice(sh->device));
+        PVS_TRY(search_fallbacks(sh, c, c.p_queries, m.p_qdtype, m.p_batch, m.p_k, m.p_metric, c.d_loc_ids, c.d_loc_dist, c.d_loc_cnt));
+        PVS_TRY(ship_page(ix, m, s, c, m.p_batch, m.p_k));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        redo = true;
+    }
+    uint32_t nd = 0;
+    for (uint8_t f : dense_q) nd += f;
+    ix->dense_queries += nd;
+    ix->fast_queries += m.p_batch - nd;
+    if (redo) {
+        HIP_TRY(hipSetDevice(root));
+        HIP_TRY(pvs_launch_merge(m.d_all_ids, m.d_all_dist, m.d_all_cnt, S, m.p_batch, m.p_k, m.p_out_ids, m.p_out_dist, m.p_out_count,
+                                 m.stream));
+        HIP_TRY(hipStreamSynchronize(m.stream));
+    }
+    return PVS_OK;
+}
+
+struct SegRange {
+    uint32_t shard;
+    uint64_t local0, n, out_off;  // out_off: offset (rows) inside the caller's range
+};
+// the pieces of global rows [row0, row0 + n)
+std::vector<SegRange> locate(const pvs_index *ix, uint64_t row0, uint64_t n) {
+    std::vector<SegRange> out;
+    auto it = std::upper_bound(ix->segs.begin(), ix->segs.end(), row0, [](uint64_t r, const MultiSegment &g) { return r < g.row0; });
+    if (it != ix->segs.begin()) --it;
+    for (; it != ix->segs.end() && it->row0 < row0 + n; ++it) {
+        const uint64_t a = std::max(row0, it->row0), b = std::min(row0 + n, it->row0 + it->n);
+        if (a < b) out.push_back({it->shard, it->local0 + (a - it->row0), b - a, a - row0});
+    }
+    return out;
+}
+}  // namespace
+
+pvs_status multi_create(const pvs_index_desc *desc, pvs_index **out) {
+    if (desc->n_devices > PVS_MAX_DEVICES) return pvs_fail(PVS_ERR_INVALID_ARG, "at most %d devices per index", PVS_MAX_DEVICES);
+    if (!desc->devices) return pvs_fail(PVS_ERR_INVALID_ARG, "n_devices > 1 needs the device list");
+    pvs_index *ix = new (std::nothrow) pvs_index();
+    if (!ix) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
+    ix->dtype = desc->dtype;
+    ix->dim = desc->dim;
+    ix->id_base = desc->id_base;
+    const uint32_t S = desc->n_devices;
+    for (uint32_t s = 0; s < S; s++) {
+        pvs_index_desc d1;
+        memset(&d1, 0, sizeof d1);
+        d1.struct_size = sizeof d1;
+        d1.device = desc->devices[s];
+        d1.dtype = desc->dtype;
+        d1.dim = desc->dim;
+        d1.capacity_rows = (desc->capacity_rows + S - 1) / S;
+        d1.id_base = desc->id_base;
+        if (d1.device < 0) {
+            multi_destroy(ix);
+            return pvs_fail(PVS_ERR_INVALID_ARG, "devices[%u] must be an explicit ordinal", s);
+        }
+        pvs_index *sh = nullptr;
+        pvs_status st = pvs_index_create(&d1, &sh);
+        if (st != PVS_OK) {
+            multi_destroy(ix);
+            return st;
+        }
+        ix->shards.push_back(sh);
+    }
+    ix->esz = ix->shards[0]->esz;
+    ix->stride = ix->shards[0]->stride;
+    ix->device = ix->shards[0]->device;
+    // direct xGMI peer copies between the root and every other shard's device (without peer access the runtime
+    // stages hipMemcpyPeerAsync through host memory: still correct)
+    const int root = root_device(ix);
+    for (uint32_t s = 1; s < S; s++) {
+        const int dev = ix->shards[s]->device;
+        if (dev == root) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, root, dev) == hipSuccess && can) {
+            (void)hipSetDevice(root);
+            (void)hipDeviceEnablePeerAccess(dev, 0);
+            (void)hipSetDevice(dev);
+            (void)hipDeviceEnablePeerAccess(root, 0);
+        }
+        (void)hipGetLastError();  // "already enabled" is fine
+    }
+    (void)hipSetDevice(root);
+    *out = ix;
+    return PVS_OK;
+}
+
+void multi_destroy(pvs_index *ix) {
+    if (!ix->shards.empty()) {
+        (void)multi_sync(ix);
+        (void)hipSetDevice(root_device(ix));
+        (void)hipDeviceSynchronize();
+    }
+    for (auto &m : ix->mctx) {
+        for (size_t s = 0; s < m.d_q.size(); s++)
+            if (m.d_q[s]) {
+                (void)hipSetDevice(ix->shards[s]->device);
+                hipFree(m.d_q[s]);
+            }
+        if (!ix->shards.empty()) (void)hipSetDevice(root_device(ix));
+        mctx_release(m);
+    }
+    for (pvs_index *sh : ix->shards) pvs_index_destroy(sh);
+    ix->shards.clear();
+    delete ix;
+}
+
+pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
+                     pvs_space space) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    const uint32_t S = (uint32_t)ix->shards.size();
+    if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set)
+        return pvs_fail(PVS_ERR_STATE, "int8 index has no scale artifact: set it before adding f32 rows");
+    int64_t last = 0;
+    PVS_TRY(check_ids(ix, row_ids, n, &last));  // increasing over the WHOLE index, like a single-device one
+    const size_t row_bytes = (size_t)ix->dim * (from_f32 ? 4 : ix->esz);
+    int src_dev = -1;
+    if (space == PVS_DEVICE) {
+        hipPointerAttribute_t at;
+        HIP_TRY(hipPointerGetAttributes(&at, rows));
+        src_dev = at.device;
+    }
+    const uint64_t base = n / S, rem = n % S;
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < S; s++) {
+        const uint64_t m = base + (s < rem ? 1 : 0);
+        if (m == 0) continue;
+        pvs_index *sh = ix->shards[s];
+        const uint8_t *piece = (const uint8_t *)rows + off * row_bytes;
+        const int64_t id0 = ix->id_base + (int64_t)(ix->n + off);
+        const uint64_t local0 = sh->n;
+        pvs_status st;
+        if (space == PVS_DEVICE && src_dev != sh->device) {
+            // rows resident on another GPU: stage the piece on the shard's device in bounded chunks
+            HIP_TRY(hipSetDevice(sh->device));
+            const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+            void *stage = nullptr;
+            HIP_TRY(hipMalloc(&stage, std::min(chunk, m) * row_bytes));
+            st = PVS_OK;
+            for (uint64_t o = 0; o < m && st == PVS_OK; o += chunk) {
+                const uint64_t mm = std::min(chunk, m - o);
+                hipError_t e = hipMemcpyPeer(stage, sh->device, piece + o * row_bytes, src_dev, mm * row_bytes);
+                if (e != hipSuccess) {
+                    st = pvs_fail(PVS_ERR_DEVICE, "hipMemcpyPeer: %s", hipGetErrorString(e));
+                    break;
+                }
+                st = add_impl(sh, stage, from_f32, mm, row_ids ? row_ids + off + o : nullptr, group_ids ? group_ids + off + o : nullptr,
+                              PVS_DEVICE, id0 + (int64_t)o);
+            }
+            (void)hipSetDevice(sh->device);
+            hipFree(stage);
+        } else {
+            st = add_impl(sh, piece, from_f32, m, row_ids ? row_ids + off : nullptr, group_ids ? group_ids + off : nullptr, space, id0);
+        }
+        if (st != PVS_OK) return st;  // rows already appended to earlier shards stay; the caller rebuilds on failure
+        ix->segs.push_back({ix->n + off, m, s, local0});
+        off += m;
+    }
+    ix->n += n;
+    ix->last_id = last;
+    return PVS_OK;
+}
+
+pvs_status multi_set_scale(pvs_index *ix, float scale) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->n && ix->scale_set && ix->scale != scale)
+        return pvs_fail(PVS_ERR_STATE, "scale is frozen once rows exist (artifact_rev semantics): rebuild the index");
+    for (pvs_index *sh : ix->shards) PVS_TRY(pvs_index_set_scale(sh, scale));
+    ix->scale = scale;
+    ix->scale_set = true;
+    return PVS_OK;
+}
+
+pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
+    pvs_stats s;
+    memset(&s, 0, sizeof s);
+    s.struct_size = sizeof s;
+    s.dtype = ix->dtype;
+    s.dim = ix->dim;
+    s.row_stride_bytes = ix->stride;
+    s.scale = ix->scale_set ? ix->scale : 0.f;
+    for (pvs_index *sh : ix->shards) {
+        pvs_stats p;
+        PVS_TRY(pvs_index_stats(sh, &p));
+        s.rows += p.rows;
+        s.capacity_rows += p.capacity_rows;
+        s.hbm_bytes += p.hbm_bytes;
+        s.last_candidates += p.last_candidates;
+    }
+    s.searches = ix->searches.load();
+    s.fast_queries = ix->fast_queries.load();
+    s.dense_queries = ix->dense_queries.load();
+    *out = s;
+    return PVS_OK;
+}
+
+pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
+    if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
+                                          (unsigned long long)(row0 + n), (unsigned long long)ix->n);
+    const size_t w = (size_t)ix->dim * ix->esz;
+    for (const SegRange &r : locate(ix, row0, n))
+        PVS_TRY(pvs_index_read_rows(ix->shards[r.shard], r.local0, r.n, (uint8_t *)out_host + r.out_off * w));
+    return PVS_OK;
+}
+
+pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
+    if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
+                                          (unsigned long long)(row0 + n), (unsigned long long)ix->n);
+    for (const SegRange &r : locate(ix, row0, n))
+        PVS_TRY(pvs_index_read_ids(ix->shards[r.shard], r.local0, r.n, out_row_ids + r.out_off, out_group_ids ? out_group_ids + r.out_off : nullptr));
+    return PVS_OK;
+}
+
+pvs_status multi_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, uint32_t *out_ticket) {
+    PVS_TRY(validate_search(ix->shards[0], d_queries, qdtype, batch, k, metric));
+    if (!d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    uint32_t t;
+    MultiCtx *m = mctx_acquire(ix, &t, false);
+    if (!m) return PVS_ERR_STATE;
+    pvs_status st = mctx_prepare(ix, *m, batch, k);
+    if (st == PVS_OK) st = multi_enqueue(ix, *m, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count);
+    if (st != PVS_OK) {
+        for (size_t s = 0; s < m->tickets.size(); s++) {
+            (void)hipSetDevice(ix->shards[s]->device);
+            (void)hipStreamSynchronize(ix->shards[s]->ctx[m->tickets[s]].stream);
+        }
+        release_shard_ctxs(ix, *m);
+        mctx_done(ix, m);
+        return st;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        m->pending = true;
+    }
+    ix->searches++;
+    *out_ticket = t;
+    return PVS_OK;
+}
+
+pvs_status multi_wait(pvs_index *ix, uint32_t ticket) {
+    MultiCtx *m = &ix->mctx[ticket];
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (!m->busy || !m->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+    }
+    pvs_status st = multi_complete(ix, *m);
+    release_shard_ctxs(ix, *m);
+    mctx_done(ix, m);
+    return st;
+}
+
+pvs_status multi_sync(pvs_index *ix) {
+    pvs_status st = PVS_OK;
+    for (uint32_t i = 0; i < NCTX; i++) {
+        bool live;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            live = ix->mctx[i].busy && ix->mctx[i].pending;
+        }
+        if (live) {
+            pvs_status s = multi_wait(ix, i);
+            if (s != PVS_OK) st = s;
+        }
+    }
+    return st;
+}
+
+pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                             int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return PVS_OK;
+    uint32_t t;
+    MultiCtx *m = mctx_acquire(ix, &t, true);
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(mctx_prepare(ix, *m, batch, k));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4) * batch;
+        if (qbytes > m->qroot_cap) {
+            hipFree(m->d_qroot);
+            m->d_qroot = nullptr;
+            m->qroot_cap = 0;
+            const size_t cap = pvs_round_up(qbytes, 1 << 16);
+            HIP_TRY(hipMalloc(&m->d_qroot, cap));
+            m->qroot_cap = cap;
+        }
+        const uint64_t need = (uint64_t)batch * k;
+        if (need > m->out_cap || batch > m->out_batch_cap) {
+            hipFree(m->d_out_ids);
+            hipFree(m->d_out_dist);
+            hipFree(m->d_out_cnt);
+            m->d_out_ids = nullptr;
+            m->d_out_dist = nullptr;
+            m->d_out_cnt = nullptr;
+            m->out_cap = 0;
+            HIP_TRY(hipMalloc((void **)&m->d_out_ids, need * 8));
+            HIP_TRY(hipMalloc((void **)&m->d_out_dist, need * 4));
+            HIP_TRY(hipMalloc((void **)&m->d_out_cnt, (size_t)batch * 4));
+            m->out_cap = need;
+            m->out_batch_cap = batch;
+        }
+        HIP_TRY(hipMemcpyAsync(m->d_qroot, queries, qbytes, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));  // the shard streams read (or peer-copy) the staged queries
+        pvs_status st = multi_enqueue(ix, *m, m->d_qroot, qdtype, batch, k, metric, m->d_out_ids, m->d_out_dist, m->d_out_cnt);
+        if (st == PVS_OK) st = multi_complete(ix, *m);
+        if (st != PVS_OK) {
+            for (size_t s = 0; s < m->tickets.size(); s++) {
+                (void)hipSetDevice(ix->shards[s]->device);
+                (void)hipStreamSynchronize(ix->shards[s]->ctx[m->tickets[s]].stream);
+            }
+            return st;
+        }
+        HIP_TRY(hipSetDevice(root_device(ix)));
+        HIP_TRY(hipMemcpyAsync(out_ids, m->d_out_ids, need * 8, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(out_dist, m->d_out_dist, need * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(out_count, m->d_out_cnt, (size_t)batch * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    release_shard_ctxs(ix, *m);
+    ix->searches++;
+    mctx_done(ix, m);
+    return st;
+}
+
+pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist, pvs_space out_space) {
+    PVS_TRY(validate_search(ix->shards[0], query, qdtype, 1, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (out_space != PVS_HOST) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_score_all on a multi-device index writes host memory only");
+    // one dense column per shard (they run one after the other: this is the build-side / SQL-seam entry point, not the hot one),
+    // scattered into global row order
+    std::vector<float> col;
+    for (uint32_t s = 0; s < ix->shards.size(); s++) {
+        pvs_index *sh = ix->shards[s];
+        if (sh->n == 0) continue;
+        col.resize(sh->n);
+        PVS_TRY(pvs_score_all(sh, query, qdtype, metric, col.data(), PVS_HOST));
+        for (const MultiSegment &g : ix->segs)
+            if (g.shard == s) memcpy(out_dist + g.row0, col.data() + g.local0, g.n * 4);
+    }
+    return PVS_OK;
+}
+
+// Per-item pages across row shards, MIN only: a group's global MIN is attained in some shard, where it is the
+// group's shard value; every other group's shard value is >= its global value, so a group of the global top-k is
+// inside the top-k of the shard that holds its best row.  Hence: per-shard top-k pages, duplicates folded to their
+// minimum, merged under (value asc, group id asc, NULL last).  (MAX / AVG need every row of a group on one device.)
+pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (agg != PVS_AGG_MIN || row_weights)
+        return pvs_fail(PVS_ERR_UNSUPPORTED, "a multi-device index serves per-item search with MIN only (MAX/AVG/weights need every row of a group on one device)");
+    if (batch == 0) return PVS_OK;
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> g(S * elems);
+    std::vector<double> v(S * elems);
+    std::vector<uint32_t> c((size_t)S * batch, 0);
+    std::vector<pvs_status> st(S, PVS_OK);
+    std::vector<std::string> err(S);
+    std::vector<std::thread> th;
+    for (uint32_t s = 0; s < S; s++)
+        th.emplace_back([&, s]() {
+            st[s] = search_groups_impl(ix->shards[s], queries, qdtype, batch, k, metric, PVS_AGG_MIN, nullptr, nullptr, PVS_HOST,
+                                       g.data() + s * elems, v.data() + s * elems, c.data() + (size_t)s * batch);
+            if (st[s] != PVS_OK) err[s] = pvs_last_error();
+        });
+    for (auto &t : th) t.join();
+    for (uint32_t s = 0; s < S; s++)
+        if (st[s] != PVS_OK) return pvs_fail(st[s], "shard %u: %s", s, err[s].c_str());
+    struct GV {
+        double v;
+        int64_t g;
+    };
+    std::vector<GV> all;
+    for (uint32_t q = 0; q < batch; q++) {
+        all.clear();
+        for (uint32_t s = 0; s < S; s++)
+            for (uint32_t i = 0; i < c[(size_t)s * batch + q]; i++) all.push_back({v[s * elems + (size_t)q * k + i], g[s * elems + (size_t)q * k + i]});
+        // fold duplicates: smallest non-NULL value of the group
+        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
+            if (a.g != b.g) return a.g < b.g;
+            const bool na = a.v != a.v, nb = b.v != b.v;
+            if (na != nb) return nb;
+            return a.v < b.v;
+        });
+        size_t w = 0;
+        for (size_t i = 0; i < all.size(); i++)
+            if (i == 0 || all[i].g != all[i - 1].g) all[w++] = all[i];
+        all.resize(w);
+        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
+            const bool na = a.v != a.v, nb = b.v != b.v;
+            if (na != nb) return nb;
+            if (!na && a.v != b.v) return a.v < b.v;
+            return a.g < b.g;
+        });
+        const uint32_t nout = (uint32_t)std::min<size_t>(k, all.size());
+        for (uint32_t i = 0; i < k; i++) {
+            out_groups[(size_t)q * k + i] = i < nout ? all[i].g : -1;
+            out_values[(size_t)q * k + i] = i < nout ? all[i].v : __builtin_nan("");
+        }
+        out_count[q] = nout;
+    }
+    ix->searches++;
+    return PVS_OK;
+}

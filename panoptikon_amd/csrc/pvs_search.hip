@@ -50,7 +50,7 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 }
 
 // Enqueues the whole search on c.stream.  Outputs are device buffers.
-static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                  int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast) {
     const bool fast = fast_path_ok(ix, k);
     *used_fast = fast;
@@ -163,7 +163,7 @@ static pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_quer
 }
 
 // After the stream drained: answer the queries the filter path handed back.
-static pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
+pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                    int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
     uint32_t n_dense = 0;
     for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
@@ -186,24 +186,32 @@ static pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_qu
     return PVS_OK;
 }
 
-SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket) {
+// Contexts = searches in flight on one index (NCTX, the size of the reference's read pool).  Synchronous entry
+// points block on a condition variable until one is free; the stream-ordered ones (block == false) fail with
+// PVS_ERR_STATE instead — their caller may be the very thread that has to pvs_wait() to free one.
+SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket, bool block) {
+    std::unique_lock<std::mutex> lk(ix->mu);
     for (;;) {
-        {
-            std::lock_guard<std::mutex> lk(ix->mu);
-            for (uint32_t i = 0; i < NCTX; i++)
-                if (!ix->ctx[i].busy) {
-                    ix->ctx[i].busy = true;
-                    *ticket = i;
-                    return &ix->ctx[i];
-                }
+        for (uint32_t i = 0; i < NCTX; i++)
+            if (!ix->ctx[i].busy) {
+                ix->ctx[i].busy = true;
+                *ticket = i;
+                return &ix->ctx[i];
+            }
+        if (!block) {
+            pvs_fail(PVS_ERR_STATE, "too many searches in flight on this index (limit %u): pvs_wait() one first", NCTX);
+            return nullptr;
         }
-        sched_yield();
+        ix->ctx_cv.wait(lk);
     }
 }
 void ctx_done(pvs_index *ix, SearchCtx *c) {
-    std::lock_guard<std::mutex> lk(ix->mu);
-    c->pending = false;
-    c->busy = false;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        c->pending = false;
+        c->busy = false;
+    }
+    ix->ctx_cv.notify_one();
 }
 
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
@@ -211,6 +219,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
 
 PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                  pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix && is_multi(ix)) return multi_search_host(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
     return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
 }
 
@@ -218,6 +227,7 @@ PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pv
                                           pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
                                           float *out_dist, uint32_t *out_count) {
     if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
+    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "candidate masks are not served on a multi-device index");
     return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
 }
 
@@ -298,12 +308,14 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
 PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
                                         uint32_t *out_ticket) {
+    if (ix && is_multi(ix)) return multi_search_device(ix, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, out_ticket);
     PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
     if (!d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
     HIP_TRY(hipSetDevice(ix->device));
     uint32_t t;
-    SearchCtx *c = ctx_acquire(ix, &t);
+    SearchCtx *c = ctx_acquire(ix, &t, false);
+    if (!c) return PVS_ERR_STATE;
     pvs_status st = ctx_prepare(ix, *c, batch, k, false);
     bool fast = false;
     if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast);
@@ -312,7 +324,10 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
         ctx_done(ix, c);
         return st;
     }
-    c->pending = true;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        c->pending = true;
+    }
     c->p_queries = d_queries;
     c->p_qdtype = qdtype;
     c->p_metric = metric;
@@ -329,8 +344,12 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
 
 PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     if (!ix || ticket >= NCTX) return pvs_fail(PVS_ERR_INVALID_ARG, "bad ticket");
+    if (is_multi(ix)) return multi_wait(ix, ticket);
     SearchCtx *c = &ix->ctx[ticket];
-    if (!c->busy || !c->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (!c->busy || !c->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+    }
     HIP_TRY(hipSetDevice(ix->device));
     pvs_status st = PVS_OK;
     hipError_t e = hipEventSynchronize(c->done);
@@ -347,7 +366,7 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
                 st = search_fallbacks(ix, *c, c->p_queries, c->p_qdtype, c->p_batch, c->p_k, c->p_metric, c->d_loc_ids, c->d_loc_dist,
                                       c->d_loc_cnt);
             // (search_fallbacks drained c->stream; the redo's collective goes where all the others go)
-            hipStream_t cs = ix->multi_stream ? ix->comm_stream : c->stream;
+            hipStream_t cs = ix->comm_stream;
             if (st == PVS_OK) {
                 hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
@@ -371,36 +390,52 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     return st;
 }
 
+// this context's own page buffers (a rank's / a shard's local result before the exchange)
+pvs_status ctx_reserve_local_pages(SearchCtx &c, uint64_t elems, uint32_t batch) {
+    if (elems <= c.loc_elems && batch <= c.loc_batch) return PVS_OK;
+    hipFree(c.d_loc_ids);
+    hipFree(c.d_loc_dist);
+    hipFree(c.d_loc_cnt);
+    c.d_loc_ids = nullptr;
+    c.d_loc_dist = nullptr;
+    c.d_loc_cnt = nullptr;
+    c.loc_elems = 0;
+    c.loc_batch = 0;
+    HIP_TRY(hipMalloc((void **)&c.d_loc_ids, elems * 8));
+    HIP_TRY(hipMalloc((void **)&c.d_loc_dist, elems * 4));
+    HIP_TRY(hipMalloc((void **)&c.d_loc_cnt, (size_t)batch * 4));
+    c.loc_elems = elems;
+    c.loc_batch = batch;
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, const void *d_queries, pvs_dtype qdtype, uint32_t batch,
                                                uint32_t k, pvs_metric metric, int64_t *d_out_ids, float *d_out_dist,
                                                uint32_t *d_out_count, uint32_t *out_ticket) {
     PVS_TRY(validate_search(ix, d_queries, qdtype, batch, k, metric));
     if (!comm || !d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
+    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "a multi-device index shards inside one process: use pvs_search / pvs_search_device");
     if (pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t world = (uint32_t)pvs_comm_world_(comm);
     uint32_t t;
-    SearchCtx *c = ctx_acquire(ix, &t);
+    SearchCtx *c = ctx_acquire(ix, &t, false);
+    if (!c) return PVS_ERR_STATE;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const uint64_t elems = (uint64_t)batch * k;
+        PVS_TRY(ctx_reserve_local_pages(*c, elems, batch));
         if (elems > c->sh_elems || batch > c->sh_batch || world != c->sh_world) {
-            hipFree(c->d_loc_ids);
             hipFree(c->d_all_ids);
-            hipFree(c->d_loc_dist);
             hipFree(c->d_all_dist);
-            hipFree(c->d_loc_cnt);
             hipFree(c->d_all_cnt);
             hipFree(c->d_all_flags);
             if (c->h_all_flags) hipHostFree(c->h_all_flags);
-            c->d_loc_ids = c->d_all_ids = nullptr;
-            c->d_loc_dist = c->d_all_dist = nullptr;
-            c->d_loc_cnt = c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
+            c->d_all_ids = nullptr;
+            c->d_all_dist = nullptr;
+            c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
             c->sh_elems = 0;
-            HIP_TRY(hipMalloc((void **)&c->d_loc_ids, elems * 8));
-            HIP_TRY(hipMalloc((void **)&c->d_loc_dist, elems * 4));
-            HIP_TRY(hipMalloc((void **)&c->d_loc_cnt, (size_t)batch * 4));
             HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * world));
             HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * world));
             HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
@@ -417,17 +452,21 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
         // With one stream per context (pvs_index_set_streams) the local scans of several searches
         // overlap, but their collectives still go out on ONE stream in program order: a communicator
         // is never driven from two streams at once.
-        hipStream_t cs = c->stream;
-        if (ix->multi_stream) {
-            cs = ix->comm_stream;
-            HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
-        }
+        // (Both stream modes: every collective of an index goes out on comm_stream, also the per-item pages of
+        // pvs_search_groups_sharded.)
+        hipStream_t cs = ix->comm_stream;
+        HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
+        span_begin(ix, *c, 3, 0, cs);
         PVS_TRY(pvs_comm_gather_pages_(comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids, c->d_all_dist,
                                        c->d_all_cnt, c->d_all_flags, elems, batch, cs));
         HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
+        span_end(ix, *c, cs);
         HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, cs));
         HIP_TRY(hipEventRecord(c->done, cs));
-        c->pending = true;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            c->pending = true;
+        }
         c->p_comm = comm;
         c->p_queries = d_queries;
         c->p_qdtype = qdtype;
@@ -463,17 +502,25 @@ PVS_EXPORT pvs_status pvs_search_sharded(pvs_index *ix, pvs_comm *comm, const vo
 
 PVS_EXPORT pvs_status pvs_sync(pvs_index *ix) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (is_multi(ix)) return multi_sync(ix);
     pvs_status st = PVS_OK;
-    for (uint32_t i = 0; i < NCTX; i++)
-        if (ix->ctx[i].busy && ix->ctx[i].pending) {
+    for (uint32_t i = 0; i < NCTX; i++) {
+        bool live;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            live = ix->ctx[i].busy && ix->ctx[i].pending;
+        }
+        if (live) {
             pvs_status s = pvs_wait(ix, i);
             if (s != PVS_OK) st = s;
         }
+    }
     return st;
 }
 
 PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist,
                                     pvs_space out_space) {
+    if (ix && is_multi(ix)) return multi_score_all(ix, query, qdtype, metric, out_dist, out_space);
     PVS_TRY(validate_search(ix, query, qdtype, 1, 1, metric));
     if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (ix->n == 0) return PVS_OK;

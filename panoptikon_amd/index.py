@@ -74,9 +74,15 @@ def quantize_int8(x, scale: float, device: int = -1) -> np.ndarray:
 
 
 class VectorIndex:
-    def __init__(self, dtype: int, dim: int, device: int = -1, capacity_rows: int = 0, id_base: int = 0):
-        self.dtype, self.dim, self.device = dtype, dim, device
-        d = L.IndexDesc(C.sizeof(L.IndexDesc), device, dtype, dim, capacity_rows, id_base)
+    def __init__(self, dtype: int, dim: int, device: int = -1, capacity_rows: int = 0, id_base: int = 0, devices=None):
+        """devices: list of HIP ordinals -> one index sharded over several GPUs inside this process
+        (pvs_index_desc.n_devices; buffers of the device entry points then live on devices[0])."""
+        self.dtype, self.dim = dtype, dim
+        self.devices = None if devices is None else [int(x) for x in devices]
+        self.device = device if not self.devices else self.devices[0]
+        arr = (C.c_int32 * len(self.devices))(*self.devices) if self.devices else None
+        d = L.IndexDesc(C.sizeof(L.IndexDesc), self.device, dtype, dim, capacity_rows, id_base,
+                        len(self.devices) if self.devices else 0, arr)
         h = C.c_void_p()
         L.check(L.lib().pvs_index_create(C.byref(d), C.byref(h)))
         self._h = h

@@ -19,6 +19,7 @@ reference's ``files`` join does).
 from __future__ import annotations
 
 import sqlite3
+import zlib
 from dataclasses import dataclass, field
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -142,6 +143,10 @@ def coverage_revs(conn: sqlite3.Connection, profile_id: int, setter_names: Seque
     return tuple(out)
 
 
+TAIL_WINDOW = 1024
+_FP_MASK = (1 << 32) - 1  # sums of 32-bit residues stay below 2^63 for 2^31 rows (SQLite's SUM raises on i64 overflow)
+
+
 @dataclass
 class LoadedIndex:
     index: object  # VectorIndex
@@ -152,6 +157,21 @@ class LoadedIndex:
     scale: Optional[float] = None
     key: tuple = field(default_factory=tuple)
     last_id: int = -1  # largest item_data.id loaded (appends resume after it)
+    # what validates the loaded prefix after an epoch bump (append_new_rows): integer sums over every loaded
+    # (id, item_id) and the (id, item_id, crc32(payload)) of the newest TAIL_WINDOW rows
+    sum_id: int = 0
+    sum_item: int = 0
+    tail: list = field(default_factory=list)
+
+    def note_chunk(self, ids: np.ndarray, items: np.ndarray, mat: np.ndarray) -> None:
+        self.rows += len(ids)
+        self.last_id = int(ids[-1])
+        self.sum_id += int(np.sum(ids & _FP_MASK, dtype=np.int64))
+        self.sum_item += int(np.sum(items & _FP_MASK, dtype=np.int64))
+        w = min(len(ids), TAIL_WINDOW)
+        raw = np.ascontiguousarray(mat[len(ids) - w:])
+        new = [(int(ids[len(ids) - w + i]), int(items[len(ids) - w + i]), zlib.crc32(raw[i].tobytes())) for i in range(w)]
+        self.tail = (self.tail + new)[-TAIL_WINDOW:]
 
 
 def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtype: int = L.F32, device: int = 0,
@@ -159,17 +179,14 @@ def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtyp
     """The reference's *exact* mode on the device: the setters' f32 embeddings as an f32 (or f16) index."""
     from .index import VectorIndex
 
-    ix, n, dim, last = None, 0, 0, -1
+    li = None
     for ids, items, mat in iter_exact_rows(conn, setter_names, chunk_rows):
-        if ix is None:
+        if li is None:
             dim = mat.shape[1]
-            ix = VectorIndex(dtype, dim, device=device)
-        ix.add_f32(mat, row_ids=ids, group_ids=items)
-        n += len(ids)
-        last = int(ids[-1])
-    if ix is None:
-        return None
-    return LoadedIndex(ix, "exact", n, dim, last_id=last)
+            li = LoadedIndex(VectorIndex(dtype, dim, device=device), "exact", 0, dim)
+        li.index.add_f32(mat, row_ids=ids, group_ids=items)
+        li.note_chunk(ids, items, mat)
+    return li
 
 
 def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: Sequence[str], device: int = 0,
@@ -183,52 +200,65 @@ def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: 
         return None
     ix = VectorIndex(L.I8, pair.dim, device=device)
     ix.set_scale(pair.scale)
-    n, last = 0, -1
+    li = LoadedIndex(ix, "quant", 0, pair.dim, profile_id=pair.profile_id, scale=pair.scale)
     for ids, items, mat in iter_quant_rows(conn, pair.profile_id, setter_names, pair.dim, chunk_rows):
         ix.add(mat, row_ids=ids, group_ids=items)
-        n += len(ids)
-        last = int(ids[-1])
-    return LoadedIndex(ix, "quant", n, pair.dim, profile_id=pair.profile_id, scale=pair.scale, last_id=last)
+        li.note_chunk(ids, items, mat)
+    return li
 
 
-def _count_prefix(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str]) -> int:
-    """Rows the loader would stream with id <= li.last_id — equals li.rows iff nothing the index holds was
-    deleted or replaced since it was loaded."""
+def _prefix_intact(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str]) -> bool:
+    """True iff the rows the loader would stream with id <= li.last_id are the rows the index holds.
+
+    `item_data.id` is INTEGER PRIMARY KEY *without* AUTOINCREMENT (init.sql:94): SQLite hands out max(id)+1, so
+    once the newest rows are deleted their ids are reused by the next extraction, and a row count alone cannot
+    tell the old prefix from the new one.  Checks: (1) COUNT and integer sums of (id, item_id) over the whole
+    prefix — one index scan; (2) the newest TAIL_WINDOW loaded rows are re-read and their (id, item_id,
+    crc32(payload)) compared.  (2) is where reuse can hide: a reused id is larger than every id that survived
+    the delete, so if the newest loaded row is still there unchanged no id at or below it was reused, and if it is
+    not, the tail comparison fails."""
     sids = _existing_setter_ids(conn, setter_names)
     if not sids:
-        return 0
+        return li.rows == 0
     marks = ",".join("?" * len(sids))
+    fp = f"COUNT(*), COALESCE(SUM(d.id & {_FP_MASK}), 0), COALESCE(SUM(d.item_id & {_FP_MASK}), 0)"
+    lo = li.tail[0][0] if li.tail else li.last_id + 1
     if li.kind == "exact":
-        row = conn.execute(f"SELECT COUNT(*) FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN ({marks}) "
-                           f"AND d.id <= ? AND length(e.embedding) = ?", [*sids, li.last_id, li.dim * 4]).fetchone()
+        frm = (f"FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN ({marks}) AND d.id <= ? "
+               f"AND length(e.embedding) = ?")
+        args = [*sids, li.last_id, li.dim * 4]
+        payload = "e.embedding"
     else:
-        row = conn.execute(f"SELECT COUNT(*) FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
-                           f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
-                           f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id <= ? AND length(q.quant) = ?",
-                           [li.profile_id, *sids, li.last_id, li.dim]).fetchone()
-    return int(row[0])
+        frm = (f"FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
+               f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
+               f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id <= ? AND length(q.quant) = ?")
+        args = [li.profile_id, *sids, li.last_id, li.dim]
+        payload = "q.quant"
+    cnt, sid, sitem = conn.execute(f"SELECT {fp} {frm}", args).fetchone()
+    if (int(cnt), int(sid), int(sitem)) != (li.rows, li.sum_id, li.sum_item):
+        return False
+    tail = [(int(r[0]), int(r[1]), zlib.crc32(bytes(r[2]))) for r in
+            conn.execute(f"SELECT d.id, d.item_id, {payload} {frm} AND d.id >= ? ORDER BY d.id", [*args, lo])]
+    return tail == li.tail
 
 
 def append_new_rows(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str], chunk_rows: int = 65536) -> Optional[int]:
     """After an epoch bump: if every row the index holds is still there (extractions are immutable; deletes
     cascade), only rows with a larger item_data.id are new — append them.  Returns the number appended, or
     None when the prefix changed and the caller must rebuild."""
-    if _count_prefix(conn, li, setter_names) != li.rows:
+    if not _prefix_intact(conn, li, setter_names):
         return None
-    added = 0
+    before = li.rows
     if li.kind == "exact":
         stream = iter_exact_rows(conn, setter_names, chunk_rows, after_id=li.last_id, dim_bytes=li.dim * 4)
         for ids, items, mat in stream:
             li.index.add_f32(mat, row_ids=ids, group_ids=items)
-            added += len(ids)
-            li.last_id = int(ids[-1])
+            li.note_chunk(ids, items, mat)
     else:
         for ids, items, mat in iter_quant_rows(conn, li.profile_id, setter_names, li.dim, chunk_rows, after_id=li.last_id):
             li.index.add(mat, row_ids=ids, group_ids=items)
-            added += len(ids)
-            li.last_id = int(ids[-1])
-    li.rows += added
-    return added
+            li.note_chunk(ids, items, mat)
+    return li.rows - before
 
 
 class IndexCache:

@@ -2,9 +2,10 @@
 queries replicated, per-shard pages exchanged once and merged on every rank.
 
 The GPU data path is pvs_search_sharded (RCCL all-gather + device merge inside
-libpvs).  This module holds the rank arithmetic and the host-side exchange used
-when the pages are gathered by other means (gloo on CPU tests, or as the bench's
-fallback when RCCL cannot be initialised)."""
+libpvs) or, in one process, a multi-device index (pvs_multi.hip).  This module holds
+the rank arithmetic and the host-side exchange used when the pages are gathered by
+other means: `gather` is any callable that all-gathers a numpy array over the ranks
+(rendezvous.LocalRendezvous; torch.distributed over gloo in the CPU tests)."""
 from __future__ import annotations
 
 import numpy as np
@@ -17,24 +18,6 @@ def shard_range(n_rows: int, world: int, rank: int):
     global row id = r0 + local row and ids stay increasing across ranks."""
     per = (n_rows + world - 1) // world
     return min(rank * per, n_rows), min((rank + 1) * per, n_rows)
-
-
-class TorchDistGather:
-    """all_gather of small numpy arrays through torch.distributed (any backend that
-    moves CPU tensors, i.e. gloo)."""
-
-    def __init__(self, dist):
-        self.dist = dist
-        self.world = dist.get_world_size()
-
-    def __call__(self, a: np.ndarray) -> np.ndarray:
-        import torch
-
-        a = np.ascontiguousarray(a)
-        t = torch.from_numpy(a.view(np.uint8).reshape(-1))  # raw bytes: gloo has no u32 / i64-safe dtypes for all
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return np.stack([o.numpy().view(a.dtype).reshape(a.shape) for o in outs])
 
 
 def merge_shard_pages(local_ids, local_dist, local_cnt, gather, k: int):

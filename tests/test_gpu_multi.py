@@ -1,0 +1,285 @@
+"""Several shards behind one search, on real multi-shard data.
+
+* one process, several GPUs: a multi-device pvs_index (pvs_index_desc.n_devices).  On a one-GPU machine the device
+  list repeats ordinal 0, which still exercises everything that can go wrong in the sharded path — the row split,
+  per-shard ids, peer copies into the root's [shards][batch][k] gather buffers, k_merge's indexing, the dense-path
+  redo — against the oracle over the WHOLE corpus (not against pvs_search on the same index);
+* one process per GPU (RCCL): two ranks as two host threads when at least two devices are visible (skipped, not
+  passed, otherwise: RCCL refuses two ranks on one GPU);
+* concurrency regressions: searches in flight never share sort scratch; the in-flight limit is an error, not a hang.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pvs():
+    import panoptikon_amd as p
+
+    if p.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the gpu tests need an MI355X")
+    return p
+
+
+def _layouts(pvs):
+    n = pvs.device_count()
+    out = [[0, 0], [0, 0, 0]]
+    if n >= 2:
+        out.append(list(range(min(n, 8))))
+    return out
+
+
+def _host_corpus(dtype, rows, scale):
+    if dtype == "i8":
+        return orc.quantize_int8(rows, scale)
+    if dtype == "f16":
+        return rows.astype(np.float16)
+    return rows
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_multi_device_index_equals_oracle_over_whole_corpus(pvs, dtype, metric):
+    from panoptikon_amd import _lib as L
+
+    pdt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    odt = {"i8": orc.I8, "f16": orc.F16, "f32": orc.F32}[dtype]
+    pm, om = (pvs.COSINE, orc.COSINE) if metric == "cosine" else (pvs.L2, orc.L2)
+    dim, k = 768, 40
+    rows = orc.synth_rows(77, 0, 21_003, dim)
+    rows[5000] = rows[100]  # a duplicate vector that lands in another shard: tie broken by id across shards
+    scale = orc.compute_int8_scale(rows) if dtype == "i8" else None
+    corpus = _host_corpus(dtype, rows, scale)
+    queries = orc.synth_rows(0x5EED0000, 0, 37, dim)
+    queries[0] = rows[100]
+    hq = orc.quantize_int8(queries, scale) if dtype == "i8" else queries
+    ids = np.cumsum(np.random.default_rng(5).integers(1, 4, len(rows))).astype(np.int64) + 1000  # increasing, with gaps
+    exp = orc.search(odt, om, corpus, hq, k, ids=ids)
+    for devices in _layouts(pvs):
+        ix = pvs.VectorIndex(pdt, dim, devices=devices)
+        if scale is not None:
+            ix.set_scale(scale)
+        # ragged add calls, one smaller than the number of shards
+        cuts = [0, 1, 7000, 7001, 7003, 15_000, len(rows)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ix.add_f32(rows[a:b], row_ids=ids[a:b])
+        st = ix.stats()
+        assert st.rows == len(rows) and st.dim == dim
+        assert np.array_equal(ix.read_ids(), ids), "global row order = order of the add calls"
+        assert np.array_equal(ix.read_rows(6990, 40).view(np.uint8), np.ascontiguousarray(corpus[6990:7030]).view(np.uint8))
+        gi, gd, gc = ix.search(queries, k, pm)
+        assert gc.tolist() == [k] * len(queries)
+        assert np.array_equal(gi, exp[0]), f"devices={devices}: ids differ from the oracle over the whole corpus"
+        assert np.array_equal(gd.view(np.uint32), exp[1].view(np.uint32)), f"devices={devices}: distances not bit-exact"
+        assert gi[0, 0] == ids[100] and gi[0, 1] == ids[5000], "equal distances across shards: smaller id first"
+        # the `d` column in global row order
+        d_all = ix.score_all(queries[3], pm)
+        e_all = orc.score_all(odt, om, corpus, hq[3])
+        assert np.array_equal(d_all.view(np.uint32), e_all.view(np.uint32))
+        # stream-ordered form, several searches in flight, buffers on devices[0]
+        dq = pvs.DeviceBuffer.from_numpy(queries, devices[0])
+        outs = [(pvs.DeviceBuffer(37 * k * 8, devices[0]), pvs.DeviceBuffer(37 * k * 4, devices[0]), pvs.DeviceBuffer(37 * 4, devices[0]))
+                for _ in range(3)]
+        for streams in (1, 2):
+            ix.set_streams(streams)
+            tickets = [ix.search_device(dq, L.F32, 37, k, pm, *o) for o in outs]
+            for t, o in zip(tickets, outs):
+                ix.wait(t)
+                assert np.array_equal(o[0].to_numpy(np.int64, (37, k)), exp[0])
+                assert np.array_equal(o[1].to_numpy(np.float32, (37, k)).view(np.uint32), exp[1].view(np.uint32))
+        ix.set_streams(1)
+        if metric == "cosine":
+            # a zero query: every cosine distance is NULL, every shard hands it to its dense path, the root merges again
+            qz = queries.copy()
+            qz[2] = 0.0
+            zi, zd, zc = ix.search(qz, k, pm)
+            assert np.isnan(zd[2]).all() and zi[2].tolist() == ids[:k].tolist(), "NULL distances: id order over the whole corpus"
+            assert np.array_equal(zi[3:], exp[0][3:]) and np.array_equal(zd[3:].view(np.uint32), exp[1][3:].view(np.uint32))
+        # forced dense path on every shard
+        ix.set_path(1)
+        gi2, gd2, _ = ix.search(queries[:5], k, pm)
+        assert np.array_equal(gi2, exp[0][:5]) and np.array_equal(gd2.view(np.uint32), exp[1][:5].view(np.uint32))
+        ix.close()
+
+
+def test_multi_device_short_pages_and_implicit_ids(pvs):
+    """Fewer rows than k, fewer rows than shards, implicit ids (id_base + global row index)."""
+    dim = 64
+    rows = orc.synth_rows(3, 0, 11, dim)
+    q = orc.synth_rows(4, 0, 3, dim)
+    ix = pvs.VectorIndex(pvs.F32, dim, devices=[0, 0, 0, 0], id_base=500)
+    ix.add(rows[:2])   # two rows over four shards
+    ix.add(rows[2:])
+    gi, gd, gc = ix.search(q, 20, pvs.L2)
+    ei, ed = orc.search(orc.F32, orc.L2, rows, q, 20, ids=np.arange(500, 511, dtype=np.int64))
+    assert gc.tolist() == [11] * 3 and np.array_equal(gi[:, :11], ei) and np.array_equal(gd[:, :11].view(np.uint32), ed.view(np.uint32))
+    assert (gi[:, 11:] == -1).all() and np.isnan(gd[:, 11:]).all()
+    assert np.array_equal(ix.read_ids(), np.arange(500, 511))
+    with pytest.raises(pvs.PvsError):
+        ix.add(rows[:1], row_ids=np.array([505], np.int64))  # not increasing over the whole index
+    ix.close()
+
+
+def test_multi_device_min_groups_spanning_shards(pvs):
+    """pvs_search_groups(MIN) on a multi-device index: groups span shards; the global MIN is the min of shard minima."""
+    rng = np.random.default_rng(11)
+    dim, n, k = 256, 9000, 25
+    rows = orc.synth_rows(19, 0, n, dim)
+    grp = rng.integers(0, 1500, n).astype(np.int64) * 5 + 7
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    q = orc.synth_rows(23, 0, 6, dim)
+    hq = orc.quantize_int8(q, scale)
+    for devices in _layouts(pvs):
+        ix = pvs.VectorIndex(pvs.I8, dim, devices=devices)
+        ix.set_scale(scale)
+        ix.add_f32(rows[:4000], group_ids=grp[:4000])
+        ix.add_f32(rows[4000:], group_ids=grp[4000:])
+        og, ov, oc = ix.search_groups(hq, k, pvs.COSINE, pvs.AGG_MIN)
+        for j in range(len(hq)):
+            eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, hq[j], grp, orc.AGG_MIN, k)
+            assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), f"devices={devices} query {j}"
+            assert np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64))
+        with pytest.raises(pvs.PvsError) as e:
+            ix.search_groups(hq, k, pvs.COSINE, pvs.AGG_AVG)
+        assert e.value.status == 6  # PVS_ERR_UNSUPPORTED, stated in pvs.h
+        ix.close()
+
+
+def test_rccl_two_ranks_as_two_threads(pvs):
+    """One process per GPU in miniature: two ranks (two host threads, one device each) over a real RCCL communicator.
+    Needs two devices — RCCL refuses two ranks on one GPU."""
+    from panoptikon_amd import _lib as L
+
+    if pvs.device_count() < 2:
+        pytest.skip("needs >= 2 visible devices (RCCL: 'Duplicate GPU detected' with two ranks on one)")
+    world, dim, k, b = 2, 768, 50, 64
+    n = 40_000
+    rows = orc.synth_rows(41, 0, n, dim)
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    q = orc.synth_rows(43, 0, b, dim)
+    exp = orc.search(orc.I8, orc.COSINE, codes, orc.quantize_int8(q, scale), k)
+    uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+    L.check(pvs.lib().pvs_comm_unique_id(uid))
+    res, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            r0, r1 = pvs.shard_range(n, world, r)
+            comm = C.c_void_p()
+            L.check(pvs.lib().pvs_comm_create(uid, world, r, r, C.byref(comm)))
+            ix = pvs.VectorIndex(pvs.I8, dim, device=r, id_base=r0)
+            ix.set_scale(scale)
+            ix.add_f32(rows[r0:r1])
+            dq = pvs.DeviceBuffer.from_numpy(q, r)
+            oi, od, oc = pvs.DeviceBuffer(b * k * 8, r), pvs.DeviceBuffer(b * k * 4, r), pvs.DeviceBuffer(b * 4, r)
+            for _ in range(3):
+                L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dq.ptr, L.F32, b, k, pvs.COSINE, oi.ptr, od.ptr, oc.ptr))
+            res[r] = (oi.to_numpy(np.int64, (b, k)), od.to_numpy(np.float32, (b, k)), oc.to_numpy(np.uint32, (b,)))
+            pvs.lib().pvs_comm_destroy(comm)
+            ix.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(res[r][0], exp[0]) and np.array_equal(res[r][1].view(np.uint32), exp[1].view(np.uint32)), f"rank {r}"
+
+
+def test_in_flight_limit_is_an_error_not_a_hang(pvs):
+    from panoptikon_amd import _lib as L
+
+    rows = orc.synth_rows(7, 0, 4096, 128)
+    ix = pvs.VectorIndex(pvs.F16, 128)
+    ix.add_f32(rows)
+    q = pvs.DeviceBuffer.from_numpy(orc.synth_rows(8, 0, 4, 128))
+    outs = [(pvs.DeviceBuffer(4 * 5 * 8), pvs.DeviceBuffer(4 * 5 * 4), pvs.DeviceBuffer(4 * 4)) for _ in range(17)]
+    tickets = [ix.search_device(q, L.F32, 4, 5, pvs.COSINE, *outs[i]) for i in range(16)]
+    with pytest.raises(pvs.PvsError) as e:
+        ix.search_device(q, L.F32, 4, 5, pvs.COSINE, *outs[16])
+    assert e.value.status == 5 and "in flight" in e.value.message  # PVS_ERR_STATE
+    for t in tickets:
+        ix.wait(t)
+    t = ix.search_device(q, L.F32, 4, 5, pvs.COSINE, *outs[16])
+    ix.wait(t)
+    ref = outs[0][0].to_numpy(np.int64, (4, 5))
+    assert all(np.array_equal(o[0].to_numpy(np.int64, (4, 5)), ref) for o in outs)
+    ix.close()
+
+
+def test_concurrent_per_item_searches_do_not_share_sort_scratch(pvs):
+    """MAX / AVG / weighted group searches and similar_to rank through a radix sort; searches in flight on one index must
+    each own that scratch (16 read connections in the reference, db/connection.rs:235)."""
+    rng = np.random.default_rng(2)
+    dim, n = 128, 6000
+    rows = orc.synth_rows(51, 0, n, dim)
+    grp = rng.integers(0, 900, n).astype(np.int64)
+    ix = pvs.VectorIndex(pvs.F16, dim)
+    ix.add_f32(rows, group_ids=grp)
+    qs = orc.synth_rows(53, 0, 12, dim)
+    w = rng.random(n).astype(np.float32) + 0.1
+    targets = np.flatnonzero(grp == grp[17])[:3].astype(np.int64)
+
+    def work(i):
+        q = qs[i % len(qs)][None, :]
+        kind = i % 4
+        if kind == 0:
+            return ix.search_groups(q, 40, pvs.COSINE, pvs.AGG_AVG)
+        if kind == 1:
+            return ix.search_groups(q, 40, pvs.L2, pvs.AGG_MAX)
+        if kind == 2:
+            return ix.search_groups(q, 40, pvs.COSINE, pvs.AGG_AVG, row_weights=w)
+        return ix.similar_to(targets, 40, pvs.L2, pvs.AGG_AVG)
+
+    ref = [work(i) for i in range(24)]
+    got = [None] * 96
+    errs = []
+
+    def runner(t):
+        try:
+            for i in range(t, 96, 8):
+                got[i] = work(i % 24)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=runner, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+    for i in range(96):
+        for a, b in zip(got[i], ref[i % 24]):
+            a, b = np.asarray(a), np.asarray(b)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"call {i} differs under concurrency"
+    ix.close()
+
+
+def test_similar_to_leaves_out_groups_without_a_joined_pair(pvs):
+    """INNER JOIN + `other.sha256 != target` + the cross-modal gates (item_similarity.rs:445-489): the target's own
+    group and groups whose every pair is gated away are not in the result, even when k exceeds the number of groups."""
+    dim, n = 64, 40
+    rows = orc.synth_rows(61, 0, n, dim)
+    grp = (np.arange(n) // 4).astype(np.int64)          # 10 groups of 4 rows
+    kind = np.zeros(n, np.uint8)
+    kind[grp == 3] = 1                                   # group 3: text rows only
+    ix = pvs.VectorIndex(pvs.F32, dim)
+    ix.add(rows, group_ids=grp)
+    targets = np.array([0, 1, 2, 3], np.int64)           # every row of group 0 (all clip)
+    g, v = ix.similar_to(targets, 50, pvs.L2, pvs.AGG_AVG)
+    eg, ev = orc.similar_to(orc.F32, orc.L2, rows, targets.tolist(), grp, orc.AGG_AVG, 50)
+    assert 0 not in g.tolist() and len(g) == 9 and np.array_equal(g, eg) and np.array_equal(v.view(np.uint64), ev.view(np.uint64))
+    # i2i off: clip x clip pairs leave the join -> only the text group remains
+    g2, v2 = ix.similar_to_ex(targets, 50, pvs.L2, pvs.AGG_AVG, row_kind=kind, xmodal_i2i=False)
+    eg2, ev2 = orc.similar_to_ex(orc.F32, orc.L2, rows, targets.tolist(), grp, orc.AGG_AVG, 50, kind=kind, xmodal_i2i=False)
+    assert g2.tolist() == [3] and np.array_equal(g2, eg2) and np.array_equal(v2.view(np.uint64), ev2.view(np.uint64))
+    ix.close()

@@ -180,6 +180,69 @@ def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
     cache.clear()
 
 
+class _StubIndex:
+    """Stands in for VectorIndex in the CPU tests of the cache logic: records what was appended."""
+
+    def __init__(self, *a, **k):
+        self.ids = []
+
+    def set_scale(self, s):
+        pass
+
+    def add_f32(self, mat, row_ids=None, group_ids=None):
+        self.ids += list(map(int, row_ids))
+
+    add = add_f32
+
+    def close(self):
+        pass
+
+
+def test_reused_rowids_force_a_rebuild(monkeypatch):
+    """item_data.id is INTEGER PRIMARY KEY without AUTOINCREMENT (init.sql:94): deleting the newest extraction and
+    inserting another one reuses its id.  COUNT(prefix) is then unchanged; the loader must still notice."""
+    from panoptikon_amd import index as pvs_index
+    from panoptikon_amd import loader
+
+    monkeypatch.setattr(pvs_index, "VectorIndex", _StubIndex)
+    conn, good, scale, codes = build_db(ragged=False)
+    names = ["clip/m", "tclip/m"]
+    for kind in ("exact", "quant"):
+        li = loader.load_exact_index(conn, names) if kind == "exact" else loader.load_quant_index(conn, "int8", names)
+        assert li.rows == len(good) and li.last_id == good[-1][0] and len(li.tail) == min(len(good), loader.TAIL_WINDOW)
+        assert loader.append_new_rows(conn, li, names) == 0  # untouched database: nothing to append, prefix intact
+        conn.execute("SAVEPOINT t")
+        last_id, last_item, last_setter = good[-1][0], good[-1][1], good[-1][2]
+        conn.execute("DELETE FROM embeddings WHERE id = ?", (last_id,))
+        conn.execute("DELETE FROM embedding_quants WHERE id = ?", (last_id,))
+        conn.execute("DELETE FROM item_data WHERE id = ?", (last_id,))
+        # a new extraction of the SAME item: SQLite hands out the same id again, item_id is the same too
+        cur = conn.execute("INSERT INTO item_data (item_id, setter_id, data_type, idx) VALUES (?, ?, 'clip', 0)", (last_item, last_setter))
+        assert cur.lastrowid == last_id
+        vec = -good[-1][3]
+        conn.execute("INSERT INTO embeddings (id, embedding) VALUES (?, ?)", (last_id, vec.astype("<f4").tobytes()))
+        conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 2, ?)",
+                     (last_id, orc.quantize_int8(vec[None, :], scale)[0].tobytes()))
+        assert loader.append_new_rows(conn, li, names) is None, f"{kind}: same count, same ids, new payload -> rebuild"
+        conn.execute("ROLLBACK TO t")
+        # a different item takes the id: caught by the integer sums even outside the tail window
+        conn.execute("DELETE FROM embeddings WHERE id = ?", (last_id,))
+        conn.execute("DELETE FROM embedding_quants WHERE id = ?", (last_id,))
+        conn.execute("DELETE FROM item_data WHERE id = ?", (last_id,))
+        other_item = last_item - 1
+        conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (?, ?, ?, 'clip', 7)", (last_id, other_item, last_setter))
+        conn.execute("INSERT INTO embeddings (id, embedding) VALUES (?, ?)", (last_id, good[-1][3].astype("<f4").tobytes()))
+        conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 2, ?)", (last_id, codes[-1].tobytes()))
+        monkeypatch.setattr(loader, "TAIL_WINDOW", 0)
+        li0 = type(li)(li.index, li.kind, li.rows, li.dim, profile_id=li.profile_id, scale=li.scale, last_id=li.last_id,
+                       sum_id=li.sum_id, sum_item=li.sum_item, tail=[])
+        assert loader.append_new_rows(conn, li0, names) is None, f"{kind}: another item under a reused id"
+        monkeypatch.undo()
+        monkeypatch.setattr(pvs_index, "VectorIndex", _StubIndex)
+        conn.execute("ROLLBACK TO t")
+        conn.execute("RELEASE t")
+
+
 @pytest.mark.gpu
 def test_dist_cte_seam_sql_runs_unchanged_over_device_distances():
     """The SQL shape the reference generates around the distance column — MATERIALIZED dist CTE, GROUP BY file_id
