@@ -446,6 +446,17 @@ pvs_status pvs_memcpy(void *dst, const void *src, size_t bytes, int32_t device);
 pvs_status pvs_synth_rows_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                               float *d_out);
 
+/* On-box peaks for the roofline report (SURVEY.md 8d asks for datasheet AND measured peaks): streaming HBM reads with plain
+ * 16-byte loads and with the LDS-DMA transport the scan uses, a device-to-device copy (read + write bytes), and the dense
+ * int8 / f16 matrix-core rate at the clock the chip sustains.  Diagnostic only; allocates 8 GiB for a second or two. */
+typedef struct pvs_microbench_result {
+    uint32_t struct_size;
+    uint32_t compute_units, clock_mhz;
+    double hbm_read_gbs, hbm_lds_dma_gbs, hbm_copy_gbs;
+    double mfma_i8_tops, mfma_f16_tflops;
+} pvs_microbench_result;
+pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,11 @@ class Profile(C.Structure):
                 ("exchange_launches", C.c_uint64), ("exchange_ms", C.c_double)]
 
 
+class MicrobenchResult(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("compute_units", C.c_uint32), ("clock_mhz", C.c_uint32), ("hbm_read_gbs", C.c_double),
+                ("hbm_lds_dma_gbs", C.c_double), ("hbm_copy_gbs", C.c_double), ("mfma_i8_tops", C.c_double), ("mfma_f16_tflops", C.c_double)]
+
+
 class ReadyPair(C.Structure):
     _fields_ = [("have_db_context", C.c_int32), ("have_default_profile", C.c_int32), ("pair_ready", C.c_int32),
                 ("profile_id", C.c_int64), ("scale", C.c_float), ("dim", C.c_int64)]
@@ -126,6 +131,7 @@ SYMBOLS = {
     "pvs_device_free": (_i32, [_i32, _vp]),
     "pvs_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
     "pvs_synth_rows_f32": (_i32, [_i32, _u64, _u64, _u64, _u32, _vp]),
+    "pvs_microbench": (_i32, [_i32, C.POINTER(MicrobenchResult)]),
 }
 
 _lib = None

@@ -40,6 +40,7 @@ SOURCES = [
     "pvs_rrf.hip",
     "pvs_comm.hip",
     "pvs_multi.hip",
+    "pvs_microbench.hip",
     "pvs_host.cpp",
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
@@ -73,8 +74,10 @@ def _compile(src: str, force: bool = False) -> str:
     if not force and not _stale(src, obj):
         return obj
     dep = ["-MD", "-MF", obj[:-2] + ".d"]
+    # tuning experiments: PVS_FLAGS_<stem>="-mllvm ..." adds flags to one translation unit
+    extra = os.environ.get("PVS_FLAGS_" + os.path.splitext(src)[0], "").split()
     if src.endswith(".hip"):
-        cmd = [HIPCC, *COMMON, *HIPFLAGS, *dep, "-c", path, "-o", obj]
+        cmd = [HIPCC, *COMMON, *HIPFLAGS, *extra, *dep, "-c", path, "-o", obj]
     else:
         cmd = [HIPCC, *COMMON, *HOSTFLAGS, *dep, "-x", "c++", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -159,7 +159,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_SCAN_MAX_BATCH));
         HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_SCAN_MAX_BATCH));
         HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
-        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_SCAN_MAX_BATCH * PVS_CNT_STRIDE));
         HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
     }
     if (batch > c.flags_cap) {
@@ -247,14 +247,20 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
     float *norm_new = nullptr;
     int64_t *ids_new = nullptr;
     HIP_TRY(hipMalloc((void **)&rows_new, cap * (uint64_t)ix->stride));
-    float *rnorm_new = nullptr;
+    float *rnorm_new = nullptr, *scos_new = nullptr, *sl2_new = nullptr;
+    const uint64_t aux_floats = cap / 32 * PVS_AUX_REC;
     hipError_t e = hipMalloc((void **)&norm_new, cap * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&rnorm_new, cap * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ids_new, cap * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&scos_new, aux_floats * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&sl2_new, aux_floats * 4);
     if (e != hipSuccess) {
         hipFree(rows_new);
         hipFree(norm_new);
         hipFree(rnorm_new);
+        hipFree(ids_new);
+        hipFree(scos_new);
+        hipFree(sl2_new);
         return pvs_fail(PVS_ERR_OOM, "hipMalloc: %s", hipGetErrorString(e));
     }
     hipStream_t s = ix->admin_stream;
@@ -271,15 +277,21 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
         HIP_TRY(hipMemcpyAsync(rnorm_new, ix->d_rnorm, ix->n * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(ids_new, ix->d_ids, ix->n * 8, hipMemcpyDeviceToDevice, s));
     }
+    // the scan's row-scalar records of every tile, old rows and padding alike, from the arrays just filled
+    HIP_TRY(pvs_launch_scan_aux(norm_new, rnorm_new, 0, cap, scos_new, sl2_new, s));
     HIP_TRY(hipStreamSynchronize(s));
     hipFree(ix->d_rows);
     hipFree(ix->d_norm2);
     hipFree(ix->d_rnorm);
     hipFree(ix->d_ids);
+    hipFree(ix->d_scan_cos);
+    hipFree(ix->d_scan_l2);
     ix->d_rows = rows_new;
     ix->d_norm2 = norm_new;
     ix->d_rnorm = rnorm_new;
     ix->d_ids = ids_new;
+    ix->d_scan_cos = scos_new;
+    ix->d_scan_l2 = sl2_new;
     ix->cap = cap;
     return PVS_OK;
 }
@@ -294,6 +306,8 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_norm2);
     hipFree(ix->d_rnorm);
     hipFree(ix->d_ids);
+    hipFree(ix->d_scan_cos);
+    hipFree(ix->d_scan_l2);
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
@@ -329,6 +343,7 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
     const int mode = (from_f32 && ix->dtype == PVS_I8) ? 0 : (from_f32 && ix->dtype == PVS_F16) ? 1 : 2;
     HIP_TRY(pvs_launch_rows_ingest(mode, rows_dev, ix->dim, ix->esz, ix->n, n, ix->scale, ix->d_rows, ix->stride, s));
     HIP_TRY(pvs_launch_norm2((int)ix->dtype, ix->d_rows, ix->stride, ix->dim, ix->n, n, ix->d_norm2, ix->d_rnorm, s));
+    HIP_TRY(pvs_launch_scan_aux(ix->d_norm2, ix->d_rnorm, ix->n, n, ix->d_scan_cos, ix->d_scan_l2, s));
     if (row_ids)
         HIP_TRY(hipMemcpyAsync(ix->d_ids + ix->n, row_ids, n * 8, hipMemcpyHostToDevice, s));
     else
@@ -437,7 +452,7 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     s.rows = ix->n;
     s.capacity_rows = ix->cap;
     s.row_stride_bytes = ix->stride;
-    s.hbm_bytes = ix->cap * ((uint64_t)ix->stride + 16);
+    s.hbm_bytes = ix->cap * ((uint64_t)ix->stride + 16 + 2 * PVS_AUX_REC * 4 / 32);
     s.scale = ix->scale_set ? ix->scale : 0.f;
     s.searches = ix->searches.load();
     s.fast_queries = ix->fast_queries.load();

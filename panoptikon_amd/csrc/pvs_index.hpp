@@ -32,7 +32,7 @@ struct SearchCtx {
     float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
     const uint8_t *cur_mask = nullptr;  // pvs_search_filtered: candidate mask of the search in flight (device, [rows])
     uint8_t *d_mask = nullptr;          // its staging copy when the caller's mask is in host memory
-    float *d_aux_masked = nullptr;      // [cap] per-row scalar stream with NaN on rows outside the mask
+    float *d_aux_masked = nullptr;      // [cap/32][PVS_AUX_REC] row-scalar stream with NaN on rows outside the mask
     uint64_t mask_cap = 0;
     void *d_qstage = nullptr;     // pvs_search: the caller's host queries, staged (grown on demand, never freed per call)
     size_t qstage_cap = 0;
@@ -134,6 +134,7 @@ struct pvs_index {
     uint8_t *d_rows = nullptr;
     float *d_norm2 = nullptr;   // |a|^2, the reference's aMag (sequential f32)
     float *d_rnorm = nullptr;   // 1/|a|
+    float *d_scan_cos = nullptr, *d_scan_l2 = nullptr;  // the scan's row-scalar streams: [cap/32][PVS_AUX_REC] (k_scan_aux)
     int64_t *d_ids = nullptr;
     std::vector<int64_t> h_groups;  // optional group ids per row (host copy)
     std::vector<int64_t> h_ids_cache;  // host copy of row ids (lazy; similar_to's id -> row lookup)

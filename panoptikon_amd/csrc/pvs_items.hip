@@ -56,7 +56,7 @@ static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t
         a.kslabs = kslabs;
         a.qgroups = batch_pad / 32;
         a.rows = ix->d_rows;
-        a.aux = ix->d_norm2;
+        a.aux = ix->d_scan_l2;  // MODE 2 streams |a|^2
         a.stride = ix->stride;
         a.n_rows = ix->n;
         a.qmat = c.d_qmat;

@@ -6,6 +6,9 @@
 hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t row0, uint64_t n,
                             float *norm2, float *rnorm, hipStream_t s);
 hipError_t pvs_launch_fill_f32(float *p, uint64_t n, float v, hipStream_t s);
+// (re)builds the scan's row-scalar records (PVS_AUX_REC floats per 32-row tile) of every tile that overlaps rows [row0, row0+n)
+hipError_t pvs_launch_scan_aux(const float *norm2, const float *rnorm, uint64_t row0, uint64_t n, float *scan_cos, float *scan_l2,
+                               hipStream_t s);
 // dense [n][dim] rows -> tiled index rows row0..: mode 0 = quantize_int8 from f32, 1 = f16 from f32, 2 = copy
 hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint32_t esz, uint64_t row0, uint64_t n, float scale,
                                   uint8_t *rows, uint32_t stride, hipStream_t s);
@@ -41,7 +44,7 @@ struct ScanArgs {
     uint32_t kslabs;        // stride / 256
     uint32_t qgroups;       // batch_pad / 32 in {1,2,4} (and 8 where pvs_scan_max_batch() is 256)
     const uint8_t *rows;
-    const float *aux;       // per-row scalar for the metric: 1/|a| (cosine) or |a|^2 (L2)
+    const float *aux;       // the metric's row-scalar stream in tile records (k_scan_aux): 1/|a| (cosine) or |a|^2 (L2)
     uint32_t stride;
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;
@@ -56,7 +59,7 @@ struct ScanArgs {
     uint32_t groups_per_query;
     uint32_t gmin_per_lane = 16;  // mode 0: 1..16 (power of two); groups_per_query = grid * RT * 2 * gmin_per_lane
     const float *thr;       // mode 1: [batch_pad]
-    uint32_t *cand_cnt;     // [batch_pad]
+    uint32_t *cand_cnt;     // [batch_pad] counters, PVS_CNT_STRIDE u32 apart
     uint2 *cand;            // [batch_pad][cand_cap] = (row, key bits)
     uint32_t cand_cap;
 };
@@ -103,8 +106,8 @@ void pvs_dense_release(DenseWork &w);
 // mask (optional, [n] bytes on the device): rows with mask == 0 are not candidates at all
 pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids,
                           float *out_dist, uint32_t *out_count, hipStream_t s, const uint8_t *mask = nullptr);
-// out[r] = r < n && mask[r] ? aux[r] : NaN for r < cap: the per-row scalar stream of a filtered scan (a NaN
-// scalar makes every filter comparison of the row false)
+// aux / out: the scan's row-scalar stream in tile records (cap/32 * PVS_AUX_REC floats); rows outside the mask get a NaN
+// scalar (a NaN scalar makes every filter comparison of the row false)
 hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s);
 
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]

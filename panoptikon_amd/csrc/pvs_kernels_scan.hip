@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     const int tid = threadIdx.x;
     int64_t *oid = a.out_ids + (size_t)q * a.k;
     float *od = a.out_dist + (size_t)q * a.k;
-    const uint32_t cnt = a.cand_cnt[q];
+    const uint32_t cnt = a.cand_cnt[(size_t)q * PVS_CNT_STRIDE];
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
     if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
         if (tid == 0) {

@@ -29,6 +29,43 @@ hipError_t pvs_launch_norm2(int dtype, const uint8_t *rows, uint32_t stride, uin
     return hipGetLastError();
 }
 
+// The scan's row-scalar stream: one record of PVS_AUX_REC floats per 32-row tile — the 32 row scalars (cosine: 1/|a|,
+// L2: |a|^2; NaN on padding rows), then the tile's extremes for the pass-B pre-test (pvs_scan_kernel.hpp):
+//   cosine  [32] = min |a|, [33] = max |a| over the rows with a finite 1/|a| (|a| = 1/(1/|a|), clamped to FLT_MAX);
+//   L2      [32] = min |a|^2, [33] = max |a|^2 over the rows whose |a|^2 is not NaN (clamped to FLT_MAX);
+//   no such row: min = +inf, max = -inf (every bound derived from them compares false).
+// One wave per tile.
+__global__ __launch_bounds__(256) void k_scan_aux(const float *norm2, const float *rnorm, uint64_t tile0, uint64_t ntiles, float *scan_cos,
+                                                  float *scan_l2) {
+    const uint64_t t = tile0 + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= tile0 + ntiles) return;
+    const uint64_t r = t * 32 + (uint64_t)(lane & 31);
+    const float rn = rnorm[r], n2 = norm2[r];
+    const float FMAX = 3.402823466e38f, INF = __builtin_inff();
+    const bool okc = rn == rn && rn < INF;
+    const float w = fminf(__fdiv_rn(1.0f, rn), FMAX);
+    float cmn = okc ? w : INF, cmx = okc ? w : -INF;
+    const bool okl = n2 == n2;
+    const float v = fminf(n2, FMAX);
+    float lmn = okl ? v : INF, lmx = okl ? v : -INF;
+    for (int off = 16; off > 0; off >>= 1) {
+        cmn = fminf(cmn, __shfl_xor(cmn, off));
+        cmx = fmaxf(cmx, __shfl_xor(cmx, off));
+        lmn = fminf(lmn, __shfl_xor(lmn, off));
+        lmx = fmaxf(lmx, __shfl_xor(lmx, off));
+    }
+    scan_cos[t * PVS_AUX_REC + lane] = lane < 32 ? rn : lane == 32 ? cmn : lane == 33 ? cmx : 0.f;
+    scan_l2[t * PVS_AUX_REC + lane] = lane < 32 ? n2 : lane == 32 ? lmn : lane == 33 ? lmx : 0.f;
+}
+hipError_t pvs_launch_scan_aux(const float *norm2, const float *rnorm, uint64_t row0, uint64_t n, float *scan_cos, float *scan_l2,
+                               hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t t0 = row0 / 32, t1 = (row0 + n + 31) / 32;
+    hipLaunchKernelGGL(k_scan_aux, dim3((unsigned)((t1 - t0 + 3) / 4)), dim3(256), 0, s, norm2, rnorm, t0, t1 - t0, scan_cos, scan_l2);
+    return hipGetLastError();
+}
+
 __global__ void k_fill_f32(float *p, uint64_t n, float v) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         p[i] = v;
@@ -251,7 +288,7 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
     const uint32_t b = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) {  // per-search state the later kernels count into (saves two memset launches)
-        cand_cnt[b] = 0;
+        cand_cnt[(size_t)b * PVS_CNT_STRIDE] = 0;
         if (b < batch) need_dense[b] = 0;
     }
     uint8_t *mrow = qmat + (uint64_t)b * stride;
@@ -398,13 +435,20 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
 }
 
 // ------------------------------------------------------------ candidate mask
+// The scan's row-scalar stream (records of PVS_AUX_REC floats per 32-row tile, k_scan_aux) with NaN in place of the
+// scalar of every row the mask leaves out; the tile extremes stay those of the unmasked tile (still necessary
+// conditions: a subset's extremes lie inside them).
 __global__ __launch_bounds__(256) void k_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out) {
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < cap; r += (uint64_t)gridDim.x * 256)
-        out[r] = (r < n && mask[r]) ? aux[r] : __builtin_nanf("");
+    const uint64_t total = cap / 32 * PVS_AUX_REC;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t e = (uint32_t)(i % PVS_AUX_REC);
+        const uint64_t r = i / PVS_AUX_REC * 32 + e;
+        out[i] = (e >= 32 || (r < n && mask[r])) ? aux[i] : __builtin_nanf("");
+    }
 }
 hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s) {
     if (cap == 0) return hipSuccess;
-    const unsigned g = (unsigned)std::min<uint64_t>((cap + 255) / 256, 16384);
+    const unsigned g = (unsigned)std::min<uint64_t>((cap * 2 + 255) / 256, 16384);
     hipLaunchKernelGGL(k_mask_aux, dim3(g), dim3(256), 0, s, aux, mask, n, cap, out);
     return hipGetLastError();
 }

@@ -1,0 +1,134 @@
+// pvs_microbench.hip — on-box peaks for the roofline report ("take peaks from the datasheet AND a measured
+// stream / MFMA microbenchmark on the box; record both").  Nothing here is on the product path: bench.py calls
+// pvs_microbench once per run and prints the numbers next to the datasheet ones.
+//   hbm_read      every lane streams 16-byte non-temporal loads over a buffer far larger than L2 + MALL, grid = 8 workgroups per CU
+//   hbm_lds_dma   the same bytes moved by LDS-DMA (global_load_lds_dwordx4 … nt, 1 KiB per wave-instruction, 8 in flight per wave)
+//                 and never read back: the ceiling of the transport the scan kernel uses
+//   hbm_copy      read + write (hipMemcpyAsync device-to-device)
+//   mfma_i8/f16   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 on registers, four independent accumulators per wave,
+//                 two waves per SIMD: the dense matrix-core ceiling at the clock the chip sustains under that load
+#include "pvs_index.hpp"
+#include "pvs_lds_dma.hpp"
+
+typedef int mb_v4i __attribute__((ext_vector_type(4)));
+typedef int mb_v16i __attribute__((ext_vector_type(16)));
+typedef float mb_v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 mb_v8h __attribute__((ext_vector_type(8)));
+
+typedef unsigned int mb_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mb_read(const mb_v4u *src, uint64_t n16, uint32_t *sink) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const mb_v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                    c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc += a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i).x;
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // keeps the loads alive, (almost) never stores
+}
+
+// LDS-DMA stream: each wave lands 1 KiB pieces in its own 8-slot LDS ring, 7 in flight, nothing reads them back
+__global__ __launch_bounds__(256, 2) void k_mb_ldsdma(const uint8_t *src, uint64_t n_pieces) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring[4 * 8 * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t base = lds_addr(ring) + (uint32_t)wave * 8192;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
+    int slot = 0;
+    for (uint64_t p = wid; p < n_pieces; p += nw) {
+        const uint8_t *sb = src + p * 1024;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)sb >> 32));
+        dma16((const void *)(((uint64_t)hi << 32) | lo), (uint32_t)lane * 16u, base + (uint32_t)slot * 1024);
+        slot = (slot + 1) & 7;
+        wait_vm<7>();
+    }
+    wait_vm<0>();
+}
+
+template <int I8>
+__global__ __launch_bounds__(256, 2) void k_mb_mfma(uint32_t iters, uint32_t *sink) {
+    mb_v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7};
+    if (I8) {
+        mb_v16i c0 = {}, c1 = {}, c2 = {}, c3 = {};
+        for (uint32_t i = 0; i < iters; i++) {
+            c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c3, 0, 0, 0);
+        }
+        const int v = c0[0] + c1[1] + c2[2] + c3[3];
+        if (v == 0x12345678) sink[0] = (uint32_t)v;
+    } else {
+        mb_v16f c0 = {}, c1 = {}, c2 = {}, c3 = {};
+        const mb_v8h ah = __builtin_bit_cast(mb_v8h, a), bh = __builtin_bit_cast(mb_v8h, b);
+        for (uint32_t i = 0; i < iters; i++) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c3, 0, 0, 0);
+        }
+        const float v = c0[0] + c1[1] + c2[2] + c3[3];
+        if (v == 1.2345e33f) sink[0] = 1;
+    }
+}
+
+PVS_EXPORT pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out) {
+    if (!out || out->struct_size < sizeof(pvs_microbench_result)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_microbench_result.struct_size too small");
+    int dev = 0;
+    PVS_TRY(use_device(device, &dev));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    const unsigned cus = (unsigned)p.multiProcessorCount;
+    const uint64_t bytes = 4ull << 30;  // 4 GiB: far beyond L2 (32 MiB) + MALL (256 MiB)
+    uint8_t *a = nullptr, *b = nullptr;
+    uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&a, bytes));
+        HIP_TRY(hipMalloc((void **)&b, bytes));
+        HIP_TRY(hipMalloc((void **)&sink, 64));
+        HIP_TRY(hipMemset(a, 0x5a, bytes));
+        HIP_TRY(hipMemset(b, 0, bytes));
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        auto timed = [&](auto &&launch, int reps, float *ms_best) -> pvs_status {
+            *ms_best = 1e30f;
+            for (int w = 0; w < 2; w++) launch();
+            for (int r = 0; r < reps; r++) {
+                HIP_TRY(hipEventRecord(e0, nullptr));
+                launch();
+                HIP_TRY(hipEventRecord(e1, nullptr));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < *ms_best) *ms_best = ms;
+            }
+            return hipGetLastError() == hipSuccess ? PVS_OK : pvs_fail(PVS_ERR_DEVICE, "microbenchmark launch failed");
+        };
+        float ms = 0.f;
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_read, dim3(cus * 8), dim3(256), 0, nullptr, (const mb_v4u *)a, bytes / 16, sink); }, 5, &ms));
+        out->hbm_read_gbs = (double)bytes / (ms * 1e-3) / 1e9;
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_ldsdma, dim3(cus * 2), dim3(256), 0, nullptr, (const uint8_t *)a, bytes / 1024); }, 5, &ms));
+        out->hbm_lds_dma_gbs = (double)bytes / (ms * 1e-3) / 1e9;
+        PVS_TRY(timed([&]() { (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr); }, 3, &ms));
+        out->hbm_copy_gbs = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;  // bytes read + bytes written
+        const uint32_t iters = 20000;
+        const double ops = 2.0 * 32 * 32 * 32 * 4.0 * iters * (double)(cus * 2 * 4);  // per launch: 4 MFMAs x iters per wave, 8 waves per CU
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_mfma<1>, dim3(cus * 2), dim3(256), 0, nullptr, iters, sink); }, 3, &ms));
+        out->mfma_i8_tops = ops / (ms * 1e-3) / 1e12;
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_mfma<0>, dim3(cus * 2), dim3(256), 0, nullptr, iters, sink); }, 3, &ms));
+        out->mfma_f16_tflops = ops / 2.0 / (ms * 1e-3) / 1e12;  // K = 16 instead of 32
+        out->compute_units = cus;
+        out->clock_mhz = (uint32_t)(p.clockRate / 1000);
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(a);
+    hipFree(b);
+    hipFree(sink);
+    return st;
+}

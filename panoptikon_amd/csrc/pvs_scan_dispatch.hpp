@@ -3,7 +3,8 @@
 #include "pvs_kernels.hpp"
 struct ScanK {
     const uint8_t *rows;
-    const float *aux;  // per-row scalar streamed with the tiles: 1/|a| (cosine) or |a|^2 (L2); NaN on padding rows
+    const float *aux;  // row scalars streamed with the tiles, in records of PVS_AUX_REC floats per 32-row tile (k_scan_aux):
+                       // 1/|a| (cosine) or |a|^2 (L2), NaN on padding rows, then the tile's min / max
     const uint8_t *qmat;
     const QInfo *qinfo;
     const float *thr;

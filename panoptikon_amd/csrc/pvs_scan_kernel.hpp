@@ -13,21 +13,35 @@
 //   pass C  (pvs_kernels_scan.hip) exact rerank of the few survivors.
 //
 // Geometry (64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
-//   workgroup = 4 waves; wave (qg, rt) owns query group qg (32 queries, held in VGPRs for
-//   the whole kernel as MFMA B fragments) and row sub-tile rt (32 rows);
-//   QG = batch_pad/32 in {1,2,4}, RT = 4/QG, workgroup tile = 32*RT rows.
+//   workgroup = 4 waves; wave (qw, rt) owns GPW query groups of 32 queries (held in VGPRs for the whole kernel
+//   as MFMA B fragments) and row sub-tile rt (32 rows);
+//   QG = batch_pad/32 in {1,2,4,8}; GPW = 2 for QG = 8 (256 queries per pass, int8 rows up to 1 KiB), else 1;
+//   RT = 4*GPW/QG, workgroup tile = 32*RT rows.
 //   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
 //   in "slabs" of (32*RT rows x 256 B) grouped into chunks of SPB slabs (the whole 24 KiB tile for
-//   768-B rows and 128 queries): NC-chunk ring, NC-1 chunks in flight, one s_barrier and one counted
+//   768-B rows and >= 128 queries): NC-chunk ring, NC-1 chunks in flight, one s_barrier and one counted
 //   s_waitcnt vmcnt per chunk (never 0 in steady state).  MODE 2 = dense exact int8 distances.
-//   QG = 8 (256 queries, int8): 8 waves, one query group each, on one 32-row tile (Geo below).
 //   A fragments are ds_read_b128 from an XOR-swizzled slab image (chunk ^= row & 15).  The corpus
 //   is STORED in that image (tiled layout, pvs_common.hpp), so a DMA piece is one contiguous KiB
 //   of HBM landing lane-linear in LDS; reads are conflict-free for ds_read_b128's 16-lane groups.
 //   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 (f32 rows: scaled per row and narrowed to f16 on the
 //   way from LDS, see Acc<PVS_F32>) with A = 32 corpus rows, B = 32 queries:
-//   each lane ends up with ONE query (lane & 31) and 16 rows, so the per-query threshold is
-//   a lane-private register and the epilogue is 3-4 VALU per score until a row passes.
+//   each lane ends up with ONE query per group (lane & 31) and 16 rows, so the per-query threshold is
+//   a lane-private register.
+//
+// Why 256 queries run as TWO groups per wave: one A fragment (1 KiB per wave-instruction, 8 LDS cycles per CU)
+// feeds one 32-cycle MFMA per query group.  With one group per wave the four SIMDs ask the CU's single LDS pipe for
+// 4 x 8 = 32 cycles of reads per 32 cycles of matrix-core time: at 256 queries LDS reads + DMA writes need more
+// cycles per tile than HBM delivers it in (the round-1 8-wave geometry: 2.0 ms against 0.96 ms of HBM time).  Two
+// groups per wave halve the LDS traffic; the 192 fragment registers that costs leave one wave per SIMD, which is
+// only workable because the pass-B epilogue is now ~1 VALU per score (below) instead of ~4.
+//
+// Pass-B epilogue (MODE 1, int8 and f16 rows): "could any of this lane's 16 rows pass?" is answered without
+// touching the per-row scalars: fold the 16 accumulators with v_max3 (8 VALU) and compare with a per-(query, tile)
+// bound derived from the tile's extreme row scalars (k_scan_aux: min/max of |a| resp. |a|^2 over the 32 rows,
+// built at add time, streamed behind the row scalars) — a NECESSARY condition for the exact per-row test, so the emitted candidate set is exactly
+// what the per-row test alone would emit.  Only wave-tiles where some lane passes run the per-row test, with the
+// row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
 #pragma once
 #include <cstdlib>
 
@@ -40,23 +54,33 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int WCAP = 96;          // candidate staging entries per WAVE (wave-private LDS region)
+constexpr int WCAP = 64;          // candidate staging entries per WAVE (wave-private LDS region; with the scalar ring this
+                                  // keeps the 128-query instance at 2 workgroups per CU: 2 x 80,912 B)
+#ifndef PVS_PF
+#define PVS_PF 4                  // A fragments read ahead of the MFMA that consumes them (tuning experiments override it)
+#endif
 
 template <int DT>
 struct Acc;
 template <>
 struct Acc<PVS_I8> {
     using type = v16i;
+    using elem = int;
     __device__ static inline type mfma(v4i a, v4i b, type c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
     __device__ static inline int sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }  // exact
+    __device__ static inline int lowest() { return (int)0x80000000; }
+    __device__ static inline int max3(int a, int b, int c) { return max(a, max(b, c)); }  // v_max3_i32
 };
 template <>
 struct Acc<PVS_F16> {
     using type = v16f;
+    using elem = float;
     __device__ static inline type mfma(v4i a, v4i b, type c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
     }
     __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
+    __device__ static inline float lowest() { return -__builtin_inff(); }
+    __device__ static inline float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }  // v_max3_f32 (drops NaN)
 };
 
 // f32 rows go to the matrix core as f16: on their way from LDS a lane scales its row by a power of two chosen from
@@ -68,10 +92,13 @@ struct Acc<PVS_F16> {
 template <>
 struct Acc<PVS_F32> {
     using type = v16f;
+    using elem = float;
     __device__ static inline type mfma(v4i a, v4i b, type c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
     }
     __device__ static inline float sum2(const type &a, const type &b, int r) { return a[r] + b[r]; }
+    __device__ static inline float lowest() { return -__builtin_inff(); }
+    __device__ static inline float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 };
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 __device__ static inline int cvt_pkrtz_f16(float lo, float hi) {
@@ -94,14 +121,17 @@ constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 // Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
 // vmcnt wait + one s_barrier per chunk.  For the headline shape (768-B rows, 128 queries) a
 // chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
-// QG = 8 (256 queries per pass) runs EIGHT waves per workgroup, one query group each, all on the same
-// 32-row tile: every stored byte is used by twice as many queries per HBM read.  Its 8 waves fill the
-// CU's wave slots at this register budget (2 per SIMD), so there is one workgroup per CU and its ring
-// takes most of the LDS.
 template <int QG, int KSLABS>
 struct Geo {
+#ifdef PVS_WIDE8  // experiment: 256 queries as 8 waves x 1 group (2 waves per SIMD) instead of 4 waves x 2 groups
     static constexpr int WAVES = QG == 8 ? 8 : 4;
-    static constexpr int RT = WAVES / QG;
+    static constexpr int GPW = 1;
+#else
+    static constexpr int WAVES = 4;
+    static constexpr int GPW = QG == 8 ? 2 : 1;  // query groups per wave
+#endif
+    static constexpr int QW = QG / GPW;          // waves side by side along the queries
+    static constexpr int RT = WAVES / QW;        // row sub-tiles per workgroup
     static constexpr int SLAB_ROWS = 32 * RT;
     static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
     static constexpr int PPW = 8 * RT / WAVES;  // 1-KiB DMA pieces per wave and slab
@@ -112,37 +142,48 @@ struct Geo {
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
     static constexpr int PC = NC - 1;                                              // chunks in flight
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
-    static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 norm DMA
+    static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
+                                                          // same record): tiles in flight + the previous tile, kept for its epilogue
+    static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 row-scalar DMA
     static constexpr int LCAP = WAVES * WCAP;           // candidate staging entries per workgroup
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NC * WAVES * 256 + 16 + LCAP * 12;
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + 16 + LCAP * 12;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
 
+#ifdef PVS_WIDE8
 constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
 constexpr int scan_threads(int QG) { return QG == 8 ? 512 : 256; }
+#else
+constexpr int scan_threads(int) { return 256; }
+constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || QG == 8 || KSLABS > 4) ? 1 : 2; }
+#endif
 
 template <int DT, int KSLABS, int QG, int METRIC, int MODE>
 __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
     using G = Geo<QG, KSLABS>;
     using A = Acc<DT>;
+    using elem_t = typename A::elem;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
-                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, LCAP = G::LCAP;
+                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, LCAP = G::LCAP, GPW = G::GPW, QW = G::QW, NCN = G::NCN;
     constexpr bool COS = METRIC == PVS_COSINE;
+    constexpr bool PRETEST = MODE == 1 && DT != PVS_F32;  // (f32 rows carry a per-row power-of-two scale in their sums)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
-    uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NC][WAVES][256 B]
-    uint32_t *const st_cnt = (uint32_t *)(normring + NC * WAVES * 256);
+    uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NCN][WAVES][256 B]
+    uint32_t *const st_cnt = (uint32_t *)(normring + NCN * WAVES * 256);
     uint32_t *const st_row = st_cnt + 4;
     uint32_t *const st_key = st_row + LCAP;
     uint32_t *const st_q = st_key + LCAP;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qg = wave % QG, rt = wave / QG;
+    const int qw = wave % QW, rt = wave / QW;
     const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
     const uint32_t sid = blockIdx.x, nstreams = a.grid;  // this workgroup's tile stream
-    const int myq = qg * 32 + j;
+    int myq[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; g++) myq[g] = (qw * GPW + g) * 32 + j;
 
     const uint32_t ring_lds = lds_addr(ring), norm_lds = lds_addr(normring);
 
@@ -151,42 +192,56 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     const int n_my = sid < n_samp ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
     const uint64_t tile_bytes = (uint64_t)SLAB_ROWS * a.stride;
 
-    float mins[MODE == 0 ? 16 : 1];
+    float mins[MODE == 0 ? GPW : 1][MODE == 0 ? 16 : 1];
 #pragma unroll
-    for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[r] = __builtin_inff();
+    for (int g = 0; g < (MODE == 0 ? GPW : 1); g++)
+#pragma unroll
+        for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
     if (n_my > 0) {
         // ---- query fragments: resident in registers for the whole kernel
-        // (f32 index: the operand row holds the bf16 image of the query in its first half)
         constexpr int SPS = steps_per_slab<DT>();
         constexpr int NQF = KSLABS * SPS;
-        v4i qf[NQF];
-        {
-            const uint8_t *qrow = a.qmat + (size_t)myq * a.stride;
+        v4i qf[GPW][NQF];
 #pragma unroll
-            for (int x = 0; x < NQF; x++) qf[x] = *(const v4i *)(qrow + (x * 2 + h) * 16);
+        for (int g = 0; g < GPW; g++) {
+            const uint8_t *qrow = a.qmat + (size_t)myq[g] * a.stride;
+#pragma unroll
+            for (int x = 0; x < NQF; x++) qf[g][x] = *(const v4i *)(qrow + (x * 2 + h) * 16);
         }
-        QInfo qi = a.qinfo[myq];
-        float thr = MODE == 1 ? a.thr[myq] : 0.f;
+        QInfo qi[GPW];
+        float thr[GPW];
+#pragma unroll
+        for (int g = 0; g < GPW; g++) {
+            qi[g] = a.qinfo[myq[g]];
+            thr[g] = MODE == 1 ? a.thr[myq[g]] : 0.f;
+        }
         // Pin every value loaded above as an asm operand: hipcc must retire its own loads HERE
         // (it cannot see the asm waits), otherwise it re-emits partial vmcnt waits for them
         // inside the main loop and throttles the DMA prefetch depth.
 #pragma unroll
-        for (int x = 0; x < NQF; x++) asm volatile("" : "+v"(qf[x]));
-        asm volatile("" : "+v"(qi.bb), "+v"(qi.dscale), "+v"(qi.eA), "+v"(qi.eR), "+v"(thr));
+        for (int g = 0; g < GPW; g++) {
+#pragma unroll
+            for (int x = 0; x < NQF; x++) asm volatile("" : "+v"(qf[g][x]));
+            asm volatile("" : "+v"(qi[g].bb), "+v"(qi[g].dscale), "+v"(qi[g].eA), "+v"(qi[g].eR), "+v"(thr[g]));
+        }
         wait_vm<0>();
-        // Filter tests folded into one per-lane constant (key/err algebra of DESIGN.md §5):
+        // Filter tests folded into one per-lane constant (key/err algebra of DESIGN.md §4.2):
         //   cosine  key = -dscale*acc/|a|, err = eA
         //           pass: key-err <= thr  <=>  acc/|a| >= -(thr+eA)/dscale
         //   L2      key = |a|^2 + bb - 2 dscale acc, err = eA + eR|a|^2
         //           pass: (1-eR)|a|^2 - 2 dscale acc <= thr + eA - bb
-        const float c1 = 1.0f - qi.eR;
-        const float m2d = -2.0f * qi.dscale;
-        float tS;
-        if (COS)
-            tS = qi.dscale > 0.f ? -(thr + qi.eA) / qi.dscale : __builtin_inff();  // padding query: never passes
-        else
-            tS = qi.dscale > 0.f ? thr + qi.eA - qi.bb : -__builtin_inff();
+        float c1[GPW], m2d[GPW], tS[GPW], hd[GPW];
+#pragma unroll
+        for (int g = 0; g < GPW; g++) {
+            c1[g] = 1.0f - qi[g].eR;
+            m2d[g] = -2.0f * qi[g].dscale;
+            hd[g] = qi[g].dscale > 0.f ? 0.5f / qi[g].dscale : 0.f;
+            if (COS)
+                tS[g] = qi[g].dscale > 0.f ? -(thr[g] + qi[g].eA) / qi[g].dscale : __builtin_inff();  // padding query: never passes
+            else
+                tS[g] = qi[g].dscale > 0.f ? thr[g] + qi[g].eA - qi[g].bb : -__builtin_inff();
+        }
 
         // ---- per-lane DMA source offsets inside a slab (row/chunk swizzle), computed once
         uint32_t voff[PPW];
@@ -196,7 +251,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             const int r = 4 * (wave * PPW + e);                          // first slab row of the piece
             voff[e] = (uint32_t)(r >> 5) * (32u * a.stride) + (uint32_t)(r & 31) * 256u + (uint32_t)lane * 16u;
         }
-        const uint32_t nvoff = (uint32_t)(rt * 32 + j) * 4u;
+        const uint32_t nvoff = (uint32_t)(rt * PVS_AUX_REC + lane) * 4u;  // this wave's tile record: 32 row scalars, then the tile's extremes
         // A-fragment LDS byte offsets of this lane inside a slab
         const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
         const uint32_t jx = (uint32_t)(j & 15);
@@ -210,36 +265,39 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         }
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
-        int i_tl = 0, i_ck = 0, i_slot = 0;  // tile, chunk within tile, ring chunk slot
+        int i_tl = 0, i_ck = 0, i_slot = 0, i_nslot = 0;  // tile, chunk within tile, ring chunk slot, row-scalar ring slot
         constexpr int DMA_PARTS = SPB * PPW + 1;  // row pieces + the per-row scalars
         const uint8_t *is_base = nullptr;
         const float *is_aux = nullptr;
         uint32_t is_lds = 0, is_norm = 0;
+        auto uni = [](const void *p) {  // pin a wave-uniform pointer in SGPRs (the asm's "s" operands)
+            const uint64_t v = (uint64_t)(uintptr_t)p;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+        };
         auto issue_begin = [&]() {
             const int tl = i_tl < n_my ? i_tl : n_my - 1;  // past the end: harmless re-read keeps vmcnt uniform
             const uint64_t wt = (uint64_t)(sid + (uint32_t)tl * nstreams) * a.tile_step;
             is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
-            is_aux = a.aux + wt * SLAB_ROWS;
+            is_aux = a.aux + wt * (RT * PVS_AUX_REC);  // one 64-float record per 32-row tile
             if constexpr (DT == PVS_F32 || QG == 8) {
-                // the 16-chunk unroll of the widest f32 instance makes hipcc lose track of the uniformity of
-                // these two and hand VGPRs to the asm's SGPR operands; pin them scalar
-                auto uni = [](const void *p) {
-                    const uint64_t v = (uint64_t)(uintptr_t)p;
-                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-                    return (const void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
-                };
+                // the long unrolls of these instances make hipcc lose track of the uniformity of these two
                 is_base = (const uint8_t *)uni(is_base);
                 is_aux = (const float *)uni(is_aux);
             }
             is_lds = ring_lds + (uint32_t)i_slot * (SPB * SLAB_BYTES) + (uint32_t)wave * (PPW * 1024);
-            is_norm = norm_lds + (uint32_t)i_slot * (WAVES * 256) + (uint32_t)wave * 256;
+            is_norm = norm_lds + (uint32_t)i_nslot * (WAVES * 256) + (uint32_t)wave * 256;
             if (++i_ck == CPT) {
                 i_ck = 0;
                 i_tl++;
+                if (++i_nslot == NCN) i_nslot = 0;
             }
             if (++i_slot == NC) i_slot = 0;
         };
         auto issue_part = [&](int part) {  // part is a compile-time constant at every call site
+#ifdef PVS_ABL_NODMA
+            return;
+#endif
             if (part < DMA_PARTS - 1) {
                 const int sb = part / PPW, e = part % PPW;
                 dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
@@ -257,43 +315,17 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // ---- main loop, software-pipelined inside each wave: the MFMAs of tile t are issued while
         // the VALU works through the epilogue of tile t-1 (MFMA and VALU are separate pipes; a wave
         // issues in order, so the two instruction streams must sit in one basic block for the
-        // scheduler to interleave them).  `hold` carries tile t-1's 16 dot products and `xh` its
-        // per-row scalars across the iteration boundary.
+        // scheduler to interleave them).
         using acc_t = typename A::type;
-        int c_slot = 0;
-        float xh[16];
-        decltype(A::sum2(acc_t{}, acc_t{}, 0)) hold[16];
+        int c_slot = 0, c_nslot = 0;   // consumer: ring chunk slot, row-scalar slot of the chunk being consumed
+        int p_nslot = -1;              // row-scalar slot of the PREVIOUS tile (its last chunk); -1: there is none yet
+        elem_t hold[GPW][16];          // !PARITY: the previous tile's 16 dot products per group
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            xh[r] = __builtin_nanf("");  // tile "-1": every test fails
-            hold[r] = 0;
-        }
+        for (int g = 0; g < GPW; g++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) hold[g][r] = 0;
         uint32_t prev_row_base = 0;
-        bool prev_valid = false;  // MODE 2: the dummy tile "-1" writes nothing
 
-        // Fast part of an epilogue, cut into 24 micro-steps so the main loop can drop them between
-        // MFMAs:  m < 16: sv[m] = score of row m;  m >= 16: fold two scores into the running best.
-        //   sv[r]: cosine  dot * (1/|a|)                 (pass iff sv >= tS)
-        //          L2      (1-eR)*|a|^2 - 2*dscale*dot   (pass iff sv <= tS)
-        // (two rows per step: v_pk_mul_f32 / v_pk_fma_f32)
-        auto epi_micro = [&](int m, float(&sv)[16], float &best, auto &&pv) {
-            if (m < 8) {
-                v2f d = {(float)pv(2 * m), (float)pv(2 * m + 1)};
-                if constexpr (DT == PVS_F32) {  // undo the per-row power-of-two scaling (exact)
-                    d[0] = __builtin_ldexpf(d[0], -f32_row_exp<COS>(xh[2 * m]));
-                    d[1] = __builtin_ldexpf(d[1], -f32_row_exp<COS>(xh[2 * m + 1]));
-                }
-                const v2f x = {xh[2 * m], xh[2 * m + 1]};
-                const v2f r = COS ? d * x : __builtin_elementwise_fma(d, (v2f){m2d, m2d}, (v2f){c1, c1} * x);
-                sv[2 * m] = r[0];
-                sv[2 * m + 1] = r[1];
-            } else {
-                const int r = (m - 8) * 2;
-                // NaN (padding / zero-norm rows) never wins a fmax/fmin
-                best = COS ? fmaxf(best, fmaxf(sv[r], sv[r + 1])) : fminf(best, fminf(sv[r], sv[r + 1]));
-            }
-        };
-        constexpr int EPI_STEPS = 16;
         // wave-private candidate staging: fill count (wave-uniform) and the flush to HBM.  The flush
         // issues global atomics/stores, which are unordered against the DMA loads the counted
         // vmcnt waits rely on, so it ends with a full drain of this wave's VMEM queue.
@@ -302,98 +334,239 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             for (uint32_t e = (uint32_t)lane; e < wcnt; e += 64) {
                 const uint32_t slot = (uint32_t)wave * WCAP + e;
                 const uint32_t q = st_q[slot];
-                const uint32_t gp = atomicAdd(&a.cand_cnt[q], 1u);
+                const uint32_t gp = atomicAdd(&a.cand_cnt[(size_t)q * PVS_CNT_STRIDE], 1u);
                 if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[slot], st_key[slot]);
             }
             wcnt = 0;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         };
-        // the rest: group minima (pass A) or candidate emission (pass B)
-        auto epi_rest = [&](const float(&sv)[16], float best, auto &&pv) {
+        // the previous tile's 16 row scalars of this lane (rows 4h + (r&3) + 8(r>>2)), from its slot of the scalar ring
+        auto load_xh = [&](float(&xh)[16]) {
+            if (p_nslot < 0) {  // tile "-1": every test fails
+#pragma unroll
+                for (int r = 0; r < 16; r++) xh[r] = __builtin_nanf("");
+                return;
+            }
+            const float *nl = (const float *)(normring + p_nslot * (WAVES * 256) + wave * 256);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
+                xh[4 * g4 + 0] = v.x;
+                xh[4 * g4 + 1] = v.y;
+                xh[4 * g4 + 2] = v.z;
+                xh[4 * g4 + 3] = v.w;
+            }
+        };
+        // score of row slot r from its dot product d and row scalar x:
+        //   cosine  d * (1/|a|)                  (pass iff sv >= tS)
+        //   L2      (1-eR)*|a|^2 - 2*dscale*d    (pass iff sv <= tS)
+        auto score = [&](int g, float d, float x) { return COS ? d * x : __builtin_fmaf(d, m2d[g], c1[g] * x); };
+        auto undo_f32 = [&](float d, float x) {  // f32 rows: undo the per-row power-of-two scaling (exact)
+            if constexpr (DT == PVS_F32) return __builtin_ldexpf(d, -f32_row_exp<COS>(x));
+            return d;
+        };
+        // per-row emission for one group: rows whose exact filter test passes go to the wave's staging list.  One ballot per
+        // tile row r (compile-time r: no dynamic register indexing).  A full staging list is flushed from ONE site: the row
+        // loop stops at the row that does not fit, flushes and resumes there — inlining the flush at each of the 16 rows (x
+        // groups x accumulator parities) made the 256-query instance 75 KB of code, more than the instruction cache holds.
+        auto emit_rows = [&](int g, const float(&xh)[16], auto &&pv) {
+            int r0 = 0;  // rows below r0 are done
+            bool full;
+            do {
+                full = false;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (r < r0 || full) continue;  // (wave-uniform)
+                    const float sv = score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]);
+                    const bool p = COS ? (sv >= tS[g]) : (sv <= tS[g]);
+                    unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
+#ifdef PVS_ABL_NOEMIT
+                    asm volatile("" : "+s"(bal));
+                    bal = 0;
+#endif
+                    if (bal != 0) {
+                        const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
+                        if (__builtin_expect(wcnt + npass > (uint32_t)WCAP, 0)) {
+                            full = true;
+                            r0 = r;
+                            continue;
+                        }
+                        uint32_t payload;
+                        if constexpr (DT == PVS_I8)
+                            payload = (uint32_t)pv(g, r);  // exact integer dot
+                        else
+                            payload = __builtin_bit_cast(uint32_t, COS ? -sv * qi[g].dscale : sv + qi[g].bb + qi[g].eR * xh[r]);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        if (p) {
+                            const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
+                            st_row[slot] = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
+                            st_key[slot] = payload;
+                            st_q[slot] = (uint32_t)myq[g];
+                        }
+                        wcnt += npass;
+                    }
+                }
+                if (full) flush_wave();
+            } while (full);
+        };
+        // ---- epilogue of the previous tile, cut into micro-steps the main loop drops between MFMAs, plus a rest.
+        //  PRETEST: 8 steps per group (v_max3 fold of two accumulators each) — no row scalar is touched;
+        //  otherwise 16 steps per group (8 score pairs, 8 folds), row scalars in xh.
+        struct Epi {
+            float xh[16];
+            float sv[GPW][16];
+            float best[GPW];
+            elem_t mx[GPW];
+        };
+        constexpr int EPI_STEPS = PRETEST ? 8 * GPW : 16 * GPW;
+        auto epi_begin = [&](Epi &e) {
+            if constexpr (!PRETEST) load_xh(e.xh);
+#pragma unroll
+            for (int g = 0; g < GPW; g++) {
+                e.best[g] = COS ? -__builtin_inff() : __builtin_inff();
+                e.mx[g] = A::lowest();
+            }
+        };
+        auto epi_micro = [&](int m, Epi &e, auto &&pv) {
+#ifdef PVS_ABL_NOEPI
+            if (MODE == 1) return;
+#endif
+            if constexpr (PRETEST) {
+                const int g = m / 8, i = m % 8;
+                e.mx[g] = A::max3(e.mx[g], pv(g, 2 * i), pv(g, 2 * i + 1));
+            } else {
+                const int g = m / 16, i = m % 16;
+                if (i < 8) {
+                    e.sv[g][2 * i] = score(g, undo_f32((float)pv(g, 2 * i), e.xh[2 * i]), e.xh[2 * i]);
+                    e.sv[g][2 * i + 1] = score(g, undo_f32((float)pv(g, 2 * i + 1), e.xh[2 * i + 1]), e.xh[2 * i + 1]);
+                } else {
+                    const int r = (i - 8) * 2;
+                    // NaN (padding / zero-norm rows) never wins a fmax/fmin
+                    e.best[g] = COS ? fmaxf(e.best[g], fmaxf(e.sv[g][r], e.sv[g][r + 1])) : fminf(e.best[g], fminf(e.sv[g][r], e.sv[g][r + 1]));
+                }
+            }
+        };
+        bool prev_valid = false;  // MODE 2: the dummy tile "-1" writes nothing
+        auto epi_rest = [&](Epi &e, auto &&pv) {
+#ifdef PVS_ABL_NOEPI
+            if (MODE == 1) {
+                asm volatile("" ::"v"(pv(0, 0)), "v"(pv(GPW - 1, 15)));
+                return;
+            }
+#endif
             if constexpr (MODE == 2) {
                 // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
                 // closed form of the exact integer sums, valid while they stay below 2^24
                 // (oracle: orc_i8_cosine_from_sums / orc_i8_l2_from_sums).  xh = |a|^2 here.
-                if (myq < (int)a.batch) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
-                        if (row < a.n_rows && prev_valid) {
-                            float d;
-                            if (COS) {
-                                d = ref_cosine_finish((float)pv(r), xh[r], qi.bb);
-                            } else {
-                                const double ss = (double)xh[r] + (double)qi.bb - 2.0 * (double)pv(r);
-                                if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
-                                d = ref_l2_finish((float)ss);
+                for (int g = 0; g < GPW; g++)
+                    if (myq[g] < (int)a.batch) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
+                            if (row < a.n_rows && prev_valid) {
+                                float d;
+                                if (COS) {
+                                    d = ref_cosine_finish((float)pv(g, r), e.xh[r], qi[g].bb);
+                                } else {
+                                    const double ss = (double)e.xh[r] + (double)qi[g].bb - 2.0 * (double)pv(g, r);
+                                    if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
+                                    d = ref_l2_finish((float)ss);
+                                }
+                                a.dense_out[(size_t)row * a.dense_ld + myq[g]] = d;
                             }
-                            a.dense_out[(size_t)row * a.dense_ld + myq] = d;
                         }
                     }
-                }
-            } else if (MODE == 0) {
+            } else if constexpr (MODE == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    // upper bound of this row's key: key + err
-                    const float ub = COS ? __builtin_fmaf(-sv[r], qi.dscale, qi.eA) : sv[r] + (qi.bb + qi.eA) + 2.0f * qi.eR * xh[r];
-                    mins[r] = fminf(mins[r], ub);
+                for (int g = 0; g < GPW; g++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        // upper bound of this row's key: key + err
+                        const float ub = COS ? __builtin_fmaf(-e.sv[g][r], qi[g].dscale, qi[g].eA)
+                                             : e.sv[g][r] + (qi[g].bb + qi[g].eA) + 2.0f * qi[g].eR * e.xh[r];
+                        mins[g][r] = fminf(mins[g][r], ub);
+                    }
+            } else if constexpr (PRETEST) {
+                // Necessary condition for "some row of this lane passes", from the tile's extreme row scalars, which
+                // ride behind the 32 row scalars in the tile's record (k_scan_aux: prev_t0 = min |a| resp. min |a|^2 over
+                // the tile's rows with a usable norm, prev_t1 = the max):
+                //   cosine  d/|a| >= tS            =>  d >= tS * (tS > 0 ? min|a| : max|a|)
+                //   L2      c1|a|^2 - 2 ds d <= tS =>  d >= (c1 * min|a|^2 - tS) / (2 ds)
+                // minus a slack that covers the f32 roundings of the exact test (2^-18 relative is 30x what they add up to,
+                // +1 for the integer floor).  NaN bounds (no usable row) compare false: nothing passes, which is right.
+                bool any = false;
+                bool lp[GPW];
+                float prev_t0 = __builtin_nanf(""), prev_t1 = __builtin_nanf("");  // tile "-1": NaN bounds, nothing passes
+                if (p_nslot >= 0) {
+                    const float2 tmm = *(const float2 *)((const float *)(normring + p_nslot * (WAVES * 256) + wave * 256) + 32);
+                    prev_t0 = tmm.x;
+                    prev_t1 = tmm.y;
+                }
+#pragma unroll
+                for (int g = 0; g < GPW; g++) {
+                    float b, mag;
+                    if (COS) {
+                        b = tS[g] * (tS[g] > 0.f ? prev_t0 : prev_t1);
+                        mag = fabsf(b);
+                    } else {
+                        const float x = c1[g] * prev_t0;
+                        b = (x - tS[g]) * hd[g];
+                        mag = (fabsf(x) + fabsf(tS[g])) * hd[g];
+                    }
+                    b = b - mag * 3.8147e-6f;
+                    if constexpr (DT == PVS_I8) b -= 1.0f;  // (integer dots; their f32 image below is within 2^-24 relative)
+                    lp[g] = (float)e.mx[g] >= b;
+                    any |= lp[g];
+                }
+#ifdef PVS_ABL_FOLDONLY
+                asm volatile("" ::"v"(any));
+                any = false;
+#endif
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                    // Some lane of the wave may hold a passing row (~15 % of the wave-tiles at k=100 over 10M rows): now
+                    // the per-row scalars are needed.  Staging is wave-private and its fill count lives in a scalar
+                    // register: no LDS atomics, no barrier.  One ballot per tile row r (compile-time r).
+                    load_xh(e.xh);
+#pragma unroll
+                    for (int g = 0; g < GPW; g++)
+                        if (__builtin_amdgcn_ballot_w64(lp[g]) != 0) emit_rows(g, e.xh, pv);
                 }
             } else {
-                const bool lane_pass = COS ? (best >= tS) : (best <= tS);
-                if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) {
-                    // Rare path (some lane of the wave has a passing row).  Staging is wave-private and its
-                    // fill count lives in a scalar register: no LDS atomics, no barrier.  One ballot per
-                    // tile row r (compile-time r: no dynamic register indexing, no select chains); rows
-                    // nobody passes cost one compare and one not-taken scalar branch.
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const bool p = COS ? (sv[r] >= tS) : (sv[r] <= tS);
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
-                        if (bal != 0) {
-                            const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
-                            if (__builtin_expect(wcnt + npass > (uint32_t)WCAP, 0)) flush_wave();
-                            uint32_t payload;
-                            if constexpr (DT == PVS_I8)
-                                payload = (uint32_t)pv(r);  // exact integer dot
-                            else
-                                payload = __builtin_bit_cast(uint32_t, COS ? -sv[r] * qi.dscale : sv[r] + qi.bb + qi.eR * xh[r]);
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                            if (p) {
-                                const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
-                                st_row[slot] = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
-                                st_key[slot] = payload;
-                                st_q[slot] = (uint32_t)myq;
-                            }
-                            wcnt += npass;
-                        }
-                    }
+                for (int g = 0; g < GPW; g++) {
+                    const bool lane_pass = COS ? (e.best[g] >= tS[g]) : (e.best[g] <= tS[g]);
+                    if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) emit_rows(g, e.xh, pv);
                 }
             }
         };
 
-        // One tile: MFMA burst into (acc, acc1) with the previous tile's epilogue slices in its shadow; `pv(r)` = the
-        // previous tile's r-th dot product.  PARITY (the 8-wave geometry): accumulators alternate between two
-        // register sets, the previous tile's sums are read where the matrix core left them — no hand-off copy or
-        // add, and one accumulation chain is enough because the SIMD's second wave fills the dependent-issue gap.
+        // One tile: MFMA burst into the accumulators with the previous tile's epilogue slices in its shadow; `pv(g, r)` =
+        // the previous tile's r-th dot product of group g.  PARITY (two groups per wave): accumulators alternate between
+        // two register sets, the previous tile's sums are read where the matrix core left them — no hand-off copy, and
+        // the two groups are the two independent accumulation chains.  Otherwise two chains (acc, acc1) per tile,
+        // summed into `hold` at the end of the tile.
         constexpr bool PARITY = QG == 8;
-        auto run_tile = [&](int tl, acc_t &acc, acc_t &acc1, auto &&pv) {
+        auto run_tile = [&](int tl, acc_t(&acc)[GPW], acc_t &acc1, auto &&pv) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                acc[r] = 0;
-                if (!PARITY) acc1[r] = 0;
+            for (int g = 0; g < GPW; g++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[g][r] = 0;
+            if constexpr (!PARITY) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc1[r] = 0;
             }
-            int norm_slot = 0;
-            float sv[16];
-            float best = COS ? -__builtin_inff() : __builtin_inff();
+            Epi e;
 #pragma unroll
             for (int ck = 0; ck < CPT; ck++) {
                 wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
                 wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
                 issue_begin();                          // the slot the previous chunk occupied is refilled below
+                if (ck == 0) epi_begin(e);
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
                 float row_scale = 1.0f;  // f32 rows: 2^e of this lane's A row (its scalar sits in this chunk's slot)
                 if constexpr (DT == PVS_F32) {
-                    const float ax = ((const float *)(normring + c_slot * (WAVES * 256) + wave * 256))[lane];
+                    const float ax = ((const float *)(normring + c_nslot * (WAVES * 256) + wave * 256))[j];
                     row_scale = __builtin_ldexpf(1.0f, f32_row_exp<COS>(ax));
                 }
                 (void)row_scale;
@@ -401,10 +574,10 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
                 for (int i = 0; i < 8; i++) fb[i] = cb + swz[i];
                 // Explicit software pipeline, fenced with sched_barrier(0) so hipcc keeps the order:
-                //   step t:  LDS read of fragment t+PF | MFMA t | one DMA piece of the chunk PC ahead |
+                //   step t:  LDS read of fragment t+PF | MFMA t (one per group) | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
-                constexpr int NF = SPB * SPS, PF = 4;
+                constexpr int NF = SPB * SPS, PF = (GPW == 2 ? PVS_PF : 4);
                 v4i af[NF];
                 v4i raw[DT == PVS_F32 ? NF : 1][2];  // f32: the two 16-B pieces of a step, before narrowing
                 (void)raw;
@@ -437,95 +610,84 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
                 for (int t = 0; t < NF; t++) {
                     if (t + PF < NF) frag(t + PF);
-                    if (!PARITY && (t & 1))
-                        acc1 = A::mfma(af[t], qf[ck * NF + t], acc1);
-                    else
-                        acc = A::mfma(af[t], qf[ck * NF + t], acc);
+                    if constexpr (PARITY) {
+#pragma unroll
+                        for (int g = 0; g < GPW; g++) acc[g] = A::mfma(af[t], qf[g][ck * NF + t], acc[g]);
+                    } else {
+                        if (t & 1)
+                            acc1 = A::mfma(af[t], qf[0][ck * NF + t], acc1);
+                        else
+                            acc[0] = A::mfma(af[t], qf[0][ck * NF + t], acc[0]);
+                    }
                     if (t + 1 < NF) narrow(t + 1);
 #pragma unroll
                     for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
                     if (ck == 0) {
 #pragma unroll
-                        for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, sv, best, pv);
+                        for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, e, pv);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                norm_slot = c_slot;
                 if (++c_slot == NC) c_slot = 0;
-            }
-            epi_rest(sv, best, pv);
-            // ---- hand this tile's results to the next iteration (its row scalars leave LDS now: the
-            // slot is refilled by the DMA issued after the next barrier)
-            {
-                const float *nl = (const float *)(normring + norm_slot * (WAVES * 256) + wave * 256);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
-                    xh[4 * g4 + 0] = v.x;
-                    xh[4 * g4 + 1] = v.y;
-                    xh[4 * g4 + 2] = v.z;
-                    xh[4 * g4 + 3] = v.w;
+                if (ck == CPT - 1) {  // this tile's row scalars: kept in their slot until the end of the NEXT tile
+                    epi_rest(e, pv);  // (the previous tile's, reading p_nslot)
+                    p_nslot = c_nslot;
+                    if (++c_nslot == NCN) c_nslot = 0;
                 }
-                if constexpr (!PARITY) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) hold[r] = A::sum2(acc, acc1, r);  // i8: exact integers; floats: within the error budget
-                }
-                prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
-                prev_valid = true;
             }
-        };
-        auto drain = [&](auto &&pv) {  // the last tile's epilogue
-            float sv[16];
-            float best = COS ? -__builtin_inff() : __builtin_inff();
+            // ---- hand this tile's results to the next iteration
+            if constexpr (!PARITY) {
 #pragma unroll
-            for (int m = 0; m < EPI_STEPS; m++) epi_micro(m, sv, best, pv);
-            epi_rest(sv, best, pv);
+                for (int r = 0; r < 16; r++) hold[0][r] = A::sum2(acc[0], acc1, r);  // i8: exact integers; floats: within the error budget
+            }
+            prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
+            prev_valid = true;
         };
+        // The last tile's epilogue runs inside one extra "ghost" tile (the DMA stream already re-reads the last tile past
+        // the end to keep vmcnt uniform; its sums are never looked at): 1/n_my more work, but the epilogue — the bulk of the
+        // kernel's code — exists once per accumulator set instead of three more times in a drain path (the 256-query
+        // instance shrank from 75 KB to well inside the instruction cache).
         if constexpr (PARITY) {
-            acc_t accA, accB, unused;
+            acc_t accA[GPW], accB[GPW], unused;
 #pragma unroll
-            for (int r = 0; r < 16; r++) accB[r] = 0;  // tile "-1"
-            auto pa = [&](int r) { return accA[r]; };
-            auto pb = [&](int r) { return accB[r]; };
-            int tl = 0;
-            for (; tl + 1 < n_my; tl += 2) {
+            for (int g = 0; g < GPW; g++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) accB[g][r] = 0;  // tile "-1"
+            auto pa = [&](int g, int r) { return accA[g][r]; };
+            auto pb = [&](int g, int r) { return accB[g][r]; };
+            for (int tl = 0; tl < n_my + 1; tl += 2) {
                 run_tile(tl, accA, unused, pb);
-                run_tile(tl + 1, accB, unused, pa);
-            }
-            if (tl < n_my) {
-                run_tile(tl, accA, unused, pb);
-                drain(pa);
-            } else {
-                drain(pb);
+                if (tl + 1 < n_my + 1) run_tile(tl + 1, accB, unused, pa);
             }
         } else {
-            auto ph = [&](int r) { return hold[r]; };
-            for (int tl = 0; tl < n_my; tl++) {
-                acc_t acc, acc1;
+            auto ph = [&](int g, int r) { return hold[g][r]; };
+            for (int tl = 0; tl < n_my + 1; tl++) {
+                acc_t acc[GPW], acc1;
                 run_tile(tl, acc, acc1, ph);
             }
-            drain(ph);
         }
         if (MODE == 1) flush_wave();
         wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
     }
 
-    if (MODE == 2) {
-    } else if (MODE == 0) {
-        // Each lane holds 16 minima (one per accumulator row slot) = 16 disjoint row groups of its query.
+    if (MODE == 0) {
+        // Each lane holds 16 minima per query (one per accumulator row slot) = 16 disjoint row groups of its query.
         // The threshold only needs a few times k groups per query; folding to a.gmin_per_lane (a power of two)
         // keeps the k-th select that follows short.
         const uint32_t gr = a.gmin_per_lane;
 #pragma unroll
-        for (int sft = 8; sft >= 1; sft >>= 1)
-            if (gr <= (uint32_t)sft) {
+        for (int g = 0; g < (MODE == 0 ? GPW : 1); g++) {
 #pragma unroll
-                for (int r = 0; r < sft; r++) mins[r] = fminf(mins[r], mins[r + sft]);
-            }
-        float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * gr;
+            for (int sft = 8; sft >= 1; sft >>= 1)
+                if (gr <= (uint32_t)sft) {
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            if ((uint32_t)r < gr) o[r] = mins[r];
+                    for (int r = 0; r < sft; r++) mins[g][r] = fminf(mins[g][r], mins[g][r + sft]);
+                }
+            float *o = a.gmin + (size_t)myq[g] * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * gr;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if ((uint32_t)r < gr) o[r] = mins[g][r];
+        }
     }
 }
 
@@ -553,7 +715,7 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
 }
-// 256 queries per pass: 8 waves x 32 queries (filter passes only)
+// 256 queries per pass: 4 waves x 2 groups x 32 queries (filter passes only)
 template <int DT, int KS>
 static hipError_t scan_launch_wide(const ScanK &k, int metric, int mode, hipStream_t s) {
     if (mode != 0 && mode != 1) return hipErrorInvalidValue;

@@ -81,7 +81,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.kslabs = ix->stride / PVS_KSLAB_BYTES;
         a.qgroups = batch_pad / 32;
         a.rows = ix->d_rows;
-        a.aux = metric == PVS_COSINE ? ix->d_rnorm : ix->d_norm2;
+        a.aux = metric == PVS_COSINE ? ix->d_scan_cos : ix->d_scan_l2;
         if (c.cur_mask) {  // filtered search: rows outside the mask stream a NaN scalar and never pass
             HIP_TRY(pvs_launch_mask_aux(a.aux, c.cur_mask, ix->n, ix->cap, c.d_aux_masked, c.stream));
             a.aux = c.d_aux_masked;
@@ -272,7 +272,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
                 c->d_aux_masked = nullptr;
                 c->mask_cap = 0;
                 HIP_TRY(hipMalloc((void **)&c->d_mask, ix->cap));
-                HIP_TRY(hipMalloc((void **)&c->d_aux_masked, ix->cap * 4));
+                HIP_TRY(hipMalloc((void **)&c->d_aux_masked, ix->cap / 32 * PVS_AUX_REC * 4));
                 c->mask_cap = ix->cap;
             }
             if (mask_space == PVS_HOST) {

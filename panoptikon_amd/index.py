@@ -54,6 +54,17 @@ class DeviceBuffer:
             pass
 
 
+def microbench(device: int = -1) -> dict:
+    """On-box peaks (pvs_microbench): HBM streaming reads / LDS-DMA reads / copy in GB/s, dense int8 and f16 MFMA rates."""
+    r = L.MicrobenchResult()
+    r.struct_size = C.sizeof(L.MicrobenchResult)
+    L.check(L.lib().pvs_microbench(device, C.byref(r)))
+    return {"hbm_read_GBs": round(r.hbm_read_gbs, 1), "hbm_lds_dma_read_GBs": round(r.hbm_lds_dma_gbs, 1),
+            "hbm_copy_GBs_read_plus_write": round(r.hbm_copy_gbs, 1), "mfma_i8_TOPs": round(r.mfma_i8_tops, 1),
+            "mfma_f16_TFLOPs": round(r.mfma_f16_tflops, 1), "compute_units": int(r.compute_units), "clock_mhz": int(r.clock_mhz),
+            "how": "pvs_microbench on this device in this run (4 GiB streams, best of 5; MFMA: 4 independent accumulators, 2 waves/SIMD)"}
+
+
 def absmax(x, device: int = -1) -> float:
     """blob_absmax over all components, on the GPU (db/vector_quants.rs:1474-1483)."""
     out = C.c_float()
