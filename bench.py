@@ -372,7 +372,8 @@ def main():
                    "parallelism": f"row-shard x{n_gpus}" + (" (one process)" if single else f" ({world} rank{'s' if world > 1 else ''})"),
                    "exchange": gather_mode, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1},
         "roofline": roofline,
-        "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries)},
+        "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries),
+                 "scan_candidates_per_query": round(int(st.last_candidates) / max(B, 1), 1)},
     }
 
     # ------------------------------------------------- verification (untimed)

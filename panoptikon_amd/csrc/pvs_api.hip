@@ -118,6 +118,8 @@ void ctx_release(SearchCtx &c) {
     hipFree(c.d_thr);
     hipFree(c.d_gmin);
     hipFree(c.d_cand_cnt);
+    hipFree(c.d_seg);
+    hipFree(c.d_seg_cnt);
     hipFree(c.d_cand);
     hipFree(c.d_need_dense);
     if (c.h_need_dense) hipHostFree(c.h_need_dense);
@@ -159,7 +161,9 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_SCAN_MAX_BATCH));
         HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_SCAN_MAX_BATCH));
         HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
-        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 4 * PVS_SCAN_MAX_BATCH * PVS_CNT_STRIDE));
+        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 64));
+        HIP_TRY(hipMalloc((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
+        HIP_TRY(hipMalloc((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS));
         HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
     }
     if (batch > c.flags_cap) {
@@ -168,8 +172,9 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         c.d_need_dense = nullptr;
         c.h_need_dense = nullptr;
         uint32_t cap = (uint32_t)pvs_round_up(batch, 256);
-        HIP_TRY(hipMalloc((void **)&c.d_need_dense, 4 * (size_t)cap));
-        HIP_TRY(hipHostMalloc((void **)&c.h_need_dense, 4 * (size_t)cap, hipHostMallocDefault));
+        // [0, cap): per-query "answer me on the dense path" flags; [cap, 2 cap): candidates the filter scan emitted per query
+        HIP_TRY(hipMalloc((void **)&c.d_need_dense, 8 * (size_t)cap));
+        HIP_TRY(hipHostMalloc((void **)&c.h_need_dense, 8 * (size_t)cap, hipHostMallocDefault));
         c.flags_cap = cap;
     }
     if (host_outputs) {

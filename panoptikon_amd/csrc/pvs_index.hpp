@@ -40,7 +40,9 @@ struct SearchCtx {
     QInfo *d_qinfo = nullptr;     // [MAX_BATCH]
     float *d_thr = nullptr;       // [MAX_BATCH]
     float *d_gmin = nullptr;      // [MAX_BATCH][GMAX]
-    uint32_t *d_cand_cnt = nullptr;
+    uint32_t *d_cand_cnt = nullptr;  // one flag word (dense int8 path: an L2 sum left the exact range)
+    uint2 *d_seg = nullptr;          // [PVS_SEG_PAIRS][PVS_SEG_CAP] candidate segments of the filter scan
+    uint32_t *d_seg_cnt = nullptr;   // [PVS_SEG_PAIRS] their fill counts
     uint2 *d_cand = nullptr;      // [MAX_BATCH][CAND_CAP]
     uint32_t *d_need_dense = nullptr;  // [total batch capacity]
     uint32_t *h_need_dense = nullptr;  // pinned

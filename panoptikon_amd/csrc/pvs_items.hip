@@ -64,9 +64,6 @@ static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t
         a.thr = c.d_thr;
         a.gmin = c.d_gmin;
         a.groups_per_query = 0;
-        a.cand_cnt = c.d_cand_cnt;
-        a.cand = c.d_cand;
-        a.cand_cap = PVS_CAND_CAP;
         a.mode = 2;
         a.tile_step = 1;
         const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);

@@ -25,8 +25,7 @@ hipError_t pvs_launch_iota_ids(int64_t *ids, uint64_t n, int64_t base, hipStream
 //   qinfo [batch_pad]         per-query constants (padding queries get NaN-proof zeros).
 hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *queries, uint32_t batch,
                                    uint32_t batch_pad, uint32_t dim, uint32_t stride, float scale,
-                                   int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *cand_cnt,
-                                   uint32_t *need_dense, hipStream_t s);
+                                   int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *need_dense, hipStream_t s);
 
 // ---- exact per-row distances (pvs_dense_exact.hip): the reference's dist_{cte}.d for `nq` prepared
 // queries (qexact [nq][dim] int8 codes or f32, qinfo [nq]) -> out[row * out_ld + out_col + q].
@@ -59,12 +58,14 @@ struct ScanArgs {
     uint32_t groups_per_query;
     uint32_t gmin_per_lane = 16;  // mode 0: 1..16 (power of two); groups_per_query = grid * RT * 2 * gmin_per_lane
     const float *thr;       // mode 1: [batch_pad]
-    uint32_t *cand_cnt;     // [batch_pad] counters, PVS_CNT_STRIDE u32 apart
-    uint2 *cand;            // [batch_pad][cand_cap] = (row, key bits)
-    uint32_t cand_cap;
+    // mode 1: candidates go to per-(segment, query) lists: segment = one wave row of one workgroup stream (grid * RT of them)
+    uint2 *seg = nullptr;          // [n_segments][batch_pad][PVS_SEG_CAP] = (row, key bits)
+    uint32_t *seg_cnt = nullptr;   // [batch_pad][n_segments] fill counts, written by the scan (above PVS_SEG_CAP = overflowed)
+    uint32_t n_segments = 0;       // out: set by pvs_scan_plan(): grid * RT
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 uint32_t pvs_scan_wg_rows(uint32_t qgroups);  // rows per workgroup tile
+uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // RT: 32-row sub-tiles (= candidate segments) per workgroup
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
 
@@ -81,14 +82,17 @@ struct FinalizeArgs {
     uint64_t n_rows;
     const void *qexact;     // [batch][dim] i8 or f32
     const QInfo *qinfo;
-    const uint32_t *cand_cnt;
-    const uint2 *cand;
+    const uint2 *seg;       // the scan's candidate segments and their fill counts (ScanArgs)
+    const uint32_t *seg_cnt;
+    uint32_t n_segments, seg_queries;
+    uint2 *cand;            // [batch][cand_cap] scratch: each query's segments gathered into one list
     uint32_t cand_cap;
     uint32_t batch, k;
     int64_t *out_ids;       // [batch][k]
     float *out_dist;        // [batch][k]
     uint32_t *out_count;    // [batch]
     uint32_t *need_dense;   // [batch] 1 = this query must be answered by the dense path
+    uint32_t *cand_seen = nullptr;  // [batch] (optional) candidates the scan emitted for the query (pvs_stats.last_candidates)
 };
 hipError_t pvs_launch_finalize(const FinalizeArgs &a, hipStream_t s);
 

@@ -16,6 +16,7 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
     return false;
 }
 uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
+uint32_t pvs_scan_row_tiles(uint32_t qgroups) { return qgroups >= 4 ? 1u : 4u / qgroups; }
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
@@ -26,8 +27,11 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.qinfo = a.qinfo;
     k.thr = a.thr;
     k.gmin = a.gmin;
-    k.cand_cnt = a.cand_cnt;
-    k.cand = a.cand;
+    k.seg = a.seg;
+    k.seg_cnt = a.seg_cnt;
+    k.seg_queries = a.qgroups * 32;
+    k.seg_cap = PVS_SEG_CAP;
+    k.seg_stride = a.grid * pvs_scan_row_tiles(a.qgroups);
     k.n_rows = a.n_rows;
     k.stride = a.stride;
     const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
@@ -35,7 +39,6 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.tile_step = a.tile_step ? a.tile_step : 1;
     k.groups_per_query = a.groups_per_query;
     k.gmin_per_lane = a.gmin_per_lane ? a.gmin_per_lane : 16;
-    k.cand_cap = a.cand_cap;
     k.grid = a.grid;
     k.dense_out = a.dense_out;
     k.dense_flag = a.dense_flag;
@@ -184,13 +187,14 @@ struct FinK {
     const int64_t *ids;
     const void *qexact;
     const QInfo *qinfo;
-    const uint32_t *cand_cnt;
-    const uint2 *cand;
+    const uint2 *seg;
+    const uint32_t *seg_cnt;
+    uint2 *cand;
     int64_t *out_ids;
     float *out_dist;
-    uint32_t *out_count, *need_dense;
+    uint32_t *out_count, *need_dense, *cand_seen;
     uint64_t n_rows;
-    uint32_t stride, dim, cand_cap, k;
+    uint32_t stride, dim, cand_cap, k, n_segments, seg_queries;
     int metric;
 };
 
@@ -223,7 +227,55 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     const int tid = threadIdx.x;
     int64_t *oid = a.out_ids + (size_t)q * a.k;
     float *od = a.out_dist + (size_t)q * a.k;
-    const uint32_t cnt = a.cand_cnt[(size_t)q * PVS_CNT_STRIDE];
+    // ---- gather: the scan left this query's candidates in one segment per workgroup row stream (no atomics on its side);
+    // prefix-sum the fill counts (offsets live in the not-yet-used bound array) and copy the segments into one flat list.
+    uint2 *const flat = a.cand + (size_t)q * a.cand_cap;
+    uint32_t cnt = 0;
+    {
+        uint32_t *const s_off = s_ub;  // [n_segments + 1]
+        __shared__ uint32_t s_part[256];
+        __shared__ uint32_t s_over;
+        const uint32_t *sc = a.seg_cnt + (size_t)q * a.n_segments;
+        const uint32_t per = (a.n_segments + 255) / 256;
+        uint32_t mine = 0;
+        bool over = false;
+        for (uint32_t i = 0; i < per; i++) {
+            const uint32_t sg = tid * per + i;
+            const uint32_t c = sg < a.n_segments ? sc[sg] : 0u;
+            over |= c > PVS_SEG_CAP;
+            mine += c < PVS_SEG_CAP ? c : PVS_SEG_CAP;
+        }
+        if (tid == 0) s_over = 0;
+        s_part[tid] = mine;
+        __syncthreads();
+        if (over) s_over = 1;
+        uint32_t v = mine;
+        for (int off = 1; off < 256; off <<= 1) {  // inclusive scan over the 256 partial sums
+            const uint32_t add = tid >= off ? s_part[tid - off] : 0u;
+            __syncthreads();
+            v += add;
+            s_part[tid] = v;
+            __syncthreads();
+        }
+        cnt = s_part[255];
+        uint32_t run = v - mine;
+        const bool too_many = s_over != 0 || cnt > a.cand_cap;
+        if (!too_many) {
+            for (uint32_t i = 0; i < per; i++) {
+                const uint32_t sg = tid * per + i;
+                if (sg >= a.n_segments) break;
+                const uint32_t c = sc[sg];
+                const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * PVS_SEG_CAP;
+                for (uint32_t e = 0; e < c; e++) flat[run + e] = src[e];
+                run += c;
+            }
+        } else {
+            cnt = a.cand_cap + 1;  // a segment or the list overflowed: the dense path answers this query
+        }
+        (void)s_off;
+        __syncthreads();  // (workgroup-scope fence: the list is read back by other lanes below)
+    }
+    if (tid == 0 && a.cand_seen) a.cand_seen[q] = cnt;
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
     if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
         if (tid == 0) {
@@ -233,7 +285,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         return;
     }
     const QInfo qi = a.qinfo[q];
-    const uint2 *cand = a.cand + (size_t)q * a.cand_cap;
+    const uint2 *cand = flat;
     for (uint32_t i = tid; i < cnt; i += 256) {
         const uint2 c = cand[i];
         const float aa = a.norm2[c.x];
@@ -349,12 +401,16 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.ids = f.ids;
     k.qexact = f.qexact;
     k.qinfo = f.qinfo;
-    k.cand_cnt = f.cand_cnt;
+    k.seg = f.seg;
+    k.seg_cnt = f.seg_cnt;
+    k.n_segments = f.n_segments;
+    k.seg_queries = f.seg_queries;
     k.cand = f.cand;
     k.out_ids = f.out_ids;
     k.out_dist = f.out_dist;
     k.out_count = f.out_count;
     k.need_dense = f.need_dense;
+    k.cand_seen = f.cand_seen;
     k.n_rows = f.n_rows;
     k.stride = f.stride;
     k.dim = f.dim;

@@ -283,14 +283,10 @@ hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t d
 // One workgroup per (padded) query.
 __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtype, const void *queries,
                                                       uint32_t batch, uint32_t dim, uint32_t stride, float scale,
-                                                      int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *cand_cnt,
-                                                      uint32_t *need_dense) {
+                                                      int metric, uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *need_dense) {
     const uint32_t b = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid == 0) {  // per-search state the later kernels count into (saves two memset launches)
-        cand_cnt[(size_t)b * PVS_CNT_STRIDE] = 0;
-        if (b < batch) need_dense[b] = 0;
-    }
+    if (tid == 0 && b < batch) need_dense[b] = 0;  // per-search state (saves a memset launch)
     uint8_t *mrow = qmat + (uint64_t)b * stride;
     // zero the scan operand row (padding bytes and padding queries contribute 0 to every dot)
     for (uint32_t i = tid * 16; i < stride; i += 256 * 16) *(uint4 *)(mrow + i) = make_uint4(0, 0, 0, 0);
@@ -427,10 +423,9 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
 
 hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *queries, uint32_t batch,
                                    uint32_t batch_pad, uint32_t dim, uint32_t stride, float scale, int metric,
-                                   uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *cand_cnt, uint32_t *need_dense,
-                                   hipStream_t s) {
+                                   uint8_t *qmat, void *qexact, QInfo *qinfo, uint32_t *need_dense, hipStream_t s) {
     hipLaunchKernelGGL(k_prep_queries, dim3(batch_pad), dim3(256), 0, s, index_dtype, qdtype, queries, batch, dim,
-                       stride, scale, metric, qmat, qexact, qinfo, cand_cnt, need_dense);
+                       stride, scale, metric, qmat, qexact, qinfo, need_dense);
     return hipGetLastError();
 }
 

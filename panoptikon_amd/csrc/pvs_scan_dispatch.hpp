@@ -9,10 +9,11 @@ struct ScanK {
     const QInfo *qinfo;
     const float *thr;
     float *gmin;
-    uint32_t *cand_cnt;
-    uint2 *cand;
+    uint2 *seg;          // MODE 1: candidate segments [n_segments][seg_queries][seg_cap] = (row, key bits)
+    uint32_t *seg_cnt;   // MODE 1: fill counts [seg_queries][seg_stride] (a count above seg_cap = the segment overflowed)
+    uint32_t seg_queries, seg_cap, seg_stride;
     uint64_t n_rows;
-    uint32_t stride, n_wgtiles, tile_step, groups_per_query, cand_cap, grid;
+    uint32_t stride, n_wgtiles, tile_step, groups_per_query, grid;
     uint32_t gmin_per_lane;  // MODE 0: minima written per lane (1, 2, 4, 8 or 16); groups_per_query = grid * RT * 2 * gmin_per_lane
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)

@@ -13,10 +13,9 @@
 //   pass C  (pvs_kernels_scan.hip) exact rerank of the few survivors.
 //
 // Geometry (64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
-//   workgroup = 4 waves; wave (qw, rt) owns GPW query groups of 32 queries (held in VGPRs for the whole kernel
-//   as MFMA B fragments) and row sub-tile rt (32 rows);
-//   QG = batch_pad/32 in {1,2,4,8}; GPW = 2 for QG = 8 (256 queries per pass, int8 rows up to 1 KiB), else 1;
-//   RT = 4*GPW/QG, workgroup tile = 32*RT rows.
+//   workgroup = 4 waves (8 for 256 queries); wave (qw, rt) owns one query group of 32 queries (held in VGPRs for the
+//   whole kernel as MFMA B fragments) and row sub-tile rt (32 rows);
+//   QG = batch_pad/32 in {1,2,4,8} (8 = 256 queries per pass: int8 rows up to 1 KiB); RT = WAVES/QG, tile = 32*RT rows.
 //   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
 //   in "slabs" of (32*RT rows x 256 B) grouped into chunks of SPB slabs (the whole 24 KiB tile for
 //   768-B rows and >= 128 queries): NC-chunk ring, NC-1 chunks in flight, one s_barrier and one counted
@@ -26,22 +25,26 @@
 //   of HBM landing lane-linear in LDS; reads are conflict-free for ds_read_b128's 16-lane groups.
 //   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 (f32 rows: scaled per row and narrowed to f16 on the
 //   way from LDS, see Acc<PVS_F32>) with A = 32 corpus rows, B = 32 queries:
-//   each lane ends up with ONE query per group (lane & 31) and 16 rows, so the per-query threshold is
-//   a lane-private register.
-//
-// Why 256 queries run as TWO groups per wave: one A fragment (1 KiB per wave-instruction, 8 LDS cycles per CU)
-// feeds one 32-cycle MFMA per query group.  With one group per wave the four SIMDs ask the CU's single LDS pipe for
-// 4 x 8 = 32 cycles of reads per 32 cycles of matrix-core time: at 256 queries LDS reads + DMA writes need more
-// cycles per tile than HBM delivers it in (the round-1 8-wave geometry: 2.0 ms against 0.96 ms of HBM time).  Two
-// groups per wave halve the LDS traffic; the 192 fragment registers that costs leave one wave per SIMD, which is
-// only workable because the pass-B epilogue is now ~1 VALU per score (below) instead of ~4.
+//   each lane ends up with ONE query (lane & 31) and 16 rows, so the per-query threshold is a lane-private register.
 //
 // Pass-B epilogue (MODE 1, int8 and f16 rows): "could any of this lane's 16 rows pass?" is answered without
 // touching the per-row scalars: fold the 16 accumulators with v_max3 (8 VALU) and compare with a per-(query, tile)
-// bound derived from the tile's extreme row scalars (k_scan_aux: min/max of |a| resp. |a|^2 over the 32 rows,
-// built at add time, streamed behind the row scalars) — a NECESSARY condition for the exact per-row test, so the emitted candidate set is exactly
-// what the per-row test alone would emit.  Only wave-tiles where some lane passes run the per-row test, with the
-// row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
+// bound derived from the tile's extreme row scalars (k_scan_aux: min/max of |a| resp. |a|^2 over the 32 rows, built at
+// add time, streamed behind the row scalars) — a NECESSARY condition for the exact per-row test, so the emitted
+// candidate set is exactly what the per-row test alone would emit.  Only wave-tiles where some lane passes run the
+// per-row test, with the row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
+//
+// What the round-2 measurements say (10M x 768 int8 on MI355X; DESIGN.md §4.1b has the table):
+//   * 128 queries: 1.25-1.29 ms = 6.0-6.1 TB/s — the on-box streaming ceiling (pvs_microbench: 6.0 TB/s through LDS-DMA,
+//     6.2 TB/s with plain loads; the 8 TB/s datasheet figure is not reachable by any read stream on this part).
+//   * 256 queries: 2.10 ms.  Ablations of the same binary: MFMA + fragment reads alone 1.32 ms; + LDS-DMA issue 1.57;
+//     + fold and pre-test 1.62; + per-row tests 1.70; + candidate emission 2.10.  The last step is NOT the cost of the
+//     emission instructions (~30 per candidate; replacing staging + flush + global atomics by one LDS atomic and one
+//     scalar store changed nothing): SQ_WAIT_ANY rises by 3,500 wave-cycles per candidate = ~440 cycles of serial
+//     latency in the emitting wave x the 8 waves that meet it at the next per-tile s_barrier (1.3 candidates per
+//     workgroup tile).  Everything a wave does alone is paid eight times; the remaining lever is an elastic hand-off
+//     (per-slot ready/done counters with one tile of slack) instead of the barrier.  Two query groups per wave
+//     (4 waves, ~340 registers, 1 wave per SIMD; PVS_WIDE_GPW2) measured 2.23 ms: nothing hides its in-order issue.
 #pragma once
 #include <cstdlib>
 
@@ -54,8 +57,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int WCAP = 64;          // candidate staging entries per WAVE (wave-private LDS region; with the scalar ring this
-                                  // keeps the 128-query instance at 2 workgroups per CU: 2 x 80,912 B)
 #ifndef PVS_PF
 #define PVS_PF 4                  // A fragments read ahead of the MFMA that consumes them (tuning experiments override it)
 #endif
@@ -123,12 +124,12 @@ constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 // chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
 template <int QG, int KSLABS>
 struct Geo {
-#ifdef PVS_WIDE8  // experiment: 256 queries as 8 waves x 1 group (2 waves per SIMD) instead of 4 waves x 2 groups
-    static constexpr int WAVES = QG == 8 ? 8 : 4;
-    static constexpr int GPW = 1;
-#else
+#ifndef PVS_WIDE_GPW2
+    static constexpr int WAVES = QG == 8 ? 8 : 4;  // 256 queries: 8 waves x 1 group, 2 waves per SIMD (measured 2.10 ms at 10M x 768)
+    static constexpr int GPW = 1;                  // query groups per wave
+#else  // tuning switch: 256 queries as 4 waves x 2 groups, 1 wave per SIMD, ~340 registers (measured 2.23 ms)
     static constexpr int WAVES = 4;
-    static constexpr int GPW = QG == 8 ? 2 : 1;  // query groups per wave
+    static constexpr int GPW = QG == 8 ? 2 : 1;
 #endif
     static constexpr int QW = QG / GPW;          // waves side by side along the queries
     static constexpr int RT = WAVES / QW;        // row sub-tiles per workgroup
@@ -145,13 +146,12 @@ struct Geo {
     static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
                                                           // same record): tiles in flight + the previous tile, kept for its epilogue
     static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 row-scalar DMA
-    static constexpr int LCAP = WAVES * WCAP;           // candidate staging entries per workgroup
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + 16 + LCAP * 12;
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + WAVES * GPW * 32 * 4;  // ring, row scalars, per-wave candidate counters
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
 
-#ifdef PVS_WIDE8
+#ifndef PVS_WIDE_GPW2
 constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
 constexpr int scan_threads(int QG) { return QG == 8 ? 512 : 256; }
 #else
@@ -165,16 +165,13 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     using A = Acc<DT>;
     using elem_t = typename A::elem;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
-                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, LCAP = G::LCAP, GPW = G::GPW, QW = G::QW, NCN = G::NCN;
+                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, GPW = G::GPW, QW = G::QW, NCN = G::NCN;
     constexpr bool COS = METRIC == PVS_COSINE;
     constexpr bool PRETEST = MODE == 1 && DT != PVS_F32;  // (f32 rows carry a per-row power-of-two scale in their sums)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
     uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NCN][WAVES][256 B]
-    uint32_t *const st_cnt = (uint32_t *)(normring + NCN * WAVES * 256);
-    uint32_t *const st_row = st_cnt + 4;
-    uint32_t *const st_key = st_row + LCAP;
-    uint32_t *const st_q = st_key + LCAP;
+    uint32_t *const seg_cnt = (uint32_t *)(normring + NCN * WAVES * 256);  // [WAVES][GPW][32] candidates emitted per query of the wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,6 +195,17 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
         for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
+    // Candidate emission (MODE 1).  Every (workgroup stream, query) pair owns a SEGMENT of a.seg_cap slots in HBM; the
+    // segment of query column j of this wave is written by this wave alone (its two half-waves hold different rows of
+    // the same 32 queries), so the fill counts live in wave-private LDS: no staging list, no flush, no global atomic.
+    // A segment that overflows is reported through its count (pass C then hands the query to the dense path).
+    uint32_t *const my_cnt = seg_cnt + (size_t)wave * (GPW * 32);
+    const uint32_t seg = blockIdx.x * RT + rt;  // this wave's segment index, shared by the QW waves side by side (different queries)
+    if (MODE == 1) {
+#pragma unroll
+        for (int g = 0; g < GPW; g++)
+            if (h == 0) my_cnt[g * 32 + j] = 0;
+    }
     if (n_my > 0) {
         // ---- query fragments: resident in registers for the whole kernel
         constexpr int SPS = steps_per_slab<DT>();
@@ -326,20 +334,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             for (int r = 0; r < 16; r++) hold[g][r] = 0;
         uint32_t prev_row_base = 0;
 
-        // wave-private candidate staging: fill count (wave-uniform) and the flush to HBM.  The flush
-        // issues global atomics/stores, which are unordered against the DMA loads the counted
-        // vmcnt waits rely on, so it ends with a full drain of this wave's VMEM queue.
-        uint32_t wcnt = 0;
-        auto flush_wave = [&]() {
-            for (uint32_t e = (uint32_t)lane; e < wcnt; e += 64) {
-                const uint32_t slot = (uint32_t)wave * WCAP + e;
-                const uint32_t q = st_q[slot];
-                const uint32_t gp = atomicAdd(&a.cand_cnt[(size_t)q * PVS_CNT_STRIDE], 1u);
-                if (gp < a.cand_cap) a.cand[(size_t)q * a.cand_cap + gp] = make_uint2(st_row[slot], st_key[slot]);
-            }
-            wcnt = 0;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        };
         // the previous tile's 16 row scalars of this lane (rows 4h + (r&3) + 8(r>>2)), from its slot of the scalar ring
         auto load_xh = [&](float(&xh)[16]) {
             if (p_nslot < 0) {  // tile "-1": every test fails
@@ -365,49 +359,47 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             if constexpr (DT == PVS_F32) return __builtin_ldexpf(d, -f32_row_exp<COS>(x));
             return d;
         };
-        // per-row emission for one group: rows whose exact filter test passes go to the wave's staging list.  One ballot per
-        // tile row r (compile-time r: no dynamic register indexing).  A full staging list is flushed from ONE site: the row
-        // loop stops at the row that does not fit, flushes and resumes there — inlining the flush at each of the 16 rows (x
-        // groups x accumulator parities) made the 256-query instance 75 KB of code, more than the instruction cache holds.
+        // per-row emission for one group: rows whose exact filter test passes are appended to the query's segment — with
+        // SCALAR stores (s_store_dwordx2, one per candidate, lane by lane off the ballot).  gfx9's vmcnt counts stores too,
+        // so a vector store issued here made the next counted LDS-DMA wait cover the store's acknowledgement as well: a
+        // partial drain of the prefetch ring on nearly every tile (1.3 candidates per workgroup tile at 256 queries; measured
+        // 0.43 of 2.1 ms, whatever the form: staged + flushed with atomics, or one plain store per candidate).  Scalar
+        // stores travel on lgkmcnt, which the LDS-DMA stream never touches; s_dcache_wb at the end of the kernel writes the
+        // scalar cache back for pass C.
         auto emit_rows = [&](int g, const float(&xh)[16], auto &&pv) {
-            int r0 = 0;  // rows below r0 are done
-            bool full;
-            do {
-                full = false;
+            const uint32_t q0 = (uint32_t)(qw * GPW + g) * 32u;  // first query of the group (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    if (r < r0 || full) continue;  // (wave-uniform)
-                    const float sv = score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]);
-                    const bool p = COS ? (sv >= tS[g]) : (sv <= tS[g]);
-                    unsigned long long bal = __builtin_amdgcn_ballot_w64(p);
+            for (int r = 0; r < 16; r++) {
+                const float sv = score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]);
+                bool p = COS ? (sv >= tS[g]) : (sv <= tS[g]);
 #ifdef PVS_ABL_NOEMIT
-                    asm volatile("" : "+s"(bal));
-                    bal = 0;
+                asm volatile("" ::"v"(p));
+                p = false;
 #endif
-                    if (bal != 0) {
-                        const uint32_t npass = (uint32_t)__builtin_popcountll(bal);
-                        if (__builtin_expect(wcnt + npass > (uint32_t)WCAP, 0)) {
-                            full = true;
-                            r0 = r;
-                            continue;
+                unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+                if (m != 0) {
+                    uint32_t payload;
+                    if constexpr (DT == PVS_I8)
+                        payload = (uint32_t)pv(g, r);  // exact integer dot
+                    else
+                        payload = __builtin_bit_cast(uint32_t, COS ? -sv * qi[g].dscale : sv + qi[g].bb + qi[g].eR * xh[r]);
+                    const uint32_t rowv = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    uint32_t pos = 0;
+                    if (p) pos = atomicAdd(&my_cnt[g * 32 + j], 1u);  // LDS, wave-private; both half-waves hold rows of query j
+                    do {
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t pos_s = (uint32_t)__builtin_amdgcn_readlane((int)pos, l);
+                        if (pos_s < a.seg_cap) {
+                            const uint32_t row_s = (uint32_t)__builtin_amdgcn_readlane((int)rowv, l);
+                            const uint32_t key_s = (uint32_t)__builtin_amdgcn_readlane((int)payload, l);
+                            const uint2 *dst = a.seg + ((size_t)seg * a.seg_queries + (q0 + ((uint32_t)l & 31u))) * a.seg_cap + pos_s;
+                            const uint64_t data = ((uint64_t)key_s << 32) | row_s;
+                            asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" ::"s"(data), "s"(dst) : "memory");
                         }
-                        uint32_t payload;
-                        if constexpr (DT == PVS_I8)
-                            payload = (uint32_t)pv(g, r);  // exact integer dot
-                        else
-                            payload = __builtin_bit_cast(uint32_t, COS ? -sv * qi[g].dscale : sv + qi[g].bb + qi[g].eR * xh[r]);
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        if (p) {
-                            const uint32_t slot = (uint32_t)wave * WCAP + wcnt + rank;
-                            st_row[slot] = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
-                            st_key[slot] = payload;
-                            st_q[slot] = (uint32_t)myq[g];
-                        }
-                        wcnt += npass;
-                    }
+                    } while (m != 0);
                 }
-                if (full) flush_wave();
-            } while (full);
+            }
         };
         // ---- epilogue of the previous tile, cut into micro-steps the main loop drops between MFMAs, plus a rest.
         //  PRETEST: 8 steps per group (v_max3 fold of two accumulators each) — no row scalar is touched;
@@ -666,8 +658,13 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 run_tile(tl, acc, acc1, ph);
             }
         }
-        if (MODE == 1) flush_wave();
-        wait_vm<0>();  // retire the dummy tail DMAs before LDS is reused / the wave exits
+        wait_vm<0>();  // retire the dummy tail DMAs before the wave exits
+        if (MODE == 1) asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // candidates: scalar cache -> L2
+    }
+    if (MODE == 1) {   // this wave's fill counts: seg_cnt[query][segment]
+#pragma unroll
+        for (int g = 0; g < GPW; g++)
+            if (h == 0) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = my_cnt[g * 32 + j];
     }
 
     if (MODE == 0) {

@@ -45,7 +45,7 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
     const size_t qesz = qdtype == PVS_I8 ? 1 : 4;
     const uint8_t *qsrc = (const uint8_t *)d_queries + (size_t)qoff * ix->dim * qesz;
     HIP_TRY(pvs_launch_prep_queries((int)ix->dtype, qdtype, qsrc, nb, batch_pad, ix->dim, ix->stride, ix->scale, metric, c.d_qmat,
-                                    c.d_qexact, c.d_qinfo, c.d_cand_cnt, c.d_need_dense + qoff, c.stream));
+                                    c.d_qexact, c.d_qinfo, c.d_need_dense + qoff, c.stream));
     return PVS_OK;
 }
 
@@ -91,9 +91,8 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.qmat = c.d_qmat;
         a.qinfo = c.d_qinfo;
         a.thr = c.d_thr;
-        a.cand_cnt = c.d_cand_cnt;
-        a.cand = c.d_cand;
-        a.cand_cap = PVS_CAND_CAP;
+        a.seg = c.d_seg;
+        a.seg_cnt = c.d_seg_cnt;
         a.gmin = c.d_gmin;
         const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
@@ -128,7 +127,8 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.mode = 1;
         a.tile_step = 1;
         const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
-        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu, PVS_SEG_PAIRS / (batch_pad * rt)});
+        a.n_segments = a.grid * rt;
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
@@ -144,7 +144,10 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         f.n_rows = ix->n;
         f.qexact = c.d_qexact;
         f.qinfo = c.d_qinfo;
-        f.cand_cnt = c.d_cand_cnt;
+        f.seg = c.d_seg;
+        f.seg_cnt = c.d_seg_cnt;
+        f.n_segments = a.n_segments;
+        f.seg_queries = batch_pad;
         f.cand = c.d_cand;
         f.cand_cap = PVS_CAND_CAP;
         f.batch = nb;
@@ -153,11 +156,15 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         f.out_dist = od;
         f.out_count = oc;
         f.need_dense = c.d_need_dense + qoff;
+        f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
         span_begin(ix, c, 2, 0);
         HIP_TRY(pvs_launch_finalize(f, c.stream));
         span_end(ix, c);
     }
-    if (fast) HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+    if (fast) {
+        HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(c.h_need_dense + c.flags_cap, c.d_need_dense + c.flags_cap, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+    }
     HIP_TRY(hipEventRecord(c.done, c.stream));
     return PVS_OK;
 }
@@ -166,7 +173,12 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
 pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                    int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
     uint32_t n_dense = 0;
-    for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
+    uint64_t seen = 0;
+    for (uint32_t q = 0; q < batch; q++) {
+        n_dense += c.h_need_dense[q] ? 1 : 0;
+        seen += c.h_need_dense[c.flags_cap + q];
+    }
+    ix->last_candidates = seen;
     ix->fast_queries += batch - n_dense;
     if (!n_dense) return PVS_OK;
     if (ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "%u queries need the dense path but path=2 forbids it", n_dense);

@@ -1,0 +1,16 @@
+set -x
+O=gpurun_out/r2h; mkdir -p $O
+variant() { # name flags...
+  name=$1; shift
+  touch panoptikon_amd/csrc/pvs_scan_i8.hip
+  PVS_FLAGS_pvs_scan_i8="-DPVS_ONLY_KS3 $*" python -m panoptikon_amd.build > $O/build_$name.log 2>&1 || { echo "build $name failed"; tail -5 $O/build_$name.log; return; }
+  for b in 256; do timeout 200 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-peaks --no-verify > $O/${name}_b$b.json 2> $O/${name}_b$b.err; done
+}
+variant w8 -DPVS_WIDE8
+variant w8_noflush -DPVS_WIDE8 -DPVS_ABL_NOFLUSH
+variant w8_noatom -DPVS_WIDE8 -DPVS_ABL_NOATOM
+variant w8_wcap256 -DPVS_WIDE8 -DPVS_WCAP=256
+variant w8_inlineflush -DPVS_WIDE8 -DPVS_INLINE_FLUSH
+variant w8_noemit -DPVS_WIDE8 -DPVS_ABL_NOEMIT
+variant w8_foldonly -DPVS_WIDE8 -DPVS_ABL_FOLDONLY
+ls $O
