@@ -28,9 +28,11 @@
  *                                filters/exact.rs:67-165, pql/builder.rs:578-582
  *   pvs_similar_to[_ex]          SimilarTo: self-join fan-out, confidence weights, CLIP cross-modal gates,
  *                                filters/item_similarity.rs:84-142, 432-581
- *   pvs_row_number[_dir] / pvs_rrf_fuse
+ *   pvs_row_number[_dir] / pvs_rrf_fuse / pvs_coalesce_ranks / pvs_coalesce_values
  *                                add_rank_column_expr pql/builder.rs:757-771 and
- *                                build_coalesced_expr pql/builder.rs:1284-1317
+ *                                build_coalesced_expr pql/builder.rs:1284-1317 (RRF arm and min/max(coalesce) arm)
+ *   pvs_sort_bounds / pvs_search_bounded
+ *                                apply_sort_bounds (gt / lt on order_rank), pql/builder.rs:781-815
  *   pvs_rrf_search               the OR arm over vector filters: UNION of the branches (pql/builder.rs:638-661),
  *                                per-branch row_number(), RRF score, ORDER BY ... LIMIT k
  *   pvs_index_read_ids / pvs_index_read_rows
@@ -208,6 +210,13 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
                                pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space,
                                int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
+/* pvs_search under apply_sort_bounds (pql/builder.rs:781-815: `WHERE order_rank > gt AND order_rank < lt` with order_rank =
+ * the distance, a SQL REAL): page 1 of the rows whose distance lies inside the bounds; have_gt / have_lt select them.
+ * Rows with a NULL distance never pass a bound.  out_count[q] = min(k, rows inside the bounds). */
+pvs_status pvs_search_bounded(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
+                              pvs_metric metric, int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids,
+                              float *out_dist, uint32_t *out_count);
+
 /* Same, with every buffer resident in HBM (queries, out_*).  Enqueues on one of
  * the index's streams and returns without synchronising; *out_ticket identifies
  * the stream to wait on with pvs_wait (or pvs_sync for all of them).  At most 16 searches (the size of the
@@ -348,6 +357,17 @@ pvs_status pvs_row_number_dir(const double *values, const int64_t *ids, uint64_t
  * ranks: [n_branches][n], rank < 0 = NULL (branch did not return the row). */
 pvs_status pvs_rrf_fuse(const int64_t *ranks, uint32_t n_branches, uint64_t n, const int32_t *ks,
                         const double *weights, double *out_fused);
+
+/* Same-priority order filters WITHOUT rrf (pql/builder.rs:1303-1317): the combined order key is
+ *   min(coalesce(rank_b, 9223372036854775805), ...) ascending / max(coalesce(rank_b, -9223372036854775805), ...) descending.
+ * pvs_coalesce_ranks: integer ranks [n_filters][n], rank < 0 = NULL.  pvs_coalesce_values: raw f64 aggregates (order_rank
+ * without row_n), NaN = NULL; a row no filter returned comes out as the fallback's nearest double. */
+pvs_status pvs_coalesce_ranks(const int64_t *ranks, uint32_t n_filters, uint64_t n, int32_t descending, int64_t *out);
+pvs_status pvs_coalesce_values(const double *values, uint32_t n_filters, uint64_t n, int32_t descending, double *out);
+/* apply_sort_bounds (pql/builder.rs:781-815): keep[i] = order_rank[i] > gt AND order_rank[i] < lt, each bound optional
+ * (have_gt / have_lt); NaN = NULL fails any comparison.  The device form for a distance column is pvs_search_bounded. */
+pvs_status pvs_sort_bounds(const double *order_rank, uint64_t n, int32_t have_gt, double gt, int32_t have_lt, double lt,
+                           uint8_t *keep);
 
 /* -------------------------------------------------- query ingestion / policy */
 /* .npy (v1/2/3; f2 f4 f8 i1-8 u1-8 bool; LE/BE; C/Fortran; 1-D or first row of

@@ -78,6 +78,10 @@ def lib() -> C.CDLL:
         L.orc_row_number_dir.argtypes = [vp, vp, sz, i32, vp]
         L.orc_rrf_score.restype = d
         L.orc_rrf_score.argtypes = [vp, vp, vp, sz]
+        L.orc_coalesce_rank.restype = C.c_int64
+        L.orc_coalesce_rank.argtypes = [vp, sz, C.c_int]
+        L.orc_sort_bounds_keep.restype = C.c_int
+        L.orc_sort_bounds_keep.argtypes = [d, C.c_int, d, C.c_int, d]
         L.orc_synth_gauss.restype = f
         L.orc_synth_gauss.argtypes = [C.c_uint64, C.c_uint64, u32]
         L.orc_synth_rows.argtypes = [C.c_uint64, C.c_uint64, sz, u32, vp]
@@ -364,6 +368,17 @@ def rrf_score(ranks, ks, weights) -> float:
     k = _c(ks, np.int32)
     w = _c(weights, np.float64)
     return float(lib().orc_rrf_score(_p(r), _p(k), _p(w), r.size))
+
+
+def coalesce_rank(ranks, descending: bool = False) -> int:
+    """builder.rs:1303-1317 for one row: ranks < 0 encode SQL NULL."""
+    r = _c(ranks, np.int64)
+    return int(lib().orc_coalesce_rank(_p(r), r.size, int(descending)))
+
+
+def sort_bounds_keep(order_rank: float, gt=None, lt=None) -> bool:
+    """builder.rs:781-815 for one row (NaN = NULL)."""
+    return bool(lib().orc_sort_bounds_keep(float(order_rank), int(gt is not None), float(gt or 0.0), int(lt is not None), float(lt or 0.0)))
 
 
 # -------------------------------------------------------------- synthetic

@@ -669,6 +669,24 @@ ORC_API double orc_rrf_score(const int64_t *ranks, const int32_t *ks, const doub
     return total;
 }
 
+/* builder.rs:1303-1317: same-priority order filters without rrf: min(coalesce(rank_i, BIG), ...) ascending,
+ * max(coalesce(rank_i, -BIG), ...) descending; rank < 0 encodes SQL NULL. */
+ORC_API int64_t orc_coalesce_rank(const int64_t *ranks, size_t nb, int descending) {
+    int64_t best = 0;
+    for (size_t i = 0; i < nb; i++) {
+        int64_t v = ranks[i] < 0 ? (descending ? -VERY_LARGE_NUMBER : VERY_LARGE_NUMBER) : ranks[i];
+        if (i == 0 || (descending ? v > best : v < best)) best = v;
+    }
+    return best;
+}
+
+/* builder.rs:781-815: WHERE order_rank > gt AND order_rank < lt (each optional); NaN = NULL fails a comparison */
+ORC_API int orc_sort_bounds_keep(double order_rank, int have_gt, double gt, int have_lt, double lt) {
+    if (have_gt && !(order_rank > gt)) return 0;
+    if (have_lt && !(order_rank < lt)) return 0;
+    return 1;
+}
+
 /* -------------------------------------------------- synthetic generator */
 
 /* SURVEY §8d synthetic inputs: unit-normalised standard-normal rows, the

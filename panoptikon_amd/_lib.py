@@ -91,6 +91,7 @@ SYMBOLS = {
     "pvs_index_set_profiling": (_i32, [_vp, _i32]),
     "pvs_index_get_profile": (_i32, [_vp, C.POINTER(Profile), _i32]),
     "pvs_search": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_search_bounded": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, C.c_double, _i32, C.c_double, _vp, _vp, _vp]),
     "pvs_search_device": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_wait": (_i32, [_vp, _u32]),
     "pvs_sync": (_i32, [_vp]),
@@ -117,6 +118,9 @@ SYMBOLS = {
     "pvs_row_number": (_i32, [_vp, _vp, _u64, _vp]),
     "pvs_row_number_dir": (_i32, [_vp, _vp, _u64, _i32, _vp]),
     "pvs_rrf_fuse": (_i32, [_vp, _u32, _u64, _vp, _vp, _vp]),
+    "pvs_coalesce_ranks": (_i32, [_vp, _u32, _u64, _i32, _vp]),
+    "pvs_coalesce_values": (_i32, [_vp, _u32, _u64, _i32, _vp]),
+    "pvs_sort_bounds": (_i32, [_vp, _u64, _i32, C.c_double, _i32, C.c_double, _vp]),
     "pvs_npy_to_f32": (_i32, [_vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "pvs_resolve_vector_quant": (_i32, [_i32, C.c_char_p, _i64, C.POINTER(ReadyPair), _vp, _sz, _vp, _sz,
                                         C.POINTER(QuantResolved)]),

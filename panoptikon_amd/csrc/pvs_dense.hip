@@ -10,11 +10,15 @@
 
 // keys: real distances ascending, then NULL distances (0xfffffffe), then rows outside the candidate set
 // (mask[i] == 0 -> 0xffffffff: sorted to the very end and never emitted)
-__global__ void k_dense_keys(const float *dist, const uint8_t *mask, uint64_t n, uint32_t *keys, uint32_t *vals) {
+__global__ void k_dense_keys(const float *dist, const uint8_t *mask, uint64_t n, uint32_t *keys, uint32_t *vals, DenseBounds b) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t k = f32_sort_key(dist[i]);
         if (k == 0xffffffffu) k = 0xfffffffeu;
         if (mask && !mask[i]) k = 0xffffffffu;
+        // apply_sort_bounds (builder.rs:781-815): order_rank is the f32 distance widened to a SQL REAL; NULL fails a comparison
+        const double d = (double)dist[i];
+        if (b.have_gt && !(d > b.gt)) k = 0xffffffffu;
+        if (b.have_lt && !(d < b.lt)) k = 0xffffffffu;
         keys[i] = k;
         vals[i] = (uint32_t)i;
     }
@@ -75,12 +79,12 @@ pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n) {
 }
 
 pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids, float *out_dist,
-                          uint32_t *out_count, hipStream_t s, const uint8_t *mask) {
+                          uint32_t *out_count, hipStream_t s, const uint8_t *mask, DenseBounds bounds) {
     if (n > w.cap_rows) return pvs_fail(PVS_ERR_STATE, "dense workspace too small");
     if (n > 0x7fffffffull) return pvs_fail(PVS_ERR_UNSUPPORTED, "dense path limited to 2^31-1 rows per shard");
     if (n > 0) {
         unsigned g = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-        hipLaunchKernelGGL(k_dense_keys, dim3(g), dim3(256), 0, s, w.d_dist, mask, n, w.d_keys_in, w.d_vals_in);
+        hipLaunchKernelGGL(k_dense_keys, dim3(g), dim3(256), 0, s, w.d_dist, mask, n, w.d_keys_in, w.d_vals_in, bounds);
         size_t tb = w.temp_bytes;
         // stable LSD radix sort: equal distances keep ascending row order = ascending id
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.d_temp, tb, w.d_keys_in, w.d_keys_out, w.d_vals_in, w.d_vals_out, (int)n, 0,

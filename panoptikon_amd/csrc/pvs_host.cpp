@@ -140,6 +140,60 @@ PVS_EXPORT pvs_status pvs_rrf_fuse(const int64_t *ranks, uint32_t n_branches, ui
     return PVS_OK;
 }
 
+// builder.rs:1303-1317: filters of the same order priority WITHOUT rrf coalesce into
+//   min(coalesce(rank_1, 9223372036854775805), ...)   ascending
+//   max(coalesce(rank_1, -9223372036854775805), ...)  descending
+// (SQLite's multi-argument min()/max(); a filter that did not return the row contributes its NULL).
+static const int64_t PVS_VERY_LARGE = 9223372036854775805LL;  // builder.rs:17-18
+PVS_EXPORT pvs_status pvs_coalesce_ranks(const int64_t *ranks, uint32_t n_filters, uint64_t n, int32_t descending, int64_t *out) {
+    if (n && n_filters && (!ranks || !out)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (n_filters == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "at least one filter");
+    for (uint64_t i = 0; i < n; i++) {
+        int64_t best = 0;
+        for (uint32_t b = 0; b < n_filters; b++) {
+            const int64_t r = ranks[(uint64_t)b * n + i];
+            const int64_t v = r < 0 ? (descending ? -PVS_VERY_LARGE : PVS_VERY_LARGE) : r;
+            best = b == 0 ? v : (descending ? std::max(best, v) : std::min(best, v));
+        }
+        out[i] = best;
+    }
+    return PVS_OK;
+}
+// the same over raw aggregates (order_rank without row_n is the f64 aggregate itself): NaN = NULL.  In SQL the fallback is
+// an INTEGER and SQLite compares integers with reals exactly; as an f64 result that is indistinguishable from comparing
+// with the fallback's nearest double (+-2^63): a real on the other side of it is on the other side of 2^63 too.
+PVS_EXPORT pvs_status pvs_coalesce_values(const double *values, uint32_t n_filters, uint64_t n, int32_t descending, double *out) {
+    if (n && n_filters && (!values || !out)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (n_filters == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "at least one filter");
+    const double big = descending ? -9223372036854775808.0 : 9223372036854775808.0;
+    for (uint64_t i = 0; i < n; i++) {
+        double best = 0.0;
+        for (uint32_t b = 0; b < n_filters; b++) {
+            double v = values[(uint64_t)b * n + i];
+            if (std::isnan(v)) v = big;
+            best = b == 0 ? v : (descending ? std::max(best, v) : std::min(best, v));
+        }
+        out[i] = best;
+    }
+    return PVS_OK;
+}
+
+// builder.rs:781-815 apply_sort_bounds: `WHERE order_rank > gt AND order_rank < lt` on the wrapped filter CTE.  keep[i] = 1 for
+// rows that stay; a NULL order_rank fails both comparisons (SQL three-valued logic).  have_gt / have_lt select the bounds.
+PVS_EXPORT pvs_status pvs_sort_bounds(const double *order_rank, uint64_t n, int32_t have_gt, double gt, int32_t have_lt, double lt,
+                                      uint8_t *keep) {
+    if (n && (!order_rank || !keep)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    for (uint64_t i = 0; i < n; i++) {
+        const double v = order_rank[i];
+        bool ok = true;
+        if (have_gt) ok = ok && v > gt;  // false for NaN
+        if (have_lt) ok = ok && v < lt;
+        if (!have_gt && !have_lt) ok = true;  // no bounds: the reference does not wrap the query at all (NULL rows stay)
+        keep[i] = ok ? 1 : 0;
+    }
+    return PVS_OK;
+}
+
 // ------------------------------------------------------------ host k-way merge
 PVS_EXPORT pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world, uint32_t batch,
                                      uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {

@@ -108,8 +108,13 @@ pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n);
 void pvs_dense_release(DenseWork &w);
 // sorts d_dist[0..n) by (distance, row) and writes the first k (ids via ids[]) for one query
 // mask (optional, [n] bytes on the device): rows with mask == 0 are not candidates at all
+struct DenseBounds {  // apply_sort_bounds on the distance column: rows outside (gt, lt) are not candidates at all
+    int have_gt = 0, have_lt = 0;
+    double gt = 0.0, lt = 0.0;
+};
 pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids,
-                          float *out_dist, uint32_t *out_count, hipStream_t s, const uint8_t *mask = nullptr);
+                          float *out_dist, uint32_t *out_count, hipStream_t s, const uint8_t *mask = nullptr,
+                          DenseBounds bounds = DenseBounds());
 // aux / out: the scan's row-scalar stream in tile records (cap/32 * PVS_AUX_REC floats); rows outside the mask get a NaN
 // scalar (a NaN scalar makes every filter comparison of the row false)
 hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s);

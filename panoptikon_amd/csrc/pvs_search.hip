@@ -30,12 +30,12 @@ bool fast_path_ok(const pvs_index *ix, uint32_t k) {
 
 // one query through the dense path; q is the query's index inside the current chunk
 static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k, int metric, int64_t *out_ids, float *out_dist,
-                            uint32_t *out_count) {
+                            uint32_t *out_count, DenseBounds bounds = DenseBounds()) {
     PVS_TRY(pvs_dense_reserve(c.dense, ix->n));
     const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
     HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, 1,
                                    c.d_qpad, c.dense.d_dist, 1, 0, (uint32_t)ix->n_cu, c.stream));
-    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask));
+    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask, bounds));
     ix->dense_queries++;
     return PVS_OK;
 }
@@ -312,6 +312,62 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
     }
+    ix->searches++;
+    ctx_done(ix, c);
+    return st;
+}
+
+// pvs_search restricted by apply_sort_bounds (pql/builder.rs:781-815) on the distance: page 1 of the rows with gt < d < lt.
+// Every row is scored exactly and the ones outside the bounds leave the sort (dense path; a lower bound `gt` makes the first
+// k rows of the plain ordering useless, so the filter scan's "k best" machinery does not apply).
+PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                         int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist,
+                                         uint32_t *out_count) {
+    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_search_bounded is not served on a multi-device index");
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if ((have_gt && gt != gt) || (have_lt && lt != lt)) return pvs_fail(PVS_ERR_INVALID_ARG, "bounds must be numbers");
+    if (batch == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    DenseBounds b;
+    b.have_gt = have_gt != 0;
+    b.have_lt = have_lt != 0;
+    b.gt = gt;
+    b.lt = lt;
+    auto body = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, batch, k, true));
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        if (qbytes * batch > c->qstage_cap) {
+            hipFree(c->d_qstage);
+            c->d_qstage = nullptr;
+            c->qstage_cap = 0;
+            const size_t cap = pvs_round_up(qbytes * batch, 1 << 16);
+            HIP_TRY(hipMalloc(&c->d_qstage, cap));
+            c->qstage_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_qstage, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        if (ix->n == 0) {
+            HIP_TRY(hipMemsetAsync(c->d_out_count, 0, 4 * (size_t)batch, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_out_ids, 0xff, 8 * (size_t)batch * k, c->stream));
+            HIP_TRY(pvs_launch_fill_f32(c->d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c->stream));
+        }
+        for (uint32_t qoff = 0; qoff < batch && ix->n; qoff += PVS_MAX_BATCH) {
+            const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
+            PVS_TRY(prep_chunk(ix, *c, c->d_qstage, qdtype, qoff, nb, 32 * ((nb + 31) / 32), metric));
+            for (uint32_t q = 0; q < nb; q++)
+                PVS_TRY(dense_one(ix, *c, q, k, metric, c->d_out_ids + (size_t)(qoff + q) * k, c->d_out_dist + (size_t)(qoff + q) * k,
+                                  c->d_out_count + qoff + q, b));
+        }
+        HIP_TRY(hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) (void)hipStreamSynchronize(c->stream);
     ix->searches++;
     ctx_done(ix, c);
     return st;

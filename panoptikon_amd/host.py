@@ -69,6 +69,30 @@ def rrf_fuse(ranks, ks, weights) -> np.ndarray:
     return out[: r.shape[1]]
 
 
+def coalesce_ranks(ranks, descending: bool = False) -> np.ndarray:
+    """min/max(coalesce(rank_b, +-9223372036854775805)) over same-priority filters (builder.rs:1303-1317); ranks [nb][n], < 0 = NULL."""
+    r = np.ascontiguousarray(ranks, np.int64)
+    out = np.empty(max(r.shape[1], 1), np.int64)
+    L.check(L.lib().pvs_coalesce_ranks(_ptr(r), r.shape[0], r.shape[1], int(descending), _ptr(out)))
+    return out[: r.shape[1]]
+
+
+def coalesce_values(values, descending: bool = False) -> np.ndarray:
+    """the same over raw f64 aggregates (NaN = NULL)."""
+    v = np.ascontiguousarray(values, np.float64)
+    out = np.empty(max(v.shape[1], 1), np.float64)
+    L.check(L.lib().pvs_coalesce_values(_ptr(v), v.shape[0], v.shape[1], int(descending), _ptr(out)))
+    return out[: v.shape[1]]
+
+
+def sort_bounds(order_rank, gt=None, lt=None) -> np.ndarray:
+    """apply_sort_bounds (builder.rs:781-815): boolean keep mask for `order_rank > gt AND order_rank < lt` (NaN = NULL fails)."""
+    v = np.ascontiguousarray(order_rank, np.float64)
+    keep = np.zeros(max(v.size, 1), np.uint8)
+    L.check(L.lib().pvs_sort_bounds(_ptr(v), v.size, int(gt is not None), float(gt or 0.0), int(lt is not None), float(lt or 0.0), _ptr(keep)))
+    return keep[: v.size].astype(bool)
+
+
 def rrf_search(branches, k: int):
     """branches: dicts {index, query, metric, agg=AGG_MIN, row_weights=None, descending=False, rrf_k=1, weight=1.0}.
     OR-composition ranked by reciprocal-rank fusion on the device (pvs_rrf_search) -> (groups[k'], scores[k'])."""

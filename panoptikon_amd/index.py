@@ -167,6 +167,17 @@ class VectorIndex:
         L.check(L.lib().pvs_search(self._h, _ptr(q), qd, b, k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
 
+    def search_bounded(self, queries, k: int, metric: int = L.COSINE, gt=None, lt=None):
+        """pvs_search restricted to rows with gt < distance < lt (apply_sort_bounds, builder.rs:781-815)."""
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        ids = np.full((b, k), -1, np.int64)
+        dist = np.full((b, k), np.nan, np.float32)
+        cnt = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_bounded(self._h, _ptr(q), qd, b, k, metric, int(gt is not None), float(gt or 0.0), int(lt is not None),
+                                           float(lt or 0.0), _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
     def search_filtered(self, queries, k: int, allowed_rows, metric: int = L.COSINE):
         """pvs_search over the rows whose byte in `allowed_rows` ([rows] uint8/bool, row order) is non-zero."""
         q, qd = self._queries(queries)

@@ -1183,3 +1183,35 @@ def test_near_tied_scores_with_coherent_rounding(pvs, dtype):
     assert ix.stats().dense_queries == 0, "the filter path itself must get this right"
     _check(pvs, ix, dt, pvs.L2, hc, q, k)
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_search_bounded_applies_sort_bounds_on_the_distance(pvs, dtype):
+    """apply_sort_bounds (pql/builder.rs:781-815): `WHERE order_rank > gt AND order_rank < lt` over the distance column, then
+    the page.  Oracle: every row's exact distance, the SQL predicate in f64, (distance, id) order."""
+    pdt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    odt = {"i8": orc.I8, "f16": orc.F16, "f32": orc.F32}[dtype]
+    n, dim, k = 5000, 200, 60
+    rows = unit_rows(91, n, dim)
+    rows[17] = 0.0  # NULL cosine distance: never inside a bound
+    scale = orc.compute_int8_scale(rows) if dtype == "i8" else None
+    ix = make_index(pvs, pdt, rows, scale)
+    corpus = host_corpus(odt, rows, scale)
+    qs = orc.synth_rows(92, 0, 3, dim)
+    hq = orc.quantize_int8(qs, scale) if dtype == "i8" else qs
+    for metric, om in ((pvs.COSINE, orc.COSINE), (pvs.L2, orc.L2)):
+        for qi in range(len(qs)):
+            d = orc.score_all(odt, om, corpus, hq[qi])
+            lo, hi = np.nanquantile(d, 0.01), np.nanquantile(d, 0.03)
+            for gt, lt in ((None, float(hi)), (float(lo), None), (float(lo), float(hi)), (float(hi), float(lo)), (None, None)):
+                keep = np.array([orc.sort_bounds_keep(float(x), gt, lt) for x in d.astype(np.float64)]) if (gt is not None or lt is not None) \
+                    else np.ones(n, bool)
+                ids = np.flatnonzero(keep)
+                ei, ed = orc.topk(d[ids], k, ids=ids.astype(np.int64))
+                gi, gd, gc = ix.search_bounded(qs[qi], k, metric, gt=gt, lt=lt)
+                assert gc[0] == len(ei), (dtype, metric, gt, lt)
+                assert np.array_equal(gi[0, : len(ei)], ei)
+                got = gd[0, : len(ei)]
+                assert np.array_equal(np.isnan(got), np.isnan(ed)) and np.array_equal(got[~np.isnan(got)].view(np.uint32), ed[~np.isnan(ed)].view(np.uint32))
+                assert (gi[0, len(ei):] == -1).all()
+    ix.close()

@@ -274,6 +274,49 @@ def test_rrf_expression_and_aggregate_null_semantics_pinned_against_sqlite():
     assert [None if np.isnan(x) else float(x) for x in v] == [r[1] for r in sql]
 
 
+def test_coalesce_arm_and_sort_bounds_pinned_against_sqlite():
+    """The non-RRF arm of build_coalesced_expr (builder.rs:1303-1317) and apply_sort_bounds (:781-815), evaluated by
+    SQLite itself on the expressions the builder renders, against the oracle and the C ABI's host functions."""
+    import sqlite3
+
+    import panoptikon_amd as pvs
+
+    BIG = 9223372036854775805
+    rng = np.random.default_rng(8)
+    n = 400
+    ranks = rng.integers(1, 5000, (3, n)).astype(np.int64)
+    ranks[rng.random((3, n)) < 0.3] = -1  # NULL: the filter did not return the row
+    ranks[:, 0] = -1                      # a row no filter returned
+    conn = sqlite3.connect(":memory:")
+    conn.execute("CREATE TABLE t (i INTEGER PRIMARY KEY, a, b, c)")
+    conn.executemany("INSERT INTO t VALUES (?, ?, ?, ?)",
+                     [(i, *[None if ranks[b, i] < 0 else int(ranks[b, i]) for b in range(3)]) for i in range(n)])
+    for desc, fn, fb in ((False, "min", BIG), (True, "max", -BIG)):
+        got = [r[0] for r in conn.execute(f"SELECT {fn}(coalesce(a, {fb}), coalesce(b, {fb}), coalesce(c, {fb})) FROM t ORDER BY i")]
+        exp_o = [orc.coalesce_rank(ranks[:, i], desc) for i in range(n)]
+        assert got == exp_o, "oracle restatement differs from SQLite"
+        assert pvs.coalesce_ranks(ranks, desc).tolist() == got
+        assert got[0] == fb
+    # raw aggregates (order_rank without row_n): reals against the integer fallback
+    vals = rng.standard_normal((2, n)) * 3
+    vals[rng.random((2, n)) < 0.3] = np.nan
+    vals[:, 1] = np.nan
+    vals[0, 2], vals[1, 2] = 1e19, np.nan     # a real beyond the fallback: the INTEGER fallback wins ascending
+    conn.execute("CREATE TABLE v (i INTEGER PRIMARY KEY, a REAL, b REAL)")
+    conn.executemany("INSERT INTO v VALUES (?, ?, ?)", [(i, *[None if np.isnan(vals[b, i]) else float(vals[b, i]) for b in range(2)]) for i in range(n)])
+    for desc, fn, fb in ((False, "min", BIG), (True, "max", -BIG)):
+        got = np.array([float(r[0]) for r in conn.execute(f"SELECT {fn}(coalesce(a, {fb}), coalesce(b, {fb})) FROM v ORDER BY i")])
+        assert np.array_equal(pvs.coalesce_values(vals, desc), got)
+    # sort bounds on order_rank (REAL aggregate or INTEGER rank), NULL rows drop out as soon as a bound is given
+    col = vals[0].copy()
+    for gt, lt in ((None, None), (-0.5, None), (None, 1.25), (-1.0, 2.0), (3.0, -3.0)):
+        conds = " AND ".join(x for x in [None if gt is None else f"a > {gt!r}", None if lt is None else f"a < {lt!r}"] if x)
+        rows = {r[0] for r in conn.execute(f"SELECT i FROM v {'WHERE ' + conds if conds else ''}")}
+        keep = pvs.sort_bounds(col, gt, lt)
+        assert set(np.flatnonzero(keep).tolist()) == rows, (gt, lt)
+        assert [orc.sort_bounds_keep(x, gt, lt) for x in col] == keep.tolist()
+
+
 def test_synth_rows_are_unit_vectors_and_deterministic():
     a = orc.synth_rows(20260928, 0, 64, 768)
     b = orc.synth_rows(20260928, 32, 32, 768)
