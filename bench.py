@@ -98,6 +98,32 @@ def which_config(n, d, dtype, b, k, metric):
     return "not a BASELINE config"
 
 
+def sqlite_udf_baseline(orc, odt, omet, rows, q, k, n_total):
+    """`SELECT id, vec_distance_*(embedding, ?) AS d FROM embeddings ORDER BY d LIMIT k` through stdlib SQLite,
+    one scalar-function call per row like the reference (db/sql_functions.rs:105-128 registers sqlite-vec's); the function body is
+    the CPU oracle's.  One thread = one read connection.  Extrapolated linearly to the corpus."""
+    import sqlite3
+
+    conn = sqlite3.connect(":memory:")
+    conn.execute("CREATE TABLE embeddings (id INTEGER PRIMARY KEY, embedding BLOB)")
+    conn.executemany("INSERT INTO embeddings VALUES (?, ?)", ((i, r.tobytes()) for i, r in enumerate(rows)))
+    dt = rows.dtype
+    name = "vec_distance_cosine" if omet == orc.COSINE else "vec_distance_L2"
+
+    def udf(a, b):
+        v = orc.vec_distance(omet, np.frombuffer(a, dt), np.frombuffer(b, dt))
+        return None if v != v else float(v)
+
+    conn.create_function(name, 2, udf, deterministic=True)
+    t = time.perf_counter()
+    page = conn.execute(f"SELECT id, {name}(embedding, ?) AS d FROM embeddings ORDER BY d LIMIT ?", (q.tobytes(), k)).fetchall()
+    dt_s = time.perf_counter() - t
+    return {"value": round(1.0 / dt_s * len(rows) / n_total, 5), "unit": "queries/s", "cores": 1, "rows_timed": len(rows),
+            "seconds": round(dt_s, 2), "us_per_row": round(dt_s / len(rows) * 1e6, 2), "page_rows": len(page),
+            "how": "stdlib sqlite3, per-row scalar UDF = Python trampoline -> C oracle, ORDER BY d LIMIT k; the trampoline costs several us per "
+                   "row on top of the arithmetic (the reference's Rust+sqlite-vec path measures ~2-3.3 us/row, docs/vector-quant-measurements.md)"}
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves, relay rank 0's
     JSON line, fail if any rank fails."""
@@ -462,11 +488,10 @@ def main():
                           f"({dt1:.1f}s measured), extrapolated linearly to {N} rows",
                 "all_cores": {"value": round(Q / dt2 * S / N, 4), "cores": allc, "seconds": round(dt2, 2)},
             }
-            if hasattr(pvs, "sqlite_udf_baseline"):
-                try:
-                    result["cpu_baseline"]["sqlite_udf"] = pvs.sqlite_udf_baseline(orc, odt, omet, rows[:100_000], qq[:1], K)
-                except Exception as e:  # noqa: BLE001
-                    result["cpu_baseline"]["sqlite_udf"] = {"error": str(e)}
+            try:  # the reference's SQL shape through real SQLite, per-row scalar UDF = the oracle
+                result["cpu_baseline"]["sqlite_udf"] = sqlite_udf_baseline(orc, odt, omet, rows[:50_000], qq[0], K, N)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"]["sqlite_udf"] = {"error": str(e)}
     if rank == 0:
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()

@@ -1,0 +1,82 @@
+/*
+ * pvs_sqlite.h — the SQLite side of the drop-in boundary: libpvs_sqlite.so registers, through SQLite's own extension
+ * ABI, the functions that feed the reference's `dist_{cte}` from a device index.
+ *
+ * Replaces `sqlite3_auto_extension(sqlite3_vec_init)` (db/sql_functions.rs:105-128) for the vector path: the host calls
+ * `sqlite3_auto_extension(sqlite3_pvs_init)` (or loads libpvs_sqlite.so per connection) and binds its device indexes by
+ * name; the filter compilers then emit
+ *     FROM pvs_dist(<index>, ?, 'cosine') AS p JOIN item_data ON item_data.id = p.id ...            -- whole `d` column
+ *     pvs_distance_cosine(<index>, embeddings.id, ?) AS d                                           -- per-row drop-in
+ * where they emit `vec_distance_cosine(embeddings.embedding, ?) AS d` today (filters/image_embeddings.rs:321-362,
+ * text_embeddings.rs:386-418, exact.rs:106-165).  Everything else in the generated SQL is untouched.
+ *
+ * SQL surface
+ *   pvs_dist(index TEXT, query BLOB [, metric TEXT = 'cosine' [, k INTEGER]]) -> rows (id INTEGER, d REAL)
+ *       without k: one row per stored vector, `d` = the f32 distance sqlite-vec would return, widened; NULL where it
+ *       yields NaN.  With k: page 1 of size k of the (distance, id) ordering (the filter scan).
+ *   pvs_distance_cosine(index TEXT, id INTEGER, query BLOB) -> REAL     the same column, looked up per row: the first call
+ *   pvs_distance_l2(index TEXT, id INTEGER, query BLOB) -> REAL         of a statement runs the device pass; an id the
+ *                                                                       index does not hold gives NULL.
+ *   query: dim*4 bytes f32 little-endian, or dim int8 codes for an int8 index (QuantResolved.query_quant).
+ */
+#ifndef PVS_SQLITE_H
+#define PVS_SQLITE_H
+
+#include <stdint.h>
+
+#include "pvs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sqlite3 sqlite3;
+typedef struct sqlite3_context sqlite3_context;
+typedef struct sqlite3_value sqlite3_value;
+struct sqlite3_module;
+
+/* The SQLite entry points the extension needs, as pointers.  A host that links SQLite statically (sqlx / libsqlite3-sys
+ * "bundled") fills this from its own copy and calls pvs_sqlite_register; a process that carries libsqlite3.so (Python,
+ * the sqlite3 shell) needs nothing: the loadable-extension entry points find the functions themselves. */
+typedef struct pvs_sqlite_api {
+    uint32_t struct_size;
+    int (*create_function_v2)(sqlite3 *, const char *, int, int, void *, void (*)(sqlite3_context *, int, sqlite3_value **),
+                              void (*)(sqlite3_context *, int, sqlite3_value **), void (*)(sqlite3_context *), void (*)(void *));
+    int (*create_module_v2)(sqlite3 *, const char *, const struct sqlite3_module *, void *, void (*)(void *));
+    int (*declare_vtab)(sqlite3 *, const char *);
+    int (*value_type)(sqlite3_value *);
+    int (*value_bytes)(sqlite3_value *);
+    const void *(*value_blob)(sqlite3_value *);
+    const unsigned char *(*value_text)(sqlite3_value *);
+    long long (*value_int64)(sqlite3_value *);
+    void (*result_double)(sqlite3_context *, double);
+    void (*result_int64)(sqlite3_context *, long long);
+    void (*result_null)(sqlite3_context *);
+    void (*result_error)(sqlite3_context *, const char *, int);
+    void *(*user_data)(sqlite3_context *);
+    void *(*get_auxdata)(sqlite3_context *, int);
+    void (*set_auxdata)(sqlite3_context *, int, void *, void (*)(void *));
+    char *(*mprintf)(const char *, ...);
+    void (*free)(void *);
+} pvs_sqlite_api;
+
+/* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 on one connection.  api == NULL: use the table a previous
+ * call installed, or resolve the entry points from the SQLite already loaded in this process.  Returns an SQLite result
+ * code (0 = SQLITE_OK). */
+int32_t pvs_sqlite_register(void *db, const pvs_sqlite_api *api);
+
+/* Loadable-extension entry points (int xEntryPoint(sqlite3*, char **pzErrMsg, const sqlite3_api_routines*)): the symbol
+ * SQLite derives from the file name, the generic one, and the one to hand to sqlite3_auto_extension. */
+int sqlite3_pvs_init(void *db, char **pzErrMsg, const void *pApi);
+int sqlite3_extension_init(void *db, char **pzErrMsg, const void *pApi);
+int sqlite3_pvssqlite_init(void *db, char **pzErrMsg, const void *pApi);
+
+/* Names the SQL functions resolve: bind every device index the host wants reachable from SQL (process-wide registry;
+ * rebinding a name replaces it; unbind before pvs_index_destroy).  Return pvs_status. */
+int32_t pvs_sqlite_bind_index(const char *name, pvs_index *idx);
+int32_t pvs_sqlite_unbind_index(const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVS_SQLITE_H */

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libpvs.so")
+LIB_SQLITE = os.path.join(HERE, "libpvs_sqlite.so")  # the SQLite loadable extension (pvs_sqlite.cpp), links libpvs.so
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = [
@@ -96,12 +97,28 @@ def build(force: bool = False, jobs: int | None = None) -> str:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
     changed = any(os.path.getmtime(o) != before[s] for s, o in zip(SOURCES, objs))
     if not changed and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(o) for o in objs):
+        _build_sqlite_extension()
         return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    _build_sqlite_extension()
     return LIB
+
+
+def _build_sqlite_extension() -> str:
+    """libpvs_sqlite.so: plain C++ (no SQLite headers or library needed, see pvs_sqlite.cpp), next to libpvs.so."""
+    src = os.path.join(CSRC, "pvs_sqlite.cpp")
+    deps = [src, os.path.join(ROOT, "include", "pvs_sqlite.h"), os.path.join(ROOT, "include", "pvs.h"), LIB]
+    if os.path.exists(LIB_SQLITE) and all(os.path.getmtime(LIB_SQLITE) >= os.path.getmtime(d) for d in deps):
+        return LIB_SQLITE
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-I", os.path.join(ROOT, "include"),
+           src, "-o", LIB_SQLITE, "-L", HERE, "-l:libpvs.so", "-Wl,-rpath,$ORIGIN", "-ldl", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"sqlite extension build failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return LIB_SQLITE
 
 
 if __name__ == "__main__":

@@ -1,32 +1,52 @@
-"""The `dist_{cte}` seam, concretely: fill a TEMP table with the device-computed distance column so that the
-rest of the SQL the reference generates (GROUP BY file_id aggregate, row_number(), RRF ORDER BY, LIMIT/OFFSET
-— filters/exact.rs:106-165, pql/builder.rs:757-771,1284-1317) runs unchanged on top of it.
+"""The SQLite side of the boundary from Python: loads libpvs_sqlite.so (panoptikon_amd/csrc/pvs_sqlite.cpp, declared in
+include/pvs_sqlite.h) into a stdlib `sqlite3` connection and binds device indexes to the names the SQL uses.
 
-The reference's CTE body is `SELECT item_id, file_id, vec_distance_*(payload, ?) AS d FROM <candidate skeleton>`;
-here `d` comes from `pvs_score_all` (one exact distance per stored row, in `item_data.id` order) and is joined
-back by `item_data.id`.  NaN distances become SQL NULL, as `sqlite3_result_double(NaN)` does in the reference.
-Host-side glue (stdlib `sqlite3`); the compute is the library's.
-"""
+    seam.load(conn)                      # pvs_dist(...), pvs_distance_cosine(...), pvs_distance_l2(...) now exist on conn
+    seam.bind("clip", index)             # `index` is a VectorIndex
+    conn.execute("SELECT p.id, p.d FROM pvs_dist('clip', ?, 'cosine') AS p ...", (query_f32.tobytes(),))
+
+The compute is the library's: this module only loads the extension and passes handles."""
 from __future__ import annotations
 
-import math
+import ctypes as C
+import os
 import sqlite3
-
-import numpy as np
 
 from . import _lib as L
 
+EXT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpvs_sqlite.so")
+_ext = None
 
-def fill_distance_table(conn: sqlite3.Connection, table: str, index, query, metric: int = L.COSINE) -> int:
-    """CREATE TEMP TABLE <table>(id INTEGER PRIMARY KEY, d REAL) holding vec_distance(row, query) for every row of
-    `index`; `id` is the row id given at pvs_index_add (item_data.id).  Returns the number of rows written."""
-    if not table.replace("_", "").isalnum():
-        raise ValueError("table name must be a plain identifier")
-    d = index.score_all(query, metric)  # f32, reference arithmetic
-    ids = index.read_ids()
-    conn.execute(f"DROP TABLE IF EXISTS temp.{table}")
-    conn.execute(f"CREATE TEMP TABLE {table} (id INTEGER PRIMARY KEY, d REAL)")
-    dd = d.astype(np.float64)  # the f32 result widened, like sqlite3_result_double((double)f32)
-    conn.executemany(f"INSERT INTO {table} (id, d) VALUES (?, ?)",
-                     ((int(i), None if math.isnan(v) else float(v)) for i, v in zip(ids.tolist(), dd.tolist())))
-    return int(ids.size)
+
+def ext() -> C.CDLL:
+    global _ext
+    if _ext is None:
+        if not os.path.exists(EXT_PATH):
+            raise ImportError(f"{EXT_PATH} is missing: build it with `python -m panoptikon_amd.build`")
+        L.lib()  # libpvs.so first (the extension links it)
+        e = C.CDLL(EXT_PATH, mode=C.RTLD_GLOBAL)
+        e.pvs_sqlite_bind_index.restype = C.c_int32
+        e.pvs_sqlite_bind_index.argtypes = [C.c_char_p, C.c_void_p]
+        e.pvs_sqlite_unbind_index.restype = C.c_int32
+        e.pvs_sqlite_unbind_index.argtypes = [C.c_char_p]
+        _ext = e
+    return _ext
+
+
+def load(conn: sqlite3.Connection) -> None:
+    """Registers the SQL functions on `conn` through SQLite's loadable-extension ABI (sqlite3_extension_init)."""
+    ext()
+    conn.enable_load_extension(True)
+    try:
+        conn.load_extension(EXT_PATH)
+    finally:
+        conn.enable_load_extension(False)
+
+
+def bind(name: str, index) -> None:
+    if ext().pvs_sqlite_bind_index(name.encode(), index._h) != 0:
+        raise ValueError(f"cannot bind index name {name!r}")
+
+
+def unbind(name: str) -> None:
+    ext().pvs_sqlite_unbind_index(name.encode())

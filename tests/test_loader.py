@@ -5,6 +5,7 @@ The DDL below restates the columns of the reference's migrations that the path t
 20260720130000_vector_quants.sql + 20260730150000_embedding_quants_rowid.sql: vector_quant_profiles,
 vector_quant_coverage, embedding_quants).  Readiness cases follow resolve_ready_pair
 (db/vector_quants.rs:1795-1869)."""
+import os
 import sqlite3
 import struct
 
@@ -180,6 +181,37 @@ def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
     cache.clear()
 
 
+def codes_now(conn, good):
+    """the int8 codes currently stored for the good rows, in id order"""
+    rows = dict(conn.execute("SELECT id, quant FROM embedding_quants WHERE profile_id = 5 AND rev = 2"))
+    return np.stack([np.frombuffer(rows[m[0]], np.int8) for m in good])
+
+
+def test_sqlite_extension_loads_and_registers_without_a_gpu():
+    """libpvs_sqlite.so through SQLite's loadable-extension ABI (the reference's seam, db/sql_functions.rs:83-128): the module and
+    the scalar functions register on a stdlib connection; with no index bound every call is a clean SQL error."""
+    import re
+    import subprocess
+
+    from panoptikon_amd import sqlite_seam
+
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pvs_sqlite.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b((?:pvs_sqlite|sqlite3_pvs|sqlite3_extension)[a-z0-9_]*)\s*\(", header))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", sqlite_seam.EXT_PATH], text=True)
+    exported = set(re.findall(r"\bT ([a-z0-9_]+)", out))
+    assert declared and declared <= exported, sorted(declared - exported)
+    deps = subprocess.check_output(["ldd", sqlite_seam.EXT_PATH], text=True)
+    assert "libpvs.so" in deps and "libsqlite3" not in deps and "oracle" not in deps
+    conn = sqlite3.connect(":memory:")
+    sqlite_seam.load(conn)
+    assert [r[0] for r in conn.execute("SELECT name FROM pragma_module_list WHERE name = 'pvs_dist'")] == ["pvs_dist"]
+    assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_distance%'")} == {"pvs_distance_cosine", "pvs_distance_l2"}
+    for sql, args in (("SELECT * FROM pvs_dist('nope', ?)", (b"\0" * 16,)), ("SELECT pvs_distance_l2('nope', 1, ?)", (b"\0" * 16,)), ("SELECT * FROM pvs_dist('x')", ())):
+        with pytest.raises(sqlite3.OperationalError):
+            conn.execute(sql, args).fetchall()
+
+
 class _StubIndex:
     """Stands in for VectorIndex in the CPU tests of the cache logic: records what was appended."""
 
@@ -282,22 +314,49 @@ def test_dist_cte_seam_sql_runs_unchanged_over_device_distances():
              JOIN embedding_quants qq ON qq.id = d.id AND qq.profile_id = 5 AND qq.rev = 2
              JOIN files f ON f.item_id = d.item_id
              WHERE s.name IN ('clip/m', 'tclip/m'))""" + tail
-    sql_dev = """WITH dist AS MATERIALIZED (
+    # (B) the device column through the table-valued function registered by libpvs_sqlite.so (the SQLite extension ABI,
+    # the reference's own seam: db/sql_functions.rs:83-128); (C) the scalar drop-in in the place of vec_distance_cosine
+    sql_tvf = """WITH dist AS MATERIALIZED (
              SELECT d.item_id AS item_id, f.id AS file_id, p.d AS d
              FROM item_data d JOIN setters s ON s.id = d.setter_id
-             JOIN pvs_dist p ON p.id = d.id
+             JOIN pvs_dist('clip-int8', ?, 'cosine') p ON p.id = d.id
+             JOIN files f ON f.item_id = d.item_id
+             WHERE s.name IN ('clip/m', 'tclip/m'))""" + tail
+    sql_udf = """WITH dist AS MATERIALIZED (
+             SELECT d.item_id AS item_id, f.id AS file_id, pvs_distance_cosine('clip-int8', qq.id, ?) AS d
+             FROM item_data d JOIN setters s ON s.id = d.setter_id
+             JOIN embedding_quants qq ON qq.id = d.id AND qq.profile_id = 5 AND qq.rev = 2
              JOIN files f ON f.item_id = d.item_id
              WHERE s.name IN ('clip/m', 'tclip/m'))""" + tail
     expected = conn.execute(sql_ref, (q.tobytes(),)).fetchall()
     li = loader.load_quant_index(conn, "int8", ["clip/m", "tclip/m"])
-    n = sqlite_seam.fill_distance_table(conn, "pvs_dist", li.index, q, pvs.COSINE)
-    assert n == li.rows == len(good)
-    assert conn.execute("SELECT COUNT(*) FROM pvs_dist WHERE d IS NULL").fetchone()[0] == 1
-    got = conn.execute(sql_dev).fetchall()
+    assert li.rows == len(good)
+    sqlite_seam.load(conn)
+    sqlite_seam.bind("clip-int8", li.index)
+    assert conn.execute("SELECT COUNT(*), SUM(d IS NULL) FROM pvs_dist('clip-int8', ?)", (q.tobytes(),)).fetchone() == (len(good), 1)
+    got = conn.execute(sql_tvf, (q.tobytes(),)).fetchall()
     assert len(got) == 40 and got == expected
+    assert conn.execute(sql_udf, (q.tobytes(),)).fetchall() == expected
+    # an f32 query against the int8 index is quantized with the frozen scale on the device (compute_query_quant)
+    qf = orc.synth_rows(4242, 0, 1, 128)[0]
+    assert conn.execute(sql_tvf, (qf.astype("<f4").tobytes(),)).fetchall() == expected
+    # k given: page 1 of the row ranking from the filter scan = ORDER BY d, id LIMIT k over the whole column
+    top = conn.execute("SELECT id, d FROM pvs_dist('clip-int8', ?, 'cosine', 25)", (q.tobytes(),)).fetchall()
+    full = conn.execute("SELECT id, d FROM pvs_dist('clip-int8', ?, 'cosine') WHERE d IS NOT NULL ORDER BY d, id LIMIT 25", (q.tobytes(),)).fetchall()
+    assert top == full
+    l2 = conn.execute("SELECT id, d FROM pvs_dist('clip-int8', ?, 'l2', 5)", (q.tobytes(),)).fetchall()
+    ei, ed = orc.search(orc.I8, orc.L2, codes_now(conn, good), q[None, :], 5, ids=np.array([m[0] for m in good], np.int64))
+    assert [r[0] for r in l2] == ei[0].tolist() and [np.float32(r[1]) for r in l2] == ed[0].tolist()
+    # errors are SQL errors, like sqlite-vec's (db/pql.rs:18-21)
+    for bad_sql, args in (("SELECT * FROM pvs_dist('clip-int8', ?)", (q.tobytes()[:-1],)), ("SELECT * FROM pvs_dist('nope', ?)", (q.tobytes(),)),
+                          ("SELECT * FROM pvs_dist('clip-int8', ?, 'dot')", (q.tobytes(),)), ("SELECT * FROM pvs_dist('clip-int8', ?, 'l2', 0)", (q.tobytes(),))):
+        with pytest.raises(sqlite3.OperationalError):
+            conn.execute(bad_sql, args).fetchall()
     # and without SQL at all: the same first page from pvs_search_groups (items) expanded to files on the host
     gg, gv, gc = li.index.search_groups(q[None, :], 10, pvs.COSINE, pvs.AGG_MIN)
     first_items = [r[0] for r in conn.execute(
-        "SELECT d.item_id, MIN(p.d) AS m FROM item_data d JOIN pvs_dist p ON p.id = d.id GROUP BY d.item_id ORDER BY m ASC NULLS LAST, d.item_id LIMIT 10")]
+        "SELECT d.item_id, MIN(p.d) AS m FROM item_data d JOIN pvs_dist('clip-int8', ?) p ON p.id = d.id GROUP BY d.item_id ORDER BY m ASC NULLS LAST, d.item_id LIMIT 10",
+        (q.tobytes(),))]
     assert gg[0, : gc[0]].tolist() == first_items
+    sqlite_seam.unbind("clip-int8")
     li.index.close()
