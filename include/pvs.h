@@ -339,6 +339,27 @@ typedef struct pvs_rrf_branch {
 } pvs_rrf_branch;
 pvs_status pvs_rrf_search(const pvs_rrf_branch *branches, uint32_t n_branches, uint32_t k, int64_t *out_groups,
                           double *out_scores, uint32_t *out_count);
+/* The steps of pvs_rrf_search's bounded fusion, for hosts that shard a branch BY GROUP over several GPUs or ranks (every row of a
+ * group on one shard; configs[4] of BASELINE.json).  One pvs_rrf_cols = one branch scored on one shard: every row's exact
+ * distance, the per-group aggregate (f64) and its window key — an order-preserving u64 with the window's NULL placement and
+ * direction folded in, comparable across shards; ties are broken by group id everywhere.  Protocol (panoptikon_amd/sharded.py
+ * rrf_search_sharded): threshold proposals -> minimum over shards -> pages -> union of candidates -> their keys (lookup) ->
+ * groups strictly before each candidate on every shard (count_below) -> sum = exact global rank -> pvs_rrf_fuse. */
+typedef struct pvs_rrf_cols pvs_rrf_cols;
+pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_cols **out);
+void pvs_rrf_cols_destroy(pvs_rrf_cols *cols);
+pvs_status pvs_rrf_cols_groups(pvs_rrf_cols *cols, uint64_t *out_n_groups);
+/* a key at or below which ~1.5 x target_groups of this shard's groups lie (all ones: take everything) */
+pvs_status pvs_rrf_cols_threshold(pvs_rrf_cols *cols, uint64_t target_groups, uint64_t *out_key);
+/* every group with window key <= key (any order); *out_count > cap means nothing was written */
+pvs_status pvs_rrf_cols_page(pvs_rrf_cols *cols, uint64_t key, uint32_t cap, int64_t *out_gids, uint64_t *out_keys, uint32_t *out_count);
+pvs_status pvs_rrf_cols_lookup(pvs_rrf_cols *cols, const int64_t *gids, uint32_t m, uint64_t *out_keys, uint8_t *out_present);
+/* candidates strictly increasing in (key, group id): out_below[j] = groups of this shard strictly before candidate j */
+pvs_status pvs_rrf_cols_count_below(pvs_rrf_cols *cols, const uint64_t *keys, const int64_t *gids, uint32_t m, uint64_t *out_below);
+
+/* Which way the last pvs_rrf_search of this thread went: 1 = bounded fusion (pages of each branch's ranking + exact ranks of
+ * the candidates; the usual case), 2 = every group of every branch ranked (small inputs, negative weights, massive ties). */
+int32_t pvs_rrf_last_path(void);
 
 /* ------------------------------------------------------- codec (host scalars) */
 float pvs_scale_from_absmax(float absmax);

@@ -11,6 +11,7 @@ from .host import (aggregate, artifact_scale, coalesce_ranks, coalesce_values, s
                    resolve_vector_quant, row_number, rrf_fuse, rrf_search, scale_artifact, scale_from_absmax)
 
 from .rendezvous import LocalRendezvous
-from .sharded import merge_shard_group_pages, merge_shard_pages, shard_range, shard_ranges_by_group
+from .host import RrfCols
+from .sharded import merge_shard_group_pages, merge_shard_pages, rrf_search_sharded, shard_range, shard_ranges_by_group
 
 __all__ = [n for n in dir() if not n.startswith("_")]

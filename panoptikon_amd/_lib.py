@@ -108,6 +108,14 @@ SYMBOLS = {
     "pvs_device_synchronize": (_i32, [_i32]),
     "pvs_device_mem_info": (_i32, [_i32, _vp, _vp]),
     "pvs_rrf_search": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_rrf_last_path": (_i32, []),
+    "pvs_rrf_cols_create": (_i32, [C.POINTER(RrfBranch), C.POINTER(_vp)]),
+    "pvs_rrf_cols_destroy": (None, [_vp]),
+    "pvs_rrf_cols_groups": (_i32, [_vp, C.POINTER(_u64)]),
+    "pvs_rrf_cols_threshold": (_i32, [_vp, _u64, C.POINTER(_u64)]),
+    "pvs_rrf_cols_page": (_i32, [_vp, _u64, _u32, _vp, _vp, C.POINTER(_u32)]),
+    "pvs_rrf_cols_lookup": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "pvs_rrf_cols_count_below": (_i32, [_vp, _vp, _vp, _u32, _vp]),
     "pvs_similar_to_ex": (_i32, [_vp, _vp, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_aggregate": (_i32, [_vp, _vp, _vp, _u64, _i32, _vp, _vp, C.POINTER(_u64)]),
     "pvs_absmax": (_i32, [_vp, _u64, _i32, _i32, C.POINTER(_f)]),

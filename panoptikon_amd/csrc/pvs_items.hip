@@ -396,6 +396,249 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     return st;
 }
 
+static thread_local int32_t g_rrf_last_path = 0;
+PVS_EXPORT int32_t pvs_rrf_last_path(void) { return g_rrf_last_path; }
+
+// One branch of an OR-composition, scored (pvs_rrf_cols in the C ABI): every group's aggregate (f64, the reference's
+// arithmetic) and its window key.
+struct pvs_rrf_cols {
+    pvs_index *ix = nullptr;
+    double *d_vals = nullptr;               // [n_groups]
+    unsigned long long *d_keys = nullptr;   // [n_groups] order-preserving window key (NULL placement and direction folded in)
+    uint32_t n_groups = 0;
+    std::vector<unsigned long long> sample;  // sorted sample of the keys (threshold proposals)
+};
+typedef pvs_rrf_cols RrfBranchCols;
+
+// every row's exact distance (the dist_{cte} column), aggregated per group in row order
+static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) {
+    pvs_index *ix = b.idx;
+    out->ix = ix;
+    out->n_groups = ix->n_groups;
+    if (ix->n == 0) return PVS_OK;
+    if (ix->n > (1ull << 31) / 4) return pvs_fail(PVS_ERR_UNSUPPORTED, "more than 2^29 rows in one dense column");
+    HIP_TRY(hipSetDevice(ix->device));
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(ix, &t);
+    void *d_q = nullptr;
+    float *d_m = nullptr, *d_w = nullptr;
+    auto one = [&]() -> pvs_status {
+        PVS_TRY(ctx_prepare(ix, *c, 1, 1, false));
+        const size_t qbytes = (size_t)ix->dim * (b.query_dtype == PVS_I8 ? 1 : 4);
+        HIP_TRY(hipMalloc(&d_q, qbytes));
+        HIP_TRY(hipMemcpyAsync(d_q, b.query, qbytes, hipMemcpyHostToDevice, c->stream));
+        if (b.row_weights) {
+            HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+            HIP_TRY(hipMemcpyAsync(d_w, b.row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipMalloc((void **)&d_m, ix->n * 4));
+        HIP_TRY(hipMalloc((void **)&out->d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&out->d_keys, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+        PVS_TRY(prep_chunk(ix, *c, d_q, b.query_dtype, 0, 1, 32, b.metric));
+        PVS_TRY(dense_chunk(ix, *c, 1, 32, b.metric, d_m));
+        HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, b.agg, out->d_vals, c->stream));
+        PVS_TRY(pvs_rrf_window_keys(out->d_vals, ix->n_groups, b.row_n_descending != 0, out->d_keys, c->stream));
+        return PVS_OK;
+    };
+    pvs_status st = one();
+    hipFree(d_q);
+    hipFree(d_m);
+    hipFree(d_w);
+    ix->searches++;
+    ix->dense_queries++;
+    ctx_done(ix, c);
+    return st;
+}
+
+// ---- the pieces of the bounded fusion as C-ABI entry points: a host that shards a branch BY GROUP over several GPUs (or
+// ranks) runs them per shard and exchanges a few thousand (group id, key) pairs between the steps (sharded.py: rrf_search_sharded)
+PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_cols **out) {
+    if (!branch || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    pvs_index *ix = branch->idx;
+    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "one pvs_rrf_cols per single-device shard");
+    PVS_TRY(validate_search(ix, branch->query, branch->query_dtype, 1, 1, branch->metric));
+    if (!branch->row_weights && branch->agg != PVS_AGG_MIN && branch->agg != PVS_AGG_MAX && branch->agg != PVS_AGG_AVG)
+        return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    HIP_TRY(hipSetDevice(ix->device));
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        PVS_TRY(ensure_groups(ix));
+    }
+    pvs_rrf_cols *c = new (std::nothrow) pvs_rrf_cols();
+    if (!c) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
+    pvs_status st = rrf_score_branch(*branch, c);
+    if (st != PVS_OK) {
+        hipFree(c->d_vals);
+        hipFree(c->d_keys);
+        delete c;
+        return st;
+    }
+    *out = c;
+    return PVS_OK;
+}
+PVS_EXPORT void pvs_rrf_cols_destroy(pvs_rrf_cols *c) {
+    if (!c) return;
+    if (c->ix) (void)hipSetDevice(c->ix->device);
+    hipFree(c->d_vals);
+    hipFree(c->d_keys);
+    delete c;
+}
+PVS_EXPORT pvs_status pvs_rrf_cols_groups(pvs_rrf_cols *c, uint64_t *out_n_groups) {
+    if (!c || !out_n_groups) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    *out_n_groups = c->n_groups;
+    return PVS_OK;
+}
+// a window key at or below which about 1.5 x target_groups of this shard's groups lie (from an 8,192-key sample); all ones
+// when the shard has no more groups than that
+PVS_EXPORT pvs_status pvs_rrf_cols_threshold(pvs_rrf_cols *c, uint64_t target_groups, uint64_t *out_key) {
+    if (!c || !out_key) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    constexpr uint32_t M = 8192;
+    *out_key = ~0ull;
+    if (c->n_groups == 0 || target_groups * 2 >= c->n_groups) return PVS_OK;
+    HIP_TRY(hipSetDevice(c->ix->device));
+    if (c->sample.empty()) {
+        c->sample.resize(M);
+        PVS_TRY(pvs_rrf_sample_keys(c->d_keys, c->n_groups, M, c->sample.data(), c->ix->search_stream));
+        std::sort(c->sample.begin(), c->sample.end());
+    }
+    uint64_t j = (uint64_t)((double)M * 1.5 * (double)target_groups / (double)c->n_groups) + 1;
+    if (j >= M) j = M - 1;
+    *out_key = c->sample[j];
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_rrf_cols_page(pvs_rrf_cols *c, uint64_t key, uint32_t cap, int64_t *out_gids, uint64_t *out_keys, uint32_t *out_count) {
+    if (!c || !out_gids || !out_keys || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    *out_count = 0;
+    if (c->n_groups == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(c->ix->device));
+    return pvs_rrf_page(c->d_keys, c->ix->d_grp_ids, c->n_groups, key, cap, out_gids, (unsigned long long *)out_keys, out_count, c->ix->search_stream);
+}
+PVS_EXPORT pvs_status pvs_rrf_cols_lookup(pvs_rrf_cols *c, const int64_t *gids, uint32_t m, uint64_t *out_keys, uint8_t *out_present) {
+    if (!c || (m && (!gids || !out_keys || !out_present))) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (c->n_groups == 0) {
+        for (uint32_t i = 0; i < m; i++) out_present[i] = 0, out_keys[i] = 0;
+        return PVS_OK;
+    }
+    HIP_TRY(hipSetDevice(c->ix->device));
+    return pvs_rrf_lookup(c->d_keys, c->ix->d_grp_ids, c->n_groups, gids, m, (unsigned long long *)out_keys, out_present, c->ix->search_stream);
+}
+PVS_EXPORT pvs_status pvs_rrf_cols_count_below(pvs_rrf_cols *c, const uint64_t *keys, const int64_t *gids, uint32_t m, uint64_t *out_below) {
+    if (!c || (m && (!keys || !gids || !out_below))) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 1; i < m; i++)
+        if (keys[i - 1] > keys[i] || (keys[i - 1] == keys[i] && gids[i - 1] >= gids[i]))
+            return pvs_fail(PVS_ERR_INVALID_ARG, "candidates must be strictly increasing in (key, group id)");
+    if (c->n_groups) HIP_TRY(hipSetDevice(c->ix->device));
+    return pvs_rrf_count_below(c->d_keys, c->ix ? c->ix->d_grp_ids : nullptr, c->n_groups, (const unsigned long long *)keys, gids, m,
+                               (unsigned long long *)out_below, c->ix ? c->ix->search_stream : nullptr);
+}
+
+// SQLite's arithmetic for one fused score (pql/builder.rs:1284-1301), the same expression the device kernel evaluates
+static double rrf_score_host(const int64_t *ranks, const PvsRrfParams &p) {
+    const int64_t BIG = 9223372036854775805LL;
+    double tot = 0.0;
+    for (uint32_t b = 0; b < p.n_branches; b++) {
+        const int64_t rank = ranks[b] < 0 ? BIG : ranks[b];
+        int64_t di;
+        const double denom = __builtin_add_overflow((int64_t)p.k[b], rank, &di) ? (double)p.k[b] + (double)rank : (double)di;
+        const double t = (1.0 / denom) * p.w[b];
+        tot = b == 0 ? t : tot + t;
+    }
+    return tot;
+}
+
+// Bounded fusion.  The reference ranks EVERY group of every branch (row_number() over the whole CTE) and sorts the union;
+// only groups near the top of some branch can reach the page, so:
+//   1. per branch, the page of groups whose window key is at or below a threshold T_b taken from a sample of the keys:
+//      R_b groups, the first R_b of the branch's ranking (NULL aggregates included where the window puts them);
+//   2. candidates = union of the pages; for each candidate its EXACT window rank in every branch — one counting pass over
+//      the branch's keys (k_rank_count) — and so its exact fused score, in SQLite's arithmetic;
+//   3. a group outside every page has rank > R_b everywhere (or is absent, a still smaller term), so with weights >= 0 it
+//      scores at most U = sum_b w_b / (k_b + R_b + 1).  When the k-th best candidate beats U the candidates' first k ARE the
+//      reference's page; otherwise the thresholds move up (x4 groups) and the loop repeats; a page that would hold a
+//      quarter of a branch falls back to the full ranking below.
+// Cost beside the exact scoring of every row: a few passes over 8 B per group instead of three multi-pass radix sorts of
+// all groups (configs[4]: 2 x 8.3M groups — the sorts were 10 of 16 ms).
+static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint32_t k,
+                              int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done) {
+    *done = false;
+    (void)br;
+    const uint32_t nb = p.n_branches;
+    uint64_t total_groups = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        if (!(p.w[b] >= 0.0) || p.k[b] < 0) return PVS_OK;  // the bound needs non-negative terms (NaN weights too: full path)
+        total_groups += cols[b].n_groups;
+    }
+    if (total_groups < 65536) return PVS_OK;  // small: the full ranking is cheap
+    uint64_t target = std::max<uint64_t>(8ull * k, 2048);
+    for (int round = 0; round < 6; round++, target *= 4) {
+        std::vector<uint32_t> R(nb, 0);
+        std::vector<int64_t> cand;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t n = cols[b].n_groups;
+            if (n == 0) continue;
+            if (target * 4 >= n) return PVS_OK;  // a page that would hold a quarter of the branch: full ranking
+            uint64_t thr = 0;
+            PVS_TRY(pvs_rrf_cols_threshold(&cols[b], target, &thr));
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 8 * target + 65536);
+            std::vector<int64_t> g(cap);
+            std::vector<uint64_t> gk(cap);
+            uint32_t cnt = 0;
+            PVS_TRY(pvs_rrf_cols_page(&cols[b], thr, cap, g.data(), gk.data(), &cnt));
+            if (cnt > cap) return PVS_OK;  // many equal keys at the threshold (massive ties): full ranking
+            R[b] = cnt;
+            cand.insert(cand.end(), g.begin(), g.begin() + cnt);
+        }
+        std::sort(cand.begin(), cand.end());
+        cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+        const uint32_t m = (uint32_t)cand.size();
+        std::vector<std::vector<int64_t>> ranks(nb, std::vector<int64_t>(m, -1));
+        for (uint32_t b = 0; b < nb; b++) {
+            if (cols[b].n_groups == 0 || m == 0) continue;
+            std::vector<uint64_t> key(m);
+            std::vector<uint8_t> present(m);
+            PVS_TRY(pvs_rrf_cols_lookup(&cols[b], cand.data(), m, key.data(), present.data()));
+            std::vector<uint32_t> order;
+            for (uint32_t c = 0; c < m; c++)
+                if (present[c]) order.push_back(c);
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] != key[y] ? key[x] < key[y] : cand[x] < cand[y]; });
+            const uint32_t mp = (uint32_t)order.size();
+            std::vector<uint64_t> ck(mp), below(mp);
+            std::vector<int64_t> cg(mp);
+            for (uint32_t i = 0; i < mp; i++) {
+                ck[i] = key[order[i]];
+                cg[i] = cand[order[i]];
+            }
+            PVS_TRY(pvs_rrf_cols_count_below(&cols[b], ck.data(), cg.data(), mp, below.data()));
+            for (uint32_t i = 0; i < mp; i++) ranks[b][order[i]] = (int64_t)below[i] + 1;
+        }
+        struct GS {
+            double s;
+            int64_t g;
+        };
+        std::vector<GS> gs(m);
+        for (uint32_t i = 0; i < m; i++) {
+            int64_t r[PVS_RRF_MAX_BRANCHES];
+            for (uint32_t b = 0; b < nb; b++) r[b] = ranks[b][i];
+            gs[i] = {rrf_score_host(r, p), cand[i]};
+        }
+        std::sort(gs.begin(), gs.end(), [](const GS &a, const GS &b) { return a.s != b.s ? a.s > b.s : a.g < b.g; });  // score DESC, group id
+        // the most a group outside every page can score (absent from a branch: an even smaller term)
+        double U = 0.0;
+        for (uint32_t b = 0; b < nb; b++) U += p.w[b] / ((double)p.k[b] + (double)R[b] + 1.0);
+        U *= 1.0 + 1e-12;
+        if (m >= k && gs[k - 1].s > U) {
+            for (uint32_t i = 0; i < k; i++) {
+                out_groups[i] = gs[i].g;
+                out_scores[i] = gs[i].s;
+            }
+            *out_count = k;
+            *done = true;
+            return PVS_OK;
+        }
+    }
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
                                      uint32_t *out_count) {
     if (!br || !out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
@@ -407,6 +650,7 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     uint64_t total = 0;
     for (uint32_t b = 0; b < nb; b++) {
         pvs_index *ix = br[b].idx;
+        if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_rrf_search takes single-device branches (shard by group and fuse per-shard pages: INTEGRATION.md)");
         PVS_TRY(validate_search(ix, br[b].query, br[b].query_dtype, 1, 1, br[b].metric));
         if (ix->device != br[0].idx->device) return pvs_fail(PVS_ERR_INVALID_ARG, "all branches must live on one device");
         if (!br[b].row_weights && br[b].agg != PVS_AGG_MIN && br[b].agg != PVS_AGG_MAX && br[b].agg != PVS_AGG_AVG)
@@ -418,61 +662,43 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
         PVS_TRY(ensure_groups(ix));
         total += ix->n_groups;
     }
+    std::vector<RrfBranchCols> cols(nb);
     unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
-    void *d_q = nullptr;
-    float *d_m = nullptr, *d_w = nullptr;
-    double *d_vals = nullptr;
-    auto free_branch = [&]() {
-        hipFree(d_q);
-        hipFree(d_m);
-        hipFree(d_w);
-        hipFree(d_vals);
-        d_q = nullptr;
-        d_m = d_w = nullptr;
-        d_vals = nullptr;
-    };
     auto body = [&]() -> pvs_status {
+        for (uint32_t b = 0; b < nb; b++) PVS_TRY(rrf_score_branch(br[b], &cols[b]));
+        static const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests: compare the two paths
+        if (!force_full) {
+            bool done = false;
+            PVS_TRY(rrf_bounded(br, cols, p, k, out_groups, out_scores, out_count, &done));
+            if (done) {
+                g_rrf_last_path = 1;
+                for (uint32_t i = *out_count; i < k; i++) {
+                    out_groups[i] = -1;
+                    out_scores[i] = __builtin_nan("");
+                }
+                return PVS_OK;
+            }
+        }
+        // full ranking: every group of every branch ranked (stable radix sorts), entries appended in branch order, fused by sort
+        g_rrf_last_path = 2;
+        HIP_TRY(hipSetDevice(br[0].idx->device));
         HIP_TRY(hipMalloc((void **)&cat_key, std::max<uint64_t>(total, 1) * 8));
         HIP_TRY(hipMalloc((void **)&cat_pay, std::max<uint64_t>(total, 1) * 8));
         uint64_t off = 0;
         for (uint32_t b = 0; b < nb; b++) {
             pvs_index *ix = br[b].idx;
             if (ix->n == 0) continue;
-            if (ix->n > (1ull << 31) / 4) return pvs_fail(PVS_ERR_UNSUPPORTED, "branch %u: more than 2^29 rows in one dense column", b);
-            uint32_t t;
-            SearchCtx *c = ctx_acquire(ix, &t);
-            auto one = [&]() -> pvs_status {
-                PVS_TRY(ctx_prepare(ix, *c, 1, 1, false));
-                const size_t qbytes = (size_t)ix->dim * (br[b].query_dtype == PVS_I8 ? 1 : 4);
-                HIP_TRY(hipMalloc(&d_q, qbytes));
-                HIP_TRY(hipMemcpyAsync(d_q, br[b].query, qbytes, hipMemcpyHostToDevice, c->stream));
-                if (br[b].row_weights) {
-                    HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
-                    HIP_TRY(hipMemcpyAsync(d_w, br[b].row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
-                }
-                HIP_TRY(hipMalloc((void **)&d_m, ix->n * 4));
-                HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
-                // every row's exact distance (the dist_{cte} column), aggregated per group in row order ...
-                PVS_TRY(prep_chunk(ix, *c, d_q, br[b].query_dtype, 0, 1, 32, br[b].metric));
-                PVS_TRY(dense_chunk(ix, *c, 1, 32, br[b].metric, d_m));
-                HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, br[b].agg, d_vals,
-                                                   c->stream));
-                // ... ranked over ALL groups of the branch, entries appended in branch order
-                PVS_TRY(pvs_rrf_rank_branch(d_vals, ix->d_grp_ids, ix->n_groups, br[b].row_n_descending != 0, b, cat_key + off, cat_pay + off,
-                                            c->stream));
-                return PVS_OK;
-            };
-            pvs_status st = one();
-            free_branch();
-            ix->searches++;
-            ix->dense_queries++;
-            ctx_done(ix, c);
-            if (st != PVS_OK) return st;
+            PVS_TRY(pvs_rrf_rank_branch(cols[b].d_vals, ix->d_grp_ids, ix->n_groups, br[b].row_n_descending != 0, b, cat_key + off, cat_pay + off,
+                                        ix->search_stream));
             off += ix->n_groups;
         }
         return pvs_rrf_fuse_device(cat_key, cat_pay, off, p, k, out_groups, out_scores, out_count, br[0].idx->search_stream);
     };
     pvs_status st = body();
+    for (auto &c : cols) {
+        hipFree(c.d_vals);
+        hipFree(c.d_keys);
+    }
     hipFree(cat_key);
     hipFree(cat_pay);
     return st;

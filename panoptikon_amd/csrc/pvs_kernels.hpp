@@ -159,6 +159,16 @@ struct PvsRrfParams {
     int32_t k[PVS_RRF_MAX_BRANCHES];
     double w[PVS_RRF_MAX_BRANCHES];
 };
+// bounded fusion: window keys of every group of a branch, a sample of them, the page of groups at or below a key, the keys of
+// given groups, and how many groups stand strictly before each of a handful of candidates (one counting pass over the keys)
+pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s);
+pvs_status pvs_rrf_sample_keys(const unsigned long long *d_keys, uint32_t n, uint32_t m, unsigned long long *h_out, hipStream_t s);
+pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, unsigned long long thr, uint32_t cap,
+                        int64_t *out_gids, unsigned long long *out_keys, uint32_t *out_count, hipStream_t s);
+pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const int64_t *cand, uint32_t m,
+                          unsigned long long *out_keys, uint8_t *out_present, hipStream_t s);
+pvs_status pvs_rrf_count_below(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const unsigned long long *ckeys,
+                               const int64_t *cgids, uint32_t m, unsigned long long *out_below, hipStream_t s);
 pvs_status pvs_rrf_rank_branch(const double *d_vals, const int64_t *d_gids, uint32_t n, int descending, uint32_t branch,
                                unsigned long long *cat_key, unsigned long long *cat_pay, hipStream_t s);
 pvs_status pvs_rrf_fuse_device(unsigned long long *cat_key, unsigned long long *cat_pay, uint64_t total, const PvsRrfParams &p, uint32_t k,

@@ -106,7 +106,197 @@ __global__ void k_rrf_emit(const unsigned long long *key2_sorted, const uint32_t
     }
 }
 inline unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 65535); }
+
+// ---- bounded fusion (pvs_rrf_search's fast path): pages of each branch's ranking instead of ranking every group
+__global__ void k_sample_keys(const unsigned long long *keys, uint32_t n, uint32_t m, unsigned long long *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = keys[(uint64_t)i * n / m];
+}
+// every group whose window key is <= thr, in any order: (slot, key)
+__global__ void k_page_compact(const unsigned long long *keys, uint32_t n, unsigned long long thr, uint32_t cap, uint32_t *count, uint32_t *slots) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (keys[i] <= thr) {
+            const uint32_t p = atomicAdd(count, 1u);
+            if (p < cap) slots[p] = i;
+        }
+}
+__global__ void k_gather_page(const int64_t *gids, const unsigned long long *keys, const uint32_t *slots, uint32_t m, int64_t *out_g,
+                              unsigned long long *out_k) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) {
+        out_g[i] = gids[slots[i]];
+        out_k[i] = keys[slots[i]];
+    }
+}
+// candidate group ids -> their slot in this branch (groups are stored in id order) and window key; absent: slot = ~0
+__global__ void k_cand_lookup(const int64_t *gids, const unsigned long long *keys, uint32_t n, const int64_t *cand, uint32_t m, uint32_t *slot,
+                              unsigned long long *key) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    const int64_t g = cand[c];
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gids[mid] < g) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool found = lo < n && gids[lo] == g;
+    slot[c] = found ? lo : 0xffffffffu;
+    key[c] = found ? keys[lo] : 0ull;
+}
+// hist[p]++ with p = number of candidates whose (key, group id) is <= the group's: one pass over all groups, binary search in
+// LDS.  Candidates arrive sorted ascending by (key, group id) — the window order with its id tie-break, comparable across
+// shards.  Groups strictly before candidate j = sum_{p <= j} hist[p].
+__global__ __launch_bounds__(256) void k_rank_count(const unsigned long long *keys, const int64_t *gids, uint32_t n, const unsigned long long *ckey,
+                                                    const int64_t *cgid, uint32_t m, unsigned long long *hist) {
+    extern __shared__ unsigned long long sm[];
+    unsigned long long *sk = sm;              // [m]
+    int64_t *ss = (int64_t *)(sm + m);        // [m]
+    uint32_t *sh = (uint32_t *)(ss + m);      // [m + 1]
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+        sk[i] = ckey[i];
+        ss[i] = cgid[i];
+    }
+    for (uint32_t i = threadIdx.x; i <= m; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
+        const unsigned long long k = keys[g];
+        const int64_t gid = gids[g];
+        uint32_t lo = 0, hi = m;  // first candidate with (key, group id) > this group's
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool le = sk[mid] < k || (sk[mid] == k && ss[mid] <= gid);
+            if (le) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < m) atomicAdd(&sh[lo], 1u);  // (groups behind every candidate — nearly all of them — need no count)
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= m; i += 256)
+        if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
 }  // namespace
+
+pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s) {
+    if (n == 0) return PVS_OK;
+    uint32_t *idx = nullptr;
+    HIP_TRY(hipMalloc((void **)&idx, (size_t)n * 4));  // (k_rank_keys also writes the identity permutation)
+    hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(n)), dim3(256), 0, s, d_vals, n, descending, d_keys, idx);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(idx);
+    if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "window keys: %s", hipGetErrorString(e));
+    return PVS_OK;
+}
+pvs_status pvs_rrf_sample_keys(const unsigned long long *d_keys, uint32_t n, uint32_t m, unsigned long long *h_out, hipStream_t s) {
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)m * 8));
+    hipLaunchKernelGGL(k_sample_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_keys, n, m, d);
+    hipError_t e = hipMemcpyAsync(h_out, d, (size_t)m * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d);
+    if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "sample keys: %s", hipGetErrorString(e));
+    return PVS_OK;
+}
+// every group with key <= thr: (group id, key), any order; *out_count may exceed cap (then nothing is written)
+pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, unsigned long long thr, uint32_t cap,
+                        int64_t *out_gids, unsigned long long *out_keys, uint32_t *out_count, hipStream_t s) {
+    uint32_t *d_cnt = nullptr, *d_slots = nullptr;
+    int64_t *d_g = nullptr;
+    unsigned long long *d_k = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_cnt, 4));
+        HIP_TRY(hipMalloc((void **)&d_slots, (size_t)std::max<uint32_t>(cap, 1) * 4));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
+        if (n) hipLaunchKernelGGL(k_page_compact, dim3(grid_for(n)), dim3(256), 0, s, d_keys, n, thr, cap, d_cnt, d_slots);
+        HIP_TRY(hipGetLastError());
+        uint32_t cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        *out_count = cnt;
+        if (cnt > cap || cnt == 0) return PVS_OK;
+        HIP_TRY(hipMalloc((void **)&d_g, (size_t)cnt * 8));
+        HIP_TRY(hipMalloc((void **)&d_k, (size_t)cnt * 8));
+        hipLaunchKernelGGL(k_gather_page, dim3((cnt + 255) / 256), dim3(256), 0, s, d_gids, d_keys, d_slots, cnt, d_g, d_k);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_gids, d_g, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_keys, d_k, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_cnt);
+    hipFree(d_slots);
+    hipFree(d_g);
+    hipFree(d_k);
+    return st;
+}
+// candidate group ids -> window key in this branch; present[c] = 0 when the branch (shard) does not hold the group
+pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const int64_t *cand, uint32_t m,
+                          unsigned long long *out_keys, uint8_t *out_present, hipStream_t s) {
+    if (m == 0) return PVS_OK;
+    int64_t *d_cand = nullptr;
+    uint32_t *d_slot = nullptr;
+    unsigned long long *d_key = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_cand, (size_t)m * 8));
+        HIP_TRY(hipMalloc((void **)&d_slot, (size_t)m * 4));
+        HIP_TRY(hipMalloc((void **)&d_key, (size_t)m * 8));
+        HIP_TRY(hipMemcpyAsync(d_cand, cand, (size_t)m * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_cand_lookup, dim3((m + 255) / 256), dim3(256), 0, s, d_gids, d_keys, n, d_cand, m, d_slot, d_key);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> slot(m);
+        HIP_TRY(hipMemcpyAsync(slot.data(), d_slot, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_keys, d_key, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t c = 0; c < m; c++) out_present[c] = slot[c] != 0xffffffffu;
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_cand);
+    hipFree(d_slot);
+    hipFree(d_key);
+    return st;
+}
+// candidates sorted ascending by (key, group id): out_below[j] = groups of this branch (shard) strictly before candidate j
+pvs_status pvs_rrf_count_below(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const unsigned long long *ckeys,
+                               const int64_t *cgids, uint32_t m, unsigned long long *out_below, hipStream_t s) {
+    for (uint32_t j = 0; j < m; j++) out_below[j] = 0;
+    if (m == 0 || n == 0) return PVS_OK;
+    unsigned long long *d_ck = nullptr, *d_hist = nullptr;
+    int64_t *d_cg = nullptr;
+    const uint32_t CH = 2400;  // candidates per pass: 20 B each of LDS
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(hipMalloc((void **)&d_ck, (size_t)CH * 8));
+        HIP_TRY(hipMalloc((void **)&d_cg, (size_t)CH * 8));
+        HIP_TRY(hipMalloc((void **)&d_hist, ((size_t)CH + 1) * 8));
+        unsigned long long carried = 0;  // groups before the first candidate of the chunk = groups before the last of the previous + ...
+        (void)carried;
+        for (uint32_t c0 = 0; c0 < m; c0 += CH) {
+            const uint32_t mc = std::min(CH, m - c0);
+            HIP_TRY(hipMemcpyAsync(d_ck, ckeys + c0, (size_t)mc * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_cg, cgids + c0, (size_t)mc * 8, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemsetAsync(d_hist, 0, ((size_t)mc + 1) * 8, s));
+            const size_t lds = (size_t)mc * 16 + ((size_t)mc + 1) * 4 + 16;
+            hipLaunchKernelGGL(k_rank_count, dim3(std::min<unsigned>(grid_for(n), 2048)), dim3(256), lds, s, d_keys, d_gids, n, d_ck, d_cg, mc, d_hist);
+            HIP_TRY(hipGetLastError());
+            std::vector<unsigned long long> h((size_t)mc + 1);
+            HIP_TRY(hipMemcpyAsync(h.data(), d_hist, ((size_t)mc + 1) * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            unsigned long long run = 0;
+            for (uint32_t i = 0; i < mc; i++) {
+                run += h[i];  // groups strictly before candidate c0 + i (every chunk counts from the beginning of the order)
+                out_below[c0 + i] = run;
+            }
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    hipFree(d_ck);
+    hipFree(d_cg);
+    hipFree(d_hist);
+    return st;
+}
 
 // ranks every group of one branch and writes its (group id, branch, rank) entries at cat_*[0..n)
 pvs_status pvs_rrf_rank_branch(const double *d_vals, const int64_t *d_gids, uint32_t n, int descending, uint32_t branch,

@@ -93,19 +93,79 @@ def sort_bounds(order_rank, gt=None, lt=None) -> np.ndarray:
     return keep[: v.size].astype(bool)
 
 
+def _branch_struct(b, keep):
+    ix = b["index"]
+    q, qd = ix._queries(b["query"])
+    w = None if b.get("row_weights") is None else np.ascontiguousarray(b["row_weights"], np.float32)
+    keep += [q, w]
+    return L.RrfBranch(ix._h.value if hasattr(ix._h, "value") else ix._h, q.ctypes.data, qd, b["metric"], b.get("agg", L.AGG_MIN),
+                       None if w is None else w.ctypes.data, int(bool(b.get("descending", False))), int(b.get("rrf_k", 1)),
+                       float(b.get("weight", 1.0)))
+
+
+class RrfCols:
+    """One branch of an OR-composition scored on one shard (pvs_rrf_cols): the pieces of the bounded fusion."""
+
+    def __init__(self, branch: dict):
+        keep = []
+        st = _branch_struct(branch, keep)
+        h = C.c_void_p()
+        L.check(L.lib().pvs_rrf_cols_create(C.byref(st), C.byref(h)))
+        self._h = h
+        n = C.c_uint64()
+        L.check(L.lib().pvs_rrf_cols_groups(self._h, C.byref(n)))
+        self.n_groups = int(n.value)
+
+    def close(self):
+        if self._h:
+            L.lib().pvs_rrf_cols_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def threshold(self, target_groups: int) -> int:
+        k = C.c_uint64()
+        L.check(L.lib().pvs_rrf_cols_threshold(self._h, int(target_groups), C.byref(k)))
+        return int(k.value)
+
+    def page(self, key: int, cap: int):
+        """(group ids, keys) of every group at or below `key`; None when more than `cap` qualify."""
+        g = np.empty(max(cap, 1), np.int64)
+        kk = np.empty(max(cap, 1), np.uint64)
+        n = C.c_uint32()
+        L.check(L.lib().pvs_rrf_cols_page(self._h, int(key), int(cap), _ptr(g), _ptr(kk), C.byref(n)))
+        if n.value > cap:
+            return None
+        return g[: n.value].copy(), kk[: n.value].copy()
+
+    def lookup(self, gids):
+        g = np.ascontiguousarray(gids, np.int64)
+        keys = np.zeros(max(g.size, 1), np.uint64)
+        present = np.zeros(max(g.size, 1), np.uint8)
+        if g.size:
+            L.check(L.lib().pvs_rrf_cols_lookup(self._h, _ptr(g), g.size, _ptr(keys), _ptr(present)))
+        return keys[: g.size], present[: g.size].astype(bool)
+
+    def count_below(self, keys, gids):
+        k = np.ascontiguousarray(keys, np.uint64)
+        g = np.ascontiguousarray(gids, np.int64)
+        out = np.zeros(max(k.size, 1), np.uint64)
+        if k.size:
+            L.check(L.lib().pvs_rrf_cols_count_below(self._h, _ptr(k), _ptr(g), k.size, _ptr(out)))
+        return out[: k.size]
+
+
 def rrf_search(branches, k: int):
     """branches: dicts {index, query, metric, agg=AGG_MIN, row_weights=None, descending=False, rrf_k=1, weight=1.0}.
     OR-composition ranked by reciprocal-rank fusion on the device (pvs_rrf_search) -> (groups[k'], scores[k'])."""
     arr = (L.RrfBranch * len(branches))()
     keep = []
     for i, b in enumerate(branches):
-        ix = b["index"]
-        q, qd = ix._queries(b["query"])
-        w = None if b.get("row_weights") is None else np.ascontiguousarray(b["row_weights"], np.float32)
-        keep += [q, w]
-        arr[i] = L.RrfBranch(ix._h.value if hasattr(ix._h, "value") else ix._h, q.ctypes.data, qd, b["metric"], b.get("agg", L.AGG_MIN),
-                             None if w is None else w.ctypes.data, int(bool(b.get("descending", False))), int(b.get("rrf_k", 1)),
-                             float(b.get("weight", 1.0)))
+        arr[i] = _branch_struct(b, keep)
     og = np.empty(k, np.int64)
     ov = np.empty(k, np.float64)
     oc = C.c_uint32()

@@ -283,3 +283,72 @@ def test_similar_to_leaves_out_groups_without_a_joined_pair(pvs):
     eg2, ev2 = orc.similar_to_ex(orc.F32, orc.L2, rows, targets.tolist(), grp, orc.AGG_AVG, 50, kind=kind, xmodal_i2i=False)
     assert g2.tolist() == [3] and np.array_equal(g2, eg2) and np.array_equal(v2.view(np.uint64), ev2.view(np.uint64))
     ix.close()
+
+
+class _ThreadGather:
+    """all-gather between host threads standing in for ranks (each rank calls with the same sequence of shapes)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.slots = [None] * world
+        self.bar = threading.Barrier(world)
+
+    def for_rank(self, r):
+        def gather(a):
+            self.slots[r] = np.array(a, copy=True)
+            self.bar.wait()
+            out = np.stack(self.slots)
+            self.bar.wait()
+            return out
+
+        return gather
+
+
+def test_rrf_sharded_by_group_equals_the_whole_corpus(pvs):
+    """BASELINE configs[4] on several GPUs, in miniature: an image branch (int8 cosine, MIN) and a text branch (f16 L2, MIN) whose
+    rows are sharded BY GROUP over three shards (here three indexes per branch, three host threads as ranks); the sharded bounded
+    fusion (pvs_rrf_cols_* + panoptikon_amd.sharded.rrf_search_sharded) must return the oracle's page over the WHOLE corpus."""
+    rng = np.random.default_rng(5)
+    world, n_files, k = 3, 90_000, 100
+    specs = [(pvs.I8, orc.I8, 64, 140_000, pvs.COSINE, orc.COSINE, 5, 1.0), (pvs.F16, orc.F16, 48, 100_000, pvs.L2, orc.L2, 10, 0.7)]
+    shards = [[] for _ in range(world)]
+    ora = []
+    for i, (dt, odt, dim, n, m, om, rk, wt) in enumerate(specs):
+        rows = orc.synth_rows(500 + i, 0, n, dim)
+        pool = np.arange(0, n_files, dtype=np.int64)[rng.random(n_files) < (0.9, 0.6)[i]]
+        groups = np.sort(rng.choice(pool, n)).astype(np.int64)
+        if m == pvs.COSINE:
+            rows[np.nonzero(groups == groups[n // 2])[0]] = 0.0  # a NULL aggregate: first in the ascending window
+        scale = orc.compute_int8_scale(rows)
+        q = orc.synth_rows(600 + i, 0, 1, dim)[0]
+        hq = orc.quantize_int8(q[None, :], scale)[0] if dt == pvs.I8 else q
+        ranges = pvs.shard_ranges_by_group(groups, world)
+        for r, (a, b) in enumerate(ranges):
+            ix = pvs.VectorIndex(dt, dim, id_base=a)
+            if dt == pvs.I8:
+                ix.set_scale(scale)
+            ix.add_f32(rows[a:b], group_ids=groups[a:b])
+            shards[r].append(dict(index=ix, query=hq, metric=m, agg=pvs.AGG_MIN, rrf_k=rk, weight=wt))
+        corpus = orc.quantize_int8(rows, scale) if dt == pvs.I8 else rows.astype(np.float16)
+        ora.append(dict(dtype=odt, metric=om, corpus=corpus, query=hq, groups=groups, agg=orc.AGG_MIN, rrf_k=rk, weight=wt))
+    eg, es = orc.rrf_search(ora, k)
+    tg = _ThreadGather(world)
+    res, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            res[r] = pvs.rrf_search_sharded(shards[r], k, tg.for_rank(r))
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            tg.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(res[r][0], eg), f"rank {r}: groups differ"
+        assert np.array_equal(res[r][1].view(np.uint64), es.view(np.uint64)), f"rank {r}: scores not bit-exact"
+    for sh in shards:
+        for b in sh:
+            b["index"].close()

@@ -1215,3 +1215,49 @@ def test_search_bounded_applies_sort_bounds_on_the_distance(pvs, dtype):
                 assert np.array_equal(np.isnan(got), np.isnan(ed)) and np.array_equal(got[~np.isnan(got)].view(np.uint32), ed[~np.isnan(ed)].view(np.uint32))
                 assert (gi[0, len(ei):] == -1).all()
     ix.close()
+
+
+def test_rrf_bounded_fusion_equals_the_full_ranking(pvs):
+    """pvs_rrf_search's bounded path (pages of each branch's window ranking, exact ranks of the candidates by one counting pass,
+    the bound sum_b w_b/(k_b + R_b + 1) on everything outside the pages) must return exactly what ranking every group returns:
+    the oracle's literal composition.  Three branches over >= 65,536 groups, partial overlap, NULL aggregates first in the
+    ascending window, a descending window, production weights."""
+    rng = np.random.default_rng(77)
+    n_files = 120_000
+    specs = [(pvs.I8, orc.I8, 64, 150_000, pvs.COSINE, orc.COSINE), (pvs.F16, orc.F16, 96, 110_000, pvs.L2, orc.L2),
+             (pvs.F32, orc.F32, 32, 90_000, pvs.COSINE, orc.COSINE)]
+    dev, ora = [], []
+    for i, (dt, odt, dim, n, m, om) in enumerate(specs):
+        rows = unit_rows(301 + i, n, dim)
+        pool = np.arange(0, n_files, dtype=np.int64)[rng.random(n_files) < (0.9, 0.7, 0.5)[i]]
+        groups = np.sort(rng.choice(pool, n)).astype(np.int64)
+        if m == pvs.COSINE:
+            for gz in (groups[n // 3], groups[n // 2]):
+                rows[np.nonzero(groups == gz)[0]] = 0.0  # whole files of zero vectors: NULL aggregates, ranked FIRST ascending
+        scale = orc.compute_int8_scale(rows)
+        ix = pvs.VectorIndex(dt, dim)
+        if dt == pvs.I8:
+            ix.set_scale(scale)
+        ix.add_f32(rows, group_ids=groups)
+        q = orc.synth_rows(400 + i, 0, 1, dim)[0]
+        hq = orc.quantize_int8(q[None, :], scale)[0] if dt == pvs.I8 else q
+        agg = (pvs.AGG_MIN, pvs.AGG_AVG, pvs.AGG_MIN)[i]
+        desc = i == 2
+        rk, wt = ((5, 1.0), (5, 1.0), (10, 0.7))[i]
+        dev.append(dict(index=ix, query=hq, metric=m, agg=agg, descending=desc, rrf_k=rk, weight=wt))
+        ora.append(dict(dtype=odt, metric=om, corpus=host_corpus(dt, rows, scale), query=hq, groups=groups, agg=agg, descending=desc,
+                        rrf_k=rk, weight=wt))
+    for k, nb, path in ((1, 2, 1), (100, 2, 1), (100, 3, 1), (1000, 3, 1), (100, 1, 1)):
+        gg, gs = pvs.rrf_search(dev[:nb], k)
+        assert pvs.lib().pvs_rrf_last_path() == path, (k, nb, pvs.lib().pvs_rrf_last_path())
+        eg, es = orc.rrf_search(ora[:nb], k)
+        assert np.array_equal(gg, eg), (k, nb)
+        assert np.array_equal(gs.view(np.uint64), es.view(np.uint64)), (k, nb)
+    # a negative weight voids the bound: the full ranking answers, same contract
+    dev[1]["weight"], ora[1]["weight"] = -0.25, -0.25
+    gg, gs = pvs.rrf_search(dev[:2], 50)
+    assert pvs.lib().pvs_rrf_last_path() == 2
+    eg, es = orc.rrf_search(ora[:2], 50)
+    assert np.array_equal(gg, eg) and np.array_equal(gs.view(np.uint64), es.view(np.uint64))
+    for b in dev:
+        b["index"].close()
