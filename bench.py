@@ -40,6 +40,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0
 SEED_CORPUS = 20260928
 SEED_QUERY = 0x5EED0000
 
+CFG4_ROWS = 25_000_000  # BASELINE configs[4]: 50M rows = a 512-d image-embedding index + a 1024-d text-embedding index (split assumed
+                        # even), int8, ~3 vectors per file; the query is the PQL `or` of the two filters fused by RRF
 CONFIGS = {  # BASELINE.json configs[i] -> (rows, dim, dtype, batch, k, metric)
     1: (1_000_000, 768, "f16", 32, 100, "cosine"),
     2: (10_000_000, 768, "i8", 128, 100, "cosine"),
@@ -52,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS) + [4], default=None,
                     help="BASELINE.json configs[i]: sets --rows/--dim/--dtype/--batch/--k/--metric (default: configs[2], the metric's workload)")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--dim", type=int, default=None)
@@ -82,7 +84,7 @@ def parse():
                     help="N ranks: when RCCL cannot be initialised (e.g. two ranks on one GPU) exchange the pages over the control "
                          "socket instead of failing (testing only; the line then says exchange=ctl-host-gather)")
     a = ap.parse_args()
-    base = CONFIGS[a.config or 2]
+    base = CONFIGS[a.config if a.config in CONFIGS else 2]
     for name, val in zip(("rows", "dim", "dtype", "batch", "k", "metric"), base):
         if getattr(a, name) is None:
             setattr(a, name, val)
@@ -122,6 +124,164 @@ def sqlite_udf_baseline(orc, odt, omet, rows, q, k, n_total):
             "seconds": round(dt_s, 2), "us_per_row": round(dt_s / len(rows) * 1e6, 2), "page_rows": len(page),
             "how": "stdlib sqlite3, per-row scalar UDF = Python trampoline -> C oracle, ORDER BY d LIMIT k; the trampoline costs several us per "
                    "row on top of the arithmetic (the reference's Rust+sqlite-vec path measures ~2-3.3 us/row, docs/vector-quant-measurements.md)"}
+
+
+def run_config4(args, ctl, rank, world, device, real_stdout):
+    """BASELINE configs[4]: mixed 512-d image + 1024-d text embedding indexes (int8), PQL OR-composition of the two filters ranked
+    by reciprocal-rank fusion (pql/builder.rs:638-661, 757-771, 1284-1301).  One step = one composed query answered over both
+    corpora: every row scored exactly, MIN per file, the bounded fusion (pvs_rrf_search; rrf_search_sharded for N ranks, rows sharded
+    BY FILE)."""
+    import panoptikon_amd as pvs
+    from panoptikon_amd import _lib as L
+
+    lib = pvs.lib()
+    N = args.rows if args.rows not in (None, CONFIGS[2][0]) else CFG4_ROWS
+    K = args.k
+    per_file = 3
+    files = (N + per_file - 1) // per_file
+    f0, f1 = pvs.shard_range(files, world, rank)          # shard BY FILE: every vector of a file on one rank
+    r0, r1 = f0 * per_file, min(f1 * per_file, N)
+    n_local = r1 - r0
+    specs = [(512, pvs.COSINE, 11, 5, 1.0, 1), (1024, pvs.L2, 12, 10, 0.7, 2)]  # dim, metric, seed, rrf k, weight, file-id stride
+    branches, scales = [], []
+    t_build = time.time()
+    for dim, metric, seed, rk, wt, gstride in specs:
+        chunk = min(args.chunk_rows, max(n_local, 1))
+        stage = pvs.DeviceBuffer(chunk * dim * 4, device)
+        amax = 0.0
+        for off in range(0, n_local, chunk):
+            m = min(chunk, n_local - off)
+            L.check(lib.pvs_synth_rows_f32(device, seed, r0 + off, m, dim, stage.ptr))
+            out = L.C.c_float()
+            L.check(lib.pvs_absmax(stage.ptr, m * dim, L.DEVICE, device, L.C.byref(out)))
+            amax = max(amax, float(out.value))
+        scale = pvs.scale_from_absmax(ctl.max_float(amax))
+        ix = pvs.VectorIndex(pvs.I8, dim, device=device, capacity_rows=n_local, id_base=r0)
+        ix.set_scale(scale)
+        for off in range(0, n_local, chunk):
+            m = min(chunk, n_local - off)
+            L.check(lib.pvs_synth_rows_f32(device, seed, r0 + off, m, dim, stage.ptr))
+            g = (np.arange(r0 + off, r0 + off + m, dtype=np.int64) // per_file) * gstride  # text files: every other id -> partial overlap
+            L.check(lib.pvs_index_add_f32(ix._h, stage.ptr, m, None, g.ctypes.data, L.DEVICE))
+        stage.free()
+        branches.append(dict(index=ix, metric=metric, agg=pvs.AGG_MIN, rrf_k=rk, weight=wt, dim=dim, seed=seed))
+        scales.append(scale)
+    L.check(lib.pvs_device_synchronize(device))
+    if rank == 0:
+        print(f"[bench] configs[4]: 2 x {N} rows ({files} files x2 branches), this rank holds rows [{r0}, {r1}) of each, built in "
+              f"{time.time() - t_build:.1f}s", file=sys.stderr, flush=True)
+    NQ = 8
+    import oracle as orc  # (synthetic query vectors only: the generator is shared with the device's)
+
+    queries = [[orc.synth_rows(SEED_QUERY + 17 * bi, i, 1, b["dim"])[0] for bi, b in enumerate(branches)] for i in range(NQ)]
+
+    def step(i):
+        brs = [dict(index=b["index"], query=queries[i % NQ][j], metric=b["metric"], agg=b["agg"], rrf_k=b["rrf_k"], weight=b["weight"])
+               for j, b in enumerate(branches)]
+        if world == 1:
+            return pvs.rrf_search(brs, K)
+        return pvs.rrf_search_sharded(brs, K, ctl)
+
+    for i in range(args.warmup):
+        step(i)
+    L.check(lib.pvs_device_synchronize(device))
+    ctl.barrier()
+    for b in branches:
+        b["index"].set_profiling(not args.no_kernel_events)
+        b["index"].profile(reset=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    L.check(lib.pvs_device_synchronize(device))
+    ctl.barrier()
+    elapsed = ctl.max_float(time.perf_counter() - t0)
+    profs = [b["index"].profile() for b in branches]
+    for b in branches:
+        b["index"].set_profiling(False)
+    scan_ms = sum(p.scan_ms for p in profs) / max(args.steps, 1)                      # per composed query, both branches
+    bytes_per_query = sum(n_local * b["dim"] for b in branches)                        # every stored code read once per query
+    achieved = bytes_per_query / (scan_ms * 1e-3) / 1e9 if scan_ms else 0.0
+    result = {
+        "metric": "knn_queries_per_sec", "value": round(args.steps / elapsed, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+        "config": {"workload": f"{N}x512 + {N}x1024 i8 indexes (~{per_file} vectors per file), PQL or-composition of an image (cosine) and a "
+                               f"text (L2) filter, MIN per file, row_n + RRF (5/1.0, 10/0.7), k={K} (BASELINE configs[4])",
+                   "rows": 2 * N, "batch": 1, "k": K, "parallelism": f"shard by file x{world}", "exchange": "single-gpu" if world == 1 else
+                   "control-socket all-gather of candidate (id, key) pairs and counts (a few thousand per round)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "k_scan MODE 2 (exact int8 distances of every row, matrix core)", "launches": int(sum(p.scan_launches for p in profs)),
+                     "avg_launch_ms": round(sum(p.scan_ms for p in profs) / max(sum(p.scan_launches for p in profs), 1), 4),
+                     "algorithmic_bytes_per_query": int(bytes_per_query), "scoring_ms_per_query": round(scan_ms, 3),
+                     "whole_query_frac_of_peak": round(bytes_per_query / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        "path": {"rrf_path": {1: "bounded fusion", 2: "every group ranked"}.get(int(lib.pvs_rrf_last_path()), "sharded bounded fusion")},
+    }
+    if not args.no_verify:
+        # oracle, literally: every row of this rank scored on the CPU, MIN per file; then (N = 1) the whole composition, or (N > 1) the
+        # exact global window ranks of the returned files by counting, summed over ranks
+        t_or = time.time()
+        gq = queries[(args.warmup + args.steps - 1) % NQ]
+        cols = []
+        for j, b in enumerate(branches):
+            ix = b["index"]
+            qh = orc.quantize_int8(gq[j][None, :], scales[j])[0]
+            vals = np.empty(0, np.float64)
+            gids = np.empty(0, np.int64)
+            om = orc.COSINE if b["metric"] == pvs.COSINE else orc.L2
+            dcol = np.empty(n_local, np.float32)
+            for off in range(0, n_local, args.chunk_rows):
+                m = min(args.chunk_rows, n_local - off)
+                dcol[off: off + m] = orc.score_all(orc.I8, om, ix.read_rows(off, m), qh, threads=max(1, orc.max_threads() // world))
+            grp = (np.arange(r0, r1, dtype=np.int64) // per_file) * specs[j][5]
+            gids, vals = orc.aggregate(dcol, grp, orc.AGG_MIN)
+            cols.append((gids, vals))
+        got_g, got_s = last
+        ks, ws = [b["rrf_k"] for b in branches], [b["weight"] for b in branches]
+        if world == 1:
+            allg = np.union1d(cols[0][0], cols[1][0])
+            ranks = np.full((2, len(allg)), -1, np.int64)
+            for j, (g, v) in enumerate(cols):
+                ranks[j, np.searchsorted(allg, g)] = orc.row_number(v, g)
+            score = pvs.rrf_fuse(ranks, ks, ws)  # (host arithmetic of the C ABI = orc.rrf_score, checked in tests/)
+            order = np.lexsort((allg, -score))[:K]
+            exact = bool(np.array_equal(got_g, allg[order]) and np.array_equal(got_s.view(np.uint64), score[order].view(np.uint64)))
+            how = "oracle: every row scored on the CPU, MIN per file, row_number over ALL files of each branch, UNION, RRF, ORDER BY score DESC LIMIT k"
+        else:
+            ranks = np.full((2, len(got_g)), -1, np.int64)
+            for j, (g, v) in enumerate(cols):
+                pos = np.searchsorted(g, got_g)
+                mine = (pos < len(g)) & (g[np.minimum(pos, len(g) - 1)] == got_g)
+                val = np.where(mine, v[np.minimum(pos, len(v) - 1)], np.nan)
+                allv, allm = ctl.all_gather_np(val), ctl.all_gather_np(mine.astype(np.uint8))
+                have = allm.any(axis=0)
+                vv = np.where(have, allv[np.argmax(allm, axis=0), np.arange(len(got_g))], np.nan)
+                # window order ascending: NULL first, then value, then file id
+                below = np.zeros(len(got_g), np.int64)
+                vn = np.isnan(v)
+                sv = np.sort(v[~vn])
+                for i, (x, gid) in enumerate(zip(vv, got_g)):
+                    if not have[i]:
+                        continue
+                    if np.isnan(x):
+                        below[i] = int(np.sum(vn & (g < gid)))
+                    else:
+                        below[i] = int(vn.sum()) + int(np.searchsorted(sv, x, "left")) + int(np.sum((v == x) & (g < gid)))
+                tot = ctl.all_gather_np(below).sum(axis=0)
+                ranks[j, have] = tot[have] + 1
+            score = pvs.rrf_fuse(ranks, ks, ws)
+            sorted_ok = bool(np.all((score[:-1] > score[1:]) | ((score[:-1] == score[1:]) & (got_g[:-1] < got_g[1:]))))
+            exact = bool(np.array_equal(got_s.view(np.uint64), score.view(np.uint64)) and sorted_ok)
+            how = ("per rank: oracle distances of its rows, MIN per file; exact global window ranks of the returned files by counting, summed over "
+                   "ranks; their RRF scores and order (completeness of the page rests on the fusion's bound, proven against the full oracle at N = 1)")
+        if rank == 0:
+            result["parity"] = {"checked_queries": 1, "groups_and_scores_bit_exact": exact, "how": how, "oracle_seconds": round(time.time() - t_or, 1)}
+    if rank == 0:
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
+    ctl.barrier()
+    for b in branches:
+        b["index"].close()
+    ctl.close()
 
 
 def launch_ranks(n: int) -> int:
@@ -175,6 +335,8 @@ def main():
     n_dev = pvs.device_count()
     if n_dev < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950); libpvs has no CPU path")
+    if args.config == 4:
+        return run_config4(args, ctl, rank, world, local_rank % n_dev if world > 1 else 0, real_stdout)
     dev_list = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
     if single and (len(dev_list) != args.gpus or max(dev_list) >= n_dev):
         raise SystemExit(f"--single-process --gpus {args.gpus}: device list {dev_list} does not fit the {n_dev} visible device(s)")

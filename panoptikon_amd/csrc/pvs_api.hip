@@ -17,6 +17,73 @@ pvs_status pvs_fail(pvs_status code, const char *fmt, ...) {
     return code;
 }
 PVS_EXPORT const char *pvs_last_error(void) { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------ scratch cache
+namespace {
+struct ScratchBlock {
+    int device;
+    size_t cls;
+};
+std::mutex g_scratch_mu;
+std::map<std::pair<int, size_t>, std::vector<void *>> g_scratch_idle;  // (device, size class) -> idle blocks
+std::map<void *, ScratchBlock> g_scratch_live;
+size_t scratch_class(size_t bytes) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    if (c > (64u << 20)) c = (bytes + (16u << 20) - 1) / (16u << 20) * (16u << 20);  // big blocks: 16 MiB steps, not powers of two
+    return c;
+}
+}  // namespace
+hipError_t pvs_scratch_alloc(void **out, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t cls = scratch_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        auto &v = g_scratch_idle[{dev, cls}];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            g_scratch_live[*out] = {dev, cls};
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(out, cls);
+    if (e != hipSuccess) {  // give the idle blocks back and try once more
+        pvs_scratch_trim(dev);
+        e = hipMalloc(out, cls);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_live[*out] = {dev, cls};
+    return hipSuccess;
+}
+void pvs_scratch_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto it = g_scratch_live.find(p);
+    if (it == g_scratch_live.end()) return;  // not ours
+    g_scratch_idle[{it->second.device, it->second.cls}].push_back(p);
+    g_scratch_live.erase(it);
+}
+void pvs_scratch_trim(int device) {
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        for (auto &kv : g_scratch_idle)
+            if (kv.first.first == device) {
+                drop.insert(drop.end(), kv.second.begin(), kv.second.end());
+                kv.second.clear();
+            }
+    }
+    if (drop.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    for (void *p : drop) (void)hipFree(p);
+    (void)hipSetDevice(cur);
+}
 PVS_EXPORT uint32_t pvs_abi_version(void) { return PVS_ABI_VERSION; }
 
 PVS_EXPORT int32_t pvs_device_count(void) {
@@ -319,6 +386,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
+    pvs_scratch_trim(ix->device);
     delete ix;
 }
 

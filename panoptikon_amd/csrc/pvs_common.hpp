@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -34,6 +35,13 @@ pvs_status pvs_fail(pvs_status code, const char *fmt, ...) __attribute__((format
         pvs_status _s = (expr);       \
         if (_s != PVS_OK) return _s;  \
     } while (0)
+
+// Scratch for the host-orchestrated paths (per-item search, RRF, similar_to): blocks are kept per device and size class after
+// use instead of going back to hipMalloc / hipFree every call (each costs ~0.1-0.5 ms and hipFree synchronises the device:
+// 6 of configs[4]'s 13.8 ms per query were exactly that).  pvs_index_destroy returns the device's idle blocks to the runtime.
+hipError_t pvs_scratch_alloc(void **out, size_t bytes);  // on the current device
+void pvs_scratch_free(void *p);
+void pvs_scratch_trim(int device);
 
 // ------------------------------------------------------------ geometry
 // Rows live in HBM at a pitch that is a multiple of 256 B so that a row is a

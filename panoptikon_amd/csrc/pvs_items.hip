@@ -75,14 +75,23 @@ static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t
         a.batch = nb;
         a.dense_flag = c.d_cand_cnt;  // reused as the out-of-range flag word
         HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
+        span_begin(ix, c, 1, ix->n);  // (profiling: the dense scorer is the dominant kernel of the per-item paths)
         HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
         uint32_t flag = 0;
         HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
+        spans_collect(ix, c);
         if (!flag) return PVS_OK;  // else: some L2 sum left the exact range -> score in order below
     }
+    span_begin(ix, c, 1, ix->n);
     HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c.d_qexact, c.d_qinfo, nb,
                                    c.d_qpad, d_out, nb, 0, (uint32_t)ix->n_cu, c.stream));
+    span_end(ix, c);
+    if (ix->profiling) {
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        spans_collect(ix, c);
+    }
     return PVS_OK;
 }
 
@@ -425,15 +434,15 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) 
     auto one = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, 1, 1, false));
         const size_t qbytes = (size_t)ix->dim * (b.query_dtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(hipMalloc(&d_q, qbytes));
+        HIP_TRY(pvs_scratch_alloc(&d_q, qbytes));
         HIP_TRY(hipMemcpyAsync(d_q, b.query, qbytes, hipMemcpyHostToDevice, c->stream));
         if (b.row_weights) {
-            HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_w, ix->n * 4));
             HIP_TRY(hipMemcpyAsync(d_w, b.row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(hipMalloc((void **)&d_m, ix->n * 4));
-        HIP_TRY(hipMalloc((void **)&out->d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
-        HIP_TRY(hipMalloc((void **)&out->d_keys, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, ix->n * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&out->d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&out->d_keys, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
         PVS_TRY(prep_chunk(ix, *c, d_q, b.query_dtype, 0, 1, 32, b.metric));
         PVS_TRY(dense_chunk(ix, *c, 1, 32, b.metric, d_m));
         HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, b.agg, out->d_vals, c->stream));
@@ -441,9 +450,9 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) 
         return PVS_OK;
     };
     pvs_status st = one();
-    hipFree(d_q);
-    hipFree(d_m);
-    hipFree(d_w);
+    pvs_scratch_free(d_q);
+    pvs_scratch_free(d_m);
+    pvs_scratch_free(d_w);
     ix->searches++;
     ix->dense_queries++;
     ctx_done(ix, c);
@@ -468,8 +477,8 @@ PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_
     if (!c) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
     pvs_status st = rrf_score_branch(*branch, c);
     if (st != PVS_OK) {
-        hipFree(c->d_vals);
-        hipFree(c->d_keys);
+        pvs_scratch_free(c->d_vals);
+        pvs_scratch_free(c->d_keys);
         delete c;
         return st;
     }
@@ -479,8 +488,8 @@ PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_
 PVS_EXPORT void pvs_rrf_cols_destroy(pvs_rrf_cols *c) {
     if (!c) return;
     if (c->ix) (void)hipSetDevice(c->ix->device);
-    hipFree(c->d_vals);
-    hipFree(c->d_keys);
+    pvs_scratch_free(c->d_vals);
+    pvs_scratch_free(c->d_keys);
     delete c;
 }
 PVS_EXPORT pvs_status pvs_rrf_cols_groups(pvs_rrf_cols *c, uint64_t *out_n_groups) {
@@ -666,7 +675,7 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
     auto body = [&]() -> pvs_status {
         for (uint32_t b = 0; b < nb; b++) PVS_TRY(rrf_score_branch(br[b], &cols[b]));
-        static const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests: compare the two paths
+        const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests and profiles: compare the two paths
         if (!force_full) {
             bool done = false;
             PVS_TRY(rrf_bounded(br, cols, p, k, out_groups, out_scores, out_count, &done));
@@ -696,8 +705,8 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     };
     pvs_status st = body();
     for (auto &c : cols) {
-        hipFree(c.d_vals);
-        hipFree(c.d_keys);
+        pvs_scratch_free(c.d_vals);
+        pvs_scratch_free(c.d_keys);
     }
     hipFree(cat_key);
     hipFree(cat_pay);

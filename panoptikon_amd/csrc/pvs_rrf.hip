@@ -180,21 +180,21 @@ __global__ __launch_bounds__(256) void k_rank_count(const unsigned long long *ke
 pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s) {
     if (n == 0) return PVS_OK;
     uint32_t *idx = nullptr;
-    HIP_TRY(hipMalloc((void **)&idx, (size_t)n * 4));  // (k_rank_keys also writes the identity permutation)
+    HIP_TRY(pvs_scratch_alloc((void **)&idx, (size_t)n * 4));  // (k_rank_keys also writes the identity permutation)
     hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(n)), dim3(256), 0, s, d_vals, n, descending, d_keys, idx);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(idx);
+    pvs_scratch_free(idx);
     if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "window keys: %s", hipGetErrorString(e));
     return PVS_OK;
 }
 pvs_status pvs_rrf_sample_keys(const unsigned long long *d_keys, uint32_t n, uint32_t m, unsigned long long *h_out, hipStream_t s) {
     unsigned long long *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, (size_t)m * 8));
+    HIP_TRY(pvs_scratch_alloc((void **)&d, (size_t)m * 8));
     hipLaunchKernelGGL(k_sample_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_keys, n, m, d);
     hipError_t e = hipMemcpyAsync(h_out, d, (size_t)m * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d);
+    pvs_scratch_free(d);
     if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "sample keys: %s", hipGetErrorString(e));
     return PVS_OK;
 }
@@ -205,8 +205,8 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
     int64_t *d_g = nullptr;
     unsigned long long *d_k = nullptr;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_cnt, 4));
-        HIP_TRY(hipMalloc((void **)&d_slots, (size_t)std::max<uint32_t>(cap, 1) * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_cnt, 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_slots, (size_t)std::max<uint32_t>(cap, 1) * 4));
         HIP_TRY(hipMemsetAsync(d_cnt, 0, 4, s));
         if (n) hipLaunchKernelGGL(k_page_compact, dim3(grid_for(n)), dim3(256), 0, s, d_keys, n, thr, cap, d_cnt, d_slots);
         HIP_TRY(hipGetLastError());
@@ -215,8 +215,8 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
         HIP_TRY(hipStreamSynchronize(s));
         *out_count = cnt;
         if (cnt > cap || cnt == 0) return PVS_OK;
-        HIP_TRY(hipMalloc((void **)&d_g, (size_t)cnt * 8));
-        HIP_TRY(hipMalloc((void **)&d_k, (size_t)cnt * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_g, (size_t)cnt * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_k, (size_t)cnt * 8));
         hipLaunchKernelGGL(k_gather_page, dim3((cnt + 255) / 256), dim3(256), 0, s, d_gids, d_keys, d_slots, cnt, d_g, d_k);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out_gids, d_g, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
@@ -225,10 +225,10 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_cnt);
-    hipFree(d_slots);
-    hipFree(d_g);
-    hipFree(d_k);
+    pvs_scratch_free(d_cnt);
+    pvs_scratch_free(d_slots);
+    pvs_scratch_free(d_g);
+    pvs_scratch_free(d_k);
     return st;
 }
 // candidate group ids -> window key in this branch; present[c] = 0 when the branch (shard) does not hold the group
@@ -239,9 +239,9 @@ pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gid
     uint32_t *d_slot = nullptr;
     unsigned long long *d_key = nullptr;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_cand, (size_t)m * 8));
-        HIP_TRY(hipMalloc((void **)&d_slot, (size_t)m * 4));
-        HIP_TRY(hipMalloc((void **)&d_key, (size_t)m * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_cand, (size_t)m * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_slot, (size_t)m * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_key, (size_t)m * 8));
         HIP_TRY(hipMemcpyAsync(d_cand, cand, (size_t)m * 8, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_cand_lookup, dim3((m + 255) / 256), dim3(256), 0, s, d_gids, d_keys, n, d_cand, m, d_slot, d_key);
         HIP_TRY(hipGetLastError());
@@ -253,9 +253,9 @@ pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gid
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_cand);
-    hipFree(d_slot);
-    hipFree(d_key);
+    pvs_scratch_free(d_cand);
+    pvs_scratch_free(d_slot);
+    pvs_scratch_free(d_key);
     return st;
 }
 // candidates sorted ascending by (key, group id): out_below[j] = groups of this branch (shard) strictly before candidate j
@@ -267,9 +267,9 @@ pvs_status pvs_rrf_count_below(const unsigned long long *d_keys, const int64_t *
     int64_t *d_cg = nullptr;
     const uint32_t CH = 2400;  // candidates per pass: 20 B each of LDS
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_ck, (size_t)CH * 8));
-        HIP_TRY(hipMalloc((void **)&d_cg, (size_t)CH * 8));
-        HIP_TRY(hipMalloc((void **)&d_hist, ((size_t)CH + 1) * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_ck, (size_t)CH * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_cg, (size_t)CH * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_hist, ((size_t)CH + 1) * 8));
         unsigned long long carried = 0;  // groups before the first candidate of the chunk = groups before the last of the previous + ...
         (void)carried;
         for (uint32_t c0 = 0; c0 < m; c0 += CH) {
@@ -292,9 +292,9 @@ pvs_status pvs_rrf_count_below(const unsigned long long *d_keys, const int64_t *
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_ck);
-    hipFree(d_cg);
-    hipFree(d_hist);
+    pvs_scratch_free(d_ck);
+    pvs_scratch_free(d_cg);
+    pvs_scratch_free(d_hist);
     return st;
 }
 

@@ -1,0 +1,125 @@
+"""BASELINE.json configs[3] and configs[4] at FULL size on one MI355X (288 GB holds both), through size-independent properties:
+the filter scan against the dense path (every row scored exactly + full sort: the reference's own algorithm, an independent code
+path), the oracle on the rows that were returned and on a slab of the corpus, sortedness, determinism, sharded = whole.
+(The 8-GPU forms shard these same corpora by row / by file: tests/test_gpu_multi.py covers the sharded paths on multi-shard data.)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pvs():
+    import panoptikon_amd as p
+
+    if p.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the gpu tests need an MI355X")
+    return p
+
+
+def _build_i8(pvs, n, dim, seed, scale, groups_of=None, chunk=1_000_000):
+    from panoptikon_amd import _lib as L
+
+    lib = pvs.lib()
+    ix = pvs.VectorIndex(pvs.I8, dim, capacity_rows=n)
+    ix.set_scale(scale)
+    stage = pvs.DeviceBuffer(chunk * dim * 4)
+    for off in range(0, n, chunk):
+        m = min(chunk, n - off)
+        L.check(lib.pvs_synth_rows_f32(0, seed, off, m, dim, stage.ptr))
+        g = None if groups_of is None else groups_of(np.arange(off, off + m, dtype=np.int64))
+        L.check(lib.pvs_index_add_f32(ix._h, stage.ptr, m, None, None if g is None else g.ctypes.data, L.DEVICE))
+    stage.free()
+    return ix
+
+
+def test_config3_100M_x768_int8_batch256(pvs):
+    """configs[3]: 100,000,000 x 768 int8 (76.8 GB), batches of 256 queries, k = 100, on one GPU."""
+    free = C.c_uint64()
+    tot = C.c_uint64()
+    pvs._lib.check(pvs.lib().pvs_device_mem_info(0, C.byref(free), C.byref(tot)))
+    if free.value < 120 << 30:
+        pytest.skip("needs ~100 GB of free HBM")
+    n, dim, b, k = 100_000_000, 768, 256, 100
+    scale = 0.0015  # (the corpus-wide absmax/127 of unit Gaussian rows of this width is 0.00150-0.00151: any frozen artifact serves)
+    ix = _build_i8(pvs, n, dim, 20260928, scale)
+    q = orc.synth_rows(0x5EED0000, 0, b, dim)
+    ids, dist, cnt = ix.search(q, k, pvs.COSINE)
+    st = ix.stats()
+    assert st.rows == n and st.fast_queries == b and st.dense_queries == 0, "the 256-query filter scan must serve the whole batch"
+    assert (cnt == k).all()
+    assert (np.diff(dist, axis=1) >= 0).all(), "pages are sorted by distance"
+    same = np.diff(dist, axis=1) == 0
+    assert (np.diff(ids, axis=1)[same] > 0).all(), "ties are broken by id"
+    ids2, dist2, _ = ix.search(q, k, pvs.COSINE)
+    assert np.array_equal(ids, ids2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32)), "deterministic"
+    # prefix property: page of 10 = first 10 of the page of 100; a batch of 1 = row 0 of the batch of 256
+    i10, d10, _ = ix.search(q[:3], 10, pvs.COSINE)
+    assert np.array_equal(i10, ids[:3, :10]) and np.array_equal(d10.view(np.uint32), dist[:3, :10].view(np.uint32))
+    # the dense path (every one of the 100M rows scored exactly, full device sort) agrees on whole pages
+    ix.set_path(1)
+    di, dd, _ = ix.search(q[:2], k, pvs.COSINE)
+    ix.set_path(0)
+    assert np.array_equal(di, ids[:2]) and np.array_equal(dd.view(np.uint32), dist[:2].view(np.uint32)), "filter scan != exact scan + sort"
+    # the oracle on the rows that were returned (ids = row indexes here) ...
+    qc = orc.quantize_int8(q, scale)
+    for qi in (0, 255):
+        for j in (0, 1, 50, 99):
+            row = ix.read_rows(int(ids[qi, j]), 1)
+            assert np.float32(orc.vec_distance(orc.COSINE, row[0], qc[qi])).view(np.uint32) == dist[qi, j].view(np.uint32)
+    # ... and over a slab of the corpus: nothing in it beats the k-th distance without being on the page
+    r0, m = 61_000_000, 1_000_000
+    slab = ix.read_rows(r0, m)
+    si, sd = orc.search(orc.I8, orc.COSINE, slab, qc[:4], k, ids=np.arange(r0, r0 + m, dtype=np.int64), threads=orc.max_threads())
+    for qi in range(4):
+        better = sd[qi] < dist[qi, k - 1]
+        assert set(si[qi][better].tolist()) <= set(ids[qi].tolist()), "a slab row better than the k-th is missing from the page"
+    # row-sharded = whole: 8 shards' pages of the same corpus merge into the same page (the 8-GPU form's merge, on real pages)
+    pages_i, pages_d, pages_c = [], [], []
+    mask = np.zeros(n, np.uint8)
+    for s in range(8):
+        a, e = pvs.shard_range(n, 8, s)
+        mask[:] = 0
+        mask[a:e] = 1
+        fi, fd, fc = ix.search_filtered(q[:4], k, mask, pvs.COSINE)
+        pages_i.append(fi), pages_d.append(fd), pages_c.append(fc)
+    mi, md, mc = pvs.merge_topk(np.stack(pages_i), np.stack(pages_d), np.stack(pages_c), k)
+    assert np.array_equal(mi, ids[:4]) and np.array_equal(md.view(np.uint32), dist[:4].view(np.uint32))
+    ix.close()
+
+
+def test_config4_two_25M_row_indexes_or_composition_rrf(pvs, monkeypatch):
+    """configs[4]: a 25M x 512 image-embedding index and a 25M x 1024 text-embedding index (int8, ~3 vectors per file), the PQL
+    OR-composition ranked by RRF.  The bounded fusion must return what ranking every one of the 2 x 8.3M files returns (the
+    reference's literal composition, itself pinned against the oracle at small sizes and in bench.py --config 4 at this size)."""
+    free = C.c_uint64()
+    tot = C.c_uint64()
+    pvs._lib.check(pvs.lib().pvs_device_mem_info(0, C.byref(free), C.byref(tot)))
+    if free.value < 80 << 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    n = 25_000_000
+    img = _build_i8(pvs, n, 512, 11, 0.00185, groups_of=lambda r: r // 3)
+    txt = _build_i8(pvs, n, 1024, 12, 0.0013, groups_of=lambda r: (r // 3) * 2)
+    qi, qt = orc.synth_rows(0x5EED0000, 0, 1, 512)[0], orc.synth_rows(0x5EED0011, 0, 1, 1024)[0]
+    brs = [dict(index=img, query=qi, metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=5, weight=1.0),
+           dict(index=txt, query=qt, metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=10, weight=0.7)]
+    for k in (100, 1000):
+        g1, s1 = pvs.rrf_search(brs, k)
+        assert pvs.lib().pvs_rrf_last_path() == 1, "the bounded fusion must serve configs[4]"
+        monkeypatch.setenv("PVS_RRF_FULL", "1")
+        g2, s2 = pvs.rrf_search(brs, k)
+        assert pvs.lib().pvs_rrf_last_path() == 2
+        monkeypatch.delenv("PVS_RRF_FULL")
+        assert np.array_equal(g1, g2) and np.array_equal(s1.view(np.uint64), s2.view(np.uint64)), k
+        assert (np.diff(s1) <= 0).all()
+    # each branch alone: the per-file page of the filter scan = the head of that branch's window
+    gg, gv, gc = img.search_groups(qi[None, :], 50, pvs.COSINE, pvs.AGG_MIN)
+    g_single, s_single = pvs.rrf_search(brs[:1], 50)
+    assert np.array_equal(g_single, gg[0, : gc[0]]), "one branch: RRF order = MIN order"
+    img.close()
+    txt.close()
