@@ -1261,3 +1261,55 @@ def test_rrf_bounded_fusion_equals_the_full_ranking(pvs):
     assert np.array_equal(gg, eg) and np.array_equal(gs.view(np.uint64), es.view(np.uint64))
     for b in dev:
         b["index"].close()
+
+
+def test_device_reproduces_the_frozen_fixture_vi(pvs):
+    """SURVEY §8c fixture (vi) — frozen bytes in tests/golden/fixture_vi.npz, not computed from the oracle at test time: the filter
+    scan and the dense path must both return those ids and those f32 distances for {f32, f16, i8} x {cosine, L2}."""
+    import zlib
+
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixture_vi.npz"))
+    n, dim, k = int(f["n"]), int(f["dim"]), int(f["k"])
+    rows = orc.synth_rows(int(f["seed_rows"]), 0, n, dim)
+    queries = orc.synth_rows(int(f["seed_queries"]), 0, 8, dim)
+    assert zlib.crc32(rows.tobytes()) == int(f["rows_crc32"])
+    scale = float(f["scale"])
+    assert pvs.scale_from_absmax(pvs.absmax(rows)) == np.float32(scale)
+    for name, dt in (("f32", pvs.F32), ("f16", pvs.F16), ("i8", pvs.I8)):
+        ix = make_index(pvs, dt, rows, scale)
+        for mname, m in (("cosine", pvs.COSINE), ("l2", pvs.L2)):
+            for path in (0, 1):
+                ix.set_path(path)
+                ids, dist, cnt = ix.search(queries, k, m)  # f32 queries: an int8 index quantizes them on the device (compute_query_quant)
+                assert np.array_equal(ids, f[f"{name}_{mname}_ids"]), (name, mname, path)
+                assert np.array_equal(dist.view(np.uint32), f[f"{name}_{mname}_dist"].view(np.uint32)), (name, mname, path)
+        ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_float_distances_within_1e5_of_the_f64_formula(pvs, dtype):
+    """BASELINE.json north_star: fp32 / fp16 cosine within 1e-5 relative of the reference.  Asserted here WITHOUT the oracle:
+    returned distances against numpy f64 evaluations of 1 - a.q/(|a||q|) and |a - q| over the stored values, and the returned
+    ids against the f64 ranking wherever the f64 gap to the next row exceeds the tolerance."""
+    pdt = pvs.F16 if dtype == "f16" else pvs.F32
+    n, dim, k = 60_000, 768, 50
+    rows = unit_rows(123, n, dim)
+    stored = (rows.astype(np.float16) if dtype == "f16" else rows).astype(np.float64)
+    ix = make_index(pvs, pdt, rows)
+    qs = orc.synth_rows(124, 0, 6, dim)
+    qf = qs.astype(np.float64)
+    for m in (pvs.COSINE, pvs.L2):
+        ids, dist, cnt = ix.search(qs, k, m)
+        for qi in range(len(qs)):
+            if m == pvs.COSINE:
+                full = 1.0 - (stored @ qf[qi]) / (np.linalg.norm(stored, axis=1) * np.linalg.norm(qf[qi]))
+            else:
+                full = np.linalg.norm(stored - qf[qi], axis=1)
+            exact = full[ids[qi]]
+            assert np.all(np.abs(dist[qi] - exact) <= REL_TOL * np.abs(exact)), (dtype, m, qi, float(np.max(np.abs(dist[qi] - exact) / np.abs(exact))))
+            order = np.argsort(full, kind="stable")[: k + 1]
+            gaps = np.diff(full[order])
+            for j in range(k):
+                if gaps[j] > 2 * REL_TOL * full[order[j]] and (j == 0 or gaps[j - 1] > 2 * REL_TOL * full[order[j]]):
+                    assert ids[qi, j] == order[j], (dtype, m, qi, j)
+    ix.close()

@@ -3,6 +3,8 @@ the vector-similarity path.  Values are restated from the
 reference's #[test] bodies; file:line under /root/reference/panoptikon/src/."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -325,3 +327,40 @@ def test_synth_rows_are_unit_vectors_and_deterministic():
     assert np.allclose(n, 1.0, atol=1e-6)
     comp = a.ravel() * np.sqrt(768)
     assert abs(comp.mean()) < 0.02 and abs(comp.std() - 1.0) < 0.02
+
+
+def _fixture_vi():
+    import zlib
+
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixture_vi.npz"))
+    rows = orc.synth_rows(int(f["seed_rows"]), 0, int(f["n"]), int(f["dim"]))
+    queries = orc.synth_rows(int(f["seed_queries"]), 0, 8, int(f["dim"]))
+    assert zlib.crc32(rows.tobytes()) == int(f["rows_crc32"]) and zlib.crc32(queries.tobytes()) == int(f["queries_crc32"]), "the synthetic generator drifted"
+    return f, rows, queries
+
+
+def test_oracle_reproduces_the_frozen_fixture_vi():
+    """SURVEY §8c fixture (vi): 10k x 512 seeded corpus, 8 queries, top-10 for {f32, f16, i8} x {cosine, L2} — frozen bytes
+    (tests/golden/fixture_vi.npz, made by tests/golden/make_fixture_vi.py).  The oracle must keep producing them; the GPU test
+    test_device_reproduces_the_frozen_fixture_vi checks the kernels against the same bytes."""
+    f, rows, queries = _fixture_vi()
+    scale = float(f["scale"])
+    assert np.float32(orc.compute_int8_scale(rows)) == np.float32(scale)
+    corp = {"f32": (orc.F32, rows, queries), "f16": (orc.F16, rows.astype(np.float16), queries),
+            "i8": (orc.I8, orc.quantize_int8(rows, scale), orc.quantize_int8(queries, scale))}
+    for name, (dt, c, q) in corp.items():
+        for mname, m in (("cosine", orc.COSINE), ("l2", orc.L2)):
+            ids, dist = orc.search(dt, m, c, q, int(f["k"]))
+            assert np.array_equal(ids, f[f"{name}_{mname}_ids"]), (name, mname)
+            assert np.array_equal(dist.view(np.uint32), f[f"{name}_{mname}_dist"].view(np.uint32)), (name, mname)
+            # and the fixture itself agrees with the f64 formulas within the north star's 1e-5 relative (floats) / the reference's 1e-4 (int8)
+            cf = c.astype(np.float64)
+            qf = q.astype(np.float64)
+            for qi in range(len(q)):
+                a = cf[ids[qi]]
+                if m == orc.COSINE:
+                    exact = 1.0 - (a @ qf[qi]) / (np.linalg.norm(a, axis=1) * np.linalg.norm(qf[qi]))
+                else:
+                    exact = np.linalg.norm(a - qf[qi], axis=1)
+                tol = 1e-4 if name == "i8" else 1e-5
+                assert np.all(np.abs(dist[qi] - exact) <= tol * np.maximum(np.abs(exact), 1e-3) + 1e-6), (name, mname, qi)
