@@ -134,9 +134,51 @@ __global__ __launch_bounds__(256) void k_rows_ingest(const void *src, uint32_t d
         *(uint4 *)(rows + pvs_chunk_off(row0 + r, c, stride)) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
+// quantize_int8 without the IEEE division on the common path: t = x * (1/s) is within 2 ulp of x/s, so rint(t) = rint(fl(x/s))
+// unless t sits within a few ulp of a half-integer (where the rounding of the quotient itself decides: the exact division then)
+__device__ static inline int8_t quant_fast(float x, float scale, float inv_scale) {
+    const float t = x * inv_scale;
+    const float a = fabsf(t);
+    const float f = a - floorf(a);
+    if (__builtin_expect(!(fabsf(f - 0.5f) > a * 6.0e-7f + 1.0e-30f), 0)) return quant_one(x, scale);  // (also NaN)
+    const float q = fminf(fmaxf(rintf(t), -128.0f), 127.0f);
+    return (int8_t)(int)q;
+}
+// The build-side codec at streaming speed: one lane = four consecutive f32 components (16-byte loads, a wave reads 1 KiB
+// contiguous) -> 4 int8 codes (one dword) or 4 f16 (two dwords) into the tiled layout.  dim % 4 == 0, 16-byte aligned source.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rows_ingest4(const float4 *src, uint32_t dim4, uint64_t row0, uint64_t n, float scale, float inv_scale,
+                                                      uint8_t *rows, uint32_t stride) {
+    const uint64_t total = n * (uint64_t)dim4;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = t / dim4;
+        const uint32_t g = (uint32_t)(t - r * dim4);
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        const v4f_t vv = __builtin_nontemporal_load((const v4f_t *)(src + t));  // read once
+        const float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (MODE == 0) {
+            const uint32_t w = (uint32_t)(uint8_t)quant_fast(v.x, scale, inv_scale) | ((uint32_t)(uint8_t)quant_fast(v.y, scale, inv_scale) << 8) |
+                               ((uint32_t)(uint8_t)quant_fast(v.z, scale, inv_scale) << 16) | ((uint32_t)(uint8_t)quant_fast(v.w, scale, inv_scale) << 24);
+            *(uint32_t *)(rows + pvs_chunk_off(row0 + r, g >> 2, stride) + (g & 3u) * 4u) = w;
+        } else {
+            const uint32_t lo = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v.x) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v.y) << 16);
+            const uint32_t hi = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v.z) | ((uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v.w) << 16);
+            *(uint2 *)(rows + pvs_chunk_off(row0 + r, g >> 1, stride) + (g & 1u) * 8u) = make_uint2(lo, hi);
+        }
+    }
+}
 hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint32_t esz, uint64_t row0, uint64_t n, float scale,
                                   uint8_t *rows, uint32_t stride, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    if ((mode == 0 || mode == 1) && dim % 4 == 0 && ((uintptr_t)src & 15) == 0) {
+        const uint64_t total = n * (uint64_t)(dim / 4);
+        const unsigned g = (unsigned)std::min<uint64_t>((total + 255) / 256, 65536);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_rows_ingest4<0>, dim3(g), dim3(256), 0, s, (const float4 *)src, dim / 4, row0, n, scale, 1.0f / scale, rows, stride);
+        else
+            hipLaunchKernelGGL(k_rows_ingest4<1>, dim3(g), dim3(256), 0, s, (const float4 *)src, dim / 4, row0, n, scale, 1.0f, rows, stride);
+        return hipGetLastError();
+    }
     const uint32_t per = 16u / esz;
     const uint64_t total = n * (uint64_t)((dim + per - 1) / per);
     unsigned g = (unsigned)((total + 255) / 256 > 32768 ? 32768 : (total + 255) / 256);

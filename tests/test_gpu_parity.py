@@ -1313,3 +1313,44 @@ def test_float_distances_within_1e5_of_the_f64_formula(pvs, dtype):
                 if gaps[j] > 2 * REL_TOL * full[order[j]] and (j == 0 or gaps[j - 1] > 2 * REL_TOL * full[order[j]]):
                     assert ids[qi, j] == order[j], (dtype, m, qi, j)
     ix.close()
+
+
+def test_ingest_codec_is_bit_exact_on_rounding_boundaries(pvs):
+    """The build-side codec (k_rows_ingest4: multiply by 1/s on the common path, IEEE division only near half-integers) against
+    quantize_int8's definition clamp(round_ties_even(x / s)) (db/vector_quants.rs:1489-1497): quotients on, just below and just
+    above every half-integer and integer in the code range and beyond, for awkward scales, plus NaN / inf / huge values."""
+    rng = np.random.default_rng(17)
+    dim = 256
+    for scale in (np.float32(3.0 / 127), np.float32(11.0 / 127), np.float32(0.0015056864), np.float32(1.0), np.float32(7.3e-5), np.float32(123.456)):
+        m = np.arange(-135, 136, dtype=np.float64)
+        targets = np.concatenate([m, m + 0.5, m + 0.25])
+        base = (targets * np.float64(scale)).astype(np.float32)
+        vals = [base]
+        for step in (1, 2, 3, 8):
+            up, dn = base.copy(), base.copy()
+            for _ in range(step):
+                up = np.nextafter(up, np.float32(np.inf))
+                dn = np.nextafter(dn, np.float32(-np.inf))
+            vals += [up, dn]
+        x = np.concatenate(vals + [np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 0.0, -0.0, 1e-45, -1e-45], np.float32),
+                                   (rng.standard_normal(5000) * 40 * scale).astype(np.float32)])
+        n = (len(x) + dim - 1) // dim
+        x = np.concatenate([x, np.zeros(n * dim - len(x), np.float32)]).reshape(n, dim)
+        ix = pvs.VectorIndex(pvs.I8, dim)
+        ix.set_scale(float(scale))
+        ix.add_f32(x)
+        got = ix.read_rows(0, n)
+        exp = orc.quantize_int8(x, float(scale))
+        bad = np.argwhere(got != exp)
+        assert len(bad) == 0, (float(scale), x[tuple(bad[0])], got[tuple(bad[0])], exp[tuple(bad[0])])
+        ix.close()
+    # f16 ingest (round to nearest even) through the same kernel shape
+    x = (rng.standard_normal((300, dim)) * 10).astype(np.float32)
+    x[0, :8] = [65504.0, 65520.0, 1e-8, 6.1e-5, np.nan, np.inf, -0.0, 5.96e-8]
+    ix = pvs.VectorIndex(pvs.F16, dim)
+    ix.add_f32(x)
+    with np.errstate(over="ignore"):
+        exp = x.astype(np.float16)
+    got = ix.read_rows(0, 300)
+    assert np.array_equal(got.view(np.uint16)[~np.isnan(exp)], exp.view(np.uint16)[~np.isnan(exp)]) and np.isnan(got[np.isnan(exp)]).all()
+    ix.close()
