@@ -5,6 +5,7 @@ FETCH_SIZE is doubled: gfx950 reports half the bytes of a wide coalesced stream 
 import json
 import re
 import sys
+import time
 
 
 def per_launch(md, counter):
@@ -41,5 +42,6 @@ out = {
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
               "(gfx950 reports half the bytes of a wide coalesced stream); WRITE_SIZE as reported",
     "algorithmic_bytes_per_launch": j["roofline"]["algorithmic_bytes_per_launch"],
+    "collected": time.strftime("%Y-%m-%d", time.gmtime()),
 }
 print(json.dumps(out, indent=1))
