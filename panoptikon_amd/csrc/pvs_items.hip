@@ -46,7 +46,7 @@ pvs_status ensure_groups(pvs_index *ix) {
 }
 
 // d_out[row * nb + q], nb <= PVS_MAX_BATCH queries already prepared in ctx c (prep_chunk)
-static pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
+pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
     const uint32_t kslabs = ix->stride / PVS_KSLAB_BYTES;
     if (ix->dtype == PVS_I8 && pvs_scan_supported(PVS_I8, kslabs) && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
         // matrix-core path: exact integer dots, closed-form finish (valid below 2^24)

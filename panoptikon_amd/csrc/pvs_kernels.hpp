@@ -119,6 +119,11 @@ pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *i
 // scalar (a NaN scalar makes every filter comparison of the row false)
 hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s);
 
+// ---- page 1 of many dense columns at once (pvs_select.hip): m [n][ld] f32, column j -> query slot qmap[j] (or j)
+bool pvs_select_supported(uint32_t k);
+pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq, uint32_t k, const uint8_t *mask, const int64_t *ids,
+                           const uint32_t *d_qmap, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s);
+
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,

@@ -72,6 +72,25 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         float *od = d_out_dist + (size_t)qoff * k;
         uint32_t *oc = d_out_count + qoff;
         if (!fast) {
+            static const bool per_query = getenv("PVS_DENSE_PER_QUERY") != nullptr;
+            if (nb >= 2 && pvs_select_supported(k) && !per_query) {  // all of the chunk's queries per corpus pass, pages by radix select
+                const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nb, (1ull << 31) / (4 * std::max<uint64_t>(ix->n, 1))));
+                float *d_m = nullptr;
+                HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)ix->n * per * 4));
+                pvs_status st = PVS_OK;
+                for (uint32_t off = 0; off < nb && st == PVS_OK; off += per) {
+                    const uint32_t nbb = std::min(per, nb - off);
+                    const uint32_t pad = nbb <= 32 ? 32 : nbb <= 64 ? 64 : 128;
+                    st = prep_chunk(ix, c, d_queries, qdtype, qoff + off, nbb, pad, metric);
+                    if (st == PVS_OK) st = dense_chunk(ix, c, nbb, pad, metric, d_m);
+                    if (st == PVS_OK)
+                        st = pvs_select_topk(d_m, ix->n, nbb, nbb, k, c.cur_mask, ix->d_ids, nullptr, oid + (size_t)off * k, od + (size_t)off * k, oc + off, c.stream);
+                }
+                pvs_scratch_free(d_m);
+                PVS_TRY(st);
+                ix->dense_queries += nb;
+                continue;
+            }
             for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
             continue;
         }
@@ -182,6 +201,44 @@ pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, 
     ix->fast_queries += batch - n_dense;
     if (!n_dense) return PVS_OK;
     if (ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "%u queries need the dense path but path=2 forbids it", n_dense);
+    static const bool no_batched = getenv("PVS_DENSE_PER_QUERY") != nullptr;  // tests: the round-1 form (one query per pass, full sort)
+    if (n_dense >= 2 && pvs_select_supported(k) && !no_batched) {
+        // Several queries at once: scored together into one [rows][queries] matrix (int8: up to 128 per corpus pass on the
+        // matrix cores), pages by an exact radix select over all columns (pvs_select.hip) — not one corpus pass + one full
+        // sort per query.
+        std::vector<uint32_t> dq;
+        for (uint32_t q = 0; q < batch; q++)
+            if (c.h_need_dense[q]) dq.push_back(q);
+        const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+        const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)PVS_MAX_BATCH, (1ull << 31) / (4 * std::max<uint64_t>(ix->n, 1)), (uint64_t)n_dense}));
+        uint8_t *d_qd = nullptr;
+        float *d_m = nullptr;
+        uint32_t *d_qmap = nullptr;
+        auto body = [&]() -> pvs_status {
+            HIP_TRY(pvs_scratch_alloc((void **)&d_qd, qbytes * n_dense));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)ix->n * per * 4));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_qmap, (size_t)n_dense * 4));
+            for (uint32_t i = 0; i < n_dense; i++)
+                HIP_TRY(hipMemcpyAsync(d_qd + (size_t)i * qbytes, (const uint8_t *)d_queries + (size_t)dq[i] * qbytes, qbytes, hipMemcpyDeviceToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_qmap, dq.data(), (size_t)n_dense * 4, hipMemcpyHostToDevice, c.stream));
+            for (uint32_t off = 0; off < n_dense; off += per) {
+                const uint32_t nb = std::min(per, n_dense - off);
+                const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+                PVS_TRY(prep_chunk(ix, c, d_qd, qdtype, off, nb, pad, metric));
+                PVS_TRY(dense_chunk(ix, c, nb, pad, metric, d_m));
+                PVS_TRY(pvs_select_topk(d_m, ix->n, nb, nb, k, c.cur_mask, ix->d_ids, d_qmap + off, d_out_ids, d_out_dist, d_out_count, c.stream));
+            }
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            return PVS_OK;
+        };
+        pvs_status st = body();
+        if (st != PVS_OK) (void)hipStreamSynchronize(c.stream);
+        pvs_scratch_free(d_qd);
+        pvs_scratch_free(d_m);
+        pvs_scratch_free(d_qmap);
+        if (st == PVS_OK) ix->dense_queries += n_dense;
+        return st;
+    }
     for (uint32_t qoff = 0; qoff < batch; qoff += PVS_MAX_BATCH) {
         const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
         bool any = false;

@@ -1354,3 +1354,49 @@ def test_ingest_codec_is_bit_exact_on_rounding_boundaries(pvs):
     got = ix.read_rows(0, 300)
     assert np.array_equal(got.view(np.uint16)[~np.isnan(exp)], exp.view(np.uint16)[~np.isnan(exp)]) and np.isnan(got[np.isnan(exp)]).all()
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_batched_dense_select_on_massive_ties_and_nulls(pvs, dtype):
+    """The dense path for many queries at once (pvs_select.hip): every query scored per corpus pass, pages by an exact radix
+    select with ties cut by row.  Worst cases for a select: all distances equal (duplicated corpus), two-valued distances, NULL
+    rows needed to fill the page, fewer rows than k, a candidate mask — all against the oracle; and the round-1 per-query form
+    must agree (same kernel inputs, full sort)."""
+    pdt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    odt = {"i8": orc.I8, "f16": orc.F16, "f32": orc.F32}[dtype]
+    rng = np.random.default_rng(3)
+    dim, n = 64, 30_000
+    base = unit_rows(211, 7, dim)
+    rows = base[rng.integers(0, 7, n)]          # 7 distinct vectors: every query sees 7 tie classes of ~4,300 rows
+    rows[1000:1100] = 0.0                       # NULL cosine distances
+    rows[5] = unit_rows(212, 1, dim)[0]         # one unique row
+    scale = orc.compute_int8_scale(rows) if dtype == "i8" else None
+    corpus = host_corpus(odt, rows, scale)
+    qs = np.concatenate([base[:3], unit_rows(213, 9, dim)])
+    hq = orc.quantize_int8(qs, scale) if dtype == "i8" else qs
+    ix = make_index(pvs, pdt, rows, scale)
+    for metric, om in ((pvs.COSINE, orc.COSINE), (pvs.L2, orc.L2)):
+        for k in (1, 50, 5000):
+            ei, ed = orc.search(odt, om, corpus, hq, k)
+            for path in (0, 1):   # 0: the filter scan hands the tie-heavy queries back; 1: dense for everyone
+                ix.set_path(path)
+                gi, gd, gc = ix.search(qs, k, metric)
+                assert (gc == min(k, n)).all()
+                assert np.array_equal(gi[:, : ei.shape[1]], ei), (dtype, metric, k, path)
+                g = gd[:, : ei.shape[1]]
+                assert np.array_equal(np.isnan(g), np.isnan(ed)) and np.array_equal(g[~np.isnan(g)].view(np.uint32), ed[~np.isnan(ed)].view(np.uint32))
+            ix.set_path(0)
+    st = ix.stats()
+    assert st.dense_queries > 0
+    # a candidate mask that leaves fewer rows than k, and one that cuts through a tie class
+    mask = np.zeros(n, np.uint8)
+    mask[2000:2040] = 1
+    mask[1050] = 1  # a NULL row among the candidates
+    ix.set_path(1)
+    gi, gd, gc = ix.search_filtered(qs, 64, mask, pvs.COSINE)
+    d = np.stack([orc.score_all(odt, orc.COSINE, corpus, hq[i]) for i in range(len(qs))])
+    cand = np.flatnonzero(mask)
+    for i in range(len(qs)):
+        ei, ed = orc.topk(d[i][cand], 64, ids=cand.astype(np.int64))
+        assert gc[i] == len(cand) and np.array_equal(gi[i, : len(ei)], ei)
+    ix.close()
