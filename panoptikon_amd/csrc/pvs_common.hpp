@@ -54,8 +54,9 @@ constexpr uint32_t PVS_MAX_BATCH = 128;   // queries per dense / group pass (4 w
 constexpr uint32_t PVS_SCAN_MAX_BATCH = 256;  // queries per filter-scan pass (int8: 4 waves x 2 groups x 32); sizes the per-search buffers
 constexpr uint32_t PVS_MAX_K = 4096;      // page size served by the filter path (the reference prefetches up to 4096 rows, api/search.rs:51)
 constexpr uint32_t PVS_CAND_CAP = 16384;  // candidate slots per query
-constexpr uint32_t PVS_SEG_CAP = 64;      // candidate slots per (segment, query): ~6 expected at k = 100 (1,600 candidates over >= 256 segments)
-constexpr uint32_t PVS_SEG_PAIRS = 65536; // (segment, query) pairs per pass: 256 queries x 256 segments ... 32 queries x 2,048 segments
+constexpr uint32_t PVS_SEG_CAP = 64;       // candidate slots per (segment, query): ~3 expected at k = 100 (1,600 candidates over >= 512 segments)
+constexpr uint32_t PVS_SEG_PAIRS = 131072; // (segment, query) pairs per pass: 256 queries x 512 segments ... 32 queries x 4,096 segments
+                                           // (segment = one half-wave of one workgroup row stream: its candidates are written by one lane)
 constexpr uint32_t PVS_AUX_REC = 64;     // floats per 32-row tile in the scan's row-scalar stream: 32 row scalars, min, max, padding
 constexpr uint32_t PVS_SURV_CAP = 8192;   // survivors reranked exactly per query (their sort records overlay the 64 KiB bound array)
 

@@ -31,7 +31,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg_cnt = a.seg_cnt;
     k.seg_queries = a.qgroups * 32;
     k.seg_cap = PVS_SEG_CAP;
-    k.seg_stride = a.grid * pvs_scan_row_tiles(a.qgroups);
+    k.seg_stride = a.grid * pvs_scan_row_tiles(a.qgroups) * 2;
     k.n_rows = a.n_rows;
     k.stride = a.stride;
     const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);

@@ -146,7 +146,7 @@ struct Geo {
     static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
                                                           // same record): tiles in flight + the previous tile, kept for its epilogue
     static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 row-scalar DMA
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + WAVES * GPW * 32 * 4;  // ring, row scalars, per-wave candidate counters
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256;  // ring, row-scalar records
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
@@ -171,7 +171,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
     uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NCN][WAVES][256 B]
-    uint32_t *const seg_cnt = (uint32_t *)(normring + NCN * WAVES * 256);  // [WAVES][GPW][32] candidates emitted per query of the wave
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,17 +194,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
         for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
-    // Candidate emission (MODE 1).  Every (workgroup stream, query) pair owns a SEGMENT of a.seg_cap slots in HBM; the
-    // segment of query column j of this wave is written by this wave alone (its two half-waves hold different rows of
-    // the same 32 queries), so the fill counts live in wave-private LDS: no staging list, no flush, no global atomic.
-    // A segment that overflows is reported through its count (pass C then hands the query to the dense path).
-    uint32_t *const my_cnt = seg_cnt + (size_t)wave * (GPW * 32);
-    const uint32_t seg = blockIdx.x * RT + rt;  // this wave's segment index, shared by the QW waves side by side (different queries)
-    if (MODE == 1) {
+    // Candidate emission (MODE 1).  Every (workgroup row stream, half-wave, query) triple owns a SEGMENT of a.seg_cap slots in
+    // HBM, written by exactly one LANE (lane (j, h) holds query column j and the rows of half h), so the fill count is a
+    // register of that lane: no staging list, no flush, no atomic of any kind.  A segment that overflows is reported through
+    // its count (pass C then hands the query to the dense path).
+    const uint32_t seg = (blockIdx.x * RT + rt) * 2 + h;  // this lane's segment index (the QW waves side by side hold different queries)
+    uint32_t mycnt[GPW];
 #pragma unroll
-        for (int g = 0; g < GPW; g++)
-            if (h == 0) my_cnt[g * 32 + j] = 0;
-    }
+    for (int g = 0; g < GPW; g++) mycnt[g] = 0;
     if (n_my > 0) {
         // ---- query fragments: resident in registers for the whole kernel
         constexpr int SPS = steps_per_slab<DT>();
@@ -359,24 +355,44 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             if constexpr (DT == PVS_F32) return __builtin_ldexpf(d, -f32_row_exp<COS>(x));
             return d;
         };
-        // per-row emission for one group: rows whose exact filter test passes are appended to the query's segment — with
-        // SCALAR stores (s_store_dwordx2, one per candidate, lane by lane off the ballot).  gfx9's vmcnt counts stores too,
-        // so a vector store issued here made the next counted LDS-DMA wait cover the store's acknowledgement as well: a
-        // partial drain of the prefetch ring on nearly every tile (1.3 candidates per workgroup tile at 256 queries; measured
-        // 0.43 of 2.1 ms, whatever the form: staged + flushed with atomics, or one plain store per candidate).  Scalar
-        // stores travel on lgkmcnt, which the LDS-DMA stream never touches; s_dcache_wb at the end of the kernel writes the
-        // scalar cache back for pass C.
-        auto emit_rows = [&](int g, const float(&xh)[16], auto &&pv) {
+        // per-row emission for one group: rows whose exact filter test passes are appended to the lane's segment — with
+        // SCALAR stores (s_store_dwordx2, one per candidate, lane by lane off the ballot), fire and forget.  Why not a vector
+        // store: gfx9's vmcnt counts stores too, so one issued here makes the next counted LDS-DMA wait cover the store's
+        // acknowledgement as well — a partial drain of the prefetch ring.  Scalar stores travel on lgkmcnt, which the LDS-DMA
+        // stream never touches; their operands are read at issue (tools/probe/sstore_nowait_test.hip: 84M back-to-back stores
+        // with the SGPRs rewritten right behind them), so nothing waits per candidate; s_dcache_wb at the end of the kernel
+        // writes the scalar cache back for pass C.  What a candidate costs matters eight-fold: the emitting wave's extra
+        // cycles are what the other waves of the workgroup wait for at the next per-tile barrier (§4.1b of DESIGN.md).
+        // Two stages, so that the common case — one passing row in one lane — costs one pipelined sweep and one branch chain on
+        // SCALAR masks instead of 16 dependent (convert, scale, compare, branch-on-VCC) sequences: stage 1 compares all 16
+        // sums with the lane's pre-test bound `eb` (no row scalar, v_cmp straight into an SGPR pair per row); stage 2 runs the
+        // exact per-row test only for the rows whose mask is non-empty.  Without a pre-test (f32 rows) stage 1 IS the exact test.
+        auto emit_rows = [&](int g, elem_t eb, const float(&xh)[16], auto &&pv) {
             const uint32_t q0 = (uint32_t)(qw * GPW + g) * 32u;  // first query of the group (wave-uniform)
+            const uint32_t seg0 = (blockIdx.x * RT + rt) * 2;    // segment of half 0 (wave-uniform)
+            auto exact = [&](int r) { return score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]); };
+            unsigned long long mr[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float sv = score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]);
-                bool p = COS ? (sv >= tS[g]) : (sv <= tS[g]);
+                bool c;
+                if constexpr (PRETEST) {
+                    c = pv(g, r) >= eb;
+                } else {
+                    const float sv = exact(r);
+                    c = COS ? (sv >= tS[g]) : (sv <= tS[g]);
+                }
 #ifdef PVS_ABL_NOEMIT
-                asm volatile("" ::"v"(p));
-                p = false;
+                asm volatile("" ::"v"(c));
+                c = false;
 #endif
-                unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+                mr[r] = __builtin_amdgcn_ballot_w64(c);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (mr[r] == 0) continue;
+                const float sv = exact(r);
+                const bool p = COS ? (sv >= tS[g]) : (sv <= tS[g]);
+                unsigned long long m = PRETEST ? __builtin_amdgcn_ballot_w64(p) : mr[r];
                 if (m != 0) {
                     uint32_t payload;
                     if constexpr (DT == PVS_I8)
@@ -384,20 +400,21 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     else
                         payload = __builtin_bit_cast(uint32_t, COS ? -sv * qi[g].dscale : sv + qi[g].bb + qi[g].eR * xh[r]);
                     const uint32_t rowv = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
-                    uint32_t pos = 0;
-                    if (p) pos = atomicAdd(&my_cnt[g * 32 + j], 1u);  // LDS, wave-private; both half-waves hold rows of query j
                     do {
                         const int l = __builtin_ctzll(m);
                         m &= m - 1;
-                        const uint32_t pos_s = (uint32_t)__builtin_amdgcn_readlane((int)pos, l);
+                        const uint32_t pos_s = (uint32_t)__builtin_amdgcn_readlane((int)mycnt[g], l);
                         if (pos_s < a.seg_cap) {
                             const uint32_t row_s = (uint32_t)__builtin_amdgcn_readlane((int)rowv, l);
                             const uint32_t key_s = (uint32_t)__builtin_amdgcn_readlane((int)payload, l);
-                            const uint2 *dst = a.seg + ((size_t)seg * a.seg_queries + (q0 + ((uint32_t)l & 31u))) * a.seg_cap + pos_s;
+                            const uint2 *dst = a.seg + ((size_t)(seg0 + ((uint32_t)l >> 5)) * a.seg_queries + (q0 + ((uint32_t)l & 31u))) * a.seg_cap + pos_s;
                             const uint64_t data = ((uint64_t)key_s << 32) | row_s;
-                            asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" ::"s"(data), "s"(dst) : "memory");
+                            // s_nop: a readlane result (VALU-written SGPR) may not feed an SMEM instruction within 4 wait states,
+                            // and the hazard recognizer does not look inside inline asm
+                            asm volatile("s_nop 4\n\ts_store_dwordx2 %0, %1, 0x0" ::"s"(data), "s"(dst) : "memory");
                         }
                     } while (m != 0);
+                    if (p) mycnt[g]++;
                 }
             }
         };
@@ -409,6 +426,8 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             float sv[GPW][16];
             float best[GPW];
             elem_t mx[GPW];
+            elem_t eb[GPW];  // PRETEST: the lane's bound for this tile
+            float t0, t1;    // PRETEST: the previous tile's extreme row scalars
         };
         constexpr int EPI_STEPS = PRETEST ? 8 * GPW : 16 * GPW;
         auto epi_begin = [&](Epi &e) {
@@ -424,8 +443,48 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             if (MODE == 1) return;
 #endif
             if constexpr (PRETEST) {
+                // Every slice ends in an empty volatile asm on its result: without it the optimizer reassociates the fold and
+                // sinks it, the bound and the LDS read of the extremes behind the last MFMA of the tile, where nothing hides
+                // them (~250 cycles per wave and tile, in front of the barrier the other waves are waiting at).
                 const int g = m / 8, i = m % 8;
+                if (m == 0) {
+                    // Necessary condition for "some row of this lane passes", from the tile's extreme row scalars, which
+                    // ride behind the 32 row scalars in the tile's record (k_scan_aux: t0 = min |a| resp. min |a|^2 over
+                    // the tile's rows with a usable norm, t1 = the max).  Tile "-1": NaN bounds, nothing passes.
+                    e.t0 = e.t1 = __builtin_nanf("");
+                    if (p_nslot >= 0) {
+                        const float2 tmm = *(const float2 *)((const float *)(normring + p_nslot * (WAVES * 256) + wave * 256) + 32);
+                        e.t0 = tmm.x;
+                        e.t1 = tmm.y;
+                    }
+                    asm volatile("" : "+v"(e.t0), "+v"(e.t1));
+                }
+                if (i == 4) {
+                    //   cosine  d/|a| >= tS            =>  d >= tS * (tS > 0 ? min|a| : max|a|)
+                    //   L2      c1|a|^2 - 2 ds d <= tS =>  d >= (c1 * min|a|^2 - tS) / (2 ds)
+                    // minus a slack that covers the f32 roundings of the exact test (2^-18 relative is 30x what they add up
+                    // to).  NaN bounds (no usable row) compare false: nothing passes, which is right.
+                    float b, mag;
+                    if (COS) {
+                        b = tS[g] * (tS[g] > 0.f ? e.t0 : e.t1);
+                        mag = fabsf(b);
+                    } else {
+                        const float x = c1[g] * e.t0;
+                        b = (x - tS[g]) * hd[g];
+                        mag = (fabsf(x) + fabsf(tS[g])) * hd[g];
+                    }
+                    b = b - mag * 3.8147e-6f;
+                    if constexpr (DT == PVS_I8) {
+                        // integer dots (|d| < 2^24, exact in f32): d >= b  <=>  d >= ceil(b); one more of slack for the floor
+                        b -= 1.0f;
+                        e.eb[g] = b == b ? (int)fminf(fmaxf(ceilf(b), -1.0e9f), 1.0e9f) : 0x7fffffff;
+                    } else {
+                        e.eb[g] = b;
+                    }
+                    asm volatile("" : "+v"(e.eb[g]));
+                }
                 e.mx[g] = A::max3(e.mx[g], pv(g, 2 * i), pv(g, 2 * i + 1));
+                asm volatile("" : "+v"(e.mx[g]));
             } else {
                 const int g = m / 16, i = m % 16;
                 if (i < 8) {
@@ -480,35 +539,12 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                         mins[g][r] = fminf(mins[g][r], ub);
                     }
             } else if constexpr (PRETEST) {
-                // Necessary condition for "some row of this lane passes", from the tile's extreme row scalars, which
-                // ride behind the 32 row scalars in the tile's record (k_scan_aux: prev_t0 = min |a| resp. min |a|^2 over
-                // the tile's rows with a usable norm, prev_t1 = the max):
-                //   cosine  d/|a| >= tS            =>  d >= tS * (tS > 0 ? min|a| : max|a|)
-                //   L2      c1|a|^2 - 2 ds d <= tS =>  d >= (c1 * min|a|^2 - tS) / (2 ds)
-                // minus a slack that covers the f32 roundings of the exact test (2^-18 relative is 30x what they add up to,
-                // +1 for the integer floor).  NaN bounds (no usable row) compare false: nothing passes, which is right.
+                // the bound was computed in the shadow of the MFMAs (epi_micro); what is left here is one compare per group
                 bool any = false;
                 bool lp[GPW];
-                float prev_t0 = __builtin_nanf(""), prev_t1 = __builtin_nanf("");  // tile "-1": NaN bounds, nothing passes
-                if (p_nslot >= 0) {
-                    const float2 tmm = *(const float2 *)((const float *)(normring + p_nslot * (WAVES * 256) + wave * 256) + 32);
-                    prev_t0 = tmm.x;
-                    prev_t1 = tmm.y;
-                }
 #pragma unroll
                 for (int g = 0; g < GPW; g++) {
-                    float b, mag;
-                    if (COS) {
-                        b = tS[g] * (tS[g] > 0.f ? prev_t0 : prev_t1);
-                        mag = fabsf(b);
-                    } else {
-                        const float x = c1[g] * prev_t0;
-                        b = (x - tS[g]) * hd[g];
-                        mag = (fabsf(x) + fabsf(tS[g])) * hd[g];
-                    }
-                    b = b - mag * 3.8147e-6f;
-                    if constexpr (DT == PVS_I8) b -= 1.0f;  // (integer dots; their f32 image below is within 2^-24 relative)
-                    lp[g] = (float)e.mx[g] >= b;
+                    lp[g] = e.mx[g] >= e.eb[g];
                     any |= lp[g];
                 }
 #ifdef PVS_ABL_FOLDONLY
@@ -522,13 +558,13 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     load_xh(e.xh);
 #pragma unroll
                     for (int g = 0; g < GPW; g++)
-                        if (__builtin_amdgcn_ballot_w64(lp[g]) != 0) emit_rows(g, e.xh, pv);
+                        if (__builtin_amdgcn_ballot_w64(lp[g]) != 0) emit_rows(g, e.eb[g], e.xh, pv);
                 }
             } else {
 #pragma unroll
                 for (int g = 0; g < GPW; g++) {
                     const bool lane_pass = COS ? (e.best[g] >= tS[g]) : (e.best[g] <= tS[g]);
-                    if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) emit_rows(g, e.xh, pv);
+                    if (__builtin_amdgcn_ballot_w64(lane_pass) != 0) emit_rows(g, elem_t{}, e.xh, pv);
                 }
             }
         };
@@ -659,12 +695,11 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         }
         wait_vm<0>();  // retire the dummy tail DMAs before the wave exits
-        if (MODE == 1) asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // candidates: scalar cache -> L2
+        if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // candidates: scalar cache -> L2
     }
-    if (MODE == 1) {   // this wave's fill counts: seg_cnt[query][segment]
+    if (MODE == 1) {   // every lane's fill count: seg_cnt[query][segment]
 #pragma unroll
-        for (int g = 0; g < GPW; g++)
-            if (h == 0) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = my_cnt[g * 32 + j];
+        for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = mycnt[g];
     }
 
     if (MODE == 0) {

@@ -146,8 +146,8 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.mode = 1;
         a.tile_step = 1;
         const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
-        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu, PVS_SEG_PAIRS / (batch_pad * rt)});
-        a.n_segments = a.grid * rt;
+        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu, PVS_SEG_PAIRS / (batch_pad * rt * 2)});
+        a.n_segments = a.grid * rt * 2;
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
