@@ -62,6 +62,7 @@ struct ScanArgs {
     uint2 *seg = nullptr;          // [n_segments][batch_pad][PVS_SEG_CAP] = (row, key bits)
     uint32_t *seg_cnt = nullptr;   // [batch_pad][n_segments] fill counts, written by the scan (above PVS_SEG_CAP = overflowed)
     uint32_t n_segments = 0;       // out: set by pvs_scan_plan(): grid * RT
+    uint32_t qsplit = 1;           // workgroups per tile stream, each with its own qgroups*32 queries of the batch (mode 1; see ScanK.qsplit)
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 uint32_t pvs_scan_wg_rows(uint32_t qgroups);  // rows per workgroup tile

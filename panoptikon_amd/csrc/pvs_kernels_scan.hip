@@ -44,6 +44,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.dense_flag = a.dense_flag;
     k.dense_ld = a.dense_ld;
     k.batch = a.batch;
+    k.qsplit = a.qsplit ? a.qsplit : 1;
+    k.seg_queries = a.qgroups * 32 * k.qsplit;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
         e = a.qgroups == 8   ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)

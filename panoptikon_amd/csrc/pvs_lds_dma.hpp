@@ -36,3 +36,21 @@ __device__ static inline void wait_vm() {
 }
 __device__ static inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+
+// ---- elastic hand-off between the waves of a workgroup (instead of s_barrier): monotonic arrival counters in LDS.
+// `lds_signal` adds one arrival from this wave (call it from every lane: only lane 0 issues the atomic);
+// `lds_await2` polls until both counters have reached their targets, with a bound on the number of polls so that a
+// protocol bug can never hang the device: it returns false when it gave up.
+__device__ static inline void lds_signal(uint32_t lds_counter, int lane) {
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(lds_counter), "v"(1u) : "memory");
+}
+__device__ static inline bool lds_await2(uint32_t lds_a, uint32_t need_a, uint32_t lds_b, uint32_t need_b) {
+    for (int it = 0; it < (1 << 16); it++) {  // ~3 ms at the very least; a legitimate wait is a few microseconds
+        uint32_t va, vb;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(va), "=&v"(vb) : "v"(lds_a), "v"(lds_b) : "memory");
+        const uint32_t sa = __builtin_amdgcn_readfirstlane(va), sb = __builtin_amdgcn_readfirstlane(vb);
+        if ((int)(sa - need_a) >= 0 && (int)(sb - need_b) >= 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}

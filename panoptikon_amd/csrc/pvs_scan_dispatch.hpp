@@ -18,6 +18,11 @@ struct ScanK {
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
     uint32_t dense_ld, batch;
+    // Query split: `qsplit` workgroups walk the SAME tile stream, each with its own QG*32 queries (query offset = its index in
+    // the split) — 256 queries as two independent 4-wave workgroups instead of one 8-wave workgroup.  The launch has
+    // 8 * ceil(grid / 8) * qsplit workgroups, numbered so that the workgroups of one stream land on the same XCD (workgroups go
+    // to the XCDs round-robin by index): the second one finds the tile in that XCD's L2.  grid stays the number of STREAMS.
+    uint32_t qsplit;
 };
 
 hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

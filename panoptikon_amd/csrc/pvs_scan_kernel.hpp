@@ -137,16 +137,31 @@ struct Geo {
     static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
     static constexpr int PPW = 8 * RT / WAVES;  // 1-KiB DMA pieces per wave and slab
     static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
-    static constexpr int NC_FIT = 150000 / (SPB * SLAB_BYTES + WAVES * 256);  // ring + row scalars beside ~9 KiB of staging
-    static constexpr int NC_BIG = NC_FIT > 16 ? 16 : NC_FIT;
-    static constexpr int NC = QG == 8 ? NC_BIG : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8)));  // chunks in the ring
-    static constexpr int NS = NC * SPB;                                            // slabs in the ring
-    static constexpr int PC = NC - 1;                                              // chunks in flight
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
+    // 256 queries (one workgroup of 8 waves per CU): the waves hand chunks to each other through arrival counters instead of
+    // a barrier, with one chunk of SLACK — the chunk being refilled is the one consumed two steps ago, so a wave that is
+    // late (a candidate to emit, a slow DMA piece) does not stop the other seven (pvs_lds_dma.hpp: lds_signal / lds_await2).
+#ifdef PVS_ELASTIC
+    static constexpr bool ELASTIC = QG == 8;
+#else
+    static constexpr bool ELASTIC = false;
+#endif
+    static constexpr int SLACK = ELASTIC ? 1 : 0;
+    static constexpr int ring_chunks_that_fit() {  // as many chunks as the 160 KiB hold beside the row-scalar records and the counters
+        int nc = 16;
+        while (nc > 3 && nc * SPB * SLAB_BYTES + (2 + (nc - 1 - SLACK + CPT - 1) / CPT) * WAVES * 256 + 128 > 160 * 1024) nc--;
+        return nc;
+    }
+    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8)));  // chunks in the ring
+    static constexpr int NS = NC * SPB;                                            // slabs in the ring
+    // chunks in flight: the rest of the ring, but no more than ~96 KiB for the 8-wave instances (a fifth 24-KiB tile in
+    // flight measured 2.08 ms against 1.99 ms with four at 10M x 768 x 256 queries)
+    static constexpr int PC_CAP = 98304 / (SPB * SLAB_BYTES) < 2 ? 2 : 98304 / (SPB * SLAB_BYTES);
+    static constexpr int PC = (QG == 8 && NC - 1 - SLACK > PC_CAP) ? PC_CAP : NC - 1 - SLACK;
     static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
                                                           // same record): tiles in flight + the previous tile, kept for its epilogue
     static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 row-scalar DMA
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256;  // ring, row-scalar records
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + 128;  // ring, row-scalar records, hand-off counters
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
@@ -171,21 +186,34 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
     uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NCN][WAVES][256 B]
+    constexpr bool ELASTIC = G::ELASTIC && MODE == 1;   // (the sample pass and the dense pass keep the barrier: their results have no second line of defence)
+    uint32_t *const flags = (uint32_t *)(normring + NCN * WAVES * 256);  // ELASTIC: ready[16], done[16] arrival counters per ring chunk
+    if constexpr (ELASTIC) {
+        if (threadIdx.x < 32) flags[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    bool handoff_ok = true;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = wave % QW, rt = wave / QW;
     const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
-    const uint32_t sid = blockIdx.x, nstreams = a.grid;  // this workgroup's tile stream
+    uint32_t sid = blockIdx.x, qoff = 0;  // this workgroup's tile stream, and its first query in the batch
+    const uint32_t nstreams = a.grid;
+    if (a.qsplit > 1) {  // (ScanK.qsplit: streams are numbered so that the workgroups sharing one sit on the same XCD)
+        const uint32_t xcd = blockIdx.x & 7u, r = blockIdx.x >> 3;
+        qoff = (r % a.qsplit) * (uint32_t)(QG * 32);
+        sid = (r / a.qsplit) * 8u + xcd;
+    }
     int myq[GPW];
 #pragma unroll
-    for (int g = 0; g < GPW; g++) myq[g] = (qw * GPW + g) * 32 + j;
+    for (int g = 0; g < GPW; g++) myq[g] = (int)qoff + (qw * GPW + g) * 32 + j;
 
     const uint32_t ring_lds = lds_addr(ring), norm_lds = lds_addr(normring);
 
     // tiles of this workgroup: (sid + it*nstreams) * tile_step
     const uint32_t n_samp = (a.n_wgtiles + a.tile_step - 1) / a.tile_step;
-    const int n_my = sid < n_samp ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
+    const int n_my = (sid < n_samp && sid < nstreams) ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
     const uint64_t tile_bytes = (uint64_t)SLAB_ROWS * a.stride;
 
     float mins[MODE == 0 ? GPW : 1][MODE == 0 ? 16 : 1];
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     // HBM, written by exactly one LANE (lane (j, h) holds query column j and the rows of half h), so the fill count is a
     // register of that lane: no staging list, no flush, no atomic of any kind.  A segment that overflows is reported through
     // its count (pass C then hands the query to the dense path).
-    const uint32_t seg = (blockIdx.x * RT + rt) * 2 + h;  // this lane's segment index (the QW waves side by side hold different queries)
+    const uint32_t seg = (sid * RT + rt) * 2 + h;  // this lane's segment index (the QW waves side by side hold different queries)
     uint32_t mycnt[GPW];
 #pragma unroll
     for (int g = 0; g < GPW; g++) mycnt[g] = 0;
@@ -270,6 +298,8 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
         int i_tl = 0, i_ck = 0, i_slot = 0, i_nslot = 0;  // tile, chunk within tile, ring chunk slot, row-scalar ring slot
+        uint32_t i_gen = 0, c_gen = 0;                    // ELASTIC: times the producer / consumer side has wrapped around the ring
+        const uint32_t flags_lds = lds_addr(flags);
         constexpr int DMA_PARTS = SPB * PPW + 1;  // row pieces + the per-row scalars
         const uint8_t *is_base = nullptr;
         const float *is_aux = nullptr;
@@ -296,7 +326,10 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 i_tl++;
                 if (++i_nslot == NCN) i_nslot = 0;
             }
-            if (++i_slot == NC) i_slot = 0;
+            if (++i_slot == NC) {
+                i_slot = 0;
+                i_gen++;
+            }
         };
         auto issue_part = [&](int part) {  // part is a compile-time constant at every call site
 #ifdef PVS_ABL_NODMA
@@ -321,6 +354,17 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // issues in order, so the two instruction streams must sit in one basic block for the
         // scheduler to interleave them).
         using acc_t = typename A::type;
+#ifdef PVS_TILE_PROF  // tuning build: where a wave's cycles go (s_memtime stamps around the phases of a chunk), printed by two workgroups
+        unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_acc[5] = {0, 0, 0, 0, 0};
+#define PROF_STAMP(i)                                                      \
+    do {                                                                   \
+        prof_t[i] = __builtin_readcyclecounter();                          \
+        if ((i) > 0) prof_acc[i] += prof_t[i] - prof_t[(i) - 1];           \
+        if ((i) == 0 && prof_t[4] != 0) prof_acc[0] += prof_t[0] - prof_t[4]; \
+    } while (0)
+#else
+#define PROF_STAMP(i) do { } while (0)
+#endif
         int c_slot = 0, c_nslot = 0;   // consumer: ring chunk slot, row-scalar slot of the chunk being consumed
         int p_nslot = -1;              // row-scalar slot of the PREVIOUS tile (its last chunk); -1: there is none yet
         elem_t hold[GPW][16];          // !PARITY: the previous tile's 16 dot products per group
@@ -368,8 +412,8 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // sums with the lane's pre-test bound `eb` (no row scalar, v_cmp straight into an SGPR pair per row); stage 2 runs the
         // exact per-row test only for the rows whose mask is non-empty.  Without a pre-test (f32 rows) stage 1 IS the exact test.
         auto emit_rows = [&](int g, elem_t eb, const float(&xh)[16], auto &&pv) {
-            const uint32_t q0 = (uint32_t)(qw * GPW + g) * 32u;  // first query of the group (wave-uniform)
-            const uint32_t seg0 = (blockIdx.x * RT + rt) * 2;    // segment of half 0 (wave-uniform)
+            const uint32_t q0 = qoff + (uint32_t)(qw * GPW + g) * 32u;  // first query of the group (wave-uniform)
+            const uint32_t seg0 = (sid * RT + rt) * 2;    // segment of half 0 (wave-uniform)
             auto exact = [&](int r) { return score(g, undo_f32((float)pv(g, r), xh[r]), xh[r]); };
             unsigned long long mr[16];
 #pragma unroll
@@ -574,7 +618,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // two register sets, the previous tile's sums are read where the matrix core left them — no hand-off copy, and
         // the two groups are the two independent accumulation chains.  Otherwise two chains (acc, acc1) per tile,
         // summed into `hold` at the end of the tile.
+        // (256 queries, one group per wave: the single-chain form it is.  Two chains summed into `hold` measured 2.06 ms against
+        //  1.99 ms — s_memtime stamps, PVS_TILE_PROF, show the matrix pipe of a SIMD fully booked while its older wave runs its 24
+        //  MFMAs, whichever form: the two waves of a SIMD share it about 2:1.)
+#ifdef PVS_QG8_TWO_CHAINS
+        constexpr bool PARITY = GPW == 2;
+#else
         constexpr bool PARITY = QG == 8;
+#endif
         auto run_tile = [&](int tl, acc_t(&acc)[GPW], acc_t &acc1, auto &&pv) {
 #pragma unroll
             for (int g = 0; g < GPW; g++)
@@ -587,8 +638,20 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             Epi e;
 #pragma unroll
             for (int ck = 0; ck < CPT; ck++) {
+                PROF_STAMP(0);
                 wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
-                wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
+                PROF_STAMP(1);
+                if constexpr (ELASTIC) {
+                    // ... tell the others, then wait until everyone's share of THIS chunk has landed and everyone has
+                    // finished reading the chunk whose slot is refilled below (the one consumed SLACK+1 steps ago)
+                    lds_signal(flags_lds + (uint32_t)c_slot * 4u, lane);
+                    if (handoff_ok)  // (once a wait gave up the pass is void — its counts say "overflow" — and nothing is waited for again)
+                        handoff_ok = lds_await2(flags_lds + (uint32_t)c_slot * 4u, (uint32_t)WAVES * (c_gen + 1u),
+                                                flags_lds + 64u + (uint32_t)i_slot * 4u, (uint32_t)WAVES * i_gen);
+                } else {
+                    wg_barrier();                       // ... and everyone else's; the previous chunk is consumed
+                }
+                PROF_STAMP(2);
                 issue_begin();                          // the slot the previous chunk occupied is refilled below
                 if (ck == 0) epi_begin(e);
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
@@ -605,7 +668,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 //   step t:  LDS read of fragment t+PF | MFMA t (one per group) | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
-                constexpr int NF = SPB * SPS, PF = (GPW == 2 ? PVS_PF : 4);
+                constexpr int NF = SPB * SPS, PF = ((GPW == 2 || QG == 8) ? PVS_PF : 4);
                 v4i af[NF];
                 v4i raw[DT == PVS_F32 ? NF : 1][2];  // f32: the two 16-B pieces of a step, before narrowing
                 (void)raw;
@@ -656,9 +719,15 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (++c_slot == NC) c_slot = 0;
+                PROF_STAMP(3);
+                if constexpr (ELASTIC) lds_signal(flags_lds + 64u + (uint32_t)c_slot * 4u, lane);  // this wave is done reading the chunk
+                if (++c_slot == NC) {
+                    c_slot = 0;
+                    c_gen++;
+                }
                 if (ck == CPT - 1) {  // this tile's row scalars: kept in their slot until the end of the NEXT tile
                     epi_rest(e, pv);  // (the previous tile's, reading p_nslot)
+                    PROF_STAMP(4);
                     p_nslot = c_nslot;
                     if (++c_nslot == NCN) c_nslot = 0;
                 }
@@ -695,14 +764,19 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         }
         wait_vm<0>();  // retire the dummy tail DMAs before the wave exits
+#ifdef PVS_TILE_PROF
+        if (MODE == 1 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131))
+            printf("tileprof wg %u wave %d tiles %d: loop-top %llu dma-wait %llu barrier %llu mfma %llu epilogue %llu (cycles of s_memtime)\n", blockIdx.x,
+                   wave, n_my + 1, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4]);
+#endif
         if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // candidates: scalar cache -> L2
     }
-    if (MODE == 1) {   // every lane's fill count: seg_cnt[query][segment]
+    if (MODE == 1 && sid < nstreams) {   // every lane's fill count: seg_cnt[query][segment]; a hand-off that gave up reports an overflow (-> dense path)
 #pragma unroll
-        for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = mycnt[g];
+        for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = handoff_ok ? mycnt[g] : 0xffffffffu;
     }
 
-    if (MODE == 0) {
+    if (MODE == 0 && sid < nstreams) {
         // Each lane holds 16 minima per query (one per accumulator row slot) = 16 disjoint row groups of its query.
         // The threshold only needs a few times k groups per query; folding to a.gmin_per_lane (a power of two)
         // keeps the k-th select that follows short.
@@ -715,7 +789,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
                     for (int r = 0; r < sft; r++) mins[g][r] = fminf(mins[g][r], mins[g][r + sft]);
                 }
-            float *o = a.gmin + (size_t)myq[g] * a.groups_per_query + (size_t)((blockIdx.x * RT + rt) * 2 + h) * gr;
+            float *o = a.gmin + (size_t)myq[g] * a.groups_per_query + (size_t)((sid * RT + rt) * 2 + h) * gr;
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if ((uint32_t)r < gr) o[r] = mins[g][r];
@@ -733,7 +807,8 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
+    const uint32_t blocks = k.qsplit > 1 ? (k.grid + 7) / 8 * 8 * k.qsplit : k.grid;
+    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(blocks), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
     return hipGetLastError();
 }
 template <int DT, int KS, int QG>

@@ -145,8 +145,17 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         // pass B: every row once (candidate counters were zeroed by the prep kernel)
         a.mode = 1;
         a.tile_step = 1;
+        // 256 queries: two 4-wave workgroups of 128 queries share each tile stream (the second finds the tile in the XCD's
+        // L2) instead of one 8-wave workgroup whose waves all meet at one barrier per tile
+        // — measured 2.46 ms against 2.07 ms at 10M x 768 (the 128-query pass is bound by the fetch path, which this doubles):
+        // off unless PVS_QSPLIT is set.
+        static const bool use_qsplit = getenv("PVS_QSPLIT") != nullptr;  // tuning experiments
+        if (a.qgroups == 8 && use_qsplit) {
+            a.qgroups = 4;
+            a.qsplit = 2;
+        }
         const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
-        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu, PVS_SEG_PAIRS / (batch_pad * rt * 2)});
+        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu / a.qsplit, PVS_SEG_PAIRS / (batch_pad * rt * 2)});
         a.n_segments = a.grid * rt * 2;
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
