@@ -501,17 +501,17 @@ PVS_EXPORT pvs_status pvs_rrf_cols_groups(pvs_rrf_cols *c, uint64_t *out_n_group
 // when the shard has no more groups than that
 PVS_EXPORT pvs_status pvs_rrf_cols_threshold(pvs_rrf_cols *c, uint64_t target_groups, uint64_t *out_key) {
     if (!c || !out_key) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
-    constexpr uint32_t M = 8192;
+    constexpr uint32_t M = 16384;
     *out_key = ~0ull;
     if (c->n_groups == 0 || target_groups * 2 >= c->n_groups) return PVS_OK;
     HIP_TRY(hipSetDevice(c->ix->device));
     if (c->sample.empty()) {
         c->sample.resize(M);
         PVS_TRY(pvs_rrf_sample_keys(c->d_keys, c->n_groups, M, c->sample.data(), c->ix->search_stream));
-        std::sort(c->sample.begin(), c->sample.end());
     }
     uint64_t j = (uint64_t)((double)M * 1.5 * (double)target_groups / (double)c->n_groups) + 1;
     if (j >= M) j = M - 1;
+    std::nth_element(c->sample.begin(), c->sample.begin() + j, c->sample.end());  // (the j-th smallest: no full sort of the sample)
     *out_key = c->sample[j];
     return PVS_OK;
 }
@@ -567,6 +567,17 @@ static double rrf_score_host(const int64_t *ranks, const PvsRrfParams &p) {
 //      quarter of a branch falls back to the full ranking below.
 // Cost beside the exact scoring of every row: a few passes over 8 B per group instead of three multi-pass radix sorts of
 // all groups (configs[4]: 2 x 8.3M groups — the sorts were 10 of 16 ms).
+// PVS_RRF_TRACE=1: host wall time of every phase of a composed query on stderr (tuning)
+struct RrfTrace {
+    bool on = getenv("PVS_RRF_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rrf] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint32_t k,
                               int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done) {
     *done = false;
@@ -578,7 +589,10 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
         total_groups += cols[b].n_groups;
     }
     if (total_groups < 65536) return PVS_OK;  // small: the full ranking is cheap
-    uint64_t target = std::max<uint64_t>(8ull * k, 2048);
+    // first page size: R_b ~ 4k already puts the bound (sum of w/(k_b + R_b + 1)) far below the k-th fused score unless the
+    // branches barely overlap near the top; every host-side step below is linear (or n log n) in the pages
+    uint64_t target = std::max<uint64_t>(4ull * k, 1024);
+    RrfTrace tr;
     for (int round = 0; round < 6; round++, target *= 4) {
         std::vector<uint32_t> R(nb, 0);
         std::vector<int64_t> cand;
@@ -588,6 +602,7 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
             if (target * 4 >= n) return PVS_OK;  // a page that would hold a quarter of the branch: full ranking
             uint64_t thr = 0;
             PVS_TRY(pvs_rrf_cols_threshold(&cols[b], target, &thr));
+            tr.lap("threshold");
             const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 8 * target + 65536);
             std::vector<int64_t> g(cap);
             std::vector<uint64_t> gk(cap);
@@ -596,16 +611,19 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
             if (cnt > cap) return PVS_OK;  // many equal keys at the threshold (massive ties): full ranking
             R[b] = cnt;
             cand.insert(cand.end(), g.begin(), g.begin() + cnt);
+            tr.lap("page");
         }
         std::sort(cand.begin(), cand.end());
         cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
         const uint32_t m = (uint32_t)cand.size();
+        tr.lap("union");
         std::vector<std::vector<int64_t>> ranks(nb, std::vector<int64_t>(m, -1));
         for (uint32_t b = 0; b < nb; b++) {
             if (cols[b].n_groups == 0 || m == 0) continue;
             std::vector<uint64_t> key(m);
             std::vector<uint8_t> present(m);
             PVS_TRY(pvs_rrf_cols_lookup(&cols[b], cand.data(), m, key.data(), present.data()));
+            tr.lap("lookup");
             std::vector<uint32_t> order;
             for (uint32_t c = 0; c < m; c++)
                 if (present[c]) order.push_back(c);
@@ -617,7 +635,9 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
                 ck[i] = key[order[i]];
                 cg[i] = cand[order[i]];
             }
+            tr.lap("order");
             PVS_TRY(pvs_rrf_cols_count_below(&cols[b], ck.data(), cg.data(), mp, below.data()));
+            tr.lap("count_below");
             for (uint32_t i = 0; i < mp; i++) ranks[b][order[i]] = (int64_t)below[i] + 1;
         }
         struct GS {
@@ -631,6 +651,8 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
             gs[i] = {rrf_score_host(r, p), cand[i]};
         }
         std::sort(gs.begin(), gs.end(), [](const GS &a, const GS &b) { return a.s != b.s ? a.s > b.s : a.g < b.g; });  // score DESC, group id
+        tr.lap("fuse");
+        if (tr.on) fprintf(stderr, "[rrf] round %d: target %llu, %u candidates\n", round, (unsigned long long)target, m);
         // the most a group outside every page can score (absent from a branch: an even smaller term)
         double U = 0.0;
         for (uint32_t b = 0; b < nb; b++) U += p.w[b] / ((double)p.k[b] + (double)R[b] + 1.0);
@@ -674,7 +696,11 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     std::vector<RrfBranchCols> cols(nb);
     unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
     auto body = [&]() -> pvs_status {
-        for (uint32_t b = 0; b < nb; b++) PVS_TRY(rrf_score_branch(br[b], &cols[b]));
+        RrfTrace tr;
+        for (uint32_t b = 0; b < nb; b++) {
+            PVS_TRY(rrf_score_branch(br[b], &cols[b]));
+            tr.lap("score branch (enqueue)");
+        }
         const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests and profiles: compare the two paths
         if (!force_full) {
             bool done = false;

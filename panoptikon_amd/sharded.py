@@ -87,7 +87,7 @@ def rrf_search_sharded(branches, k: int, gather, max_rounds: int = 6):
     try:
         n_tot = [int(gather(np.array([c.n_groups], np.int64)).sum()) for c in cols]
         world = len(gather(np.array([0], np.int64)))
-        target = max(8 * k, 2048)
+        target = max(4 * k, 1024)
         for _ in range(max_rounds):
             R, cand_parts = [], []
             for b in range(nb):
