@@ -18,6 +18,15 @@
  *   pvs_distance_l2(index TEXT, id INTEGER, query BLOB) -> REAL         of a statement runs the device pass; an id the
  *                                                                       index does not hold gives NULL.
  *   query: dim*4 bytes f32 little-endian, or dim int8 codes for an int8 index (QuantResolved.query_quant).
+ *   pvs_load(index TEXT, sql TEXT [, param ...]) -> INTEGER            index lifecycle: runs `sql` on this
+ *       connection with the parameters bound in order and appends every row it yields — (row id INTEGER, group id INTEGER
+ *       or NULL, payload BLOB), in the order the index shall hold them, i.e. the loaders' ORDER BY item_data.id
+ *       (db/vector_quants.rs:1085-1099) — to the bound index, in chunks, without the rows ever becoming SQL values of the
+ *       caller.  payload = dim*4 bytes (f32 LE: embeddings.embedding, converted on the device to the index dtype) or dim
+ *       bytes of int8 codes for an int8 index (embedding_quants.quant); NULLs and blobs of any other length are skipped —
+ *       the `length(embedding) = dim*4` guard of the reference's backfill.  Returns the number of rows appended.
+ *   pvs_load_info(index TEXT) -> TEXT    JSON of that index's last pvs_load: rows, skipped, last_id, sum_id, sum_group
+ *       (sums of the 32-bit residues of the ids: what a host keeps to recognise its loaded prefix after an epoch bump).
  */
 #ifndef PVS_SQLITE_H
 #define PVS_SQLITE_H
@@ -58,6 +67,19 @@ typedef struct pvs_sqlite_api {
     void (*set_auxdata)(sqlite3_context *, int, void *, void (*)(void *));
     char *(*mprintf)(const char *, ...);
     void (*free)(void *);
+    /* since ABI v2 of this struct — the statement interface pvs_load streams rows through.  A host that passes the shorter
+     * v1 struct (struct_size up to `free`) gets everything except pvs_load. */
+    int (*prepare_v2)(sqlite3 *, const char *, int, void **, const char **);
+    int (*step)(void *);
+    int (*finalize)(void *);
+    int (*column_type)(void *, int);
+    const void *(*column_blob)(void *, int);
+    int (*column_bytes)(void *, int);
+    long long (*column_int64)(void *, int);
+    int (*bind_value)(void *, int, const sqlite3_value *);
+    sqlite3 *(*context_db_handle)(sqlite3_context *);
+    const char *(*errmsg)(sqlite3 *);
+    void (*result_text)(sqlite3_context *, const char *, int, void (*)(void *));
 } pvs_sqlite_api;
 
 /* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 on one connection.  api == NULL: use the table a previous
@@ -70,6 +92,18 @@ int32_t pvs_sqlite_register(void *db, const pvs_sqlite_api *api);
 int sqlite3_pvs_init(void *db, char **pzErrMsg, const void *pApi);
 int sqlite3_extension_init(void *db, char **pzErrMsg, const void *pApi);
 int sqlite3_pvssqlite_init(void *db, char **pzErrMsg, const void *pApi);
+
+/* The row streamer behind pvs_load, for a host that holds the connection itself: prepares `sql` on `db` (no parameters),
+ * streams its (row id, group id, payload) rows into `idx` in chunks of `chunk_rows` (0 = 65536).  `out` may be NULL.
+ * Returns pvs_status; PVS_ERR_STATE when the registered SQLite entry points lack the statement interface. */
+typedef struct pvs_sqlite_load_result {
+    uint64_t rows;      /* appended */
+    uint64_t skipped;   /* NULL payloads and blobs of another length */
+    int64_t last_id;    /* row id of the last appended row (-1: none) */
+    uint64_t sum_id;    /* sum over appended rows of (row id & 0xffffffff) */
+    uint64_t sum_group; /* sum over appended rows of (group id & 0xffffffff) */
+} pvs_sqlite_load_result;
+int32_t pvs_sqlite_load(void *db, const char *sql, pvs_index *idx, uint32_t chunk_rows, pvs_sqlite_load_result *out);
 
 /* Names the SQL functions resolve: bind every device index the host wants reachable from SQL (process-wide registry;
  * rebinding a name replaces it; unbind before pvs_index_destroy).  Return pvs_status. */

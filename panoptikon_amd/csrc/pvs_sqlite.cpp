@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -110,7 +111,7 @@ struct sqlite3_module {
     int (*xShadowName)(const char *);
 };
 }
-enum { SQLITE_OK = 0, SQLITE_ERROR = 1, SQLITE_NOMEM = 7, SQLITE_CONSTRAINT = 19 };
+enum { SQLITE_OK = 0, SQLITE_ERROR = 1, SQLITE_NOMEM = 7, SQLITE_CONSTRAINT = 19, SQLITE_ROW = 100, SQLITE_DONE = 101 };
 enum { SQLITE_INTEGER = 1, SQLITE_FLOAT = 2, SQLITE_TEXT = 3, SQLITE_BLOB = 4, SQLITE_NULL = 5 };
 enum { SQLITE_UTF8 = 1, SQLITE_DETERMINISTIC = 0x800, SQLITE_INDEX_CONSTRAINT_EQ = 2 };
 
@@ -124,6 +125,7 @@ std::mutex g_mu;
 
 struct Bound {
     pvs_index *ix = nullptr;
+    pvs_sqlite_load_result last_load = {0, 0, -1, 0, 0};
     std::vector<int64_t> ids;  // host copy of the row ids (strictly increasing), refreshed when the row count moves
     uint64_t ids_rows = UINT64_MAX;
 };
@@ -385,9 +387,167 @@ void distance_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
         g_api.result_double(ctx, (double)d);
 }
 
+// ------------------------------------------------------------------ pvs_load(index, sql, params...)
+// Index lifecycle glue in C: the rows go from SQLite's page cache into a staging buffer and from there to the
+// device (pvs_index_add[_f32], which converts f32 rows to the index dtype on the device) without becoming values of the host
+// language.  The statement is the loader's own — `SELECT d.id, d.item_id, e.embedding FROM item_data d JOIN embeddings e ...
+// ORDER BY d.id` (panoptikon_amd/loader.py; the order BACKFILL_CHUNK_SQL streams, db/vector_quants.rs:1085-1099).
+bool have_stmt_api() { return g_api.struct_size >= sizeof(pvs_sqlite_api) && g_api.prepare_v2 && g_api.step && g_api.finalize && g_api.column_blob; }
+
+pvs_status stream_rows(void *stmt, pvs_index *ix, uint32_t chunk_rows, pvs_sqlite_load_result *res, std::string *err) {
+    pvs_stats st;
+    pvs_status s = pvs_index_stats(ix, &st);
+    if (s != PVS_OK) return s;
+    const uint64_t dim = st.dim;
+    if (!chunk_rows) chunk_rows = 65536;
+    std::vector<int64_t> ids, groups;
+    std::vector<uint8_t> payload;
+    int kind = 0;  // bytes per component of the rows staged so far: 4 (f32) or 1 (int8 codes)
+    bool any_group = false, any_null_group = false;
+    ids.reserve(chunk_rows);
+    groups.reserve(chunk_rows);
+    auto flush = [&]() -> pvs_status {
+        if (ids.empty()) return PVS_OK;
+        if (any_group && any_null_group) {
+            *err = "group ids must be given for every row or for none";
+            return PVS_ERR_INVALID_ARG;
+        }
+        const int64_t *g = any_group ? groups.data() : nullptr;
+        pvs_status r = kind == 4 ? pvs_index_add_f32(ix, (const float *)payload.data(), ids.size(), ids.data(), g, PVS_HOST)
+                                 : pvs_index_add(ix, payload.data(), ids.size(), ids.data(), g, PVS_HOST);
+        if (r != PVS_OK) return r;
+        for (size_t i = 0; i < ids.size(); i++) {
+            res->sum_id += (uint64_t)ids[i] & 0xffffffffull;
+            res->sum_group += (uint64_t)groups[i] & 0xffffffffull;
+        }
+        res->rows += ids.size();
+        res->last_id = ids.back();
+        ids.clear();
+        groups.clear();
+        payload.clear();
+        return PVS_OK;
+    };
+    for (;;) {
+        const int rc = g_api.step(stmt);
+        if (rc == SQLITE_DONE) break;
+        if (rc != SQLITE_ROW) {
+            *err = "the statement failed while streaming";
+            return PVS_ERR_INVALID_ARG;
+        }
+        if (g_api.column_type(stmt, 2) != SQLITE_BLOB) {
+            res->skipped++;
+            continue;
+        }
+        const void *blob = g_api.column_blob(stmt, 2);  // (before column_bytes: sqlite.org/c3ref/column_blob.html)
+        const uint64_t n = (uint64_t)g_api.column_bytes(stmt, 2);
+        const int k = n == dim * 4 ? 4 : (n == dim && st.dtype == PVS_I8 ? 1 : 0);
+        if (!k || !blob) {
+            res->skipped++;
+            continue;
+        }
+        if (kind && k != kind) {  // f32 rows after int8 codes or the other way round: separate add calls
+            if ((s = flush()) != PVS_OK) return s;
+        }
+        kind = k;
+        ids.push_back((int64_t)g_api.column_int64(stmt, 0));
+        if (g_api.column_type(stmt, 1) == SQLITE_NULL) {
+            any_null_group = true;
+            groups.push_back(0);
+        } else {
+            any_group = true;
+            groups.push_back((int64_t)g_api.column_int64(stmt, 1));
+        }
+        payload.insert(payload.end(), (const uint8_t *)blob, (const uint8_t *)blob + n);
+        if ((ids.size() >= chunk_rows || payload.size() >= (64u << 20)) && (s = flush()) != PVS_OK) return s;  // (chunks of <= 64 MiB)
+    }
+    return flush();
+}
+
+void load_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
+    if (argc < 2) {
+        g_api.result_error(ctx, "pvs_load(index, sql[, param ...])", -1);
+        return;
+    }
+    if (!have_stmt_api()) {
+        g_api.result_error(ctx, "pvs_load: the host registered SQLite entry points without the statement interface", -1);
+        return;
+    }
+    const unsigned char *nm = g_api.value_text(argv[0]);
+    const unsigned char *sql = g_api.value_text(argv[1]);
+    pvs_index *ix = nullptr;
+    uint32_t dtype = 0, dim = 0;
+    uint64_t rows = 0;
+    if (!nm || !sql || lookup((const char *)nm, &ix, &dtype, &dim, &rows) != PVS_OK) {
+        g_api.result_error(ctx, "pvs_load: no index is bound to that name", -1);
+        return;
+    }
+    const std::string name((const char *)nm);
+    sqlite3 *db = g_api.context_db_handle(ctx);
+    void *stmt = nullptr;
+    if (g_api.prepare_v2(db, (const char *)sql, -1, &stmt, nullptr) != SQLITE_OK || !stmt) {
+        char *m = g_api.mprintf("pvs_load: %s", g_api.errmsg(db));
+        g_api.result_error(ctx, m ? m : "pvs_load: prepare failed", -1);
+        if (m) g_api.free(m);
+        return;
+    }
+    for (int i = 2; i < argc; i++)
+        if (g_api.bind_value(stmt, i - 1, argv[i]) != SQLITE_OK) {
+            g_api.finalize(stmt);
+            g_api.result_error(ctx, "pvs_load: more parameters than the statement has", -1);
+            return;
+        }
+    pvs_sqlite_load_result res = {0, 0, -1, 0, 0};
+    std::string err;
+    const pvs_status s = stream_rows(stmt, ix, 0, &res, &err);
+    g_api.finalize(stmt);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_indexes.find(name);
+        if (it != g_indexes.end()) it->second.last_load = res;
+    }
+    if (s != PVS_OK) {
+        char *m = g_api.mprintf("pvs_load: %s (after %lld rows)", err.empty() ? pvs_last_error() : err.c_str(), (long long)res.rows);
+        g_api.result_error(ctx, m ? m : "pvs_load failed", -1);
+        if (m) g_api.free(m);
+        return;
+    }
+    g_api.result_int64(ctx, (long long)res.rows);
+}
+void load_info_udf(sqlite3_context *ctx, int, sqlite3_value **argv) {
+    const unsigned char *nm = g_api.value_text(argv[0]);
+    pvs_sqlite_load_result r = {0, 0, -1, 0, 0};
+    bool found = false;
+    if (nm) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_indexes.find((const char *)nm);
+        if (it != g_indexes.end()) {
+            r = it->second.last_load;
+            found = true;
+        }
+    }
+    if (!found || !g_api.result_text) {
+        g_api.result_null(ctx);
+        return;
+    }
+    char *m = g_api.mprintf("{\"rows\": %llu, \"skipped\": %llu, \"last_id\": %lld, \"sum_id\": %llu, \"sum_group\": %llu}", (unsigned long long)r.rows,
+                            (unsigned long long)r.skipped, (long long)r.last_id, (unsigned long long)r.sum_id, (unsigned long long)r.sum_group);
+    if (!m) {
+        g_api.result_null(ctx);
+        return;
+    }
+    g_api.result_text(ctx, m, -1, (void (*)(void *))(intptr_t)-1);  // SQLITE_TRANSIENT: SQLite copies
+    g_api.free(m);
+}
+
 int register_all(sqlite3 *db) {
     int rc = g_api.create_module_v2(db, "pvs_dist", &g_dist_module, nullptr, nullptr);
     if (rc != SQLITE_OK) return rc;
+    if (have_stmt_api()) {
+        rc = g_api.create_function_v2(db, "pvs_load", -1, SQLITE_UTF8, nullptr, load_udf, nullptr, nullptr, nullptr);
+        if (rc != SQLITE_OK) return rc;
+        rc = g_api.create_function_v2(db, "pvs_load_info", 1, SQLITE_UTF8, nullptr, load_info_udf, nullptr, nullptr, nullptr);
+        if (rc != SQLITE_OK) return rc;
+    }
     // not SQLITE_DETERMINISTIC: the result depends on the bound index's contents, which SQLite cannot see
     rc = g_api.create_function_v2(db, "pvs_distance_cosine", 3, SQLITE_UTF8, (void *)(intptr_t)PVS_COSINE, distance_udf, nullptr, nullptr, nullptr);
     if (rc != SQLITE_OK) return rc;
@@ -424,6 +584,17 @@ bool fill_api_from_process(std::string *missing) {
     SYM(set_auxdata, "sqlite3_set_auxdata")
     SYM(mprintf, "sqlite3_mprintf")
     SYM(free, "sqlite3_free")
+    SYM(prepare_v2, "sqlite3_prepare_v2")
+    SYM(step, "sqlite3_step")
+    SYM(finalize, "sqlite3_finalize")
+    SYM(column_type, "sqlite3_column_type")
+    SYM(column_blob, "sqlite3_column_blob")
+    SYM(column_bytes, "sqlite3_column_bytes")
+    SYM(column_int64, "sqlite3_column_int64")
+    SYM(bind_value, "sqlite3_bind_value")
+    SYM(context_db_handle, "sqlite3_context_db_handle")
+    SYM(errmsg, "sqlite3_errmsg")
+    SYM(result_text, "sqlite3_result_text")
 #undef SYM
     g_api = a;
     g_api_set = true;
@@ -437,8 +608,10 @@ PVS_EXPORT int32_t pvs_sqlite_register(void *db, const pvs_sqlite_api *api) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (api) {
-            if (api->struct_size < sizeof(pvs_sqlite_api)) return SQLITE_ERROR;
-            g_api = *api;
+            const size_t v1 = offsetof(pvs_sqlite_api, prepare_v2);  // the struct before the statement interface was added
+            if (api->struct_size < v1) return SQLITE_ERROR;
+            memset(&g_api, 0, sizeof g_api);
+            memcpy(&g_api, api, std::min<size_t>(api->struct_size, sizeof g_api));
             g_api_set = true;
         } else if (!g_api_set) {
             std::string missing;
@@ -458,6 +631,27 @@ PVS_EXPORT int sqlite3_pvs_init(void *db, char **pzErrMsg, const void *pApi) {
 }
 PVS_EXPORT int sqlite3_extension_init(void *db, char **pzErrMsg, const void *pApi) { return sqlite3_pvs_init(db, pzErrMsg, pApi); }
 PVS_EXPORT int sqlite3_pvssqlite_init(void *db, char **pzErrMsg, const void *pApi) { return sqlite3_pvs_init(db, pzErrMsg, pApi); }
+
+// ---- the row streamer for a host that holds the connection itself
+PVS_EXPORT int32_t pvs_sqlite_load(void *db, const char *sql, pvs_index *idx, uint32_t chunk_rows, pvs_sqlite_load_result *out) {
+    if (!db || !sql || !idx) return PVS_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_api_set) {
+            std::string missing;
+            if (!fill_api_from_process(&missing)) return PVS_ERR_STATE;
+        }
+    }
+    if (!have_stmt_api()) return PVS_ERR_STATE;
+    void *stmt = nullptr;
+    if (g_api.prepare_v2((sqlite3 *)db, sql, -1, &stmt, nullptr) != SQLITE_OK || !stmt) return PVS_ERR_INVALID_ARG;
+    pvs_sqlite_load_result res = {0, 0, -1, 0, 0};
+    std::string err;
+    const pvs_status s = stream_rows(stmt, idx, chunk_rows, &res, &err);
+    g_api.finalize(stmt);
+    if (out) *out = res;
+    return s;
+}
 
 // ---- index registry
 PVS_EXPORT int32_t pvs_sqlite_bind_index(const char *name, pvs_index *idx) {

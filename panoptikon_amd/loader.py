@@ -174,11 +174,76 @@ class LoadedIndex:
         self.tail = (self.tail + new)[-TAIL_WINDOW:]
 
 
+_EXACT_FROM = "FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN ({marks}) AND d.id > ?"
+_QUANT_FROM = ("FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
+               "JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
+               "WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id > ?")
+_native_seq = 0
+
+
+def _native_stream(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str], after_id: int) -> int:
+    """The same row stream as iter_exact_rows / iter_quant_rows, pulled by the C streamer of libpvs_sqlite.so
+    (`pvs_load`, include/pvs_sqlite.h): SQLite page cache -> staging buffer -> device, no per-row Python objects.
+    Updates li's fingerprint from the streamer's sums and re-reads the newest TAIL_WINDOW rows for the tail."""
+    import json
+
+    from . import sqlite_seam as seam
+
+    global _native_seq
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids:
+        return 0
+    marks = ",".join("?" * len(sids))
+    if li.kind == "exact":
+        frm, payload, args = _EXACT_FROM.format(marks=marks), "e.embedding", [*sids, after_id]
+        nbytes = li.dim * 4
+    else:
+        frm, payload, args = _QUANT_FROM.format(marks=marks), "q.quant", [li.profile_id, *sids, after_id]
+        nbytes = li.dim
+    seam.load(conn)
+    _native_seq += 1
+    name = f"__loader_{id(li):x}_{_native_seq}"
+    seam.bind(name, li.index)
+    try:
+        # blobs of another length are skipped by the streamer as well; the guard keeps them out of the statement entirely
+        n = int(conn.execute(f"SELECT pvs_load(?, ?, {','.join('?' * (len(args) + 1))})",
+                             [name, f"SELECT d.id, d.item_id, {payload} {frm} AND length({payload}) = ? ORDER BY d.id", *args, nbytes]).fetchone()[0])
+        info = json.loads(conn.execute("SELECT pvs_load_info(?)", (name,)).fetchone()[0])
+    finally:
+        seam.unbind(name)
+    if n:
+        li.rows += n
+        li.last_id = int(info["last_id"])
+        li.sum_id += int(info["sum_id"])
+        li.sum_item += int(info["sum_group"])
+        tail = [(int(r[0]), int(r[1]), zlib.crc32(bytes(r[2]))) for r in conn.execute(
+            f"SELECT d.id, d.item_id, {payload} {frm} AND length({payload}) = ? ORDER BY d.id DESC LIMIT {TAIL_WINDOW}", [*args, nbytes])]
+        li.tail = (li.tail + tail[::-1])[-TAIL_WINDOW:]
+    return n
+
+
+def _first_payload_bytes(conn: sqlite3.Connection, setter_names: Sequence[str]) -> Optional[int]:
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids:
+        return None
+    marks = ",".join("?" * len(sids))
+    row = conn.execute(f"SELECT length(e.embedding) {_EXACT_FROM.format(marks=marks)} ORDER BY d.id LIMIT 1", [*sids, -1]).fetchone()
+    return None if row is None or row[0] is None else int(row[0])
+
+
 def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtype: int = L.F32, device: int = 0,
-                     chunk_rows: int = 65536) -> Optional[LoadedIndex]:
-    """The reference's *exact* mode on the device: the setters' f32 embeddings as an f32 (or f16) index."""
+                     chunk_rows: int = 65536, native: bool = False) -> Optional[LoadedIndex]:
+    """The reference's *exact* mode on the device: the setters' f32 embeddings as an f32 (or f16) index.
+    native=True streams the rows through the C streamer (pvs_load) instead of Python chunks."""
     from .index import VectorIndex
 
+    if native:
+        nbytes = _first_payload_bytes(conn, setter_names)
+        if not nbytes or nbytes % 4:
+            return None
+        li = LoadedIndex(VectorIndex(dtype, nbytes // 4, device=device), "exact", 0, nbytes // 4)
+        _native_stream(conn, li, setter_names, -1)
+        return li
     li = None
     for ids, items, mat in iter_exact_rows(conn, setter_names, chunk_rows):
         if li is None:
@@ -190,7 +255,7 @@ def load_exact_index(conn: sqlite3.Connection, setter_names: Sequence[str], dtyp
 
 
 def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: Sequence[str], device: int = 0,
-                     chunk_rows: int = 65536) -> Optional[LoadedIndex]:
+                     chunk_rows: int = 65536, native: bool = False) -> Optional[LoadedIndex]:
     """The *quant* mode: int8 codes of a ready pair with its frozen scale.  None when the pair is not ready
     (the caller falls back to exact under ``auto``, or raises under strict selection — pql/preprocess.rs:327-383)."""
     from .index import VectorIndex
@@ -201,6 +266,9 @@ def load_quant_index(conn: sqlite3.Connection, profile_name: str, setter_names: 
     ix = VectorIndex(L.I8, pair.dim, device=device)
     ix.set_scale(pair.scale)
     li = LoadedIndex(ix, "quant", 0, pair.dim, profile_id=pair.profile_id, scale=pair.scale)
+    if native:
+        _native_stream(conn, li, setter_names, -1)
+        return li
     for ids, items, mat in iter_quant_rows(conn, pair.profile_id, setter_names, pair.dim, chunk_rows):
         ix.add(mat, row_ids=ids, group_ids=items)
         li.note_chunk(ids, items, mat)
@@ -242,13 +310,16 @@ def _prefix_intact(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequ
     return tail == li.tail
 
 
-def append_new_rows(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str], chunk_rows: int = 65536) -> Optional[int]:
+def append_new_rows(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str], chunk_rows: int = 65536,
+                    native: bool = False) -> Optional[int]:
     """After an epoch bump: if every row the index holds is still there (extractions are immutable; deletes
     cascade), only rows with a larger item_data.id are new — append them.  Returns the number appended, or
     None when the prefix changed and the caller must rebuild."""
     if not _prefix_intact(conn, li, setter_names):
         return None
     before = li.rows
+    if native:
+        return _native_stream(conn, li, setter_names, li.last_id)
     if li.kind == "exact":
         stream = iter_exact_rows(conn, setter_names, chunk_rows, after_id=li.last_id, dim_bytes=li.dim * 4)
         for ids, items, mat in stream:

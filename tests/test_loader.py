@@ -207,7 +207,10 @@ def test_sqlite_extension_loads_and_registers_without_a_gpu():
     sqlite_seam.load(conn)
     assert [r[0] for r in conn.execute("SELECT name FROM pragma_module_list WHERE name = 'pvs_dist'")] == ["pvs_dist"]
     assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_distance%'")} == {"pvs_distance_cosine", "pvs_distance_l2"}
-    for sql, args in (("SELECT * FROM pvs_dist('nope', ?)", (b"\0" * 16,)), ("SELECT pvs_distance_l2('nope', 1, ?)", (b"\0" * 16,)), ("SELECT * FROM pvs_dist('x')", ())):
+    assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_load%'")} == {"pvs_load", "pvs_load_info"}
+    assert conn.execute("SELECT pvs_load_info('nope')").fetchone()[0] is None
+    for sql, args in (("SELECT * FROM pvs_dist('nope', ?)", (b"\0" * 16,)), ("SELECT pvs_distance_l2('nope', 1, ?)", (b"\0" * 16,)), ("SELECT * FROM pvs_dist('x')", ()),
+                      ("SELECT pvs_load('nope', 'SELECT 1, 1, zeroblob(4)')", ()), ("SELECT pvs_load('nope')", ())):
         with pytest.raises(sqlite3.OperationalError):
             conn.execute(sql, args).fetchall()
 
@@ -360,3 +363,64 @@ def test_dist_cte_seam_sql_runs_unchanged_over_device_distances():
     assert gg[0, : gc[0]].tolist() == first_items
     sqlite_seam.unbind("clip-int8")
     li.index.close()
+
+
+@pytest.mark.gpu
+def test_native_row_streamer_loads_what_the_python_loader_loads():
+    """pvs_load (the C streamer of libpvs_sqlite.so) against the Python chunk loader on the same database: same rows, ids, groups,
+    fingerprint and tail; ragged and NULL payloads skipped; appends after an epoch bump; errors are SQL errors."""
+    import json
+
+    import panoptikon_amd as pvs
+    from panoptikon_amd import loader, sqlite_seam
+
+    conn, good, scale, codes = build_db(n_items=700, dim=128, ragged=True)
+    names = ["clip/m", "tclip/m"]
+    for kind in ("exact", "quant"):
+        if kind == "exact":
+            py = loader.load_exact_index(conn, names)
+            nat = loader.load_exact_index(conn, names, native=True)
+        else:
+            py = loader.load_quant_index(conn, "int8", names)
+            nat = loader.load_quant_index(conn, "int8", names, native=True)
+        assert nat.rows == py.rows == len(good) and nat.dim == py.dim
+        assert (nat.last_id, nat.sum_id, nat.sum_item, nat.tail) == (py.last_id, py.sum_id, py.sum_item, py.tail)
+        assert np.array_equal(nat.index.read_ids(), py.index.read_ids())
+        assert np.array_equal(nat.index.read_rows(0, nat.rows).view(np.uint8), py.index.read_rows(0, py.rows).view(np.uint8))
+        q = orc.synth_rows(5, 0, 1, 128)
+        a, b = nat.index.search_groups(q, 7, pvs.L2, pvs.AGG_MIN), py.index.search_groups(q, 7, pvs.L2, pvs.AGG_MIN)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), "group ids travelled with the rows"
+        # append after an epoch bump: only the new row is streamed, the fingerprint follows
+        nid = 50_000 + (0 if kind == "exact" else 1)
+        conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (?, 3, 1, 'clip', 1)", (nid,))
+        conn.execute("INSERT INTO embeddings (id, embedding) VALUES (?, ?)", (nid, q[0].astype("<f4").tobytes()))
+        conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 2, ?)", (nid, orc.quantize_int8(q, scale)[0].tobytes()))
+        assert loader.append_new_rows(conn, nat, names, native=True) == 1 and loader.append_new_rows(conn, py, names) == 1
+        assert (nat.rows, nat.last_id, nat.sum_id, nat.sum_item, nat.tail) == (py.rows, py.last_id, py.sum_id, py.sum_item, py.tail)
+        assert np.array_equal(nat.index.read_ids(), py.index.read_ids())
+        conn.execute("DELETE FROM embeddings WHERE id = ?", (nid,))
+        conn.execute("DELETE FROM item_data WHERE id = ?", (nid,))
+        conn.execute("DELETE FROM embedding_quants WHERE id = ?", (nid,))
+        nat.index.close()
+        py.index.close()
+    # the SQL function itself: f32 payloads into an int8 index go through the device codec; bad input is an SQL error
+    ix = pvs.VectorIndex(pvs.I8, 128)
+    ix.set_scale(scale)
+    sqlite_seam.load(conn)
+    sqlite_seam.bind("t", ix)
+    stream = "SELECT d.id, d.item_id, e.embedding FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN (?, ?) ORDER BY d.id"
+    try:
+        n = conn.execute("SELECT pvs_load('t', ?, 1, 2)", (stream,)).fetchone()[0]
+        assert n == len(good)
+        info = json.loads(conn.execute("SELECT pvs_load_info('t')").fetchone()[0])
+        assert info["rows"] == len(good) and info["skipped"] == 1 and info["last_id"] == good[-1][0]
+        assert np.array_equal(ix.read_rows(0, n), codes), "device quantization of the streamed f32 rows = the stored codes"
+        with pytest.raises(sqlite3.OperationalError, match="pvs_load"):
+            conn.execute("SELECT pvs_load('t', ?, 1, 2)", (stream,)).fetchall()  # ids not above the loaded ones
+        with pytest.raises(sqlite3.OperationalError, match="pvs_load"):
+            conn.execute("SELECT pvs_load('t', 'SELECT nonsense FROM nowhere')").fetchall()
+        with pytest.raises(sqlite3.OperationalError, match="pvs_load"):
+            conn.execute("SELECT pvs_load('t', 'SELECT 1, 1, zeroblob(4)', 5)").fetchall()  # more parameters than placeholders
+    finally:
+        sqlite_seam.unbind("t")
+        ix.close()
