@@ -700,6 +700,19 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NF; t++) {
+#ifdef PVS_PRIO_SWAP
+                    // 8-wave instances: the two waves of a SIMD take turns at the matrix pipe instead of sharing it 2:1 in favour of
+                    // the older one for the whole tile (PVS_TILE_PROF: 1,175 vs 1,880 cycles) — the younger wave leads the first
+                    // PVS_PRIO_SWAP/16 of the MFMAs, the older one the rest, so both finish near 1,536
+                    if constexpr (QG == 8 && CPT == 1) {
+                        if (t == 0) {
+                            if (wave >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+                        }
+                        if (t == NF * PVS_PRIO_SWAP / 16) {
+                            if (wave >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
+                        }
+                    }
+#endif
                     if (t + PF < NF) frag(t + PF);
                     if constexpr (PARITY) {
 #pragma unroll
