@@ -1,5 +1,9 @@
 // pvs_items.hip — C ABI of libpvs, part 3: per-item results on the device — GROUP BY aggregates and their
 // ranking, dense score matrices, similar_to, reciprocal-rank fusion across indexes, sharded per-item search.
+#include <chrono>
+#include <string>
+#include <thread>
+
 #include "pvs_index.hpp"
 
 // ------------------------------------------------- groups, dense scores, similar_to
@@ -567,6 +571,35 @@ static double rrf_score_host(const int64_t *ranks, const PvsRrfParams &p) {
 //      quarter of a branch falls back to the full ranking below.
 // Cost beside the exact scoring of every row: a few passes over 8 B per group instead of three multi-pass radix sorts of
 // all groups (configs[4]: 2 x 8.3M groups — the sorts were 10 of 16 ms).
+// The branches of a composition live in different indexes (their own streams, contexts and scratch): their per-branch steps run
+// on one host thread each, so that the round trips of one branch (uploads, the exact-range flag, page and count read-backs)
+// hide behind the other's kernels.  Branches that share an index run one after the other.
+template <class F>
+static pvs_status per_branch(const pvs_rrf_branch *br, uint32_t nb, F &&f) {
+    bool distinct = true;
+    for (uint32_t a = 0; a < nb; a++)
+        for (uint32_t b = a + 1; b < nb; b++) distinct &= br[a].idx != br[b].idx;
+    static const bool serial = getenv("PVS_RRF_SERIAL") != nullptr;  // tuning
+    if (nb == 1 || !distinct || serial) {
+        for (uint32_t b = 0; b < nb; b++) PVS_TRY(f(b));
+        return PVS_OK;
+    }
+    std::vector<pvs_status> st(nb, PVS_OK);
+    std::vector<std::string> msg(nb);
+    std::vector<std::thread> th;
+    for (uint32_t b = 1; b < nb; b++)
+        th.emplace_back([&, b] {
+            st[b] = f(b);
+            if (st[b] != PVS_OK) msg[b] = pvs_last_error();
+        });
+    st[0] = f(0);
+    for (auto &t : th) t.join();
+    if (st[0] != PVS_OK) return st[0];
+    for (uint32_t b = 1; b < nb; b++)
+        if (st[b] != PVS_OK) return pvs_fail(st[b], "%s", msg[b].c_str());
+    return PVS_OK;
+}
+
 // PVS_RRF_TRACE=1: host wall time of every phase of a composed query on stderr (tuning)
 struct RrfTrace {
     bool on = getenv("PVS_RRF_TRACE") != nullptr;
@@ -581,7 +614,6 @@ struct RrfTrace {
 static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint32_t k,
                               int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done) {
     *done = false;
-    (void)br;
     const uint32_t nb = p.n_branches;
     uint64_t total_groups = 0;
     for (uint32_t b = 0; b < nb; b++) {
@@ -596,34 +628,43 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
     for (int round = 0; round < 6; round++, target *= 4) {
         std::vector<uint32_t> R(nb, 0);
         std::vector<int64_t> cand;
-        for (uint32_t b = 0; b < nb; b++) {
+        for (uint32_t b = 0; b < nb; b++)
+            if (cols[b].n_groups && target * 4 >= cols[b].n_groups) return PVS_OK;  // a page that would hold a quarter of the branch: full ranking
+        std::vector<std::vector<int64_t>> page(nb);
+        std::vector<uint8_t> overflow(nb, 0);
+        PVS_TRY(per_branch(br, nb, [&](uint32_t b) -> pvs_status {
             const uint32_t n = cols[b].n_groups;
-            if (n == 0) continue;
-            if (target * 4 >= n) return PVS_OK;  // a page that would hold a quarter of the branch: full ranking
+            if (n == 0) return PVS_OK;
             uint64_t thr = 0;
             PVS_TRY(pvs_rrf_cols_threshold(&cols[b], target, &thr));
-            tr.lap("threshold");
             const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 8 * target + 65536);
-            std::vector<int64_t> g(cap);
+            page[b].resize(cap);
             std::vector<uint64_t> gk(cap);
             uint32_t cnt = 0;
-            PVS_TRY(pvs_rrf_cols_page(&cols[b], thr, cap, g.data(), gk.data(), &cnt));
-            if (cnt > cap) return PVS_OK;  // many equal keys at the threshold (massive ties): full ranking
+            PVS_TRY(pvs_rrf_cols_page(&cols[b], thr, cap, page[b].data(), gk.data(), &cnt));
+            if (cnt > cap) {  // many equal keys at the threshold (massive ties): full ranking
+                overflow[b] = 1;
+                return PVS_OK;
+            }
             R[b] = cnt;
-            cand.insert(cand.end(), g.begin(), g.begin() + cnt);
-            tr.lap("page");
+            page[b].resize(cnt);
+            return PVS_OK;
+        }));
+        for (uint32_t b = 0; b < nb; b++) {
+            if (overflow[b]) return PVS_OK;
+            cand.insert(cand.end(), page[b].begin(), page[b].end());
         }
+        tr.lap("thresholds + pages");
         std::sort(cand.begin(), cand.end());
         cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
         const uint32_t m = (uint32_t)cand.size();
         tr.lap("union");
         std::vector<std::vector<int64_t>> ranks(nb, std::vector<int64_t>(m, -1));
-        for (uint32_t b = 0; b < nb; b++) {
-            if (cols[b].n_groups == 0 || m == 0) continue;
+        PVS_TRY(per_branch(br, nb, [&](uint32_t b) -> pvs_status {
+            if (cols[b].n_groups == 0 || m == 0) return PVS_OK;
             std::vector<uint64_t> key(m);
             std::vector<uint8_t> present(m);
             PVS_TRY(pvs_rrf_cols_lookup(&cols[b], cand.data(), m, key.data(), present.data()));
-            tr.lap("lookup");
             std::vector<uint32_t> order;
             for (uint32_t c = 0; c < m; c++)
                 if (present[c]) order.push_back(c);
@@ -635,11 +676,11 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
                 ck[i] = key[order[i]];
                 cg[i] = cand[order[i]];
             }
-            tr.lap("order");
             PVS_TRY(pvs_rrf_cols_count_below(&cols[b], ck.data(), cg.data(), mp, below.data()));
-            tr.lap("count_below");
             for (uint32_t i = 0; i < mp; i++) ranks[b][order[i]] = (int64_t)below[i] + 1;
-        }
+            return PVS_OK;
+        }));
+        tr.lap("lookups + exact ranks");
         struct GS {
             double s;
             int64_t g;
@@ -697,10 +738,8 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
     auto body = [&]() -> pvs_status {
         RrfTrace tr;
-        for (uint32_t b = 0; b < nb; b++) {
-            PVS_TRY(rrf_score_branch(br[b], &cols[b]));
-            tr.lap("score branch (enqueue)");
-        }
+        PVS_TRY(per_branch(br, nb, [&](uint32_t b) { return rrf_score_branch(br[b], &cols[b]); }));
+        tr.lap("score branches");
         const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests and profiles: compare the two paths
         if (!force_full) {
             bool done = false;
