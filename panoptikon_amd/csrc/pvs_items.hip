@@ -377,12 +377,12 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     std::vector<double> av((size_t)world * elems);
     std::vector<uint32_t> ac((size_t)world * batch);
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_g, elems * 8));
-        HIP_TRY(hipMalloc((void **)&d_v, elems * 8));
-        HIP_TRY(hipMalloc((void **)&d_c, (size_t)batch * 4));
-        HIP_TRY(hipMalloc((void **)&d_ag, elems * 8 * world));
-        HIP_TRY(hipMalloc((void **)&d_av, elems * 8 * world));
-        HIP_TRY(hipMalloc((void **)&d_ac, (size_t)batch * 4 * world));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_g, elems * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_v, elems * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_c, (size_t)batch * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_ag, elems * 8 * world));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_av, elems * 8 * world));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_ac, (size_t)batch * 4 * world));
         hipStream_t s = ix->comm_stream;  // every collective of this index goes out on this one stream
         HIP_TRY(hipMemcpyAsync(d_g, lg.data(), elems * 8, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_v, lv.data(), elems * 8, hipMemcpyHostToDevice, s));
@@ -400,12 +400,7 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
     };
     pvs_status st = body();
-    hipFree(d_g);
-    hipFree(d_v);
-    hipFree(d_c);
-    hipFree(d_ag);
-    hipFree(d_av);
-    hipFree(d_ac);
+    for (void *p : {(void *)d_g, (void *)d_v, (void *)d_c, (void *)d_ag, (void *)d_av, (void *)d_ac}) pvs_scratch_free(p);  // (cached blocks: no hipFree, which would synchronise the device)
     return st;
 }
 

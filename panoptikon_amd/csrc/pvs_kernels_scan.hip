@@ -200,7 +200,8 @@ struct FinK {
     int metric;
 };
 
-constexpr int FIN_LDS = PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
+constexpr int FIN_QMAX = 8192;  // bytes of LDS for the query vector the rerank reads (dims beyond that read it from global memory)
+constexpr int FIN_LDS = PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64 + FIN_QMAX;
 
 __device__ static inline float cand_err(const FinK &a, const QInfo &qi, float aa) {
     return a.metric == PVS_COSINE ? qi.eA : qi.eA + qi.eR * aa;
@@ -216,6 +217,86 @@ __device__ static inline float cand_key(const FinK &a, const QInfo &qi, uint32_t
     }
 }
 
+// Pass C's exact distance of one survivor, in the reference's order (sqlite-vec's scalar kernels: one rounding per multiply and
+// per add, components in sequence — oracle/pvs_oracle.c), written for a lane that is alone with a cold row: the row streams from
+// global memory in groups of 8 sixteen-byte chunks with the next group requested before the current one is consumed, the query
+// comes from LDS (s_q, zero-padded to a whole chunk) one vector read per chunk, and whole chunks are processed without a bounds
+// test per component — the padding of row and query is zero, and adding +0 products changes nothing a distance can show (at
+// most the sign of a zero dot product, which `1 - dot/den` does not see).  The generic form (exact_distance<DT> with the query in
+// global memory) compiled to a flat load of the query plus `s_waitcnt vmcnt(0)` per component: ~125 cycles per component,
+// 50-85 us of a 90-140 us finaliser for 768-d f16 rows.
+typedef unsigned int fin_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) fin_u32x4 *gchunk_ptr;
+template <int DT>
+__device__ static inline float rerank_distance(const uint8_t *rows, uint32_t stride, uint64_t r, const uint8_t *s_q, int dim, int metric, float aa,
+                                               float bb) {
+    constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;
+    constexpr int UN = 8;  // 2 x 8 loads in flight per lane (16, 24 and 48 measured the same or worse: the lanes of a wave touch 64 different lines per load)
+    const int nchunks = (dim + PER - 1) / PER;
+    const bool l2 = metric == PVS_L2;
+    float acc = 0.0f;
+    auto step = [&](float av, float qv) {
+        if (l2) {
+            const float t = __fsub_rn(av, qv);
+            acc = __fadd_rn(acc, __fmul_rn(t, t));
+        } else {
+            acc = __fadd_rn(acc, __fmul_rn(av, qv));
+        }
+    };
+    auto visit = [&](int c, const uint4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (DT == PVS_I8) {
+            const uint4 qv = ((const uint4 *)s_q)[c];
+            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int ai = (int)(int8_t)(w[j >> 2] >> ((j & 3) * 8)), qi = (int)(int8_t)(qw[j >> 2] >> ((j & 3) * 8));
+                if (l2) {  // (integers below 2^17: the f32 images and the product are exact, as in the reference)
+                    const float t = (float)(ai - qi);
+                    acc = __fadd_rn(acc, __fmul_rn(t, t));
+                } else {
+                    acc = __fadd_rn(acc, (float)(ai * qi));
+                }
+            }
+        } else if constexpr (DT == PVS_F16) {
+            const float4 q0 = ((const float4 *)s_q)[2 * c], q1 = ((const float4 *)s_q)[2 * c + 1];
+            const float qf[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) step(h2f((uint16_t)(w[j >> 1] >> ((j & 1) * 16))), qf[j]);
+        } else {
+            const float4 q0 = ((const float4 *)s_q)[c];
+            const float qf[4] = {q0.x, q0.y, q0.z, q0.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) step(__builtin_bit_cast(float, w[j]), qf[j]);
+        }
+    };
+    auto load = [&](int c) {  // (an explicit global-memory load: pointers that arrive inside a by-value kernel argument struct compile to flat loads)
+        const fin_u32x4 v = *(gchunk_ptr)(uintptr_t)(rows + pvs_chunk_off(r, (uint32_t)c, stride));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    int c = 0;
+    if (nchunks >= UN) {
+        uint4 cur[UN], nxt[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) cur[u] = load(u);
+        for (; c + UN <= nchunks; c += UN) {
+            const bool more = c + 2 * UN <= nchunks;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UN; u++) nxt[u] = load(c + UN + u);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) visit(c + u, cur[u]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < UN; u++) cur[u] = nxt[u];
+            }
+        }
+    }
+    for (; c < nchunks; c++) visit(c, load(c));
+    return l2 ? ref_l2_finish(acc) : ref_cosine_finish(acc, aa, bb);
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -227,6 +308,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
 
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
+#ifdef PVS_FIN_PROF  // tuning build: wall clock (100 MHz s_memrealtime) at the phase boundaries of workgroup 0
+    unsigned long long fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FIN_STAMP(i) fp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define FIN_STAMP(i) do { } while (0)
+#endif
+    FIN_STAMP(0);
     int64_t *oid = a.out_ids + (size_t)q * a.k;
     float *od = a.out_dist + (size_t)q * a.k;
     // ---- gather: the scan left this query's candidates in one segment per workgroup row stream (no atomics on its side);
@@ -277,6 +365,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         (void)s_off;
         __syncthreads();  // (workgroup-scope fence: the list is read back by other lanes below)
     }
+    FIN_STAMP(1);
     if (tid == 0 && a.cand_seen) a.cand_seen[q] = cnt;
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
     if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
@@ -295,10 +384,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     }
     if (tid == 0) s_misc[0] = 0;
     __syncthreads();
+    FIN_STAMP(2);
     uint32_t kub = 0xffffffffu;
     if (cnt > a.k) kub = radix_kth(cnt, a.k, hist, s_misc + 2, [&](uint32_t i) { return s_ub[i]; });
     const float kappa = (kub == 0xffffffffu) ? __builtin_inff() : f32_from_sort_key(kub);
     __syncthreads();
+    FIN_STAMP(3);
     // survivors: lower bound <= k-th smallest upper bound
     for (uint32_t i = tid; i < cnt; i += 256) {
         const uint2 c = cand[i];
@@ -317,10 +408,22 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         }
         return;
     }
+    FIN_STAMP(4);
     uint32_t m2 = 1;
     while (m2 < m) m2 <<= 1;
     __syncthreads();  // s_ub is dead from here: s_sort overlays it
     const uint8_t *qe = (const uint8_t *)a.qexact + (size_t)q * a.dim * (DT == PVS_I8 ? 1 : 4);
+    // the query of this workgroup, zero-padded to a whole 16-byte chunk, in LDS beyond everything s_sort overlays (rerank_distance)
+    uint8_t *const s_q = smem + PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
+    {
+        const uint32_t qbytes = a.dim * (DT == PVS_I8 ? 1u : 4u), padded = (qbytes + 63u) & ~63u;
+        if constexpr (DT == PVS_I8) {
+            for (uint32_t i = tid; i < padded; i += 256) s_q[i] = i < qbytes ? qe[i] : (uint8_t)0;
+        } else {
+            for (uint32_t i = tid; i < padded / 4; i += 256) ((uint32_t *)s_q)[i] = i < qbytes / 4 ? ((const uint32_t *)qe)[i] : 0u;
+        }
+    }
+    __syncthreads();
     for (uint32_t i = tid; i < m2; i += 256) {
         unsigned long long v = ~0ull;
         if (i < m) {
@@ -348,12 +451,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     }
                 }
             }
-            if (!closed) d = exact_distance<DT>(a.rows, a.stride, row, qe, (int)a.dim, a.metric, aa, qi.bb);
+            if (!closed) d = rerank_distance<DT>(a.rows, a.stride, row, s_q, (int)a.dim, a.metric, aa, qi.bb);
             v = ((unsigned long long)f32_sort_key(d) << 32) | row;
         }
         s_sort[i] = v;
     }
     __syncthreads();
+    FIN_STAMP(5);
     // bitonic sort ascending on (distance key, row)
     for (uint32_t sz = 2; sz <= m2; sz <<= 1) {
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
@@ -370,6 +474,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
             __syncthreads();
         }
     }
+    FIN_STAMP(6);
+#ifdef PVS_FIN_PROF
+    if (q == 0 && tid == 0)
+        printf("finprof cand %u survivors %u: gather %llu ub-keys %llu kth %llu survive %llu rerank %llu sort %llu (x10 ns)\n", cnt, m, fp[1] - fp[0],
+               fp[2] - fp[1], fp[3] - fp[2], fp[4] - fp[3], fp[5] - fp[4], fp[6] - fp[5]);
+#endif
     const uint32_t nout = m < a.k ? m : a.k;
     // A NULL distance inside the page (non-finite components) or a short page: NULL rows are ordered by id over
     // the WHOLE corpus and the candidate list only holds rows whose scan key was comparable -> dense path.
@@ -429,6 +539,7 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
+    if ((((uint64_t)f.dim * (f.dtype == PVS_I8 ? 1u : 4u)) + 63u & ~63ull) > (uint64_t)FIN_QMAX) return hipErrorInvalidValue;  // (no scan instance is that wide)
     if (f.dtype == PVS_I8)
         hipLaunchKernelGGL(k_finalize<PVS_I8>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
     else if (f.dtype == PVS_F16)
