@@ -641,6 +641,17 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
                 overflow[b] = 1;
                 return PVS_OK;
             }
+            // the sampled threshold is a noisy order statistic (1.6k-5k files for a target of 1k): cut the page back to the files at
+            // or below its own target-th smallest key — still "every file with key <= T'", only with a smaller T'
+            if (cnt > target) {
+                std::vector<uint64_t> ks(gk.begin(), gk.begin() + cnt);
+                std::nth_element(ks.begin(), ks.begin() + (target - 1), ks.end());
+                const uint64_t t2 = ks[target - 1];
+                uint32_t w = 0;
+                for (uint32_t i = 0; i < cnt; i++)
+                    if (gk[i] <= t2) page[b][w++] = page[b][i];
+                cnt = w;
+            }
             R[b] = cnt;
             page[b].resize(cnt);
             return PVS_OK;
