@@ -424,3 +424,98 @@ def test_native_row_streamer_loads_what_the_python_loader_loads():
     finally:
         sqlite_seam.unbind("t")
         ix.close()
+
+
+_HOST_TABLE_SCRIPT = r"""
+import ctypes as C, sys
+from panoptikon_amd import sqlite_seam
+s3 = C.CDLL("libsqlite3.so.0")
+ext = sqlite_seam.ext()
+V1 = ["create_function_v2", "create_module_v2", "declare_vtab", "value_type", "value_bytes", "value_blob", "value_text", "value_int64",
+      "result_double", "result_int64", "result_null", "result_error", "user_data", "get_auxdata", "set_auxdata", "mprintf", "free"]
+V2 = ["prepare_v2", "step", "finalize", "column_type", "column_blob", "column_bytes", "column_int64", "bind_value", "context_db_handle",
+      "errmsg", "result_text"]
+class Api(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_void_p) for n in V1 + V2]
+def table(names, size):
+    a = Api()
+    for n in names:
+        setattr(a, n, C.cast(getattr(s3, "sqlite3_" + n), C.c_void_p).value)
+    a.struct_size = size
+    return a
+db = C.c_void_p()
+assert s3.sqlite3_open(b":memory:", C.byref(db)) == 0
+ext.pvs_sqlite_register.restype = C.c_int32
+ext.pvs_sqlite_register.argtypes = [C.c_void_p, C.c_void_p]
+mode = sys.argv[1]
+api = table(V1, Api.prepare_v2.offset) if mode == "v1" else table(V1 + V2, C.sizeof(Api))
+assert ext.pvs_sqlite_register(db, C.byref(api)) == 0
+short = table(V1, 16)
+assert ext.pvs_sqlite_register(db, C.byref(short)) != 0, "a struct shorter than v1 is refused"
+def has(fn):
+    st = C.c_void_p()
+    rc = s3.sqlite3_prepare_v2(db, ("SELECT " + fn).encode(), -1, C.byref(st), None)
+    s3.sqlite3_finalize(st)
+    return rc == 0
+print(int(has("pvs_distance_l2('x', 1, zeroblob(4))")), int(has("pvs_load('x', 'SELECT 1')")), int(has("pvs_load_info('x')")))
+"""
+
+
+@pytest.mark.parametrize("mode,expect", [("v1", "1 0 0"), ("v2", "1 1 1")])
+def test_host_supplied_sqlite_entry_points(mode, expect):
+    """pvs_sqlite_register with the host's own table of SQLite entry points (a Rust host links its own SQLite): the full
+    struct registers everything, the shorter v1 struct everything but the row streamer; no dlsym, no GPU.  (Own process:
+    the table is process-wide.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, "-c", _HOST_TABLE_SCRIPT, mode], cwd=root, text=True, env=dict(os.environ, PYTHONPATH=root))
+    assert out.strip().splitlines()[-1] == expect
+
+
+@pytest.mark.gpu
+def test_row_streamer_c_entry_point_on_a_connection_the_host_holds():
+    """pvs_sqlite_load(db, sql, idx, chunk_rows, &result): the C form of pvs_load for a host that owns the sqlite3* (here: a
+    connection opened through libsqlite3's C API with ctypes).  Small chunks, NULL and ragged payloads, rows without groups."""
+    import ctypes as C
+
+    import panoptikon_amd as pvs
+    from panoptikon_amd import sqlite_seam
+
+    s3 = C.CDLL("libsqlite3.so.0")
+    ext = sqlite_seam.ext()
+    db = C.c_void_p()
+    assert s3.sqlite3_open(b":memory:", C.byref(db)) == 0
+    dim, n = 16, 57
+    rows = orc.synth_rows(9, 0, n, dim)
+    stmts = ["CREATE TABLE v (id INTEGER PRIMARY KEY, g INTEGER, e BLOB)"]
+    for i in range(n):
+        stmts.append(f"INSERT INTO v VALUES ({10 + 3 * i}, {i // 2}, x'{rows[i].astype('<f4').tobytes().hex()}')")
+    stmts += ["INSERT INTO v VALUES (5, 0, NULL)", "INSERT INTO v VALUES (7, 0, x'00112233')"]  # skipped: NULL, wrong length
+    for sql in stmts:
+        assert s3.sqlite3_exec(db, sql.encode(), None, None, None) == 0, sql
+
+    class Res(C.Structure):
+        _fields_ = [("rows", C.c_uint64), ("skipped", C.c_uint64), ("last_id", C.c_int64), ("sum_id", C.c_uint64), ("sum_group", C.c_uint64)]
+
+    ext.pvs_sqlite_load.restype = C.c_int32
+    ext.pvs_sqlite_load.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    ix = pvs.VectorIndex(pvs.F32, dim)
+    try:
+        r = Res()
+        assert ext.pvs_sqlite_load(db, b"SELECT id, g, e FROM v ORDER BY id", ix._h, 10, C.byref(r)) == 0
+        ids = 10 + 3 * np.arange(n, dtype=np.int64)
+        assert (r.rows, r.skipped, r.last_id) == (n, 2, int(ids[-1]))
+        assert r.sum_id == int(ids.sum()) and r.sum_group == int((np.arange(n) // 2).sum())
+        assert np.array_equal(ix.read_ids(), ids) and np.array_equal(ix.read_rows(0, n).view(np.uint32), rows.view(np.uint32))
+        q = rows[20:21]
+        gg, gv, gn = ix.search_groups(q, 1, pvs.L2, pvs.AGG_MIN)
+        assert gg[0, 0] == 10 and gv[0, 0] == 0.0, "group ids arrived"
+        # a statement that fails to prepare, and rows that do not increase: status codes, nothing appended
+        assert ext.pvs_sqlite_load(db, b"SELECT nope FROM nowhere", ix._h, 0, None) != 0
+        assert ext.pvs_sqlite_load(db, b"SELECT id, g, e FROM v ORDER BY id", ix._h, 0, C.byref(r)) != 0 and r.rows == 0
+        assert ix.stats().rows == n
+    finally:
+        ix.close()
+        s3.sqlite3_close(db)
