@@ -213,6 +213,16 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
 /* pvs_search under apply_sort_bounds (pql/builder.rs:781-815: `WHERE order_rank > gt AND order_rank < lt` with order_rank =
  * the distance, a SQL REAL): page 1 of the rows whose distance lies inside the bounds; have_gt / have_lt select them.
  * Rows with a NULL distance never pass a bound.  out_count[q] = min(k, rows inside the bounds). */
+/* Request coalescing for the host-buffer entry point (pvs_search).  The reference host answers one query per SQL statement
+ * from a pool of up to 16 read connections (db/connection.rs:235,320-357); a corpus pass costs the same for one query as for
+ * 32, so callers that arrive within `window_us` of each other are answered by ONE pass: the first one waits out the window
+ * (or until `max_batch` queries are waiting; 0 = 32, at most 128), runs one search for every waiting request with its metric
+ * and query dtype at the largest k among them, and each caller gets the head of its page — results are exactly those of
+ * separate calls.  window_us = 0 (the default) switches it off; calls with more than max_batch/2 queries are never held
+ * back.  pvs_index_coalescing_stats: pvs_search calls that went through the queue, and corpus passes that served them. */
+pvs_status pvs_index_set_coalescing(pvs_index *idx, uint32_t window_us, uint32_t max_batch);
+pvs_status pvs_index_coalescing_stats(pvs_index *idx, uint64_t *out_calls, uint64_t *out_passes);
+
 pvs_status pvs_search_bounded(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
                               pvs_metric metric, int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids,
                               float *out_dist, uint32_t *out_count);

@@ -157,6 +157,29 @@ struct pvs_index {
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
+    // Request coalescing of the host-buffer entry point (pvs_index_set_coalescing): callers that arrive within a short window
+    // share one corpus pass.  `pending` holds the requests not yet taken by a leader; one caller at a time is the leader.
+    struct CoalesceReq {
+        const void *queries;
+        pvs_dtype qdtype;
+        uint32_t batch, k;
+        pvs_metric metric;
+        int64_t *out_ids;
+        float *out_dist;
+        uint32_t *out_count;
+        pvs_status st = PVS_OK;
+        std::string err;
+        bool done = false;
+    };
+    struct {
+        std::mutex mu;
+        std::condition_variable cv_leader, cv_done;
+        std::vector<CoalesceReq *> pending;
+        bool leader_active = false;
+        std::atomic<uint32_t> window_us{0};
+        uint32_t max_batch = 0;
+        std::atomic<uint64_t> calls{0}, passes{0};
+    } co;
     bool profiling = false;
     std::mutex prof_mu;
     pvs_profile prof{};

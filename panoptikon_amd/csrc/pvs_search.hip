@@ -1,5 +1,9 @@
 // pvs_search.hip — C ABI of libpvs, part 2: search orchestration over HIP streams (filter scan passes A/B/C,
 // dense fallbacks, candidate masks), the stream-ordered and sharded entry points, the dense `d` column.
+#include <chrono>
+#include <cstring>
+#include <string>
+
 #include "pvs_index.hpp"
 
 // ------------------------------------------------------------------- search
@@ -295,8 +299,140 @@ void ctx_done(pvs_index *ix, SearchCtx *c) {
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                               const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
+static pvs_status search_host_any(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                  int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (is_multi(ix)) return multi_search_host(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
+    return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
+}
+
+// ---- request coalescing.  The reference host answers one query per SQL statement from a pool of up to 16 read connections
+// (db/connection.rs:235,320-357): sixteen threads each asking for ONE query's page.  A corpus pass costs the same for 1 query as
+// for 32 (HBM-bound), so callers that arrive within `window_us` of each other are answered by ONE pass: the first caller
+// becomes the leader, waits out the window (or until `max_batch` queries are waiting), takes every pending request with its own
+// metric and query dtype, runs one search with the largest k of the group and hands each request the head of its page — the
+// page for a smaller k is a prefix of the page for a larger one (same ordering: distance, then id, NULLs last).  Requests with
+// another metric / dtype stay queued for the next leader.
+PVS_EXPORT pvs_status pvs_index_set_coalescing(pvs_index *ix, uint32_t window_us, uint32_t max_batch) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->co.mu);
+    ix->co.max_batch = max_batch ? std::min<uint32_t>(max_batch, PVS_MAX_BATCH) : 32;
+    ix->co.window_us.store(window_us);
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_index_coalescing_stats(pvs_index *ix, uint64_t *out_calls, uint64_t *out_passes) {
+    if (!ix || !out_calls || !out_passes) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    *out_calls = ix->co.calls.load();
+    *out_passes = ix->co.passes.load();
+    return PVS_OK;
+}
+
+static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                   int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    using Req = pvs_index::CoalesceReq;
+    auto &co = ix->co;
+    Req me;
+    me.queries = queries;
+    me.qdtype = qdtype;
+    me.batch = batch;
+    me.k = k;
+    me.metric = metric;
+    me.out_ids = out_ids;
+    me.out_dist = out_dist;
+    me.out_count = out_count;
+    co.calls++;
+    std::unique_lock<std::mutex> lk(co.mu);
+    co.pending.push_back(&me);
+    for (;;) {
+        if (me.done) break;
+        if (co.leader_active) {
+            co.cv_leader.notify_one();  // (the leader may be waiting for the batch to fill)
+            co.cv_done.wait(lk);
+            continue;
+        }
+        // ---- this caller leads one pass
+        co.leader_active = true;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(co.window_us.load());
+        auto waiting = [&]() {
+            uint32_t n = 0;
+            for (Req *r : co.pending)
+                if (r->metric == me.metric && r->qdtype == me.qdtype) n += r->batch;
+            return n;
+        };
+        while (waiting() < co.max_batch && co.cv_leader.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
+        std::vector<Req *> group, rest;
+        uint32_t total = 0, kmax = 0;
+        group.push_back(&me);
+        total = me.batch;
+        kmax = me.k;
+        for (Req *r : co.pending) {
+            if (r == &me) continue;
+            if (r->metric == me.metric && r->qdtype == me.qdtype && total + r->batch <= co.max_batch) {
+                group.push_back(r);
+                total += r->batch;
+                kmax = std::max(kmax, r->k);
+            } else {
+                rest.push_back(r);
+            }
+        }
+        co.pending.swap(rest);
+        lk.unlock();
+        // one pass for the group
+        pvs_status st = PVS_OK;
+        std::string err;
+        if (group.size() == 1) {
+            st = search_host_any(ix, me.queries, me.qdtype, me.batch, me.k, me.metric, me.out_ids, me.out_dist, me.out_count);
+            if (st != PVS_OK) err = pvs_last_error();
+        } else {
+            const size_t qbytes = (size_t)ix->dim * (me.qdtype == PVS_I8 ? 1 : 4);
+            std::vector<uint8_t> q((size_t)total * qbytes);
+            std::vector<int64_t> ids((size_t)total * kmax);
+            std::vector<float> dist((size_t)total * kmax);
+            std::vector<uint32_t> cnt(total);
+            size_t off = 0;
+            for (Req *r : group) {
+                memcpy(q.data() + off * qbytes, r->queries, (size_t)r->batch * qbytes);
+                off += r->batch;
+            }
+            st = search_host_any(ix, q.data(), me.qdtype, total, kmax, me.metric, ids.data(), dist.data(), cnt.data());
+            if (st != PVS_OK) err = pvs_last_error();
+            off = 0;
+            for (Req *r : group) {
+                if (st == PVS_OK)
+                    for (uint32_t b = 0; b < r->batch; b++) {
+                        const uint32_t have = std::min(cnt[off + b], r->k);
+                        for (uint32_t i = 0; i < r->k; i++) {
+                            r->out_ids[(size_t)b * r->k + i] = i < have ? ids[(off + b) * kmax + i] : -1;
+                            r->out_dist[(size_t)b * r->k + i] = i < have ? dist[(off + b) * kmax + i] : __builtin_nanf("");
+                        }
+                        r->out_count[b] = have;
+                    }
+                off += r->batch;
+            }
+        }
+        co.passes++;
+        lk.lock();
+        for (Req *r : group) {
+            r->st = st;
+            r->err = err;
+            r->done = true;
+        }
+        co.leader_active = false;
+        co.cv_done.notify_all();  // the group is served; one of the callers left in `pending` leads the next pass
+    }
+    lk.unlock();
+    if (me.st != PVS_OK) return pvs_fail(me.st, "%s", me.err.c_str());
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                  pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix && ix->co.window_us.load() && batch && batch * 2 <= ix->co.max_batch) {
+        // (arguments are checked before the request is queued: a bad call fails alone)
+        PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+        if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+        return search_coalesced(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
+    }
     if (ix && is_multi(ix)) return multi_search_host(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
     return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
 }

@@ -207,6 +207,15 @@ class VectorIndex:
     def set_streams(self, n: int):
         L.check(L.lib().pvs_index_set_streams(self._h, n))
 
+    def set_coalescing(self, window_us: int, max_batch: int = 0):
+        """Concurrent `search` calls from several host threads within `window_us` share one corpus pass (pvs.h)."""
+        L.check(L.lib().pvs_index_set_coalescing(self._h, int(window_us), int(max_batch)))
+
+    def coalescing_stats(self):
+        calls, passes = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().pvs_index_coalescing_stats(self._h, C.byref(calls), C.byref(passes)))
+        return int(calls.value), int(passes.value)
+
     def set_path(self, path: int):
         L.check(L.lib().pvs_index_set_path(self._h, path))
 

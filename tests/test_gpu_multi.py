@@ -352,3 +352,63 @@ def test_rrf_sharded_by_group_equals_the_whole_corpus(pvs):
     for sh in shards:
         for b in sh:
             b["index"].close()
+
+
+def test_coalesced_single_query_callers_get_their_own_pages(pvs):
+    """pvs_index_set_coalescing: sixteen host threads, one query (sometimes two or three) per call, different k and both metrics
+    in the mix — every caller gets exactly the page a lone call returns, and the calls were served by fewer corpus passes."""
+    import threading
+
+    dim = 256
+    rows = orc.synth_rows(31, 0, 30_000, dim)
+    rows[777] = rows[12]  # a duplicate: ties broken by id inside every page
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows)
+    nthreads, per = 16, 8
+    queries = orc.synth_rows(0x5EED0044, 0, nthreads * per + 3, dim)
+    queries[5] = rows[12]
+    hq = orc.quantize_int8(queries, scale)
+    exp = {(m, k): orc.search(orc.I8, om, codes, hq, k, threads=8) for m, om in ((pvs.COSINE, orc.COSINE), (pvs.L2, orc.L2)) for k in (7, 20, 33)}
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def worker(t):
+        try:
+            start.wait()
+            for rep in range(per):
+                q = t * per + rep
+                nb = 1 + (q % 5 == 0) + (q % 7 == 0)
+                k = (7, 20, 33)[(t + rep) % 3]
+                metric = pvs.L2 if t % 4 == 3 else pvs.COSINE
+                as_f32 = t % 2 == 0  # f32 queries are quantized on the device with the frozen scale; int8 codes pass through
+                gi, gd, gc = ix.search(queries[q:q + nb] if as_f32 else hq[q:q + nb], k, metric)
+                ei, ed = exp[(metric, k)]
+                for i in range(nb):
+                    if not (gc[i] == k and np.array_equal(gi[i], ei[q + i]) and np.array_equal(gd[i].view(np.uint32), ed[q + i].view(np.uint32))):
+                        errors.append((t, rep, q + i, k, metric))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    try:
+        ix.set_coalescing(2000, 32)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors[:5]
+        calls, passes = ix.coalescing_stats()
+        assert calls == nthreads * per and passes < calls, (calls, passes)
+        # a bad call fails alone and at once; big batches are not held back; switching it off restores the direct path
+        with pytest.raises(Exception):
+            ix.search(hq[:1], 0, pvs.COSINE)
+        gi, gd, gc = ix.search(hq[:40], 7, pvs.COSINE)
+        assert np.array_equal(gi, exp[(pvs.COSINE, 7)][0][:40]) and ix.coalescing_stats()[0] == calls
+        ix.set_coalescing(0)
+        gi, gd, gc = ix.search(hq[:1], 7, pvs.COSINE)
+        assert np.array_equal(gi, exp[(pvs.COSINE, 7)][0][:1]) and ix.coalescing_stats()[0] == calls
+    finally:
+        ix.close()
