@@ -218,7 +218,8 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
  * 32, so callers that arrive within `window_us` of each other are answered by ONE pass: the first one waits out the window
  * (or until `max_batch` queries are waiting; 0 = 32, at most 128), runs one search for every waiting request with its metric
  * and query dtype at the largest k among them, and each caller gets the head of its page — results are exactly those of
- * separate calls.  window_us = 0 (the default) switches it off; calls with more than max_batch/2 queries are never held
+ * separate calls.  pvs_search_groups calls without row weights are coalesced the same way, among callers with the same
+ * aggregate.  window_us = 0 (the default) switches it off; calls with more than max_batch/2 queries are never held
  * back.  pvs_index_coalescing_stats: pvs_search calls that went through the queue, and corpus passes that served them. */
 pvs_status pvs_index_set_coalescing(pvs_index *idx, uint32_t window_us, uint32_t max_batch);
 pvs_status pvs_index_coalescing_stats(pvs_index *idx, uint64_t *out_calls, uint64_t *out_passes);

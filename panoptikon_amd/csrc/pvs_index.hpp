@@ -164,8 +164,10 @@ struct pvs_index {
         pvs_dtype qdtype;
         uint32_t batch, k;
         pvs_metric metric;
-        int64_t *out_ids;
-        float *out_dist;
+        int kind;       // 0 = row pages (pvs_search: ids + f32 distances), 1 = per-item pages (pvs_search_groups: group ids + f64 values)
+        int agg;        // kind 1
+        int64_t *out_a; // ids / group ids
+        void *out_b;    // f32 distances / f64 values
         uint32_t *out_count;
         pvs_status st = PVS_OK;
         std::string err;
@@ -200,6 +202,10 @@ void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
 void ctx_release(SearchCtx &c);
 // ---- pvs_search.hip
+// request coalescing (pvs_search.hip): runs the call directly or as part of a group of concurrent callers
+bool coalescing_applies(pvs_index *ix, uint32_t batch);
+pvs_status coalesce_call(pvs_index *ix, int kind, int agg, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                         int64_t *out_a, void *out_b, uint32_t *out_count);
 pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric);
 bool fast_path_ok(const pvs_index *ix, uint32_t k);
 pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb, uint32_t batch_pad,

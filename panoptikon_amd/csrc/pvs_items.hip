@@ -267,6 +267,12 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
 PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                         double *out_values, uint32_t *out_count) {
+    if (!row_weights && coalescing_applies(ix, batch)) {  // (pvs_index_set_coalescing: concurrent callers share one pass)
+        PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+        if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+        if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+        return coalesce_call(ix, 1, (int)agg, queries, qdtype, batch, k, metric, out_groups, out_values, out_count);
+    }
     return search_groups_impl(ix, queries, qdtype, batch, k, metric, agg, row_weights, nullptr, PVS_HOST, out_groups, out_values, out_count);
 }
 

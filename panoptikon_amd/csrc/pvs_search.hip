@@ -326,8 +326,16 @@ PVS_EXPORT pvs_status pvs_index_coalescing_stats(pvs_index *ix, uint64_t *out_ca
     return PVS_OK;
 }
 
-static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                                   int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+bool coalescing_applies(pvs_index *ix, uint32_t batch) { return ix && ix->co.window_us.load() && batch && batch * 2 <= ix->co.max_batch; }
+
+static pvs_status coalesce_run(pvs_index *ix, int kind, int agg, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               int64_t *out_a, void *out_b, uint32_t *out_count) {
+    if (kind == 0) return search_host_any(ix, queries, qdtype, batch, k, metric, out_a, (float *)out_b, out_count);
+    return search_groups_impl(ix, queries, qdtype, batch, k, metric, (pvs_agg)agg, nullptr, nullptr, PVS_HOST, out_a, (double *)out_b, out_count);
+}
+
+pvs_status coalesce_call(pvs_index *ix, int kind, int agg, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                         int64_t *out_a, void *out_b, uint32_t *out_count) {
     using Req = pvs_index::CoalesceReq;
     auto &co = ix->co;
     Req me;
@@ -336,10 +344,14 @@ static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype
     me.batch = batch;
     me.k = k;
     me.metric = metric;
-    me.out_ids = out_ids;
-    me.out_dist = out_dist;
+    me.kind = kind;
+    me.agg = agg;
+    me.out_a = out_a;
+    me.out_b = out_b;
     me.out_count = out_count;
     co.calls++;
+    const size_t bsz = kind == 0 ? 4 : 8;  // bytes per entry of out_b
+    auto same = [&](const Req *r) { return r->metric == me.metric && r->qdtype == me.qdtype && r->kind == me.kind && r->agg == me.agg; };
     std::unique_lock<std::mutex> lk(co.mu);
     co.pending.push_back(&me);
     for (;;) {
@@ -355,19 +367,17 @@ static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype
         auto waiting = [&]() {
             uint32_t n = 0;
             for (Req *r : co.pending)
-                if (r->metric == me.metric && r->qdtype == me.qdtype) n += r->batch;
+                if (same(r)) n += r->batch;
             return n;
         };
         while (waiting() < co.max_batch && co.cv_leader.wait_until(lk, deadline) != std::cv_status::timeout) {
         }
         std::vector<Req *> group, rest;
-        uint32_t total = 0, kmax = 0;
         group.push_back(&me);
-        total = me.batch;
-        kmax = me.k;
+        uint32_t total = me.batch, kmax = me.k;
         for (Req *r : co.pending) {
             if (r == &me) continue;
-            if (r->metric == me.metric && r->qdtype == me.qdtype && total + r->batch <= co.max_batch) {
+            if (same(r) && total + r->batch <= co.max_batch) {
                 group.push_back(r);
                 total += r->batch;
                 kmax = std::max(kmax, r->k);
@@ -381,29 +391,37 @@ static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype
         pvs_status st = PVS_OK;
         std::string err;
         if (group.size() == 1) {
-            st = search_host_any(ix, me.queries, me.qdtype, me.batch, me.k, me.metric, me.out_ids, me.out_dist, me.out_count);
+            st = coalesce_run(ix, kind, agg, me.queries, me.qdtype, me.batch, me.k, me.metric, me.out_a, me.out_b, me.out_count);
             if (st != PVS_OK) err = pvs_last_error();
         } else {
             const size_t qbytes = (size_t)ix->dim * (me.qdtype == PVS_I8 ? 1 : 4);
-            std::vector<uint8_t> q((size_t)total * qbytes);
-            std::vector<int64_t> ids((size_t)total * kmax);
-            std::vector<float> dist((size_t)total * kmax);
+            std::vector<uint8_t> q((size_t)total * qbytes), vb((size_t)total * kmax * bsz);
+            std::vector<int64_t> va((size_t)total * kmax);
             std::vector<uint32_t> cnt(total);
             size_t off = 0;
             for (Req *r : group) {
                 memcpy(q.data() + off * qbytes, r->queries, (size_t)r->batch * qbytes);
                 off += r->batch;
             }
-            st = search_host_any(ix, q.data(), me.qdtype, total, kmax, me.metric, ids.data(), dist.data(), cnt.data());
+            st = coalesce_run(ix, kind, agg, q.data(), me.qdtype, total, kmax, me.metric, va.data(), vb.data(), cnt.data());
             if (st != PVS_OK) err = pvs_last_error();
             off = 0;
+            const float nan32 = __builtin_nanf("");
+            const double nan64 = __builtin_nan("");
             for (Req *r : group) {
                 if (st == PVS_OK)
                     for (uint32_t b = 0; b < r->batch; b++) {
                         const uint32_t have = std::min(cnt[off + b], r->k);
-                        for (uint32_t i = 0; i < r->k; i++) {
-                            r->out_ids[(size_t)b * r->k + i] = i < have ? ids[(off + b) * kmax + i] : -1;
-                            r->out_dist[(size_t)b * r->k + i] = i < have ? dist[(off + b) * kmax + i] : __builtin_nanf("");
+                        int64_t *oa = r->out_a + (size_t)b * r->k;
+                        uint8_t *ob = (uint8_t *)r->out_b + (size_t)b * r->k * bsz;
+                        memcpy(oa, va.data() + (off + b) * kmax, (size_t)have * 8);
+                        memcpy(ob, vb.data() + (off + b) * kmax * bsz, (size_t)have * bsz);
+                        for (uint32_t i = have; i < r->k; i++) {
+                            oa[i] = -1;
+                            if (bsz == 4)
+                                memcpy(ob + (size_t)i * 4, &nan32, 4);
+                            else
+                                memcpy(ob + (size_t)i * 8, &nan64, 8);
                         }
                         r->out_count[b] = have;
                     }
@@ -427,11 +445,11 @@ static pvs_status search_coalesced(pvs_index *ix, const void *queries, pvs_dtype
 
 PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                  pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
-    if (ix && ix->co.window_us.load() && batch && batch * 2 <= ix->co.max_batch) {
+    if (coalescing_applies(ix, batch)) {
         // (arguments are checked before the request is queued: a bad call fails alone)
         PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
         if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
-        return search_coalesced(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
+        return coalesce_call(ix, 0, 0, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
     }
     if (ix && is_multi(ix)) return multi_search_host(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count);
     return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);

@@ -366,7 +366,8 @@ def test_coalesced_single_query_callers_get_their_own_pages(pvs):
     codes = orc.quantize_int8(rows, scale)
     ix = pvs.VectorIndex(pvs.I8, dim)
     ix.set_scale(scale)
-    ix.add_f32(rows)
+    groups = (np.arange(len(rows), dtype=np.int64) // 3) * 7 + 1
+    ix.add_f32(rows, group_ids=groups)
     nthreads, per = 16, 8
     queries = orc.synth_rows(0x5EED0044, 0, nthreads * per + 3, dim)
     queries[5] = rows[12]
@@ -380,6 +381,14 @@ def test_coalesced_single_query_callers_get_their_own_pages(pvs):
             start.wait()
             for rep in range(per):
                 q = t * per + rep
+                if t % 4 in (1, 2) and rep % 2 == 1:  # per-item searches share passes among themselves (same aggregate)
+                    agg, oagg = (pvs.AGG_MIN, orc.AGG_MIN) if t % 4 == 1 else (pvs.AGG_MAX, orc.AGG_MAX)
+                    kg = 5 + rep
+                    gg, gv, gn = ix.search_groups(hq[q:q + 1], kg, pvs.COSINE, agg)
+                    eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, hq[q], groups, oagg, kg)
+                    if not (gn[0] == len(eg) and np.array_equal(gg[0, :gn[0]], eg) and np.array_equal(gv[0, :gn[0]].view(np.uint64), ev.view(np.uint64))):
+                        errors.append((t, rep, q, "groups", agg))
+                    continue
                 nb = 1 + (q % 5 == 0) + (q % 7 == 0)
                 k = (7, 20, 33)[(t + rep) % 3]
                 metric = pvs.L2 if t % 4 == 3 else pvs.COSINE
