@@ -67,49 +67,61 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
 // 4-pass MSB radix select on order-preserving u32 keys, one workgroup (256 threads) per query.
 // (Measured alternatives on MI355X: a bitonic sort in LDS was 4x slower, wave-aggregated LDS
 // atomics 1.7x slower; what matters is keeping the keys on chip across the four passes.)
+// One radix digit: after the histogram of the matching keys is complete (and a __syncthreads), find the bin that holds rank kk.
+// The inclusive prefix over the 256 bins is a shuffle scan inside each of the four waves plus their totals through LDS — two
+// workgroup barriers per digit where a Hillis-Steele scan through LDS took sixteen (this select is pure latency: 22 us -> see
+// DESIGN.md for a 16k-key query).  s_sel: 4 words, two per parity of `pass` (a thread may still be reading the previous digit's
+// answer when thread 0 resets the next one's).  Returns the bin (256: fewer than kk keys match) and updates kk.
+__device__ static inline uint32_t radix_pick(const uint32_t *hist, uint32_t *s_sel, int pass, uint32_t &kk) {
+    __shared__ uint32_t s_wave_total[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *sel = s_sel + 2 * (pass & 1);
+    const uint32_t own = hist[tid];
+    uint32_t v = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += up;
+    }
+    if (lane == 63) s_wave_total[wave] = v;
+    if (tid == 0) sel[0] = 256;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) v += s_wave_total[w];
+    const uint32_t before = v - own;
+    if (before < kk && v >= kk) {  // (at most one bin satisfies this)
+        sel[0] = (uint32_t)tid;
+        sel[1] = kk - before;
+    }
+    __syncthreads();
+    const uint32_t bin = sel[0];
+    if (bin < 256) kk = sel[1];
+    return bin;
+}
+
 template <typename KeyAt>
 __device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hist, uint32_t *s_sel, KeyAt key_at) {
     const int tid = threadIdx.x;
     uint32_t prefix = 0, mask = 0, kk = k;
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
+        hist[tid] = 0;  // (every thread has read the previous digit's histogram before radix_pick's first barrier)
         __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) {
             const uint32_t key = key_at(i);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        // inclusive prefix over the 256 bins (Hillis-Steele in LDS), then the bin holding rank kk
-        uint32_t v = hist[tid];
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t add = tid >= off ? hist[tid - off] : 0u;
-            __syncthreads();
-            v += add;
-            hist[tid] = v;
-            __syncthreads();
-        }
-        if (tid == 0) s_sel[0] = 256;  // 256 => fewer than kk keys match
-        __syncthreads();
-        const uint32_t before = tid ? hist[tid - 1] : 0u;
-        if (before < kk && v >= kk) {
-            s_sel[0] = (uint32_t)tid;
-            s_sel[1] = kk - before;
-        }
-        __syncthreads();
-        const uint32_t b = s_sel[0];
+        const uint32_t b = radix_pick(hist, s_sel, pass, kk);
         if (b >= 256) return 0xffffffffu;
-        kk = s_sel[1];
         prefix |= b << shift;
         mask |= 0xffu << shift;
-        __syncthreads();
     }
     return prefix;
 }
 
 __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_sel[2];
+    __shared__ uint32_t s_sel[4];
     const uint32_t q = blockIdx.x;
     if (q >= batch) {  // padding query: never admits a candidate
         if (threadIdx.x == 0) out[q] = -__builtin_inff();
@@ -139,31 +151,13 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
                     if (i < per_query && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                uint32_t val = hist[tid];
-                for (int off = 1; off < 256; off <<= 1) {
-                    const uint32_t add = tid >= off ? hist[tid - off] : 0u;
-                    __syncthreads();
-                    val += add;
-                    hist[tid] = val;
-                    __syncthreads();
-                }
-                if (tid == 0) s_sel[0] = 256;
-                __syncthreads();
-                const uint32_t before = tid ? hist[tid - 1] : 0u;
-                if (before < kk && val >= kk) {
-                    s_sel[0] = (uint32_t)tid;
-                    s_sel[1] = kk - before;
-                }
-                __syncthreads();
-                const uint32_t b = s_sel[0];
+                const uint32_t b = radix_pick(hist, s_sel, pass, kk);
                 if (b >= 256) {
                     ok = false;
                 } else {
-                    kk = s_sel[1];
                     prefix |= b << shift;
                     mask |= 0xffu << shift;
                 }
-                __syncthreads();
             }
             key = ok ? prefix : 0xffffffffu;
         } else {
@@ -327,37 +321,74 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         __shared__ uint32_t s_over;
         const uint32_t *sc = a.seg_cnt + (size_t)q * a.n_segments;
         const uint32_t per = (a.n_segments + 255) / 256;
+        // (this part of pass C is pure load latency: the counts and the first slot of every non-empty segment are requested in
+        //  independent batches — at most 4,096 segments = 16 per lane — instead of one dependent load after the other)
+        constexpr uint32_t PER_MAX = 16;
+        uint32_t cs[PER_MAX];
         uint32_t mine = 0;
         bool over = false;
-        for (uint32_t i = 0; i < per; i++) {
-            const uint32_t sg = tid * per + i;
-            const uint32_t c = sg < a.n_segments ? sc[sg] : 0u;
-            over |= c > PVS_SEG_CAP;
-            mine += c < PVS_SEG_CAP ? c : PVS_SEG_CAP;
+        if (per <= PER_MAX) {
+#pragma unroll
+            for (uint32_t i = 0; i < PER_MAX; i++) {
+                const uint32_t sg = tid * per + i;
+                cs[i] = (i < per && sg < a.n_segments) ? sc[sg] : 0u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < PER_MAX; i++) {
+                over |= cs[i] > PVS_SEG_CAP;
+                cs[i] = cs[i] < PVS_SEG_CAP ? cs[i] : PVS_SEG_CAP;
+                mine += cs[i];
+            }
+        } else {
+            for (uint32_t i = 0; i < per; i++) {
+                const uint32_t sg = tid * per + i;
+                const uint32_t c = sg < a.n_segments ? sc[sg] : 0u;
+                over |= c > PVS_SEG_CAP;
+                mine += c < PVS_SEG_CAP ? c : PVS_SEG_CAP;
+            }
         }
         if (tid == 0) s_over = 0;
-        s_part[tid] = mine;
         __syncthreads();
         if (over) s_over = 1;
+        // exclusive prefix of the 256 per-lane totals: shuffle scan inside each wave + the wave totals through LDS
         uint32_t v = mine;
-        for (int off = 1; off < 256; off <<= 1) {  // inclusive scan over the 256 partial sums
-            const uint32_t add = tid >= off ? s_part[tid - off] : 0u;
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)v, off, 64);
+                if (lane >= off) v += up;
+            }
+            if (lane == 63) s_part[wave] = v;
             __syncthreads();
-            v += add;
-            s_part[tid] = v;
-            __syncthreads();
+            for (int w = 0; w < wave; w++) v += s_part[w];
+            cnt = s_part[0] + s_part[1] + s_part[2] + s_part[3];
         }
-        cnt = s_part[255];
         uint32_t run = v - mine;
         const bool too_many = s_over != 0 || cnt > a.cand_cap;
         if (!too_many) {
-            for (uint32_t i = 0; i < per; i++) {
-                const uint32_t sg = tid * per + i;
-                if (sg >= a.n_segments) break;
-                const uint32_t c = sc[sg];
-                const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * PVS_SEG_CAP;
-                for (uint32_t e = 0; e < c; e++) flat[run + e] = src[e];
-                run += c;
+            if (per <= PER_MAX) {
+                uint2 first[PER_MAX];
+#pragma unroll
+                for (uint32_t i = 0; i < PER_MAX; i++)
+                    if (cs[i]) first[i] = a.seg[((size_t)(tid * per + i) * a.seg_queries + q) * PVS_SEG_CAP];
+#pragma unroll
+                for (uint32_t i = 0; i < PER_MAX; i++)
+                    if (cs[i]) {
+                        flat[run] = first[i];
+                        const uint2 *src = a.seg + ((size_t)(tid * per + i) * a.seg_queries + q) * PVS_SEG_CAP;
+                        for (uint32_t e = 1; e < cs[i]; e++) flat[run + e] = src[e];
+                        run += cs[i];
+                    }
+            } else {
+                for (uint32_t i = 0; i < per; i++) {
+                    const uint32_t sg = tid * per + i;
+                    if (sg >= a.n_segments) break;
+                    const uint32_t c = sc[sg];
+                    const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * PVS_SEG_CAP;
+                    for (uint32_t e = 0; e < c; e++) flat[run + e] = src[e];
+                    run += c;
+                }
             }
         } else {
             cnt = a.cand_cap + 1;  // a segment or the list overflowed: the dense path answers this query
