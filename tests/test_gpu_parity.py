@@ -975,10 +975,12 @@ def test_non_finite_components(pvs, dtype):
     ix.close()
 
 
-@pytest.mark.parametrize("dtype,n,b", [("i8", 10_000_000, 128), ("f16", 1_000_000, 32), ("f32", 1_000_000, 8)])
+@pytest.mark.parametrize("dtype,n,b", [("i8", 10_000_000, 128), ("f16", 1_000_000, 32), ("f32", 1_000_000, 8), ("i8", 10_000_000, 256),
+                                       ("f16", 10_000_000, 1), ("f32", 10_000_000, 128)])
 def test_full_size_properties(pvs, dtype, n, b):
-    """BASELINE configs[2] (10M x 768 int8, 128 queries) and configs[1] (1M x 768 f16, 32 queries; also as f32, the
-    reference's exact mode) at full size, k = 100, checked through size-independent
+    """BASELINE configs[2] (10M x 768 int8, 128 queries; also 256 queries = one pass of the 8-wave instance), configs[1]
+    (1M x 768 f16, 32 queries; also as f32, the reference's exact mode) and the north star's single-query 10M x 768 f16
+    shape at full size, k = 100, checked through size-independent
     properties: pages sorted by (distance, id), ids unique and in range, full pages, two runs bit-identical, the
     filter path and the dense path (two different algorithms on the device) agree on a few queries, the page is a
     prefix of the k = 400 page, every returned distance equals the dense `d` column at that row, and row shards
