@@ -188,6 +188,11 @@ void ctx_release(SearchCtx &c) {
     hipFree(c.d_seg);
     hipFree(c.d_seg_cnt);
     hipFree(c.d_cand);
+    hipFree(c.d_fin_ub);
+    hipFree(c.d_fin_surv);
+    hipFree(c.d_fin_sort);
+    c.d_fin_ub = c.d_fin_surv = nullptr;
+    c.d_fin_sort = nullptr;
     hipFree(c.d_need_dense);
     if (c.h_need_dense) hipHostFree(c.h_need_dense);
     hipFree(c.d_out_ids);
@@ -232,6 +237,12 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(hipMalloc((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
         HIP_TRY(hipMalloc((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS));
         HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+    }
+    static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;  // tests: the LDS-light pass C on every search
+    if ((ix->multi_stream || force_light) && ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan)
+        HIP_TRY(hipMalloc((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+        HIP_TRY(hipMalloc((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
+        HIP_TRY(hipMalloc((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
     }
     if (batch > c.flags_cap) {
         hipFree(c.d_need_dense);

@@ -44,6 +44,8 @@ struct SearchCtx {
     uint2 *d_seg = nullptr;          // [PVS_SEG_PAIRS][PVS_SEG_CAP] candidate segments of the filter scan
     uint32_t *d_seg_cnt = nullptr;   // [PVS_SEG_PAIRS] their fill counts
     uint2 *d_cand = nullptr;      // [MAX_BATCH][CAND_CAP]
+    uint32_t *d_fin_ub = nullptr, *d_fin_surv = nullptr;  // pass C's global work area (FinalizeArgs.w_*), allocated in multi-stream mode
+    unsigned long long *d_fin_sort = nullptr;
     uint32_t *d_need_dense = nullptr;  // [total batch capacity]
     uint32_t *h_need_dense = nullptr;  // pinned
     uint32_t flags_cap = 0;

@@ -94,6 +94,12 @@ struct FinalizeArgs {
     uint32_t *out_count;    // [batch]
     uint32_t *need_dense;   // [batch] 1 = this query must be answered by the dense path
     uint32_t *cand_seen = nullptr;  // [batch] (optional) candidates the scan emitted for the query (pvs_stats.last_candidates)
+    // Optional global-memory work area: with it (int8 rows) pass C keeps its bound keys, survivor list and large sorts in HBM/L2
+    // and needs ~6 KB of LDS instead of ~104 KB, so it can run NEXT TO the scan of another search (k_scan's two workgroups per
+    // CU leave 7.8 KB of LDS free).  Used when an index runs its searches on several streams.
+    uint32_t *w_ub = nullptr;             // [batch][cand_cap]
+    uint32_t *w_surv = nullptr;           // [batch][PVS_SURV_CAP]
+    unsigned long long *w_sort = nullptr; // [batch][PVS_SURV_CAP]
 };
 hipError_t pvs_launch_finalize(const FinalizeArgs &a, hipStream_t s);
 

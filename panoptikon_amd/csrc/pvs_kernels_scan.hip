@@ -192,6 +192,8 @@ struct FinK {
     uint64_t n_rows;
     uint32_t stride, dim, cand_cap, k, n_segments, seg_queries;
     int metric;
+    uint32_t *w_ub, *w_surv;       // LIGHT: global work area (FinalizeArgs.w_*)
+    unsigned long long *w_sort;
 };
 
 constexpr int FIN_QMAX = 8192;  // bytes of LDS for the query vector the rerank reads (dims beyond that read it from global memory)
@@ -291,16 +293,22 @@ __device__ static inline float rerank_distance(const uint8_t *rows, uint32_t str
     return l2 ? ref_l2_finish(acc) : ref_cosine_finish(acc, aa, bb);
 }
 
-template <int DT>
+// LIGHT (int8 rows, FinalizeArgs.w_*): bound keys, survivor list and sorts of more than 512 records live in global memory (they
+// stay in L2: a few KB per query), LDS holds the histogram and a 512-record sort buffer — ~6 KB, so the workgroup fits beside
+// k_scan's two workgroups on a CU and pass C of one search runs under the scan of the next one (several streams per index).
+constexpr uint32_t FIN_SMALL_SORT = 512;
+template <int DT, bool LIGHT>
 __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *const s_ub = (uint32_t *)smem;                        // [CAND_CAP] sort keys of upper bounds
-    uint32_t *const s_surv = (uint32_t *)(smem + PVS_CAND_CAP * 4);  // [SURV_CAP] candidate slots
-    uint32_t *const s_misc = s_surv + PVS_SURV_CAP;                  // [0]=survivor count, [2..3] select scratch
-    unsigned long long *const s_sort = (unsigned long long *)smem;   // overlays s_ub after the select
     __shared__ uint32_t hist[256];
-
+    __shared__ uint32_t s_misc_light[LIGHT ? 16 : 1];
+    __shared__ unsigned long long s_sort_light[LIGHT ? FIN_SMALL_SORT : 1];
     const uint32_t q = blockIdx.x;
+    uint32_t *const s_ub = LIGHT ? a.w_ub + (size_t)q * a.cand_cap : (uint32_t *)smem;                            // [CAND_CAP] sort keys of upper bounds
+    uint32_t *const s_surv = LIGHT ? a.w_surv + (size_t)q * PVS_SURV_CAP : (uint32_t *)(smem + PVS_CAND_CAP * 4);  // [SURV_CAP] candidate slots
+    uint32_t *const s_misc = LIGHT ? s_misc_light : (uint32_t *)(smem + PVS_CAND_CAP * 4) + PVS_SURV_CAP;          // [0]=survivor count, [2..5] select scratch
+    unsigned long long *s_sort = LIGHT ? s_sort_light : (unsigned long long *)smem;  // !LIGHT: overlays s_ub after the select
+
     const int tid = threadIdx.x;
 #ifdef PVS_FIN_PROF  // tuning build: wall clock (100 MHz s_memrealtime) at the phase boundaries of workgroup 0
     unsigned long long fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -443,10 +451,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     uint32_t m2 = 1;
     while (m2 < m) m2 <<= 1;
     __syncthreads();  // s_ub is dead from here: s_sort overlays it
+    if (LIGHT && m2 > FIN_SMALL_SORT) s_sort = a.w_sort + (size_t)q * PVS_SURV_CAP;  // (many near-ties or a large k: sort in global memory)
     const uint8_t *qe = (const uint8_t *)a.qexact + (size_t)q * a.dim * (DT == PVS_I8 ? 1 : 4);
     // the query of this workgroup, zero-padded to a whole 16-byte chunk, in LDS beyond everything s_sort overlays (rerank_distance)
     uint8_t *const s_q = smem + PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
-    {
+    if constexpr (!LIGHT) {
         const uint32_t qbytes = a.dim * (DT == PVS_I8 ? 1u : 4u), padded = (qbytes + 63u) & ~63u;
         if constexpr (DT == PVS_I8) {
             for (uint32_t i = tid; i < padded; i += 256) s_q[i] = i < qbytes ? qe[i] : (uint8_t)0;
@@ -482,7 +491,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     }
                 }
             }
-            if (!closed) d = rerank_distance<DT>(a.rows, a.stride, row, s_q, (int)a.dim, a.metric, aa, qi.bb);
+            if (!closed) {  // (LIGHT keeps no query in LDS: the generic in-order form, rare — sums beyond 2^24)
+                if constexpr (LIGHT)
+                    d = exact_distance<DT>(a.rows, a.stride, row, qe, (int)a.dim, a.metric, aa, qi.bb);
+                else
+                    d = rerank_distance<DT>(a.rows, a.stride, row, s_q, (int)a.dim, a.metric, aa, qi.bb);
+            }
             v = ((unsigned long long)f32_sort_key(d) << 32) | row;
         }
         s_sort[i] = v;
@@ -547,6 +561,9 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.seg = f.seg;
     k.seg_cnt = f.seg_cnt;
     k.n_segments = f.n_segments;
+    k.w_ub = f.w_ub;
+    k.w_surv = f.w_surv;
+    k.w_sort = f.w_sort;
     k.seg_queries = f.seg_queries;
     k.cand = f.cand;
     k.out_ids = f.out_ids;
@@ -562,21 +579,23 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.metric = f.metric;
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_finalize<PVS_I8>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)k_finalize<PVS_I8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_finalize<PVS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
+            e = hipFuncSetAttribute((const void *)k_finalize<PVS_F16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_finalize<PVS_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
+            e = hipFuncSetAttribute((const void *)k_finalize<PVS_F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
     if ((((uint64_t)f.dim * (f.dtype == PVS_I8 ? 1u : 4u)) + 63u & ~63ull) > (uint64_t)FIN_QMAX) return hipErrorInvalidValue;  // (no scan instance is that wide)
-    if (f.dtype == PVS_I8)
-        hipLaunchKernelGGL(k_finalize<PVS_I8>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
+    if (f.dtype == PVS_I8 && f.w_ub && f.w_surv && f.w_sort)
+        hipLaunchKernelGGL((k_finalize<PVS_I8, true>), dim3(f.batch), dim3(256), 0, s, k);
+    else if (f.dtype == PVS_I8)
+        hipLaunchKernelGGL((k_finalize<PVS_I8, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
     else if (f.dtype == PVS_F16)
-        hipLaunchKernelGGL(k_finalize<PVS_F16>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
+        hipLaunchKernelGGL((k_finalize<PVS_F16, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
     else
-        hipLaunchKernelGGL(k_finalize<PVS_F32>, dim3(f.batch), dim3(256), FIN_LDS, s, k);
+        hipLaunchKernelGGL((k_finalize<PVS_F32, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
     return hipGetLastError();
 }
 

@@ -181,6 +181,13 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         f.n_segments = a.n_segments;
         f.seg_queries = batch_pad;
         f.cand = c.d_cand;
+        static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
+        static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;
+        if ((ix->multi_stream || force_light) && c.d_fin_ub && !no_light) {
+            f.w_ub = c.d_fin_ub;
+            f.w_surv = c.d_fin_surv;
+            f.w_sort = c.d_fin_sort;
+        }
         f.cand_cap = PVS_CAND_CAP;
         f.batch = nb;
         f.k = k;

@@ -421,3 +421,44 @@ def test_coalesced_single_query_callers_get_their_own_pages(pvs):
         assert np.array_equal(gi, exp[(pvs.COSINE, 7)][0][:1]) and ix.coalescing_stats()[0] == calls
     finally:
         ix.close()
+
+
+def test_pass_c_in_global_memory_on_several_streams(pvs):
+    """With several streams per index, int8 indexes run pass C out of a global-memory work area (~6 KB of LDS, so that it fits
+    beside another search's scan): small and large k (the 512-record LDS sort and the global-memory sort), duplicates (ties by
+    id), both metrics, several searches in flight — pages bit-identical to the one-stream form and to the oracle."""
+    dim = 384
+    rows = orc.synth_rows(91, 0, 60_000, dim)
+    rows[40_000:40_050] = rows[7]  # 51 equal rows: a tie block inside every page
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    queries = orc.synth_rows(0x5EED0077, 0, 40, dim)
+    queries[3] = rows[7]
+    hq = orc.quantize_int8(queries, scale)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows)
+    try:
+        for k in (10, 100, 700, 2000):
+            for metric, om in ((pvs.COSINE, orc.COSINE), (pvs.L2, orc.L2)):
+                ei, ed = orc.search(orc.I8, om, codes, hq, k, threads=8)
+                ix.set_streams(1)
+                a = ix.search(hq, k, metric)
+                ix.set_streams(2)
+                b = ix.search(hq, k, metric)
+                for got in (a, b):
+                    assert np.array_equal(got[0], ei) and np.array_equal(got[1].view(np.uint32), ed.view(np.uint32)), (k, metric)
+        # four searches in flight on their own streams
+        dq = pvs.DeviceBuffer.from_numpy(hq, 0)
+        k = 100
+        ei, ed = orc.search(orc.I8, orc.COSINE, codes, hq, k, threads=8)
+        outs = [(pvs.DeviceBuffer(40 * k * 8, 0), pvs.DeviceBuffer(40 * k * 4, 0), pvs.DeviceBuffer(40 * 4, 0)) for _ in range(4)]
+        from panoptikon_amd import _lib as L
+        tickets = [ix.search_device(dq, L.I8, 40, k, pvs.COSINE, *o) for o in outs]
+        for t, o in zip(tickets, outs):
+            ix.wait(t)
+            assert np.array_equal(o[0].to_numpy(np.int64, (40, k)), ei)
+            assert np.array_equal(o[1].to_numpy(np.float32, (40, k)).view(np.uint32), ed.view(np.uint32))
+    finally:
+        ix.set_streams(1)
+        ix.close()
