@@ -213,6 +213,17 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
 /* pvs_search under apply_sort_bounds (pql/builder.rs:781-815: `WHERE order_rank > gt AND order_rank < lt` with order_rank =
  * the distance, a SQL REAL): page 1 of the rows whose distance lies inside the bounds; have_gt / have_lt select them.
  * Rows with a NULL distance never pass a bound.  out_count[q] = min(k, rows inside the bounds). */
+/* Pagination (pql/builder.rs:578-582: `LIMIT ? OFFSET ?` behind the final ORDER BY; api/search.rs:51,777-783 executes
+ * LIMIT = max(page_size, prefetch_rows <= 4096) at OFFSET (page-1)*page_size): entries [offset, offset+limit) of the same
+ * ordering pvs_search / pvs_search_groups return — (distance asc, id asc, NULL last) resp. (value asc, group id asc, NULL
+ * last).  out_* hold `limit` entries per query; out_count[q] = entries actually present (0 when the offset is past the end).
+ * One pass at k = offset + limit (the filter scan serves k <= 4096, the dense path anything larger). */
+pvs_status pvs_search_page(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint64_t offset,
+                           uint32_t limit, pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+pvs_status pvs_search_groups_page(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint64_t offset,
+                                  uint32_t limit, pvs_metric metric, pvs_agg agg, const float *row_weights,
+                                  int64_t *out_groups, double *out_values, uint32_t *out_count);
+
 /* Request coalescing for the host-buffer entry point (pvs_search).  The reference host answers one query per SQL statement
  * from a pool of up to 16 read connections (db/connection.rs:235,320-357); a corpus pass costs the same for one query as for
  * 32, so callers that arrive within `window_us` of each other are answered by ONE pass: the first one waits out the window

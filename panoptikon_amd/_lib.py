@@ -91,6 +91,8 @@ SYMBOLS = {
     "pvs_index_set_profiling": (_i32, [_vp, _i32]),
     "pvs_index_get_profile": (_i32, [_vp, C.POINTER(Profile), _i32]),
     "pvs_search": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_search_page": (_i32, [_vp, _vp, _i32, _u32, C.c_uint64, _u32, _i32, _vp, _vp, _vp]),
+    "pvs_search_groups_page": (_i32, [_vp, _vp, _i32, _u32, C.c_uint64, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_index_set_coalescing": (_i32, [_vp, _u32, _u32]),
     "pvs_index_coalescing_stats": (_i32, [_vp, _vp, _vp]),
     "pvs_search_bounded": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, C.c_double, _i32, C.c_double, _vp, _vp, _vp]),

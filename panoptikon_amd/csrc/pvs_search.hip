@@ -462,6 +462,43 @@ PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype q
     return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count);
 }
 
+// ---- pagination: one search at k = offset + limit, the tail handed out
+template <typename V, typename Run>
+static pvs_status search_page_impl(uint32_t batch, uint64_t offset, uint32_t limit, int64_t *out_a, V *out_b, uint32_t *out_count, V nan, Run &&run) {
+    if (!out_a || !out_b || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (limit < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    if (offset + limit > 0x7fffffffull) return pvs_fail(PVS_ERR_INVALID_ARG, "offset + limit too large");
+    const uint32_t k = (uint32_t)(offset + limit);
+    std::vector<int64_t> a((size_t)batch * k);
+    std::vector<V> b((size_t)batch * k);
+    std::vector<uint32_t> c(batch);
+    PVS_TRY(run(k, a.data(), b.data(), c.data()));
+    for (uint32_t q = 0; q < batch; q++) {
+        const uint32_t have = c[q] > offset ? (uint32_t)std::min<uint64_t>(c[q] - offset, limit) : 0u;
+        for (uint32_t i = 0; i < limit; i++) {
+            out_a[(size_t)q * limit + i] = i < have ? a[(size_t)q * k + offset + i] : -1;
+            out_b[(size_t)q * limit + i] = i < have ? b[(size_t)q * k + offset + i] : nan;
+        }
+        out_count[q] = have;
+    }
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_search_page(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint64_t offset, uint32_t limit,
+                                      pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (offset == 0) return pvs_search(ix, queries, qdtype, batch, limit, metric, out_ids, out_dist, out_count);
+    return search_page_impl<float>(batch, offset, limit, out_ids, out_dist, out_count, __builtin_nanf(""), [&](uint32_t k, int64_t *a, float *b, uint32_t *c) {
+        return pvs_search(ix, queries, qdtype, batch, k, metric, a, b, c);
+    });
+}
+PVS_EXPORT pvs_status pvs_search_groups_page(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint64_t offset, uint32_t limit,
+                                             pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values,
+                                             uint32_t *out_count) {
+    if (offset == 0) return pvs_search_groups(ix, queries, qdtype, batch, limit, metric, agg, row_weights, out_groups, out_values, out_count);
+    return search_page_impl<double>(batch, offset, limit, out_groups, out_values, out_count, __builtin_nan(""), [&](uint32_t k, int64_t *a, double *b, uint32_t *c) {
+        return pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, a, b, c);
+    });
+}
+
 PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                           pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
                                           float *out_dist, uint32_t *out_count) {

@@ -167,6 +167,26 @@ class VectorIndex:
         L.check(L.lib().pvs_search(self._h, _ptr(q), qd, b, k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
 
+    def search_page(self, queries, offset: int, limit: int, metric: int = L.COSINE):
+        """Entries [offset, offset + limit) of the search ordering (LIMIT ? OFFSET ?, pql/builder.rs:578-582)."""
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        ids = np.empty((b, max(limit, 1)), np.int64)
+        dist = np.empty((b, max(limit, 1)), np.float32)
+        cnt = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_page(self._h, _ptr(q), qd, b, int(offset), int(limit), metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
+    def search_groups_page(self, queries, offset: int, limit: int, metric: int = L.COSINE, agg: int = L.AGG_MIN, row_weights=None):
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        w = None if row_weights is None else np.ascontiguousarray(row_weights, np.float32)
+        og = np.empty((b, max(limit, 1)), np.int64)
+        ov = np.empty((b, max(limit, 1)), np.float64)
+        oc = np.zeros(b, np.uint32)
+        L.check(L.lib().pvs_search_groups_page(self._h, _ptr(q), qd, b, int(offset), int(limit), metric, agg, _ptr(w), _ptr(og), _ptr(ov), _ptr(oc)))
+        return og, ov, oc
+
     def search_bounded(self, queries, k: int, metric: int = L.COSINE, gt=None, lt=None):
         """pvs_search restricted to rows with gt < distance < lt (apply_sort_bounds, builder.rs:781-815)."""
         q, qd = self._queries(queries)

@@ -1402,3 +1402,40 @@ def test_batched_dense_select_on_massive_ties_and_nulls(pvs, dtype):
         ei, ed = orc.topk(d[i][cand], 64, ids=cand.astype(np.int64))
         assert gc[i] == len(cand) and np.array_equal(gi[i, : len(ei)], ei)
     ix.close()
+
+
+def test_pagination_is_a_window_of_the_same_ordering(pvs):
+    """pvs_search_page / pvs_search_groups_page (LIMIT ? OFFSET ?, pql/builder.rs:578-582): every page is the matching window of
+    the oracle's ordering over the whole corpus — across the filter-path / dense-path boundary (k > 4096), past the end, with a
+    tie block straddling a page boundary."""
+    dim = 192
+    rows = unit_rows(21, 9000, dim)
+    rows[100:140] = rows[50]  # 41 equal rows: ties broken by id across page boundaries
+    ix = make_index(pvs, pvs.F32, rows, None)
+    groups = np.arange(len(rows), dtype=np.int64) // 4
+    ixg = pvs.VectorIndex(pvs.F32, dim)
+    ixg.add(rows, group_ids=groups)
+    q = orc.synth_rows(0x5EED0123, 0, 3, dim)
+    q[1] = rows[50]
+    try:
+        ei, ed = orc.search(orc.F32, orc.COSINE, rows, q, len(rows))
+        for offset, limit in ((0, 25), (25, 25), (30, 20), (4090, 50), (8990, 25), (9000, 10), (20000, 5)):
+            gi, gd, gc = ix.search_page(q, offset, limit, pvs.COSINE)
+            have = max(0, min(len(rows) - offset, limit))
+            assert gc.tolist() == [have] * 3, (offset, limit, gc)
+            assert np.array_equal(gi[:, :have], ei[:, offset:offset + have]), (offset, limit)
+            assert np.array_equal(gd[:, :have].view(np.uint32), ed[:, offset:offset + have].view(np.uint32))
+            assert (gi[:, have:] == -1).all() and np.isnan(gd[:, have:]).all()
+        n_groups = len(rows) // 4
+        for qi in range(2):
+            eg, ev = orc.search_groups(orc.F32, orc.L2, rows, q[qi], groups, orc.AGG_MIN, n_groups)
+            for offset, limit in ((0, 10), (10, 10), (2240, 20)):
+                gg, gv, gn = ixg.search_groups_page(q[qi:qi + 1], offset, limit, pvs.L2, pvs.AGG_MIN)
+                have = max(0, min(n_groups - offset, limit))
+                assert gn[0] == have and np.array_equal(gg[0, :have], eg[offset:offset + have])
+                assert np.array_equal(gv[0, :have].view(np.uint64), ev[offset:offset + have].view(np.uint64))
+        with pytest.raises(Exception):
+            ix.search_page(q, 5, 0, pvs.COSINE)
+    finally:
+        ix.close()
+        ixg.close()
