@@ -135,7 +135,15 @@ struct Geo {
     static constexpr int RT = WAVES / QW;        // row sub-tiles per workgroup
     static constexpr int SLAB_ROWS = 32 * RT;
     static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
-    static constexpr int PPW = 8 * RT / WAVES;  // 1-KiB DMA pieces per wave and slab
+    // Tuning switch PVS_QG8_OLD_WAVES_DMA: in the 8-wave instances only the OLDER wave of every SIMD (waves 0-3, which otherwise sit
+    // ~800 cycles at the per-tile barrier) issues LDS-DMA, the younger waves none.  Measured 2.095 / 1.897 ms (k = 100 / 1) against
+    // 2.063 / 1.893 with every wave issuing its share: the DMA issue is not on the critical path either.
+#ifdef PVS_QG8_OLD_WAVES_DMA
+    static constexpr int DMAW = QG == 8 ? 4 : WAVES;   // waves that issue DMA
+#else
+    static constexpr int DMAW = WAVES;
+#endif
+    static constexpr int PPW = 8 * RT / DMAW;  // 1-KiB DMA pieces per issuing wave and slab
     static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
     // 256 queries (one workgroup of 8 waves per CU): the waves hand chunks to each other through arrival counters instead of
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
     using A = Acc<DT>;
     using elem_t = typename A::elem;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
-                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, GPW = G::GPW, QW = G::QW, NCN = G::NCN;
+                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, GPW = G::GPW, QW = G::QW, NCN = G::NCN, DMAW = G::DMAW;
     constexpr bool COS = METRIC == PVS_COSINE;
     constexpr bool PRETEST = MODE == 1 && DT != PVS_F32;  // (f32 rows carry a per-row power-of-two scale in their sums)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -284,6 +292,9 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             voff[e] = (uint32_t)(r >> 5) * (32u * a.stride) + (uint32_t)(r & 31) * 256u + (uint32_t)lane * 16u;
         }
         const uint32_t nvoff = (uint32_t)(rt * PVS_AUX_REC + lane) * 4u;  // this wave's tile record: 32 row scalars, then the tile's extremes
+        const bool dma_wave = wave < DMAW;   // (wave-uniform) does this wave issue DMA at all
+        const int rec_wave = wave % DMAW;    // whose copy of the tile record this wave reads (DMAW < WAVES only with RT = 1: one record)
+        static_assert(DMAW == WAVES || RT == 1, "record sharing assumes one row sub-tile per workgroup");
         // A-fragment LDS byte offsets of this lane inside a slab
         const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
         const uint32_t jx = (uint32_t)(j & 15);
@@ -335,6 +346,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #ifdef PVS_ABL_NODMA
             return;
 #endif
+            if (!dma_wave) return;
             if (part < DMA_PARTS - 1) {
                 const int sb = part / PPW, e = part % PPW;
                 dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 for (int r = 0; r < 16; r++) xh[r] = __builtin_nanf("");
                 return;
             }
-            const float *nl = (const float *)(normring + p_nslot * (WAVES * 256) + wave * 256);
+            const float *nl = (const float *)(normring + p_nslot * (WAVES * 256) + rec_wave * 256);
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 const float4 v = *(const float4 *)(nl + 8 * g4 + 4 * h);
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     // the tile's rows with a usable norm, t1 = the max).  Tile "-1": NaN bounds, nothing passes.
                     e.t0 = e.t1 = __builtin_nanf("");
                     if (p_nslot >= 0) {
-                        const float2 tmm = *(const float2 *)((const float *)(normring + p_nslot * (WAVES * 256) + wave * 256) + 32);
+                        const float2 tmm = *(const float2 *)((const float *)(normring + p_nslot * (WAVES * 256) + rec_wave * 256) + 32);
                         e.t0 = tmm.x;
                         e.t1 = tmm.y;
                     }
@@ -657,7 +669,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
                 float row_scale = 1.0f;  // f32 rows: 2^e of this lane's A row (its scalar sits in this chunk's slot)
                 if constexpr (DT == PVS_F32) {
-                    const float ax = ((const float *)(normring + c_nslot * (WAVES * 256) + wave * 256))[j];
+                    const float ax = ((const float *)(normring + c_nslot * (WAVES * 256) + rec_wave * 256))[j];
                     row_scale = __builtin_ldexpf(1.0f, f32_row_exp<COS>(ax));
                 }
                 (void)row_scale;
