@@ -57,6 +57,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef PVS_NC_SPB1
+#define PVS_NC_SPB1 8
+#endif
 #ifndef PVS_PF
 #define PVS_PF 4                  // A fragments read ahead of the MFMA that consumes them (tuning experiments override it)
 #endif
@@ -144,7 +147,11 @@ struct Geo {
     static constexpr int DMAW = WAVES;
 #endif
     static constexpr int PPW = 8 * RT / DMAW;  // 1-KiB DMA pieces per issuing wave and slab
+#ifdef PVS_B128_SPB1  // tuning: 128 queries with one k-slab per chunk (a deeper DMA queue, three barriers per tile)
+    static constexpr int SPB = (RT > 1 || QG == 4) ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
+#else
     static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
+#endif
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
     // 256 queries (one workgroup of 8 waves per CU): the waves hand chunks to each other through arrival counters instead of
     // a barrier, with one chunk of SLACK — the chunk being refilled is the one consumed two steps ago, so a wave that is
@@ -160,7 +167,7 @@ struct Geo {
         while (nc > 3 && nc * SPB * SLAB_BYTES + (2 + (nc - 1 - SLACK + CPT - 1) / CPT) * WAVES * 256 + 128 > 160 * 1024) nc--;
         return nc;
     }
-    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8)));  // chunks in the ring
+    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : PVS_NC_SPB1)));  // chunks in the ring
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
     // chunks in flight: the rest of the ring, but no more than ~96 KiB for the 8-wave instances (a fifth 24-KiB tile in
     // flight measured 2.08 ms against 1.99 ms with four at 10M x 768 x 256 queries)
@@ -736,8 +743,12 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                             acc[0] = A::mfma(af[t], qf[0][ck * NF + t], acc[0]);
                     }
                     if (t + 1 < NF) narrow(t + 1);
+#ifdef PVS_DMA_FRONT  // tuning: the chunk's DMA pieces right behind the first MFMAs instead of spread over the whole chunk
+                    if (t < DMA_PARTS) issue_part(t);
+#else
 #pragma unroll
                     for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
+#endif
                     if (ck == 0) {
 #pragma unroll
                         for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, e, pv);
