@@ -57,6 +57,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef PVS_NC_SPB3
+#define PVS_NC_SPB3 3   // (tuning: 2 = a two-chunk ring, three workgroups per CU at 128 queries — with PVS_SCAN_WG_PER_CU=3 on the host)
+#endif
 #ifndef PVS_NC_SPB1
 #define PVS_NC_SPB1 8
 #endif
@@ -167,7 +170,7 @@ struct Geo {
         while (nc > 3 && nc * SPB * SLAB_BYTES + (2 + (nc - 1 - SLACK + CPT - 1) / CPT) * WAVES * 256 + 128 > 160 * 1024) nc--;
         return nc;
     }
-    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : PVS_NC_SPB1)));  // chunks in the ring
+    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? PVS_NC_SPB3 : (SPB == 2 ? 4 : PVS_NC_SPB1)));  // chunks in the ring
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
     // chunks in flight: the rest of the ring, but no more than ~96 KiB for the 8-wave instances (a fifth 24-KiB tile in
     // flight measured 2.08 ms against 1.99 ms with four at 10M x 768 x 256 queries)

@@ -158,7 +158,8 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
             a.qgroups = 4;
             a.qsplit = 2;
         }
-        const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
+        static const uint32_t per_cu_env = getenv("PVS_SCAN_WG_PER_CU") ? (uint32_t)atoi(getenv("PVS_SCAN_WG_PER_CU")) : 0;  // tuning
+        const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : (per_cu_env && a.qgroups == 4 ? per_cu_env : 2);
         a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu / a.qsplit, PVS_SEG_PAIRS / (batch_pad * rt * 2)});
         a.n_segments = a.grid * rt * 2;
         span_begin(ix, c, 1, ix->n);
