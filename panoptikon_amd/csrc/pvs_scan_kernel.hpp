@@ -690,7 +690,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 //   step t:  LDS read of fragment t+PF | MFMA t (one per group) | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
-                constexpr int NF = SPB * SPS, PF = ((GPW == 2 || QG == 8) ? PVS_PF : 4);
+                constexpr int NF = SPB * SPS, PF = ((GPW == 2 || QG >= 4) ? PVS_PF : 4);
                 v4i af[NF];
                 v4i raw[DT == PVS_F32 ? NF : 1][2];  // f32: the two 16-B pieces of a step, before narrowing
                 (void)raw;
