@@ -1,0 +1,124 @@
+// Probe for a barrier-free filter scan: every wave owns its stream of 32-row tiles, the corpus is stored
+// "fragment-linear" (one contiguous KiB per MFMA step: 64 lanes x 16 B, lane l = h*32 + row), A fragments go straight from HBM into
+// registers (double-buffered: the next tile is in flight while the current one is multiplied), the B fragments of 128 queries sit
+// read-only in LDS (96 KB), four accumulator chains per wave, no s_barrier after the prologue.  The epilogue is the v_max3 fold
+// of the pass-B pre-test.  What it answers: how fast does this structure stream 10M x 768 int8 rows with the full MFMA work?
+// Build: hipcc --offload-arch=gfx950 -O3 -o wave_private_scan wave_private_scan.hip ; run: ./wave_private_scan [rows] [waves_per_simd]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) v4i *gptr;
+
+constexpr int STEPS = 24;        // 768 B per row / 32 B per MFMA step and half-wave
+constexpr int TILE_BYTES = 32 * 768;
+constexpr int QGROUPS = 4;       // 128 queries
+
+template <int WPS>  // waves per SIMD the launch bounds ask for
+__global__ __launch_bounds__(256, WPS) void k_probe(const uint8_t *rows, const uint8_t *qfrag, uint32_t n_tiles, int *out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [QGROUPS][STEPS][64][16] B fragments
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < QGROUPS * STEPS * 64; i += 256) ((v4i *)smem)[i] = ((const v4i *)qfrag)[i];
+    __syncthreads();
+    const uint32_t wid = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const v4i *bl = (const v4i *)smem + lane;
+    auto load_tile = [&](uint32_t t, v4i(&a)[STEPS]) {
+        gptr p = (gptr)(uintptr_t)(rows + (size_t)t * TILE_BYTES) + lane;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) a[s] = __builtin_nontemporal_load(p + s * 64);
+    };
+    int best = (int)0x80000000;
+    v4i bufA[STEPS], bufB[STEPS];
+    auto multiply = [&](const v4i(&a)[STEPS]) {
+        v16i acc[QGROUPS];
+#pragma unroll
+        for (int g = 0; g < QGROUPS; g++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[g][r] = 0;
+        v4i b[2][QGROUPS];
+#pragma unroll
+        for (int g = 0; g < QGROUPS; g++) b[0][g] = bl[(g * STEPS + 0) * 64];
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            if (s + 1 < STEPS) {
+#pragma unroll
+                for (int g = 0; g < QGROUPS; g++) b[(s + 1) & 1][g] = bl[(g * STEPS + s + 1) * 64];
+            }
+#pragma unroll
+            for (int g = 0; g < QGROUPS; g++) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s & 1][g], acc[g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < QGROUPS; g++)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) best = max(best, max(acc[g][r], acc[g][r + 1]));
+    };
+    uint32_t t = wid;
+    if (t < n_tiles) load_tile(t, bufA);
+    while (t < n_tiles) {
+        if (t + nw < n_tiles) load_tile(t + nw, bufB);
+        multiply(bufA);
+        t += nw;
+        if (t >= n_tiles) break;
+        if (t + nw < n_tiles) load_tile(t + nw, bufA);
+        multiply(bufB);
+        t += nw;
+    }
+    if (best == 123456789) out[wid] = best;  // (keeps the work alive)
+}
+
+int main(int argc, char **argv) {
+    const uint64_t n_rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 10000000ull;
+    const int wps = argc > 2 ? atoi(argv[2]) : 1;
+    const uint32_t n_tiles = (uint32_t)(n_rows / 32);
+    const size_t bytes = (size_t)n_tiles * TILE_BYTES;
+    uint8_t *d_rows, *d_q;
+    int *d_out;
+    hipMalloc(&d_rows, bytes);
+    hipMemset(d_rows, 1, bytes);
+    hipMalloc(&d_q, QGROUPS * STEPS * 64 * 16);
+    hipMemset(d_q, 2, QGROUPS * STEPS * 64 * 16);
+    hipMalloc(&d_out, 4 * 1024 * 16);
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int lds = QGROUPS * STEPS * 64 * 16;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int wg_per_cu = 1; wg_per_cu <= (wps >= 2 ? 1 : 1); wg_per_cu++) {
+        const int grid = prop.multiProcessorCount * wg_per_cu;
+        auto launch = [&]() {
+            if (wps == 1) {
+                hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(k_probe<1>, dim3(grid), dim3(256), lds, 0, d_rows, d_q, n_tiles, d_out);
+            } else {
+                hipFuncSetAttribute((const void *)k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(k_probe<2>, dim3(grid), dim3(256), lds, 0, d_rows, d_q, n_tiles, d_out);
+            }
+        };
+        for (int i = 0; i < 3; i++) launch();
+        hipDeviceSynchronize();
+        float best_ms = 1e9f, sum = 0;
+        const int reps = 10;
+        for (int i = 0; i < reps; i++) {
+            hipEventRecord(e0, 0);
+            launch();
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            best_ms = ms < best_ms ? ms : best_ms;
+            sum += ms;
+        }
+        hipError_t err = hipGetLastError();
+        printf("wave-private scan probe: %llu rows x 768 B x 128 queries, %d workgroup(s)/CU, launch bounds %d wave(s)/SIMD: avg %.4f ms best %.4f ms = %.2f TB/s (best), "
+               "%.2f POP/s int8  [%s]\n",
+               (unsigned long long)n_rows, wg_per_cu, wps, sum / reps, best_ms, bytes / (best_ms * 1e-3) / 1e12, 2.0 * n_rows * 768 * 128 / (best_ms * 1e-3) / 1e15,
+               hipGetErrorString(err));
+    }
+    return 0;
+}
