@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
     float acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
-    const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 256u;
-    const uint32_t jx = (uint32_t)lane & 15u;
+    const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 16u;  // (fragment-linear block: chunk c of a row at (c/2) KiB + (c%2)*512)
     uint32_t cp = 0, cs = 0;  // consume cursor
     issue(0);
     for (uint32_t it = 0; it < n_items; it++) {
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
         const float *q0 = qlds + (size_t)cs * EPS;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
+            const uint4 v = *(const uint4 *)(tile + ((uint32_t)c >> 1) * 1024u + ((uint32_t)c & 1u) * 512u);
             float4 qv4[NQ][PER / 4];
 #pragma unroll
             for (int q = 0; q < NQ; q++)
