@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
     float acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
-    const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 16u;  // (fragment-linear block: chunk c of a row at (c/2) KiB + (c%2)*512)
+    const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 256u;
+    const uint32_t jx = (uint32_t)lane & 15u;
     uint32_t cp = 0, cs = 0;  // consume cursor
     issue(0);
     for (uint32_t it = 0; it < n_items; it++) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
         const float *q0 = qlds + (size_t)cs * EPS;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            const uint4 v = *(const uint4 *)(tile + ((uint32_t)c >> 1) * 1024u + ((uint32_t)c & 1u) * 512u);
+            const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
             float4 qv4[NQ][PER / 4];
 #pragma unroll
             for (int q = 0; q < NQ; q++)

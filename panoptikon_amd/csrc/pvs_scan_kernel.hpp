@@ -306,14 +306,15 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         const int rec_wave = wave % DMAW;    // whose copy of the tile record this wave reads (DMAW < WAVES only with RT = 1: one record)
         static_assert(DMAW == WAVES || RT == 1, "record sharing assumes one row sub-tile per workgroup");
         // A-fragment LDS byte offsets of this lane inside a slab
-        const uint32_t frag_row = (uint32_t)rt * 8192u + (uint32_t)j * 16u;  // (fragment-linear blocks: pvs_common.hpp)
-        // the 8 chunk positions this lane reads in every slab (k order): chunk c of row j sits at (c/2) KiB + (c%2)*512 + 16j;
-        // the slab steps ride in the ds_read immediate offset
+        const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
+        const uint32_t jx = (uint32_t)(j & 15);
+        // the 8 swizzled 16-B chunk positions this lane reads in every slab (k order): one base address per
+        // position and chunk, the slab steps ride in the ds_read immediate offset
         uint32_t swz[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const uint32_t c = DT == PVS_F32 ? (uint32_t)(4 * (i >> 1) + 2 * h + (i & 1)) : (uint32_t)(2 * i + h);
-            swz[i] = (c >> 1) * 1024u + (c & 1u) * 512u;
+            swz[i] = (c ^ jx) << 4;
         }
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
