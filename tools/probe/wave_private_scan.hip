@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -18,7 +19,7 @@ constexpr int STEPS = 24;        // 768 B per row / 32 B per MFMA step and half-
 constexpr int TILE_BYTES = 32 * 768;
 constexpr int QGROUPS = 4;       // 128 queries
 
-template <int WPS>  // waves per SIMD the launch bounds ask for
+template <int WPS, bool NOMFMA = false>  // waves per SIMD the launch bounds ask for; NOMFMA: the same streams without the matrix work
 __global__ __launch_bounds__(256, WPS) void k_probe(const uint8_t *rows, const uint8_t *qfrag, uint32_t n_tiles, int *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // [QGROUPS][STEPS][64][16] B fragments
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,8 +49,13 @@ __global__ __launch_bounds__(256, WPS) void k_probe(const uint8_t *rows, const u
 #pragma unroll
                 for (int g = 0; g < QGROUPS; g++) b[(s + 1) & 1][g] = bl[(g * STEPS + s + 1) * 64];
             }
+            if (NOMFMA) {
 #pragma unroll
-            for (int g = 0; g < QGROUPS; g++) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s & 1][g], acc[g], 0, 0, 0);
+                for (int g = 0; g < QGROUPS; g++) acc[g][s & 15] ^= a[s][g] + b[s & 1][g][0];
+            } else {
+#pragma unroll
+                for (int g = 0; g < QGROUPS; g++) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s & 1][g], acc[g], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -74,12 +80,22 @@ __global__ __launch_bounds__(256, WPS) void k_probe(const uint8_t *rows, const u
 int main(int argc, char **argv) {
     const uint64_t n_rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 10000000ull;
     const int wps = argc > 2 ? atoi(argv[2]) : 1;
+    const bool nomfma = argc > 4;
     const uint32_t n_tiles = (uint32_t)(n_rows / 32);
     const size_t bytes = (size_t)n_tiles * TILE_BYTES;
     uint8_t *d_rows, *d_q;
     int *d_out;
     hipMalloc(&d_rows, bytes);
     hipMemset(d_rows, 1, bytes);
+    if (argc > 3 && argv[3][0] == 'r') {  // random bytes instead of a constant: the matrix core's power draw (and with it the clock) depends on the data
+        std::vector<uint32_t> h(1 << 22);
+        uint32_t x = 12345;
+        for (auto &v : h) { x = x * 1664525u + 1013904223u; v = x ^ (x >> 13); }
+        for (size_t off = 0; off < bytes; off += h.size() * 4) hipMemcpy(d_rows + off, h.data(), std::min(bytes - off, h.size() * 4), hipMemcpyHostToDevice);
+        hipMemcpy(d_q, h.data(), QGROUPS * STEPS * 64 * 16, hipMemcpyHostToDevice);
+        hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     hipMalloc(&d_q, QGROUPS * STEPS * 64 * 16);
     hipMemset(d_q, 2, QGROUPS * STEPS * 64 * 16);
     hipMalloc(&d_out, 4 * 1024 * 16);
@@ -92,7 +108,10 @@ int main(int argc, char **argv) {
     for (int wg_per_cu = 1; wg_per_cu <= (wps >= 2 ? 1 : 1); wg_per_cu++) {
         const int grid = prop.multiProcessorCount * wg_per_cu;
         auto launch = [&]() {
-            if (wps == 1) {
+            if (wps == 1 && nomfma) {
+                hipFuncSetAttribute((const void *)k_probe<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL((k_probe<1, true>), dim3(grid), dim3(256), lds, 0, d_rows, d_q, n_tiles, d_out);
+            } else if (wps == 1) {
                 hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 hipLaunchKernelGGL(k_probe<1>, dim3(grid), dim3(256), lds, 0, d_rows, d_q, n_tiles, d_out);
             } else {
@@ -103,7 +122,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 3; i++) launch();
         hipDeviceSynchronize();
         float best_ms = 1e9f, sum = 0;
-        const int reps = 10;
+        const int reps = 30;
         for (int i = 0; i < reps; i++) {
             hipEventRecord(e0, 0);
             launch();
@@ -115,9 +134,9 @@ int main(int argc, char **argv) {
             sum += ms;
         }
         hipError_t err = hipGetLastError();
-        printf("wave-private scan probe: %llu rows x 768 B x 128 queries, %d workgroup(s)/CU, launch bounds %d wave(s)/SIMD: avg %.4f ms best %.4f ms = %.2f TB/s (best), "
+        printf("wave-private scan probe: %llu rows x 768 B x 128 queries, %d workgroup(s)/CU, launch bounds %d wave(s)/SIMD%s%s: avg %.4f ms best %.4f ms = %.2f TB/s (best), "
                "%.2f POP/s int8  [%s]\n",
-               (unsigned long long)n_rows, wg_per_cu, wps, sum / reps, best_ms, bytes / (best_ms * 1e-3) / 1e12, 2.0 * n_rows * 768 * 128 / (best_ms * 1e-3) / 1e15,
+               (unsigned long long)n_rows, wg_per_cu, wps, argc > 3 && argv[3][0] == 'r' ? ", random bytes" : ", constant bytes", nomfma ? ", no MFMA" : "", sum / reps, best_ms, bytes / (best_ms * 1e-3) / 1e12, 2.0 * n_rows * 768 * 128 / (best_ms * 1e-3) / 1e15,
                hipGetErrorString(err));
     }
     return 0;
