@@ -1,8 +1,9 @@
 // pvs_microbench.hip — on-box peaks for the roofline report ("take peaks from the datasheet AND a measured
 // stream / MFMA microbenchmark on the box; record both").  Nothing here is on the product path: bench.py calls
 // pvs_microbench once per run and prints the numbers next to the datasheet ones.
-//   hbm_read      every lane streams 16-byte non-temporal loads over a buffer far larger than L2 + MALL, grid = 8 workgroups per CU
-//   hbm_lds_dma   the same bytes moved by LDS-DMA (global_load_lds_dwordx4 … nt, 1 KiB per wave-instruction, 8 in flight per wave)
+//   hbm_read      every wave streams contiguous 24-KiB blocks with 16-byte non-temporal loads, two blocks in flight, over a buffer far
+//                 larger than L2 + MALL, one workgroup per CU
+//   hbm_lds_dma   the same bytes moved by LDS-DMA (global_load_lds_dwordx4 … nt, 1 KiB per wave-instruction, 31 in flight per wave)
 //                 and never read back: the ceiling of the transport the scan kernel uses
 //   hbm_copy      read + write (hipMemcpyAsync device-to-device)
 //   mfma_i8/f16   v_mfma_i32_32x32x32_i8 / v_mfma_f32_32x32x16_f16 on registers, four independent accumulators per wave,
@@ -16,33 +17,61 @@ typedef float mb_v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 mb_v8h __attribute__((ext_vector_type(8)));
 
 typedef unsigned int mb_v4u __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k_mb_read(const mb_v4u *src, uint64_t n16, uint32_t *sink) {
+// Streaming read: every wave walks its own sequence of contiguous 24-KiB blocks, 24 sixteen-byte non-temporal loads per lane
+// and block, the next block requested before the current one is folded (48 KiB per wave in flight), one workgroup of four
+// waves per CU.  (The first form of this benchmark — 8 workgroups per CU, 4 loads in flight per lane, each KiB of a wave 8 MB
+// from the next — topped out at 6.0-6.2 TB/s; this access pattern, the one tools/probe/wave_private_scan.hip found, reaches
+// 7.0-7.1 TB/s on the same part.)
+__global__ __launch_bounds__(256, 1) void k_mb_read(const mb_v4u *src, uint64_t n16, uint32_t *sink) {
+    constexpr int N = 24;                       // loads per lane and block
+    const uint64_t n_blocks = n16 / (64 * N);   // 24-KiB blocks
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
     uint32_t acc = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const mb_v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                    c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        acc += a.x ^ b.y ^ c.z ^ d.w;
+    mb_v4u bufA[N], bufB[N];
+    auto load = [&](uint64_t blk, mb_v4u(&d)[N]) {
+        const mb_v4u *p = src + blk * (64 * N) + lane;
+#pragma unroll
+        for (int i = 0; i < N; i++) d[i] = __builtin_nontemporal_load(p + i * 64);
+    };
+    auto fold = [&](const mb_v4u(&d)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; i++) acc += d[i].x ^ d[i].w;
+    };
+    uint64_t b = wid;
+    if (b < n_blocks) load(b, bufA);
+    while (b < n_blocks) {
+        if (b + nw < n_blocks) load(b + nw, bufB);
+        fold(bufA);
+        b += nw;
+        if (b >= n_blocks) break;
+        if (b + nw < n_blocks) load(b + nw, bufA);
+        fold(bufB);
+        b += nw;
     }
-    for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i).x;
     if (acc == 0x9e3779b9u) sink[0] = acc;  // keeps the loads alive, (almost) never stores
 }
 
-// LDS-DMA stream: each wave lands 1 KiB pieces in its own 8-slot LDS ring, 7 in flight, nothing reads them back
-__global__ __launch_bounds__(256, 2) void k_mb_ldsdma(const uint8_t *src, uint64_t n_pieces) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[4 * 8 * 1024];
+// LDS-DMA stream: each wave walks its own sequence of contiguous 24-KiB blocks and lands the 1-KiB pieces in its own 32-slot LDS
+// ring (31 in flight per wave, 124 KiB per CU with one workgroup of four waves); nothing reads them back
+__global__ __launch_bounds__(256, 1) void k_mb_ldsdma(const uint8_t *src, uint64_t n_pieces) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ring[];  // 4 waves x 32 KiB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t base = lds_addr(ring) + (uint32_t)wave * 8192;
+    const uint32_t base = lds_addr(ring) + (uint32_t)wave * 32768;
+    const uint64_t n_blocks = n_pieces / 24;
     const uint64_t wid = (uint64_t)blockIdx.x * 4 + wave, nw = (uint64_t)gridDim.x * 4;
     int slot = 0;
-    for (uint64_t p = wid; p < n_pieces; p += nw) {
-        const uint8_t *sb = src + p * 1024;
+    for (uint64_t blk = wid; blk < n_blocks; blk += nw) {
+        const uint8_t *sb = src + blk * (24 * 1024);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sb), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)sb >> 32));
-        dma16((const void *)(((uint64_t)hi << 32) | lo), (uint32_t)lane * 16u, base + (uint32_t)slot * 1024);
-        slot = (slot + 1) & 7;
-        wait_vm<7>();
+        const uint8_t *ub = (const uint8_t *)(((uint64_t)hi << 32) | lo);
+#pragma unroll
+        for (int p = 0; p < 24; p++) {
+            dma16((const void *)(ub + p * 1024), (uint32_t)lane * 16u, base + (uint32_t)slot * 1024);
+            slot = (slot + 1) & 31;
+            wait_vm<31>();
+        }
     }
     wait_vm<0>();
 }
@@ -93,6 +122,7 @@ PVS_EXPORT pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out)
         HIP_TRY(hipMemset(b, 0, bytes));
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipFuncSetAttribute((const void *)k_mb_ldsdma, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
         auto timed = [&](auto &&launch, int reps, float *ms_best) -> pvs_status {
             *ms_best = 1e30f;
             for (int w = 0; w < 2; w++) launch();
@@ -108,9 +138,9 @@ PVS_EXPORT pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out)
             return hipGetLastError() == hipSuccess ? PVS_OK : pvs_fail(PVS_ERR_DEVICE, "microbenchmark launch failed");
         };
         float ms = 0.f;
-        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_read, dim3(cus * 8), dim3(256), 0, nullptr, (const mb_v4u *)a, bytes / 16, sink); }, 5, &ms));
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_read, dim3(cus), dim3(256), 0, nullptr, (const mb_v4u *)a, bytes / 16, sink); }, 5, &ms));
         out->hbm_read_gbs = (double)bytes / (ms * 1e-3) / 1e9;
-        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_ldsdma, dim3(cus * 2), dim3(256), 0, nullptr, (const uint8_t *)a, bytes / 1024); }, 5, &ms));
+        PVS_TRY(timed([&]() { hipLaunchKernelGGL(k_mb_ldsdma, dim3(cus), dim3(256), 4 * 32768, nullptr, (const uint8_t *)a, bytes / 1024); }, 5, &ms));
         out->hbm_lds_dma_gbs = (double)bytes / (ms * 1e-3) / 1e9;
         PVS_TRY(timed([&]() { (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr); }, 3, &ms));
         out->hbm_copy_gbs = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;  // bytes read + bytes written

@@ -35,8 +35,9 @@
 // per-row test, with the row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
 //
 // What the round-2 measurements say (10M x 768 int8 on MI355X; DESIGN.md §4.1b has the table):
-//   * 128 queries: 1.25-1.29 ms = 6.0-6.1 TB/s — the on-box streaming ceiling (pvs_microbench: 6.0 TB/s through LDS-DMA,
-//     6.2 TB/s with plain loads; the 8 TB/s datasheet figure is not reachable by any read stream on this part).
+//   * 128 queries: 1.25-1.30 ms = 5.9-6.1 TB/s; a pure read stream (plain loads or LDS-DMA, pvs_microbench) reaches 7.1 TB/s on the
+//     box and the 32-query instance 6.7: the 128-query pass is bound by how fast a workgroup turns a tile around, and no knob
+//     inside this wave / barrier structure moved it (profiles/r02_tile_phase_profile_b256.txt; DESIGN.md §9 for the way out).
 //   * 256 queries: 2.10 ms.  Ablations of the same binary: MFMA + fragment reads alone 1.32 ms; + LDS-DMA issue 1.57;
 //     + fold and pre-test 1.62; + per-row tests 1.70; + candidate emission 2.10.  The last step is NOT the cost of the
 //     emission instructions (~30 per candidate; replacing staging + flush + global atomics by one LDS atomic and one
