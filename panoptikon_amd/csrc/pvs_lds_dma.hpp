@@ -12,12 +12,16 @@
 // SGPR base (uniform: tile + k-slab) + 32-bit VGPR offset (lane's row/chunk inside the slab).
 // `nt`: every corpus byte is read once per launch by exactly one CU (streaming policy).
 __device__ static inline void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+#ifdef PVS_DMA_M0_CLOBBER  // tuning: tell the compiler M0 is gone instead of saving and restoring it around every piece
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+#else
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
+#endif
 }
 __device__ static inline void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;

@@ -304,7 +304,12 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         }
         const uint32_t nvoff = (uint32_t)(rt * PVS_AUX_REC + lane) * 4u;  // this wave's tile record: 32 row scalars, then the tile's extremes
         const bool dma_wave = wave < DMAW;   // (wave-uniform) does this wave issue DMA at all
-        const int rec_wave = wave % DMAW;    // whose copy of the tile record this wave reads (DMAW < WAVES only with RT = 1: one record)
+#ifdef PVS_REC_SHARE  // tuning: with one row sub-tile per workgroup all waves need the SAME tile record — wave 0 alone fetches it
+        constexpr bool REC_SHARE = RT == 1 && DMAW == WAVES;
+#else
+        constexpr bool REC_SHARE = false;
+#endif
+        const int rec_wave = REC_SHARE ? 0 : wave % DMAW;  // whose copy of the tile record this wave reads
         static_assert(DMAW == WAVES || RT == 1, "record sharing assumes one row sub-tile per workgroup");
         // A-fragment LDS byte offsets of this lane inside a slab
         const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 const int sb = part / PPW, e = part % PPW;
                 dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
             } else {
-                dma4(is_aux, nvoff, is_norm);
+                if (!REC_SHARE || wave == 0) dma4(is_aux, nvoff, is_norm);
             }
         };
         auto issue = [&]() {
@@ -662,7 +667,10 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 #pragma unroll
             for (int ck = 0; ck < CPT; ck++) {
                 PROF_STAMP(0);
-                wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
+                if (REC_SHARE && wave != 0)
+                    wait_vm<(PC - 1) * (G::VM_PER_CHUNK - 1)>();  // (no record DMA of its own)
+                else
+                    wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
                 PROF_STAMP(1);
                 if constexpr (ELASTIC) {
                     // ... tell the others, then wait until everyone's share of THIS chunk has landed and everyone has
