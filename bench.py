@@ -284,6 +284,49 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
     ctl.close()
 
 
+def sample_clock_and_power(step, drain, seconds=1.5):
+    """rocm-smi's shader clock and socket power while `step` loops (a side thread polls rocm-smi; the loop runs on this one)."""
+    import re
+    import shutil
+    import threading
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:  # noqa: BLE001
+                return
+            clk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            pw = re.search(r"Power \(W\): ([0-9.]+)", out)
+            if clk and pw:
+                samples.append((int(clk.group(1)), float(pw.group(1))))
+
+    th = threading.Thread(target=poll, daemon=True)
+    t_end = time.perf_counter() + seconds
+    i = 0
+    th.start()
+    while time.perf_counter() < t_end or len(samples) < 2:
+        step(i)
+        i += 1
+        if time.perf_counter() > t_end + 8.0:
+            break
+    stop.set()
+    drain()
+    th.join(timeout=15)
+    if not samples:
+        return {"error": "no rocm-smi sample"}
+    samples = samples[1:] or samples  # (the first one may predate the loop)
+    clk = sorted(c for c, _ in samples)[len(samples) // 2]
+    pw = sorted(p for _, p in samples)[len(samples) // 2]
+    return {"sclk_mhz": clk, "socket_power_w": pw, "samples": len(samples), "steps_looped": i,
+            "how": "median of rocm-smi --showclocks --showpower polled while the same steps loop, after the timed region"}
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) ourselves, relay rank 0's
     JSON line, fail if any rank fails."""
@@ -545,6 +588,13 @@ def main():
     }
     if prof.exchange_launches:
         roofline["exchange_avg_ms"] = round(prof.exchange_ms / prof.exchange_launches, 4)  # grouped all-gather + merge kernel
+    if not args.no_peaks and rank == 0 and world == 1 and not args.force_comm:
+        # What clock and power does the part hold under this workload?  (The 128- and 256-query passes run at the board power
+        # limit: DESIGN.md section 5.)  Untimed: the same steps loop for ~1.5 s while rocm-smi is sampled from a side thread.
+        try:
+            roofline["under_load"] = sample_clock_and_power(lambda i: step(i), drain, seconds=1.5)
+        except Exception as e:  # noqa: BLE001
+            roofline["under_load"] = {"error": str(e)}
     if not args.no_peaks and rank == 0 and hasattr(lib, "pvs_microbench"):
         try:
             roofline["measured_peaks"] = pvs.microbench(device)
