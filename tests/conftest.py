@@ -20,6 +20,16 @@ def pytest_configure(config):
         subprocess.check_call([sys.executable, "-m", "panoptikon_amd.build"], cwd=ROOT, stdout=subprocess.DEVNULL)
 
 
+def pytest_collection_modifyitems(config, items):
+    # A test that never comes back (a collective with a missing rank, a device that stopped answering) must fail, not hold the
+    # whole run: every test gets a generous ceiling unless it set its own (pytest-timeout; absent plugin: no ceiling).
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

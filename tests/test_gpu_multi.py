@@ -189,9 +189,10 @@ def test_rccl_two_ranks_as_two_threads(pvs):
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
 
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]  # (daemon: a rank stuck in a collective fails the test, it does not hang the run)
     [t.start() for t in th]
-    [t.join(300) for t in th]
+    [t.join(180) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank did not come back from the RCCL exchange within 180 s"
     assert not errs, errs
     for r in range(world):
         assert np.array_equal(res[r][0], exp[0]) and np.array_equal(res[r][1].view(np.uint32), exp[1].view(np.uint32)), f"rank {r}"
