@@ -27,6 +27,7 @@ SOURCES = [
     "pvs_kernels_util.hip",
     "pvs_kernels_scan.hip",
     "pvs_scan_i8.hip",
+    "pvs_scan_i8_wide.hip",
     "pvs_scan_f16_small.hip",
     "pvs_scan_f16_large.hip",
     "pvs_scan_f16_xl.hip",

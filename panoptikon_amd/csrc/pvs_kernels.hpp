@@ -65,7 +65,7 @@ struct ScanArgs {
     uint32_t qsplit = 1;           // workgroups per tile stream, each with its own qgroups*32 queries of the batch (mode 1; see ScanK.qsplit)
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
-uint32_t pvs_scan_wg_rows(uint32_t qgroups);  // rows per workgroup tile
+uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs);  // rows per workgroup tile
 uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // RT: 32-row sub-tiles (= candidate segments) per workgroup
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);

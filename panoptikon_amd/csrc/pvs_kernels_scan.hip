@@ -15,7 +15,7 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
                kslabs == 20 || kslabs == 24;
     return false;
 }
-uint32_t pvs_scan_wg_rows(uint32_t qgroups) { return qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
+uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs) { return qgroups == 8 ? pvs_scan_wide_rows(kslabs) : qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
 uint32_t pvs_scan_row_tiles(uint32_t qgroups) { return qgroups >= 4 ? 1u : 4u / qgroups; }
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
@@ -34,7 +34,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg_stride = a.grid * pvs_scan_row_tiles(a.qgroups) * 2;
     k.n_rows = a.n_rows;
     k.stride = a.stride;
-    const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+    const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
     k.n_wgtiles = (uint32_t)((a.n_rows + wg_rows - 1) / wg_rows);
     k.tile_step = a.tile_step ? a.tile_step : 1;
     k.groups_per_query = a.groups_per_query;

@@ -31,7 +31,8 @@ hipError_t pvs_scan_dispatch_f16_large(const ScanK &k, uint32_t kslabs, uint32_t
 hipError_t pvs_scan_dispatch_f32_small(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_mid(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
-hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s);
+hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s);  // 256 queries (pvs_scan_wide.hpp)
+uint32_t pvs_scan_wide_rows(uint32_t kslabs);  // rows per workgroup tile of the 256-query kernel
 hipError_t pvs_scan_dispatch_i8_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f16_xl(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_xl(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

@@ -12,15 +12,3 @@ hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, in
     }
     return hipErrorInvalidValue;
 }
-// 256 queries per pass: two query groups per wave (Geo::GPW)
-hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s) {
-    switch (kslabs) {
-#ifndef PVS_ONLY_KS3
-        case 1: return scan_launch_wide<PVS_I8, 1>(k, metric, mode, s);
-        case 2: return scan_launch_wide<PVS_I8, 2>(k, metric, mode, s);
-        case 4: return scan_launch_wide<PVS_I8, 4>(k, metric, mode, s);
-#endif
-        case 3: return scan_launch_wide<PVS_I8, 3>(k, metric, mode, s);
-    }
-    return hipErrorInvalidValue;
-}

@@ -1,0 +1,12 @@
+// int8 instances of the 256-query filter scan (pvs_scan_wide.hpp): row pitch 256..1024 B (dim <= 1024).
+#include "pvs_scan_wide.hpp"
+hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s) {
+    switch (kslabs) {
+        case 1: return scan_wide_launch<1>(k, metric, mode, s);
+        case 2: return scan_wide_launch<2>(k, metric, mode, s);
+        case 3: return scan_wide_launch<3>(k, metric, mode, s);
+        case 4: return scan_wide_launch<4>(k, metric, mode, s);
+    }
+    return hipErrorInvalidValue;
+}
+uint32_t pvs_scan_wide_rows(uint32_t kslabs) { return kslabs <= 3 ? 64u : 32u; }

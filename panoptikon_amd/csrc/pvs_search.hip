@@ -117,7 +117,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.seg = c.d_seg;
         a.seg_cnt = c.d_seg_cnt;
         a.gmin = c.d_gmin;
-        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups);
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         // pass A: strided sample of row tiles -> group minima -> threshold
         // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
