@@ -235,7 +235,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
         HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 64));
         HIP_TRY(hipMalloc((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
-        HIP_TRY(hipMalloc((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS));
+        HIP_TRY(hipMalloc((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS * (PVS_SEG_CAP / PVS_WIDE_SEG_CAP)));  // (the 256-query kernel: twice the lists at half the slots)
         HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
     }
     static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;  // tests: the LDS-light pass C on every search

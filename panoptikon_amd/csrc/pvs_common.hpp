@@ -57,6 +57,11 @@ constexpr uint32_t PVS_CAND_CAP = 16384;  // candidate slots per query
 constexpr uint32_t PVS_SEG_CAP = 64;       // candidate slots per (segment, query): ~3 expected at k = 100 (1,600 candidates over >= 512 segments)
 constexpr uint32_t PVS_SEG_PAIRS = 131072; // (segment, query) pairs per pass: 256 queries x 512 segments ... 32 queries x 4,096 segments
                                            // (segment = one half-wave of one workgroup row stream: its candidates are written by one lane)
+// the 256-query int8 kernel (pvs_scan_wide.hpp): a lane quarter c of every workgroup stream owns a segment; a (lane, query)
+// supplies up to 8 group minima in pass A
+constexpr uint32_t PVS_WIDE_SEG_PER_STREAM = 4;
+constexpr uint32_t PVS_WIDE_SEG_CAP = 32;   // slots per (segment, query): ~1.6 expected at k = 100 over 1,024 segments
+constexpr uint32_t PVS_WIDE_GMIN_MAX = 8;
 constexpr uint32_t PVS_AUX_REC = 64;     // floats per 32-row tile in the scan's row-scalar stream: 32 row scalars, min, max, padding
 constexpr uint32_t PVS_SURV_CAP = 8192;   // survivors reranked exactly per query (their sort records overlay the 64 KiB bound array)
 

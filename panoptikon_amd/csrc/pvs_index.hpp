@@ -42,7 +42,7 @@ struct SearchCtx {
     float *d_gmin = nullptr;      // [MAX_BATCH][GMAX]
     uint32_t *d_cand_cnt = nullptr;  // one flag word (dense int8 path: an L2 sum left the exact range)
     uint2 *d_seg = nullptr;          // [PVS_SEG_PAIRS][PVS_SEG_CAP] candidate segments of the filter scan
-    uint32_t *d_seg_cnt = nullptr;   // [PVS_SEG_PAIRS] their fill counts
+    uint32_t *d_seg_cnt = nullptr;   // their fill counts (one per list: PVS_SEG_PAIRS, twice that for the 256-query kernel's half-size lists)
     uint2 *d_cand = nullptr;      // [MAX_BATCH][CAND_CAP]
     uint32_t *d_fin_ub = nullptr, *d_fin_surv = nullptr;  // pass C's global work area (FinalizeArgs.w_*), allocated in multi-stream mode
     unsigned long long *d_fin_sort = nullptr;

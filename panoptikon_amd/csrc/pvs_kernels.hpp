@@ -56,7 +56,7 @@ struct ScanArgs {
     uint32_t grid;          // workgroups
     float *gmin;            // mode 0: [batch_pad][groups_per_query]
     uint32_t groups_per_query;
-    uint32_t gmin_per_lane = 16;  // mode 0: 1..16 (power of two); groups_per_query = grid * RT * 2 * gmin_per_lane
+    uint32_t gmin_per_lane = 16;  // mode 0: 1..pvs_scan_gmin_max (power of two); groups_per_query = grid * pvs_scan_segs_per_stream * gmin_per_lane
     const float *thr;       // mode 1: [batch_pad]
     // mode 1: candidates go to per-(segment, query) lists: segment = one wave row of one workgroup stream (grid * RT of them)
     uint2 *seg = nullptr;          // [n_segments][batch_pad][PVS_SEG_CAP] = (row, key bits)
@@ -66,7 +66,10 @@ struct ScanArgs {
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs);  // rows per workgroup tile
-uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // RT: 32-row sub-tiles (= candidate segments) per workgroup
+uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // RT: 32-row sub-tiles per workgroup
+uint32_t pvs_scan_segs_per_stream(uint32_t qgroups);  // candidate segments (= lanes per query that hold group minima) per workgroup stream
+uint32_t pvs_scan_seg_cap(uint32_t qgroups);          // slots per (segment, query)
+uint32_t pvs_scan_gmin_max(uint32_t qgroups);         // pass A: minima one lane can supply per query
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
 
@@ -86,6 +89,7 @@ struct FinalizeArgs {
     const uint2 *seg;       // the scan's candidate segments and their fill counts (ScanArgs)
     const uint32_t *seg_cnt;
     uint32_t n_segments, seg_queries;
+    uint32_t seg_cap = PVS_SEG_CAP;  // slots per (segment, query) as the scan wrote them (pvs_scan_seg_cap)
     uint2 *cand;            // [batch][cand_cap] scratch: each query's segments gathered into one list
     uint32_t cand_cap;
     uint32_t batch, k;

@@ -17,6 +17,9 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
 }
 uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs) { return qgroups == 8 ? pvs_scan_wide_rows(kslabs) : qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
 uint32_t pvs_scan_row_tiles(uint32_t qgroups) { return qgroups >= 4 ? 1u : 4u / qgroups; }
+uint32_t pvs_scan_segs_per_stream(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(qgroups) * 2u; }
+uint32_t pvs_scan_seg_cap(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP; }
+uint32_t pvs_scan_gmin_max(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_GMIN_MAX : 16u; }
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
@@ -30,8 +33,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg = a.seg;
     k.seg_cnt = a.seg_cnt;
     k.seg_queries = a.qgroups * 32;
-    k.seg_cap = PVS_SEG_CAP;
-    k.seg_stride = a.grid * pvs_scan_row_tiles(a.qgroups) * 2;
+    k.seg_cap = pvs_scan_seg_cap(a.qgroups);
+    k.seg_stride = a.grid * pvs_scan_segs_per_stream(a.qgroups);
     k.n_rows = a.n_rows;
     k.stride = a.stride;
     const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
@@ -190,7 +193,7 @@ struct FinK {
     float *out_dist;
     uint32_t *out_count, *need_dense, *cand_seen;
     uint64_t n_rows;
-    uint32_t stride, dim, cand_cap, k, n_segments, seg_queries;
+    uint32_t stride, dim, cand_cap, k, n_segments, seg_queries, seg_cap;
     int metric;
     uint32_t *w_ub, *w_surv;       // LIGHT: global work area (FinalizeArgs.w_*)
     unsigned long long *w_sort;
@@ -343,16 +346,16 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
             }
 #pragma unroll
             for (uint32_t i = 0; i < PER_MAX; i++) {
-                over |= cs[i] > PVS_SEG_CAP;
-                cs[i] = cs[i] < PVS_SEG_CAP ? cs[i] : PVS_SEG_CAP;
+                over |= cs[i] > a.seg_cap;
+                cs[i] = cs[i] < a.seg_cap ? cs[i] : a.seg_cap;
                 mine += cs[i];
             }
         } else {
             for (uint32_t i = 0; i < per; i++) {
                 const uint32_t sg = tid * per + i;
                 const uint32_t c = sg < a.n_segments ? sc[sg] : 0u;
-                over |= c > PVS_SEG_CAP;
-                mine += c < PVS_SEG_CAP ? c : PVS_SEG_CAP;
+                over |= c > a.seg_cap;
+                mine += c < a.seg_cap ? c : a.seg_cap;
             }
         }
         if (tid == 0) s_over = 0;
@@ -379,12 +382,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                 uint2 first[PER_MAX];
 #pragma unroll
                 for (uint32_t i = 0; i < PER_MAX; i++)
-                    if (cs[i]) first[i] = a.seg[((size_t)(tid * per + i) * a.seg_queries + q) * PVS_SEG_CAP];
+                    if (cs[i]) first[i] = a.seg[((size_t)(tid * per + i) * a.seg_queries + q) * a.seg_cap];
 #pragma unroll
                 for (uint32_t i = 0; i < PER_MAX; i++)
                     if (cs[i]) {
                         flat[run] = first[i];
-                        const uint2 *src = a.seg + ((size_t)(tid * per + i) * a.seg_queries + q) * PVS_SEG_CAP;
+                        const uint2 *src = a.seg + ((size_t)(tid * per + i) * a.seg_queries + q) * a.seg_cap;
                         for (uint32_t e = 1; e < cs[i]; e++) flat[run + e] = src[e];
                         run += cs[i];
                     }
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     const uint32_t sg = tid * per + i;
                     if (sg >= a.n_segments) break;
                     const uint32_t c = sc[sg];
-                    const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * PVS_SEG_CAP;
+                    const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * a.seg_cap;
                     for (uint32_t e = 0; e < c; e++) flat[run + e] = src[e];
                     run += c;
                 }
@@ -565,6 +568,7 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.w_surv = f.w_surv;
     k.w_sort = f.w_sort;
     k.seg_queries = f.seg_queries;
+    k.seg_cap = f.seg_cap;
     k.cand = f.cand;
     k.out_ids = f.out_ids;
     k.out_dist = f.out_dist;

@@ -2,10 +2,12 @@
 #include "pvs_scan_wide.hpp"
 hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s) {
     switch (kslabs) {
+#ifndef PVS_WIDE_ONLY_KS3  // (tuning sweeps build the 768-B instance alone)
         case 1: return scan_wide_launch<1>(k, metric, mode, s);
         case 2: return scan_wide_launch<2>(k, metric, mode, s);
-        case 3: return scan_wide_launch<3>(k, metric, mode, s);
         case 4: return scan_wide_launch<4>(k, metric, mode, s);
+#endif
+        case 3: return scan_wide_launch<3>(k, metric, mode, s);
     }
     return hipErrorInvalidValue;
 }

@@ -3,37 +3,41 @@
 // Replaces, for 256 queries at once, the reference's per-row vec_distance_{cosine,L2}(payload, ?) + ORDER BY ... LIMIT k
 // (filters/image_embeddings.rs:321-362, text_embeddings.rs:386-418, pql/builder.rs:578-582) — the same contract as k_scan
 // (pvs_scan_kernel.hpp): pass A = group minima of an upper bound of the key over a strided sample of tiles, pass B = every
-// row whose lower bound is at or below the threshold goes to its (stream, half-wave, query) segment.  Same HBM layout, same
-// ScanK arguments, same outputs; pass C does not know which kernel produced its candidates.
+// row whose lower bound is at or below the threshold goes to a candidate segment owned by one lane.  Same HBM layout, same
+// ScanK arguments; pass C does not know which kernel produced its candidates.
 //
-// Why a kernel of its own.  At 256 queries the pass is matrix-pipe AND HBM bound at once (10M x 768: 1,536 matrix-pipe cycles
-// per SIMD and 32-row tile against ~1,580 cycles of HBM time), so everything a wave does alone — loop top, barrier skew,
-// epilogue rest, a candidate to emit — is paid by the seven waves waiting for it at the per-tile barrier.  Round 2's form (8
-// waves x 32 queries on 32-row tiles inside k_scan) spent 2,320-2,870 cycles per tile.  This kernel changes three things:
-//   * 64-row workgroup tiles (two layout tiles = one contiguous 48 KiB of HBM at 768-B rows, ring of 3): every wave keeps its
-//     32 queries' B fragments in registers and runs TWO independent accumulation chains (rows 0-31, rows 32-63) per barrier —
-//     48 MFMAs between barriers instead of 24, and a wave that has the matrix pipe to itself can issue back to back;
-//   * the pass-B test of the previous tile runs entirely in the shadow of the current tile's MFMAs and is branch-free up to the
-//     (wave-uniform) decision to store: the 16 sums of a lane are packed as (sum << 4 | slot) and folded to their TOP TWO with
-//     v_max3 / v_med3; the best row is tested exactly (its row scalar comes from the tile record in LDS) and, when it passes,
-//     written with ONE predicated vector store; only when the second best also clears the tile bound — two candidates in one
-//     lane and tile: ties, clustered data — does the wave take the per-row path.  No lane loop, no scalar stores, nothing left
-//     behind the last MFMA of a tile;
-//   * one copy of the tile record per workgroup (wave 0 fetches it) and incremental tile addresses: the loop top is a counted
-//     wait and the barrier.
-// Stores and the counted vmcnt waits: gfx9 counts stores on vmcnt too and retires VMEM operations of a wave in order, so a
+// What bounds this pass is ENERGY.  At 256 queries x 10M x 768 the part sits at its 1,400 W limit and lowers its clock until
+// the work fits; ablations of this kernel add up instead of overlapping (tools/probe/wide_probe.hip, profiles/r03_*):
+// matrix cores 1.14 ms-equivalents, HBM + LDS-DMA transport 0.46, A-fragment reads from LDS 0.17, epilogue VALU 0.15 — sum
+// 1.91 = what the full kernel takes.  Stalls are free (the clock rises), instructions are not.  So:
+//   * v_mfma_i32_16x16x64_i8, not 32x32x32: on int8 codes the matrix pipe sustains 4.1 POP/s through the 16x16 shape and 3.4
+//     through the 32x32 shape at the same board power (tools/probe/mfma_rate.hip) — K = 64 per instruction means a quarter of
+//     the accumulator traffic per operation;
+//   * a wave owns 32 queries (two 16-query B fragments per 64 bytes of k, resident in registers: 96 VGPRs at 768-B rows) and
+//     ALL 64 rows of the workgroup tile (four 16-row A fragments per k step, each feeding two MFMAs): 96 MFMAs, 48 fragment
+//     reads and ONE barrier per 64-row tile (two layout tiles = one contiguous 48 KiB of HBM, ring of 3);
+//   * the pass-B test of the previous tile runs in the shadow of the current tile's MFMAs and costs ~40 VALU per wave-tile:
+//     per (query, 32-row layout tile) a float bound from the tile's extreme row scalars (1-4 VALU), a v_max3 fold of the
+//     lane's 8 sums (4 VALU), one compare.  Only wave-tiles where some lane passes (a necessary condition of the exact test)
+//     look at row scalars, and a passing row is written with one predicated vector store: no lane loop, no scalar stores;
+//   * one copy of the tile record per workgroup (wave 0 fetches it), incremental tile addresses.
+// Stores and the counted vmcnt waits: gfx9 counts stores on vmcnt too and retires a wave's VMEM operations in order, so a
 // store issued between LDS-DMA pieces makes a later counted wait cover at most that many pieces more than it needs — pieces
 // issued a whole tile earlier.  The waits stay correct (never too few), the prefetch ring is not drained.
+//
+// Lane geometry (n = lane & 15, c = lane >> 4): A fragment of row group rg = row 16 rg + n, bytes 16 c .. 16 c + 15 of the
+// k step; B fragment of query group q = query 16 q + n, same bytes; D block (rg, q): register v = row 16 rg + 4 c + v,
+// query 16 q + n.  A lane therefore holds two queries x 16 rows per tile, its thresholds are lane-private registers, and
+// candidate segment (stream, c) x query has exactly one writer.  A dot product is invariant under a common permutation of
+// k, so only "A and B use the same 16-byte chunk per (c, k step)" matters, not the instruction's internal k order.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "pvs_lds_dma.hpp"
 #include "pvs_scan_dispatch.hpp"
 
-#include <type_traits>
-
 typedef int wv4i __attribute__((ext_vector_type(4)));
-typedef int wv16i __attribute__((ext_vector_type(16)));
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) — the tile body below must be straight-line code with
 // every index a constant (a "#pragma unroll" the optimizer declines turns register arrays into scratch)
@@ -48,9 +52,10 @@ __device__ static inline __attribute__((always_inline)) void static_for(F &&f) {
 
 template <int KSLABS>
 struct WideGeo {
-    static constexpr int WAVES = 8;                       // one query group of 32 per wave
-    static constexpr int RPW = KSLABS <= 3 ? 2 : 1;       // 32-row sub-tiles per wave and barrier
+    static constexpr int WAVES = 8;                       // 32 queries per wave
+    static constexpr int RPW = KSLABS <= 3 ? 2 : 1;       // 32-row layout tiles per workgroup tile
     static constexpr int TILE_ROWS = 32 * RPW;
+    static constexpr int RG = 2 * RPW;                    // 16-row A fragments per k step
     static constexpr int SUB_BYTES = KSLABS * 8192;       // one 32-row layout tile
     static constexpr int TILE_BYTES = RPW * SUB_BYTES;    // contiguous in HBM and, byte for byte, in LDS
     static constexpr int PIECES = TILE_BYTES / 1024;      // 1-KiB LDS-DMA pieces per tile
@@ -66,11 +71,17 @@ struct WideGeo {
     static_assert((PC - 1) * (PPW + 1) <= 63, "vmcnt is a 6-bit counter");
 };
 
+struct WideCnt {  // fill counts of a lane's two (segment, query) lists
+    uint32_t k0, k1;
+};
+
 // MODE 0 = pass A (group minima), MODE 1 = pass B (candidates)
 template <int KSLABS, int METRIC, int MODE>
 __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
     using G = WideGeo<KSLABS>;
-    constexpr int RPW = G::RPW, NC = G::NC, PC = G::PC, NCN = G::NCN, PPW = G::PPW, NF = KSLABS * 8, NG = NF * RPW;
+    constexpr int RPW = G::RPW, RG = G::RG, NC = G::NC, PC = G::PC, NCN = G::NCN, PPW = G::PPW;
+    constexpr int NK = KSLABS * 4;       // k steps of 64 bytes
+    constexpr int NG = NK * RG * 2;      // MFMAs (= filler gaps) per tile
     constexpr bool COS = METRIC == PVS_COSINE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;                           // [NC][TILE_BYTES]
@@ -78,44 +89,78 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;  // j: query column of the wave's group (B operand / C column) and A row; h: k half / row half
+    const int n = lane & 15, c = lane >> 4;
     const uint32_t sid = blockIdx.x, nstreams = a.grid;
-    const int myq = wave * 32 + j;
     const uint32_t ring_lds = lds_addr(ring), rec_lds = lds_addr(recring);
     if (tid < 256) ((float *)(recring + (NCN - 1) * G::REC_SLOT))[tid] = __builtin_nanf("");  // the record of tile "-1" (see p_nslot)
 
-    // tiles of this workgroup: (sid + it * nstreams) * tile_step, in units of 64-row (RPW = 2) workgroup tiles
+    // tiles of this workgroup: (sid + it * nstreams) * tile_step, in units of workgroup tiles
     const uint32_t n_samp = (a.n_wgtiles + a.tile_step - 1) / a.tile_step;
     const int n_my = (sid < n_samp && sid < nstreams) ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
 
-    float mins[MODE == 0 ? 16 : 1];
+    constexpr int NMIN = MODE == 0 ? 8 : 1;
+    float mins[2][NMIN];  // pass A: per query 8 minima, one per (row group parity, v): 8 disjoint row groups
 #pragma unroll
-    for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[r] = __builtin_inff();
-    const uint32_t seg = sid * 2 + h;  // this lane's segment (written by no other lane)
-    uint32_t mycnt = 0;
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < NMIN; r++) mins[q][r] = __builtin_inff();
+    const uint32_t seg = sid * PVS_WIDE_SEG_PER_STREAM + (uint32_t)c;  // this lane's segment (both of its queries; no other writer)
+    WideCnt cnt = {0, 0};
 
     if (n_my > 0) {
         // ---- query fragments: resident for the whole kernel
-        wv4i qf[NF];
-        {
-            const uint8_t *qrow = a.qmat + (size_t)myq * a.stride;
+        wv4i qf[NK][2];
 #pragma unroll
-            for (int x = 0; x < NF; x++) qf[x] = *(const wv4i *)(qrow + (x * 2 + h) * 16);
+        for (int q = 0; q < 2; q++) {
+            const uint8_t *qrow = a.qmat + (size_t)(wave * 32 + 16 * q + n) * a.stride;
+#pragma unroll
+            for (int i = 0; i < NK; i++) qf[i][q] = *(const wv4i *)(qrow + (4 * i + c) * 16);
         }
-        QInfo qi = a.qinfo[myq];
-        float thr = MODE == 1 ? a.thr[myq] : 0.f;
+        QInfo qi[2];
+        float thr[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            qi[q] = a.qinfo[wave * 32 + 16 * q + n];
+            thr[q] = MODE == 1 ? a.thr[wave * 32 + 16 * q + n] : 0.f;
+        }
         // retire the compiler's own loads here (it cannot see the asm waits below)
 #pragma unroll
-        for (int x = 0; x < NF; x++) asm volatile("" : "+v"(qf[x]));
-        asm volatile("" : "+v"(qi.bb), "+v"(qi.dscale), "+v"(qi.eA), "+v"(qi.eR), "+v"(thr));
+        for (int i = 0; i < NK; i++) asm volatile("" : "+v"(qf[i][0]), "+v"(qf[i][1]));
+#pragma unroll
+        for (int q = 0; q < 2; q++) asm volatile("" : "+v"(qi[q].bb), "+v"(qi[q].dscale), "+v"(qi[q].eA), "+v"(qi[q].eR), "+v"(thr[q]));
         wait_vm<0>();
-        // filter test folded into per-lane constants (key / err algebra of DESIGN.md §4.2, as in k_scan)
-        const float c1 = 1.0f - qi.eR, m2d = -2.0f * qi.dscale, hd = qi.dscale > 0.f ? 0.5f / qi.dscale : 0.f;
-        const float tS = COS ? (qi.dscale > 0.f ? -(thr + qi.eA) / qi.dscale : __builtin_inff())
-                             : (qi.dscale > 0.f ? thr + qi.eA - qi.bb : -__builtin_inff());
-        auto score = [&](float d, float x) __attribute__((always_inline)) { return COS ? d * x : __builtin_fmaf(d, m2d, c1 * x); };
-        auto passes = [&](float sv) __attribute__((always_inline)) { return COS ? sv >= tS : sv <= tS; };
-        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)myq) * a.seg_cap;  // MODE 1: this lane's slots
+        // Filter test folded into per-lane constants (key / err algebra of DESIGN.md §4.2, as in k_scan):
+        //   cosine  pass iff d * (1/|a|) >= tS              tS = -(thr + eA) / dscale
+        //   L2      pass iff c1 |a|^2 + m2d d <= tS         tS = thr + eA - bb, c1 = 1 - eR, m2d = -2 dscale
+        // and the necessary condition on d alone from the tile's extreme row scalars (t0 = min, t1 = max of |a| resp. |a|^2):
+        //   cosine  d >= tS * (tS > 0 ? t0 : t1)            L2   d >= (c1 t0 - tS) / (2 dscale)
+        // minus a slack of 2^-18 relative (30x the f32 roundings of the exact test) and 1:
+        //   cosine  bound = tSe * t - 1,  tSe = tS (1 -+ 2^-18), t chosen by the sign of tS
+        //   L2      bound = (x hd - tShd) - (|x| hde + tSae) - 1,  x = c1 t0
+        // A NaN bound (no usable row in the tile, padding query) compares false: nothing passes.
+        float c1[2], m2d[2], tS[2], tSe[2], hd[2], tShd[2], hde[2], tSae[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const bool live = qi[q].dscale > 0.f;  // padding queries: dscale = 0, never pass
+            c1[q] = 1.0f - qi[q].eR;
+            m2d[q] = -2.0f * qi[q].dscale;
+            hd[q] = live ? 0.5f / qi[q].dscale : 0.f;
+            if (COS) {
+                tS[q] = live ? -(thr[q] + qi[q].eA) / qi[q].dscale : __builtin_inff();
+                tSe[q] = tS[q] - fabsf(tS[q]) * 3.8147e-6f;  // (an infinite tS gives NaN: nothing passes)
+            } else {
+                tS[q] = live ? thr[q] + qi[q].eA - qi[q].bb : -__builtin_inff();
+                tSe[q] = 0.f;
+            }
+            tShd[q] = live ? tS[q] * hd[q] : -__builtin_inff();
+            hde[q] = hd[q] * 3.8147e-6f;
+            tSae[q] = live ? fabsf(tS[q]) * hde[q] : 0.f;
+        }
+        auto score = [&](int q, float d, float x) __attribute__((always_inline)) { return COS ? d * x : __builtin_fmaf(d, m2d[q], c1[q] * x); };
+        auto passes = [&](int q, float sv) __attribute__((always_inline)) { return COS ? sv >= tS[q] : sv <= tS[q]; };
+        // MODE 1: this lane's slots for its first query; the second (= +16 queries) sits 16 * seg_cap slots further
+        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)(wave * 32 + n)) * a.seg_cap;
+        const uint32_t seg_q1 = 16u * a.seg_cap;
 
         // ---- LDS-DMA producer state: PC tiles ahead of the consumer
         const uint32_t voff = (uint32_t)lane * 16u;
@@ -139,7 +184,11 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             is_srec = uni64(srec);
             is_dst = i_dst;
             is_rec = i_rec;
+#ifdef PVS_WABL_L2SRC  // energy probe: every tile streams from the same 48 KiB (L2-resident): the transport without the HBM
+            if (false) {
+#else
             if (i_tl + 1 < n_my) {  // past the end: the last tile again (keeps vmcnt uniform; its sums are never looked at)
+#endif
                 src += tile_stride;
                 srec += rec_stride;
             }
@@ -158,6 +207,9 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             }
         };
         auto issue_part = [&](int part) __attribute__((always_inline)) {  // compile-time part: 0..PPW-1 = this wave's row pieces, PPW = the tile record (wave 0)
+#ifdef PVS_WABL_NODMA
+            return;
+#endif
             if (part < PPW)
                 dma16(is_src + part * 1024, voff, is_dst + part * 1024);
             else if (wave == 0)
@@ -173,225 +225,226 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
         // ---- consumer state
         int c_slot = 0, c_nslot = 0, p_nslot = NCN - 1;  // ring slot / record slot of the tile being consumed; record slot of the previous
                                                         // tile (tile "-1": the last slot, preset to NaN — nothing passes, no minimum moves)
-        uint32_t prev_row_base = 0;                 // first row of the previous tile's rows of this lane (sub-tile 0)
+        uint32_t prev_row_base = 0;                 // row 4 c of the previous tile (the lane's first row in row group 0)
         uint32_t wt_cur = sid * a.tile_step;        // workgroup tile being consumed
         const uint32_t wt_step = nstreams * a.tile_step;
-        // A-fragment LDS addresses: 8 swizzled chunk positions of row j, the k-slab and the sub-tile ride in the immediate offset
-        uint32_t swz[8];
+        // A-fragment LDS addresses: row 16 (rg & 1) + n of layout tile rg >> 1, chunk (4 (i & 3) + c) ^ n of k-slab i >> 2: four
+        // swizzled bases; row group, layout tile and k-slab ride in the ds_read immediate offset
+        uint32_t swz[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) swz[i] = (uint32_t)j * 256u + ((((uint32_t)(2 * i + h)) ^ (uint32_t)(j & 15)) << 4);
+        for (int i = 0; i < 4; i++) swz[i] = (uint32_t)n * 256u + ((((uint32_t)(4 * i + c)) ^ (uint32_t)n) << 4);
 
-        // per-row path (pass B: rare): every row of sub-tile s whose sum clears the tile bound gets the exact test
-        auto emit_rows = [&](int s, int eb, uint32_t cnt, auto &&pv) __attribute__((always_inline)) {
+        // the lane's 8 row scalars of layout tile s (rows 16 r2 + 4 c + v), from the previous tile's record
+        auto load_xs = [&](int s, float(&xs)[8]) __attribute__((always_inline)) {
             const float *rec = (const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC;
-            float xh[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                const float4 v = *(const float4 *)(rec + 8 * g4 + 4 * h);
-                xh[4 * g4 + 0] = v.x;
-                xh[4 * g4 + 1] = v.y;
-                xh[4 * g4 + 2] = v.z;
-                xh[4 * g4 + 3] = v.w;
+            for (int r2 = 0; r2 < 2; r2++) {
+                const float4 v = *(const float4 *)(rec + 16 * r2 + 4 * c);
+                xs[4 * r2 + 0] = v.x;
+                xs[4 * r2 + 1] = v.y;
+                xs[4 * r2 + 2] = v.z;
+                xs[4 * r2 + 3] = v.w;
             }
+        };
+        // per-row path of pass B for (query q, layout tile s): the exact test of the lane's 8 rows, a passing row -> one predicated store
+        auto emit_rows = [&](int q, int s, uint32_t k, auto &&pv) __attribute__((always_inline)) {
+            float xs[8];
+            load_xs(s, xs);
+            uint2 *const dst = seg_lane + (q ? seg_q1 : 0u);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int d = pv(s, r);
-                const bool c = d >= eb;
-                if (__builtin_amdgcn_ballot_w64(c) == 0) continue;
-                const bool p = c && passes(score((float)d, xh[r]));
+            for (int r = 0; r < 8; r++) {
+                const int d = pv(2 * s + (r >> 2), q, r & 3);
+                const bool p = passes(q, score(q, (float)d, xs[r]));
+                if (__builtin_amdgcn_ballot_w64(p) == 0) continue;
                 if (p) {
-                    if (cnt < a.seg_cap) seg_lane[cnt] = make_uint2(prev_row_base + (uint32_t)(s * 32 + (r & 3) + 8 * (r >> 2)), (uint32_t)d);
-                    cnt++;
+                    if (k < a.seg_cap) dst[k] = make_uint2(prev_row_base + (uint32_t)(32 * s + 16 * (r >> 2) + (r & 3)), (uint32_t)d);
+                    k++;
                 }
             }
-            return cnt;
+            return k;
         };
 
-        struct Epi {   // pass B, per sub-tile
-            float t0, t1, x;
-            int eb, ebk, m1, m2;
+        struct Epi {
+            float t[RPW][2];                   // per layout tile: min / max row scalar
+            float bnd[2][RPW];                 // per (query, layout tile): the bound on d
+            int mx[2][RPW];                    // running v_max3 fold
+            unsigned long long hit[2][RPW];    // lanes whose fold clears the bound
+            float xs[8];                       // pass A: row scalars of the layout tile being scored
         };
-        struct EpiA {  // pass A
-            float xh[8];
-        };
-        constexpr int EPI_STEPS = MODE == 1 ? 13 : 10;  // per sub-tile
-        // slice m of the previous tile's epilogue for sub-tile s (compile-time m, s); pv(s, r) = its r-th sum
-        auto epi_slice = [&](auto sc, auto mc, Epi &e, EpiA &ea, uint32_t cnt, auto &&pv) __attribute__((always_inline)) {
-            constexpr int s = PVS_CI(sc), m = PVS_CI(mc);
+        // Epilogue slices of the previous tile (compile-time m); pv(rg, q, v) = its sum for row 16 rg + 4 c + v, query 16 q + n.
+        //   pass B: 0 = read the extremes; combo x = 2 q + s at 1 + 5 x: bound + first fold, +1..+3 = folds, +4 = compare;
+        //           21 = decisions.  pass A: per layout tile s: 10 s = read row scalars, 10 s + 1 .. + 8 = one row x two queries each.
+        constexpr int EPI_STEPS = MODE == 1 ? 22 : 10 * RPW;
+        auto epi_slice = [&](auto mc, Epi &e, WideCnt k, auto &&pv) __attribute__((always_inline)) {
+            constexpr int m = PVS_CI(mc);
+#ifdef PVS_WABL_NOEPI
+            if (MODE == 1) {
+                if (m == 21) asm volatile("" ::"v"(pv(0, 0, 0)), "v"(pv(RG - 1, 1, 3)));
+                return k;
+            }
+#endif
             if constexpr (MODE == 1) {
-                if constexpr (m == 0) {  // the tile's extreme row scalars (k_scan_aux: min / max over the rows with a usable norm); tile "-1": NaN
-                    const float2 tmm = *(const float2 *)((const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC + 32);
-                    e.t0 = tmm.x;
-                    e.t1 = tmm.y;
-                } else if constexpr (m == 1) {
-                    // necessary condition for "row passes", from the tile's extremes (same algebra and slack as k_scan):
-                    //   cosine  d/|a| >= tS            =>  d >= tS * (tS > 0 ? min|a| : max|a|)
-                    //   L2      c1|a|^2 - 2 ds d <= tS =>  d >= (c1 * min|a|^2 - tS) / (2 ds)
-                    asm volatile("" : "+v"(e.t0), "+v"(e.t1));  // (the LDS read of slice 0 is waited for here, one MFMA later)
-                    float b, mag;
-                    if (COS) {
-                        b = tS * (tS > 0.f ? e.t0 : e.t1);
-                        mag = fabsf(b);
-                    } else {
-                        const float x = c1 * e.t0;
-                        b = (x - tS) * hd;
-                        mag = (fabsf(x) + fabsf(tS)) * hd;
+                if constexpr (m == 0) {
+#pragma unroll
+                    for (int s = 0; s < RPW; s++) {
+                        const float2 tmm = *(const float2 *)((const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC + 32);
+                        e.t[s][0] = tmm.x;
+                        e.t[s][1] = tmm.y;
                     }
-                    b = b - mag * 3.8147e-6f - 1.0f;
-                    e.eb = b == b ? (int)fminf(fmaxf(ceilf(b), -1.0e9f), 1.0e9f) : 0x7fffffff;
-                    // sums are below 2^24 in magnitude: beyond +-2^26 the bound decides for every row, and the packed form fits
-                    const int ebc = e.eb < -(1 << 26) ? -(1 << 26) : (e.eb > (1 << 26) ? (1 << 26) : e.eb);
-                    e.ebk = ebc * 16;
-                    asm volatile("" : "+v"(e.eb), "+v"(e.ebk));
-                } else if constexpr (m < 10) {
-                    // top two of the packed sums (sum << 4 | slot): d >= eb  <=>  packed >= 16 eb
-                    constexpr int i = m - 2;
-                    const int ka = (int)(((uint32_t)pv(s, 2 * i) << 4) | (uint32_t)(2 * i));
-                    const int kb = (int)(((uint32_t)pv(s, 2 * i + 1) << 4) | (uint32_t)(2 * i + 1));
-                    if constexpr (i == 0) {
-                        e.m1 = max(ka, kb);
-                        e.m2 = min(ka, kb);
-                    } else {
-                        int md;  // second largest of (m1, ka, kb); hipcc has no pattern for v_med3_i32 on three variables
-                        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(md) : "v"(e.m1), "v"(ka), "v"(kb));
-                        e.m2 = max(e.m2, md);
-                        e.m1 = max(e.m1, max(ka, kb));  // v_max3_i32
-                    }
-                    asm volatile("" : "+v"(e.m1), "+v"(e.m2));
-                } else if constexpr (m == 10) {
-                    // the best row's scalar, from the tile record (kept in LDS one tile longer than the rows)
-                    const int r1 = e.m1 & 15;
-                    const int ri = 4 * h + (r1 & 3) + 8 * (r1 >> 2);
-                    e.x = ((const float *)(recring + p_nslot * G::REC_SLOT))[s * PVS_AUX_REC + ri];
-                } else if constexpr (m == 11) {
-                    // wave-uniform decisions: two rows of one lane at or above the bound -> per-row path; else the best row alone
-                    asm volatile("" : "+v"(e.x));  // (slice 10's LDS read is waited for here)
-                    const bool hit2 = e.m2 >= e.ebk;
-                    if (__builtin_amdgcn_ballot_w64(hit2) != 0) {
-                        cnt = emit_rows(s, e.eb, cnt, pv);
-                    } else {
-                        const int d = e.m1 >> 4;
-                        const bool p = e.m1 >= e.ebk && passes(score((float)d, e.x));
-                        if (__builtin_amdgcn_ballot_w64(p) != 0) {
-                            if (p) {
-                                const int r1 = e.m1 & 15;
-                                if (cnt < a.seg_cap)
-                                    seg_lane[cnt] = make_uint2(prev_row_base + (uint32_t)(s * 32 + (r1 & 3) + 8 * (r1 >> 2)), (uint32_t)d);
-                                cnt++;
-                            }
+                } else if constexpr (m == 21) {
+                    // wave-uniform decisions: per (query, layout tile), only if some lane's fold cleared its bound
+                    unsigned long long any = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+#pragma unroll
+                        for (int s = 0; s < RPW; s++) any |= e.hit[q][s];
+                    if (any != 0) {
+#pragma unroll
+                        for (int s = 0; s < RPW; s++) {
+                            if (e.hit[0][s] != 0) k.k0 = emit_rows(0, s, k.k0, pv);
+                            if (e.hit[1][s] != 0) k.k1 = emit_rows(1, s, k.k1, pv);
                         }
+                    }
+                } else {
+                    constexpr int x = (m - 1) / 5, st = (m - 1) % 5, q = x >> 1, s = x & 1;
+                    if constexpr (s < RPW) {
+                        if constexpr (st == 0) {
+                            if constexpr (x == 0) {
+#pragma unroll
+                                for (int ss = 0; ss < RPW; ss++) asm volatile("" : "+v"(e.t[ss][0]), "+v"(e.t[ss][1]));  // (slice 0's LDS reads are waited for here)
+                            }
+                            if (COS) {
+                                e.bnd[q][s] = __builtin_fmaf(tSe[q], tS[q] > 0.f ? e.t[s][0] : e.t[s][1], -1.0f);
+                            } else {
+                                const float xx = c1[q] * e.t[s][0];
+                                e.bnd[q][s] = (__builtin_fmaf(xx, hd[q], -tShd[q]) - __builtin_fmaf(fabsf(xx), hde[q], tSae[q])) - 1.0f;
+                            }
+                            e.mx[q][s] = max(pv(2 * s, q, 0), max(pv(2 * s, q, 1), pv(2 * s, q, 2)));
+                        } else if constexpr (st == 1) {
+                            e.mx[q][s] = max(e.mx[q][s], max(pv(2 * s, q, 3), pv(2 * s + 1, q, 0)));
+                        } else if constexpr (st == 2) {
+                            e.mx[q][s] = max(e.mx[q][s], max(pv(2 * s + 1, q, 1), pv(2 * s + 1, q, 2)));
+                        } else if constexpr (st == 3) {
+                            e.mx[q][s] = max(e.mx[q][s], pv(2 * s + 1, q, 3));
+                        } else {
+                            e.hit[q][s] = __builtin_amdgcn_ballot_w64((float)e.mx[q][s] >= e.bnd[q][s]);
+                        }
+                        if constexpr (st < 4) asm volatile("" : "+v"(e.mx[q][s]));  // keep the slice where it is (the optimizer would sink the fold behind the last MFMA)
                     }
                 }
             } else {
-                // rows 0-7 of the lane's 16 in slices 0-4, rows 8-15 in slices 5-9 (eight row scalars live at a time)
-                constexpr int half = m / 5, i = m % 5;
-                if constexpr (i == 0) {
-                    const float *rec = (const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC;
+                constexpr int s = m / 10, st = m % 10;
+                if constexpr (st == 0) {
+                    load_xs(s, e.xs);
+                } else if constexpr (st <= 8) {
+                    // upper bound of the key of one row for the lane's two queries: key + err (NaN — padding, zero norm, masked — never wins a fmin)
+                    constexpr int r = st - 1;  // row 16 (r >> 2) + 4 c + (r & 3) of layout tile s
 #pragma unroll
-                    for (int g4 = 0; g4 < 2; g4++) {
-                        const float4 v = *(const float4 *)(rec + 8 * (2 * half + g4) + 4 * h);
-                        ea.xh[4 * g4 + 0] = v.x;
-                        ea.xh[4 * g4 + 1] = v.y;
-                        ea.xh[4 * g4 + 2] = v.z;
-                        ea.xh[4 * g4 + 3] = v.w;
-                    }
-                } else {
-                    // upper bound of the key of two rows: key + err (NaN — padding, zero norm, masked — never wins a fmin)
-#pragma unroll
-                    for (int rr = 2 * (i - 1); rr < 2 * i; rr++) {
-                        constexpr int r0 = 8 * half;
-                        const float sv = score((float)pv(s, r0 + rr), ea.xh[rr]);
-                        const float ub = COS ? __builtin_fmaf(-sv, qi.dscale, qi.eA) : sv + (qi.bb + qi.eA) + 2.0f * qi.eR * ea.xh[rr];
-                        mins[MODE == 0 ? r0 + rr : 0] = fminf(mins[MODE == 0 ? r0 + rr : 0], ub);
+                    for (int q = 0; q < 2; q++) {
+                        const float sv = score(q, (float)pv(2 * s + (r >> 2), q, r & 3), e.xs[r]);
+                        const float ub = COS ? __builtin_fmaf(-sv, qi[q].dscale, qi[q].eA) : sv + (qi[q].bb + qi[q].eA) + 2.0f * qi[q].eR * e.xs[r];
+                        mins[q][MODE == 0 ? r : 0] = fminf(mins[q][MODE == 0 ? r : 0], ub);
                     }
                 }
             }
-            return cnt;
+            return k;
         };
 
-        // One tile: 2 * NF MFMAs (two accumulation chains) with the LDS-DMA pieces of the tile PC ahead and the previous tile's
-        // epilogue slices between them.  Accumulators alternate between two register sets; the previous tile's sums are read where
-        // the matrix core left them.
-        auto run_tile = [&](wv16i(&acc)[RPW], uint32_t tcnt, auto &&pv) __attribute__((always_inline)) {
+        // One tile: NG MFMAs with the LDS-DMA pieces of the tile PC ahead and the previous tile's epilogue slices between them.
+        // Accumulators alternate between two register sets; the previous tile's sums are read where the matrix core left them.
+        auto run_tile = [&](wv4i(&acc)[RG][2], WideCnt k, auto &&pv) __attribute__((always_inline)) {
             if (wave == 0)
                 wait_vm<(PC - 1) * (PPW + 1)>();
             else
                 wait_vm<(PC - 1) * PPW>();
+#ifndef PVS_WABL_NOBAR
             wg_barrier();
+#endif
             issue_begin();  // refills the slot the previous tile occupied
             const uint8_t *cb = ring + c_slot * G::TILE_BYTES;
-            const uint8_t *fb[8];
+            const uint8_t *fb[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) fb[i] = cb + swz[i];
-            Epi e[RPW];
-            EpiA ea;
-            constexpr int PF = MODE == 0 ? 1 : 2;  // k-steps of A fragments read ahead (pass A holds 16 minima and 8 row scalars more per lane)
-            wv4i af[RPW][NF];
-            auto frag = [&](int t) __attribute__((always_inline)) {
+            for (int i = 0; i < 4; i++) fb[i] = cb + swz[i];
+            Epi e;
 #pragma unroll
-                for (int s = 0; s < RPW; s++) af[s][t] = *(const wv4i *)(fb[t & 7] + s * G::SUB_BYTES + (t >> 3) * 8192);
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int s = 0; s < RPW; s++) e.hit[q][s] = 0;
+            wv4i af[NK][RG];
+            auto frag = [&](int i, int rg) __attribute__((always_inline)) {  // k step i, row group rg
+#ifdef PVS_WABL_NOREAD
+                af[i][rg] = qf[(i + rg + 1) % NK][rg & 1];
+                return;
+#endif
+                af[i][rg] = *(const wv4i *)(fb[i & 3] + (rg >> 1) * G::SUB_BYTES + (i >> 2) * 8192 + (rg & 1) * 4096);
             };
 #pragma unroll
-            for (int t = 0; t < PF && t < NF; t++) frag(t);
+            for (int rg = 0; rg < RG; rg++) frag(0, rg);
             __builtin_amdgcn_sched_barrier(0);
-            const wv16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            static_for<0, NF>([&](auto tc) __attribute__((always_inline)) {
-                constexpr int t = PVS_CI(tc);
-                if constexpr (t + PF < NF) frag(t + PF);
-                static_for<0, RPW>([&](auto sc) __attribute__((always_inline)) {
-                    constexpr int s = PVS_CI(sc);
-                    constexpr int g = t * RPW + s;  // MFMA gap index, 0 .. NG-1
-                    if constexpr (t == 0)
-                        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s][t], qf[t], zero, 0, 0, 0);
-                    else
-                        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s][t], qf[t], acc[s], 0, 0, 0);
-                    static_for<g * (PPW + 1) / NG, (g + 1) * (PPW + 1) / NG>([&](auto pc) __attribute__((always_inline)) { issue_part(PVS_CI(pc)); });
-                    // epilogue slices: sub-tile 0's over the first half of the gaps, sub-tile 1's over the second (RPW = 1: all gaps)
-                    constexpr int GPS = NG / RPW;  // gaps per sub-tile
-                    constexpr int es = g / GPS, eg = g % GPS;
-                    static_for<eg * EPI_STEPS / GPS, (eg + 1) * EPI_STEPS / GPS>(
-                        [&](auto mc) __attribute__((always_inline)) { tcnt = epi_slice(std::integral_constant<int, es>{}, mc, e[es], ea, tcnt, pv); });
-                    __builtin_amdgcn_sched_barrier(0);
+            const wv4i zero = {0, 0, 0, 0};
+            static_for<0, NK>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = PVS_CI(ic);
+                static_for<0, RG>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int rg = PVS_CI(rc);
+                    static_for<0, 2>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = PVS_CI(qc);
+                        constexpr int g = (i * RG + rg) * 2 + q;  // MFMA gap index, 0 .. NG-1
+                        if constexpr (i == 0)
+                            acc[rg][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i][rg], qf[i][q], zero, 0, 0, 0);
+                        else
+                            acc[rg][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i][rg], qf[i][q], acc[rg][q], 0, 0, 0);
+                        if constexpr (q == 0 && i + 1 < NK) frag(i + 1, rg);  // the next k step's fragment of this row group
+                        static_for<g * (PPW + 1) / NG, (g + 1) * (PPW + 1) / NG>([&](auto pc) __attribute__((always_inline)) { issue_part(PVS_CI(pc)); });
+                        static_for<g * EPI_STEPS / NG, (g + 1) * EPI_STEPS / NG>(
+                            [&](auto mc) __attribute__((always_inline)) { k = epi_slice(mc, e, k, pv); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 });
             });
             if (++c_slot == NC) c_slot = 0;
             p_nslot = c_nslot;
             if (++c_nslot == NCN) c_nslot = 0;
-            prev_row_base = wt_cur * (uint32_t)G::TILE_ROWS + 4u * (uint32_t)h;
+            prev_row_base = wt_cur * (uint32_t)G::TILE_ROWS + 4u * (uint32_t)c;
             wt_cur += wt_step;
-            return tcnt;
+            return k;
         };
         // The last tile's epilogue runs inside one extra "ghost" tile (the DMA stream re-reads the last tile past the end).
         {
-            wv16i accA[RPW], accB[RPW];
+            wv4i accA[RG][2], accB[RG][2];
 #pragma unroll
-            for (int s = 0; s < RPW; s++)
+            for (int rg = 0; rg < RG; rg++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) accB[s][r] = 0;  // tile "-1"
-            auto pa = [&](int s, int r) __attribute__((always_inline)) { return accA[s][r]; };
-            auto pb = [&](int s, int r) __attribute__((always_inline)) { return accB[s][r]; };
+                for (int q = 0; q < 2; q++) accB[rg][q] = wv4i{0, 0, 0, 0};  // tile "-1"
+            auto pa = [&](int rg, int q, int v) __attribute__((always_inline)) { return accA[rg][q][v]; };
+            auto pb = [&](int rg, int q, int v) __attribute__((always_inline)) { return accB[rg][q][v]; };
             for (int tl = 0; tl < n_my + 1; tl += 2) {
-                mycnt = run_tile(accA, mycnt, pb);
-                if (tl + 1 < n_my + 1) mycnt = run_tile(accB, mycnt, pa);
+                cnt = run_tile(accA, cnt, pb);
+                if (tl + 1 < n_my + 1) cnt = run_tile(accB, cnt, pa);
             }
         }
         wait_vm<0>();  // retire the tail DMAs (and the candidate stores) before the wave exits
     }
     if constexpr (MODE == 1) {
-        if (sid < nstreams) a.seg_cnt[(size_t)myq * a.seg_stride + seg] = mycnt;  // every lane's fill count (above seg_cap: overflowed)
+        if (sid < nstreams) {  // every lane's fill counts (above seg_cap: overflowed)
+            a.seg_cnt[(size_t)(wave * 32 + n) * a.seg_stride + seg] = cnt.k0;
+            a.seg_cnt[(size_t)(wave * 32 + 16 + n) * a.seg_stride + seg] = cnt.k1;
+        }
     } else {
         if (sid < nstreams) {
-            const uint32_t gr = a.gmin_per_lane;  // fold the 16 minima of a lane to gmin_per_lane (a power of two)
+            const uint32_t gr = a.gmin_per_lane;  // fold the 8 minima of a (lane, query) to gmin_per_lane (a power of two <= 8)
 #pragma unroll
-            for (int sft = 8; sft >= 1; sft >>= 1)
-                if (gr <= (uint32_t)sft) {
+            for (int q = 0; q < 2; q++) {
 #pragma unroll
-                    for (int r = 0; r < sft; r++) mins[r] = fminf(mins[r], mins[r + sft]);
-                }
-            float *o = a.gmin + (size_t)myq * a.groups_per_query + (size_t)(sid * 2 + h) * gr;
+                for (int sft = 4; sft >= 1; sft >>= 1)
+                    if (gr <= (uint32_t)sft) {
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                if ((uint32_t)r < gr) o[r] = mins[r];
+                        for (int r = 0; r < sft; r++) mins[q][r] = fminf(mins[q][r], mins[q][r + sft]);
+                    }
+                float *o = a.gmin + (size_t)(wave * 32 + 16 * q + n) * a.groups_per_query + (size_t)(sid * PVS_WIDE_SEG_PER_STREAM + c) * gr;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+                    if ((uint32_t)r < gr) o[r] = mins[q][r];
+            }
         }
     }
 }

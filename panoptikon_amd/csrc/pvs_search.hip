@@ -134,14 +134,14 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
         const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
         const uint32_t per_cu_a = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
-        const uint32_t rt = a.qgroups >= 4 ? 1 : 4 / a.qgroups;  // row sub-tiles per workgroup
-        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (rt * 32)});
+        const uint32_t spp = pvs_scan_segs_per_stream(a.qgroups);  // lanes per query and workgroup stream (= its candidate segments)
+        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.qgroups))});
         a.mode = 0;
         // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
         // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
-        a.gmin_per_lane = 16;
-        while (a.gmin_per_lane > 1 && (uint64_t)a.grid * rt * 2 * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
-        a.groups_per_query = a.grid * rt * 2 * a.gmin_per_lane;
+        a.gmin_per_lane = pvs_scan_gmin_max(a.qgroups);
+        while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
+        a.groups_per_query = a.grid * spp * a.gmin_per_lane;
         span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
@@ -160,8 +160,9 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         }
         static const uint32_t per_cu_env = getenv("PVS_SCAN_WG_PER_CU") ? (uint32_t)atoi(getenv("PVS_SCAN_WG_PER_CU")) : 0;  // tuning
         const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : (per_cu_env && a.qgroups == 4 ? per_cu_env : 2);
-        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu / a.qsplit, PVS_SEG_PAIRS / (batch_pad * rt * 2)});
-        a.n_segments = a.grid * rt * 2;
+        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu / a.qsplit,
+                                     (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.qgroups)))});
+        a.n_segments = a.grid * spp;
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
         span_end(ix, c);
@@ -181,6 +182,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         f.seg_cnt = c.d_seg_cnt;
         f.n_segments = a.n_segments;
         f.seg_queries = batch_pad;
+        f.seg_cap = pvs_scan_seg_cap(a.qgroups);
         f.cand = c.d_cand;
         static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
         static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;
