@@ -11,4 +11,4 @@ hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric
     }
     return hipErrorInvalidValue;
 }
-uint32_t pvs_scan_wide_rows(uint32_t kslabs) { return kslabs <= 3 ? 64u : 32u; }
+uint32_t pvs_scan_wide_rows(uint32_t kslabs) { return (uint32_t)(kslabs <= 3 ? 64u : 32u); }

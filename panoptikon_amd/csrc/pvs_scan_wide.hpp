@@ -50,9 +50,9 @@ __device__ static inline __attribute__((always_inline)) void static_for(F &&f) {
 }
 #define PVS_CI(x) (decltype(x)::value)
 
-template <int KSLABS>
+template <int KSLABS, int NQ>
 struct WideGeo {
-    static constexpr int WAVES = 8;                       // 32 queries per wave
+    static constexpr int WAVES = 16 / NQ;                 // 16 NQ queries per wave: 8 waves x 32 (two per SIMD) or 4 waves x 64 (one per SIMD)
     static constexpr int RPW = KSLABS <= 3 ? 2 : 1;       // 32-row layout tiles per workgroup tile
     static constexpr int TILE_ROWS = 32 * RPW;
     static constexpr int RG = 2 * RPW;                    // 16-row A fragments per k step
@@ -71,17 +71,19 @@ struct WideGeo {
     static_assert((PC - 1) * (PPW + 1) <= 63, "vmcnt is a 6-bit counter");
 };
 
-struct WideCnt {  // fill counts of a lane's two (segment, query) lists
-    uint32_t k0, k1;
+template <int NQ>
+struct WideCnt {  // fill counts of a lane's (segment, query) lists
+    uint32_t k[NQ];
 };
 
 // MODE 0 = pass A (group minima), MODE 1 = pass B (candidates)
-template <int KSLABS, int METRIC, int MODE>
-__global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
-    using G = WideGeo<KSLABS>;
+template <int KSLABS, int NQ, int METRIC, int MODE>
+__global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK a) {
+    using G = WideGeo<KSLABS, NQ>;
+    constexpr int QPW = 16 * NQ;         // queries per wave
     constexpr int RPW = G::RPW, RG = G::RG, NC = G::NC, PC = G::PC, NCN = G::NCN, PPW = G::PPW;
     constexpr int NK = KSLABS * 4;       // k steps of 64 bytes
-    constexpr int NG = NK * RG * 2;      // MFMAs (= filler gaps) per tile
+    constexpr int NG = NK * RG * NQ;     // MFMAs (= filler gaps) per tile
     constexpr bool COS = METRIC == PVS_COSINE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;                           // [NC][TILE_BYTES]
@@ -99,35 +101,39 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
     const int n_my = (sid < n_samp && sid < nstreams) ? (int)((n_samp - sid + nstreams - 1) / nstreams) : 0;
 
     constexpr int NMIN = MODE == 0 ? 8 : 1;
-    float mins[2][NMIN];  // pass A: per query 8 minima, one per (row group parity, v): 8 disjoint row groups
+    float mins[NQ][NMIN];  // pass A: per query 8 minima, one per (row group parity, v): 8 disjoint row groups
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int r = 0; r < NMIN; r++) mins[q][r] = __builtin_inff();
     const uint32_t seg = sid * PVS_WIDE_SEG_PER_STREAM + (uint32_t)c;  // this lane's segment (both of its queries; no other writer)
-    WideCnt cnt = {0, 0};
+    WideCnt<NQ> cnt;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) cnt.k[q] = 0;
 
     if (n_my > 0) {
         // ---- query fragments: resident for the whole kernel
-        wv4i qf[NK][2];
+        wv4i qf[NK][NQ];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint8_t *qrow = a.qmat + (size_t)(wave * 32 + 16 * q + n) * a.stride;
+        for (int q = 0; q < NQ; q++) {
+            const uint8_t *qrow = a.qmat + (size_t)(wave * QPW + 16 * q + n) * a.stride;
 #pragma unroll
             for (int i = 0; i < NK; i++) qf[i][q] = *(const wv4i *)(qrow + (4 * i + c) * 16);
         }
-        QInfo qi[2];
-        float thr[2];
+        QInfo qi[NQ];
+        float thr[NQ];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            qi[q] = a.qinfo[wave * 32 + 16 * q + n];
-            thr[q] = MODE == 1 ? a.thr[wave * 32 + 16 * q + n] : 0.f;
+        for (int q = 0; q < NQ; q++) {
+            qi[q] = a.qinfo[wave * QPW + 16 * q + n];
+            thr[q] = MODE == 1 ? a.thr[wave * QPW + 16 * q + n] : 0.f;
         }
         // retire the compiler's own loads here (it cannot see the asm waits below)
 #pragma unroll
-        for (int i = 0; i < NK; i++) asm volatile("" : "+v"(qf[i][0]), "+v"(qf[i][1]));
+        for (int i = 0; i < NK; i++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) asm volatile("" : "+v"(qi[q].bb), "+v"(qi[q].dscale), "+v"(qi[q].eA), "+v"(qi[q].eR), "+v"(thr[q]));
+            for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(qf[i][q]));
+#pragma unroll
+        for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(qi[q].bb), "+v"(qi[q].dscale), "+v"(qi[q].eA), "+v"(qi[q].eR), "+v"(thr[q]));
         wait_vm<0>();
         // Filter test folded into per-lane constants (key / err algebra of DESIGN.md §4.2, as in k_scan):
         //   cosine  pass iff d * (1/|a|) >= tS              tS = -(thr + eA) / dscale
@@ -138,9 +144,9 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
         //   cosine  bound = tSe * t - 1,  tSe = tS (1 -+ 2^-18), t chosen by the sign of tS
         //   L2      bound = (x hd - tShd) - (|x| hde + tSae) - 1,  x = c1 t0
         // A NaN bound (no usable row in the tile, padding query) compares false: nothing passes.
-        float c1[2], m2d[2], tS[2], tSe[2], hd[2], tShd[2], hde[2], tSae[2];
+        float c1[NQ], m2d[NQ], tS[NQ], tSe[NQ], hd[NQ], tShd[NQ], hde[NQ], tSae[NQ];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NQ; q++) {
             const bool live = qi[q].dscale > 0.f;  // padding queries: dscale = 0, never pass
             c1[q] = 1.0f - qi[q].eR;
             m2d[q] = -2.0f * qi[q].dscale;
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
         }
         auto score = [&](int q, float d, float x) __attribute__((always_inline)) { return COS ? d * x : __builtin_fmaf(d, m2d[q], c1[q] * x); };
         auto passes = [&](int q, float sv) __attribute__((always_inline)) { return COS ? sv >= tS[q] : sv <= tS[q]; };
-        // MODE 1: this lane's slots for its first query; the second (= +16 queries) sits 16 * seg_cap slots further
-        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)(wave * 32 + n)) * a.seg_cap;
+        // MODE 1: this lane's slots for its first query; query group q (= +16 q queries) sits 16 q seg_cap slots further
+        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)(wave * QPW + n)) * a.seg_cap;
         const uint32_t seg_q1 = 16u * a.seg_cap;
 
         // ---- LDS-DMA producer state: PC tiles ahead of the consumer
@@ -184,11 +190,7 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             is_srec = uni64(srec);
             is_dst = i_dst;
             is_rec = i_rec;
-#ifdef PVS_WABL_L2SRC  // energy probe: every tile streams from the same 48 KiB (L2-resident): the transport without the HBM
-            if (false) {
-#else
             if (i_tl + 1 < n_my) {  // past the end: the last tile again (keeps vmcnt uniform; its sums are never looked at)
-#endif
                 src += tile_stride;
                 srec += rec_stride;
             }
@@ -207,9 +209,6 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             }
         };
         auto issue_part = [&](int part) __attribute__((always_inline)) {  // compile-time part: 0..PPW-1 = this wave's row pieces, PPW = the tile record (wave 0)
-#ifdef PVS_WABL_NODMA
-            return;
-#endif
             if (part < PPW)
                 dma16(is_src + part * 1024, voff, is_dst + part * 1024);
             else if (wave == 0)
@@ -246,16 +245,20 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
                 xs[4 * r2 + 3] = v.w;
             }
         };
-        // per-row path of pass B for (query q, layout tile s): the exact test of the lane's 8 rows, a passing row -> one predicated store
-        auto emit_rows = [&](int q, int s, uint32_t k, auto &&pv) __attribute__((always_inline)) {
+        // per-row path of pass B for (query q, layout tile s), taken by ~8 % of the (wave, q, s) combinations at k = 100: each of
+        // the lane's 8 sums against the tile bound first (one integer compare, no row scalar), the exact test only where that
+        // passes, a passing row -> one predicated store
+        auto emit_rows = [&](int q, int s, float bnd, uint32_t k, auto &&pv) __attribute__((always_inline)) {
             float xs[8];
             load_xs(s, xs);
-            uint2 *const dst = seg_lane + (q ? seg_q1 : 0u);
+            // d >= bnd  <=>  d >= ceil(bnd) for an integer d; sums are below 2^24 in magnitude, a NaN bound passes nothing
+            const int ebi = bnd == bnd ? (int)ceilf(fminf(fmaxf(bnd, -1.0e9f), 1.0e9f)) : 0x7fffffff;
+            uint2 *const dst = seg_lane + (uint32_t)q * seg_q1;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 const int d = pv(2 * s + (r >> 2), q, r & 3);
+                if (__builtin_amdgcn_ballot_w64(d >= ebi) == 0) continue;
                 const bool p = passes(q, score(q, (float)d, xs[r]));
-                if (__builtin_amdgcn_ballot_w64(p) == 0) continue;
                 if (p) {
                     if (k < a.seg_cap) dst[k] = make_uint2(prev_row_base + (uint32_t)(32 * s + 16 * (r >> 2) + (r & 3)), (uint32_t)d);
                     k++;
@@ -266,23 +269,18 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
 
         struct Epi {
             float t[RPW][2];                   // per layout tile: min / max row scalar
-            float bnd[2][RPW];                 // per (query, layout tile): the bound on d
-            int mx[2][RPW];                    // running v_max3 fold
-            unsigned long long hit[2][RPW];    // lanes whose fold clears the bound
+            float bnd[NQ][RPW];                // per (query, layout tile): the bound on d
+            int mx[NQ][RPW];                   // running v_max3 fold
+            unsigned long long hit[NQ][RPW];   // lanes whose fold clears the bound
             float xs[8];                       // pass A: row scalars of the layout tile being scored
         };
         // Epilogue slices of the previous tile (compile-time m); pv(rg, q, v) = its sum for row 16 rg + 4 c + v, query 16 q + n.
-        //   pass B: 0 = read the extremes; combo x = 2 q + s at 1 + 5 x: bound + first fold, +1..+3 = folds, +4 = compare;
-        //           21 = decisions.  pass A: per layout tile s: 10 s = read row scalars, 10 s + 1 .. + 8 = one row x two queries each.
-        constexpr int EPI_STEPS = MODE == 1 ? 22 : 10 * RPW;
-        auto epi_slice = [&](auto mc, Epi &e, WideCnt k, auto &&pv) __attribute__((always_inline)) {
+        //   pass B: 0 = read the extremes; combo x = RPW q + s at 1 + 5 x: bound + first fold, +1..+3 = folds, +4 = compare;
+        //           M_DEC = decisions.  pass A: per layout tile s: 10 s = read row scalars, 10 s + 1 .. + 8 = one row x NQ queries each.
+        constexpr int M_DEC = 1 + 5 * NQ * RPW;
+        constexpr int EPI_STEPS = MODE == 1 ? M_DEC + 1 : 10 * RPW;
+        auto epi_slice = [&](auto mc, Epi &e, WideCnt<NQ> k, auto &&pv) __attribute__((always_inline)) {
             constexpr int m = PVS_CI(mc);
-#ifdef PVS_WABL_NOEPI
-            if (MODE == 1) {
-                if (m == 21) asm volatile("" ::"v"(pv(0, 0, 0)), "v"(pv(RG - 1, 1, 3)));
-                return k;
-            }
-#endif
             if constexpr (MODE == 1) {
                 if constexpr (m == 0) {
 #pragma unroll
@@ -291,23 +289,23 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
                         e.t[s][0] = tmm.x;
                         e.t[s][1] = tmm.y;
                     }
-                } else if constexpr (m == 21) {
+                } else if constexpr (m == M_DEC) {
                     // wave-uniform decisions: per (query, layout tile), only if some lane's fold cleared its bound
                     unsigned long long any = 0;
 #pragma unroll
-                    for (int q = 0; q < 2; q++)
+                    for (int q = 0; q < NQ; q++)
 #pragma unroll
                         for (int s = 0; s < RPW; s++) any |= e.hit[q][s];
                     if (any != 0) {
 #pragma unroll
-                        for (int s = 0; s < RPW; s++) {
-                            if (e.hit[0][s] != 0) k.k0 = emit_rows(0, s, k.k0, pv);
-                            if (e.hit[1][s] != 0) k.k1 = emit_rows(1, s, k.k1, pv);
-                        }
+                        for (int s = 0; s < RPW; s++)
+#pragma unroll
+                            for (int q = 0; q < NQ; q++)
+                                if (e.hit[q][s] != 0) k.k[q] = emit_rows(q, s, e.bnd[q][s], k.k[q], pv);
                     }
                 } else {
-                    constexpr int x = (m - 1) / 5, st = (m - 1) % 5, q = x >> 1, s = x & 1;
-                    if constexpr (s < RPW) {
+                    constexpr int x = (m - 1) / 5, st = (m - 1) % 5, q = x / RPW, s = x % RPW;
+                    {
                         if constexpr (st == 0) {
                             if constexpr (x == 0) {
 #pragma unroll
@@ -337,10 +335,10 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
                 if constexpr (st == 0) {
                     load_xs(s, e.xs);
                 } else if constexpr (st <= 8) {
-                    // upper bound of the key of one row for the lane's two queries: key + err (NaN — padding, zero norm, masked — never wins a fmin)
+                    // upper bound of the key of one row for the lane's queries: key + err (NaN — padding, zero norm, masked — never wins a fmin)
                     constexpr int r = st - 1;  // row 16 (r >> 2) + 4 c + (r & 3) of layout tile s
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
+                    for (int q = 0; q < NQ; q++) {
                         const float sv = score(q, (float)pv(2 * s + (r >> 2), q, r & 3), e.xs[r]);
                         const float ub = COS ? __builtin_fmaf(-sv, qi[q].dscale, qi[q].eA) : sv + (qi[q].bb + qi[q].eA) + 2.0f * qi[q].eR * e.xs[r];
                         mins[q][MODE == 0 ? r : 0] = fminf(mins[q][MODE == 0 ? r : 0], ub);
@@ -352,14 +350,12 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
 
         // One tile: NG MFMAs with the LDS-DMA pieces of the tile PC ahead and the previous tile's epilogue slices between them.
         // Accumulators alternate between two register sets; the previous tile's sums are read where the matrix core left them.
-        auto run_tile = [&](wv4i(&acc)[RG][2], WideCnt k, auto &&pv) __attribute__((always_inline)) {
+        auto run_tile = [&](wv4i(&acc)[RG][NQ], WideCnt<NQ> k, auto &&pv) __attribute__((always_inline)) {
             if (wave == 0)
                 wait_vm<(PC - 1) * (PPW + 1)>();
             else
                 wait_vm<(PC - 1) * PPW>();
-#ifndef PVS_WABL_NOBAR
             wg_barrier();
-#endif
             issue_begin();  // refills the slot the previous tile occupied
             const uint8_t *cb = ring + c_slot * G::TILE_BYTES;
             const uint8_t *fb[4];
@@ -367,15 +363,11 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             for (int i = 0; i < 4; i++) fb[i] = cb + swz[i];
             Epi e;
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < NQ; q++)
 #pragma unroll
                 for (int s = 0; s < RPW; s++) e.hit[q][s] = 0;
             wv4i af[NK][RG];
             auto frag = [&](int i, int rg) __attribute__((always_inline)) {  // k step i, row group rg
-#ifdef PVS_WABL_NOREAD
-                af[i][rg] = qf[(i + rg + 1) % NK][rg & 1];
-                return;
-#endif
                 af[i][rg] = *(const wv4i *)(fb[i & 3] + (rg >> 1) * G::SUB_BYTES + (i >> 2) * 8192 + (rg & 1) * 4096);
             };
 #pragma unroll
@@ -386,14 +378,14 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
                 constexpr int i = PVS_CI(ic);
                 static_for<0, RG>([&](auto rc) __attribute__((always_inline)) {
                     constexpr int rg = PVS_CI(rc);
-                    static_for<0, 2>([&](auto qc) __attribute__((always_inline)) {
+                    static_for<0, NQ>([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = PVS_CI(qc);
-                        constexpr int g = (i * RG + rg) * 2 + q;  // MFMA gap index, 0 .. NG-1
+                        constexpr int g = (i * RG + rg) * NQ + PVS_CI(qc);  // MFMA gap index, 0 .. NG-1
                         if constexpr (i == 0)
                             acc[rg][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i][rg], qf[i][q], zero, 0, 0, 0);
                         else
                             acc[rg][q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i][rg], qf[i][q], acc[rg][q], 0, 0, 0);
-                        if constexpr (q == 0 && i + 1 < NK) frag(i + 1, rg);  // the next k step's fragment of this row group
+                        if constexpr (PVS_CI(qc) == 0 && i + 1 < NK) frag(i + 1, rg);  // the next k step's fragment of this row group
                         static_for<g * (PPW + 1) / NG, (g + 1) * (PPW + 1) / NG>([&](auto pc) __attribute__((always_inline)) { issue_part(PVS_CI(pc)); });
                         static_for<g * EPI_STEPS / NG, (g + 1) * EPI_STEPS / NG>(
                             [&](auto mc) __attribute__((always_inline)) { k = epi_slice(mc, e, k, pv); });
@@ -410,11 +402,11 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
         };
         // The last tile's epilogue runs inside one extra "ghost" tile (the DMA stream re-reads the last tile past the end).
         {
-            wv4i accA[RG][2], accB[RG][2];
+            wv4i accA[RG][NQ], accB[RG][NQ];
 #pragma unroll
             for (int rg = 0; rg < RG; rg++)
 #pragma unroll
-                for (int q = 0; q < 2; q++) accB[rg][q] = wv4i{0, 0, 0, 0};  // tile "-1"
+                for (int q = 0; q < NQ; q++) accB[rg][q] = wv4i{0, 0, 0, 0};  // tile "-1"
             auto pa = [&](int rg, int q, int v) __attribute__((always_inline)) { return accA[rg][q][v]; };
             auto pb = [&](int rg, int q, int v) __attribute__((always_inline)) { return accB[rg][q][v]; };
             for (int tl = 0; tl < n_my + 1; tl += 2) {
@@ -426,21 +418,21 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
     }
     if constexpr (MODE == 1) {
         if (sid < nstreams) {  // every lane's fill counts (above seg_cap: overflowed)
-            a.seg_cnt[(size_t)(wave * 32 + n) * a.seg_stride + seg] = cnt.k0;
-            a.seg_cnt[(size_t)(wave * 32 + 16 + n) * a.seg_stride + seg] = cnt.k1;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) a.seg_cnt[(size_t)(wave * QPW + 16 * q + n) * a.seg_stride + seg] = cnt.k[q];
         }
     } else {
         if (sid < nstreams) {
             const uint32_t gr = a.gmin_per_lane;  // fold the 8 minima of a (lane, query) to gmin_per_lane (a power of two <= 8)
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
+            for (int q = 0; q < NQ; q++) {
 #pragma unroll
                 for (int sft = 4; sft >= 1; sft >>= 1)
                     if (gr <= (uint32_t)sft) {
 #pragma unroll
                         for (int r = 0; r < sft; r++) mins[q][r] = fminf(mins[q][r], mins[q][r + sft]);
                     }
-                float *o = a.gmin + (size_t)(wave * 32 + 16 * q + n) * a.groups_per_query + (size_t)(sid * PVS_WIDE_SEG_PER_STREAM + c) * gr;
+                float *o = a.gmin + (size_t)(wave * QPW + 16 * q + n) * a.groups_per_query + (size_t)(sid * PVS_WIDE_SEG_PER_STREAM + c) * gr;
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if ((uint32_t)r < gr) o[r] = mins[q][r];
@@ -449,16 +441,21 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
     }
 }
 
+// NQ = 2: eight waves x 32 queries, two per SIMD.  (NQ = 4 — four waves x 64 queries, one per SIMD, ~400 registers, half the
+// A-fragment reads — measured 1.86 ms against 1.70: the fragment reads do drop from 0.19 to 0.10 ms-equivalents, but the per-row
+// path, now alone on its SIMD, doubles; profiles/r03_wide_ablation.md.)
+constexpr int PVS_WIDE_NQ = 2;
 template <int KS, int METRIC, int MODE>
 static hipError_t scan_wide_launch_one(const ScanK &k, hipStream_t s) {
+    constexpr int NQ = PVS_WIDE_NQ;
     static std::atomic<bool> configured{false};
-    constexpr int lds = WideGeo<KS>::LDS_BYTES;
+    constexpr int lds = WideGeo<KS, NQ>::LDS_BYTES;
     if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_scan_wide<KS, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_scan_wide<KS, NQ, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan_wide<KS, METRIC, MODE>), dim3(k.grid), dim3(512), lds, s, k);
+    hipLaunchKernelGGL((k_scan_wide<KS, NQ, METRIC, MODE>), dim3(k.grid), dim3(1024 / NQ), lds, s, k);
     return hipGetLastError();
 }
 template <int KS>

@@ -44,14 +44,14 @@ int main(int argc, char **argv) {
     const int launches = argc > 3 ? atoi(argv[3]) : 40;
     constexpr int KS = 3;
     const uint32_t stride = KS * 256, batch = 256, grid = 256;
-    const uint32_t wg_rows = WideGeo<KS>::TILE_ROWS;
+    const uint32_t wg_rows = WideGeo<KS, PVS_WIDE_NQ>::TILE_ROWS;
     const uint64_t cap = (n_rows + 127) / 128 * 128 + 128;
     uint8_t *rows, *qmat;
     float *aux, *thr;
     QInfo *qinfo;
     uint2 *seg;
     uint32_t *seg_cnt;
-    CK(hipMalloc(&rows, cap * stride));
+    CK(hipMalloc(&rows, cap * stride));  // (hipDeviceMallocUncached: no difference, 1.72 ms both)
     CK(hipMalloc(&aux, cap / 32 * PVS_AUX_REC * 4));
     CK(hipMalloc(&qmat, batch * stride));
     CK(hipMalloc(&qinfo, batch * sizeof(QInfo)));
