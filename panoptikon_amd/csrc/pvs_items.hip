@@ -70,7 +70,7 @@ pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_
         a.groups_per_query = 0;
         a.mode = 2;
         a.tile_step = 1;
-        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
+        const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);  // (MODE 2 always runs on k_scan)
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
         a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);

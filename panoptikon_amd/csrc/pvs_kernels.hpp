@@ -41,7 +41,7 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
 struct ScanArgs {
     int dtype, metric;
     uint32_t kslabs;        // stride / 256
-    uint32_t qgroups;       // batch_pad / 32 in {1,2,4} (and 8 where pvs_scan_max_batch() is 256)
+    uint32_t qgroups;       // batch_pad / 32 in {1,2,4} (and 8 where pvs_scan_max_batch() is 256: k_scan_wide)
     const uint8_t *rows;
     const float *aux;       // the metric's row-scalar stream in tile records (k_scan_aux): 1/|a| (cosine) or |a|^2 (L2)
     uint32_t stride;
@@ -61,15 +61,17 @@ struct ScanArgs {
     // mode 1: candidates go to per-(segment, query) lists: segment = one wave row of one workgroup stream (grid * RT of them)
     uint2 *seg = nullptr;          // [n_segments][batch_pad][PVS_SEG_CAP] = (row, key bits)
     uint32_t *seg_cnt = nullptr;   // [batch_pad][n_segments] fill counts, written by the scan (above PVS_SEG_CAP = overflowed)
-    uint32_t n_segments = 0;       // out: set by pvs_scan_plan(): grid * RT
-    uint32_t qsplit = 1;           // workgroups per tile stream, each with its own qgroups*32 queries of the batch (mode 1; see ScanK.qsplit)
+    uint32_t n_segments = 0;       // grid * pvs_scan_segs_per_stream
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
-uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs);  // rows per workgroup tile
-uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // RT: 32-row sub-tiles per workgroup
-uint32_t pvs_scan_segs_per_stream(uint32_t qgroups);  // candidate segments (= lanes per query that hold group minima) per workgroup stream
-uint32_t pvs_scan_seg_cap(uint32_t qgroups);          // slots per (segment, query)
-uint32_t pvs_scan_gmin_max(uint32_t qgroups);         // pass A: minima one lane can supply per query
+// geometry of the filter passes (modes 0 / 1) of a shape — it depends on which kernel serves them (pvs_scan_is_wide)
+bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs);
+uint32_t pvs_scan_wg_rows(int dtype, uint32_t qgroups, uint32_t kslabs);  // rows per workgroup tile
+uint32_t pvs_scan_row_tiles(uint32_t qgroups);  // k_scan's RT: 32-row sub-tiles per workgroup
+uint32_t pvs_scan_segs_per_stream(int dtype, uint32_t qgroups, uint32_t kslabs);  // candidate segments (= lanes per query holding group minima) per workgroup stream
+uint32_t pvs_scan_seg_cap(int dtype, uint32_t qgroups, uint32_t kslabs);          // slots per (segment, query)
+uint32_t pvs_scan_gmin_max(int dtype, uint32_t qgroups, uint32_t kslabs);         // pass A: minima one lane can supply per query
+uint32_t pvs_scan_wg_per_cu(int dtype, uint32_t qgroups, uint32_t kslabs);        // resident workgroups per CU
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
 

@@ -15,11 +15,23 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
                kslabs == 20 || kslabs == 24;
     return false;
 }
-uint32_t pvs_scan_wg_rows(uint32_t qgroups, uint32_t kslabs) { return qgroups == 8 ? pvs_scan_wide_rows(kslabs) : qgroups >= 4 ? 32u : 32u * (4u / qgroups); }
+// Which kernel serves the filter passes (modes 0 and 1) of a shape: k_scan_wide (pvs_scan_wide.hpp: int8, 256 queries at row
+// pitches up to 1 KiB) or k_scan.
+bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs) { return dtype == PVS_I8 && pvs_scan_wide_serves(qgroups, kslabs, 1); }
+uint32_t pvs_scan_wg_rows(int dtype, uint32_t qgroups, uint32_t kslabs) {
+    if (pvs_scan_is_wide(dtype, qgroups, kslabs)) return pvs_scan_wide_rows(kslabs);
+    return qgroups >= 4 ? 32u : 32u * (4u / qgroups);
+}
 uint32_t pvs_scan_row_tiles(uint32_t qgroups) { return qgroups >= 4 ? 1u : 4u / qgroups; }
-uint32_t pvs_scan_segs_per_stream(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(qgroups) * 2u; }
-uint32_t pvs_scan_seg_cap(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP; }
-uint32_t pvs_scan_gmin_max(uint32_t qgroups) { return qgroups == 8 ? PVS_WIDE_GMIN_MAX : 16u; }
+uint32_t pvs_scan_segs_per_stream(int dtype, uint32_t qgroups, uint32_t kslabs) {
+    return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(qgroups) * 2u;
+}
+uint32_t pvs_scan_seg_cap(int dtype, uint32_t qgroups, uint32_t kslabs) { return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP; }
+uint32_t pvs_scan_gmin_max(int dtype, uint32_t qgroups, uint32_t kslabs) { return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_GMIN_MAX : 16u; }
+uint32_t pvs_scan_wg_per_cu(int dtype, uint32_t qgroups, uint32_t kslabs) {
+    if (pvs_scan_is_wide(dtype, qgroups, kslabs)) return 1u;
+    return (qgroups == 1 || kslabs > 4) ? 1u : 2u;
+}
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
@@ -33,11 +45,12 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg = a.seg;
     k.seg_cnt = a.seg_cnt;
     k.seg_queries = a.qgroups * 32;
-    k.seg_cap = pvs_scan_seg_cap(a.qgroups);
-    k.seg_stride = a.grid * pvs_scan_segs_per_stream(a.qgroups);
+    const bool wide = (a.mode == 0 || a.mode == 1) && pvs_scan_is_wide(a.dtype, a.qgroups, a.kslabs);
+    k.seg_cap = wide ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP;
+    k.seg_stride = a.grid * (wide ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(a.qgroups) * 2u);
     k.n_rows = a.n_rows;
     k.stride = a.stride;
-    const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
+    const uint32_t wg_rows = wide ? pvs_scan_wide_rows(a.kslabs) : (a.qgroups >= 4 ? 32u : 32u * (4u / a.qgroups));
     k.n_wgtiles = (uint32_t)((a.n_rows + wg_rows - 1) / wg_rows);
     k.tile_step = a.tile_step ? a.tile_step : 1;
     k.groups_per_query = a.groups_per_query;
@@ -47,11 +60,9 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.dense_flag = a.dense_flag;
     k.dense_ld = a.dense_ld;
     k.batch = a.batch;
-    k.qsplit = a.qsplit ? a.qsplit : 1;
-    k.seg_queries = a.qgroups * 32 * k.qsplit;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
-        e = a.qgroups == 8   ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
+        e = wide            ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
             : a.kslabs <= 4 ? pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                             : pvs_scan_dispatch_i8_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     else if (a.dtype == PVS_F16)

@@ -13,16 +13,13 @@
 // `nt`: every corpus byte is read once per launch by exactly one CU (streaming policy; default / sc0 / sc1 measured 1.80 ms
 // against 1.77 for the 256-query pass).
 __device__ static inline void dma16(const void *sbase, uint32_t voff, uint32_t lds_dst) {
-#ifdef PVS_DMA_M0_CLOBBER  // tuning: tell the compiler M0 is gone instead of saving and restoring it around every piece
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
-#else
+    // (M0 declared clobbered instead of saved and restored: 1.270 vs 1.282 ms at 128 queries, noise)
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
-#endif
 }
 __device__ static inline void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
@@ -41,21 +38,3 @@ __device__ static inline void wait_vm() {
 }
 __device__ static inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-
-// ---- elastic hand-off between the waves of a workgroup (instead of s_barrier): monotonic arrival counters in LDS.
-// `lds_signal` adds one arrival from this wave (call it from every lane: only lane 0 issues the atomic);
-// `lds_await2` polls until both counters have reached their targets, with a bound on the number of polls so that a
-// protocol bug can never hang the device: it returns false when it gave up.
-__device__ static inline void lds_signal(uint32_t lds_counter, int lane) {
-    if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(lds_counter), "v"(1u) : "memory");
-}
-__device__ static inline bool lds_await2(uint32_t lds_a, uint32_t need_a, uint32_t lds_b, uint32_t need_b) {
-    for (int it = 0; it < (1 << 16); it++) {  // ~3 ms at the very least; a legitimate wait is a few microseconds
-        uint32_t va, vb;
-        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(va), "=&v"(vb) : "v"(lds_a), "v"(lds_b) : "memory");
-        const uint32_t sa = __builtin_amdgcn_readfirstlane(va), sb = __builtin_amdgcn_readfirstlane(vb);
-        if ((int)(sa - need_a) >= 0 && (int)(sb - need_b) >= 0) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}

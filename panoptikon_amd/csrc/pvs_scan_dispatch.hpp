@@ -18,11 +18,6 @@ struct ScanK {
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
     uint32_t dense_ld, batch;
-    // Query split: `qsplit` workgroups walk the SAME tile stream, each with its own QG*32 queries (query offset = its index in
-    // the split) — 256 queries as two independent 4-wave workgroups instead of one 8-wave workgroup.  The launch has
-    // 8 * ceil(grid / 8) * qsplit workgroups, numbered so that the workgroups of one stream land on the same XCD (workgroups go
-    // to the XCDs round-robin by index): the second one finds the tile in that XCD's L2.  grid stays the number of STREAMS.
-    uint32_t qsplit;
 };
 
 hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
@@ -31,8 +26,9 @@ hipError_t pvs_scan_dispatch_f16_large(const ScanK &k, uint32_t kslabs, uint32_t
 hipError_t pvs_scan_dispatch_f32_small(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_mid(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
-hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s);  // 256 queries (pvs_scan_wide.hpp)
-uint32_t pvs_scan_wide_rows(uint32_t kslabs);  // rows per workgroup tile of the 256-query kernel
+hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s);  // 256 queries: pvs_scan_wide.hpp
+bool pvs_scan_wide_serves(uint32_t qgroups, uint32_t kslabs, int mode);  // int8: does k_scan_wide serve this pass (else k_scan)
+uint32_t pvs_scan_wide_rows(uint32_t kslabs);  // rows per workgroup tile of k_scan_wide
 hipError_t pvs_scan_dispatch_i8_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f16_xl(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_xl(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

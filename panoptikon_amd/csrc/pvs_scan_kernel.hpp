@@ -13,9 +13,8 @@
 //   pass C  (pvs_kernels_scan.hip) exact rerank of the few survivors.
 //
 // Geometry (64-wide waves, 4 SIMDs/CU, 160 KiB LDS/CU):
-//   workgroup = 4 waves (8 for 256 queries); wave (qw, rt) owns one query group of 32 queries (held in VGPRs for the
-//   whole kernel as MFMA B fragments) and row sub-tile rt (32 rows);
-//   QG = batch_pad/32 in {1,2,4,8} (8 = 256 queries per pass: int8 rows up to 1 KiB); RT = WAVES/QG, tile = 32*RT rows.
+//   workgroup = 4 waves; wave (qw, rt) owns one query group of 32 queries (held in VGPRs for the whole kernel as MFMA B
+//   fragments) and row sub-tile rt (32 rows); QG = batch_pad/32 in {1,2,4}; RT = 4/QG, tile = 32*RT rows.
 //   The corpus streams HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip)
 //   in "slabs" of (32*RT rows x 256 B) grouped into chunks of SPB slabs (the whole 24 KiB tile for
 //   768-B rows and >= 128 queries): NC-chunk ring, NC-1 chunks in flight, one s_barrier and one counted
@@ -34,18 +33,12 @@
 // candidate set is exactly what the per-row test alone would emit.  Only wave-tiles where some lane passes run the
 // per-row test, with the row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
 //
-// What the round-2 measurements say (10M x 768 int8 on MI355X; DESIGN.md §4.1b has the table):
-//   * 128 queries: 1.25-1.30 ms = 5.9-6.1 TB/s; a pure read stream (plain loads or LDS-DMA, pvs_microbench) reaches 7.1 TB/s on the
-//     box and the 32-query instance 6.7: the 128-query pass is bound by how fast a workgroup turns a tile around, and no knob
-//     inside this wave / barrier structure moved it (profiles/r02_tile_phase_profile_b256.txt; DESIGN.md §9 for the way out).
-//   * 256 queries: 2.10 ms.  Ablations of the same binary: MFMA + fragment reads alone 1.32 ms; + LDS-DMA issue 1.57;
-//     + fold and pre-test 1.62; + per-row tests 1.70; + candidate emission 2.10.  The last step is NOT the cost of the
-//     emission instructions (~30 per candidate; replacing staging + flush + global atomics by one LDS atomic and one
-//     scalar store changed nothing): SQ_WAIT_ANY rises by 3,500 wave-cycles per candidate = ~440 cycles of serial
-//     latency in the emitting wave x the 8 waves that meet it at the next per-tile s_barrier (1.3 candidates per
-//     workgroup tile).  Everything a wave does alone is paid eight times; the remaining lever is an elastic hand-off
-//     (per-slot ready/done counters with one tile of slack) instead of the barrier.  Two query groups per wave
-//     (4 waves, ~340 registers, 1 wave per SIMD; PVS_WIDE_GPW2) measured 2.23 ms: nothing hides its in-order issue.
+// What the measurements say (10M x 768 int8 on MI355X):
+//   * 128 queries: 1.25-1.31 ms = 5.9-6.1 TB/s; a pure read stream (plain loads or LDS-DMA, pvs_microbench) reaches 7.1 TB/s on the
+//     box and the 32-query instance 6.7.  The part runs this pass at its 1,400 W limit with the clock lowered: ring depth, prefetch
+//     depth, DMA placement, workgroups per CU and a barrier-free rewrite all measured the same (profiles/r02_tile_phase_profile_b256.txt),
+//     and so did the 16x16x64 instruction shape that pays at 256 queries (profiles/r03_wide_ablation.md).
+//   * 256 queries (int8, row pitch <= 1 KiB) run on k_scan_wide (pvs_scan_wide.hpp), not here.
 #pragma once
 #include <cstdlib>
 
@@ -58,15 +51,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef PVS_NC_SPB3
-#define PVS_NC_SPB3 3   // (tuning: 2 = a two-chunk ring, three workgroups per CU at 128 queries — with PVS_SCAN_WG_PER_CU=3 on the host)
-#endif
-#ifndef PVS_NC_SPB1
-#define PVS_NC_SPB1 8
-#endif
-#ifndef PVS_PF
-#define PVS_PF 4                  // A fragments read ahead of the MFMA that consumes them (tuning experiments override it)
-#endif
 
 template <int DT>
 struct Acc;
@@ -131,99 +115,49 @@ constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 // chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
 template <int QG, int KSLABS>
 struct Geo {
-#ifndef PVS_WIDE_GPW2
-    static constexpr int WAVES = QG == 8 ? 8 : 4;  // 256 queries: 8 waves x 1 group, 2 waves per SIMD (measured 2.10 ms at 10M x 768)
-    static constexpr int GPW = 1;                  // query groups per wave
-#else  // tuning switch: 256 queries as 4 waves x 2 groups, 1 wave per SIMD, ~340 registers (measured 2.23 ms)
     static constexpr int WAVES = 4;
-    static constexpr int GPW = QG == 8 ? 2 : 1;
-#endif
-    static constexpr int QW = QG / GPW;          // waves side by side along the queries
-    static constexpr int RT = WAVES / QW;        // row sub-tiles per workgroup
+    static constexpr int RT = WAVES / QG;        // row sub-tiles per workgroup
     static constexpr int SLAB_ROWS = 32 * RT;
     static constexpr int SLAB_BYTES = SLAB_ROWS * 256;
-    // Tuning switch PVS_QG8_OLD_WAVES_DMA: in the 8-wave instances only the OLDER wave of every SIMD (waves 0-3, which otherwise sit
-    // ~800 cycles at the per-tile barrier) issues LDS-DMA, the younger waves none.  Measured 2.095 / 1.897 ms (k = 100 / 1) against
-    // 2.063 / 1.893 with every wave issuing its share: the DMA issue is not on the critical path either.
-#ifdef PVS_QG8_OLD_WAVES_DMA
-    static constexpr int DMAW = QG == 8 ? 4 : WAVES;   // waves that issue DMA
-#else
-    static constexpr int DMAW = WAVES;
-#endif
-    static constexpr int PPW = 8 * RT / DMAW;  // 1-KiB DMA pieces per issuing wave and slab
-#ifdef PVS_B128_SPB1  // tuning: 128 queries with one k-slab per chunk (a deeper DMA queue, three barriers per tile)
-    static constexpr int SPB = (RT > 1 || QG == 4) ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
-#else
-    static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));
-#endif
+    static constexpr int PPW = 8 * RT / WAVES;   // 1-KiB DMA pieces per wave and slab
+    static constexpr int SPB = RT > 1 ? 1 : (KSLABS % 3 == 0 ? 3 : (KSLABS % 2 == 0 ? 2 : 1));  // k-slabs per chunk
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
-    // 256 queries (one workgroup of 8 waves per CU): the waves hand chunks to each other through arrival counters instead of
-    // a barrier, with one chunk of SLACK — the chunk being refilled is the one consumed two steps ago, so a wave that is
-    // late (a candidate to emit, a slow DMA piece) does not stop the other seven (pvs_lds_dma.hpp: lds_signal / lds_await2).
-#ifdef PVS_ELASTIC
-    static constexpr bool ELASTIC = QG == 8;
-#else
-    static constexpr bool ELASTIC = false;
-#endif
-    static constexpr int SLACK = ELASTIC ? 1 : 0;
-    static constexpr int ring_chunks_that_fit() {  // as many chunks as the 160 KiB hold beside the row-scalar records and the counters
-        int nc = 16;
-        while (nc > 3 && nc * SPB * SLAB_BYTES + (2 + (nc - 1 - SLACK + CPT - 1) / CPT) * WAVES * 256 + 128 > 160 * 1024) nc--;
-        return nc;
-    }
-    static constexpr int NC = QG == 8 ? ring_chunks_that_fit() : (RT > 1 ? 4 : (SPB == 3 ? PVS_NC_SPB3 : (SPB == 2 ? 4 : PVS_NC_SPB1)));  // chunks in the ring
+    // chunks in the ring (measured at 128 queries x 768 B: 2-chunk rings with 2 or 3 workgroups per CU 1.295 / 1.398 ms against 1.28;
+    // one k-slab per chunk with 6 / 8 / 9 chunks 1.35)
+    static constexpr int NC = RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8));
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
-    // chunks in flight: the rest of the ring, but no more than ~96 KiB for the 8-wave instances (a fifth 24-KiB tile in
-    // flight measured 2.08 ms against 1.99 ms with four at 10M x 768 x 256 queries)
-    static constexpr int PC_CAP = 98304 / (SPB * SLAB_BYTES) < 2 ? 2 : 98304 / (SPB * SLAB_BYTES);
-    static constexpr int PC = (QG == 8 && NC - 1 - SLACK > PC_CAP) ? PC_CAP : NC - 1 - SLACK;
+    static constexpr int PC = NC - 1;                                              // chunks in flight
     static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
                                                           // same record): tiles in flight + the previous tile, kept for its epilogue
     static constexpr int VM_PER_CHUNK = PPW * SPB + 1;  // per wave: row DMAs + 1 row-scalar DMA
-    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256 + 128;  // ring, row-scalar records, hand-off counters
+    static constexpr int LDS_BYTES = NS * SLAB_BYTES + NCN * WAVES * 256;  // ring, row-scalar records
+    static_assert(QG == 1 || QG == 2 || QG == 4, "32, 64 or 128 queries per pass");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS per CU");
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
 
-#ifndef PVS_WIDE_GPW2
 constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
-constexpr int scan_threads(int QG) { return QG == 8 ? 512 : 256; }
-#else
-constexpr int scan_threads(int) { return 256; }
-constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || QG == 8 || KSLABS > 4) ? 1 : 2; }
-#endif
 
 template <int DT, int KSLABS, int QG, int METRIC, int MODE>
-__global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
+__global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
     using G = Geo<QG, KSLABS>;
     using A = Acc<DT>;
     using elem_t = typename A::elem;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
-                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, GPW = G::GPW, QW = G::QW, NCN = G::NCN, DMAW = G::DMAW;
+                  SPB = G::SPB, CPT = G::CPT, WAVES = G::WAVES, PPW = G::PPW, NCN = G::NCN;
+    constexpr int GPW = 1, QW = QG;  // one query group per wave, QG waves side by side along the queries
     constexpr bool COS = METRIC == PVS_COSINE;
     constexpr bool PRETEST = MODE == 1 && DT != PVS_F32;  // (f32 rows carry a per-row power-of-two scale in their sums)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *const ring = smem;
     uint8_t *const normring = smem + NS * SLAB_BYTES;  // [NCN][WAVES][256 B]
-    constexpr bool ELASTIC = G::ELASTIC && MODE == 1;   // (the sample pass and the dense pass keep the barrier: their results have no second line of defence)
-    uint32_t *const flags = (uint32_t *)(normring + NCN * WAVES * 256);  // ELASTIC: ready[16], done[16] arrival counters per ring chunk
-    if constexpr (ELASTIC) {
-        if (threadIdx.x < 32) flags[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    bool handoff_ok = true;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qw = wave % QW, rt = wave / QW;
     const int j = lane & 31, h = lane >> 5;  // j: query (B operand / C column) and row (A operand)
-    uint32_t sid = blockIdx.x, qoff = 0;  // this workgroup's tile stream, and its first query in the batch
+    const uint32_t sid = blockIdx.x, qoff = 0;  // this workgroup's tile stream, and its first query in the batch
     const uint32_t nstreams = a.grid;
-    if (a.qsplit > 1) {  // (ScanK.qsplit: streams are numbered so that the workgroups sharing one sit on the same XCD)
-        const uint32_t xcd = blockIdx.x & 7u, r = blockIdx.x >> 3;
-        qoff = (r % a.qsplit) * (uint32_t)(QG * 32);
-        sid = (r / a.qsplit) * 8u + xcd;
-    }
     int myq[GPW];
 #pragma unroll
     for (int g = 0; g < GPW; g++) myq[g] = (int)qoff + (qw * GPW + g) * 32 + j;
@@ -303,14 +237,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             voff[e] = (uint32_t)(r >> 5) * (32u * a.stride) + (uint32_t)(r & 31) * 256u + (uint32_t)lane * 16u;
         }
         const uint32_t nvoff = (uint32_t)(rt * PVS_AUX_REC + lane) * 4u;  // this wave's tile record: 32 row scalars, then the tile's extremes
-        const bool dma_wave = wave < DMAW;   // (wave-uniform) does this wave issue DMA at all
-#ifdef PVS_REC_SHARE  // tuning: with one row sub-tile per workgroup all waves need the SAME tile record — wave 0 alone fetches it
-        constexpr bool REC_SHARE = RT == 1 && DMAW == WAVES;
-#else
-        constexpr bool REC_SHARE = false;
-#endif
-        const int rec_wave = REC_SHARE ? 0 : wave % DMAW;  // whose copy of the tile record this wave reads
-        static_assert(DMAW == WAVES || RT == 1, "record sharing assumes one row sub-tile per workgroup");
+        const int rec_wave = wave;  // every wave fetches its own copy of its tile record
         // A-fragment LDS byte offsets of this lane inside a slab
         const uint32_t frag_row = (uint32_t)(rt * 32 + j) * 256u;
         const uint32_t jx = (uint32_t)(j & 15);
@@ -325,8 +252,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
 
         // ---- DMA issue state (runs PC chunks ahead of the consumer)
         int i_tl = 0, i_ck = 0, i_slot = 0, i_nslot = 0;  // tile, chunk within tile, ring chunk slot, row-scalar ring slot
-        uint32_t i_gen = 0, c_gen = 0;                    // ELASTIC: times the producer / consumer side has wrapped around the ring
-        const uint32_t flags_lds = lds_addr(flags);
         constexpr int DMA_PARTS = SPB * PPW + 1;  // row pieces + the per-row scalars
         const uint8_t *is_base = nullptr;
         const float *is_aux = nullptr;
@@ -341,7 +266,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             const uint64_t wt = (uint64_t)(sid + (uint32_t)tl * nstreams) * a.tile_step;
             is_base = a.rows + wt * tile_bytes + (uint32_t)i_ck * (SPB * 8192u);  // k-slab = 8 KiB per 32-row tile
             is_aux = a.aux + wt * (RT * PVS_AUX_REC);  // one 64-float record per 32-row tile
-            if constexpr (DT == PVS_F32 || QG == 8) {
+            if constexpr (DT == PVS_F32) {
                 // the long unrolls of these instances make hipcc lose track of the uniformity of these two
                 is_base = (const uint8_t *)uni(is_base);
                 is_aux = (const float *)uni(is_aux);
@@ -353,21 +278,14 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 i_tl++;
                 if (++i_nslot == NCN) i_nslot = 0;
             }
-            if (++i_slot == NC) {
-                i_slot = 0;
-                i_gen++;
-            }
+            if (++i_slot == NC) i_slot = 0;
         };
         auto issue_part = [&](int part) {  // part is a compile-time constant at every call site
-#ifdef PVS_ABL_NODMA
-            return;
-#endif
-            if (!dma_wave) return;
             if (part < DMA_PARTS - 1) {
                 const int sb = part / PPW, e = part % PPW;
                 dma16(is_base + sb * 8192, voff[e], is_lds + sb * SLAB_BYTES + e * 1024);
             } else {
-                if (!REC_SHARE || wave == 0) dma4(is_aux, nvoff, is_norm);
+                dma4(is_aux, nvoff, is_norm);
             }
         };
         auto issue = [&]() {
@@ -382,20 +300,9 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         // issues in order, so the two instruction streams must sit in one basic block for the
         // scheduler to interleave them).
         using acc_t = typename A::type;
-#ifdef PVS_TILE_PROF  // tuning build: where a wave's cycles go (s_memtime stamps around the phases of a chunk), printed by two workgroups
-        unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_acc[5] = {0, 0, 0, 0, 0};
-#define PROF_STAMP(i)                                                      \
-    do {                                                                   \
-        prof_t[i] = __builtin_readcyclecounter();                          \
-        if ((i) > 0) prof_acc[i] += prof_t[i] - prof_t[(i) - 1];           \
-        if ((i) == 0 && prof_t[4] != 0) prof_acc[0] += prof_t[0] - prof_t[4]; \
-    } while (0)
-#else
-#define PROF_STAMP(i) do { } while (0)
-#endif
         int c_slot = 0, c_nslot = 0;   // consumer: ring chunk slot, row-scalar slot of the chunk being consumed
         int p_nslot = -1;              // row-scalar slot of the PREVIOUS tile (its last chunk); -1: there is none yet
-        elem_t hold[GPW][16];          // !PARITY: the previous tile's 16 dot products per group
+        elem_t hold[GPW][16];          // the previous tile's 16 dot products per group
 #pragma unroll
         for (int g = 0; g < GPW; g++)
 #pragma unroll
@@ -453,10 +360,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     const float sv = exact(r);
                     c = COS ? (sv >= tS[g]) : (sv <= tS[g]);
                 }
-#ifdef PVS_ABL_NOEMIT
-                asm volatile("" ::"v"(c));
-                c = false;
-#endif
                 mr[r] = __builtin_amdgcn_ballot_w64(c);
             }
 #pragma unroll
@@ -511,9 +414,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         };
         auto epi_micro = [&](int m, Epi &e, auto &&pv) {
-#ifdef PVS_ABL_NOEPI
-            if (MODE == 1) return;
-#endif
             if constexpr (PRETEST) {
                 // Every slice ends in an empty volatile asm on its result: without it the optimizer reassociates the fold and
                 // sinks it, the bound and the LDS read of the extremes behind the last MFMA of the tile, where nothing hides
@@ -571,12 +471,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
         };
         bool prev_valid = false;  // MODE 2: the dummy tile "-1" writes nothing
         auto epi_rest = [&](Epi &e, auto &&pv) {
-#ifdef PVS_ABL_NOEPI
-            if (MODE == 1) {
-                asm volatile("" ::"v"(pv(0, 0)), "v"(pv(GPW - 1, 15)));
-                return;
-            }
-#endif
             if constexpr (MODE == 2) {
                 // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
                 // closed form of the exact integer sums, valid while they stay below 2^24
@@ -619,10 +513,6 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                     lp[g] = e.mx[g] >= e.eb[g];
                     any |= lp[g];
                 }
-#ifdef PVS_ABL_FOLDONLY
-                asm volatile("" ::"v"(any));
-                any = false;
-#endif
                 if (__builtin_amdgcn_ballot_w64(any) != 0) {
                     // Some lane of the wave may hold a passing row (~15 % of the wave-tiles at k=100 over 10M rows): now
                     // the per-row scalars are needed.  Staging is wave-private and its fill count lives in a scalar
@@ -641,48 +531,20 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         };
 
-        // One tile: MFMA burst into the accumulators with the previous tile's epilogue slices in its shadow; `pv(g, r)` =
-        // the previous tile's r-th dot product of group g.  PARITY (two groups per wave): accumulators alternate between
-        // two register sets, the previous tile's sums are read where the matrix core left them — no hand-off copy, and
-        // the two groups are the two independent accumulation chains.  Otherwise two chains (acc, acc1) per tile,
-        // summed into `hold` at the end of the tile.
-        // (256 queries, one group per wave: the single-chain form it is.  Two chains summed into `hold` measured 2.06 ms against
-        //  1.99 ms — s_memtime stamps, PVS_TILE_PROF, show the matrix pipe of a SIMD fully booked while its older wave runs its 24
-        //  MFMAs, whichever form: the two waves of a SIMD share it about 2:1.)
-#ifdef PVS_QG8_TWO_CHAINS
-        constexpr bool PARITY = GPW == 2;
-#else
-        constexpr bool PARITY = QG == 8;
-#endif
+        // One tile: MFMA burst into two accumulation chains (acc, acc1) with the previous tile's epilogue slices in its shadow;
+        // `pv(g, r)` = the previous tile's r-th dot product of group g, summed into `hold` at the end of its tile.
         auto run_tile = [&](int tl, acc_t(&acc)[GPW], acc_t &acc1, auto &&pv) {
 #pragma unroll
             for (int g = 0; g < GPW; g++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[g][r] = 0;
-            if constexpr (!PARITY) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc1[r] = 0;
-            }
+            for (int r = 0; r < 16; r++) acc1[r] = 0;
             Epi e;
 #pragma unroll
             for (int ck = 0; ck < CPT; ck++) {
-                PROF_STAMP(0);
-                if (REC_SHARE && wave != 0)
-                    wait_vm<(PC - 1) * (G::VM_PER_CHUNK - 1)>();  // (no record DMA of its own)
-                else
-                    wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
-                PROF_STAMP(1);
-                if constexpr (ELASTIC) {
-                    // ... tell the others, then wait until everyone's share of THIS chunk has landed and everyone has
-                    // finished reading the chunk whose slot is refilled below (the one consumed SLACK+1 steps ago)
-                    lds_signal(flags_lds + (uint32_t)c_slot * 4u, lane);
-                    if (handoff_ok)  // (once a wait gave up the pass is void — its counts say "overflow" — and nothing is waited for again)
-                        handoff_ok = lds_await2(flags_lds + (uint32_t)c_slot * 4u, (uint32_t)WAVES * (c_gen + 1u),
-                                                flags_lds + 64u + (uint32_t)i_slot * 4u, (uint32_t)WAVES * i_gen);
-                } else {
-                    wg_barrier();                       // ... and everyone else's; the previous chunk is consumed
-                }
-                PROF_STAMP(2);
+                wait_vm<(PC - 1) * G::VM_PER_CHUNK>();  // this wave's share of the chunk has landed
+                wg_barrier();                           // ... and everyone else's; the previous chunk is consumed
                 issue_begin();                          // the slot the previous chunk occupied is refilled below
                 if (ck == 0) epi_begin(e);
                 const uint8_t *cb = ring + c_slot * (SPB * SLAB_BYTES) + frag_row;
@@ -699,7 +561,7 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 //   step t:  LDS read of fragment t+PF | MFMA t (one per group) | one DMA piece of the chunk PC ahead |
                 //            a slice of the previous tile's epilogue
                 // A wave issues in order, so only VALU placed BETWEEN MFMAs runs in their shadow.
-                constexpr int NF = SPB * SPS, PF = ((GPW == 2 || QG >= 4) ? PVS_PF : 4);
+                constexpr int NF = SPB * SPS, PF = 4;  // (prefetch depth 2 / 6 / 8 / 12 at 128 queries: 1.297 / 1.304 / 1.296 / 1.305 ms against 1.302)
                 v4i af[NF];
                 v4i raw[DT == PVS_F32 ? NF : 1][2];  // f32: the two 16-B pieces of a step, before narrowing
                 (void)raw;
@@ -731,80 +593,37 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NF; t++) {
-#ifdef PVS_PRIO_SWAP
-                    // 8-wave instances: the two waves of a SIMD take turns at the matrix pipe instead of sharing it 2:1 in favour of
-                    // the older one for the whole tile (PVS_TILE_PROF: 1,175 vs 1,880 cycles) — the younger wave leads the first
-                    // PVS_PRIO_SWAP/16 of the MFMAs, the older one the rest, so both finish near 1,536
-                    if constexpr (QG == 8 && CPT == 1) {
-                        if (t == 0) {
-                            if (wave >= 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-                        }
-                        if (t == NF * PVS_PRIO_SWAP / 16) {
-                            if (wave >= 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2);
-                        }
-                    }
-#endif
                     if (t + PF < NF) frag(t + PF);
-                    if constexpr (PARITY) {
-#pragma unroll
-                        for (int g = 0; g < GPW; g++) acc[g] = A::mfma(af[t], qf[g][ck * NF + t], acc[g]);
-                    } else {
-                        if (t & 1)
-                            acc1 = A::mfma(af[t], qf[0][ck * NF + t], acc1);
-                        else
-                            acc[0] = A::mfma(af[t], qf[0][ck * NF + t], acc[0]);
-                    }
+                    if (t & 1)
+                        acc1 = A::mfma(af[t], qf[0][ck * NF + t], acc1);
+                    else
+                        acc[0] = A::mfma(af[t], qf[0][ck * NF + t], acc[0]);
                     if (t + 1 < NF) narrow(t + 1);
-#ifdef PVS_DMA_FRONT  // tuning: the chunk's DMA pieces right behind the first MFMAs instead of spread over the whole chunk
-                    if (t < DMA_PARTS) issue_part(t);
-#else
 #pragma unroll
                     for (int part = t * DMA_PARTS / NF; part < (t + 1) * DMA_PARTS / NF; part++) issue_part(part);
-#endif
                     if (ck == 0) {
 #pragma unroll
                         for (int m = t * EPI_STEPS / NF; m < (t + 1) * EPI_STEPS / NF; m++) epi_micro(m, e, pv);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                PROF_STAMP(3);
-                if constexpr (ELASTIC) lds_signal(flags_lds + 64u + (uint32_t)c_slot * 4u, lane);  // this wave is done reading the chunk
-                if (++c_slot == NC) {
-                    c_slot = 0;
-                    c_gen++;
-                }
+                if (++c_slot == NC) c_slot = 0;
                 if (ck == CPT - 1) {  // this tile's row scalars: kept in their slot until the end of the NEXT tile
                     epi_rest(e, pv);  // (the previous tile's, reading p_nslot)
-                    PROF_STAMP(4);
                     p_nslot = c_nslot;
                     if (++c_nslot == NCN) c_nslot = 0;
                 }
             }
             // ---- hand this tile's results to the next iteration
-            if constexpr (!PARITY) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) hold[0][r] = A::sum2(acc[0], acc1, r);  // i8: exact integers; floats: within the error budget
-            }
+            for (int r = 0; r < 16; r++) hold[0][r] = A::sum2(acc[0], acc1, r);  // i8: exact integers; floats: within the error budget
             prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
             prev_valid = true;
         };
         // The last tile's epilogue runs inside one extra "ghost" tile (the DMA stream already re-reads the last tile past
         // the end to keep vmcnt uniform; its sums are never looked at): 1/n_my more work, but the epilogue — the bulk of the
-        // kernel's code — exists once per accumulator set instead of three more times in a drain path (the 256-query
-        // instance shrank from 75 KB to well inside the instruction cache).
-        if constexpr (PARITY) {
-            acc_t accA[GPW], accB[GPW], unused;
-#pragma unroll
-            for (int g = 0; g < GPW; g++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) accB[g][r] = 0;  // tile "-1"
-            auto pa = [&](int g, int r) { return accA[g][r]; };
-            auto pb = [&](int g, int r) { return accB[g][r]; };
-            for (int tl = 0; tl < n_my + 1; tl += 2) {
-                run_tile(tl, accA, unused, pb);
-                if (tl + 1 < n_my + 1) run_tile(tl + 1, accB, unused, pa);
-            }
-        } else {
+        // kernel's code — exists once instead of three more times in a drain path.
+        {
             auto ph = [&](int g, int r) { return hold[g][r]; };
             for (int tl = 0; tl < n_my + 1; tl++) {
                 acc_t acc[GPW], acc1;
@@ -812,16 +631,11 @@ __global__ __launch_bounds__(scan_threads(QG), scan_waves_per_simd(QG, KSLABS)) 
             }
         }
         wait_vm<0>();  // retire the dummy tail DMAs before the wave exits
-#ifdef PVS_TILE_PROF
-        if (MODE == 1 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131))
-            printf("tileprof wg %u wave %d tiles %d: loop-top %llu dma-wait %llu barrier %llu mfma %llu epilogue %llu (cycles of s_memtime)\n", blockIdx.x,
-                   wave, n_my + 1, prof_acc[0], prof_acc[1], prof_acc[2], prof_acc[3], prof_acc[4]);
-#endif
         if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");  // candidates: scalar cache -> L2
     }
-    if (MODE == 1 && sid < nstreams) {   // every lane's fill count: seg_cnt[query][segment]; a hand-off that gave up reports an overflow (-> dense path)
+    if (MODE == 1 && sid < nstreams) {   // every lane's fill count: seg_cnt[query][segment] (above seg_cap: overflowed -> dense path)
 #pragma unroll
-        for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = handoff_ok ? mycnt[g] : 0xffffffffu;
+        for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = mycnt[g];
     }
 
     if (MODE == 0 && sid < nstreams) {
@@ -855,8 +669,7 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    const uint32_t blocks = k.qsplit > 1 ? (k.grid + 7) / 8 * 8 * k.qsplit : k.grid;
-    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(blocks), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
+    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
     return hipGetLastError();
 }
 template <int DT, int KS, int QG>
@@ -869,13 +682,6 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
-}
-// 256 queries per pass: 4 waves x 2 groups x 32 queries (filter passes only)
-template <int DT, int KS>
-static hipError_t scan_launch_wide(const ScanK &k, int metric, int mode, hipStream_t s) {
-    if (mode != 0 && mode != 1) return hipErrorInvalidValue;
-    if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, 8, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, 8, PVS_COSINE, 1>(k, s);
-    return mode == 0 ? scan_launch_one<DT, KS, 8, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, 8, PVS_L2, 1>(k, s);
 }
 template <int DT, int KS>
 static hipError_t scan_launch_qg(const ScanK &k, uint32_t qg, int metric, int mode, hipStream_t s) {

@@ -50,9 +50,12 @@ __device__ static inline __attribute__((always_inline)) void static_for(F &&f) {
 }
 #define PVS_CI(x) (decltype(x)::value)
 
+// (A 4-wave, two-workgroups-per-CU instance of this kernel for 128-query passes measured 1.285 - 1.310 ms at 10M x 768 against
+//  1.292 - 1.313 for k_scan in the same runs: at 128 queries the pass is bound by the fetch path, not by the matrix cores' share of
+//  the power budget, and the instruction shape does not matter.  Not kept.)
 template <int KSLABS, int NQ>
 struct WideGeo {
-    static constexpr int WAVES = 16 / NQ;                 // 16 NQ queries per wave: 8 waves x 32 (two per SIMD) or 4 waves x 64 (one per SIMD)
+    static constexpr int WAVES = 16 / NQ;                 // 16 NQ queries per wave, 256 per workgroup
     static constexpr int RPW = KSLABS <= 3 ? 2 : 1;       // 32-row layout tiles per workgroup tile
     static constexpr int TILE_ROWS = 32 * RPW;
     static constexpr int RG = 2 * RPW;                    // 16-row A fragments per k step
@@ -441,9 +444,9 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
     }
 }
 
-// NQ = 2: eight waves x 32 queries, two per SIMD.  (NQ = 4 — four waves x 64 queries, one per SIMD, ~400 registers, half the
-// A-fragment reads — measured 1.86 ms against 1.70: the fragment reads do drop from 0.19 to 0.10 ms-equivalents, but the per-row
-// path, now alone on its SIMD, doubles; profiles/r03_wide_ablation.md.)
+// NQ = 2: 32 queries per wave, two waves per SIMD.  (NQ = 4 — four waves x 64 queries, one per SIMD, ~400 registers, half the
+// A-fragment reads — measured 1.86 ms against 1.70 at 256 queries: the fragment reads do drop from 0.19 to 0.10 ms-equivalents,
+// but the per-row path, now alone on its SIMD, doubles; profiles/r03_wide_ablation.md.)
 constexpr int PVS_WIDE_NQ = 2;
 template <int KS, int METRIC, int MODE>
 static hipError_t scan_wide_launch_one(const ScanK &k, hipStream_t s) {

@@ -117,7 +117,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         a.seg = c.d_seg;
         a.seg_cnt = c.d_seg_cnt;
         a.gmin = c.d_gmin;
-        const uint32_t wg_rows = pvs_scan_wg_rows(a.qgroups, a.kslabs);
+        const uint32_t wg_rows = pvs_scan_wg_rows(a.dtype, a.qgroups, a.kslabs);
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         // pass A: strided sample of row tiles -> group minima -> threshold
         // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
@@ -133,13 +133,13 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
         a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
         const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
-        const uint32_t per_cu_a = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : 2;
-        const uint32_t spp = pvs_scan_segs_per_stream(a.qgroups);  // lanes per query and workgroup stream (= its candidate segments)
-        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.qgroups))});
+        const uint32_t per_cu_a = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
+        const uint32_t spp = pvs_scan_segs_per_stream(a.dtype, a.qgroups, a.kslabs);  // lanes per query and workgroup stream (= its candidate segments)
+        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs))});
         a.mode = 0;
         // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
         // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
-        a.gmin_per_lane = pvs_scan_gmin_max(a.qgroups);
+        a.gmin_per_lane = pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs);
         while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
         a.groups_per_query = a.grid * spp * a.gmin_per_lane;
         span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
@@ -149,19 +149,9 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         // pass B: every row once (candidate counters were zeroed by the prep kernel)
         a.mode = 1;
         a.tile_step = 1;
-        // 256 queries: two 4-wave workgroups of 128 queries share each tile stream (the second finds the tile in the XCD's
-        // L2) instead of one 8-wave workgroup whose waves all meet at one barrier per tile
-        // — measured 2.46 ms against 2.07 ms at 10M x 768 (the 128-query pass is bound by the fetch path, which this doubles):
-        // off unless PVS_QSPLIT is set.
-        static const bool use_qsplit = getenv("PVS_QSPLIT") != nullptr;  // tuning experiments
-        if (a.qgroups == 8 && use_qsplit) {
-            a.qgroups = 4;
-            a.qsplit = 2;
-        }
-        static const uint32_t per_cu_env = getenv("PVS_SCAN_WG_PER_CU") ? (uint32_t)atoi(getenv("PVS_SCAN_WG_PER_CU")) : 0;  // tuning
-        const uint32_t per_cu = (a.qgroups == 1 || a.qgroups == 8 || a.kslabs > 4) ? 1 : (per_cu_env && a.qgroups == 4 ? per_cu_env : 2);
-        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu / a.qsplit,
-                                     (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.qgroups)))});
+        const uint32_t per_cu = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
+        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu,
+                                     (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs)))});
         a.n_segments = a.grid * spp;
         span_begin(ix, c, 1, ix->n);
         HIP_TRY(pvs_launch_scan(a, c.stream));
@@ -182,7 +172,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         f.seg_cnt = c.d_seg_cnt;
         f.n_segments = a.n_segments;
         f.seg_queries = batch_pad;
-        f.seg_cap = pvs_scan_seg_cap(a.qgroups);
+        f.seg_cap = pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs);
         f.cand = c.d_cand;
         static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
         static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;

@@ -1,7 +1,7 @@
 // wide_probe.hip — times k_scan_wide (pvs_scan_wide.hpp) alone on a synthetic tiled corpus: back-to-back launches, sustained,
 // no pass A / C, no dense fallback in between (bench.py's ablation builds answer garbage and spend the step in the dense path,
 // which changes the power state the next scan runs in).  Candidate rate is set by bisection on the threshold.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I panoptikon_amd/csrc [-DPVS_WABL_...] -o wide_probe tools/probe/wide_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I panoptikon_amd/csrc [-Dtemporary ablation edits] -o wide_probe tools/probe/wide_probe.hip
 //   ./wide_probe [rows=10000000] [cands_per_query=1600] [launches=40]
 #include "pvs_scan_wide.hpp"
 
@@ -89,7 +89,6 @@ int main(int argc, char **argv) {
     k.n_wgtiles = (uint32_t)((n_rows + wg_rows - 1) / wg_rows);
     k.tile_step = 1;
     k.grid = grid;
-    k.qsplit = 1;
     std::vector<uint32_t> cnt((size_t)batch * grid * PVS_WIDE_SEG_PER_STREAM);
     auto launch = [&]() { CK((scan_wide_launch_one<KS, PVS_COSINE, 1>(k, 0))); };
     auto candidates = [&](float t) {  // average candidates per query at threshold t (cosine: pass iff -acc/|a| <= t)
