@@ -16,15 +16,20 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
     return false;
 }
 // Which kernel serves the filter passes (modes 0 and 1) of a shape: k_scan_wide (pvs_scan_wide.hpp: int8, 256 queries at row
-// pitches up to 1 KiB) or k_scan.
-bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs) { return dtype == PVS_I8 && pvs_scan_wide_serves(qgroups, kslabs, 1); }
+// pitches up to 1 KiB, 128 queries up to 768 B) or k_scan.  PVS_SCAN_NO_WIDE128=1 keeps the 128-query passes on k_scan (A/B
+// timing of the two kernels; both are product paths, the GPU suite runs under either).
+bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs) {
+    static const bool no128 = getenv("PVS_SCAN_NO_WIDE128") != nullptr;
+    if (dtype != PVS_I8 || (qgroups == 4 && no128)) return false;
+    return pvs_scan_wide_serves(qgroups, kslabs, 1);
+}
 uint32_t pvs_scan_wg_rows(int dtype, uint32_t qgroups, uint32_t kslabs) {
     if (pvs_scan_is_wide(dtype, qgroups, kslabs)) return pvs_scan_wide_rows(kslabs);
     return qgroups >= 4 ? 32u : 32u * (4u / qgroups);
 }
 uint32_t pvs_scan_row_tiles(uint32_t qgroups) { return qgroups >= 4 ? 1u : 4u / qgroups; }
 uint32_t pvs_scan_segs_per_stream(int dtype, uint32_t qgroups, uint32_t kslabs) {
-    return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(qgroups) * 2u;
+    return pvs_scan_is_wide(dtype, qgroups, kslabs) ? pvs_scan_wide_segs(qgroups) : pvs_scan_row_tiles(qgroups) * 2u;
 }
 uint32_t pvs_scan_seg_cap(int dtype, uint32_t qgroups, uint32_t kslabs) { return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP; }
 uint32_t pvs_scan_gmin_max(int dtype, uint32_t qgroups, uint32_t kslabs) { return pvs_scan_is_wide(dtype, qgroups, kslabs) ? PVS_WIDE_GMIN_MAX : 16u; }
@@ -47,7 +52,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg_queries = a.qgroups * 32;
     const bool wide = (a.mode == 0 || a.mode == 1) && pvs_scan_is_wide(a.dtype, a.qgroups, a.kslabs);
     k.seg_cap = wide ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP;
-    k.seg_stride = a.grid * (wide ? PVS_WIDE_SEG_PER_STREAM : pvs_scan_row_tiles(a.qgroups) * 2u);
+    k.seg_stride = a.grid * (wide ? pvs_scan_wide_segs(a.qgroups) : pvs_scan_row_tiles(a.qgroups) * 2u);
     k.n_rows = a.n_rows;
     k.stride = a.stride;
     const uint32_t wg_rows = wide ? pvs_scan_wide_rows(a.kslabs) : (a.qgroups >= 4 ? 32u : 32u * (4u / a.qgroups));
@@ -62,7 +67,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.batch = a.batch;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
-        e = wide            ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.metric, a.mode, s)
+        e = wide            ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
             : a.kslabs <= 4 ? pvs_scan_dispatch_i8(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                             : pvs_scan_dispatch_i8_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     else if (a.dtype == PVS_F16)

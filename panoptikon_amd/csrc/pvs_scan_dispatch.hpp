@@ -26,7 +26,8 @@ hipError_t pvs_scan_dispatch_f16_large(const ScanK &k, uint32_t kslabs, uint32_t
 hipError_t pvs_scan_dispatch_f32_small(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_mid(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f32_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
-hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, int metric, int mode, hipStream_t s);  // 256 queries: pvs_scan_wide.hpp
+hipError_t pvs_scan_dispatch_i8_wide(const ScanK &k, uint32_t kslabs, uint32_t qgroups, int metric, int mode, hipStream_t s);  // pvs_scan_wide.hpp
+uint32_t pvs_scan_wide_segs(uint32_t qgroups);  // candidate segments per workgroup stream of k_scan_wide
 bool pvs_scan_wide_serves(uint32_t qgroups, uint32_t kslabs, int mode);  // int8: does k_scan_wide serve this pass (else k_scan)
 uint32_t pvs_scan_wide_rows(uint32_t kslabs);  // rows per workgroup tile of k_scan_wide
 hipError_t pvs_scan_dispatch_i8_large(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

@@ -1,4 +1,5 @@
-// pvs_scan_wide.hpp — the 256-query int8 filter scan (gfx950): passes A and B of DESIGN.md §4.1 for row pitches up to 1 KiB.
+// pvs_scan_wide.hpp — the 256- and 128-query int8 filter scans (gfx950): passes A and B of DESIGN.md §4.1 for row pitches up to
+// 1 KiB (256 queries) / 768 B (128 queries).
 //
 // Replaces, for 256 queries at once, the reference's per-row vec_distance_{cosine,L2}(payload, ?) + ORDER BY ... LIMIT k
 // (filters/image_embeddings.rs:321-362, text_embeddings.rs:386-418, pql/builder.rs:578-582) — the same contract as k_scan
@@ -50,15 +51,20 @@ __device__ static inline __attribute__((always_inline)) void static_for(F &&f) {
 }
 #define PVS_CI(x) (decltype(x)::value)
 
-// (A 4-wave, two-workgroups-per-CU instance of this kernel for 128-query passes measured 1.285 - 1.310 ms at 10M x 768 against
-//  1.292 - 1.313 for k_scan in the same runs: at 128 queries the pass is bound by the fetch path, not by the matrix cores' share of
-//  the power budget, and the instruction shape does not matter.  Not kept.)
-template <int KSLABS, int NQ>
+// Eight waves = QW query blocks (16 NQ queries each) x RW row blocks.  RW = 1: every wave works on all rows of the tile, 256
+// queries per pass.  RW = 2: a wave works on one of the tile's two 32-row layout tiles, 128 queries per pass — every A
+// fragment is then read by four waves instead of eight.  (128 queries at 10M x 768, same probe: this form 1.1x ms; 8 waves x 16
+// queries on all 64 rows 1.229; 4 waves x 32 queries, two workgroups per CU, 32-row tiles 1.268; k_scan 1.29-1.31.  With the
+// matrix cores at 0.47 ms-equivalents the stream itself, 1.08 ms at 7.1 TB/s, is the floor: profiles/r03_wide_ablation.md.)
+template <int KSLABS, int NQ, int RW>
 struct WideGeo {
-    static constexpr int WAVES = 16 / NQ;                 // 16 NQ queries per wave, 256 per workgroup
+    static constexpr int WAVES = 8;
+    static constexpr int QW = WAVES / RW;                 // query blocks; QW * 16 * NQ queries per pass
     static constexpr int RPW = KSLABS <= 3 ? 2 : 1;       // 32-row layout tiles per workgroup tile
+    static constexpr int LTW = RPW / RW;                  // layout tiles per wave
     static constexpr int TILE_ROWS = 32 * RPW;
-    static constexpr int RG = 2 * RPW;                    // 16-row A fragments per k step
+    static constexpr int RG = 2 * LTW;                    // 16-row A fragments per wave and k step
+    static_assert(RPW % RW == 0 && LTW >= 1, "a wave works on whole layout tiles");
     static constexpr int SUB_BYTES = KSLABS * 8192;       // one 32-row layout tile
     static constexpr int TILE_BYTES = RPW * SUB_BYTES;    // contiguous in HBM and, byte for byte, in LDS
     static constexpr int PIECES = TILE_BYTES / 1024;      // 1-KiB LDS-DMA pieces per tile
@@ -80,11 +86,11 @@ struct WideCnt {  // fill counts of a lane's (segment, query) lists
 };
 
 // MODE 0 = pass A (group minima), MODE 1 = pass B (candidates)
-template <int KSLABS, int NQ, int METRIC, int MODE>
-__global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK a) {
-    using G = WideGeo<KSLABS, NQ>;
+template <int KSLABS, int NQ, int RW, int METRIC, int MODE>
+__global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
+    using G = WideGeo<KSLABS, NQ, RW>;
     constexpr int QPW = 16 * NQ;         // queries per wave
-    constexpr int RPW = G::RPW, RG = G::RG, NC = G::NC, PC = G::PC, NCN = G::NCN, PPW = G::PPW;
+    constexpr int RPW = G::RPW, LTW = G::LTW, RG = G::RG, QW = G::QW, NC = G::NC, PC = G::PC, NCN = G::NCN, PPW = G::PPW;
     constexpr int NK = KSLABS * 4;       // k steps of 64 bytes
     constexpr int NG = NK * RG * NQ;     // MFMAs (= filler gaps) per tile
     constexpr bool COS = METRIC == PVS_COSINE;
@@ -94,6 +100,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = wave % QW, rw = wave / QW;  // this wave's query block and row block
     const int n = lane & 15, c = lane >> 4;
     const uint32_t sid = blockIdx.x, nstreams = a.grid;
     const uint32_t ring_lds = lds_addr(ring), rec_lds = lds_addr(recring);
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
     for (int q = 0; q < NQ; q++)
 #pragma unroll
         for (int r = 0; r < NMIN; r++) mins[q][r] = __builtin_inff();
-    const uint32_t seg = sid * PVS_WIDE_SEG_PER_STREAM + (uint32_t)c;  // this lane's segment (both of its queries; no other writer)
+    const uint32_t seg = (sid * RW + (uint32_t)rw) * PVS_WIDE_SEG_PER_STREAM + (uint32_t)c;  // this lane's segment (all of its queries; no other writer)
     WideCnt<NQ> cnt;
 #pragma unroll
     for (int q = 0; q < NQ; q++) cnt.k[q] = 0;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
         wv4i qf[NK][NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            const uint8_t *qrow = a.qmat + (size_t)(wave * QPW + 16 * q + n) * a.stride;
+            const uint8_t *qrow = a.qmat + (size_t)(qw * QPW + 16 * q + n) * a.stride;
 #pragma unroll
             for (int i = 0; i < NK; i++) qf[i][q] = *(const wv4i *)(qrow + (4 * i + c) * 16);
         }
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
         float thr[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            qi[q] = a.qinfo[wave * QPW + 16 * q + n];
-            thr[q] = MODE == 1 ? a.thr[wave * QPW + 16 * q + n] : 0.f;
+            qi[q] = a.qinfo[qw * QPW + 16 * q + n];
+            thr[q] = MODE == 1 ? a.thr[qw * QPW + 16 * q + n] : 0.f;
         }
         // retire the compiler's own loads here (it cannot see the asm waits below)
 #pragma unroll
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
         auto score = [&](int q, float d, float x) __attribute__((always_inline)) { return COS ? d * x : __builtin_fmaf(d, m2d[q], c1[q] * x); };
         auto passes = [&](int q, float sv) __attribute__((always_inline)) { return COS ? sv >= tS[q] : sv <= tS[q]; };
         // MODE 1: this lane's slots for its first query; query group q (= +16 q queries) sits 16 q seg_cap slots further
-        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)(wave * QPW + n)) * a.seg_cap;
+        uint2 *const seg_lane = a.seg + ((size_t)seg * a.seg_queries + (uint32_t)(qw * QPW + n)) * a.seg_cap;
         const uint32_t seg_q1 = 16u * a.seg_cap;
 
         // ---- LDS-DMA producer state: PC tiles ahead of the consumer
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 
         // the lane's 8 row scalars of layout tile s (rows 16 r2 + 4 c + v), from the previous tile's record
         auto load_xs = [&](int s, float(&xs)[8]) __attribute__((always_inline)) {
-            const float *rec = (const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC;
+            const float *rec = (const float *)(recring + p_nslot * G::REC_SLOT) + (rw * LTW + s) * PVS_AUX_REC;
 #pragma unroll
             for (int r2 = 0; r2 < 2; r2++) {
                 const float4 v = *(const float4 *)(rec + 16 * r2 + 4 * c);
@@ -271,24 +278,24 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
         };
 
         struct Epi {
-            float t[RPW][2];                   // per layout tile: min / max row scalar
-            float bnd[NQ][RPW];                // per (query, layout tile): the bound on d
-            int mx[NQ][RPW];                   // running v_max3 fold
-            unsigned long long hit[NQ][RPW];   // lanes whose fold clears the bound
+            float t[LTW][2];                   // per layout tile of the wave: min / max row scalar
+            float bnd[NQ][LTW];                // per (query, layout tile): the bound on d
+            int mx[NQ][LTW];                   // running v_max3 fold
+            unsigned long long hit[NQ][LTW];   // lanes whose fold clears the bound
             float xs[8];                       // pass A: row scalars of the layout tile being scored
         };
         // Epilogue slices of the previous tile (compile-time m); pv(rg, q, v) = its sum for row 16 rg + 4 c + v, query 16 q + n.
-        //   pass B: 0 = read the extremes; combo x = RPW q + s at 1 + 5 x: bound + first fold, +1..+3 = folds, +4 = compare;
+        //   pass B: 0 = read the extremes; combo x = LTW q + s at 1 + 5 x: bound + first fold, +1..+3 = folds, +4 = compare;
         //           M_DEC = decisions.  pass A: per layout tile s: 10 s = read row scalars, 10 s + 1 .. + 8 = one row x NQ queries each.
-        constexpr int M_DEC = 1 + 5 * NQ * RPW;
-        constexpr int EPI_STEPS = MODE == 1 ? M_DEC + 1 : 10 * RPW;
+        constexpr int M_DEC = 1 + 5 * NQ * LTW;
+        constexpr int EPI_STEPS = MODE == 1 ? M_DEC + 1 : 10 * LTW;
         auto epi_slice = [&](auto mc, Epi &e, WideCnt<NQ> k, auto &&pv) __attribute__((always_inline)) {
             constexpr int m = PVS_CI(mc);
             if constexpr (MODE == 1) {
                 if constexpr (m == 0) {
 #pragma unroll
-                    for (int s = 0; s < RPW; s++) {
-                        const float2 tmm = *(const float2 *)((const float *)(recring + p_nslot * G::REC_SLOT) + s * PVS_AUX_REC + 32);
+                    for (int s = 0; s < LTW; s++) {
+                        const float2 tmm = *(const float2 *)((const float *)(recring + p_nslot * G::REC_SLOT) + (rw * LTW + s) * PVS_AUX_REC + 32);
                         e.t[s][0] = tmm.x;
                         e.t[s][1] = tmm.y;
                     }
@@ -298,21 +305,21 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 #pragma unroll
                     for (int q = 0; q < NQ; q++)
 #pragma unroll
-                        for (int s = 0; s < RPW; s++) any |= e.hit[q][s];
+                        for (int s = 0; s < LTW; s++) any |= e.hit[q][s];
                     if (any != 0) {
 #pragma unroll
-                        for (int s = 0; s < RPW; s++)
+                        for (int s = 0; s < LTW; s++)
 #pragma unroll
                             for (int q = 0; q < NQ; q++)
                                 if (e.hit[q][s] != 0) k.k[q] = emit_rows(q, s, e.bnd[q][s], k.k[q], pv);
                     }
                 } else {
-                    constexpr int x = (m - 1) / 5, st = (m - 1) % 5, q = x / RPW, s = x % RPW;
+                    constexpr int x = (m - 1) / 5, st = (m - 1) % 5, q = x / LTW, s = x % LTW;
                     {
                         if constexpr (st == 0) {
                             if constexpr (x == 0) {
 #pragma unroll
-                                for (int ss = 0; ss < RPW; ss++) asm volatile("" : "+v"(e.t[ss][0]), "+v"(e.t[ss][1]));  // (slice 0's LDS reads are waited for here)
+                                for (int ss = 0; ss < LTW; ss++) asm volatile("" : "+v"(e.t[ss][0]), "+v"(e.t[ss][1]));  // (slice 0's LDS reads are waited for here)
                             }
                             if (COS) {
                                 e.bnd[q][s] = __builtin_fmaf(tSe[q], tS[q] > 0.f ? e.t[s][0] : e.t[s][1], -1.0f);
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
                 wait_vm<(PC - 1) * PPW>();
             wg_barrier();
             issue_begin();  // refills the slot the previous tile occupied
-            const uint8_t *cb = ring + c_slot * G::TILE_BYTES;
+            const uint8_t *cb = ring + c_slot * G::TILE_BYTES + rw * (LTW * G::SUB_BYTES);  // this wave's layout tile(s) of the slot
             const uint8_t *fb[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) fb[i] = cb + swz[i];
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 #pragma unroll
             for (int q = 0; q < NQ; q++)
 #pragma unroll
-                for (int s = 0; s < RPW; s++) e.hit[q][s] = 0;
+                for (int s = 0; s < LTW; s++) e.hit[q][s] = 0;
             wv4i af[NK][RG];
             auto frag = [&](int i, int rg) __attribute__((always_inline)) {  // k step i, row group rg
                 af[i][rg] = *(const wv4i *)(fb[i & 3] + (rg >> 1) * G::SUB_BYTES + (i >> 2) * 8192 + (rg & 1) * 4096);
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
             if (++c_slot == NC) c_slot = 0;
             p_nslot = c_nslot;
             if (++c_nslot == NCN) c_nslot = 0;
-            prev_row_base = wt_cur * (uint32_t)G::TILE_ROWS + 4u * (uint32_t)c;
+            prev_row_base = wt_cur * (uint32_t)G::TILE_ROWS + (uint32_t)(rw * (32 * LTW)) + 4u * (uint32_t)c;
             wt_cur += wt_step;
             return k;
         };
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
     if constexpr (MODE == 1) {
         if (sid < nstreams) {  // every lane's fill counts (above seg_cap: overflowed)
 #pragma unroll
-            for (int q = 0; q < NQ; q++) a.seg_cnt[(size_t)(wave * QPW + 16 * q + n) * a.seg_stride + seg] = cnt.k[q];
+            for (int q = 0; q < NQ; q++) a.seg_cnt[(size_t)(qw * QPW + 16 * q + n) * a.seg_stride + seg] = cnt.k[q];
         }
     } else {
         if (sid < nstreams) {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 #pragma unroll
                         for (int r = 0; r < sft; r++) mins[q][r] = fminf(mins[q][r], mins[q][r + sft]);
                     }
-                float *o = a.gmin + (size_t)(wave * QPW + 16 * q + n) * a.groups_per_query + (size_t)(sid * PVS_WIDE_SEG_PER_STREAM + c) * gr;
+                float *o = a.gmin + (size_t)(qw * QPW + 16 * q + n) * a.groups_per_query + (size_t)seg * gr;
 #pragma unroll
                 for (int r = 0; r < 8; r++)
                     if ((uint32_t)r < gr) o[r] = mins[q][r];
@@ -448,22 +455,22 @@ __global__ __launch_bounds__(1024 / NQ, NQ == 2 ? 2 : 1) void k_scan_wide(ScanK 
 // A-fragment reads — measured 1.86 ms against 1.70 at 256 queries: the fragment reads do drop from 0.19 to 0.10 ms-equivalents,
 // but the per-row path, now alone on its SIMD, doubles; profiles/r03_wide_ablation.md.)
 constexpr int PVS_WIDE_NQ = 2;
-template <int KS, int METRIC, int MODE>
+template <int KS, int RW, int METRIC, int MODE>
 static hipError_t scan_wide_launch_one(const ScanK &k, hipStream_t s) {
     constexpr int NQ = PVS_WIDE_NQ;
     static std::atomic<bool> configured{false};
-    constexpr int lds = WideGeo<KS, NQ>::LDS_BYTES;
+    constexpr int lds = WideGeo<KS, NQ, RW>::LDS_BYTES;
     if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_scan_wide<KS, NQ, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_scan_wide<KS, NQ, RW, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan_wide<KS, NQ, METRIC, MODE>), dim3(k.grid), dim3(1024 / NQ), lds, s, k);
+    hipLaunchKernelGGL((k_scan_wide<KS, NQ, RW, METRIC, MODE>), dim3(k.grid), dim3(512), lds, s, k);
     return hipGetLastError();
 }
-template <int KS>
+template <int KS, int RW>
 static hipError_t scan_wide_launch(const ScanK &k, int metric, int mode, hipStream_t s) {
     if (mode != 0 && mode != 1) return hipErrorInvalidValue;
-    if (metric == PVS_COSINE) return mode == 0 ? scan_wide_launch_one<KS, PVS_COSINE, 0>(k, s) : scan_wide_launch_one<KS, PVS_COSINE, 1>(k, s);
-    return mode == 0 ? scan_wide_launch_one<KS, PVS_L2, 0>(k, s) : scan_wide_launch_one<KS, PVS_L2, 1>(k, s);
+    if (metric == PVS_COSINE) return mode == 0 ? scan_wide_launch_one<KS, RW, PVS_COSINE, 0>(k, s) : scan_wide_launch_one<KS, RW, PVS_COSINE, 1>(k, s);
+    return mode == 0 ? scan_wide_launch_one<KS, RW, PVS_L2, 0>(k, s) : scan_wide_launch_one<KS, RW, PVS_L2, 1>(k, s);
 }

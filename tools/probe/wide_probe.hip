@@ -3,6 +3,9 @@
 // which changes the power state the next scan runs in).  Candidate rate is set by bisection on the threshold.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I panoptikon_amd/csrc [-Dtemporary ablation edits] -o wide_probe tools/probe/wide_probe.hip
 //   ./wide_probe [rows=10000000] [cands_per_query=1600] [launches=40]
+#ifndef PROBE_RW
+#define PROBE_RW 1  // 1: 256 queries per pass, 2: 128
+#endif
 #include "pvs_scan_wide.hpp"
 
 #include <cmath>
@@ -43,8 +46,8 @@ int main(int argc, char **argv) {
     const double want = argc > 2 ? atof(argv[2]) : 1600.0;
     const int launches = argc > 3 ? atoi(argv[3]) : 40;
     constexpr int KS = 3;
-    const uint32_t stride = KS * 256, batch = 256, grid = 256;
-    const uint32_t wg_rows = WideGeo<KS, PVS_WIDE_NQ>::TILE_ROWS;
+    const uint32_t stride = KS * 256, batch = 256 / PROBE_RW, grid = 256;
+    const uint32_t wg_rows = WideGeo<KS, PVS_WIDE_NQ, PROBE_RW>::TILE_ROWS;
     const uint64_t cap = (n_rows + 127) / 128 * 128 + 128;
     uint8_t *rows, *qmat;
     float *aux, *thr;
@@ -56,8 +59,8 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&qmat, batch * stride));
     CK(hipMalloc(&qinfo, batch * sizeof(QInfo)));
     CK(hipMalloc(&thr, batch * 4));
-    CK(hipMalloc(&seg, (size_t)grid * PVS_WIDE_SEG_PER_STREAM * batch * PVS_WIDE_SEG_CAP * 8));
-    CK(hipMalloc(&seg_cnt, (size_t)batch * grid * PVS_WIDE_SEG_PER_STREAM * 4));
+    CK(hipMalloc(&seg, (size_t)grid * (PVS_WIDE_SEG_PER_STREAM * PROBE_RW) * batch * PVS_WIDE_SEG_CAP * 8));
+    CK(hipMalloc(&seg_cnt, (size_t)batch * grid * (PVS_WIDE_SEG_PER_STREAM * PROBE_RW) * 4));
     hipLaunchKernelGGL(k_fill_codes, dim3(4096), dim3(256), 0, 0, (uint32_t *)rows, cap * stride / 4, 1u);
     hipLaunchKernelGGL(k_fill_codes, dim3(64), dim3(256), 0, 0, (uint32_t *)qmat, (size_t)batch * stride / 4, 77u);
     const float norm = 23.0f * sqrtf(768.f);
@@ -83,14 +86,14 @@ int main(int argc, char **argv) {
     k.seg_cnt = seg_cnt;
     k.seg_queries = batch;
     k.seg_cap = PVS_WIDE_SEG_CAP;
-    k.seg_stride = grid * PVS_WIDE_SEG_PER_STREAM;
+    k.seg_stride = grid * (PVS_WIDE_SEG_PER_STREAM * PROBE_RW);
     k.n_rows = n_rows;
     k.stride = stride;
     k.n_wgtiles = (uint32_t)((n_rows + wg_rows - 1) / wg_rows);
     k.tile_step = 1;
     k.grid = grid;
-    std::vector<uint32_t> cnt((size_t)batch * grid * PVS_WIDE_SEG_PER_STREAM);
-    auto launch = [&]() { CK((scan_wide_launch_one<KS, PVS_COSINE, 1>(k, 0))); };
+    std::vector<uint32_t> cnt((size_t)batch * grid * (PVS_WIDE_SEG_PER_STREAM * PROBE_RW));
+    auto launch = [&]() { CK((scan_wide_launch_one<KS, PROBE_RW, PVS_COSINE, 1>(k, 0))); };
     auto candidates = [&](float t) {  // average candidates per query at threshold t (cosine: pass iff -acc/|a| <= t)
         std::vector<float> h(batch, t);
         CK(hipMemcpy(thr, h.data(), batch * 4, hipMemcpyHostToDevice));
@@ -125,7 +128,7 @@ int main(int argc, char **argv) {
         last = ms / launches;
         if (last < best) best = last;
     }
-    const double ops = 2.0 * n_rows * 768.0 * batch;
+    const double ops = 2.0 * n_rows * 768.0 * batch;  // (batch = 256 / PROBE_RW)
     printf("k_scan_wide<3,cos,B>: %.4f ms/launch sustained (best group %.4f)  %.2f TB/s  %.2f POP/s\n", last, best,
            n_rows * 768.0 / (last * 1e-3) / 1e12, ops / (last * 1e-3) / 1e15);
     return 0;
