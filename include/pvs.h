@@ -260,9 +260,23 @@ pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
  * instead of falling back).  For tests and profiling. */
 pvs_status pvs_index_set_path(pvs_index *idx, uint32_t path);
 
+/* Which filter-scan kernel serves a pass of `batch` queries on this index (profiling reports): writes a NUL-terminated
+ * name such as "k_scan_wide<i8, 768 B, 128 queries>" or "k_scan<f16, 1536 B, 32 queries>", or "dense path" when the shape
+ * has no filter-scan instance. */
+pvs_status pvs_index_scan_kernel_name(pvs_index *idx, uint32_t batch, char *out, uint32_t out_len);
+
 /* The `d` column of dist_{cte}: one distance per row, in row order. */
 pvs_status pvs_score_all(pvs_index *idx, const void *query, pvs_dtype query_dtype, pvs_metric metric,
                          float *out_dist, pvs_space out_space);
+
+/* The same column kept by the library and read in windows (the SQLite scalar drop-ins look rows up one at a time and must not
+ * hold 4 bytes per row per statement on the host): one device pass at creation; single-device indexes keep the column in HBM,
+ * multi-device ones on the host.  Rows appended to the index afterwards are not part of the column. */
+typedef struct pvs_column pvs_column;
+pvs_status pvs_score_column_create(pvs_index *idx, const void *query, pvs_dtype query_dtype, pvs_metric metric, pvs_column **out);
+pvs_status pvs_score_column_rows(const pvs_column *col, uint64_t *out_rows);
+pvs_status pvs_score_column_read(pvs_column *col, uint64_t row0, uint64_t n, float *out_host);
+void pvs_score_column_destroy(pvs_column *col);
 
 /* Dense exact distances for a batch: out[row * batch + q] = the reference's
  * vec_distance_*(row payload, query q) — the `d` column of dist_{cte} for `batch`

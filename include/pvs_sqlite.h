@@ -80,15 +80,29 @@ typedef struct pvs_sqlite_api {
     sqlite3 *(*context_db_handle)(sqlite3_context *);
     const char *(*errmsg)(sqlite3 *);
     void (*result_text)(sqlite3_context *, const char *, int, void (*)(void *));
+    /* since ABI v3 — what pvs_backfill writes codes with.  A host that passes a shorter struct gets everything except
+     * pvs_backfill. */
+    int (*bind_blob)(void *, int, const void *, int, void (*)(void *));
+    int (*bind_int64)(void *, int, long long);
+    int (*reset)(void *);
 } pvs_sqlite_api;
 
-/* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 on one connection.  api == NULL: use the table a previous
- * call installed, or resolve the entry points from the SQLite already loaded in this process.  Returns an SQLite result
- * code (0 = SQLITE_OK). */
+/* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 / pvs_load / pvs_backfill on one connection.  api == NULL: use
+ * the table a previous call (or a loadable-extension entry point) installed, or — explicit opt-in of a process that knows it
+ * carries exactly one SQLite, exported — resolve the entry points by name from the process image.  Returns an SQLite
+ * result code (0 = SQLITE_OK). */
 int32_t pvs_sqlite_register(void *db, const pvs_sqlite_api *api);
 
+/* Diagnostics: copies the table of SQLite entry points currently installed (by an extension entry point, by
+ * pvs_sqlite_register, or by the by-name lookup) into *out, at most out->struct_size bytes; returns 0, or 1 when none is
+ * installed yet.  A host can compare it with its own functions' addresses to see which SQLite the extension talks to. */
+int32_t pvs_sqlite_api_snapshot(pvs_sqlite_api *out);
+
 /* Loadable-extension entry points (int xEntryPoint(sqlite3*, char **pzErrMsg, const sqlite3_api_routines*)): the symbol
- * SQLite derives from the file name, the generic one, and the one to hand to sqlite3_auto_extension. */
+ * SQLite derives from the file name, the generic one, and the one to hand to sqlite3_auto_extension — exactly where the
+ * reference hands sqlite3_vec_init (db/sql_functions.rs:105-128).  They take every SQLite entry point from the
+ * sqlite3_api_routines table SQLite passes in (the calling SQLite's OWN functions, whether it is a shared library or linked
+ * statically into the host with hidden symbols), never from a name lookup; SQLite >= 3.8.0. */
 int sqlite3_pvs_init(void *db, char **pzErrMsg, const void *pApi);
 int sqlite3_extension_init(void *db, char **pzErrMsg, const void *pApi);
 int sqlite3_pvssqlite_init(void *db, char **pzErrMsg, const void *pApi);
@@ -104,6 +118,24 @@ typedef struct pvs_sqlite_load_result {
     uint64_t sum_group; /* sum over appended rows of (group id & 0xffffffff) */
 } pvs_sqlite_load_result;
 int32_t pvs_sqlite_load(void *db, const char *sql, pvs_index *idx, uint32_t chunk_rows, pvs_sqlite_load_result *out);
+
+/* Write side of the lifecycle (the reference's backfill_chunk, db/vector_quants.rs:1119-1163): runs
+ * `select_sql` on `db` to completion — rows (id INTEGER, embedding BLOB f32 LE, artifact BLOB, artifact_rev INTEGER), the shape
+ * of BACKFILL_CHUNK_SQL (:1085-1099), with the caller's own LIMIT — then quantizes all embeddings in one device pass
+ * (quantize_int8 with the scale the artifact holds, :1489-1503) and runs `upsert_sql` once per row with
+ * (?1 id, ?2 profile_id, ?3 artifact_rev, ?4 codes BLOB) — the shape of INSERT_QUANT_SQL (:1101-1117).  Like the reference,
+ * the select is read completely before the first write (it reads embedding_quants itself), nothing is written when a row's
+ * artifact is not a valid scale, and a blob whose length is not a multiple of 4 or differs from the first row's is an error
+ * (the SQL guards `length(e.embedding) = c.dim * 4`).  `device`: HIP ordinal, -1 = current.  Also reachable from SQL:
+ *     SELECT pvs_backfill(select_sql, upsert_sql, profile_id, device [, select parameter ...])   -> rows written
+ *     SELECT pvs_backfill_cursor()                 -> largest id written by this connection's last pvs_backfill (NULL: none)
+ * Returns pvs_status; PVS_ERR_STATE when the registered SQLite entry points lack bind_blob / bind_int64 / reset. */
+typedef struct pvs_sqlite_backfill_result {
+    uint64_t written; /* rows upserted */
+    int64_t cursor;   /* max(id) over them, or the value passed in `after_id` semantics of the caller: -1 when none */
+} pvs_sqlite_backfill_result;
+int32_t pvs_sqlite_backfill(void *db, const char *select_sql, const char *upsert_sql, int64_t profile_id, int32_t device,
+                            pvs_sqlite_backfill_result *out);
 
 /* Names the SQL functions resolve: bind every device index the host wants reachable from SQL (process-wide registry;
  * rebinding a name replaces it; unbind before pvs_index_destroy).  Return pvs_status. */

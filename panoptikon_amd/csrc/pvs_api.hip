@@ -525,6 +525,21 @@ PVS_EXPORT pvs_status pvs_index_set_path(pvs_index *ix, uint32_t path) {
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_index_scan_kernel_name(pvs_index *ix, uint32_t batch, char *out, uint32_t out_len) {
+    if (!ix || !out || out_len < 2 || batch < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "bad argument");
+    const pvs_index *sh = is_multi(ix) && !ix->shards.empty() ? ix->shards[0] : ix;
+    const uint32_t ks = sh->stride / PVS_KSLAB_BYTES;
+    if (!pvs_scan_supported((int)sh->dtype, ks)) {
+        snprintf(out, out_len, "dense path");
+        return PVS_OK;
+    }
+    const uint32_t pass = std::min<uint32_t>(batch, pvs_scan_max_batch((int)sh->dtype, ks));
+    const uint32_t pad = pass <= 32 ? 32 : pass <= 64 ? 64 : pass <= 128 ? 128 : 256;
+    const char *dt = sh->dtype == PVS_I8 ? "i8" : sh->dtype == PVS_F16 ? "f16" : "f32";
+    snprintf(out, out_len, "%s<%s, %u B, %u queries>", pvs_scan_is_wide((int)sh->dtype, pad / 32, ks) ? "k_scan_wide" : "k_scan", dt, sh->stride, pad);
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (is_multi(ix)) return multi_stats(ix, out);

@@ -2,6 +2,7 @@
 // dense fallbacks, candidate masks), the stream-ordered and sharded entry points, the dense `d` column.
 #include <chrono>
 #include <cstring>
+#include <new>
 #include <string>
 
 #include "pvs_index.hpp"
@@ -871,5 +872,76 @@ PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype 
     if (st == PVS_OK) st = body();
     ctx_done(ix, c);
     return st;
+}
+
+// ---- the same column as a handle read in windows (pvs_sqlite.cpp's scalar drop-ins: one device pass per statement, then
+// one lookup per row; the statement must not hold the whole column on the host)
+struct pvs_column {
+    uint64_t rows = 0;
+    int device = -1;
+    float *d_dev = nullptr;     // single-device index: the column stays in HBM
+    std::vector<float> host;    // multi-device index: multi_score_all gathers on the host
+};
+PVS_EXPORT pvs_status pvs_score_column_create(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, pvs_column **out) {
+    if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    pvs_column *c = new (std::nothrow) pvs_column();
+    if (!c) return pvs_fail(PVS_ERR_OOM, "out of host memory");
+    pvs_status st = PVS_OK;
+    if (is_multi(ix)) {
+        c->rows = ix->n;
+        try {
+            c->host.assign(c->rows, 0.f);
+        } catch (...) {
+            delete c;
+            return pvs_fail(PVS_ERR_OOM, "out of host memory for a %llu-row column", (unsigned long long)ix->n);
+        }
+        if (c->rows) st = multi_score_all(ix, query, qdtype, metric, c->host.data(), PVS_HOST);
+    } else {
+        c->rows = ix->n;
+        c->device = ix->device;
+        if (c->rows) {
+            hipError_t e = hipSetDevice(ix->device);
+            if (e == hipSuccess) e = hipMalloc((void **)&c->d_dev, c->rows * 4);
+            if (e != hipSuccess) {
+                delete c;
+                return pvs_fail(e == hipErrorOutOfMemory ? PVS_ERR_OOM : PVS_ERR_DEVICE, "hipMalloc of a %llu-row column: %s", (unsigned long long)ix->n, hipGetErrorString(e));
+            }
+            st = pvs_score_all(ix, query, qdtype, metric, c->d_dev, PVS_DEVICE);
+        } else {
+            st = validate_search(ix, query, qdtype, 1, 1, metric);
+        }
+    }
+    if (st != PVS_OK) {
+        pvs_score_column_destroy(c);
+        return st;
+    }
+    *out = c;
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_score_column_rows(const pvs_column *c, uint64_t *out_rows) {
+    if (!c || !out_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    *out_rows = c->rows;
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_score_column_read(pvs_column *c, uint64_t row0, uint64_t n, float *out_host) {
+    if (!c || (n && !out_host)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (row0 > c->rows || n > c->rows - row0) return pvs_fail(PVS_ERR_INVALID_ARG, "rows [%llu, +%llu) outside the column (%llu rows)", (unsigned long long)row0, (unsigned long long)n, (unsigned long long)c->rows);
+    if (!n) return PVS_OK;
+    if (c->d_dev) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpy(out_host, c->d_dev + row0, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        memcpy(out_host, c->host.data() + row0, n * 4);
+    }
+    return PVS_OK;
+}
+PVS_EXPORT void pvs_score_column_destroy(pvs_column *c) {
+    if (!c) return;
+    if (c->d_dev) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->d_dev);
+    }
+    delete c;
 }
 

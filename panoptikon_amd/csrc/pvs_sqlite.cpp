@@ -22,10 +22,14 @@
 // `query` is a BLOB: dim*4 bytes = f32 little-endian (QuantResolved._embedding, db/pql.rs:76-85), or dim bytes = int8
 // codes (query_quant) for an int8 index.  Distances are the f32 value widened to a REAL, NULL where sqlite-vec yields NaN.
 //
-// No SQLite headers exist on this image (and a Rust host links its own copy, libsqlite3-sys), so nothing here includes
-// sqlite3.h or links libsqlite3: the ~20 entry points used are declared below with their documented prototypes and reach
-// the library through a table of function pointers — filled by the host (pvs_sqlite_register, for a statically linked
-// SQLite) or, for a loadable extension, from the SQLite the calling process already carries (dlsym).
+// A Rust host links its own copy of SQLite (libsqlite3-sys "bundled", symbols not exported), so nothing here includes
+// sqlite3.h or links libsqlite3: the ~30 entry points used are declared below with their documented prototypes and reach
+// the library through a table of function pointers.  The loadable-extension entry points fill it from the
+// sqlite3_api_routines table SQLite hands them — the calling SQLite's own functions, by their slot in that append-only
+// struct (sqlite3ext.h; slots below) — which is what makes `sqlite3_auto_extension(sqlite3_pvs_init)` work in a host with a
+// statically linked SQLite, and what rules out binding to a different copy of SQLite that merely happens to be loaded.
+// pvs_sqlite_register(db, &table) serves a host that fills the table itself; the by-name lookup (dlsym) is left only behind
+// the explicit pvs_sqlite_register(db, NULL) / pvs_sqlite_load of a process that never went through an entry point.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -34,7 +38,9 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -126,8 +132,8 @@ std::mutex g_mu;
 struct Bound {
     pvs_index *ix = nullptr;
     pvs_sqlite_load_result last_load = {0, 0, -1, 0, 0};
-    std::vector<int64_t> ids;  // host copy of the row ids (strictly increasing), refreshed when the row count moves
-    uint64_t ids_rows = UINT64_MAX;
+    std::shared_ptr<const std::vector<int64_t>> ids;  // host copy of the row ids (strictly increasing), refreshed when the row
+    uint64_t ids_rows = UINT64_MAX;                   // count moves; statements share it (8 bytes per row per INDEX, not per statement)
 };
 std::map<std::string, Bound> g_indexes;
 
@@ -144,18 +150,19 @@ pvs_status lookup(const std::string &name, pvs_index **ix, uint32_t *dtype, uint
     *rows = st.rows;
     return PVS_OK;
 }
-// a copy of the index's row ids (cached per binding)
-pvs_status row_ids(const std::string &name, uint64_t rows, std::vector<int64_t> *out) {
+// the index's row ids (cached per binding, shared by the statements that use them)
+pvs_status row_ids(const std::string &name, uint64_t rows, std::shared_ptr<const std::vector<int64_t>> *out) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_indexes.find(name);
     if (it == g_indexes.end()) return PVS_ERR_INVALID_ARG;
     Bound &b = it->second;
-    if (b.ids_rows != rows) {
-        b.ids.resize(rows);
+    if (b.ids_rows != rows || !b.ids) {
+        auto v = std::make_shared<std::vector<int64_t>>(rows);
         if (rows) {
-            pvs_status s = pvs_index_read_ids(b.ix, 0, rows, b.ids.data(), nullptr);
+            pvs_status s = pvs_index_read_ids(b.ix, 0, rows, v->data(), nullptr);
             if (s != PVS_OK) return s;
         }
+        b.ids = v;
         b.ids_rows = rows;
     }
     *out = b.ids;
@@ -200,9 +207,23 @@ struct DistVtab {
 };
 struct DistCursor {
     sqlite3_vtab_cursor base;
+    uint64_t pos = 0, n = 0;
+    // page mode (k given): the page itself
     std::vector<int64_t> ids;
     std::vector<float> d;
-    size_t pos = 0, n = 0;
+    // column mode: the ids shared with the binding, the `d` column kept by libpvs and read through a window
+    std::shared_ptr<const std::vector<int64_t>> all_ids;
+    pvs_column *col = nullptr;
+    static constexpr uint64_t WIN = 1u << 18;
+    uint64_t win0 = UINT64_MAX;
+    std::vector<float> win;
+    void drop_column() {
+        pvs_score_column_destroy(col);
+        col = nullptr;
+        all_ids.reset();
+        win0 = UINT64_MAX;
+    }
+    ~DistCursor() { drop_column(); }
 };
 enum { COL_ID = 0, COL_D = 1, COL_INDEX = 2, COL_QUERY = 3, COL_METRIC = 4, COL_K = 5 };
 
@@ -261,6 +282,7 @@ int vtab_error(sqlite3_vtab *v, const char *fmt, const char *detail) {
 int dist_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *, int argc, sqlite3_value **argv) {
     DistCursor *c = (DistCursor *)cur;
     c->pos = c->n = 0;
+    c->drop_column();
     int a = 0;
     sqlite3_value *v_index = (idxNum & 1) ? argv[a++] : nullptr, *v_query = (idxNum & 2) ? argv[a++] : nullptr,
                   *v_metric = (idxNum & 4) ? argv[a++] : nullptr, *v_k = (idxNum & 8) ? argv[a++] : nullptr;
@@ -289,11 +311,11 @@ int dist_filter(sqlite3_vtab_cursor *cur, int idxNum, const char *, int argc, sq
             return vtab_error(cur->pVtab, "pvs_dist: %s", pvs_last_error());
         c->n = cnt;
     } else {
-        if (row_ids((const char *)nm, rows, &c->ids) != PVS_OK) return vtab_error(cur->pVtab, "pvs_dist: %s", pvs_last_error());
-        c->d.assign(rows, 0.f);
-        if (rows && pvs_score_all(ix, q, qd, metric, c->d.data(), PVS_HOST) != PVS_OK)
+        if (row_ids((const char *)nm, rows, &c->all_ids) != PVS_OK || pvs_score_column_create(ix, q, qd, metric, &c->col) != PVS_OK)
             return vtab_error(cur->pVtab, "pvs_dist: %s", pvs_last_error());
-        c->n = rows;
+        uint64_t crows = 0;
+        (void)pvs_score_column_rows(c->col, &crows);
+        c->n = std::min<uint64_t>(crows, c->all_ids->size());
     }
     return SQLITE_OK;
 }
@@ -305,9 +327,24 @@ int dist_eof(sqlite3_vtab_cursor *c) { return ((DistCursor *)c)->pos >= ((DistCu
 int dist_column(sqlite3_vtab_cursor *cur, sqlite3_context *ctx, int col) {
     DistCursor *c = (DistCursor *)cur;
     if (col == COL_ID)
-        g_api.result_int64(ctx, c->ids[c->pos]);
+        g_api.result_int64(ctx, c->col ? (*c->all_ids)[c->pos] : c->ids[c->pos]);
     else if (col == COL_D) {
-        const float d = c->d[c->pos];
+        float d;
+        if (c->col) {
+            const uint64_t w0 = c->pos / DistCursor::WIN * DistCursor::WIN;
+            if (w0 != c->win0) {
+                const uint64_t n = std::min<uint64_t>(DistCursor::WIN, c->n - w0);
+                c->win.resize(n);
+                if (pvs_score_column_read(c->col, w0, n, c->win.data()) != PVS_OK) {
+                    g_api.result_error(ctx, pvs_last_error(), -1);
+                    return SQLITE_ERROR;
+                }
+                c->win0 = w0;
+            }
+            d = c->win[(size_t)(c->pos - w0)];
+        } else {
+            d = c->d[c->pos];
+        }
         if (d != d)
             g_api.result_null(ctx);  // sqlite3_result_double(NaN) stores NULL; say so directly
         else
@@ -328,8 +365,12 @@ sqlite3_module g_dist_module = {
 
 // ------------------------------------------------------------------ pvs_distance_{cosine,l2}(index, id, query)
 struct Column {  // one device pass, parked on the statement (auxiliary data of the query argument)
-    std::vector<int64_t> ids;
-    std::vector<float> d;
+    std::shared_ptr<const std::vector<int64_t>> ids;  // shared with the binding
+    pvs_column *col = nullptr;                         // the `d` column, kept by libpvs (in HBM for a single-device index)
+    static constexpr uint64_t WIN = 1u << 18;          // rows per host window (1 MiB): SQL walks the ids in order, so a
+    uint64_t win0 = UINT64_MAX;                        // statement reads each window once
+    std::vector<float> win;
+    ~Column() { pvs_score_column_destroy(col); }
 };
 void column_free(void *p) { delete (Column *)p; }
 
@@ -361,8 +402,7 @@ void distance_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
             g_api.result_error(ctx, "out of memory", -1);
             return;
         }
-        col->d.assign(rows, 0.f);
-        if (row_ids((const char *)nm, rows, &col->ids) != PVS_OK || (rows && pvs_score_all(ix, q, qd, metric, col->d.data(), PVS_HOST) != PVS_OK)) {
+        if (row_ids((const char *)nm, rows, &col->ids) != PVS_OK || pvs_score_column_create(ix, q, qd, metric, &col->col) != PVS_OK) {
             g_api.result_error(ctx, pvs_last_error(), -1);
             delete col;
             return;
@@ -375,12 +415,26 @@ void distance_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
         }
     }
     const sqlite3_int64 id = g_api.value_int64(argv[1]);
-    auto it = std::lower_bound(col->ids.begin(), col->ids.end(), (int64_t)id);
-    if (it == col->ids.end() || *it != id) {
+    const std::vector<int64_t> &ids = *col->ids;
+    uint64_t crows = 0;
+    (void)pvs_score_column_rows(col->col, &crows);
+    auto it = std::lower_bound(ids.begin(), ids.end(), (int64_t)id);
+    const uint64_t row = (uint64_t)(it - ids.begin());
+    if (it == ids.end() || *it != id || row >= crows) {
         g_api.result_null(ctx);  // the row is not in the index (the reference would have had no payload row to score either)
         return;
     }
-    const float d = col->d[(size_t)(it - col->ids.begin())];
+    const uint64_t w0 = row / Column::WIN * Column::WIN;
+    if (w0 != col->win0) {
+        const uint64_t n = std::min<uint64_t>(Column::WIN, crows - w0);
+        col->win.resize(n);
+        if (pvs_score_column_read(col->col, w0, n, col->win.data()) != PVS_OK) {
+            g_api.result_error(ctx, pvs_last_error(), -1);
+            return;
+        }
+        col->win0 = w0;
+    }
+    const float d = col->win[(size_t)(row - w0)];
     if (d != d)
         g_api.result_null(ctx);
     else
@@ -392,7 +446,8 @@ void distance_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
 // device (pvs_index_add[_f32], which converts f32 rows to the index dtype on the device) without becoming values of the host
 // language.  The statement is the loader's own — `SELECT d.id, d.item_id, e.embedding FROM item_data d JOIN embeddings e ...
 // ORDER BY d.id` (panoptikon_amd/loader.py; the order BACKFILL_CHUNK_SQL streams, db/vector_quants.rs:1085-1099).
-bool have_stmt_api() { return g_api.struct_size >= sizeof(pvs_sqlite_api) && g_api.prepare_v2 && g_api.step && g_api.finalize && g_api.column_blob; }
+bool have_stmt_api() { return g_api.struct_size >= offsetof(pvs_sqlite_api, bind_blob) && g_api.prepare_v2 && g_api.step && g_api.finalize && g_api.column_blob; }
+bool have_write_api() { return have_stmt_api() && g_api.struct_size >= sizeof(pvs_sqlite_api) && g_api.bind_blob && g_api.bind_int64 && g_api.reset; }
 
 pvs_status stream_rows(void *stmt, pvs_index *ix, uint32_t chunk_rows, pvs_sqlite_load_result *res, std::string *err) {
     pvs_stats st;
@@ -539,6 +594,133 @@ void load_info_udf(sqlite3_context *ctx, int, sqlite3_value **argv) {
     g_api.free(m);
 }
 
+// ------------------------------------------------------------------ pvs_backfill(select_sql, upsert_sql, profile_id, device, params...)
+// The write side of the lifecycle: the reference's backfill_chunk (db/vector_quants.rs:1119-1163) with quantize_int8 on the
+// device.  `sel` is prepared and bound by the caller; it is stepped to completion BEFORE the first write (it reads
+// embedding_quants itself — NOT EXISTS — and the reference fetches the whole chunk first too).
+thread_local pvs_sqlite_backfill_result t_last_backfill = {0, -1};
+
+pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t profile_id, int32_t device, pvs_sqlite_backfill_result *res,
+                        std::string *err) {
+    std::vector<int64_t> ids, revs;
+    std::vector<float> scales;
+    std::vector<uint8_t> payload;
+    uint64_t row_bytes = 0;
+    for (;;) {
+        const int rc = g_api.step(sel);
+        if (rc == SQLITE_DONE) break;
+        if (rc != SQLITE_ROW) {
+            *err = std::string("the select failed: ") + g_api.errmsg(db);
+            return PVS_ERR_INVALID_ARG;
+        }
+        if (g_api.column_type(sel, 1) != SQLITE_BLOB || g_api.column_type(sel, 2) != SQLITE_BLOB) {
+            *err = "pvs_backfill: the select must yield (id, embedding BLOB, artifact BLOB, artifact_rev)";
+            return PVS_ERR_INVALID_ARG;
+        }
+        const void *emb = g_api.column_blob(sel, 1);
+        const uint64_t nb = (uint64_t)g_api.column_bytes(sel, 1);
+        if (!emb || nb == 0 || nb % 4 != 0 || (row_bytes && nb != row_bytes)) {
+            *err = "pvs_backfill: embeddings must be non-empty f32 blobs of one length (guard the select with length(e.embedding) = c.dim * 4)";
+            return PVS_ERR_DIM_MISMATCH;
+        }
+        row_bytes = nb;
+        payload.insert(payload.end(), (const uint8_t *)emb, (const uint8_t *)emb + nb);
+        const void *art = g_api.column_blob(sel, 2);
+        const uint64_t na = (uint64_t)g_api.column_bytes(sel, 2);
+        float scale = 0.f;
+        if (!art || pvs_artifact_scale((const uint8_t *)art, (size_t)na, &scale) != PVS_OK) {
+            *err = "Invalid vector quant scale artifact";  // (the reference's message, :1141-1148: refuse to backfill)
+            return PVS_ERR_INVALID_ARG;
+        }
+        scales.push_back(scale);
+        ids.push_back((int64_t)g_api.column_int64(sel, 0));
+        revs.push_back((int64_t)g_api.column_int64(sel, 3));
+    }
+    res->written = 0;
+    res->cursor = -1;
+    if (ids.empty()) return PVS_OK;
+    const uint64_t dim = row_bytes / 4, n = ids.size();
+    std::vector<int8_t> codes(n * dim);
+    for (uint64_t i = 0; i < n;) {  // one device pass per run of rows sharing a scale (one pair: one run)
+        uint64_t j = i + 1;
+        while (j < n && memcmp(&scales[j], &scales[i], 4) == 0) j++;
+        const pvs_status qs = pvs_quantize_i8((const float *)payload.data() + i * dim, (j - i) * dim, scales[i], codes.data() + i * dim, PVS_HOST, device);
+        if (qs != PVS_OK) {
+            *err = pvs_last_error();
+            return qs;
+        }
+        i = j;
+    }
+    void *up = nullptr;
+    if (g_api.prepare_v2(db, upsert_sql, -1, &up, nullptr) != SQLITE_OK || !up) {
+        *err = std::string("the upsert does not prepare: ") + g_api.errmsg(db);
+        return PVS_ERR_INVALID_ARG;
+    }
+    pvs_status st = PVS_OK;
+    for (uint64_t i = 0; i < n; i++) {
+        g_api.reset(up);
+        if (g_api.bind_int64(up, 1, ids[i]) != SQLITE_OK || g_api.bind_int64(up, 2, profile_id) != SQLITE_OK || g_api.bind_int64(up, 3, revs[i]) != SQLITE_OK ||
+            g_api.bind_blob(up, 4, codes.data() + i * dim, (int)dim, nullptr /* SQLITE_STATIC: codes outlives the step */) != SQLITE_OK ||
+            g_api.step(up) != SQLITE_DONE) {
+            *err = std::string("the upsert failed: ") + g_api.errmsg(db);
+            st = PVS_ERR_INVALID_ARG;
+            break;
+        }
+        res->written++;
+        res->cursor = std::max(res->cursor, ids[i]);
+    }
+    g_api.finalize(up);
+    return st;
+}
+
+void backfill_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
+    if (argc < 4) {
+        g_api.result_error(ctx, "pvs_backfill(select_sql, upsert_sql, profile_id, device[, select parameter ...])", -1);
+        return;
+    }
+    const unsigned char *sel_sql = g_api.value_text(argv[0]);
+    const unsigned char *up_sql = g_api.value_text(argv[1]);
+    if (!sel_sql || !up_sql) {
+        g_api.result_error(ctx, "pvs_backfill: NULL statement text", -1);
+        return;
+    }
+    const std::string up_copy((const char *)up_sql);  // (value_text pointers do not survive other calls on the same value set)
+    sqlite3 *db = g_api.context_db_handle(ctx);
+    void *sel = nullptr;
+    if (g_api.prepare_v2(db, (const char *)sel_sql, -1, &sel, nullptr) != SQLITE_OK || !sel) {
+        char *m = g_api.mprintf("pvs_backfill: %s", g_api.errmsg(db));
+        g_api.result_error(ctx, m ? m : "pvs_backfill: prepare failed", -1);
+        if (m) g_api.free(m);
+        return;
+    }
+    const long long profile_id = g_api.value_int64(argv[2]);
+    const int device = (int)g_api.value_int64(argv[3]);
+    for (int i = 4; i < argc; i++)
+        if (g_api.bind_value(sel, i - 3, argv[i]) != SQLITE_OK) {
+            g_api.finalize(sel);
+            g_api.result_error(ctx, "pvs_backfill: more parameters than the select has", -1);
+            return;
+        }
+    pvs_sqlite_backfill_result res = {0, -1};
+    std::string err;
+    const pvs_status s = backfill_run(db, sel, up_copy.c_str(), profile_id, device, &res, &err);
+    g_api.finalize(sel);
+    t_last_backfill = res;
+    if (s != PVS_OK) {
+        char *m = g_api.mprintf("pvs_backfill: %s (after %lld rows)", err.empty() ? pvs_last_error() : err.c_str(), (long long)res.written);
+        g_api.result_error(ctx, m ? m : "pvs_backfill failed", -1);
+        if (m) g_api.free(m);
+        return;
+    }
+    g_api.result_int64(ctx, (long long)res.written);
+}
+void backfill_cursor_udf(sqlite3_context *ctx, int, sqlite3_value **) {
+    if (t_last_backfill.cursor < 0 && t_last_backfill.written == 0)
+        g_api.result_null(ctx);
+    else
+        g_api.result_int64(ctx, (long long)t_last_backfill.cursor);
+}
+
 int register_all(sqlite3 *db) {
     int rc = g_api.create_module_v2(db, "pvs_dist", &g_dist_module, nullptr, nullptr);
     if (rc != SQLITE_OK) return rc;
@@ -548,15 +730,57 @@ int register_all(sqlite3 *db) {
         rc = g_api.create_function_v2(db, "pvs_load_info", 1, SQLITE_UTF8, nullptr, load_info_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;
     }
+    if (have_write_api()) {
+        rc = g_api.create_function_v2(db, "pvs_backfill", -1, SQLITE_UTF8, nullptr, backfill_udf, nullptr, nullptr, nullptr);
+        if (rc != SQLITE_OK) return rc;
+        rc = g_api.create_function_v2(db, "pvs_backfill_cursor", 0, SQLITE_UTF8, nullptr, backfill_cursor_udf, nullptr, nullptr, nullptr);
+        if (rc != SQLITE_OK) return rc;
+    }
     // not SQLITE_DETERMINISTIC: the result depends on the bound index's contents, which SQLite cannot see
     rc = g_api.create_function_v2(db, "pvs_distance_cosine", 3, SQLITE_UTF8, (void *)(intptr_t)PVS_COSINE, distance_udf, nullptr, nullptr, nullptr);
     if (rc != SQLITE_OK) return rc;
     return g_api.create_function_v2(db, "pvs_distance_l2", 3, SQLITE_UTF8, (void *)(intptr_t)PVS_L2, distance_udf, nullptr, nullptr, nullptr);
 }
 
+// Slots of sqlite3_api_routines (sqlite3ext.h), an append-only struct of function pointers: the index of each entry point
+// this file uses.  create_function_v2 (3.7.3) is the youngest; libversion_number gates the read.
+enum ApiSlot {
+    SLOT_bind_blob = 2, SLOT_bind_int64 = 5, SLOT_bind_value = 12, SLOT_column_blob = 19, SLOT_column_bytes = 20, SLOT_column_int64 = 29,
+    SLOT_column_type = 38, SLOT_declare_vtab = 50, SLOT_errmsg = 53, SLOT_finalize = 57, SLOT_free = 58, SLOT_get_auxdata = 61,
+    SLOT_libversion_number = 67, SLOT_mprintf = 69, SLOT_reset = 77, SLOT_result_double = 79, SLOT_result_error = 80,
+    SLOT_result_int64 = 83, SLOT_result_null = 84, SLOT_result_text = 85, SLOT_set_auxdata = 92, SLOT_step = 94, SLOT_user_data = 101,
+    SLOT_value_blob = 102, SLOT_value_bytes = 103, SLOT_value_int64 = 107, SLOT_value_text = 109, SLOT_value_type = 113,
+    SLOT_prepare_v2 = 116, SLOT_create_module_v2 = 119, SLOT_context_db_handle = 149, SLOT_create_function_v2 = 162
+};
+bool fill_api_from_routines(const void *pApi, const char **why) {
+    void *const *slot = (void *const *)pApi;
+    int (*libversion_number)(void) = (int (*)(void))slot[SLOT_libversion_number];
+    if (!libversion_number || libversion_number() < 3008000) {
+        *why = "libpvs_sqlite needs SQLite >= 3.8.0";
+        return false;
+    }
+    pvs_sqlite_api a;
+    memset(&a, 0, sizeof a);
+    a.struct_size = sizeof a;
+#define SLOT(field) a.field = (decltype(a.field))slot[SLOT_##field];
+    SLOT(create_function_v2) SLOT(create_module_v2) SLOT(declare_vtab) SLOT(value_type) SLOT(value_bytes) SLOT(value_blob)
+    SLOT(value_text) SLOT(value_int64) SLOT(result_double) SLOT(result_int64) SLOT(result_null) SLOT(result_error) SLOT(user_data)
+    SLOT(get_auxdata) SLOT(set_auxdata) SLOT(mprintf) SLOT(free) SLOT(prepare_v2) SLOT(step) SLOT(finalize) SLOT(column_type)
+    SLOT(column_blob) SLOT(column_bytes) SLOT(column_int64) SLOT(bind_value) SLOT(context_db_handle) SLOT(errmsg) SLOT(result_text)
+    SLOT(bind_blob) SLOT(bind_int64) SLOT(reset)
+#undef SLOT
+    g_api = a;
+    g_api_set = true;
+    return true;
+}
+
+// By-name lookup in the process image: only behind the explicit pvs_sqlite_register(db, NULL) / pvs_sqlite_load of a process
+// that never went through an extension entry point (the Python test harness's ctypes route).  The process's own image first;
+// a loaded libsqlite3.so.0 only when the image exports nothing.
 bool fill_api_from_process(std::string *missing) {
-    void *h = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_NOLOAD);  // the copy the host process already loaded
-    if (!h) h = dlopen(nullptr, RTLD_NOW);                        // or the host binary's own (statically linked) SQLite
+    void *h = dlopen(nullptr, RTLD_NOW);
+    if (h && !dlsym(h, "sqlite3_create_function_v2")) h = nullptr;
+    if (!h) h = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_NOLOAD);
     if (!h) return false;
     pvs_sqlite_api a;
     memset(&a, 0, sizeof a);
@@ -595,6 +819,9 @@ bool fill_api_from_process(std::string *missing) {
     SYM(context_db_handle, "sqlite3_context_db_handle")
     SYM(errmsg, "sqlite3_errmsg")
     SYM(result_text, "sqlite3_result_text")
+    SYM(bind_blob, "sqlite3_bind_blob")
+    SYM(bind_int64, "sqlite3_bind_int64")
+    SYM(reset, "sqlite3_reset")
 #undef SYM
     g_api = a;
     g_api_set = true;
@@ -622,11 +849,20 @@ PVS_EXPORT int32_t pvs_sqlite_register(void *db, const pvs_sqlite_api *api) {
 }
 // loadable-extension entry points: `.load libpvs_sqlite`, sqlite3_load_extension, Python's Connection.load_extension,
 // or sqlite3_auto_extension(sqlite3_pvs_init) exactly where the reference registers sqlite3_vec_init
-// (db/sql_functions.rs:105-128).  The third argument (sqlite3_api_routines*) is not used: see the file comment.
+// (db/sql_functions.rs:105-128).  Every SQLite entry point comes from the third argument.
 PVS_EXPORT int sqlite3_pvs_init(void *db, char **pzErrMsg, const void *pApi) {
-    (void)pApi;
-    const int rc = pvs_sqlite_register(db, nullptr);
-    if (rc != SQLITE_OK && pzErrMsg && g_api_set) *pzErrMsg = g_api.mprintf("%s", "libpvs_sqlite: registration failed");
+    if (!db || !pApi) return SQLITE_ERROR;  // (an entry point is only ever called by SQLite, which always passes its table)
+    const char *why = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!fill_api_from_routines(pApi, &why)) {
+            char *(*mprintf)(const char *, ...) = (char *(*)(const char *, ...))((void *const *)pApi)[SLOT_mprintf];
+            if (pzErrMsg && mprintf) *pzErrMsg = mprintf("%s", why);
+            return SQLITE_ERROR;
+        }
+    }
+    const int rc = register_all((sqlite3 *)db);
+    if (rc != SQLITE_OK && pzErrMsg) *pzErrMsg = g_api.mprintf("%s", "libpvs_sqlite: registration failed");
     return rc;
 }
 PVS_EXPORT int sqlite3_extension_init(void *db, char **pzErrMsg, const void *pApi) { return sqlite3_pvs_init(db, pzErrMsg, pApi); }
@@ -649,6 +885,38 @@ PVS_EXPORT int32_t pvs_sqlite_load(void *db, const char *sql, pvs_index *idx, ui
     std::string err;
     const pvs_status s = stream_rows(stmt, idx, chunk_rows, &res, &err);
     g_api.finalize(stmt);
+    if (out) *out = res;
+    return s;
+}
+
+PVS_EXPORT int32_t pvs_sqlite_api_snapshot(pvs_sqlite_api *out) {
+    if (!out) return 1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_api_set) return 1;
+    const uint32_t want = out->struct_size;
+    memcpy(out, &g_api, std::min<size_t>(want, sizeof g_api));
+    out->struct_size = (uint32_t)std::min<size_t>(want, g_api.struct_size);
+    return 0;
+}
+
+// ---- the backfill for a host that holds the connection itself (select without parameters)
+PVS_EXPORT int32_t pvs_sqlite_backfill(void *db, const char *select_sql, const char *upsert_sql, int64_t profile_id, int32_t device,
+                                       pvs_sqlite_backfill_result *out) {
+    if (!db || !select_sql || !upsert_sql) return PVS_ERR_INVALID_ARG;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_api_set) {
+            std::string missing;
+            if (!fill_api_from_process(&missing)) return PVS_ERR_STATE;
+        }
+    }
+    if (!have_write_api()) return PVS_ERR_STATE;
+    void *sel = nullptr;
+    if (g_api.prepare_v2((sqlite3 *)db, select_sql, -1, &sel, nullptr) != SQLITE_OK || !sel) return PVS_ERR_INVALID_ARG;
+    pvs_sqlite_backfill_result res = {0, -1};
+    std::string err;
+    const pvs_status s = backfill_run((sqlite3 *)db, sel, upsert_sql, profile_id, device, &res, &err);
+    g_api.finalize(sel);
     if (out) *out = res;
     return s;
 }

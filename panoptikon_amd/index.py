@@ -239,6 +239,11 @@ class VectorIndex:
     def set_path(self, path: int):
         L.check(L.lib().pvs_index_set_path(self._h, path))
 
+    def scan_kernel_name(self, batch: int) -> str:
+        buf = C.create_string_buffer(128)
+        L.check(L.lib().pvs_index_scan_kernel_name(self._h, batch, buf, 128))
+        return buf.value.decode()
+
     def score_all(self, query, metric: int = L.COSINE) -> np.ndarray:
         q, qd = self._queries(query)
         out = np.empty(self.stats().rows, np.float32)

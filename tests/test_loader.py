@@ -208,11 +208,59 @@ def test_sqlite_extension_loads_and_registers_without_a_gpu():
     assert [r[0] for r in conn.execute("SELECT name FROM pragma_module_list WHERE name = 'pvs_dist'")] == ["pvs_dist"]
     assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_distance%'")} == {"pvs_distance_cosine", "pvs_distance_l2"}
     assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_load%'")} == {"pvs_load", "pvs_load_info"}
+    assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_backfill%'")} == {"pvs_backfill", "pvs_backfill_cursor"}
     assert conn.execute("SELECT pvs_load_info('nope')").fetchone()[0] is None
+    assert conn.execute("SELECT pvs_backfill_cursor()").fetchone()[0] is None
+    # backfill: errors that need no device (the select is read, and refused, before anything is quantized)
+    for sql in ("SELECT pvs_backfill('SELECT 1, 2, 3, 4', 'SELECT 1', 5, 0)",                       # embedding / artifact are not blobs
+                "SELECT pvs_backfill('SELECT 1, zeroblob(6), zeroblob(4), 2', 'SELECT 1', 5, 0)",   # not a whole number of floats
+                "SELECT pvs_backfill('SELECT 1, zeroblob(8), zeroblob(3), 2', 'SELECT 1', 5, 0)",   # artifact is not a scale
+                "SELECT pvs_backfill('SELECT nope', 'SELECT 1', 5, 0)", "SELECT pvs_backfill('SELECT 1')"):
+        with pytest.raises(sqlite3.OperationalError):
+            conn.execute(sql).fetchall()
+    assert conn.execute("SELECT pvs_backfill('SELECT 1, zeroblob(8), zeroblob(4), 2 WHERE 0', 'SELECT 1', 5, 0)").fetchone()[0] == 0  # nothing to do
     for sql, args in (("SELECT * FROM pvs_dist('nope', ?)", (b"\0" * 16,)), ("SELECT pvs_distance_l2('nope', 1, ?)", (b"\0" * 16,)), ("SELECT * FROM pvs_dist('x')", ()),
                       ("SELECT pvs_load('nope', 'SELECT 1, 1, zeroblob(4)')", ()), ("SELECT pvs_load('nope')", ())):
         with pytest.raises(sqlite3.OperationalError):
             conn.execute(sql, args).fetchall()
+
+
+_PAPI_SCRIPT = r"""
+import ctypes as C, sqlite3
+from panoptikon_amd import sqlite_seam
+NAMES = ["create_function_v2", "create_module_v2", "declare_vtab", "value_type", "value_bytes", "value_blob", "value_text", "value_int64",
+         "result_double", "result_int64", "result_null", "result_error", "user_data", "get_auxdata", "set_auxdata", "mprintf", "free",
+         "prepare_v2", "step", "finalize", "column_type", "column_blob", "column_bytes", "column_int64", "bind_value", "context_db_handle",
+         "errmsg", "result_text", "bind_blob", "bind_int64", "reset"]
+class Api(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_void_p) for n in NAMES]
+ext = sqlite_seam.ext()
+ext.pvs_sqlite_api_snapshot.restype = C.c_int32
+ext.pvs_sqlite_api_snapshot.argtypes = [C.c_void_p]
+a = Api(); a.struct_size = C.sizeof(Api)
+assert ext.pvs_sqlite_api_snapshot(C.byref(a)) == 1, "nothing installed before an entry point ran"
+conn = sqlite3.connect(":memory:")
+sqlite_seam.load(conn)   # sqlite3_load_extension -> sqlite3_extension_init(db, &err, pApi): SQLite's own table
+a = Api(); a.struct_size = C.sizeof(Api)
+assert ext.pvs_sqlite_api_snapshot(C.byref(a)) == 0 and a.struct_size == C.sizeof(Api)
+s3 = C.CDLL("libsqlite3.so.0")  # the SQLite the stdlib module runs on
+bad = [n for n in NAMES if getattr(a, n) != C.cast(getattr(s3, "sqlite3_" + n), C.c_void_p).value]
+print("mismatched slots:", bad)
+"""
+
+
+def test_extension_entry_point_takes_sqlite_from_the_api_routines_table():
+    """sqlite3_auto_extension(sqlite3_pvs_init) in a host with a statically linked SQLite (the reference: libsqlite3-sys bundled,
+    db/sql_functions.rs:105-128) only works when the entry point uses the sqlite3_api_routines table SQLite passes it.  Every slot
+    index the extension reads (csrc/pvs_sqlite.cpp: ApiSlot) is checked here against the real library: after the stdlib module
+    loaded the extension, the installed table must hold exactly the addresses of libsqlite3's own functions.  (Own process: the
+    table is process-wide, and nothing may have installed one before.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, "-c", _PAPI_SCRIPT], cwd=root, text=True, env=dict(os.environ, PYTHONPATH=root))
+    assert out.strip().splitlines()[-1] == "mismatched slots: []", out
 
 
 class _StubIndex:
@@ -435,8 +483,9 @@ V1 = ["create_function_v2", "create_module_v2", "declare_vtab", "value_type", "v
       "result_double", "result_int64", "result_null", "result_error", "user_data", "get_auxdata", "set_auxdata", "mprintf", "free"]
 V2 = ["prepare_v2", "step", "finalize", "column_type", "column_blob", "column_bytes", "column_int64", "bind_value", "context_db_handle",
       "errmsg", "result_text"]
+V3 = ["bind_blob", "bind_int64", "reset"]
 class Api(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_void_p) for n in V1 + V2]
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_void_p) for n in V1 + V2 + V3]
 def table(names, size):
     a = Api()
     for n in names:
@@ -448,7 +497,7 @@ assert s3.sqlite3_open(b":memory:", C.byref(db)) == 0
 ext.pvs_sqlite_register.restype = C.c_int32
 ext.pvs_sqlite_register.argtypes = [C.c_void_p, C.c_void_p]
 mode = sys.argv[1]
-api = table(V1, Api.prepare_v2.offset) if mode == "v1" else table(V1 + V2, C.sizeof(Api))
+api = table(V1, Api.prepare_v2.offset) if mode == "v1" else table(V1 + V2, Api.bind_blob.offset) if mode == "v2" else table(V1 + V2 + V3, C.sizeof(Api))
 assert ext.pvs_sqlite_register(db, C.byref(api)) == 0
 short = table(V1, 16)
 assert ext.pvs_sqlite_register(db, C.byref(short)) != 0, "a struct shorter than v1 is refused"
@@ -457,14 +506,15 @@ def has(fn):
     rc = s3.sqlite3_prepare_v2(db, ("SELECT " + fn).encode(), -1, C.byref(st), None)
     s3.sqlite3_finalize(st)
     return rc == 0
-print(int(has("pvs_distance_l2('x', 1, zeroblob(4))")), int(has("pvs_load('x', 'SELECT 1')")), int(has("pvs_load_info('x')")))
+print(int(has("pvs_distance_l2('x', 1, zeroblob(4))")), int(has("pvs_load('x', 'SELECT 1')")), int(has("pvs_load_info('x')")), int(has("pvs_backfill('a', 'b', 1, 0)")))
 """
 
 
-@pytest.mark.parametrize("mode,expect", [("v1", "1 0 0"), ("v2", "1 1 1")])
+@pytest.mark.parametrize("mode,expect", [("v1", "1 0 0 0"), ("v2", "1 1 1 0"), ("v3", "1 1 1 1")])
 def test_host_supplied_sqlite_entry_points(mode, expect):
     """pvs_sqlite_register with the host's own table of SQLite entry points (a Rust host links its own SQLite): the full
-    struct registers everything, the shorter v1 struct everything but the row streamer; no dlsym, no GPU.  (Own process:
+    struct registers everything, the v2 struct everything but pvs_backfill, the v1 struct neither that nor the row streamer; no
+    dlsym, no GPU.  (Own process:
     the table is process-wide.)"""
     import subprocess
     import sys
@@ -519,3 +569,89 @@ def test_row_streamer_c_entry_point_on_a_connection_the_host_holds():
     finally:
         ix.close()
         s3.sqlite3_close(db)
+
+
+# The reference's two statements of a backfill chunk, restated (db/vector_quants.rs:1085-1117): what is outstanding for a
+# (profile, setter) pair that is `building`, past a cursor, in id order; and the upsert that keeps a row's rowid.
+_BACKFILL_SELECT = """SELECT d.id, e.embedding, c.artifact, c.artifact_rev
+    FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id JOIN embeddings e ON e.id = d.id
+    WHERE c.profile_id = ? AND c.setter_id = ? AND c.state = 'building' AND c.artifact IS NOT NULL AND d.id > ?
+      AND length(e.embedding) = c.dim * 4
+      AND NOT EXISTS (SELECT 1 FROM embedding_quants q WHERE q.id = e.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev)
+    ORDER BY d.id LIMIT ?"""
+_BACKFILL_UPSERT = """INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, ?, ?, ?)
+    ON CONFLICT (id, profile_id) DO UPDATE SET rev = excluded.rev, quant = excluded.quant"""
+
+
+@pytest.mark.gpu
+def test_backfill_quantizes_on_the_device_and_upserts_like_backfill_chunk():
+    """pvs_backfill = the reference's backfill_chunk (db/vector_quants.rs:1119-1163) with quantize_int8 on the device: same rows
+    written, same codes (the oracle's, bit for bit), same cursor protocol, nothing written for a pair that is not `building` or
+    whose artifact is not a scale; the rows keep their rowids (upsert, not replace)."""
+    from panoptikon_amd import sqlite_seam
+
+    conn, good, scale, codes = build_db(n_items=400, dim=96, ragged=True)
+    sqlite_seam.load(conn)
+    mine = [m for m in good if m[2] == 1]  # setter 1's vectors
+    want = {m[0]: c.tobytes() for m, c in zip(good, codes) if m[2] == 1}
+    rowids = dict(conn.execute("SELECT id, rowid FROM embedding_quants WHERE profile_id = 5"))
+    # a rebuild of setter 1's pair: new revision, pair back to `building`; its rows are now all outstanding
+    conn.execute("UPDATE vector_quant_coverage SET state = 'building', artifact_rev = 3 WHERE profile_id = 5 AND setter_id = 1")
+    conn.execute("UPDATE embedding_quants SET quant = zeroblob(96) WHERE id IN (SELECT id FROM item_data WHERE setter_id = 1)")  # stale codes
+    cursor, total, chunks = 0, 0, 0
+    while True:
+        n = conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, ?, 64)", (_BACKFILL_SELECT, _BACKFILL_UPSERT, cursor)).fetchone()[0]
+        if n == 0:
+            break
+        cursor = conn.execute("SELECT pvs_backfill_cursor()").fetchone()[0]
+        total += n
+        chunks += 1
+    assert total == len(mine) and chunks == -(-len(mine) // 64) and cursor == max(m[0] for m in mine)
+    got = dict(conn.execute("SELECT id, quant FROM embedding_quants WHERE profile_id = 5 AND rev = 3"))
+    assert got == want, "device codes differ from quantize_int8"
+    assert dict(conn.execute("SELECT id, rowid FROM embedding_quants WHERE profile_id = 5")) == rowids, "the upsert must keep rowids"
+    assert conn.execute("SELECT COUNT(*) FROM embedding_quants WHERE profile_id = 5 AND rev = 2").fetchone()[0] == len(good) - len(mine)  # setter 2 untouched
+    assert conn.execute("SELECT COUNT(*) FROM embedding_quants WHERE id = 7").fetchone()[0] == 0  # the ragged vector is not quantized
+    # complete: nothing outstanding from the start
+    assert conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, 0, 64)", (_BACKFILL_SELECT, _BACKFILL_UPSERT)).fetchone()[0] == 0
+    # a pair that is not building yields nothing; an artifact that is not a scale refuses before writing anything
+    conn.execute("UPDATE vector_quant_coverage SET state = 'ready' WHERE profile_id = 5 AND setter_id = 1")
+    conn.execute("UPDATE vector_quant_coverage SET artifact_rev = 4 WHERE profile_id = 5 AND setter_id = 1")
+    assert conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, 0, 64)", (_BACKFILL_SELECT, _BACKFILL_UPSERT)).fetchone()[0] == 0
+    conn.execute("UPDATE vector_quant_coverage SET state = 'building', artifact = x'0000' WHERE profile_id = 5 AND setter_id = 1")
+    with pytest.raises(sqlite3.OperationalError, match="Invalid vector quant scale artifact"):
+        conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, 0, 64)", (_BACKFILL_SELECT, _BACKFILL_UPSERT)).fetchall()
+    assert conn.execute("SELECT COUNT(*) FROM embedding_quants WHERE rev = 4").fetchone()[0] == 0
+
+
+@pytest.mark.gpu
+def test_sql_seam_reads_a_column_longer_than_one_window():
+    """pvs_dist / pvs_distance_* keep the `d` column in HBM and read it through a 262,144-row window: a column of 600k rows
+    (three windows) must come out exactly as pvs_score_all returns it, in order and by random id lookups."""
+    import panoptikon_amd as pvs
+    from panoptikon_amd import sqlite_seam
+
+    n, dim = 600_000, 32
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = (np.arange(n, dtype=np.int64) * 3 + 11)  # sparse, increasing
+    ix = pvs.VectorIndex(pvs.F32, dim)
+    ix.add_f32(rows, row_ids=ids)
+    q = rng.standard_normal(dim).astype(np.float32)
+    ref = ix.score_all(q, pvs.L2)
+    conn = sqlite3.connect(":memory:")
+    sqlite_seam.load(conn)
+    sqlite_seam.bind("big", ix)
+    try:
+        got = conn.execute("SELECT id, d FROM pvs_dist('big', ?, 'l2')", (q.tobytes(),)).fetchall()
+        assert len(got) == n and [g[0] for g in got[:5]] == ids[:5].tolist() and got[-1][0] == int(ids[-1])
+        assert np.array_equal(np.array([g[1] for g in got], np.float32).view(np.uint32), ref.view(np.uint32))
+        conn.execute("CREATE TABLE probe (id INTEGER PRIMARY KEY)")
+        pick = rng.choice(n, 4000, replace=False)
+        conn.executemany("INSERT INTO probe (id) VALUES (?)", [(int(ids[i]),) for i in pick] + [(5,), (int(ids[-1]) + 1,)])  # two ids the index lacks
+        out = dict(conn.execute("SELECT id, pvs_distance_l2('big', id, ?) FROM probe", (q.tobytes(),)))
+        assert out[5] is None and out[int(ids[-1]) + 1] is None
+        assert all(np.float32(out[int(ids[i])]) == ref[i] for i in pick)
+    finally:
+        sqlite_seam.unbind("big")
+        ix.close()
