@@ -108,8 +108,10 @@ typedef struct pvs_index_desc {
      * (SURVEY.md §8e).  n_devices 0 or 1 = single device.  An ordinal may repeat (several shards on one GPU:
      * used by the tests on one-GPU machines).  Served on a multi-device index: add, scale, stats, read back,
      * pvs_search / pvs_search_device + pvs_wait, pvs_score_all, pvs_search_groups with MIN (a group may span
-     * shards: the minimum of the shard minima), pvs_rrf_search over MIN branches; other per-item entry
-     * points return PVS_ERR_UNSUPPORTED (MAX/AVG need every row of a group on one device). */
+     * shards: the minimum of the shard minima); the other per-item entry points (MAX / AVG / weights, masks,
+     * pvs_score_batch, pvs_similar_to, pvs_rrf_search) return PVS_ERR_UNSUPPORTED — they need every row of a
+     * group on one device.  A pvs_index_add that fails after some shards took their piece leaves the index
+     * unusable (PVS_ERR_STATE from every later call): destroy and rebuild it. */
     uint32_t n_devices;
     const int32_t *devices; /* [n_devices] HIP ordinals */
 } pvs_index_desc;

@@ -19,19 +19,74 @@ pvs_status pvs_fail(pvs_status code, const char *fmt, ...) {
 PVS_EXPORT const char *pvs_last_error(void) { return g_last_error.c_str(); }
 
 // ------------------------------------------------------------------ scratch cache
+// Blocks for the host-orchestrated paths, kept per (device, size class) after use.  Three rules:
+//   * a block handed back while work that touches it may still be queued (pvs_scratch_free_on: the usual case — the caller
+//     enqueued kernels and returns) carries an event recorded on that stream and is only handed out again once the event has
+//     completed: another thread, on another stream, can never get a block a kernel is still reading or writing;
+//   * idle bytes per device are capped (PVS_SCRATCH_IDLE_CAP_MB, default 16 GiB): beyond the cap the least recently used idle
+//     blocks go back to the runtime — the dense fallback's n x per x 4 byte matrices come in dozens of size classes and would
+//     otherwise pile up multi-GB blocks nobody asks for again;
+//   * every device allocation of the library (pvs_malloc_retry) returns the idle blocks to the runtime and tries again before it
+//     reports out-of-memory.
 namespace {
 struct ScratchBlock {
     int device;
     size_t cls;
 };
+struct IdleBlock {
+    void *p;
+    hipEvent_t ev;      // nullptr: nothing pending
+    uint64_t stamp;     // LRU clock
+};
 std::mutex g_scratch_mu;
-std::map<std::pair<int, size_t>, std::vector<void *>> g_scratch_idle;  // (device, size class) -> idle blocks
+std::map<std::pair<int, size_t>, std::vector<IdleBlock>> g_scratch_idle;  // (device, size class) -> idle blocks
 std::map<void *, ScratchBlock> g_scratch_live;
+std::map<int, size_t> g_scratch_idle_bytes;  // per device
+uint64_t g_scratch_clock = 0;
 size_t scratch_class(size_t bytes) {
     size_t c = 4096;
     while (c < bytes) c <<= 1;
     if (c > (64u << 20)) c = (bytes + (16u << 20) - 1) / (16u << 20) * (16u << 20);  // big blocks: 16 MiB steps, not powers of two
     return c;
+}
+size_t scratch_idle_cap() {
+    static const size_t cap = getenv("PVS_SCRATCH_IDLE_CAP_MB") ? (size_t)strtoull(getenv("PVS_SCRATCH_IDLE_CAP_MB"), nullptr, 10) << 20 : (size_t)16 << 30;
+    return cap;
+}
+// (lock held) idle blocks of `device` beyond the cap, least recently used first, are moved to `drop`
+void scratch_evict_locked(int device, std::vector<IdleBlock> *drop) {
+    while (g_scratch_idle_bytes[device] > scratch_idle_cap()) {
+        std::vector<IdleBlock> *best_v = nullptr;
+        size_t best_i = 0, best_cls = 0;
+        uint64_t best_stamp = ~0ull;
+        for (auto &kv : g_scratch_idle)
+            if (kv.first.first == device)
+                for (size_t i = 0; i < kv.second.size(); i++)
+                    if (kv.second[i].stamp < best_stamp) {
+                        best_stamp = kv.second[i].stamp;
+                        best_v = &kv.second;
+                        best_i = i;
+                        best_cls = kv.first.second;
+                    }
+        if (!best_v) break;
+        drop->push_back((*best_v)[best_i]);
+        best_v->erase(best_v->begin() + (long)best_i);
+        g_scratch_idle_bytes[device] -= best_cls;
+    }
+}
+void scratch_release(int device, std::vector<IdleBlock> &drop) {  // (no lock held) hipFree waits for whatever still uses the block
+    if (drop.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    for (IdleBlock &b : drop) {
+        if (b.ev) {
+            (void)hipEventSynchronize(b.ev);
+            (void)hipEventDestroy(b.ev);
+        }
+        (void)hipFree(b.p);
+    }
+    (void)hipSetDevice(cur);
 }
 }  // namespace
 hipError_t pvs_scratch_alloc(void **out, size_t bytes) {
@@ -42,33 +97,58 @@ hipError_t pvs_scratch_alloc(void **out, size_t bytes) {
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         auto &v = g_scratch_idle[{dev, cls}];
-        if (!v.empty()) {
-            *out = v.back();
-            v.pop_back();
+        for (size_t i = v.size(); i-- > 0;) {  // most recently freed first
+            if (v[i].ev) {
+                if (hipEventQuery(v[i].ev) != hipSuccess) {
+                    (void)hipGetLastError();  // (hipErrorNotReady is sticky in hipGetLastError)
+                    continue;                // still in use on the stream it was freed on
+                }
+                (void)hipEventDestroy(v[i].ev);
+            }
+            *out = v[i].p;
+            v.erase(v.begin() + (long)i);
+            g_scratch_idle_bytes[dev] -= cls;
             g_scratch_live[*out] = {dev, cls};
             return hipSuccess;
         }
     }
-    e = hipMalloc(out, cls);
-    if (e != hipSuccess) {  // give the idle blocks back and try once more
-        pvs_scratch_trim(dev);
-        e = hipMalloc(out, cls);
-        if (e != hipSuccess) return e;
-    }
+    e = pvs_malloc_retry(out, cls);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     g_scratch_live[*out] = {dev, cls};
     return hipSuccess;
 }
-void pvs_scratch_free(void *p) {
+// `s`: the stream whose queued work may still touch the block; nullptr = the caller has already waited for it
+void pvs_scratch_free_on(void *p, hipStream_t s, bool pending) {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    auto it = g_scratch_live.find(p);
-    if (it == g_scratch_live.end()) return;  // not ours
-    g_scratch_idle[{it->second.device, it->second.cls}].push_back(p);
-    g_scratch_live.erase(it);
+    hipEvent_t ev = nullptr;
+    if (pending) {
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+            if (ev) (void)hipEventDestroy(ev);
+            ev = nullptr;
+            (void)hipStreamSynchronize(s);  // no event: wait here instead
+        }
+    }
+    std::vector<IdleBlock> drop;
+    int dev = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        auto it = g_scratch_live.find(p);
+        if (it == g_scratch_live.end()) {  // not ours
+            if (ev) (void)hipEventDestroy(ev);
+            return;
+        }
+        dev = it->second.device;
+        g_scratch_idle[{dev, it->second.cls}].push_back({p, ev, ++g_scratch_clock});
+        g_scratch_idle_bytes[dev] += it->second.cls;
+        g_scratch_live.erase(it);
+        scratch_evict_locked(dev, &drop);
+    }
+    scratch_release(dev, drop);
 }
+void pvs_scratch_free(void *p) { pvs_scratch_free_on(p, nullptr, false); }
 void pvs_scratch_trim(int device) {
-    std::vector<void *> drop;
+    std::vector<IdleBlock> drop;
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         for (auto &kv : g_scratch_idle)
@@ -76,13 +156,22 @@ void pvs_scratch_trim(int device) {
                 drop.insert(drop.end(), kv.second.begin(), kv.second.end());
                 kv.second.clear();
             }
+        g_scratch_idle_bytes[device] = 0;
     }
-    if (drop.empty()) return;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    (void)hipSetDevice(device);
-    for (void *p : drop) (void)hipFree(p);
-    (void)hipSetDevice(cur);
+    scratch_release(device, drop);
+}
+// hipMalloc that gives the scratch cache's idle blocks back to the runtime and tries again before reporting out-of-memory
+hipError_t pvs_malloc_retry(void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            pvs_scratch_trim(dev);
+            e = hipMalloc(out, bytes);
+        }
+    }
+    return e;
 }
 PVS_EXPORT uint32_t pvs_abi_version(void) { return PVS_ABI_VERSION; }
 
@@ -226,23 +315,23 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
     c.cur_mask = nullptr;
     if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     if (!c.d_qmat) {
-        HIP_TRY(hipMalloc((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
-        HIP_TRY(hipMalloc((void **)&c.d_qmat, (size_t)PVS_SCAN_MAX_BATCH * ix->stride));
-        HIP_TRY(hipMalloc((void **)&c.d_qpad, pvs_dense_exact_scratch_bytes(ix->stride, ix->esz)));
-        HIP_TRY(hipMalloc((void **)&c.d_qexact, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
-        HIP_TRY(hipMalloc((void **)&c.d_qinfo, sizeof(QInfo) * PVS_SCAN_MAX_BATCH));
-        HIP_TRY(hipMalloc((void **)&c.d_thr, 4 * PVS_SCAN_MAX_BATCH));
-        HIP_TRY(hipMalloc((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
-        HIP_TRY(hipMalloc((void **)&c.d_cand_cnt, 64));
-        HIP_TRY(hipMalloc((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
-        HIP_TRY(hipMalloc((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS * (PVS_SEG_CAP / PVS_WIDE_SEG_CAP)));  // (the 256-query kernel: twice the lists at half the slots)
-        HIP_TRY(hipMalloc((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_qmat, (size_t)PVS_SCAN_MAX_BATCH * ix->stride));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_qpad, pvs_dense_exact_scratch_bytes(ix->stride, ix->esz)));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_qexact, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_qinfo, sizeof(QInfo) * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_thr, 4 * PVS_SCAN_MAX_BATCH));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_gmin, (size_t)4 * PVS_SCAN_MAX_BATCH * GMAX));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_cand_cnt, 64));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS * (PVS_SEG_CAP / PVS_WIDE_SEG_CAP)));  // (the 256-query kernel: twice the lists at half the slots)
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
     }
     static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;  // tests: the LDS-light pass C on every search
     if ((ix->multi_stream || force_light) && ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan)
-        HIP_TRY(hipMalloc((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
-        HIP_TRY(hipMalloc((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
-        HIP_TRY(hipMalloc((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
     }
     if (batch > c.flags_cap) {
         hipFree(c.d_need_dense);
@@ -251,7 +340,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         c.h_need_dense = nullptr;
         uint32_t cap = (uint32_t)pvs_round_up(batch, 256);
         // [0, cap): per-query "answer me on the dense path" flags; [cap, 2 cap): candidates the filter scan emitted per query
-        HIP_TRY(hipMalloc((void **)&c.d_need_dense, 8 * (size_t)cap));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_need_dense, 8 * (size_t)cap));
         HIP_TRY(hipHostMalloc((void **)&c.h_need_dense, 8 * (size_t)cap, hipHostMallocDefault));
         c.flags_cap = cap;
     }
@@ -264,9 +353,9 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
             c.d_out_ids = nullptr;
             c.d_out_dist = nullptr;
             c.d_out_count = nullptr;
-            HIP_TRY(hipMalloc((void **)&c.d_out_ids, 8 * need));
-            HIP_TRY(hipMalloc((void **)&c.d_out_dist, 4 * need));
-            HIP_TRY(hipMalloc((void **)&c.d_out_count, 4 * (size_t)batch));
+            HIP_TRY(pvs_malloc_retry((void **)&c.d_out_ids, 8 * need));
+            HIP_TRY(pvs_malloc_retry((void **)&c.d_out_dist, 4 * need));
+            HIP_TRY(pvs_malloc_retry((void **)&c.d_out_count, 4 * (size_t)batch));
             c.out_cap = need;
             c.out_batch_cap = batch;
         }
@@ -329,14 +418,14 @@ pvs_status pvs_index_reserve_(pvs_index *ix, uint64_t rows) {
     uint8_t *rows_new = nullptr;
     float *norm_new = nullptr;
     int64_t *ids_new = nullptr;
-    HIP_TRY(hipMalloc((void **)&rows_new, cap * (uint64_t)ix->stride));
+    HIP_TRY(pvs_malloc_retry((void **)&rows_new, cap * (uint64_t)ix->stride));
     float *rnorm_new = nullptr, *scos_new = nullptr, *sl2_new = nullptr;
     const uint64_t aux_floats = cap / 32 * PVS_AUX_REC;
-    hipError_t e = hipMalloc((void **)&norm_new, cap * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&rnorm_new, cap * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&ids_new, cap * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&scos_new, aux_floats * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&sl2_new, aux_floats * 4);
+    hipError_t e = pvs_malloc_retry((void **)&norm_new, cap * 4);
+    if (e == hipSuccess) e = pvs_malloc_retry((void **)&rnorm_new, cap * 4);
+    if (e == hipSuccess) e = pvs_malloc_retry((void **)&ids_new, cap * 8);
+    if (e == hipSuccess) e = pvs_malloc_retry((void **)&scos_new, aux_floats * 4);
+    if (e == hipSuccess) e = pvs_malloc_retry((void **)&sl2_new, aux_floats * 4);
     if (e != hipSuccess) {
         hipFree(rows_new);
         hipFree(norm_new);
@@ -464,7 +553,7 @@ pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, 
     const uint64_t row_bytes = (uint64_t)ix->dim * src_esz;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
     void *stage = nullptr;
-    HIP_TRY(hipMalloc(&stage, std::min(chunk, n) * row_bytes));
+    HIP_TRY(pvs_malloc_retry(&stage, std::min(chunk, n) * row_bytes));
     pvs_status st = PVS_OK;
     if (ix->n + n > ix->cap) st = pvs_index_reserve_(ix, std::max<uint64_t>(ix->n + n, ix->cap * 2));
     for (uint64_t off = 0; off < n && st == PVS_OK; off += chunk) {
@@ -609,7 +698,7 @@ PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t
     const size_t w = (size_t)ix->dim * ix->esz;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / w);
     uint8_t *stage = nullptr;
-    HIP_TRY(hipMalloc((void **)&stage, std::min(chunk, n) * w));
+    HIP_TRY(pvs_malloc_retry((void **)&stage, std::min(chunk, n) * w));
     pvs_status st = PVS_OK;
     for (uint64_t off = 0; off < n; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
@@ -664,7 +753,7 @@ static pvs_status with_device_chunks(const float *x, uint64_t n, pvs_space space
     if (space == PVS_DEVICE) return fn(x, n, (uint64_t)0);
     const uint64_t chunk = 64ull << 20;  // elements (256 MiB)
     float *stage = nullptr;
-    HIP_TRY(hipMalloc((void **)&stage, std::min(chunk, n) * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&stage, std::min(chunk, n) * 4));
     pvs_status st = PVS_OK;
     for (uint64_t off = 0; off < n && st == PVS_OK; off += chunk) {
         const uint64_t m = std::min(chunk, n - off);
@@ -683,7 +772,7 @@ PVS_EXPORT pvs_status pvs_absmax(const float *x, uint64_t n, pvs_space space, in
     if (!out_absmax || (n && !x)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     PVS_TRY(use_device(device, nullptr));
     float *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, 4));
+    HIP_TRY(pvs_malloc_retry((void **)&d_out, 4));
     float result = 0.f;
     pvs_status st = with_device_chunks(x, n, space, [&](const float *d, uint64_t m, uint64_t) -> pvs_status {
         HIP_TRY(pvs_launch_absmax(d, m, d_out, nullptr));
@@ -707,7 +796,7 @@ PVS_EXPORT pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, i
     }
     int8_t *d_out = nullptr;
     const uint64_t chunk = 64ull << 20;
-    HIP_TRY(hipMalloc((void **)&d_out, std::min(chunk, std::max<uint64_t>(n, 1))));
+    HIP_TRY(pvs_malloc_retry((void **)&d_out, std::min(chunk, std::max<uint64_t>(n, 1))));
     pvs_status st = with_device_chunks(x, n, space, [&](const float *d, uint64_t m, uint64_t off) -> pvs_status {
         HIP_TRY(pvs_launch_quantize_flat(d, m, scale, d_out, nullptr));
         HIP_TRY(hipMemcpy(out + off, d_out, m, hipMemcpyDeviceToHost));
@@ -732,7 +821,7 @@ PVS_EXPORT pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids
 PVS_EXPORT pvs_status pvs_device_malloc(int32_t device, size_t bytes, void **out) {
     if (!out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     PVS_TRY(use_device(device, nullptr));
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    HIP_TRY(pvs_malloc_retry(out, bytes ? bytes : 16));
     return PVS_OK;
 }
 PVS_EXPORT pvs_status pvs_device_free(int32_t device, void *ptr) {

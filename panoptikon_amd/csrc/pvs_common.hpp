@@ -39,9 +39,15 @@ pvs_status pvs_fail(pvs_status code, const char *fmt, ...) __attribute__((format
 // Scratch for the host-orchestrated paths (per-item search, RRF, similar_to): blocks are kept per device and size class after
 // use instead of going back to hipMalloc / hipFree every call (each costs ~0.1-0.5 ms and hipFree synchronises the device:
 // 6 of configs[4]'s 13.8 ms per query were exactly that).  pvs_index_destroy returns the device's idle blocks to the runtime.
+// A block that queued work may still touch goes back with pvs_scratch_free_on(p, stream): it is handed out again only after
+// that stream has passed the point of the call.  pvs_scratch_free(p) is for blocks whose work the caller has waited for.  Idle
+// bytes per device are capped (least recently used blocks return to the runtime); pvs_malloc_retry is hipMalloc that empties
+// the cache and retries before it reports out-of-memory — every device allocation of the library goes through it.
 hipError_t pvs_scratch_alloc(void **out, size_t bytes);  // on the current device
+void pvs_scratch_free_on(void *p, hipStream_t s, bool pending = true);
 void pvs_scratch_free(void *p);
 void pvs_scratch_trim(int device);
+hipError_t pvs_malloc_retry(void **out, size_t bytes);
 
 // ------------------------------------------------------------ geometry
 // Rows live in HBM at a pitch that is a multiple of 256 B so that a row is a

@@ -65,14 +65,14 @@ pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n) {
     if (n <= w.cap_rows) return PVS_OK;
     pvs_dense_release(w);
     const uint64_t cap = pvs_round_up(n, 1024);
-    HIP_TRY(hipMalloc((void **)&w.d_dist, cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.d_keys_in, cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.d_keys_out, cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.d_vals_in, cap * 4));
-    HIP_TRY(hipMalloc((void **)&w.d_vals_out, cap * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&w.d_dist, cap * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&w.d_keys_in, cap * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&w.d_keys_out, cap * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&w.d_vals_in, cap * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&w.d_vals_out, cap * 4));
     size_t tb = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, w.d_keys_in, w.d_keys_out, w.d_vals_in, w.d_vals_out, (int)cap));
-    HIP_TRY(hipMalloc(&w.d_temp, tb ? tb : 16));
+    HIP_TRY(pvs_malloc_retry(&w.d_temp, tb ? tb : 16));
     w.temp_bytes = tb;
     w.cap_rows = cap;
     return PVS_OK;

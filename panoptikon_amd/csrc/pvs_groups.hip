@@ -160,13 +160,13 @@ pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint
         hipFree(w.temp);
         w = GroupWork();
         const uint32_t cap = (uint32_t)pvs_round_up(n_groups, 1024);
-        HIP_TRY(hipMalloc((void **)&w.keys_in, (size_t)cap * 8));
-        HIP_TRY(hipMalloc((void **)&w.keys_out, (size_t)cap * 8));
-        HIP_TRY(hipMalloc((void **)&w.idx_in, (size_t)cap * 4));
-        HIP_TRY(hipMalloc((void **)&w.idx_out, (size_t)cap * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&w.keys_in, (size_t)cap * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&w.keys_out, (size_t)cap * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&w.idx_in, (size_t)cap * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&w.idx_out, (size_t)cap * 4));
         size_t tb = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (int)cap));
-        HIP_TRY(hipMalloc(&w.temp, tb ? tb : 16));
+        HIP_TRY(pvs_malloc_retry(&w.temp, tb ? tb : 16));
         w.temp_bytes = tb;
         w.cap = cap;
     }

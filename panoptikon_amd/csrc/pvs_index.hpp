@@ -158,6 +158,7 @@ struct pvs_index {
     hipStream_t search_stream = nullptr;
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
+    bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     // Request coalescing of the host-buffer entry point (pvs_index_set_coalescing): callers that arrive within a short window
     // share one corpus pass.  `pending` holds the requests not yet taken by a leader; one caller at a time is the leader.

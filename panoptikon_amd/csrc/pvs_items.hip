@@ -39,9 +39,9 @@ pvs_status ensure_groups(pvs_index *ix) {
         off.push_back((uint32_t)n);
     }
     ix->n_groups = (uint32_t)gids.size();
-    HIP_TRY(hipMalloc((void **)&ix->d_grp_off, (off.size() + 1) * 4));
-    HIP_TRY(hipMalloc((void **)&ix->d_grp_rows, (n + 1) * 4));
-    HIP_TRY(hipMalloc((void **)&ix->d_grp_ids, (gids.size() + 1) * 8));
+    HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_off, (off.size() + 1) * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_rows, (n + 1) * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_ids, (gids.size() + 1) * 8));
     HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
     if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
@@ -119,10 +119,10 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, 1, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(pvs_malloc_retry(&d_q, qbytes * batch));
         HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
         const uint32_t cq = dense_chunk_queries(ix, batch);
-        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * cq * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&d_m, (size_t)ix->n * cq * 4));
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
@@ -152,10 +152,10 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
     double *d_ov = nullptr;
     uint32_t *d_oc = nullptr;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
-        HIP_TRY(hipMalloc((void **)&d_og, (size_t)k * 8));
-        HIP_TRY(hipMalloc((void **)&d_ov, (size_t)k * 8));
-        HIP_TRY(hipMalloc((void **)&d_oc, 4));
+        HIP_TRY(pvs_malloc_retry((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&d_og, (size_t)k * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&d_ov, (size_t)k * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
                                            c.stream, fw, skip_when));
         for (uint32_t q = 0; q < ncol; q++) {
@@ -314,12 +314,12 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(hipMalloc(&d_q, qbytes * batch));
+        HIP_TRY(pvs_malloc_retry(&d_q, qbytes * batch));
         HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
         const uint8_t *dm = nullptr;  // candidate mask on the device
         if (mask && ix->n) {
             if (mask_space == PVS_HOST) {
-                HIP_TRY(hipMalloc((void **)&d_mask, ix->n));
+                HIP_TRY(pvs_malloc_retry((void **)&d_mask, ix->n));
                 HIP_TRY(hipMemcpyAsync(d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
                 dm = d_mask;
             } else {
@@ -327,11 +327,11 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
             }
         }
         if (row_weights && ix->n) {
-            HIP_TRY(hipMalloc((void **)&d_w, ix->n * 4));
+            HIP_TRY(pvs_malloc_retry((void **)&d_w, ix->n * 4));
             HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
         }
         const uint32_t cq = dense_chunk_queries(ix, batch);
-        HIP_TRY(hipMalloc((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
+        HIP_TRY(pvs_malloc_retry((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
@@ -406,7 +406,7 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
     };
     pvs_status st = body();
-    for (void *p : {(void *)d_g, (void *)d_v, (void *)d_c, (void *)d_ag, (void *)d_av, (void *)d_ac}) pvs_scratch_free(p);  // (cached blocks: no hipFree, which would synchronise the device)
+    for (void *p : {(void *)d_g, (void *)d_v, (void *)d_c, (void *)d_ag, (void *)d_av, (void *)d_ac}) pvs_scratch_free_on(p, ix->comm_stream);  // (cached blocks: no hipFree, which would synchronise the device; an early error may have left work queued)
     return st;
 }
 
@@ -455,9 +455,9 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) 
         return PVS_OK;
     };
     pvs_status st = one();
-    pvs_scratch_free(d_q);
-    pvs_scratch_free(d_m);
-    pvs_scratch_free(d_w);
+    pvs_scratch_free_on(d_q, c->stream);  // (the scoring is still queued: the blocks are reusable once the stream has passed this point)
+    pvs_scratch_free_on(d_m, c->stream);
+    pvs_scratch_free_on(d_w, c->stream);
     ix->searches++;
     ix->dense_queries++;
     ctx_done(ix, c);
@@ -482,6 +482,7 @@ PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_
     if (!c) return pvs_fail(PVS_ERR_OOM, "host allocation failed");
     pvs_status st = rrf_score_branch(*branch, c);
     if (st != PVS_OK) {
+        (void)hipDeviceSynchronize();  // (whatever was queued before the failure may still write the columns)
         pvs_scratch_free(c->d_vals);
         pvs_scratch_free(c->d_keys);
         delete c;
@@ -492,7 +493,10 @@ PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_
 }
 PVS_EXPORT void pvs_rrf_cols_destroy(pvs_rrf_cols *c) {
     if (!c) return;
-    if (c->ix) (void)hipSetDevice(c->ix->device);
+    if (c->ix) {
+        (void)hipSetDevice(c->ix->device);
+        (void)hipStreamSynchronize(c->ix->search_stream);  // (the fusion steps that read the columns run there)
+    }
     pvs_scratch_free(c->d_vals);
     pvs_scratch_free(c->d_keys);
     delete c;
@@ -768,8 +772,8 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
         // full ranking: every group of every branch ranked (stable radix sorts), entries appended in branch order, fused by sort
         g_rrf_last_path = 2;
         HIP_TRY(hipSetDevice(br[0].idx->device));
-        HIP_TRY(hipMalloc((void **)&cat_key, std::max<uint64_t>(total, 1) * 8));
-        HIP_TRY(hipMalloc((void **)&cat_pay, std::max<uint64_t>(total, 1) * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&cat_key, std::max<uint64_t>(total, 1) * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&cat_pay, std::max<uint64_t>(total, 1) * 8));
         uint64_t off = 0;
         for (uint32_t b = 0; b < nb; b++) {
             pvs_index *ix = br[b].idx;
@@ -781,6 +785,7 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
         return pvs_rrf_fuse_device(cat_key, cat_pay, off, p, k, out_groups, out_scores, out_count, br[0].idx->search_stream);
     };
     pvs_status st = body();
+    if (st != PVS_OK) (void)hipDeviceSynchronize();  // (a failure part-way may have left work queued on a branch's stream)
     for (auto &c : cols) {
         pvs_scratch_free(c.d_vals);
         pvs_scratch_free(c.d_keys);
@@ -831,12 +836,12 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
         PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
         FanoutWeights fw;
         if (weighted || gated) {
-            HIP_TRY(hipMalloc((void **)&d_trows, (size_t)n_targets * 4));
+            HIP_TRY(pvs_malloc_retry((void **)&d_trows, (size_t)n_targets * 4));
             HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
             fw.trows = d_trows;
         }
         if (gated) {
-            HIP_TRY(hipMalloc((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
+            HIP_TRY(pvs_malloc_retry((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
             HIP_TRY(hipMemcpy(d_kind, row_kind, ix->n, hipMemcpyHostToDevice));
             fw.kind = d_kind;
             fw.skip_i2i = skip_i2i;
@@ -845,7 +850,7 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
         if (weighted) {
             // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
             auto upload = [&](const double *src, double **dst) -> pvs_status {
-                HIP_TRY(hipMalloc((void **)dst, std::max<uint64_t>(ix->n, 1) * 8));
+                HIP_TRY(pvs_malloc_retry((void **)dst, std::max<uint64_t>(ix->n, 1) * 8));
                 if (src)
                     HIP_TRY(hipMemcpy(*dst, src, ix->n * 8, hipMemcpyHostToDevice));
                 else
@@ -879,12 +884,12 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
                 memcpy(dst, rowbuf.data(), rowbuf.size());
             }
         }
-        HIP_TRY(hipMalloc(&d_q, hq.size()));
+        HIP_TRY(pvs_malloc_retry(&d_q, hq.size()));
         HIP_TRY(hipMemcpy(d_q, hq.data(), hq.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&d_ex, ix->n + 1));
+        HIP_TRY(pvs_malloc_retry((void **)&d_ex, ix->n + 1));
         HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
         for (uint32_t i = 0; i < n_targets; i++) HIP_TRY(hipMemsetAsync(d_ex + trow[i], 1, 1, c->stream));
-        HIP_TRY(hipMalloc((void **)&d_m, (size_t)ix->n * n_targets * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&d_m, (size_t)ix->n * n_targets * 4));
         const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
         PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));

@@ -77,9 +77,9 @@ pvs_status mctx_prepare(pvs_index *ix, MultiCtx &m, uint32_t batch, uint32_t k) 
         m.d_all_cnt = nullptr;
         m.elems_cap = 0;
         m.batch_cap = 0;
-        HIP_TRY(hipMalloc((void **)&m.d_all_ids, elems * 8 * S));
-        HIP_TRY(hipMalloc((void **)&m.d_all_dist, elems * 4 * S));
-        HIP_TRY(hipMalloc((void **)&m.d_all_cnt, (size_t)batch * 4 * S));
+        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_ids, elems * 8 * S));
+        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_dist, elems * 4 * S));
+        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_cnt, (size_t)batch * 4 * S));
         m.elems_cap = elems;
         m.batch_cap = batch;
     }
@@ -122,7 +122,7 @@ pvs_status multi_enqueue(pvs_index *ix, MultiCtx &m, const void *d_queries, pvs_
                 m.d_q[s] = nullptr;
                 m.q_cap[s] = 0;
                 const size_t cap = pvs_round_up(qbytes, 1 << 16);
-                HIP_TRY(hipMalloc(&m.d_q[s], cap));
+                HIP_TRY(pvs_malloc_retry(&m.d_q[s], cap));
                 m.q_cap[s] = cap;
             }
             HIP_TRY(hipMemcpyPeerAsync(m.d_q[s], sh->device, d_queries, root, qbytes, c->stream));
@@ -286,6 +286,7 @@ void multi_destroy(pvs_index *ix) {
 
 pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
                      pvs_space space) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     std::lock_guard<std::mutex> lk(ix->mu);
     const uint32_t S = (uint32_t)ix->shards.size();
     if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set)
@@ -314,7 +315,7 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
             HIP_TRY(hipSetDevice(sh->device));
             const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
             void *stage = nullptr;
-            HIP_TRY(hipMalloc(&stage, std::min(chunk, m) * row_bytes));
+            HIP_TRY(pvs_malloc_retry(&stage, std::min(chunk, m) * row_bytes));
             st = PVS_OK;
             for (uint64_t o = 0; o < m && st == PVS_OK; o += chunk) {
                 const uint64_t mm = std::min(chunk, m - o);
@@ -331,7 +332,12 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
         } else {
             st = add_impl(sh, piece, from_f32, m, row_ids ? row_ids + off : nullptr, group_ids ? group_ids + off : nullptr, space, id0);
         }
-        if (st != PVS_OK) return st;  // rows already appended to earlier shards stay; the caller rebuilds on failure
+        if (st != PVS_OK) {
+            // earlier shards already hold their pieces of this call while the parent's row count does not: the global row order is
+            // gone.  Every later call fails instead of reading rows at the wrong offsets; the caller rebuilds the index.
+            ix->poisoned = true;
+            return st;
+        }
         ix->segs.push_back({ix->n + off, m, s, local0});
         off += m;
     }
@@ -341,6 +347,7 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
 }
 
 pvs_status multi_set_scale(pvs_index *ix, float scale) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->n && ix->scale_set && ix->scale != scale)
         return pvs_fail(PVS_ERR_STATE, "scale is frozen once rows exist (artifact_rev semantics): rebuild the index");
@@ -374,6 +381,7 @@ pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
 }
 
 pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);
     const size_t w = (size_t)ix->dim * ix->esz;
@@ -383,6 +391,7 @@ pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_h
 }
 
 pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);
     for (const SegRange &r : locate(ix, row0, n))
@@ -392,6 +401,7 @@ pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out
 
 pvs_status multi_search_device(pvs_index *ix, const void *d_queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, uint32_t *out_ticket) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     PVS_TRY(validate_search(ix->shards[0], d_queries, qdtype, batch, k, metric));
     if (!d_out_ids || !d_out_dist || !d_out_count || !out_ticket) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty batch");
@@ -448,6 +458,7 @@ pvs_status multi_sync(pvs_index *ix) {
 
 pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                              int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0) return PVS_OK;
@@ -461,7 +472,7 @@ pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtyp
             m->d_qroot = nullptr;
             m->qroot_cap = 0;
             const size_t cap = pvs_round_up(qbytes, 1 << 16);
-            HIP_TRY(hipMalloc(&m->d_qroot, cap));
+            HIP_TRY(pvs_malloc_retry(&m->d_qroot, cap));
             m->qroot_cap = cap;
         }
         const uint64_t need = (uint64_t)batch * k;
@@ -473,9 +484,9 @@ pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtyp
             m->d_out_dist = nullptr;
             m->d_out_cnt = nullptr;
             m->out_cap = 0;
-            HIP_TRY(hipMalloc((void **)&m->d_out_ids, need * 8));
-            HIP_TRY(hipMalloc((void **)&m->d_out_dist, need * 4));
-            HIP_TRY(hipMalloc((void **)&m->d_out_cnt, (size_t)batch * 4));
+            HIP_TRY(pvs_malloc_retry((void **)&m->d_out_ids, need * 8));
+            HIP_TRY(pvs_malloc_retry((void **)&m->d_out_dist, need * 4));
+            HIP_TRY(pvs_malloc_retry((void **)&m->d_out_cnt, (size_t)batch * 4));
             m->out_cap = need;
             m->out_batch_cap = batch;
         }
@@ -505,6 +516,7 @@ pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtyp
 }
 
 pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist, pvs_space out_space) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     PVS_TRY(validate_search(ix->shards[0], query, qdtype, 1, 1, metric));
     if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (out_space != PVS_HOST) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_score_all on a multi-device index writes host memory only");
@@ -528,6 +540,7 @@ pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, p
 // minimum, merged under (value asc, group id asc, NULL last).  (MAX / AVG need every row of a group on one device.)
 pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
     if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (agg != PVS_AGG_MIN || row_weights)

@@ -184,7 +184,7 @@ pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending,
     hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(n)), dim3(256), 0, s, d_vals, n, descending, d_keys, idx);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    pvs_scratch_free(idx);
+    pvs_scratch_free_on(idx, s);
     if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "window keys: %s", hipGetErrorString(e));
     return PVS_OK;
 }
@@ -194,7 +194,7 @@ pvs_status pvs_rrf_sample_keys(const unsigned long long *d_keys, uint32_t n, uin
     hipLaunchKernelGGL(k_sample_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_keys, n, m, d);
     hipError_t e = hipMemcpyAsync(h_out, d, (size_t)m * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    pvs_scratch_free(d);
+    pvs_scratch_free_on(d, s);
     if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "sample keys: %s", hipGetErrorString(e));
     return PVS_OK;
 }
@@ -225,10 +225,10 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
         return PVS_OK;
     };
     pvs_status st = body();
-    pvs_scratch_free(d_cnt);
-    pvs_scratch_free(d_slots);
-    pvs_scratch_free(d_g);
-    pvs_scratch_free(d_k);
+    pvs_scratch_free_on(d_cnt, s);
+    pvs_scratch_free_on(d_slots, s);
+    pvs_scratch_free_on(d_g, s);
+    pvs_scratch_free_on(d_k, s);
     return st;
 }
 // candidate group ids -> window key in this branch; present[c] = 0 when the branch (shard) does not hold the group
@@ -253,9 +253,9 @@ pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gid
         return PVS_OK;
     };
     pvs_status st = body();
-    pvs_scratch_free(d_cand);
-    pvs_scratch_free(d_slot);
-    pvs_scratch_free(d_key);
+    pvs_scratch_free_on(d_cand, s);
+    pvs_scratch_free_on(d_slot, s);
+    pvs_scratch_free_on(d_key, s);
     return st;
 }
 // candidates sorted ascending by (key, group id): out_below[j] = groups of this branch (shard) strictly before candidate j
@@ -292,9 +292,9 @@ pvs_status pvs_rrf_count_below(const unsigned long long *d_keys, const int64_t *
         return PVS_OK;
     };
     pvs_status st = body();
-    pvs_scratch_free(d_ck);
-    pvs_scratch_free(d_cg);
-    pvs_scratch_free(d_hist);
+    pvs_scratch_free_on(d_ck, s);
+    pvs_scratch_free_on(d_cg, s);
+    pvs_scratch_free_on(d_hist, s);
     return st;
 }
 
@@ -307,13 +307,13 @@ pvs_status pvs_rrf_rank_branch(const double *d_vals, const int64_t *d_gids, uint
     uint32_t *i_in = nullptr, *i_out = nullptr;
     void *temp = nullptr;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&k_in, (size_t)n * 8));
-        HIP_TRY(hipMalloc((void **)&k_out, (size_t)n * 8));
-        HIP_TRY(hipMalloc((void **)&i_in, (size_t)n * 4));
-        HIP_TRY(hipMalloc((void **)&i_out, (size_t)n * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&k_in, (size_t)n * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&k_out, (size_t)n * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&i_in, (size_t)n * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&i_out, (size_t)n * 4));
         size_t tb = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, i_in, i_out, (int)n));
-        HIP_TRY(hipMalloc(&temp, tb ? tb : 16));
+        HIP_TRY(pvs_malloc_retry(&temp, tb ? tb : 16));
         hipLaunchKernelGGL(k_rank_keys, dim3(grid_for(n)), dim3(256), 0, s, d_vals, n, descending, k_in, i_in);
         // stable: equal values keep the input order = group id ascending (groups are stored in id order)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, tb, k_in, k_out, i_in, i_out, (int)n, 0, 64, s));
@@ -341,22 +341,22 @@ pvs_status pvs_rrf_fuse_device(unsigned long long *cat_key, unsigned long long *
     void *temp = nullptr;
     if (total >= (1ull << 31)) return pvs_fail(PVS_ERR_UNSUPPORTED, "too many (group, branch) entries");
     auto body = [&]() -> pvs_status {
-        HIP_TRY(hipMalloc((void **)&d_og, (size_t)k * 8));
-        HIP_TRY(hipMalloc((void **)&d_os, (size_t)k * 8));
-        HIP_TRY(hipMalloc((void **)&d_oc, 4));
+        HIP_TRY(pvs_malloc_retry((void **)&d_og, (size_t)k * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&d_os, (size_t)k * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&d_oc, 4));
         const size_t tn = std::max<uint64_t>(total, 1);
-        HIP_TRY(hipMalloc((void **)&key_s, tn * 8));
-        HIP_TRY(hipMalloc((void **)&pay_s, tn * 8));
-        HIP_TRY(hipMalloc((void **)&score, tn * 8));
-        HIP_TRY(hipMalloc((void **)&k2, tn * 8));
-        HIP_TRY(hipMalloc((void **)&k2s, tn * 8));
-        HIP_TRY(hipMalloc((void **)&i2, tn * 4));
-        HIP_TRY(hipMalloc((void **)&i2s, tn * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&key_s, tn * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&pay_s, tn * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&score, tn * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&k2, tn * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&k2s, tn * 8));
+        HIP_TRY(pvs_malloc_retry((void **)&i2, tn * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&i2s, tn * 4));
         if (total) {
             size_t t1 = 0, t2 = 0;
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, cat_key, key_s, cat_pay, pay_s, (int)total));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t2, k2, k2s, i2, i2s, (int)total));
-            HIP_TRY(hipMalloc(&temp, std::max<size_t>(std::max(t1, t2), 16)));
+            HIP_TRY(pvs_malloc_retry(&temp, std::max<size_t>(std::max(t1, t2), 16)));
             // by group id, stable: a group's entries stay in branch order
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, t1, cat_key, key_s, cat_pay, pay_s, (int)total, 0, 64, s));
             hipLaunchKernelGGL(k_rrf_score, dim3(grid_for(total)), dim3(256), 0, s, key_s, pay_s, total, p, score, k2, i2);

@@ -91,7 +91,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
                     if (st == PVS_OK)
                         st = pvs_select_topk(d_m, ix->n, nbb, nbb, k, c.cur_mask, ix->d_ids, nullptr, oid + (size_t)off * k, od + (size_t)off * k, oc + off, c.stream);
                 }
-                pvs_scratch_free(d_m);
+                pvs_scratch_free_on(d_m, c.stream);  // (scoring and select are queued, not finished)
                 PVS_TRY(st);
                 ix->dense_queries += nb;
                 continue;
@@ -391,43 +391,53 @@ pvs_status coalesce_call(pvs_index *ix, int kind, int agg, const void *queries, 
         // one pass for the group
         pvs_status st = PVS_OK;
         std::string err;
-        if (group.size() == 1) {
-            st = coalesce_run(ix, kind, agg, me.queries, me.qdtype, me.batch, me.k, me.metric, me.out_a, me.out_b, me.out_count);
-            if (st != PVS_OK) err = pvs_last_error();
-        } else {
-            const size_t qbytes = (size_t)ix->dim * (me.qdtype == PVS_I8 ? 1 : 4);
-            std::vector<uint8_t> q((size_t)total * qbytes), vb((size_t)total * kmax * bsz);
-            std::vector<int64_t> va((size_t)total * kmax);
-            std::vector<uint32_t> cnt(total);
-            size_t off = 0;
-            for (Req *r : group) {
-                memcpy(q.data() + off * qbytes, r->queries, (size_t)r->batch * qbytes);
-                off += r->batch;
-            }
-            st = coalesce_run(ix, kind, agg, q.data(), me.qdtype, total, kmax, me.metric, va.data(), vb.data(), cnt.data());
-            if (st != PVS_OK) err = pvs_last_error();
-            off = 0;
-            const float nan32 = __builtin_nanf("");
-            const double nan64 = __builtin_nan("");
-            for (Req *r : group) {
-                if (st == PVS_OK)
-                    for (uint32_t b = 0; b < r->batch; b++) {
-                        const uint32_t have = std::min(cnt[off + b], r->k);
-                        int64_t *oa = r->out_a + (size_t)b * r->k;
-                        uint8_t *ob = (uint8_t *)r->out_b + (size_t)b * r->k * bsz;
-                        memcpy(oa, va.data() + (off + b) * kmax, (size_t)have * 8);
-                        memcpy(ob, vb.data() + (off + b) * kmax * bsz, (size_t)have * bsz);
-                        for (uint32_t i = have; i < r->k; i++) {
-                            oa[i] = -1;
-                            if (bsz == 4)
-                                memcpy(ob + (size_t)i * 4, &nan32, 4);
-                            else
-                                memcpy(ob + (size_t)i * 8, &nan64, 8);
+        // (nothing may unwind past this point: the group would never be marked done and leader_active never cleared — every
+        //  coalesced caller on the index, present and future, would wait forever)
+        try {
+            if (group.size() == 1) {
+                st = coalesce_run(ix, kind, agg, me.queries, me.qdtype, me.batch, me.k, me.metric, me.out_a, me.out_b, me.out_count);
+                if (st != PVS_OK) err = pvs_last_error();
+            } else {
+                const size_t qbytes = (size_t)ix->dim * (me.qdtype == PVS_I8 ? 1 : 4);
+                std::vector<uint8_t> q((size_t)total * qbytes), vb((size_t)total * kmax * bsz);
+                std::vector<int64_t> va((size_t)total * kmax);
+                std::vector<uint32_t> cnt(total);
+                size_t off = 0;
+                for (Req *r : group) {
+                    memcpy(q.data() + off * qbytes, r->queries, (size_t)r->batch * qbytes);
+                    off += r->batch;
+                }
+                st = coalesce_run(ix, kind, agg, q.data(), me.qdtype, total, kmax, me.metric, va.data(), vb.data(), cnt.data());
+                if (st != PVS_OK) err = pvs_last_error();
+                off = 0;
+                const float nan32 = __builtin_nanf("");
+                const double nan64 = __builtin_nan("");
+                for (Req *r : group) {
+                    if (st == PVS_OK)
+                        for (uint32_t b = 0; b < r->batch; b++) {
+                            const uint32_t have = std::min(cnt[off + b], r->k);
+                            int64_t *oa = r->out_a + (size_t)b * r->k;
+                            uint8_t *ob = (uint8_t *)r->out_b + (size_t)b * r->k * bsz;
+                            memcpy(oa, va.data() + (off + b) * kmax, (size_t)have * 8);
+                            memcpy(ob, vb.data() + (off + b) * kmax * bsz, (size_t)have * bsz);
+                            for (uint32_t i = have; i < r->k; i++) {
+                                oa[i] = -1;
+                                if (bsz == 4)
+                                    memcpy(ob + (size_t)i * 4, &nan32, 4);
+                                else
+                                    memcpy(ob + (size_t)i * 8, &nan64, 8);
+                            }
+                            r->out_count[b] = have;
                         }
-                        r->out_count[b] = have;
-                    }
-                off += r->batch;
+                    off += r->batch;
+                }
             }
+        } catch (const std::bad_alloc &) {
+            st = PVS_ERR_OOM;
+            err = "out of host memory while coalescing requests";
+        } catch (...) {
+            st = PVS_ERR_STATE;
+            err = "unexpected failure while coalescing requests";
         }
         co.passes++;
         lk.lock();
@@ -520,7 +530,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
             c->d_qstage = nullptr;
             c->qstage_cap = 0;
             const size_t cap = pvs_round_up(qbytes * batch, 1 << 16);
-            hipError_t e = hipMalloc(&c->d_qstage, cap);
+            hipError_t e = pvs_malloc_retry(&c->d_qstage, cap);
             if (e != hipSuccess)
                 st = pvs_fail(PVS_ERR_OOM, "hipMalloc queries: %s", hipGetErrorString(e));
             else
@@ -541,8 +551,8 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
                 c->d_mask = nullptr;
                 c->d_aux_masked = nullptr;
                 c->mask_cap = 0;
-                HIP_TRY(hipMalloc((void **)&c->d_mask, ix->cap));
-                HIP_TRY(hipMalloc((void **)&c->d_aux_masked, ix->cap / 32 * PVS_AUX_REC * 4));
+                HIP_TRY(pvs_malloc_retry((void **)&c->d_mask, ix->cap));
+                HIP_TRY(pvs_malloc_retry((void **)&c->d_aux_masked, ix->cap / 32 * PVS_AUX_REC * 4));
                 c->mask_cap = ix->cap;
             }
             if (mask_space == PVS_HOST) {
@@ -602,7 +612,7 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
             c->d_qstage = nullptr;
             c->qstage_cap = 0;
             const size_t cap = pvs_round_up(qbytes * batch, 1 << 16);
-            HIP_TRY(hipMalloc(&c->d_qstage, cap));
+            HIP_TRY(pvs_malloc_retry(&c->d_qstage, cap));
             c->qstage_cap = cap;
         }
         HIP_TRY(hipMemcpyAsync(c->d_qstage, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
@@ -727,9 +737,9 @@ pvs_status ctx_reserve_local_pages(SearchCtx &c, uint64_t elems, uint32_t batch)
     c.d_loc_cnt = nullptr;
     c.loc_elems = 0;
     c.loc_batch = 0;
-    HIP_TRY(hipMalloc((void **)&c.d_loc_ids, elems * 8));
-    HIP_TRY(hipMalloc((void **)&c.d_loc_dist, elems * 4));
-    HIP_TRY(hipMalloc((void **)&c.d_loc_cnt, (size_t)batch * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_ids, elems * 8));
+    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_dist, elems * 4));
+    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_cnt, (size_t)batch * 4));
     c.loc_elems = elems;
     c.loc_batch = batch;
     return PVS_OK;
@@ -762,10 +772,10 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
             c->d_all_dist = nullptr;
             c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
             c->sh_elems = 0;
-            HIP_TRY(hipMalloc((void **)&c->d_all_ids, elems * 8 * world));
-            HIP_TRY(hipMalloc((void **)&c->d_all_dist, elems * 4 * world));
-            HIP_TRY(hipMalloc((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
-            HIP_TRY(hipMalloc((void **)&c->d_all_flags, (size_t)batch * 4 * world));
+            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_ids, elems * 8 * world));
+            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_dist, elems * 4 * world));
+            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
+            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_flags, (size_t)batch * 4 * world));
             HIP_TRY(hipHostMalloc((void **)&c->h_all_flags, (size_t)batch * 4 * world, hipHostMallocDefault));
             c->sh_elems = elems;
             c->sh_batch = batch;
@@ -902,7 +912,7 @@ PVS_EXPORT pvs_status pvs_score_column_create(pvs_index *ix, const void *query, 
         c->device = ix->device;
         if (c->rows) {
             hipError_t e = hipSetDevice(ix->device);
-            if (e == hipSuccess) e = hipMalloc((void **)&c->d_dev, c->rows * 4);
+            if (e == hipSuccess) e = pvs_malloc_retry((void **)&c->d_dev, c->rows * 4);
             if (e != hipSuccess) {
                 delete c;
                 return pvs_fail(e == hipErrorOutOfMemory ? PVS_ERR_OOM : PVS_ERR_DEVICE, "hipMalloc of a %llu-row column: %s", (unsigned long long)ix->n, hipGetErrorString(e));

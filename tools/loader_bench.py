@@ -25,7 +25,8 @@ def main():
     from test_loader import DDL
 
     path = os.path.join(tempfile.mkdtemp(prefix="pvs_loader_bench_"), "index.db")
-    conn = sqlite3.connect(path)
+    conn = sqlite3.connect(path, isolation_level=None)
+    conn.execute('BEGIN')
     conn.executescript(DDL)
     conn.execute("INSERT INTO setters (id, name) VALUES (1, 'clip/m')")
     rng = np.random.default_rng(1)
@@ -48,6 +49,35 @@ def main():
         assert li.rows == args.rows
         out[label] = {"seconds": round(dt, 3), "rows_per_s": round(args.rows / dt), "MB_per_s": round(args.rows * args.dim * 4 / dt / 1e6)}
         li.index.close()
+    # write side: the backfill of one (profile, setter) pair — the reference measured 49.8 s for 1.45M vectors
+    # (docs/vector-quant-measurements.md: quantize_int8 in Rust + one INSERT per row), i.e. ~29k rows/s
+    import struct
+
+    from panoptikon_amd import sqlite_seam
+    from test_loader import _BACKFILL_SELECT, _BACKFILL_UPSERT
+
+    conn.execute("INSERT INTO vector_quant_profiles (id, name, quantizer, state, is_default) VALUES (5, 'int8', 'int8', 'active', 1)")
+    conn.execute("INSERT INTO vector_quant_coverage (profile_id, setter_id, artifact, artifact_rev, dim, state) VALUES (5, 1, ?, 1, ?, 'building')",
+                 (struct.pack("<f", 4.5 / 127.0), args.dim))
+    conn.commit()
+    sqlite_seam.load(conn)
+    for label, chunk in (("backfill_chunks_of_8192", 8192), ("backfill_rebuild_chunks_of_65536", 65536)):
+        if label.startswith("backfill_rebuild"):
+            conn.execute("UPDATE vector_quant_coverage SET artifact_rev = artifact_rev + 1 WHERE profile_id = 5")
+            conn.commit()
+        t0 = time.time()
+        cursor, total = 0, 0
+        while True:
+            conn.execute("BEGIN IMMEDIATE")
+            n = conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, ?, ?)", (_BACKFILL_SELECT, _BACKFILL_UPSERT, cursor, chunk)).fetchone()[0]
+            conn.execute("COMMIT")
+            if n == 0:
+                break
+            cursor = conn.execute("SELECT pvs_backfill_cursor()").fetchone()[0]
+            total += n
+        dt = time.time() - t0
+        assert total == args.rows
+        out[label] = {"seconds": round(dt, 3), "rows_per_s": round(args.rows / dt), "vs_reference_29k_rows_per_s": round(args.rows / dt / 29100, 1)}
     print(json.dumps(out))
 
 
