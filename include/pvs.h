@@ -127,6 +127,9 @@ typedef struct pvs_stats {
     uint64_t fast_queries;      /* queries answered by the filter-scan path */
     uint64_t dense_queries;     /* queries answered by the dense score+sort path */
     uint64_t last_candidates;   /* candidates emitted by the last filter scan (all queries) */
+    /* since ABI v3 (set struct_size = sizeof(pvs_stats) before the call; a caller that leaves it 0 gets the fields above) */
+    uint64_t rescanned_queries; /* fast-path queries whose chunk went through the scan twice: a candidate segment overflowed
+                                 * (ties clustered in a few tile streams) and pass B was rerun into flat per-query lists */
 } pvs_stats;
 
 /* ------------------------------------------------------------------ library */

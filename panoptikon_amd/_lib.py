@@ -42,7 +42,7 @@ class Stats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_uint32), ("dim", C.c_uint32), ("rows", C.c_uint64),
                 ("capacity_rows", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("hbm_bytes", C.c_uint64),
                 ("scale", C.c_float), ("searches", C.c_uint64), ("fast_queries", C.c_uint64),
-                ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64)]
+                ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64), ("rescanned_queries", C.c_uint64)]
 
 
 class Profile(C.Structure):

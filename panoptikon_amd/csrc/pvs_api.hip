@@ -277,6 +277,7 @@ void ctx_release(SearchCtx &c) {
     hipFree(c.d_seg);
     hipFree(c.d_seg_cnt);
     hipFree(c.d_cand);
+    hipFree(c.d_flat_cnt);
     hipFree(c.d_fin_ub);
     hipFree(c.d_fin_surv);
     hipFree(c.d_fin_sort);
@@ -326,6 +327,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_seg, sizeof(uint2) * (size_t)PVS_SEG_PAIRS * PVS_SEG_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS * (PVS_SEG_CAP / PVS_WIDE_SEG_CAP)));  // (the 256-query kernel: twice the lists at half the slots)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
     }
     static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;  // tests: the LDS-light pass C on every search
     if ((ix->multi_stream || force_light) && ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan)
@@ -646,7 +648,11 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     s.fast_queries = ix->fast_queries.load();
     s.dense_queries = ix->dense_queries.load();
     s.last_candidates = ix->last_candidates.load();
-    *out = s;
+    s.rescanned_queries = ix->flat_reruns.load();
+    const size_t v2 = offsetof(pvs_stats, rescanned_queries);  // what callers of the earlier struct hold
+    const size_t want = out->struct_size >= v2 && out->struct_size <= sizeof s ? out->struct_size : v2;
+    s.struct_size = (uint32_t)want;
+    memcpy(out, &s, want);
     return PVS_OK;
 }
 

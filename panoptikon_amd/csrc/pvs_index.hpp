@@ -44,6 +44,7 @@ struct SearchCtx {
     uint2 *d_seg = nullptr;          // [PVS_SEG_PAIRS][PVS_SEG_CAP] candidate segments of the filter scan
     uint32_t *d_seg_cnt = nullptr;   // their fill counts (one per list: PVS_SEG_PAIRS, twice that for the 256-query kernel's half-size lists)
     uint2 *d_cand = nullptr;      // [MAX_BATCH][CAND_CAP]
+    uint32_t *d_flat_cnt = nullptr;  // [SCAN_MAX_BATCH] fill counts of the flat candidate lists (segment-overflow rerun)
     uint32_t *d_fin_ub = nullptr, *d_fin_surv = nullptr;  // pass C's global work area (FinalizeArgs.w_*), allocated in multi-stream mode
     unsigned long long *d_fin_sort = nullptr;
     uint32_t *d_need_dense = nullptr;  // [total batch capacity]
@@ -160,6 +161,7 @@ struct pvs_index {
     bool multi_stream = false;
     bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
+    std::atomic<uint64_t> flat_reruns{0};  // queries that went through the scan twice (segment overflow -> flat candidate lists)
     // Request coalescing of the host-buffer entry point (pvs_index_set_coalescing): callers that arrive within a short window
     // share one corpus pass.  `pending` holds the requests not yet taken by a leader; one caller at a time is the leader.
     struct CoalesceReq {

@@ -62,6 +62,9 @@ struct ScanArgs {
     uint2 *seg = nullptr;          // [n_segments][batch_pad][PVS_SEG_CAP] = (row, key bits)
     uint32_t *seg_cnt = nullptr;   // [batch_pad][n_segments] fill counts, written by the scan (above PVS_SEG_CAP = overflowed)
     uint32_t n_segments = 0;       // grid * pvs_scan_segs_per_stream
+    uint2 *flat = nullptr;         // mode 1, segment-overflow rerun: candidates appended to [batch_pad][flat_cap] lists (ScanK.flat)
+    uint32_t *flat_cnt = nullptr;  // [batch_pad], zeroed by the caller
+    uint32_t flat_cap = 0;
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 // geometry of the filter passes (modes 0 / 1) of a shape — it depends on which kernel serves them (pvs_scan_is_wide)
@@ -74,6 +77,10 @@ uint32_t pvs_scan_gmin_max(int dtype, uint32_t qgroups, uint32_t kslabs);       
 uint32_t pvs_scan_wg_per_cu(int dtype, uint32_t qgroups, uint32_t kslabs);        // resident workgroups per CU
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs);  // queries one pass can hold: 256 (int8, two groups per wave) or 128
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
+
+// thr[q] = -inf (no row passes any filter test) for every query whose flag is not 2: the segment-overflow rerun of a chunk emits
+// candidates only for the queries pass C handed back for it
+hipError_t pvs_launch_void_thresholds(float *thr, const uint32_t *need_dense, uint32_t n, hipStream_t s);
 
 // k-th smallest (1-based) of vals[q][0..per_query), +inf when fewer than k finite values
 hipError_t pvs_launch_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out,
@@ -100,6 +107,9 @@ struct FinalizeArgs {
     uint32_t *out_count;    // [batch]
     uint32_t *need_dense;   // [batch] 1 = this query must be answered by the dense path
     uint32_t *cand_seen = nullptr;  // [batch] (optional) candidates the scan emitted for the query (pvs_stats.last_candidates)
+    // segment-overflow rerun: the scan already wrote flat lists into `cand` (ScanArgs.flat); only queries whose need_dense is 2
+    // are finalised, the others keep the page they have
+    const uint32_t *flat_cnt = nullptr;
     // Optional global-memory work area: with it (int8 rows) pass C keeps its bound keys, survivor list and large sorts in HBM/L2
     // and needs ~6 KB of LDS instead of ~104 KB, so it can run NEXT TO the scan of another search (k_scan's two workgroups per
     // CU leave 7.8 KB of LDS free).  Used when an index runs its searches on several streams.

@@ -50,6 +50,9 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.seg = a.seg;
     k.seg_cnt = a.seg_cnt;
     k.seg_queries = a.qgroups * 32;
+    k.flat = a.flat;
+    k.flat_cnt = a.flat_cnt;
+    k.flat_cap = a.flat_cap;
     const bool wide = (a.mode == 0 || a.mode == 1) && pvs_scan_is_wide(a.dtype, a.qgroups, a.kslabs);
     k.seg_cap = wide ? PVS_WIDE_SEG_CAP : PVS_SEG_CAP;
     k.seg_stride = a.grid * (wide ? pvs_scan_wide_segs(a.qgroups) : pvs_scan_row_tiles(a.qgroups) * 2u);
@@ -80,6 +83,15 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
             : a.kslabs <= 16 ? pvs_scan_dispatch_f32_large(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
                              : pvs_scan_dispatch_f32_xl(k, a.kslabs, a.qgroups, a.metric, a.mode, s);
     return e;
+}
+
+__global__ void k_void_thresholds(float *thr, const uint32_t *need_dense, uint32_t n) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n && need_dense[q] != 2) thr[q] = -__builtin_inff();
+}
+hipError_t pvs_launch_void_thresholds(float *thr, const uint32_t *need_dense, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_void_thresholds, dim3((n + 255) / 256), dim3(256), 0, s, thr, need_dense, n);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------- k-th select
@@ -213,6 +225,7 @@ struct FinK {
     int metric;
     uint32_t *w_ub, *w_surv;       // LIGHT: global work area (FinalizeArgs.w_*)
     unsigned long long *w_sort;
+    const uint32_t *flat_cnt;      // segment-overflow rerun (FinalizeArgs.flat_cnt)
 };
 
 constexpr int FIN_QMAX = 8192;  // bytes of LDS for the query vector the rerank reads (dims beyond that read it from global memory)
@@ -342,7 +355,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     // prefix-sum the fill counts (offsets live in the not-yet-used bound array) and copy the segments into one flat list.
     uint2 *const flat = a.cand + (size_t)q * a.cand_cap;
     uint32_t cnt = 0;
-    {
+    bool seg_overflow_only = false;  // a segment overflowed although the query's candidates fit one list: the scan can be rerun into flat lists
+    if (a.flat_cnt) {
+        // segment-overflow rerun: only the queries handed back for it; their candidates are already one flat list
+        if (a.need_dense[q] != 2) return;
+        cnt = a.flat_cnt[q];
+        if (cnt > a.cand_cap) cnt = a.cand_cap + 1;
+    } else {
         uint32_t *const s_off = s_ub;  // [n_segments + 1]
         __shared__ uint32_t s_part[256];
         __shared__ uint32_t s_over;
@@ -352,7 +371,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         //  independent batches — at most 4,096 segments = 16 per lane — instead of one dependent load after the other)
         constexpr uint32_t PER_MAX = 16;
         uint32_t cs[PER_MAX];
-        uint32_t mine = 0;
+        uint32_t mine = 0, mine_true = 0;
         bool over = false;
         if (per <= PER_MAX) {
 #pragma unroll
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
 #pragma unroll
             for (uint32_t i = 0; i < PER_MAX; i++) {
                 over |= cs[i] > a.seg_cap;
+                mine_true += cs[i] < (1u << 20) ? cs[i] : (1u << 20);
                 cs[i] = cs[i] < a.seg_cap ? cs[i] : a.seg_cap;
                 mine += cs[i];
             }
@@ -371,12 +391,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                 const uint32_t sg = tid * per + i;
                 const uint32_t c = sg < a.n_segments ? sc[sg] : 0u;
                 over |= c > a.seg_cap;
+                mine_true += c < (1u << 20) ? c : (1u << 20);
                 mine += c < a.seg_cap ? c : a.seg_cap;
             }
         }
-        if (tid == 0) s_over = 0;
+        __shared__ uint32_t s_true;
+        if (tid == 0) {
+            s_over = 0;
+            s_true = 0;
+        }
         __syncthreads();
         if (over) s_over = 1;
+        if (mine_true) atomicAdd(&s_true, mine_true < (1u << 20) ? mine_true : (1u << 20));
         // exclusive prefix of the 256 per-lane totals: shuffle scan inside each wave + the wave totals through LDS
         uint32_t v = mine;
         {
@@ -418,7 +444,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                 }
             }
         } else {
-            cnt = a.cand_cap + 1;  // a segment or the list overflowed: the dense path answers this query
+            seg_overflow_only = s_over != 0 && s_true <= a.cand_cap;  // (s_true: what the scan emitted, segment caps ignored)
+            cnt = a.cand_cap + 1;  // a segment or the list overflowed: rerun into flat lists, or the dense path
         }
         (void)s_off;
         __syncthreads();  // (workgroup-scope fence: the list is read back by other lanes below)
@@ -428,7 +455,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
     if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
         if (tid == 0) {
-            a.need_dense[q] = 1;
+            a.need_dense[q] = seg_overflow_only ? 2 : 1;
             a.out_count[q] = 0;
         }
         return;
@@ -585,6 +612,7 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.w_sort = f.w_sort;
     k.seg_queries = f.seg_queries;
     k.seg_cap = f.seg_cap;
+    k.flat_cnt = f.flat_cnt;
     k.cand = f.cand;
     k.out_ids = f.out_ids;
     k.out_dist = f.out_dist;

@@ -367,7 +367,9 @@ pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
     s.scale = ix->scale_set ? ix->scale : 0.f;
     for (pvs_index *sh : ix->shards) {
         pvs_stats p;
+        p.struct_size = sizeof p;
         PVS_TRY(pvs_index_stats(sh, &p));
+        s.rescanned_queries += p.rescanned_queries;
         s.rows += p.rows;
         s.capacity_rows += p.capacity_rows;
         s.hbm_bytes += p.hbm_bytes;
@@ -376,7 +378,10 @@ pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
     s.searches = ix->searches.load();
     s.fast_queries = ix->fast_queries.load();
     s.dense_queries = ix->dense_queries.load();
-    *out = s;
+    const size_t v2 = offsetof(pvs_stats, rescanned_queries);
+    const size_t want = out->struct_size >= v2 && out->struct_size <= sizeof s ? out->struct_size : v2;
+    s.struct_size = (uint32_t)want;
+    memcpy(out, &s, want);
     return PVS_OK;
 }
 

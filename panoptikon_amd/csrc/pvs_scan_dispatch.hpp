@@ -12,6 +12,11 @@ struct ScanK {
     uint2 *seg;          // MODE 1: candidate segments [n_segments][seg_queries][seg_cap] = (row, key bits)
     uint32_t *seg_cnt;   // MODE 1: fill counts [seg_queries][seg_stride] (a count above seg_cap = the segment overflowed)
     uint32_t seg_queries, seg_cap, seg_stride;
+    // MODE 1, rerun after a segment overflowed (candidates clustered in a few tile streams): when `flat` is set every candidate
+    // is appended to its query's flat list [query][flat_cap] through an atomic counter instead of going to a segment
+    uint2 *flat;
+    uint32_t *flat_cnt;
+    uint32_t flat_cap;
     uint64_t n_rows;
     uint32_t stride, n_wgtiles, tile_step, groups_per_query, grid;
     uint32_t gmin_per_lane;  // MODE 0: minima written per lane (1, 2, 4, 8 or 16); groups_per_query = grid * RT * 2 * gmin_per_lane

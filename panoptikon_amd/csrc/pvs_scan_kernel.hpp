@@ -375,6 +375,14 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
                     else
                         payload = __builtin_bit_cast(uint32_t, COS ? -sv * qi[g].dscale : sv + qi[g].bb + qi[g].eR * xh[r]);
                     const uint32_t rowv = prev_row_base + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    if (a.flat) {  // rerun after a segment overflow: one list per query, slots handed out by an atomic counter
+                        if (p) {
+                            const uint32_t qg = q0 + (uint32_t)j;
+                            const uint32_t pos = atomicAdd(a.flat_cnt + qg, 1u);
+                            if (pos < a.flat_cap) a.flat[(size_t)qg * a.flat_cap + pos] = make_uint2(rowv, payload);
+                        }
+                        continue;
+                    }
                     do {
                         const int l = __builtin_ctzll(m);
                         m &= m - 1;

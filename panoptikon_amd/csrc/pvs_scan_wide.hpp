@@ -270,8 +270,15 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
                 if (__builtin_amdgcn_ballot_w64(d >= ebi) == 0) continue;
                 const bool p = passes(q, score(q, (float)d, xs[r]));
                 if (p) {
-                    if (k < a.seg_cap) dst[k] = make_uint2(prev_row_base + (uint32_t)(32 * s + 16 * (r >> 2) + (r & 3)), (uint32_t)d);
-                    k++;
+                    const uint2 cand = make_uint2(prev_row_base + (uint32_t)(32 * s + 16 * (r >> 2) + (r & 3)), (uint32_t)d);
+                    if (a.flat) {  // rerun after a segment overflow: one list per query, slots handed out by an atomic counter
+                        const uint32_t qg = (uint32_t)(qw * QPW + 16 * q + n);
+                        const uint32_t pos = atomicAdd(a.flat_cnt + qg, 1u);
+                        if (pos < a.flat_cap) a.flat[(size_t)qg * a.flat_cap + pos] = cand;
+                    } else {
+                        if (k < a.seg_cap) dst[k] = cand;
+                        k++;
+                    }
                 }
             }
             return k;

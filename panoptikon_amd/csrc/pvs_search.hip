@@ -54,6 +54,118 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
     return PVS_OK;
 }
 
+// The filter-scan passes of one chunk of <= pass_max prepared queries (prep_chunk already ran): pass A (sample -> group minima),
+// the k-th select, pass B (every row once), pass C (exact page).  flat_rerun: the chunk is run again for the queries pass C handed
+// back with need_dense == 2 — a candidate segment overflowed although the query's candidates fit one list (ties clustered in a
+// few tile streams) — with pass B appending to per-query flat lists through atomic counters; the other queries' thresholds
+// are voided so that they emit nothing, and pass C finalises the handed-back ones only.
+static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff, uint32_t nb, uint32_t batch_pad, uint32_t k, int metric,
+                                     int64_t *oid, float *od, uint32_t *oc, bool flat_rerun) {
+    ScanArgs a;
+    a.dtype = (int)ix->dtype;
+    a.metric = metric;
+    a.kslabs = ix->stride / PVS_KSLAB_BYTES;
+    a.qgroups = batch_pad / 32;
+    a.rows = ix->d_rows;
+    a.aux = metric == PVS_COSINE ? ix->d_scan_cos : ix->d_scan_l2;
+    if (c.cur_mask) {  // filtered search: rows outside the mask stream a NaN scalar and never pass
+        HIP_TRY(pvs_launch_mask_aux(a.aux, c.cur_mask, ix->n, ix->cap, c.d_aux_masked, c.stream));
+        a.aux = c.d_aux_masked;
+    }
+    a.stride = ix->stride;
+    a.n_rows = ix->n;
+    a.qmat = c.d_qmat;
+    a.qinfo = c.d_qinfo;
+    a.thr = c.d_thr;
+    a.seg = c.d_seg;
+    a.seg_cnt = c.d_seg_cnt;
+    a.gmin = c.d_gmin;
+    const uint32_t wg_rows = pvs_scan_wg_rows(a.dtype, a.qgroups, a.kslabs);
+    const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+    // pass A: strided sample of row tiles -> group minima -> threshold
+    // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
+    // candidates, and each emit costs a few hundred cycles, while pass A costs ~ n_sample/N of a
+    // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
+    // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
+    // holds ~k/frac rows: keep that 2.5x below its capacity.
+    double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
+    static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
+    if (frac_env > 0.0) frac = frac_env;
+    frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
+    const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
+    const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
+    a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
+    const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
+    const uint32_t per_cu_a = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
+    const uint32_t spp = pvs_scan_segs_per_stream(a.dtype, a.qgroups, a.kslabs);  // lanes per query and workgroup stream (= its candidate segments)
+    a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs))});
+    a.mode = 0;
+    // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
+    // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
+    a.gmin_per_lane = pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs);
+    while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
+    a.groups_per_query = a.grid * spp * a.gmin_per_lane;
+    span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
+    HIP_TRY(pvs_launch_scan(a, c.stream));
+    span_end(ix, c);
+    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
+    if (flat_rerun) {
+        HIP_TRY(pvs_launch_void_thresholds(c.d_thr, c.d_need_dense + qoff, nb, c.stream));  // queries not handed back emit nothing
+        HIP_TRY(hipMemsetAsync(c.d_flat_cnt, 0, 4 * (size_t)PVS_SCAN_MAX_BATCH, c.stream));
+        a.flat = c.d_cand;
+        a.flat_cnt = c.d_flat_cnt;
+        a.flat_cap = PVS_CAND_CAP;
+    }
+    // pass B: every row once (candidate counters were zeroed by the prep kernel)
+    a.mode = 1;
+    a.tile_step = 1;
+    const uint32_t per_cu = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
+    a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu,
+                                 (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs)))});
+    a.n_segments = a.grid * spp;
+    span_begin(ix, c, 1, ix->n);
+    HIP_TRY(pvs_launch_scan(a, c.stream));
+    span_end(ix, c);
+    // pass C
+    FinalizeArgs f;
+    f.dtype = (int)ix->dtype;
+    f.metric = metric;
+    f.rows = ix->d_rows;
+    f.norm2 = ix->d_norm2;
+    f.ids = ix->d_ids;
+    f.stride = ix->stride;
+    f.dim = ix->dim;
+    f.n_rows = ix->n;
+    f.qexact = c.d_qexact;
+    f.qinfo = c.d_qinfo;
+    f.seg = c.d_seg;
+    f.seg_cnt = c.d_seg_cnt;
+    f.n_segments = a.n_segments;
+    f.seg_queries = batch_pad;
+    f.seg_cap = pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs);
+    f.cand = c.d_cand;
+    static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
+    static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;
+    if ((ix->multi_stream || force_light) && c.d_fin_ub && !no_light) {
+        f.w_ub = c.d_fin_ub;
+        f.w_surv = c.d_fin_surv;
+        f.w_sort = c.d_fin_sort;
+    }
+    f.cand_cap = PVS_CAND_CAP;
+    f.batch = nb;
+    f.k = k;
+    f.out_ids = oid;
+    f.out_dist = od;
+    f.out_count = oc;
+    f.need_dense = c.d_need_dense + qoff;
+    f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
+    if (flat_rerun) f.flat_cnt = c.d_flat_cnt;
+    span_begin(ix, c, 2, 0);
+    HIP_TRY(pvs_launch_finalize(f, c.stream));
+    span_end(ix, c);
+    return PVS_OK;
+}
+
 // Enqueues the whole search on c.stream.  Outputs are device buffers.
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                  int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast) {
@@ -99,100 +211,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
             for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
             continue;
         }
-        ScanArgs a;
-        a.dtype = (int)ix->dtype;
-        a.metric = metric;
-        a.kslabs = ix->stride / PVS_KSLAB_BYTES;
-        a.qgroups = batch_pad / 32;
-        a.rows = ix->d_rows;
-        a.aux = metric == PVS_COSINE ? ix->d_scan_cos : ix->d_scan_l2;
-        if (c.cur_mask) {  // filtered search: rows outside the mask stream a NaN scalar and never pass
-            HIP_TRY(pvs_launch_mask_aux(a.aux, c.cur_mask, ix->n, ix->cap, c.d_aux_masked, c.stream));
-            a.aux = c.d_aux_masked;
-        }
-        a.stride = ix->stride;
-        a.n_rows = ix->n;
-        a.qmat = c.d_qmat;
-        a.qinfo = c.d_qinfo;
-        a.thr = c.d_thr;
-        a.seg = c.d_seg;
-        a.seg_cnt = c.d_seg_cnt;
-        a.gmin = c.d_gmin;
-        const uint32_t wg_rows = pvs_scan_wg_rows(a.dtype, a.qgroups, a.kslabs);
-        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
-        // pass A: strided sample of row tiles -> group minima -> threshold
-        // Sample size.  Per wave-tile (32 rows x 32 queries) pass B expects 1024*k/n_sample emitted
-        // candidates, and each emit costs a few hundred cycles, while pass A costs ~ n_sample/N of a
-        // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
-        // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
-        // holds ~k/frac rows: keep that 2.5x below its capacity.
-        double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
-        static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
-        if (frac_env > 0.0) frac = frac_env;
-        frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
-        const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
-        const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
-        a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
-        const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
-        const uint32_t per_cu_a = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
-        const uint32_t spp = pvs_scan_segs_per_stream(a.dtype, a.qgroups, a.kslabs);  // lanes per query and workgroup stream (= its candidate segments)
-        a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs))});
-        a.mode = 0;
-        // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
-        // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
-        a.gmin_per_lane = pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs);
-        while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
-        a.groups_per_query = a.grid * spp * a.gmin_per_lane;
-        span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
-        HIP_TRY(pvs_launch_scan(a, c.stream));
-        span_end(ix, c);
-        HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
-        // pass B: every row once (candidate counters were zeroed by the prep kernel)
-        a.mode = 1;
-        a.tile_step = 1;
-        const uint32_t per_cu = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
-        a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu,
-                                     (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs)))});
-        a.n_segments = a.grid * spp;
-        span_begin(ix, c, 1, ix->n);
-        HIP_TRY(pvs_launch_scan(a, c.stream));
-        span_end(ix, c);
-        // pass C
-        FinalizeArgs f;
-        f.dtype = (int)ix->dtype;
-        f.metric = metric;
-        f.rows = ix->d_rows;
-        f.norm2 = ix->d_norm2;
-        f.ids = ix->d_ids;
-        f.stride = ix->stride;
-        f.dim = ix->dim;
-        f.n_rows = ix->n;
-        f.qexact = c.d_qexact;
-        f.qinfo = c.d_qinfo;
-        f.seg = c.d_seg;
-        f.seg_cnt = c.d_seg_cnt;
-        f.n_segments = a.n_segments;
-        f.seg_queries = batch_pad;
-        f.seg_cap = pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs);
-        f.cand = c.d_cand;
-        static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
-        static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;
-        if ((ix->multi_stream || force_light) && c.d_fin_ub && !no_light) {
-            f.w_ub = c.d_fin_ub;
-            f.w_surv = c.d_fin_surv;
-            f.w_sort = c.d_fin_sort;
-        }
-        f.cand_cap = PVS_CAND_CAP;
-        f.batch = nb;
-        f.k = k;
-        f.out_ids = oid;
-        f.out_dist = od;
-        f.out_count = oc;
-        f.need_dense = c.d_need_dense + qoff;
-        f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
-        span_begin(ix, c, 2, 0);
-        HIP_TRY(pvs_launch_finalize(f, c.stream));
-        span_end(ix, c);
+        PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false));
     }
     if (fast) {
         HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
@@ -205,12 +224,35 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
 // After the stream drained: answer the queries the filter path handed back.
 pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                    int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count) {
-    uint32_t n_dense = 0;
+    uint32_t n_dense = 0, n_rerun = 0;
     uint64_t seen = 0;
     for (uint32_t q = 0; q < batch; q++) {
-        n_dense += c.h_need_dense[q] ? 1 : 0;
+        n_rerun += c.h_need_dense[q] == 2 ? 1 : 0;
         seen += c.h_need_dense[c.flags_cap + q];
     }
+    if (n_rerun && fast_path_ok(ix, k)) {
+        // A candidate segment overflowed although the query's candidates fit one list (ties clustered in a few tile streams):
+        // the chunks that hold such queries go through the scan once more, pass B appending to per-query flat lists (the scan
+        // costs the same for one query as for a chunk of them; 10M x 768 int8, 106 of 128 queries affected: 1.6 + ~1.5 ms
+        // instead of the dense path's 12.4).
+        const uint32_t pass_max = pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES);
+        for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
+            const uint32_t nb = std::min(pass_max, batch - qoff);
+            bool any = false;
+            for (uint32_t q = 0; q < nb; q++) any |= c.h_need_dense[qoff + q] == 2;
+            if (!any) continue;
+            const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : nb <= 128 ? 128 : 256;
+            PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));
+            // (prep_chunk rewrites this chunk's flags: put the hand-back marks where pass C and the threshold mask read them)
+            HIP_TRY(hipMemcpyAsync(c.d_need_dense + qoff, c.h_need_dense + qoff, 4 * (size_t)nb, hipMemcpyHostToDevice, c.stream));
+            PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, d_out_ids + (size_t)qoff * k, d_out_dist + (size_t)qoff * k,
+                                       d_out_count + qoff, true));
+        }
+        HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        ix->flat_reruns += n_rerun;
+    }
+    for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
     ix->last_candidates = seen;
     ix->fast_queries += batch - n_dense;
     if (!n_dense) return PVS_OK;
@@ -586,15 +628,33 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
 }
 
 // pvs_search restricted by apply_sort_bounds (pql/builder.rs:781-815) on the distance: page 1 of the rows with gt < d < lt.
-// Every row is scored exactly and the ones outside the bounds leave the sort (dense path; a lower bound `gt` makes the first
-// k rows of the plain ordering useless, so the filter scan's "k best" machinery does not apply).
+// An upper bound alone (the usual similarity cut-off) changes nothing about WHICH rows are best: the k smallest distances
+// among the rows with d < lt are the k smallest of all rows, cut where d reaches lt — the plain search (filter scan) with the
+// page truncated; NULL distances never satisfy a comparison.  With a lower bound `gt` the first k rows of the plain ordering
+// are useless: every row is scored exactly and the ones outside the bounds leave the sort (dense path).
 PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                          int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist,
                                          uint32_t *out_count) {
-    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_search_bounded is not served on a multi-device index");
-    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if ((have_gt && gt != gt) || (have_lt && lt != lt)) return pvs_fail(PVS_ERR_INVALID_ARG, "bounds must be numbers");
+    if (!have_gt) {
+        PVS_TRY(search_host_any(ix, queries, qdtype, batch, k, metric, out_ids, out_dist, out_count));
+        const float nan32 = __builtin_nanf("");
+        for (uint32_t q = 0; q < batch; q++) {
+            uint32_t keep = 0;
+            const float *d = out_dist + (size_t)q * k;
+            while (keep < out_count[q] && (!have_lt || (d[keep] == d[keep] && (double)d[keep] < lt))) keep++;  // sorted ascending, NULLs last
+            for (uint32_t i = keep; i < out_count[q]; i++) {
+                out_ids[(size_t)q * k + i] = -1;
+                out_dist[(size_t)q * k + i] = nan32;
+            }
+            out_count[q] = keep;
+        }
+        return PVS_OK;
+    }
+    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_search_bounded with a lower bound is not served on a multi-device index");
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (batch == 0) return PVS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     uint32_t t;

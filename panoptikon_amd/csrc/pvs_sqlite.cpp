@@ -142,6 +142,7 @@ pvs_status lookup(const std::string &name, pvs_index **ix, uint32_t *dtype, uint
     auto it = g_indexes.find(name);
     if (it == g_indexes.end()) return PVS_ERR_INVALID_ARG;
     pvs_stats st;
+    st.struct_size = sizeof st;
     pvs_status s = pvs_index_stats(it->second.ix, &st);
     if (s != PVS_OK) return s;
     *ix = it->second.ix;
@@ -451,6 +452,7 @@ bool have_write_api() { return have_stmt_api() && g_api.struct_size >= sizeof(pv
 
 pvs_status stream_rows(void *stmt, pvs_index *ix, uint32_t chunk_rows, pvs_sqlite_load_result *res, std::string *err) {
     pvs_stats st;
+    st.struct_size = sizeof st;
     pvs_status s = pvs_index_stats(ix, &st);
     if (s != PVS_OK) return s;
     const uint64_t dim = st.dim;

@@ -337,5 +337,6 @@ class VectorIndex:
 
     def stats(self) -> L.Stats:
         s = L.Stats()
+        s.struct_size = C.sizeof(L.Stats)
         L.check(L.lib().pvs_index_stats(self._h, C.byref(s)))
         return s

@@ -1439,3 +1439,37 @@ def test_pagination_is_a_window_of_the_same_ordering(pvs):
     finally:
         ix.close()
         ixg.close()
+
+
+@pytest.mark.parametrize("batch", [128, 256, 40])
+def test_ties_clustered_in_a_few_tile_streams_are_rescanned_not_sent_to_the_dense_path(pvs, batch):
+    """A corpus of few distinct vectors repeated with a period that is a multiple of the tile-stream count puts every copy of
+    the best vector into the same handful of candidate segments: they overflow although the query's candidates fit one list.
+    Such queries are handed back with need_dense = 2 and their chunk goes through the scan once more with pass B appending to
+    flat per-query lists (pvs_stats.rescanned_queries), not through the dense path; the page is the oracle's — the copies with
+    the lowest ids."""
+    # period 16,384 rows = 256 tiles of 64 rows: one or two streams hold every copy.  (k is small on purpose: the copies also share ONE
+    # of pass A's row groups, so the threshold is the k-th best SAMPLED vector — about the 16 k-th best overall — and everything
+    # closer than that, times 100 copies, has to fit the 16,384-entry list; beyond that the dense path is the right answer.)
+    dim, distinct, copies, k = 64, 16384, 100, 5
+    base = unit_rows(777, distinct, dim)
+    rows = np.tile(base, (copies, 1))
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, pvs.I8, rows, scale)
+    corpus = host_corpus(orc.I8, rows, scale)
+    # each query sits next to one stored vector, whose copies tie at the top of its page; the vectors are picked from tiles the
+    # sample pass visits (tile index = 0 mod 16), so the threshold is the tie itself and the candidates are just the copies
+    pick = 1024 * (np.arange(batch) % 16) + np.arange(batch) // 16
+    qs = base[pick] + 0.01 * orc.synth_rows(778, 0, batch, dim)
+    hq = orc.quantize_int8(qs, scale)
+    for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+        before = ix.stats()
+        gi, gd, gc = ix.search(qs, k, metric)
+        after = ix.stats()
+        ei, ed = orc.search(orc.I8, om, corpus, hq, k)
+        assert (gc == k).all()
+        assert np.array_equal(gi[:, :k], ei) and np.array_equal(gd[:, :k].view(np.uint32), ed.view(np.uint32))
+        assert after.dense_queries == before.dense_queries, "no query may need the dense path"
+        if batch >= 128:  # (k_scan's 64-slot segments at 512 streams see 50 copies each: no overflow at 40 queries)
+            assert after.rescanned_queries - before.rescanned_queries == batch, "every query's ties must have overflowed a segment"
+    ix.close()
