@@ -260,6 +260,15 @@ pvs_status pvs_sync(pvs_index *idx);
  * scans never compete for CUs; > 1: each in-flight search gets its own stream. */
 pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
 
+/* The reference's second sort key.  Its final order is `ORDER BY order_rank ASC NULLS LAST, last_modified DESC`
+ * (pql/model.rs:547-553, pql/builder.rs:1188-1223) and, with row_n off (the default, model.rs:232), order_rank IS the
+ * distance: rows that tie on it are ordered by last_modified, newest first.  One int64 key per stored row (whatever the host
+ * orders by: last_modified as a Unix time, say); afterwards every row page — pvs_search*, pvs_search_device, pvs_search_page,
+ * pvs_search_bounded, the dense fallbacks — is ordered (distance asc, NULL last, key DESC, row id asc), and a tie at the k-th
+ * distance takes the rows with the largest keys.  `n` must equal the index's row count; rows appended later drop the keys
+ * (set them again).  keys == NULL removes them.  Single-device indexes. */
+pvs_status pvs_index_set_order_keys(pvs_index *idx, const int64_t *keys, uint64_t n, pvs_space space);
+
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort
  * (every row scored exactly, full device sort), 2 = filter scan only (error
  * instead of falling back).  For tests and profiling. */

@@ -205,6 +205,17 @@ def topk(dist, k: int, ids=None):
     return oi[:cnt].copy(), od[:cnt].copy()
 
 
+def topk_ordered(dist, k: int, ids, order_keys):
+    """Page order with the reference's second sort key (`ORDER BY order_rank ASC NULLS LAST, last_modified DESC`,
+    pql/model.rs:547-553; order_rank = the distance when row_n is off): distance asc, NaN (NULL) last, key DESC, id asc."""
+    dist = np.asarray(dist, np.float32)
+    ids = np.asarray(ids, np.int64)
+    keys = np.asarray(order_keys, np.int64)
+    isn = np.isnan(dist)
+    order = np.lexsort((ids, np.negative(keys), np.where(isn, np.float32(0), dist), isn))[:k]
+    return ids[order], dist[order]
+
+
 def search(dtype: int, metric: int, corpus, queries, k: int, ids=None, threads: int = 1):
     """Batch of queries -> (ids[B][k'], dist[B][k']), k' = min(k, n)."""
     c = _corpus(dtype, corpus)

@@ -101,6 +101,7 @@ SYMBOLS = {
     "pvs_sync": (_i32, [_vp]),
     "pvs_index_set_streams": (_i32, [_vp, _u32]),
     "pvs_index_set_path": (_i32, [_vp, _u32]),
+    "pvs_index_set_order_keys": (_i32, [_vp, _vp, _u64, _i32]),
     "pvs_score_column_create": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     "pvs_score_column_rows": (_i32, [_vp, C.POINTER(_u64)]),
     "pvs_score_column_read": (_i32, [_vp, _u64, _u64, _vp]),

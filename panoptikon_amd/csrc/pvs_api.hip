@@ -482,6 +482,8 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_ids);
     hipFree(ix->d_scan_cos);
     hipFree(ix->d_scan_l2);
+    hipFree(ix->d_trank);
+    hipFree(ix->d_tinv);
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
@@ -593,6 +595,43 @@ PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
         return pvs_fail(PVS_ERR_STATE, "scale is frozen once rows exist (artifact_rev semantics): rebuild the index");
     ix->scale = scale;
     ix->scale_set = true;
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "order keys are served on single-device indexes");
+    PVS_TRY(pvs_sync(ix));  // (searches in flight read the tie ranks)
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipFree(ix->d_trank);
+    hipFree(ix->d_tinv);
+    ix->d_trank = ix->d_tinv = nullptr;
+    ix->order_rows = 0;
+    if (!keys) return PVS_OK;
+    if (n != ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "%llu order keys for %llu rows: one key per stored row", (unsigned long long)n, (unsigned long long)ix->n);
+    if (n == 0) return PVS_OK;
+    int64_t *d_keys = nullptr;
+    const int64_t *src = keys;
+    auto body = [&]() -> pvs_status {
+        if (space == PVS_HOST) {
+            HIP_TRY(pvs_scratch_alloc((void **)&d_keys, n * 8));
+            HIP_TRY(hipMemcpy(d_keys, keys, n * 8, hipMemcpyHostToDevice));
+            src = d_keys;
+        }
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_trank, n * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_tinv, n * 4));
+        PVS_TRY(pvs_build_tie_ranks(src, n, ix->d_trank, ix->d_tinv, ix->admin_stream));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    pvs_scratch_free(d_keys);  // (pvs_build_tie_ranks is synchronous)
+    if (st != PVS_OK) {
+        hipFree(ix->d_trank);
+        hipFree(ix->d_tinv);
+        ix->d_trank = ix->d_tinv = nullptr;
+        return st;
+    }
+    ix->order_rows = n;
     return PVS_OK;
 }
 PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t *artifact, size_t len) {

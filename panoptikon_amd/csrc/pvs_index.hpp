@@ -141,6 +141,10 @@ struct pvs_index {
     float *d_rnorm = nullptr;   // 1/|a|
     float *d_scan_cos = nullptr, *d_scan_l2 = nullptr;  // the scan's row-scalar streams: [cap/32][PVS_AUX_REC] (k_scan_aux)
     int64_t *d_ids = nullptr;
+    // second sort key (pvs_index_set_order_keys): d_trank[row] = position of the row in (key DESC, id ASC) order, d_tinv its inverse.
+    // Wherever a page is ordered by (distance, row) the row is replaced by its tie rank and mapped back on output.
+    uint32_t *d_trank = nullptr, *d_tinv = nullptr;
+    uint64_t order_rows = 0;  // rows the tie ranks cover (0: none set)
     std::vector<int64_t> h_groups;  // optional group ids per row (host copy)
     std::vector<int64_t> h_ids_cache;  // host copy of row ids (lazy; similar_to's id -> row lookup)
     // group CSR on the device (built lazily, rebuilt after adds)

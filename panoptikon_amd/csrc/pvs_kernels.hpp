@@ -110,6 +110,8 @@ struct FinalizeArgs {
     // segment-overflow rerun: the scan already wrote flat lists into `cand` (ScanArgs.flat); only queries whose need_dense is 2
     // are finalised, the others keep the page they have
     const uint32_t *flat_cnt = nullptr;
+    // second sort key (pvs_index_set_order_keys): ties on the distance are ordered by tie rank instead of by row
+    const uint32_t *trank = nullptr, *tinv = nullptr;
     // Optional global-memory work area: with it (int8 rows) pass C keeps its bound keys, survivor list and large sorts in HBM/L2
     // and needs ~6 KB of LDS instead of ~104 KB, so it can run NEXT TO the scan of another search (k_scan's two workgroups per
     // CU leave 7.8 KB of LDS free).  Used when an index runs its searches on several streams.
@@ -137,15 +139,19 @@ struct DenseBounds {  // apply_sort_bounds on the distance column: rows outside 
 };
 pvs_status pvs_dense_topk(DenseWork &w, uint64_t n, uint32_t k, const int64_t *ids, int64_t *out_ids,
                           float *out_dist, uint32_t *out_count, hipStream_t s, const uint8_t *mask = nullptr,
-                          DenseBounds bounds = DenseBounds());
+                          DenseBounds bounds = DenseBounds(), const uint32_t *tinv = nullptr);
+// tie ranks of the second sort key: d_tinv[t] = the row at position t of (key DESC, row ASC), d_trank its inverse (synchronous)
+pvs_status pvs_build_tie_ranks(const int64_t *d_keys, uint64_t n, uint32_t *d_trank, uint32_t *d_tinv, hipStream_t s);
 // aux / out: the scan's row-scalar stream in tile records (cap/32 * PVS_AUX_REC floats); rows outside the mask get a NaN
 // scalar (a NaN scalar makes every filter comparison of the row false)
 hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n, uint64_t cap, float *out, hipStream_t s);
 
 // ---- page 1 of many dense columns at once (pvs_select.hip): m [n][ld] f32, column j -> query slot qmap[j] (or j)
 bool pvs_select_supported(uint32_t k);
+// tinv (optional): tie order of the rows (second sort key); ties are then cut and ordered by position in it instead of by row
 pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq, uint32_t k, const uint8_t *mask, const int64_t *ids,
-                           const uint32_t *d_qmap, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s);
+                           const uint32_t *d_qmap, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s,
+                           const uint32_t *tinv = nullptr);
 
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,

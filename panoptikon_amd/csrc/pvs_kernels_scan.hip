@@ -226,6 +226,7 @@ struct FinK {
     uint32_t *w_ub, *w_surv;       // LIGHT: global work area (FinalizeArgs.w_*)
     unsigned long long *w_sort;
     const uint32_t *flat_cnt;      // segment-overflow rerun (FinalizeArgs.flat_cnt)
+    const uint32_t *trank, *tinv;  // second sort key: tie rank of a row and its inverse (FinalizeArgs.trank)
 };
 
 constexpr int FIN_QMAX = 8192;  // bytes of LDS for the query vector the rerank reads (dims beyond that read it from global memory)
@@ -543,13 +544,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                 else
                     d = rerank_distance<DT>(a.rows, a.stride, row, s_q, (int)a.dim, a.metric, aa, qi.bb);
             }
-            v = ((unsigned long long)f32_sort_key(d) << 32) | row;
+            v = ((unsigned long long)f32_sort_key(d) << 32) | (a.trank ? a.trank[row] : row);  // ties: by tie rank (key DESC, id ASC), else by row = id
         }
         s_sort[i] = v;
     }
     __syncthreads();
     FIN_STAMP(5);
-    // bitonic sort ascending on (distance key, row)
+    // bitonic sort ascending on (distance key, row or tie rank)
     for (uint32_t sz = 2; sz <= m2; sz <<= 1) {
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
             for (uint32_t i = tid; i < m2 / 2; i += 256) {
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     for (uint32_t i = tid; i < a.k; i += 256) {
         if (i < nout) {
             const unsigned long long v = s_sort[i];
-            oid[i] = a.ids[(uint32_t)v];
+            oid[i] = a.ids[a.tinv ? a.tinv[(uint32_t)v] : (uint32_t)v];
             od[i] = f32_from_sort_key((uint32_t)(v >> 32));
         } else {
             oid[i] = -1;
@@ -613,6 +614,8 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.seg_queries = f.seg_queries;
     k.seg_cap = f.seg_cap;
     k.flat_cnt = f.flat_cnt;
+    k.trank = f.trank;
+    k.tinv = f.tinv;
     k.cand = f.cand;
     k.out_ids = f.out_ids;
     k.out_dist = f.out_dist;

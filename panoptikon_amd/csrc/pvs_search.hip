@@ -26,6 +26,9 @@ pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype,
     return PVS_OK;
 }
 
+// the tie order of the second sort key, when it covers the index's rows (pvs_index_set_order_keys)
+static inline const uint32_t *order_tinv(const pvs_index *ix) { return ix->order_rows == ix->n && ix->n ? ix->d_tinv : nullptr; }
+
 bool fast_path_ok(const pvs_index *ix, uint32_t k) {
     if (ix->forced_path == 1) return false;
     if (!pvs_scan_supported((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES)) return false;
@@ -40,7 +43,7 @@ static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k,
     const uint8_t *qe = c.d_qexact + (size_t)q * ix->dim * (ix->dtype == PVS_I8 ? 1 : 4);
     HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, qe, c.d_qinfo + q, 1,
                                    c.d_qpad, c.dense.d_dist, 1, 0, (uint32_t)ix->n_cu, c.stream));
-    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask, bounds));
+    PVS_TRY(pvs_dense_topk(c.dense, ix->n, k, ix->d_ids, out_ids, out_dist, out_count, c.stream, c.cur_mask, bounds, order_tinv(ix)));
     ix->dense_queries++;
     return PVS_OK;
 }
@@ -160,6 +163,10 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.need_dense = c.d_need_dense + qoff;
     f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
     if (flat_rerun) f.flat_cnt = c.d_flat_cnt;
+    if (order_tinv(ix)) {
+        f.trank = ix->d_trank;
+        f.tinv = ix->d_tinv;
+    }
     span_begin(ix, c, 2, 0);
     HIP_TRY(pvs_launch_finalize(f, c.stream));
     span_end(ix, c);
@@ -201,7 +208,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
                     st = prep_chunk(ix, c, d_queries, qdtype, qoff + off, nbb, pad, metric);
                     if (st == PVS_OK) st = dense_chunk(ix, c, nbb, pad, metric, d_m);
                     if (st == PVS_OK)
-                        st = pvs_select_topk(d_m, ix->n, nbb, nbb, k, c.cur_mask, ix->d_ids, nullptr, oid + (size_t)off * k, od + (size_t)off * k, oc + off, c.stream);
+                        st = pvs_select_topk(d_m, ix->n, nbb, nbb, k, c.cur_mask, ix->d_ids, nullptr, oid + (size_t)off * k, od + (size_t)off * k, oc + off, c.stream, order_tinv(ix));
                 }
                 pvs_scratch_free_on(d_m, c.stream);  // (scoring and select are queued, not finished)
                 PVS_TRY(st);
@@ -282,7 +289,7 @@ pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, 
                 const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
                 PVS_TRY(prep_chunk(ix, c, d_qd, qdtype, off, nb, pad, metric));
                 PVS_TRY(dense_chunk(ix, c, nb, pad, metric, d_m));
-                PVS_TRY(pvs_select_topk(d_m, ix->n, nb, nb, k, c.cur_mask, ix->d_ids, d_qmap + off, d_out_ids, d_out_dist, d_out_count, c.stream));
+                PVS_TRY(pvs_select_topk(d_m, ix->n, nb, nb, k, c.cur_mask, ix->d_ids, d_qmap + off, d_out_ids, d_out_dist, d_out_count, c.stream, order_tinv(ix)));
             }
             HIP_TRY(hipStreamSynchronize(c.stream));
             return PVS_OK;

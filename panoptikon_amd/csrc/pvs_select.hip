@@ -30,6 +30,8 @@ struct SelCol {                // per column, in HBM
     uint32_t pad;
 };
 
+// position r of the walk -> physical row: the rows are walked in tie order when a second sort key is set (tinv), in row order else
+__device__ inline uint64_t sel_row(const uint32_t *tinv, uint64_t r) { return tinv ? (uint64_t)tinv[r] : r; }
 __device__ inline uint32_t sel_key(float d, const uint8_t *mask, uint64_t row) {
     uint32_t k = f32_sort_key(d);
     if (k == 0xffffffffu) k = 0xfffffffeu;
@@ -56,7 +58,7 @@ __global__ void k_sel_init(SelCol *cols, uint32_t nq, uint32_t k, uint32_t *hist
 }
 
 // hist[col][digit] += rows of the column whose key matches the column's prefix so far (digit = the pass's 8 bits)
-__global__ __launch_bounds__(256) void k_sel_hist(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, const SelCol *cols,
+__global__ __launch_bounds__(256) void k_sel_hist(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, const uint32_t *tinv, const SelCol *cols,
                                                   int shift, uint32_t *hist, uint64_t rows_per_wg) {
     __shared__ uint32_t sh[SEL_CG * 256];
     __shared__ uint32_t s_prefix[SEL_CG], s_mask[SEL_CG];
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void k_sel_hist(const float *m, uint64_t n, ui
     const uint32_t c = threadIdx.x & 31u;
     if (c < nc) {
         for (uint64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) {
-            const uint32_t key = sel_key(m[r * ld + c0 + c], mask, r);
+            const uint64_t pr = sel_row(tinv, r);
+            const uint32_t key = sel_key(m[pr * ld + c0 + c], mask, pr);
             if ((key & s_mask[c]) == s_prefix[c]) atomicAdd(&sh[c * 256 + ((key >> shift) & 255u)], 1u);
         }
     }
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void k_sel_pick(SelCol *cols, uint32_t *hist, 
 }
 
 // ties of K per (row block, column)
-__global__ __launch_bounds__(256) void k_sel_count_ties(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, const SelCol *cols,
+__global__ __launch_bounds__(256) void k_sel_count_ties(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, const uint32_t *tinv, const SelCol *cols,
                                                         uint32_t *blockties, uint32_t n_blocks) {
     __shared__ uint32_t s_cnt[SEL_CG];
     __shared__ uint32_t s_K[SEL_CG];
@@ -151,14 +154,17 @@ __global__ __launch_bounds__(256) void k_sel_count_ties(const float *m, uint64_t
     const uint32_t c = threadIdx.x & 31u;
     uint32_t mine = 0;
     if (c < nc)
-        for (uint64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) mine += sel_key(m[r * ld + c0 + c], mask, r) == s_K[c];
+        for (uint64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) {
+            const uint64_t pr = sel_row(tinv, r);
+            mine += sel_key(m[pr * ld + c0 + c], mask, pr) == s_K[c];
+        }
     if (mine) atomicAdd(&s_cnt[c], mine);
     __syncthreads();
     if (threadIdx.x < nc) blockties[(size_t)(c0 + threadIdx.x) * n_blocks + b] = s_cnt[threadIdx.x];
 }
 
 // one workgroup per column: the row below which exactly `ties` ties of K lie
-__global__ __launch_bounds__(256) void k_sel_tie_cut(const float *m, uint64_t n, uint32_t ld, const uint8_t *mask, SelCol *cols, const uint32_t *blockties,
+__global__ __launch_bounds__(256) void k_sel_tie_cut(const float *m, uint64_t n, uint32_t ld, const uint8_t *mask, const uint32_t *tinv, SelCol *cols, const uint32_t *blockties,
                                                      uint32_t n_blocks) {
     __shared__ uint32_t s[256];
     __shared__ uint32_t s_blk, s_before;
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(256) void k_sel_tie_cut(const float *m, uint64_t n,
     uint32_t flags = 0, cnt = 0;
     for (uint32_t i = 0; i < SEL_RB / 256; i++) {
         const uint64_t r = r0 + (uint64_t)tid * (SEL_RB / 256) + i;
-        const bool t = r < n && sel_key(m[r * ld + j], mask, r) == c.prefix;
+        const uint64_t pr = r < n ? sel_row(tinv, r) : 0;
+        const bool t = r < n && sel_key(m[pr * ld + j], mask, pr) == c.prefix;
         flags |= (uint32_t)t << i;
         cnt += t;
     }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void k_sel_tie_cut(const float *m, uint64_t n,
 }
 
 // the selected (key, row) pairs of every column: key < K, or key == K and row < rcut
-__global__ __launch_bounds__(256) void k_sel_emit(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, SelCol *cols, uint32_t k,
+__global__ __launch_bounds__(256) void k_sel_emit(const float *m, uint64_t n, uint32_t ld, uint32_t nq, const uint8_t *mask, const uint32_t *tinv, SelCol *cols, uint32_t k,
                                                   unsigned long long *sel, uint64_t rows_per_wg) {
     __shared__ uint32_t s_K[SEL_CG], s_rcut[SEL_CG];
     const uint32_t c0 = blockIdx.y * SEL_CG, nc = min(SEL_CG, nq - c0);
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(256) void k_sel_emit(const float *m, uint64_t n, ui
     const uint32_t c = threadIdx.x & 31u;
     if (c >= nc) return;
     for (uint64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) {
-        const uint32_t key = sel_key(m[r * ld + c0 + c], mask, r);
+        const uint64_t pr = sel_row(tinv, r);
+        const uint32_t key = sel_key(m[pr * ld + c0 + c], mask, pr);
         if (key == 0xffffffffu) continue;
         if (key < s_K[c] || (key == s_K[c] && r < s_rcut[c])) {
             const uint32_t p = atomicAdd(&cols[c0 + c].cnt, 1u);
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void k_sel_emit(const float *m, uint64_t n, ui
 }
 
 // one workgroup per column: order the <= k selected pairs by (key, row) and write the page
-__global__ __launch_bounds__(256) void k_sel_sort_emit(const unsigned long long *sel, const SelCol *cols, uint32_t k, const int64_t *ids, const uint32_t *qmap,
+__global__ __launch_bounds__(256) void k_sel_sort_emit(const unsigned long long *sel, const SelCol *cols, uint32_t k, const int64_t *ids, const uint32_t *tinv, const uint32_t *qmap,
                                                        int64_t *out_ids, float *out_dist, uint32_t *out_count) {
     extern __shared__ unsigned long long s_sort[];
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void k_sel_sort_emit(const unsigned long long 
         if (i < m) {
             const unsigned long long v = s_sort[i];
             const uint32_t key = (uint32_t)(v >> 32);
-            oi[i] = ids[(uint32_t)v];
+            oi[i] = ids[sel_row(tinv, (uint32_t)v)];
             od[i] = key == 0xfffffffeu ? __builtin_nanf("") : f32_from_sort_key(key);
         } else {
             oi[i] = -1;
@@ -308,7 +316,7 @@ bool pvs_select_supported(uint32_t k) { return k <= SEL_KMAX; }
 // m: [n][ld] f32 distances (column j of query slot qmap[j]); writes page 1 of size k of every column.  Scratch comes
 // from the cache (pvs_scratch_alloc); everything is enqueued on `s`, no host synchronisation.
 pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq, uint32_t k, const uint8_t *mask, const int64_t *ids,
-                           const uint32_t *d_qmap, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s) {
+                           const uint32_t *d_qmap, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s, const uint32_t *tinv) {
     if (nq == 0) return PVS_OK;
     if (k > SEL_KMAX) return pvs_fail(PVS_ERR_UNSUPPORTED, "select: k too large");
     if (n >= 0xffffffffull) return pvs_fail(PVS_ERR_UNSUPPORTED, "select: too many rows");
@@ -327,15 +335,15 @@ pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq,
         const uint64_t rows_per_wg = (n + row_wgs - 1) / row_wgs;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
-            hipLaunchKernelGGL(k_sel_hist, dim3(row_wgs, cgs), dim3(256), 0, s, m, n, ld, nq, mask, cols, shift, hist, rows_per_wg);
+            hipLaunchKernelGGL(k_sel_hist, dim3(row_wgs, cgs), dim3(256), 0, s, m, n, ld, nq, mask, tinv, cols, shift, hist, rows_per_wg);
             hipLaunchKernelGGL(k_sel_pick, dim3(nq), dim3(256), 0, s, cols, hist, shift, pass == 3 ? 1 : 0);
         }
-        hipLaunchKernelGGL(k_sel_count_ties, dim3(n_blocks, cgs), dim3(256), 0, s, m, n, ld, nq, mask, cols, blockties, n_blocks);
-        hipLaunchKernelGGL(k_sel_tie_cut, dim3(nq), dim3(256), 0, s, m, n, ld, mask, cols, blockties, n_blocks);
-        hipLaunchKernelGGL(k_sel_emit, dim3(row_wgs, cgs), dim3(256), 0, s, m, n, ld, nq, mask, cols, k, sel, rows_per_wg);
+        hipLaunchKernelGGL(k_sel_count_ties, dim3(n_blocks, cgs), dim3(256), 0, s, m, n, ld, nq, mask, tinv, cols, blockties, n_blocks);
+        hipLaunchKernelGGL(k_sel_tie_cut, dim3(nq), dim3(256), 0, s, m, n, ld, mask, tinv, cols, blockties, n_blocks);
+        hipLaunchKernelGGL(k_sel_emit, dim3(row_wgs, cgs), dim3(256), 0, s, m, n, ld, nq, mask, tinv, cols, k, sel, rows_per_wg);
         uint32_t m2 = 1;
         while (m2 < k) m2 <<= 1;
-        hipLaunchKernelGGL(k_sel_sort_emit, dim3(nq), dim3(256), (size_t)m2 * 8, s, sel, cols, k, ids, d_qmap, out_ids, out_dist, out_count);
+        hipLaunchKernelGGL(k_sel_sort_emit, dim3(nq), dim3(256), (size_t)m2 * 8, s, sel, cols, k, ids, tinv, d_qmap, out_ids, out_dist, out_count);
         HIP_TRY(hipGetLastError());
         return PVS_OK;
     };

@@ -239,6 +239,14 @@ class VectorIndex:
     def set_path(self, path: int):
         L.check(L.lib().pvs_index_set_path(self._h, path))
 
+    def set_order_keys(self, keys) -> None:
+        """One int64 per stored row (e.g. last_modified): rows that tie on the distance come out by key DESC, then id.  None removes them."""
+        if keys is None:
+            L.check(L.lib().pvs_index_set_order_keys(self._h, None, 0, L.HOST))
+            return
+        k = np.ascontiguousarray(keys, np.int64)
+        L.check(L.lib().pvs_index_set_order_keys(self._h, _ptr(k), k.size, L.HOST))
+
     def scan_kernel_name(self, batch: int) -> str:
         buf = C.create_string_buffer(128)
         L.check(L.lib().pvs_index_scan_kernel_name(self._h, batch, buf, 128))

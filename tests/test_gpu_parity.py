@@ -1473,3 +1473,62 @@ def test_ties_clustered_in_a_few_tile_streams_are_rescanned_not_sent_to_the_dens
         if batch >= 128:  # (k_scan's 64-slot segments at 512 streams see 50 copies each: no overflow at 40 queries)
             assert after.rescanned_queries - before.rescanned_queries == batch, "every query's ties must have overflowed a segment"
     ix.close()
+
+
+def test_second_sort_key_orders_ties_like_the_reference(pvs):
+    """`ORDER BY order_rank ASC NULLS LAST, last_modified DESC` (pql/model.rs:547-553; order_rank is the distance when row_n is
+    off, model.rs:232): rows that tie on the distance come out newest first, then by id, and a tie at the k-th distance takes the
+    newest rows.  int8 L2 over a corpus of few distinct vectors ties massively.  Every route to a row page must
+    agree with the oracle's ordering: the filter scan (pass C), the per-query dense sort, the batched dense select; NULL
+    distances stay last; appending rows drops the keys."""
+    rng = np.random.default_rng(99)
+    dim, distinct, copies = 96, 300, 40
+    base = unit_rows(555, distinct, dim)
+    rows = np.tile(base, (copies, 1))[rng.permutation(distinct * copies)]
+    rows[123] = 0.0  # NULL cosine distance
+    n = len(rows)
+    ids = np.arange(n, dtype=np.int64) * 2 + 5
+    keys = rng.integers(-5, 40, n).astype(np.int64) * 86_400 + 1_700_000_000  # "last_modified" days: plenty of equal keys too
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids)
+    ix.set_order_keys(keys)
+    corpus = orc.quantize_int8(rows, scale)
+    qs = base[[3, 77, 150, 299, 8]] + 0.02 * orc.synth_rows(556, 0, 5, dim)
+    hq = orc.quantize_int8(qs, scale)
+    for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+        want = {}
+        for k in (1, 7, 40, 41, 130):
+            for qi in range(len(qs)):
+                d = orc.score_all(orc.I8, om, corpus, hq[qi])
+                want[(k, qi)] = orc.topk_ordered(d, k, ids, keys)
+        for path in (0, 1):  # automatic (filter scan) / dense
+            ix.set_path(path)
+            for k in (1, 7, 40, 41, 130):
+                gi, gd, gc = ix.search(qs, k, metric)                 # batch: pass C, or the batched dense select
+                g1 = [ix.search(qs[qi], k, metric) for qi in range(2)]  # single queries: pass C, or the per-query dense sort
+                for qi in range(len(qs)):
+                    ei, ed = want[(k, qi)]
+                    assert gc[qi] == k and np.array_equal(gi[qi, :k], ei), (metric, path, k, qi)
+                    assert np.array_equal(gd[qi, :k].view(np.uint32), ed.view(np.uint32))
+                for qi in range(2):
+                    assert np.array_equal(g1[qi][0][0, :k], want[(k, qi)][0]), (metric, path, k, qi, "single")
+        ix.set_path(0)
+    # the keys really matter here (the id order alone gives another page), and removing them restores the id order
+    d = orc.score_all(orc.I8, orc.L2, corpus, hq[0])
+    plain_i, _ = orc.topk(d, 40, ids=ids)
+    assert not np.array_equal(plain_i, want[(40, 0)][0]), "the test corpus must tie at the top"
+    ix.set_order_keys(None)
+    gi, gd, gc = ix.search(qs[0], 40, pvs.L2)
+    assert np.array_equal(gi[0, :40], plain_i)
+    # appended rows drop the keys until they are set again for all rows
+    ix.set_order_keys(keys)
+    ix.add_f32(rows[:3], row_ids=np.array([10**9, 10**9 + 1, 10**9 + 2], np.int64))
+    gi, gd, gc = ix.search(qs[0], 5, pvs.L2)
+    d2 = orc.score_all(orc.I8, orc.L2, np.concatenate([corpus, corpus[:3]]), hq[0])
+    ei, _ = orc.topk(d2, 5, ids=np.concatenate([ids, [10**9, 10**9 + 1, 10**9 + 2]]))
+    assert np.array_equal(gi[0, :5], ei)
+    with pytest.raises(Exception):
+        ix.set_order_keys(keys)  # one key per stored row
+    ix.close()

@@ -655,3 +655,43 @@ def test_sql_seam_reads_a_column_longer_than_one_window():
     finally:
         sqlite_seam.unbind("big")
         ix.close()
+
+
+@pytest.mark.gpu
+def test_row_page_with_order_keys_equals_sqlites_order_by_d_last_modified_desc():
+    """The page pvs_search returns once the rows carry their `last_modified` as order keys must be the page SQLite itself
+    produces from the `d` column with the reference's final ordering (`ORDER BY order_rank ASC NULLS LAST, last_modified DESC`,
+    pql/model.rs:547-553) — on tie-heavy int8 L2 data, where the tie-break decides who is on the page at all."""
+    import panoptikon_amd as pvs
+    from panoptikon_amd import sqlite_seam
+
+    rng = np.random.default_rng(21)
+    dim, distinct, copies, k = 64, 50, 60, 75
+    base = orc.synth_rows(31, 0, distinct, dim)
+    rows = np.tile(base, (copies, 1))[rng.permutation(distinct * copies)]
+    n = len(rows)
+    ids = np.arange(1, n + 1, dtype=np.int64) * 3
+    mtime = rng.integers(0, 25, n).astype(np.int64) + 1_700_000_000
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids)
+    ix.set_order_keys(mtime)
+    conn = sqlite3.connect(":memory:")
+    conn.execute("CREATE TABLE files (id INTEGER PRIMARY KEY, last_modified INTEGER NOT NULL)")
+    conn.executemany("INSERT INTO files VALUES (?, ?)", list(zip(ids.tolist(), mtime.tolist())))
+    sqlite_seam.load(conn)
+    sqlite_seam.bind("ties", ix)
+    try:
+        for qi in (0, 17, 49):
+            q = (base[qi] + 0.01 * orc.synth_rows(32, qi, 1, dim)[0]).astype(np.float32)
+            sql = """SELECT p.id, p.d FROM pvs_dist('ties', ?, 'l2') p JOIN files f ON f.id = p.id
+                     ORDER BY p.d ASC NULLS LAST, f.last_modified DESC, p.id LIMIT ?"""
+            want = conn.execute(sql, (q.tobytes(), k)).fetchall()
+            gi, gd, gc = ix.search(q, k, pvs.L2)
+            assert gc[0] == k and gi[0, :k].tolist() == [w[0] for w in want]
+            assert [np.float32(w[1]) for w in want] == gd[0, :k].tolist()
+            assert len({w[1] for w in want}) < 4, "the page must consist of ties"
+    finally:
+        sqlite_seam.unbind("ties")
+        ix.close()
