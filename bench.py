@@ -225,6 +225,8 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
     if not args.no_verify:
         # oracle, literally: every row of this rank scored on the CPU, MIN per file; then (N = 1) the whole composition, or (N > 1) the
         # exact global window ranks of the returned files by counting, summed over ranks
+        import oracle as orc  # (the checker: verification leg only)
+
         t_or = time.time()
         gq = queries[(args.warmup + args.steps - 1) % NQ]
         cols = []
