@@ -170,6 +170,7 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
     if rank == 0:
         print(f"[bench] configs[4]: 2 x {N} rows ({files} files x2 branches), this rank holds rows [{r0}, {r1}) of each, built in "
               f"{time.time() - t_build:.1f}s", file=sys.stderr, flush=True)
+    comm4 = make_comm(lib, L, ctl, world, rank, device, args.allow_host_gather, lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if world > 1 else None
     NQ = 8
     queries = []  # [query][branch] f32 vectors from the device generator (pvs_synth_rows_f32), as every other config's
     for i in range(NQ):
@@ -186,7 +187,9 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
                for j, b in enumerate(branches)]
         if world == 1:
             return pvs.rrf_search(brs, K)
-        return pvs.rrf_search_sharded(brs, K, ctl)
+        if comm4 is not None:
+            return pvs.rrf_search_sharded(brs, K, comm=comm4)  # pvs_rrf_search_sharded over RCCL: the round loop and its exchange inside libpvs
+        return pvs.rrf_search_sharded(brs, K, gather=ctl)
 
     for i in range(args.warmup):
         step(i)
@@ -214,7 +217,8 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
         "config": {"workload": f"{N}x512 + {N}x1024 i8 indexes (~{per_file} vectors per file), PQL or-composition of an image (cosine) and a "
                                f"text (L2) filter, MIN per file, row_n + RRF (5/1.0, 10/0.7), k={K} (BASELINE configs[4])",
                    "rows": 2 * N, "batch": 1, "k": K, "parallelism": f"shard by file x{world}", "exchange": "single-gpu" if world == 1 else
-                   "control-socket all-gather of candidate (id, key) pairs and counts (a few thousand per round)"},
+                   ("pvs_rrf_search_sharded over RCCL (ncclAllGather of the padded pages, ncclAllReduce min / sum of thresholds and counts)" if comm4 is not None
+                    else "pvs_rrf_search_sharded with the control socket as its all-gather (--allow-host-gather)")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": None, "kernel": "k_scan MODE 2 (exact int8 distances of every row, matrix core)", "launches": int(sum(p.scan_launches for p in profs)),
                      "avg_launch_ms": round(sum(p.scan_ms for p in profs) / max(sum(p.scan_launches for p in profs), 1), 4),
@@ -354,6 +358,40 @@ def launch_ranks(n: int) -> int:
     return 0
 
 
+def make_comm(lib, L, ctl, world, rank, device, allow_host_gather, log):
+    """The RCCL communicator of this run, or None (with --allow-host-gather: the control socket stands in).  Every rank walks the
+    same sequence of control-plane collectives whatever fails locally, and the ranks agree on whether the in-library RCCL path is
+    usable: a rank that gave up alone would leave the others waiting in an all-gather."""
+    idb, ok, err = bytes(L.UNIQUE_ID_BYTES), 1.0, ""
+    if rank == 0:
+        try:
+            buf = (L.C.c_uint8 * L.UNIQUE_ID_BYTES)()
+            L.check(lib.pvs_comm_unique_id(buf))
+            idb = bytes(buf)
+        except Exception as e:  # noqa: BLE001
+            ok, err = 0.0, str(e)
+    idb = ctl.bcast_bytes(idb)
+    ok = ctl.min_float(ok)
+    h = None
+    if ok > 0:
+        try:
+            h = L.C.c_void_p()
+            idarr = (L.C.c_uint8 * L.UNIQUE_ID_BYTES).from_buffer_copy(idb)
+            L.check(lib.pvs_comm_create(idarr, world, rank, device, L.C.byref(h)))
+        except Exception as e:  # noqa: BLE001
+            ok, err, h = 0.0, str(e), None
+        ok = ctl.min_float(ok)
+    if ok > 0:
+        return h
+    if h is not None:
+        lib.pvs_comm_destroy(h)
+    errs = [e.decode() for e in ctl.allgather_bytes(err.encode())]
+    if not allow_host_gather:
+        raise SystemExit(f"RCCL communicator could not be created on every rank: {[e for e in errs if e]}")
+    log(f"in-library RCCL unavailable ({[e for e in errs if e]}); --allow-host-gather: pages go over the control socket")
+    return None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
@@ -427,8 +465,9 @@ def main():
             out = L.C.c_float()
             L.check(lib.pvs_absmax(stage.ptr, m * D, L.DEVICE, device, L.C.byref(out)))
             amax = max(amax, float(out.value))
-        amax = ctl.max_float(amax)  # one scale per embedding space, global over all shards
-        scale = pvs.scale_from_absmax(amax)
+        local_amax = amax
+        amax = ctl.max_float(amax)  # one scale per embedding space, global over all shards (the RCCL communicator does not exist
+        scale = pvs.scale_from_absmax(amax)  # yet: it is created after the build; pvs_comm_allreduce_max_f32 cross-checks below)
     ix = pvs.VectorIndex(dtype, D, device=device, capacity_rows=n_local, id_base=r0, devices=devices)
     if scale is not None:
         ix.set_scale(scale)
@@ -462,39 +501,13 @@ def main():
     comm = None
     gather_mode = "peer-copy (one process, multi-device index)" if single else "single-gpu"
     if world > 1 or args.force_comm:
-        # Every rank walks the same sequence of control-plane collectives whatever fails locally, and the ranks agree
-        # on whether the in-library RCCL path is usable: a rank that gave up alone would leave the others waiting
-        # in an all-gather.
-        idb, ok, err = bytes(L.UNIQUE_ID_BYTES), 1.0, ""
-        if rank == 0:
-            try:
-                buf = (L.C.c_uint8 * L.UNIQUE_ID_BYTES)()
-                L.check(lib.pvs_comm_unique_id(buf))
-                idb = bytes(buf)
-            except Exception as e:  # noqa: BLE001
-                ok, err = 0.0, str(e)
-        idb = ctl.bcast_bytes(idb)
-        ok = ctl.min_float(ok)
-        h = None
-        if ok > 0:
-            try:
-                h = L.C.c_void_p()
-                idarr = (L.C.c_uint8 * L.UNIQUE_ID_BYTES).from_buffer_copy(idb)
-                L.check(lib.pvs_comm_create(idarr, world, rank, device, L.C.byref(h)))
-            except Exception as e:  # noqa: BLE001
-                ok, err, h = 0.0, str(e), None
-            ok = ctl.min_float(ok)
-        if ok > 0:
-            comm = h
-            gather_mode = "rccl-allgather"
-        else:
-            if h is not None:
-                lib.pvs_comm_destroy(h)
-            errs = [e.decode() for e in ctl.allgather_bytes(err.encode())]
-            if not args.allow_host_gather:
-                raise SystemExit(f"RCCL communicator could not be created on every rank: {[e for e in errs if e]}")
-            log(f"in-library RCCL unavailable ({[e for e in errs if e]}); --allow-host-gather: pages go over the control socket")
-            gather_mode = "ctl-host-gather"
+        comm = make_comm(lib, L, ctl, world, rank, device, args.allow_host_gather, log)
+        gather_mode = "rccl-allgather" if comm is not None else "ctl-host-gather"
+        if comm is not None and args.dtype == "i8":  # the space's absmax once more, by ncclAllReduce(max) over xGMI: must agree bit for bit
+            v = L.C.c_float(local_amax)
+            L.check(lib.pvs_comm_allreduce_max_f32(comm, L.C.byref(v)))
+            if np.float32(v.value) != np.float32(amax):
+                raise SystemExit(f"rank {rank}: ncclAllReduce(max) of the shard absmax gave {v.value}, the control plane {amax}")
 
     pending = []
 

@@ -407,6 +407,19 @@ pvs_status pvs_rrf_cols_lookup(pvs_rrf_cols *cols, const int64_t *gids, uint32_t
 /* candidates strictly increasing in (key, group id): out_below[j] = groups of this shard strictly before candidate j */
 pvs_status pvs_rrf_cols_count_below(pvs_rrf_cols *cols, const uint64_t *keys, const int64_t *gids, uint32_t m, uint64_t *out_below);
 
+/* The same page for branches sharded BY GROUP over several ranks (every row of a group on one rank; BASELINE configs[4] on 8
+ * GPUs): the whole round loop of that protocol behind one call.  Collective: every rank calls it with its shard of each branch
+ * (same order, same k, rrf_k, weight, direction) and gets the same page — the reference's, bit for bit.  The exchange runs over
+ * RCCL when `comm` is given (ncclAllGather of the padded pages, ncclAllReduce min / sum of thresholds and counts; `world` and
+ * `gather` are ignored), otherwise through `gather` — the host's own all-gather of `bytes` bytes per rank into recv[world][bytes],
+ * returning 0 on success — for hosts on another transport (and for ranks that share one GPU, which RCCL refuses).  world = 1
+ * needs neither.  RRF weights and k must be non-negative (the bound on the groups outside the pages needs it). */
+typedef struct pvs_comm pvs_comm; /* a communicator of the multi-GPU section below */
+typedef int32_t (*pvs_allgather_fn)(void *ctx, const void *send, void *recv, uint64_t bytes);
+pvs_status pvs_rrf_search_sharded(const pvs_rrf_branch *branches, uint32_t n_branches, uint32_t k, pvs_comm *comm, uint32_t world,
+                                  pvs_allgather_fn gather, void *gather_ctx, int64_t *out_groups, double *out_scores,
+                                  uint32_t *out_count);
+
 /* Which way the last pvs_rrf_search of this thread went: 1 = bounded fusion (pages of each branch's ranking + exact ranks of
  * the candidates; the usual case), 2 = every group of every branch ranked (small inputs, negative weights, massive ties). */
 int32_t pvs_rrf_last_path(void);
@@ -475,13 +488,15 @@ pvs_status pvs_resolve_vector_quant(pvs_index_mode index, const char *variant, i
                                     size_t query_quant_cap, pvs_quant_resolved *out);
 
 /* ------------------------------------------------------------- multi-GPU (RCCL) */
-typedef struct pvs_comm pvs_comm;
 #define PVS_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id and ships the 128 bytes to the other ranks out of band */
 pvs_status pvs_comm_unique_id(uint8_t id[PVS_UNIQUE_ID_BYTES]);
 pvs_status pvs_comm_create(const uint8_t id[PVS_UNIQUE_ID_BYTES], int32_t world, int32_t rank,
                            int32_t device, pvs_comm **out);
 void pvs_comm_destroy(pvs_comm *comm);
+/* max over the ranks of one float per rank (ncclAllReduce): the absmax of a sharded space from the absmax of every shard —
+ * compute_int8_scale_artifact (db/vector_quants.rs:1513-1554) over rows that no single rank holds.  Collective: every rank calls. */
+pvs_status pvs_comm_allreduce_max_f32(pvs_comm *comm, float *inout);
 /* Row-sharded search: idx holds this rank's shard (its row ids are global).
  * Each rank scores its shard, one ncclAllGather moves the per-shard top-k
  * (batch*k*(f32,i64)) over xGMI, every rank merges.  Outputs are device buffers

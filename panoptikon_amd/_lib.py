@@ -119,6 +119,7 @@ SYMBOLS = {
     "pvs_device_mem_info": (_i32, [_i32, _vp, _vp]),
     "pvs_rrf_search": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),
     "pvs_rrf_last_path": (_i32, []),
+    "pvs_rrf_search_sharded": (_i32, [C.POINTER(RrfBranch), _u32, _u32, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "pvs_rrf_cols_create": (_i32, [C.POINTER(RrfBranch), C.POINTER(_vp)]),
     "pvs_rrf_cols_destroy": (None, [_vp]),
     "pvs_rrf_cols_groups": (_i32, [_vp, C.POINTER(_u64)]),
@@ -144,6 +145,7 @@ SYMBOLS = {
                                         C.POINTER(QuantResolved)]),
     "pvs_comm_unique_id": (_i32, [_vp]),
     "pvs_comm_create": (_i32, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "pvs_comm_allreduce_max_f32": (_i32, [_vp, C.POINTER(C.c_float)]),
     "pvs_comm_destroy": (None, [_vp]),
     "pvs_search_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp]),
     "pvs_search_sharded_async": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),

@@ -41,6 +41,7 @@ SOURCES = [
     "pvs_select.hip",
     "pvs_groups.hip",
     "pvs_rrf.hip",
+    "pvs_rrf_sharded.hip",
     "pvs_comm.hip",
     "pvs_multi.hip",
     "pvs_microbench.hip",

@@ -291,13 +291,8 @@ void ctx_release(SearchCtx &c) {
     pvs_dense_release(c.dense);
     pvs_group_work_release(c.gwork);
     if (c.done) hipEventDestroy(c.done);
-    hipFree(c.d_loc_ids);
-    hipFree(c.d_all_ids);
-    hipFree(c.d_loc_dist);
-    hipFree(c.d_all_dist);
-    hipFree(c.d_loc_cnt);
-    hipFree(c.d_all_cnt);
-    hipFree(c.d_all_flags);
+    hipFree(c.d_loc_rec);
+    hipFree(c.d_all_rec);
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
     if (c.own_stream) hipStreamDestroy(c.own_stream);
     c = SearchCtx();

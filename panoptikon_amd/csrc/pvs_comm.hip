@@ -1,5 +1,5 @@
 // pvs_comm.hip — multi-GPU: one process per GPU, the corpus row-sharded across ranks,
-// per-shard pages exchanged by ONE RCCL all-gather over xGMI and merged on every rank
+// per-shard pages exchanged by ONE RCCL all-gather (one packed record per rank) over xGMI and merged on every rank
 // (SURVEY.md §8e).  The reference has no distributed code at all; this is the build's
 // only collective.  The payload is tiny (batch*k*16 B per rank, <= 410 KB at 256x100), so
 // the step is latency-bound, not the per-link 153 GB/s ring bound.
@@ -18,6 +18,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,6 +49,7 @@ pvs_status load_rccl() {
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllGather, "ncclAllGather");
+    SYM(AllReduce, "ncclAllReduce");
     SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
@@ -115,26 +117,65 @@ PVS_EXPORT void pvs_comm_destroy(pvs_comm *c) {
 // ---- internal interface used by pvs_api.hip (stream-ordered sharded search)
 int pvs_comm_world_(pvs_comm *c) { return c->world; }
 int pvs_comm_device_(pvs_comm *c) { return c->device; }
-// one grouped all-gather of (ids i64, dist f32, counts u32, flags u32) on `s`
-pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *dist, const uint32_t *cnt, const uint32_t *flags,
-                                  int64_t *all_ids, float *all_dist, uint32_t *all_cnt, uint32_t *all_flags, uint64_t elems,
-                                  uint32_t batch, hipStream_t s) {
-    NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllGather(ids, all_ids, elems, ncclInt64, c->comm, s));
-    NCCL_TRY(g_rccl.AllGather(dist, all_dist, elems, ncclFloat32, c->comm, s));
-    NCCL_TRY(g_rccl.AllGather(cnt, all_cnt, batch, ncclUint32, c->comm, s));
-    NCCL_TRY(g_rccl.AllGather(flags, all_flags, batch, ncclUint32, c->comm, s));
-    NCCL_TRY(g_rccl.GroupEnd());
+// ONE all-gather of every rank's packed record (row pages: pvs_page_record_*; per-item pages: groups | values | counts) on `s`
+pvs_status pvs_comm_gather_records_(pvs_comm *c, const void *rec, void *all_rec, size_t rec_bytes, hipStream_t s) {
+    NCCL_TRY(g_rccl.AllGather(rec, all_rec, rec_bytes, ncclInt8, c->comm, s));
+    return PVS_OK;
+}
+// max over the ranks of one float per rank, in place on the device (the int8 scale of a sharded space: absmax of the shards)
+pvs_status pvs_comm_allreduce_max_(pvs_comm *c, float *d_inout, uint64_t n, hipStream_t s) {
+    NCCL_TRY(g_rccl.AllReduce(d_inout, d_inout, n, ncclFloat32, ncclMax, c->comm, s));
     return PVS_OK;
 }
 
-// (group id i64, value f64, count u32) pages of a per-item search
-pvs_status pvs_comm_gather_group_pages_(pvs_comm *c, const int64_t *groups, const double *values, const uint32_t *cnt, int64_t *all_groups,
-                                        double *all_values, uint32_t *all_cnt, uint64_t elems, uint32_t batch, hipStream_t s) {
-    NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.AllGather(groups, all_groups, elems, ncclInt64, c->comm, s));
-    NCCL_TRY(g_rccl.AllGather(values, all_values, elems, ncclFloat64, c->comm, s));
-    NCCL_TRY(g_rccl.AllGather(cnt, all_cnt, batch, ncclUint32, c->comm, s));
-    NCCL_TRY(g_rccl.GroupEnd());
-    return PVS_OK;
+// ---- host-buffer collectives for the small control messages of the sharded fusion (pvs_rrf_sharded.hip): staged through the
+// scratch cache, on the null stream, synchronous
+pvs_status pvs_comm_allgather_host_(pvs_comm *c, const void *send, void *recv, size_t bytes) {
+    if (bytes == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t *d = nullptr;
+    HIP_TRY(pvs_scratch_alloc((void **)&d, bytes * (size_t)(c->world + 1)));
+    pvs_status st = PVS_OK;
+    hipError_t e = hipMemcpy(d, send, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        st = pvs_comm_gather_records_(c, d, d + bytes, bytes, nullptr);
+        if (st == PVS_OK) e = hipMemcpy(recv, d + bytes, bytes * (size_t)c->world, hipMemcpyDeviceToHost);
+    }
+    pvs_scratch_free_on(d, nullptr);
+    if (st == PVS_OK && e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "all-gather staging: %s", hipGetErrorString(e));
+    return st;
+}
+pvs_status pvs_comm_allreduce_u64_host_(pvs_comm *c, uint64_t *inout, size_t n, int op) {
+    if (n == 0) return PVS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint64_t *d = nullptr;
+    HIP_TRY(pvs_scratch_alloc((void **)&d, n * 8));
+    pvs_status st = PVS_OK;
+    hipError_t e = hipMemcpy(d, inout, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ncclResult_t r = g_rccl.AllReduce(d, d, n, ncclUint64, op == 0 ? ncclMin : ncclSum, c->comm, nullptr);
+        if (r != ncclSuccess) st = pvs_fail(PVS_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        if (st == PVS_OK) e = hipMemcpy(inout, d, n * 8, hipMemcpyDeviceToHost);
+    }
+    pvs_scratch_free_on(d, nullptr);
+    if (st == PVS_OK && e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "all-reduce staging: %s", hipGetErrorString(e));
+    return st;
+}
+
+// ---- C ABI: the max over the ranks of a host float (compute_int8_scale_artifact over a sharded space: every rank passes the
+// absmax of its shard, db/vector_quants.rs:1513-1554, and gets the space's)
+PVS_EXPORT pvs_status pvs_comm_allreduce_max_f32(pvs_comm *c, float *inout) {
+    if (!c || !inout) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    float *d = nullptr;
+    HIP_TRY(pvs_scratch_alloc((void **)&d, 4));
+    pvs_status st = PVS_OK;
+    hipError_t e = hipMemcpy(d, inout, 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        st = pvs_comm_allreduce_max_(c, d, 1, nullptr);
+        if (st == PVS_OK) e = hipMemcpy(inout, d, 4, hipMemcpyDeviceToHost);  // (synchronises with the null stream's collective)
+    }
+    pvs_scratch_free_on(d, nullptr);
+    if (st == PVS_OK && e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "allreduce max: %s", hipGetErrorString(e));
+    return st;
 }

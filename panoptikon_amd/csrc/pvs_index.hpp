@@ -69,12 +69,15 @@ struct SearchCtx {
     bool p_fast = false;
     // sharded search: this rank's page, the gathered pages and flags
     pvs_comm *p_comm = nullptr;
-    int64_t *d_loc_ids = nullptr, *d_all_ids = nullptr;
-    float *d_loc_dist = nullptr, *d_all_dist = nullptr;
-    uint32_t *d_loc_cnt = nullptr, *d_all_cnt = nullptr, *d_all_flags = nullptr, *h_all_flags = nullptr;
-    uint64_t sh_elems = 0, loc_elems = 0;
-    uint32_t loc_batch = 0;
-    uint32_t sh_batch = 0, sh_world = 0;
+    // this rank's page is ONE record [ids | dist | counts | flags] (pvs_page_record_*: the exchange is a single all-gather);
+    // d_loc_ids / d_loc_dist / d_loc_cnt are views into it for the current (batch, k)
+    uint8_t *d_loc_rec = nullptr, *d_all_rec = nullptr;
+    size_t loc_rec_cap = 0, all_rec_cap = 0, rec_bytes = 0;
+    int64_t *d_loc_ids = nullptr;
+    float *d_loc_dist = nullptr;
+    uint32_t *d_loc_cnt = nullptr, *h_all_flags = nullptr;
+    size_t h_all_flags_cap = 0;
+    uint32_t sh_world = 0;
     int64_t *p_final_ids = nullptr;
     float *p_final_dist = nullptr;
     uint32_t *p_final_count = nullptr;
@@ -83,9 +86,8 @@ struct SearchCtx {
 struct pvs_comm;
 int pvs_comm_world_(pvs_comm *c);
 int pvs_comm_device_(pvs_comm *c);
-pvs_status pvs_comm_gather_pages_(pvs_comm *c, const int64_t *ids, const float *dist, const uint32_t *cnt, const uint32_t *flags,
-                                  int64_t *all_ids, float *all_dist, uint32_t *all_cnt, uint32_t *all_flags, uint64_t elems,
-                                  uint32_t batch, hipStream_t s);
+pvs_status pvs_comm_gather_records_(pvs_comm *c, const void *rec, void *all_rec, size_t rec_bytes, hipStream_t s);  // ONE all-gather, rec_bytes per rank
+pvs_status pvs_comm_allreduce_max_(pvs_comm *c, float *d_inout, uint64_t n, hipStream_t s);
 
 constexpr uint32_t GMAX = 16384;  // group minima per query (pass A grid * RT * 32 <= GMAX)
 constexpr uint32_t NCTX = 16;  // searches in flight per index = the reference's read pool (db/connection.rs:235)
@@ -228,7 +230,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
                           int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast);
 pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
                             int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
-pvs_status ctx_reserve_local_pages(SearchCtx &c, uint64_t elems, uint32_t batch);
+pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
 // d_out[row * nb + q]: exact distances of the nb queries prepared in ctx c (prep_chunk) — matrix cores for int8, k_dense_exact otherwise
@@ -255,5 +257,3 @@ pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, p
 pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count);
 // ---- pvs_comm.hip
-pvs_status pvs_comm_gather_group_pages_(pvs_comm *c, const int64_t *groups, const double *values, const uint32_t *cnt, int64_t *all_groups,
-                                        double *all_values, uint32_t *all_cnt, uint64_t elems, uint32_t batch, hipStream_t s);

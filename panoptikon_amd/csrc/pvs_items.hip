@@ -376,29 +376,30 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t world = (uint32_t)pvs_comm_world_(comm);
     const uint64_t elems = (uint64_t)batch * k;
-    int64_t *d_g = nullptr, *d_ag = nullptr;
-    double *d_v = nullptr, *d_av = nullptr;
-    uint32_t *d_c = nullptr, *d_ac = nullptr;
+    // this rank's page as ONE record [groups i64 | values f64 | counts u32] (16-byte padded): the exchange is a single all-gather
+    const size_t off_v = elems * 8, off_c = elems * 16, rec = (elems * 16 + (size_t)batch * 4 + 15) / 16 * 16;
+    uint8_t *d_rec = nullptr, *d_all = nullptr;
+    std::vector<uint8_t> h_rec(rec, 0), h_all(rec * world);
+    memcpy(h_rec.data(), lg.data(), elems * 8);
+    memcpy(h_rec.data() + off_v, lv.data(), elems * 8);
+    memcpy(h_rec.data() + off_c, lc.data(), (size_t)batch * 4);
     std::vector<int64_t> ag((size_t)world * elems);
     std::vector<double> av((size_t)world * elems);
     std::vector<uint32_t> ac((size_t)world * batch);
     auto body = [&]() -> pvs_status {
-        HIP_TRY(pvs_scratch_alloc((void **)&d_g, elems * 8));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_v, elems * 8));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_c, (size_t)batch * 4));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_ag, elems * 8 * world));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_av, elems * 8 * world));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_ac, (size_t)batch * 4 * world));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_rec, rec));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_all, rec * world));
         hipStream_t s = ix->comm_stream;  // every collective of this index goes out on this one stream
-        HIP_TRY(hipMemcpyAsync(d_g, lg.data(), elems * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_v, lv.data(), elems * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_c, lc.data(), (size_t)batch * 4, hipMemcpyHostToDevice, s));
-        // 2. one grouped all-gather over xGMI
-        PVS_TRY(pvs_comm_gather_group_pages_(comm, d_g, d_v, d_c, d_ag, d_av, d_ac, elems, batch, s));
-        HIP_TRY(hipMemcpyAsync(ag.data(), d_ag, ag.size() * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(av.data(), d_av, av.size() * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ac.data(), d_ac, ac.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d_rec, h_rec.data(), rec, hipMemcpyHostToDevice, s));
+        // 2. one all-gather over xGMI
+        PVS_TRY(pvs_comm_gather_records_(comm, d_rec, d_all, rec, s));
+        HIP_TRY(hipMemcpyAsync(h_all.data(), d_all, rec * world, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t w = 0; w < world; w++) {
+            memcpy(ag.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec, elems * 8);
+            memcpy(av.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec + off_v, elems * 8);
+            memcpy(ac.data() + (size_t)w * batch, h_all.data() + (size_t)w * rec + off_c, (size_t)batch * 4);
+        }
         if (local_st != PVS_OK) return pvs_fail(local_st, "%s", local_err.c_str());
         for (uint32_t w = 0; w < world; w++)
             if (ac[(size_t)w * batch] == PVS_PAGE_FAILED) return pvs_fail(PVS_ERR_COMM, "rank %u failed its shard of the per-item search", w);
@@ -406,7 +407,7 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
     };
     pvs_status st = body();
-    for (void *p : {(void *)d_g, (void *)d_v, (void *)d_c, (void *)d_ag, (void *)d_av, (void *)d_ac}) pvs_scratch_free_on(p, ix->comm_stream);  // (cached blocks: no hipFree, which would synchronise the device; an early error may have left work queued)
+    for (void *p : {(void *)d_rec, (void *)d_all}) pvs_scratch_free_on(p, ix->comm_stream);  // (an early error may have left work queued)
     return st;
 }
 

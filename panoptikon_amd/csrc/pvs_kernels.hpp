@@ -157,6 +157,14 @@ pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq,
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
                             uint32_t *out_count, hipStream_t s);
+// A rank's page as ONE buffer, so that the shard exchange is one all-gather: [ids i64 x batch*k | dist f32 x batch*k |
+// counts u32 x batch | flags u32 x batch], padded to 16 bytes.
+inline size_t pvs_page_record_off_dist(uint32_t batch, uint32_t k) { return (size_t)batch * k * 8; }
+inline size_t pvs_page_record_off_cnt(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12; }
+inline size_t pvs_page_record_off_flags(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12 + (size_t)batch * 4; }
+inline size_t pvs_page_record_bytes(uint32_t batch, uint32_t k) { return ((size_t)batch * k * 12 + (size_t)batch * 8 + 15) / 16 * 16; }
+hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
+                                   float *out_dist, uint32_t *out_count, hipStream_t s);
 
 // ---- per-item aggregation and ranking (pvs_groups.hip)
 struct GroupWork {

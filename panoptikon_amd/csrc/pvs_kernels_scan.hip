@@ -659,26 +659,36 @@ __device__ static inline bool page_less(float da, int64_t ia, float db, int64_t 
     if (ka != kb) return ka < kb;
     return ia < ib;
 }
-__global__ __launch_bounds__(256) void k_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
-                                               uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+// The pages of `world` shards, either as three arrays [world][batch][k] / [world][batch] (one process, several GPUs: peer copies)
+// or as `world` packed records [ids | dist | counts | flags] of `rec` bytes each (one RCCL all-gather of one buffer per rank).
+struct MergePages {
+    const uint8_t *ids, *dist, *cnt;   // rank 0's arrays
+    size_t stride_ids, stride_dist, stride_cnt;  // bytes from one rank's array to the next
+    __device__ const int64_t *ids_of(uint32_t w) const { return (const int64_t *)(ids + (size_t)w * stride_ids); }
+    __device__ const float *dist_of(uint32_t w) const { return (const float *)(dist + (size_t)w * stride_dist); }
+    __device__ const uint32_t *cnt_of(uint32_t w) const { return (const uint32_t *)(cnt + (size_t)w * stride_cnt); }
+};
+__global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
+                                               uint32_t *out_count) {
     const uint32_t q = blockIdx.x;
     uint32_t total = 0;
-    for (uint32_t w = 0; w < world; w++) total += counts[(size_t)w * batch + q];
+    for (uint32_t w = 0; w < world; w++) total += pg.cnt_of(w)[q];
     const uint32_t nout = total < k ? total : k;
     for (uint32_t e = threadIdx.x; e < world * k; e += 256) {
         const uint32_t w = e / k, p = e % k;
-        if (p >= counts[(size_t)w * batch + q]) continue;
-        const size_t off = ((size_t)w * batch + q) * k;
-        const float d = dist[off + p];
-        const int64_t id = ids[off + p];
+        if (p >= pg.cnt_of(w)[q]) continue;
+        const size_t off = (size_t)q * k;
+        const float d = pg.dist_of(w)[off + p];
+        const int64_t id = pg.ids_of(w)[off + p];
         uint32_t rank = p;
         for (uint32_t w2 = 0; w2 < world; w2++) {
             if (w2 == w) continue;
-            const size_t o2 = ((size_t)w2 * batch + q) * k;
-            uint32_t lo = 0, hi = counts[(size_t)w2 * batch + q];
+            const int64_t *i2 = pg.ids_of(w2) + off;
+            const float *d2 = pg.dist_of(w2) + off;
+            uint32_t lo = 0, hi = pg.cnt_of(w2)[q];
             while (lo < hi) {  // first entry of shard w2 that does not precede (d, id)
                 const uint32_t mid = (lo + hi) >> 1;
-                if (page_less(dist[o2 + mid], ids[o2 + mid], d, id)) lo = mid + 1;
+                if (page_less(d2[mid], i2[mid], d, id)) lo = mid + 1;
                 else hi = mid;
             }
             rank += lo;
@@ -696,6 +706,24 @@ __global__ __launch_bounds__(256) void k_merge(const int64_t *ids, const float *
 }
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world, uint32_t batch,
                             uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, ids, dist, counts, world, batch, k, out_ids, out_dist, out_count);
+    MergePages pg;
+    pg.ids = (const uint8_t *)ids;
+    pg.dist = (const uint8_t *)dist;
+    pg.cnt = (const uint8_t *)counts;
+    pg.stride_ids = (size_t)batch * k * 8;
+    pg.stride_dist = (size_t)batch * k * 4;
+    pg.stride_cnt = (size_t)batch * 4;
+    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count);
+    return hipGetLastError();
+}
+// packed records (pvs_page_record_*): rank w's record starts at all_rec + w * rec_bytes
+hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
+                                   float *out_dist, uint32_t *out_count, hipStream_t s) {
+    MergePages pg;
+    pg.ids = all_rec;
+    pg.dist = all_rec + pvs_page_record_off_dist(batch, k);
+    pg.cnt = all_rec + pvs_page_record_off_cnt(batch, k);
+    pg.stride_ids = pg.stride_dist = pg.stride_cnt = rec_bytes;
+    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count);
     return hipGetLastError();
 }

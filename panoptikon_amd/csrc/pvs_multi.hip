@@ -114,7 +114,7 @@ pvs_status multi_enqueue(pvs_index *ix, MultiCtx &m, const void *d_queries, pvs_
         SearchCtx *c = ctx_acquire(sh, &t, true);  // never blocks: a shard serves multi searches only, one context each
         m.tickets.push_back(t);
         PVS_TRY(ctx_prepare(sh, *c, batch, k, false));
-        PVS_TRY(ctx_reserve_local_pages(*c, (uint64_t)batch * k, batch));
+        PVS_TRY(ctx_reserve_local_pages(*c, batch, k));
         const void *q_local = d_queries;
         if (sh->device != root) {  // replicate the queries on the shard's device (<= 0.8 MB at 256 x 768 f32)
             if (qbytes > m.q_cap[s]) {

@@ -745,6 +745,18 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
     return PVS_OK;
 }
 
+// The shard exchange of a row search: this rank's flags join its page record, ONE all-gather of the records over xGMI, the
+// merge on every rank, the gathered flags to the host (every rank sees the same flags and so agrees on a redo).  Stream-ordered.
+static pvs_status exchange_pages(SearchCtx &c, pvs_comm *comm, uint32_t batch, uint32_t k, uint32_t world, int64_t *d_out_ids, float *d_out_dist,
+                                 uint32_t *d_out_count, hipStream_t cs) {
+    const size_t off_flags = pvs_page_record_off_flags(batch, k);
+    HIP_TRY(hipMemcpyAsync(c.d_loc_rec + off_flags, c.d_need_dense, (size_t)batch * 4, hipMemcpyDeviceToDevice, cs));
+    PVS_TRY(pvs_comm_gather_records_(comm, c.d_loc_rec, c.d_all_rec, c.rec_bytes, cs));
+    HIP_TRY(pvs_launch_merge_packed(c.d_all_rec, c.rec_bytes, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
+    HIP_TRY(hipMemcpy2DAsync(c.h_all_flags, (size_t)batch * 4, c.d_all_rec + off_flags, c.rec_bytes, (size_t)batch * 4, world, hipMemcpyDeviceToHost, cs));
+    return PVS_OK;
+}
+
 PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     if (!ix || ticket >= NCTX) return pvs_fail(PVS_ERR_INVALID_ARG, "bad ticket");
     if (is_multi(ix)) return multi_wait(ix, ticket);
@@ -774,13 +786,9 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
                 hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
             }
-            if (st == PVS_OK)
-                st = pvs_comm_gather_pages_(c->p_comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids,
-                                            c->d_all_dist, c->d_all_cnt, c->d_all_flags, (uint64_t)c->p_batch * c->p_k, c->p_batch, cs);
+            if (st == PVS_OK) st = exchange_pages(*c, c->p_comm, c->p_batch, c->p_k, c->sh_world, c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
             if (st == PVS_OK) {
-                hipError_t e2 = pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, c->sh_world, c->p_batch, c->p_k,
-                                                 c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
-                if (e2 == hipSuccess) e2 = hipStreamSynchronize(cs);
+                hipError_t e2 = hipStreamSynchronize(cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "sharded redo: %s", hipGetErrorString(e2));
             }
         }
@@ -793,22 +801,21 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     return st;
 }
 
-// this context's own page buffers (a rank's / a shard's local result before the exchange)
-pvs_status ctx_reserve_local_pages(SearchCtx &c, uint64_t elems, uint32_t batch) {
-    if (elems <= c.loc_elems && batch <= c.loc_batch) return PVS_OK;
-    hipFree(c.d_loc_ids);
-    hipFree(c.d_loc_dist);
-    hipFree(c.d_loc_cnt);
-    c.d_loc_ids = nullptr;
-    c.d_loc_dist = nullptr;
-    c.d_loc_cnt = nullptr;
-    c.loc_elems = 0;
-    c.loc_batch = 0;
-    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_ids, elems * 8));
-    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_dist, elems * 4));
-    HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_cnt, (size_t)batch * 4));
-    c.loc_elems = elems;
-    c.loc_batch = batch;
+// this context's own page (a rank's / a shard's local result before the exchange): one record, its three views repointed for
+// the current (batch, k)
+pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k) {
+    const size_t need = pvs_page_record_bytes(batch, k);
+    if (need > c.loc_rec_cap) {
+        hipFree(c.d_loc_rec);
+        c.d_loc_rec = nullptr;
+        c.loc_rec_cap = 0;
+        HIP_TRY(pvs_malloc_retry((void **)&c.d_loc_rec, need));
+        c.loc_rec_cap = need;
+    }
+    c.rec_bytes = need;
+    c.d_loc_ids = (int64_t *)c.d_loc_rec;
+    c.d_loc_dist = (float *)(c.d_loc_rec + pvs_page_record_off_dist(batch, k));
+    c.d_loc_cnt = (uint32_t *)(c.d_loc_rec + pvs_page_record_off_cnt(batch, k));
     return PVS_OK;
 }
 
@@ -827,27 +834,22 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
     if (!c) return PVS_ERR_STATE;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
-        const uint64_t elems = (uint64_t)batch * k;
-        PVS_TRY(ctx_reserve_local_pages(*c, elems, batch));
-        if (elems > c->sh_elems || batch > c->sh_batch || world != c->sh_world) {
-            hipFree(c->d_all_ids);
-            hipFree(c->d_all_dist);
-            hipFree(c->d_all_cnt);
-            hipFree(c->d_all_flags);
-            if (c->h_all_flags) hipHostFree(c->h_all_flags);
-            c->d_all_ids = nullptr;
-            c->d_all_dist = nullptr;
-            c->d_all_cnt = c->d_all_flags = c->h_all_flags = nullptr;
-            c->sh_elems = 0;
-            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_ids, elems * 8 * world));
-            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_dist, elems * 4 * world));
-            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_cnt, (size_t)batch * 4 * world));
-            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_flags, (size_t)batch * 4 * world));
-            HIP_TRY(hipHostMalloc((void **)&c->h_all_flags, (size_t)batch * 4 * world, hipHostMallocDefault));
-            c->sh_elems = elems;
-            c->sh_batch = batch;
-            c->sh_world = world;
+        PVS_TRY(ctx_reserve_local_pages(*c, batch, k));
+        if (c->rec_bytes * world > c->all_rec_cap) {
+            hipFree(c->d_all_rec);
+            c->d_all_rec = nullptr;
+            c->all_rec_cap = 0;
+            HIP_TRY(pvs_malloc_retry((void **)&c->d_all_rec, c->rec_bytes * world));
+            c->all_rec_cap = c->rec_bytes * world;
         }
+        if ((size_t)batch * world > c->h_all_flags_cap) {
+            if (c->h_all_flags) hipHostFree(c->h_all_flags);
+            c->h_all_flags = nullptr;
+            c->h_all_flags_cap = 0;
+            HIP_TRY(hipHostMalloc((void **)&c->h_all_flags, (size_t)batch * 4 * world, hipHostMallocDefault));
+            c->h_all_flags_cap = (size_t)batch * world;
+        }
+        c->sh_world = world;
         bool fast = false;
         // 1. this shard's page (row ids in the index are global ids)
         PVS_TRY(search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, &fast));
@@ -860,11 +862,8 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
         hipStream_t cs = ix->comm_stream;
         HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
         span_begin(ix, *c, 3, 0, cs);
-        PVS_TRY(pvs_comm_gather_pages_(comm, c->d_loc_ids, c->d_loc_dist, c->d_loc_cnt, c->d_need_dense, c->d_all_ids, c->d_all_dist,
-                                       c->d_all_cnt, c->d_all_flags, elems, batch, cs));
-        HIP_TRY(pvs_launch_merge(c->d_all_ids, c->d_all_dist, c->d_all_cnt, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
+        PVS_TRY(exchange_pages(*c, comm, batch, k, world, d_out_ids, d_out_dist, d_out_count, cs));
         span_end(ix, *c, cs);
-        HIP_TRY(hipMemcpyAsync(c->h_all_flags, c->d_all_flags, (size_t)batch * 4 * world, hipMemcpyDeviceToHost, cs));
         HIP_TRY(hipEventRecord(c->done, cs));
         {
             std::lock_guard<std::mutex> lk(ix->mu);

@@ -12,7 +12,7 @@ def per_launch(md, counter):
     """sum over the per-XCD/SE slices of one dispatch: avg per slice * slices / launches"""
     best = None
     for line in open(md):
-        m = re.match(r"\| `(_Z6k_scan\S*?ELi1EEv5ScanK\S*) grid=(\d+)` \| (\w+) \| (\d+) \| ([\d.e+]+) \| ([\d.e+]+) \|", line)
+        m = re.match(r"\| `(_Z\d+k_scan\w*?ELi1EEv5ScanK\S*) grid=(\d+)` \| (\w+) \| (\d+) \| ([\d.e+]+) \| ([\d.e+]+) \|", line)  # k_scan / k_scan_wide, MODE 1
         if m and m.group(3) == counter:
             total = float(m.group(6))
             if best is None or total > best[1]:

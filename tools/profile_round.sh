@@ -23,4 +23,4 @@ run pmc_WRITE_SIZE --kernel-trace --pmc WRITE_SIZE
 run pmc_SQ --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_MFMA
 python $R/tools/make_traffic.py $out/${tag}_pmc_FETCH_SIZE.md $out/${tag}_pmc_WRITE_SIZE.md $out/${tag}_kernel_stats.bench.json > $out/${tag}_traffic.json
 cat $out/${tag}_traffic.json
-grep "k_scan" $out/${tag}_kernel_stats.md | head -4
+grep "k_scan" $out/${tag}_kernel_stats.md | head -6
