@@ -169,7 +169,7 @@ def test_rccl_two_ranks_as_two_threads(pvs):
     exp = orc.search(orc.I8, orc.COSINE, codes, orc.quantize_int8(q, scale), k)
     uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
     L.check(pvs.lib().pvs_comm_unique_id(uid))
-    res, errs = [None] * world, []
+    res, errs, fused = [None] * world, [], [None] * world
 
     def rank_main(r):
         try:
@@ -184,6 +184,19 @@ def test_rccl_two_ranks_as_two_threads(pvs):
             for _ in range(3):
                 L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dq.ptr, L.F32, b, k, pvs.COSINE, oi.ptr, od.ptr, oc.ptr))
             res[r] = (oi.to_numpy(np.int64, (b, k)), od.to_numpy(np.float32, (b, k)), oc.to_numpy(np.uint32, (b,)))
+            # ncclAllReduce(max): the space's absmax from the shards'
+            v = C.c_float(float(np.abs(rows[r0:r1]).max()))
+            L.check(pvs.lib().pvs_comm_allreduce_max_f32(comm, C.byref(v)))
+            assert np.float32(v.value) == np.float32(np.abs(rows).max())
+            # the sharded OR/RRF round loop over the same communicator: rows sharded by group (3 rows per file), one branch
+            r0g = r0 - r0 % 3 if r == 0 else r0 + (-r0) % 3  # cut on a group boundary
+            r1g = r1 + (-r1) % 3 if r == 0 else r1
+            fx = pvs.VectorIndex(pvs.I8, dim, device=r, id_base=r0g)
+            fx.set_scale(scale)
+            fx.add_f32(rows[r0g:r1g], group_ids=np.arange(r0g, r1g, dtype=np.int64) // 3)
+            hq = orc.quantize_int8(q[:1], scale)[0]
+            fused[r] = pvs.rrf_search_sharded([dict(index=fx, query=hq, metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=5, weight=1.0)], 20, comm=comm)
+            fx.close()
             pvs.lib().pvs_comm_destroy(comm)
             ix.close()
         except Exception as e:  # noqa: BLE001
@@ -196,6 +209,48 @@ def test_rccl_two_ranks_as_two_threads(pvs):
     assert not errs, errs
     for r in range(world):
         assert np.array_equal(res[r][0], exp[0]) and np.array_equal(res[r][1].view(np.uint32), exp[1].view(np.uint32)), f"rank {r}"
+    eg, es = orc.rrf_search([dict(dtype=orc.I8, metric=orc.COSINE, corpus=codes, query=orc.quantize_int8(q[:1], scale)[0],
+                                  groups=np.arange(n, dtype=np.int64) // 3, agg=orc.AGG_MIN, rrf_k=5, weight=1.0)], 20)
+    for r in range(world):
+        assert np.array_equal(fused[r][0], eg) and np.array_equal(fused[r][1].view(np.uint64), es.view(np.uint64)), f"rank {r}: sharded fusion over RCCL"
+
+
+def test_rccl_one_rank_collectives_and_the_sharded_fusion_entry_point(pvs):
+    """What a one-GPU box can run of the RCCL-backed entry points: a 1-rank communicator through pvs_comm_allreduce_max_f32 and
+    pvs_rrf_search_sharded(comm) — the page must be pvs_rrf_search's, which the other tests pin against the oracle."""
+    from panoptikon_amd import _lib as L
+
+    dim, n = 96, 30_000
+    rows = orc.synth_rows(71, 0, n, dim)
+    grp = np.arange(n, dtype=np.int64) // 3
+    scale = orc.compute_int8_scale(rows)
+    uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+    L.check(pvs.lib().pvs_comm_unique_id(uid))
+    comm = C.c_void_p()
+    L.check(pvs.lib().pvs_comm_create(uid, 1, 0, 0, C.byref(comm)))
+    try:
+        v = C.c_float(1.25)
+        L.check(pvs.lib().pvs_comm_allreduce_max_f32(comm, C.byref(v)))
+        assert v.value == 1.25
+        ix = pvs.VectorIndex(pvs.I8, dim)
+        ix.set_scale(scale)
+        ix.add_f32(rows, group_ids=grp)
+        ix2 = pvs.VectorIndex(pvs.F16, dim)
+        ix2.add_f32(rows[::-1].copy(), group_ids=grp)
+        q = orc.synth_rows(72, 0, 1, dim)[0]
+        brs = [dict(index=ix, query=orc.quantize_int8(q[None, :], scale)[0], metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=5, weight=1.0),
+               dict(index=ix2, query=q, metric=pvs.L2, agg=pvs.AGG_AVG, rrf_k=10, weight=0.7)]
+        g1, s1 = pvs.rrf_search(brs, 50)
+        g2, s2 = pvs.rrf_search_sharded(brs, 50, comm=comm)
+        g3, s3 = pvs.rrf_search_sharded(brs, 50)  # world = 1 without a communicator
+        assert np.array_equal(g1, g2) and np.array_equal(s1.view(np.uint64), s2.view(np.uint64))
+        assert np.array_equal(g1, g3) and np.array_equal(s1.view(np.uint64), s3.view(np.uint64))
+        with pytest.raises(pvs.PvsError):
+            pvs.rrf_search_sharded([dict(brs[0], weight=-1.0)], 5, comm=comm)  # the bound needs non-negative weights
+        ix.close()
+        ix2.close()
+    finally:
+        pvs.lib().pvs_comm_destroy(comm)
 
 
 def test_in_flight_limit_is_an_error_not_a_hang(pvs):
