@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — k-NN queries/sec on the BASELINE.json headline workload.
 
-    python bench.py --gpus N --steps K --warmup W [--config 1|2|3]
+    python bench.py --gpus N --steps K --warmup W [--config 0|1|2|3|4]
 
 Default workload (BASELINE.json `metric`, configs[2]): 10,000,000 x 768 int8-quantized embeddings, batches of 128
 queries, cosine, k = 100.  One "step" = one batch of queries answered over the whole corpus (page 1 of the reference
@@ -43,6 +43,7 @@ SEED_QUERY = 0x5EED0000
 CFG4_ROWS = 25_000_000  # BASELINE configs[4]: 50M rows = a 512-d image-embedding index + a 1024-d text-embedding index (split assumed
                         # even), int8, ~3 vectors per file; the query is the PQL `or` of the two filters fused by RRF
 CONFIGS = {  # BASELINE.json configs[i] -> (rows, dim, dtype, batch, k, metric)
+    0: (10_000, 512, "f32", 1, 10, "cosine"),  # the reference's own CPU-runnable case (plumbing): the same shape on the device
     1: (1_000_000, 768, "f16", 32, 100, "cosine"),
     2: (10_000_000, 768, "i8", 128, 100, "cosine"),
     3: (100_000_000, 768, "i8", 256, 100, "cosine"),

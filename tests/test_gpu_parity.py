@@ -984,7 +984,8 @@ def test_full_size_properties(pvs, dtype, n, b):
     properties: pages sorted by (distance, id), ids unique and in range, full pages, two runs bit-identical, the
     filter path and the dense path (two different algorithms on the device) agree on a few queries, the page is a
     prefix of the k = 400 page, every returned distance equals the dense `d` column at that row, and row shards
-    merged with pvs_merge_topk reproduce the whole-corpus page."""
+    merged with pvs_merge_topk reproduce the whole-corpus page; for the int8 shapes the first and the last query of the batch
+    also against the CPU oracle over all 10M rows."""
     from panoptikon_amd import _lib as L
 
     lib = pvs.lib()
@@ -1022,6 +1023,20 @@ def test_full_size_properties(pvs, dtype, n, b):
         col = ix.score_all(q[0], metric)
         assert np.array_equal(col[gi[0]].view(np.uint32), gd[0].view(np.uint32))
         assert (col >= gd[0, -1]).sum() >= n - k  # nothing outside the page beats its last entry
+        if dt == pvs.I8 and metric == pvs.COSINE:
+            # the CPU oracle over the WHOLE corpus for the first and the last query of the batch (the last one lives in the last
+            # wave of the 128- / 256-query kernel): ids and int8 distances bit for bit
+            scale = ix.stats().scale
+            qc = orc.quantize_int8(q[[0, b - 1]], scale)
+            acc_i = [np.empty(0, np.int64), np.empty(0, np.int64)]
+            acc_d = [np.empty(0, np.float32), np.empty(0, np.float32)]
+            for off in range(0, n, 1_000_000):
+                slab = ix.read_rows(off, 1_000_000)
+                ci, cd = orc.search(orc.I8, orc.COSINE, slab, qc, k, ids=np.arange(off, off + 1_000_000, dtype=np.int64), threads=orc.max_threads())
+                for t in range(2):
+                    acc_i[t], acc_d[t] = orc.topk(np.concatenate([acc_d[t], cd[t]]), k, ids=np.concatenate([acc_i[t], ci[t]]))
+            for t, qi in enumerate((0, b - 1)):
+                assert np.array_equal(gi[qi], acc_i[t]) and np.array_equal(gd[qi].view(np.uint32), acc_d[t].view(np.uint32)), f"query {qi} vs the oracle over {n} rows"
     # row shards of the same corpus, merged: equals the whole-corpus page (ids are global row indexes)
     nq = min(16, b)
     gi, gd, gc = ix.search(q[:nq], k, pvs.COSINE)
