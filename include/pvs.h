@@ -102,16 +102,23 @@ typedef struct pvs_index_desc {
     uint64_t capacity_rows; /* rows to reserve up front, over all devices (0 = grow on demand) */
     int64_t id_base;        /* row id of row 0 when pvs_index_add is given row_ids == NULL */
     /* ABI v2 — one host process, several GPUs (the reference host is ONE process with a pool of read
-     * connections, db/connection.rs:320-357): the rows shard across `devices`; every pvs_index_add call
-     * splits its rows into n_devices contiguous pieces (ids stay increasing inside every shard), searches fan
-     * out to all shards, per-shard pages travel to devices[0] by peer copies over xGMI and are merged there
-     * (SURVEY.md §8e).  n_devices 0 or 1 = single device.  An ordinal may repeat (several shards on one GPU:
-     * used by the tests on one-GPU machines).  Served on a multi-device index: add, scale, stats, read back,
-     * pvs_search / pvs_search_device + pvs_wait, pvs_score_all, pvs_search_groups with MIN (a group may span
-     * shards: the minimum of the shard minima); the other per-item entry points (MAX / AVG / weights, masks,
-     * pvs_score_batch, pvs_similar_to, pvs_rrf_search) return PVS_ERR_UNSUPPORTED — they need every row of a
-     * group on one device.  A pvs_index_add that fails after some shards took their piece leaves the index
-     * unusable (PVS_ERR_STATE from every later call): destroy and rebuild it. */
+     * connections, db/connection.rs:320-357): the rows shard across `devices`, searches fan out to all shards,
+     * per-shard pages travel to devices[0] by peer copies over xGMI and are merged there.
+     * n_devices 0 or 1 = single device.  An ordinal may repeat (several shards on one GPU: used by the tests on
+     * one-GPU machines).  Row placement is decided by the first pvs_index_add:
+     *  - WITH group_ids (then every add must give them): BY GROUP — every row of a group lives on the shard
+     *    mix(group id) % n_devices, whatever call it arrives in.  Every entry point of a single-device index is
+     *    served and answers the same, bit for bit: pvs_search / pvs_search_device + pvs_wait, pvs_search_filtered,
+     *    pvs_score_all / pvs_score_batch (host outputs, global row order), pvs_search_groups[_filtered] with MIN /
+     *    MAX / AVG / row weights / candidate masks (row_weights and masks index the GLOBAL rows, in add order),
+     *    pvs_similar_to[_ex], pvs_rrf_search (every branch a multi-device index over the same number of devices),
+     *    read back, stats.  Device-space rows are staged through the host once (placement is a scatter);
+     *  - WITHOUT group_ids (then no add may give them): every add splits into n_devices contiguous pieces.  The
+     *    index holds no groups, so the per-item entry points fail as they do on a single-device index without
+     *    group ids; everything row-wise above is served.
+     * Not served on any multi-device index: pvs_index_set_order_keys, pvs_search_bounded with a lower bound, the
+     * `_sharded` (multi-process) entry points, pvs_rrf_cols.  A pvs_index_add that fails after some shards took
+     * their rows leaves the index unusable (PVS_ERR_STATE from every later call): destroy and rebuild it. */
     uint32_t n_devices;
     const int32_t *devices; /* [n_devices] HIP ordinals */
 } pvs_index_desc;

@@ -26,7 +26,7 @@ struct Kbn {
 //   fanout == 0: column q aggregates dist[row][q] over the group's rows (semantic search)
 //   fanout == M: a single output column aggregates dist[row][0..M) over rows and targets
 //                (similar_to), skipping rows flagged in `exclude`.
-//   fw.trows != nullptr (similar_to with confidence weights, item_similarity.rs:503-581): the pair weight
+//   fw.on (similar_to with confidence weights, item_similarity.rs:503-581): the pair weight
 //                w = pow(coalesce(conf_t,1)*coalesce(conf_o,1), cw) * pow(coalesce(lang_o,1)*coalesce(lang_t,1), lw)
 //                (a factor is dropped when its exponent is 0) and the value is SUM(d*w)/SUM(w).
 __device__ static inline double coalesce1(double v) { return v != v ? 1.0 : v; }
@@ -47,16 +47,15 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
             double w = 1.0;
-            if (fw.trows && fw.kind) {  // cross-modal gates: the pair is not part of the join at all
-                const uint8_t km = fw.kind[fw.trows[c]], ko = fw.kind[row];
+            if (fw.on && fw.kind) {  // cross-modal gates: the pair is not part of the join at all
+                const uint8_t km = fw.t_kind[c], ko = fw.kind[row];
                 if ((fw.skip_i2i && km == 0 && ko == 0) || (fw.skip_t2t && km == 1 && ko == 1)) continue;
             }
             joined++;
-            if (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)) {
-                const uint32_t t = fw.trows[c];
-                if (fw.cw != 0.0) w = pow(coalesce1(fw.conf[t]) * coalesce1(fw.conf[row]), fw.cw);
+            if (fw.on && (fw.cw != 0.0 || fw.lw != 0.0)) {
+                if (fw.cw != 0.0) w = pow(coalesce1(fw.t_conf[c]) * coalesce1(fw.conf[row]), fw.cw);
                 if (fw.lw != 0.0) {
-                    const double wl = pow(coalesce1(fw.lang[row]) * coalesce1(fw.lang[t]), fw.lw);
+                    const double wl = pow(coalesce1(fw.lang[row]) * coalesce1(fw.t_lang[c]), fw.lw);
                     w = fw.cw != 0.0 ? w * wl : wl;
                 }
                 wsum.step(w);  // SUM(w) runs over every joined pair
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
             const float df = dist[(size_t)row * ld + c];
             if (df != df) continue;  // SQL NULL distance: d (and d*w) is ignored by the aggregates
             const double d = (double)df;
-            if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0))) {
+            if (weights || (fw.on && (fw.cw != 0.0 || fw.lw != 0.0))) {
                 sum.step(d * w);
             } else {
                 sum.step(d);
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);
     else if (cnt == 0)
         v = __builtin_nan("");
-    else if (weights || (fw.trows && (fw.cw != 0.0 || fw.lw != 0.0)))
+    else if (weights || (fw.on && (fw.cw != 0.0 || fw.lw != 0.0)))
         v = sum.value() / wsum.value();
     else if (agg == PVS_AGG_MIN)
         v = mn;

@@ -165,6 +165,7 @@ struct pvs_index {
     hipStream_t search_stream = nullptr;
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
+    bool by_group = false;  // multi-device parent: rows are placed by group (group_ids given to every add): per-item operators are shard-local
     bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     std::atomic<uint64_t> flat_reruns{0};  // queries that went through the scan twice (segment overflow -> flat candidate lists)
@@ -238,6 +239,22 @@ pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_
 pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
                               double *out_values, uint32_t *out_count);
+struct SimilarArgs {  // similar_to's options; the row_* arrays are host arrays over the rows of the index they are passed with
+    pvs_agg agg;
+    const double *row_conf, *row_lang;
+    double cw, lw;
+    const uint8_t *row_kind;
+    bool skip_i2i, skip_t2t;
+};
+struct SimilarTargets {
+    std::vector<uint8_t> hq;         // [n_targets][dim] the target vectors as a query batch (int8 codes or f32)
+    std::vector<double> conf, lang;  // [n_targets] NaN = NULL
+    std::vector<uint8_t> kind;       // [n_targets]
+};
+pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, const SimilarArgs &a, std::vector<uint64_t> &trow,
+                           SimilarTargets &tg);
+pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targets, const std::vector<uint32_t> &excluded, uint32_t k,
+                        pvs_metric metric, const SimilarArgs &a, int64_t *out_groups, double *out_values, uint32_t *out_count);
 // ---- pvs_multi.hip (entry points of a multi-device index; the public functions dispatch here when is_multi())
 pvs_status multi_create(const pvs_index_desc *desc, pvs_index **out);
 void multi_destroy(pvs_index *ix);
@@ -255,5 +272,13 @@ pvs_status multi_wait(pvs_index *ix, uint32_t ticket);
 pvs_status multi_sync(pvs_index *ix);
 pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, pvs_metric metric, float *out_dist, pvs_space out_space);
 pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                               pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count);
+                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                               double *out_values, uint32_t *out_count);
+pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                 const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+pvs_status multi_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric, float *out_dist,
+                             pvs_space out_space);
+pvs_status multi_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric, const SimilarArgs &a,
+                            int64_t *out_groups, double *out_values, uint32_t *out_count);
+pvs_status multi_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores, uint32_t *out_count);
 // ---- pvs_comm.hip

@@ -107,7 +107,7 @@ static uint32_t dense_chunk_queries(const pvs_index *ix, uint32_t batch) {
 
 PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric,
                                       float *out_dist, pvs_space out_space) {
-    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_score_batch is not served on a multi-device index (pvs_score_all is)");
+    if (ix && is_multi(ix)) return multi_score_batch(ix, queries, qdtype, batch, metric, out_dist, out_space);
     PVS_TRY(validate_search(ix, queries, qdtype, batch, 1, metric));
     if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0 || ix->n == 0) return PVS_OK;
@@ -288,8 +288,9 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
                               double *out_values, uint32_t *out_count) {
     if (ix && is_multi(ix)) {
-        if (mask) return pvs_fail(PVS_ERR_UNSUPPORTED, "candidate masks are not served on a multi-device index");
-        return multi_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, out_groups, out_values, out_count);
+        if (!row_weights && agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG)
+            return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+        return multi_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, mask, mask_space, out_groups, out_values, out_count);
     }
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
@@ -737,9 +738,18 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     memset(&p, 0, sizeof p);
     p.n_branches = nb;
     uint64_t total = 0;
+    for (uint32_t b = 0; b < nb; b++)
+        if (br[b].idx && is_multi(br[b].idx)) {
+            if (!br[0].idx || !is_multi(br[0].idx)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_rrf_search: single- and multi-device branches cannot be mixed");
+            for (uint32_t j = 0; j < nb; j++) {
+                if (!br[j].query) return pvs_fail(PVS_ERR_INVALID_ARG, "null query");
+                if (br[j].agg != PVS_AGG_MIN && br[j].agg != PVS_AGG_MAX && br[j].agg != PVS_AGG_AVG && !br[j].row_weights)
+                    return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+            }
+            return multi_rrf_search(br, nb, k, out_groups, out_scores, out_count);
+        }
     for (uint32_t b = 0; b < nb; b++) {
         pvs_index *ix = br[b].idx;
-        if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_rrf_search takes single-device branches (shard by group and fuse per-shard pages: INTEGRATION.md)");
         PVS_TRY(validate_search(ix, br[b].query, br[b].query_dtype, 1, 1, br[b].metric));
         if (ix->device != br[0].idx->device) return pvs_fail(PVS_ERR_INVALID_ARG, "all branches must live on one device");
         if (!br[b].row_weights && br[b].agg != PVS_AGG_MIN && br[b].agg != PVS_AGG_MAX && br[b].agg != PVS_AGG_AVG)
@@ -796,118 +806,149 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     return st;
 }
 
-static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
-                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
-                                  const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,
-                                  uint32_t *out_count) {
-    if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
-    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
-    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to needs every row of a group on one device: not served on a multi-device index");
-    if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
-    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
-    if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+// similar_to, second half: the target vectors (already a query batch, with their own confidence / language / kind values) against
+// the rows of ONE single-device index.  `excluded`: this index's rows that are target rows (left out of the join); a.row_*: host
+// arrays over this index's rows.  A multi-device index runs it once per shard (every row of a group on one shard).
+pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targets, const std::vector<uint32_t> &excluded, uint32_t k,
+                        pvs_metric metric, const SimilarArgs &a, int64_t *out_groups, double *out_values, uint32_t *out_count) {
     HIP_TRY(hipSetDevice(ix->device));
-    std::vector<uint32_t> trow(n_targets);
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         PVS_TRY(ensure_groups(ix));
-        if (ix->h_ids_cache.size() != ix->n) {
-            ix->h_ids_cache.resize(ix->n);
-            if (ix->n) HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
-        }
-        for (uint32_t i = 0; i < n_targets; i++) {  // ids are strictly increasing: binary search
-            auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), target_row_ids[i]);
-            if (it == ix->h_ids_cache.end() || *it != target_row_ids[i])
-                return pvs_fail(PVS_ERR_INVALID_ARG, "target row id %lld is not in the index", (long long)target_row_ids[i]);
-            trow[i] = (uint32_t)(it - ix->h_ids_cache.begin());
-        }
     }
     if (ix->n > (1ull << 31) / (4ull * n_targets)) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to fan-out matrix would exceed 2 GiB");
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);
     void *d_q = nullptr;
     float *d_m = nullptr;
-    uint8_t *d_ex = nullptr;
-    double *d_conf = nullptr, *d_lang = nullptr;
-    uint32_t *d_trows = nullptr;
-    uint8_t *d_kind = nullptr;
-    const bool weighted = cw != 0.0 || lw != 0.0;
-    const bool gated = row_kind && (skip_i2i || skip_t2t);
+    uint8_t *d_ex = nullptr, *d_kind = nullptr, *d_tkind = nullptr;
+    double *d_conf = nullptr, *d_lang = nullptr, *d_tconf = nullptr, *d_tlang = nullptr;
+    const bool weighted = a.cw != 0.0 || a.lw != 0.0;
+    const bool gated = a.row_kind && (a.skip_i2i || a.skip_t2t);
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, n_targets, k, false));
         FanoutWeights fw;
-        if (weighted || gated) {
-            HIP_TRY(pvs_malloc_retry((void **)&d_trows, (size_t)n_targets * 4));
-            HIP_TRY(hipMemcpy(d_trows, trow.data(), (size_t)n_targets * 4, hipMemcpyHostToDevice));
-            fw.trows = d_trows;
-        }
+        fw.on = weighted || gated;
         if (gated) {
             HIP_TRY(pvs_malloc_retry((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
-            HIP_TRY(hipMemcpy(d_kind, row_kind, ix->n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_kind, a.row_kind, ix->n, hipMemcpyHostToDevice));
+            HIP_TRY(pvs_malloc_retry((void **)&d_tkind, n_targets));
+            HIP_TRY(hipMemcpy(d_tkind, tg.kind.data(), n_targets, hipMemcpyHostToDevice));
             fw.kind = d_kind;
-            fw.skip_i2i = skip_i2i;
-            fw.skip_t2t = skip_t2t;
+            fw.t_kind = d_tkind;
+            fw.skip_i2i = a.skip_i2i;
+            fw.skip_t2t = a.skip_t2t;
         }
         if (weighted) {
             // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
-            auto upload = [&](const double *src, double **dst) -> pvs_status {
-                HIP_TRY(pvs_malloc_retry((void **)dst, std::max<uint64_t>(ix->n, 1) * 8));
+            auto upload = [&](const double *src, uint64_t n, double **dst) -> pvs_status {
+                HIP_TRY(pvs_malloc_retry((void **)dst, std::max<uint64_t>(n, 1) * 8));
                 if (src)
-                    HIP_TRY(hipMemcpy(*dst, src, ix->n * 8, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(*dst, src, n * 8, hipMemcpyHostToDevice));
                 else
-                    HIP_TRY(hipMemset(*dst, 0xff, ix->n * 8));  // all-ones bits = NaN
+                    HIP_TRY(hipMemset(*dst, 0xff, n * 8));  // all-ones bits = NaN
                 return PVS_OK;
             };
-            PVS_TRY(upload(row_conf, &d_conf));
-            PVS_TRY(upload(row_lang, &d_lang));
+            PVS_TRY(upload(a.row_conf, ix->n, &d_conf));
+            PVS_TRY(upload(a.row_lang, ix->n, &d_lang));
+            PVS_TRY(upload(tg.conf.empty() ? nullptr : tg.conf.data(), n_targets, &d_tconf));
+            PVS_TRY(upload(tg.lang.empty() ? nullptr : tg.lang.data(), n_targets, &d_tlang));
             fw.conf = d_conf;
             fw.lang = d_lang;
-            fw.cw = cw;
-            fw.lw = lw;
+            fw.t_conf = d_tconf;
+            fw.t_lang = d_tlang;
+            fw.cw = a.cw;
+            fw.lw = a.lw;
         }
-        // the target's stored vectors become the query batch: int8 codes as they are, f16/f32 as f32
-        const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
-        std::vector<uint8_t> hq((size_t)n_targets * ix->dim * qesz);
-        std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
-        for (uint32_t i = 0; i < n_targets; i++) {
-            HIP_TRY(pvs_launch_rows_gather(ix->d_rows, ix->stride, (uint32_t)rowbuf.size(), trow[i], 1, c->d_qin, c->stream));
-            HIP_TRY(hipMemcpyAsync(rowbuf.data(), c->d_qin, rowbuf.size(), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            uint8_t *dst = hq.data() + (size_t)i * ix->dim * qesz;
-            if (ix->dtype == PVS_F16) {
-                for (uint32_t e = 0; e < ix->dim; e++) {
-                    _Float16 hv;
-                    memcpy(&hv, rowbuf.data() + 2 * e, 2);
-                    const float f = (float)hv;
-                    memcpy(dst + 4 * e, &f, 4);
-                }
-            } else {
-                memcpy(dst, rowbuf.data(), rowbuf.size());
-            }
-        }
-        HIP_TRY(pvs_malloc_retry(&d_q, hq.size()));
-        HIP_TRY(hipMemcpy(d_q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+        HIP_TRY(pvs_malloc_retry(&d_q, tg.hq.size()));
+        HIP_TRY(hipMemcpy(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice));
         HIP_TRY(pvs_malloc_retry((void **)&d_ex, ix->n + 1));
         HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
-        for (uint32_t i = 0; i < n_targets; i++) HIP_TRY(hipMemsetAsync(d_ex + trow[i], 1, 1, c->stream));
-        HIP_TRY(pvs_malloc_retry((void **)&d_m, (size_t)ix->n * n_targets * 4));
+        for (uint32_t r : excluded) HIP_TRY(hipMemsetAsync(d_ex + r, 1, 1, c->stream));
+        HIP_TRY(pvs_malloc_retry((void **)&d_m, std::max<size_t>((size_t)ix->n * n_targets * 4, 4)));
         const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
         PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));
-        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
+        PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, a.agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_q);
-    hipFree(d_m);
-    hipFree(d_ex);
-    hipFree(d_conf);
-    hipFree(d_lang);
-    hipFree(d_trows);
-    hipFree(d_kind);
+    for (void *p : {(void *)d_q, (void *)d_m, (void *)d_ex, (void *)d_conf, (void *)d_lang, (void *)d_tconf, (void *)d_tlang, (void *)d_kind, (void *)d_tkind})
+        hipFree(p);
     ix->searches++;
     ctx_done(ix, c);
     return st;
+}
+
+// similar_to, first half: the target rows named by id -> their global row, stored vector (the query batch: int8 codes as they
+// are, f16/f32 as f32) and confidence / language / kind values.  Works on both index kinds (pvs_index_read_rows / _read_ids).
+pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, const SimilarArgs &a, std::vector<uint64_t> &trow,
+                           SimilarTargets &tg) {
+    trow.resize(n_targets);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_ids_cache.size() != ix->n) {
+            ix->h_ids_cache.resize(ix->n);
+            if (ix->n) {
+                if (is_multi(ix))
+                    PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
+                else
+                    HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
+            }
+        }
+        for (uint32_t i = 0; i < n_targets; i++) {  // ids are strictly increasing: binary search
+            auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), target_row_ids[i]);
+            if (it == ix->h_ids_cache.end() || *it != target_row_ids[i])
+                return pvs_fail(PVS_ERR_INVALID_ARG, "target row id %lld is not in the index", (long long)target_row_ids[i]);
+            trow[i] = (uint64_t)(it - ix->h_ids_cache.begin());
+        }
+    }
+    const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
+    tg.hq.resize((size_t)n_targets * ix->dim * qesz);
+    std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
+    for (uint32_t i = 0; i < n_targets; i++) {
+        PVS_TRY(pvs_index_read_rows(ix, trow[i], 1, rowbuf.data()));
+        uint8_t *dst = tg.hq.data() + (size_t)i * ix->dim * qesz;
+        if (ix->dtype == PVS_F16) {
+            for (uint32_t e = 0; e < ix->dim; e++) {
+                _Float16 hv;
+                memcpy(&hv, rowbuf.data() + 2 * e, 2);
+                const float f = (float)hv;
+                memcpy(dst + 4 * e, &f, 4);
+            }
+        } else {
+            memcpy(dst, rowbuf.data(), rowbuf.size());
+        }
+    }
+    const double null_v = __builtin_nan("");
+    tg.conf.assign(n_targets, null_v);
+    tg.lang.assign(n_targets, null_v);
+    tg.kind.assign(n_targets, 0);
+    for (uint32_t i = 0; i < n_targets; i++) {
+        if (a.row_conf) tg.conf[i] = a.row_conf[trow[i]];
+        if (a.row_lang) tg.lang[i] = a.row_lang[trow[i]];
+        if (a.row_kind) tg.kind[i] = a.row_kind[trow[i]];
+    }
+    return PVS_OK;
+}
+
+static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
+                                  pvs_agg agg, const double *row_conf, const double *row_lang, double cw, double lw,
+                                  const uint8_t *row_kind, bool skip_i2i, bool skip_t2t, int64_t *out_groups, double *out_values,
+                                  uint32_t *out_count) {
+    if (!ix || !target_row_ids || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    if (n_targets == 0 || n_targets > PVS_MAX_BATCH) return pvs_fail(PVS_ERR_INVALID_ARG, "similar_to takes 1..%u target vectors", PVS_MAX_BATCH);
+    if (metric != PVS_COSINE && metric != PVS_L2) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown metric");
+    if (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX && agg != PVS_AGG_AVG) return pvs_fail(PVS_ERR_INVALID_ARG, "aggregation must be MIN, MAX or AVG");
+    const SimilarArgs a{agg, row_conf, row_lang, cw, lw, row_kind, skip_i2i, skip_t2t};
+    if (is_multi(ix)) return multi_similar_to(ix, target_row_ids, n_targets, k, metric, a, out_groups, out_values, out_count);
+    HIP_TRY(hipSetDevice(ix->device));
+    std::vector<uint64_t> trow;
+    SimilarTargets tg;
+    PVS_TRY(similar_targets(ix, target_row_ids, n_targets, a, trow, tg));
+    std::vector<uint32_t> excluded(trow.begin(), trow.end());
+    return similar_core(ix, tg, n_targets, excluded, k, metric, a, out_groups, out_values, out_count);
 }
 
 PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,

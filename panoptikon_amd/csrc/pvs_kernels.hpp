@@ -174,9 +174,12 @@ struct GroupWork {
     size_t temp_bytes = 0;
     uint32_t cap = 0;
 };
-// similar_to confidence weights (device pointers; trows == nullptr: unweighted fan-out)
+// similar_to confidence weights and cross-modal gates (device pointers; on == 0: plain fan-out).  The targets' own values travel
+// as [fanout] arrays, so the target rows need not be rows of the index being aggregated (a multi-device index: another shard's).
 struct FanoutWeights {
-    const uint32_t *trows = nullptr;  // [fanout] row index of each target vector
+    uint32_t on = 0;
+    const double *t_conf = nullptr, *t_lang = nullptr;  // [fanout] confidence / language_confidence of each target vector, NaN = NULL
+    const uint8_t *t_kind = nullptr;                     // [fanout] PVS_KIND_* of each target vector
     const double *conf = nullptr;     // [rows] confidence, NaN = NULL
     const double *lang = nullptr;     // [rows] language_confidence, NaN = NULL
     double cw = 0.0, lw = 0.0;

@@ -194,6 +194,23 @@ pvs_status multi_complete(pvs_index *ix, MultiCtx &m) {
     return PVS_OK;
 }
 
+// shard of a group under BY-GROUP placement: a 64-bit finaliser (splitmix64) of the group id, so that runs of consecutive
+// file ids spread evenly
+inline uint32_t multi_group_shard(int64_t g, uint32_t S) {
+    uint64_t x = (uint64_t)g + 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return (uint32_t)(x % S);
+}
+// a global per-row host array split into the shards' row orders (segments are in global order and, per shard, in local order)
+template <typename T>
+std::vector<std::vector<T>> split_rows(const pvs_index *ix, const T *global) {
+    std::vector<std::vector<T>> out(ix->shards.size());
+    for (size_t s = 0; s < out.size(); s++) out[s].reserve(ix->shards[s]->n);
+    for (const MultiSegment &g : ix->segs) out[g.shard].insert(out[g.shard].end(), global + g.row0, global + g.row0 + g.n);
+    return out;
+}
 struct SegRange {
     uint32_t shard;
     uint64_t local0, n, out_off;  // out_off: offset (rows) inside the caller's range
@@ -299,6 +316,66 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
         hipPointerAttribute_t at;
         HIP_TRY(hipPointerGetAttributes(&at, rows));
         src_dev = at.device;
+    }
+    if (group_ids || ix->by_group) {
+        // placement BY GROUP: every row of a group lives on shard mix(group) % S, so the per-item operators
+        // (MAX / AVG / weighted aggregates, candidate masks, RRF) stay shard-local.  The rows of one call are gathered per shard
+        // in their order (ids stay increasing inside every shard); the segment table records the runs.
+        if (!group_ids) return pvs_fail(PVS_ERR_INVALID_ARG, "this multi-device index places rows by group: every pvs_index_add needs group_ids");
+        if (ix->n && !ix->by_group)
+            return pvs_fail(PVS_ERR_STATE, "group ids must be given from the first pvs_index_add of a multi-device index (earlier rows were placed without them)");
+        ix->by_group = true;
+        const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+        std::vector<uint8_t> host_rows;  // device-space input is staged through the host (build-side cost, once per row)
+        std::vector<std::vector<uint8_t>> buf(S);
+        std::vector<std::vector<int64_t>> ids(S), grp(S);
+        for (uint64_t off = 0; off < n; off += chunk) {
+            const uint64_t m = std::min(chunk, n - off);
+            const uint8_t *src = (const uint8_t *)rows + off * row_bytes;
+            if (space == PVS_DEVICE) {
+                host_rows.resize(m * row_bytes);
+                HIP_TRY(hipSetDevice(src_dev));
+                HIP_TRY(hipMemcpy(host_rows.data(), src, m * row_bytes, hipMemcpyDeviceToHost));
+                src = host_rows.data();
+            }
+            for (uint32_t s = 0; s < S; s++) {
+                buf[s].clear();
+                ids[s].clear();
+                grp[s].clear();
+            }
+            std::vector<MultiSegment> runs;
+            std::vector<uint64_t> taken(S, 0);
+            for (uint64_t i = 0; i < m; i++) {
+                const uint32_t s = multi_group_shard(group_ids[off + i], S);
+                buf[s].insert(buf[s].end(), src + i * row_bytes, src + (i + 1) * row_bytes);
+                ids[s].push_back(row_ids ? row_ids[off + i] : ix->id_base + (int64_t)(ix->n + off + i));
+                grp[s].push_back(group_ids[off + i]);
+                const uint64_t local = ix->shards[s]->n + taken[s]++;
+                if (!runs.empty() && runs.back().shard == s && runs.back().row0 + runs.back().n == ix->n + off + i)
+                    runs.back().n++;
+                else
+                    runs.push_back({ix->n + off + i, 1, s, local});
+            }
+            for (uint32_t s = 0; s < S; s++) {
+                if (ids[s].empty()) continue;
+                pvs_status st = add_impl(ix->shards[s], buf[s].data(), from_f32, ids[s].size(), ids[s].data(), grp[s].data(), PVS_HOST);
+                if (st != PVS_OK) {
+                    ix->poisoned = true;  // (see below)
+                    return st;
+                }
+            }
+            // consecutive calls extend the last run when they can
+            for (const MultiSegment &r : runs) {
+                if (!ix->segs.empty() && ix->segs.back().shard == r.shard && ix->segs.back().row0 + ix->segs.back().n == r.row0 &&
+                    ix->segs.back().local0 + ix->segs.back().n == r.local0)
+                    ix->segs.back().n += r.n;
+                else
+                    ix->segs.push_back(r);
+            }
+        }
+        ix->n += n;
+        ix->last_id = last;
+        return PVS_OK;
     }
     const uint64_t base = n / S, rem = n % S;
     uint64_t off = 0;
@@ -539,35 +616,109 @@ pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, p
     return PVS_OK;
 }
 
-// Per-item pages across row shards, MIN only: a group's global MIN is attained in some shard, where it is the
-// group's shard value; every other group's shard value is >= its global value, so a group of the global top-k is
-// inside the top-k of the shard that holds its best row.  Hence: per-shard top-k pages, duplicates folded to their
-// minimum, merged under (value asc, group id asc, NULL last).  (MAX / AVG need every row of a group on one device.)
-pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                               pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values, uint32_t *out_count) {
-    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
-    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
-    if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
-    if (agg != PVS_AGG_MIN || row_weights)
-        return pvs_fail(PVS_ERR_UNSUPPORTED, "a multi-device index serves per-item search with MIN only (MAX/AVG/weights need every row of a group on one device)");
-    if (batch == 0) return PVS_OK;
+// a candidate mask over the global rows as host bytes (device-space masks are read back: the per-shard masks are gathers)
+static pvs_status host_mask(pvs_index *ix, const uint8_t *mask, pvs_space space, std::vector<uint8_t> &stage, const uint8_t **out) {
+    *out = mask;
+    if (!mask || space == PVS_HOST) return PVS_OK;
+    stage.resize(ix->n);
+    if (ix->n) HIP_TRY(hipMemcpy(stage.data(), mask, ix->n, hipMemcpyDeviceToHost));
+    *out = stage.data();
+    return PVS_OK;
+}
+template <typename F>
+static pvs_status per_shard(pvs_index *ix, F f) {
     const uint32_t S = (uint32_t)ix->shards.size();
-    const size_t elems = (size_t)batch * k;
-    std::vector<int64_t> g(S * elems);
-    std::vector<double> v(S * elems);
-    std::vector<uint32_t> c((size_t)S * batch, 0);
     std::vector<pvs_status> st(S, PVS_OK);
     std::vector<std::string> err(S);
     std::vector<std::thread> th;
     for (uint32_t s = 0; s < S; s++)
         th.emplace_back([&, s]() {
-            st[s] = search_groups_impl(ix->shards[s], queries, qdtype, batch, k, metric, PVS_AGG_MIN, nullptr, nullptr, PVS_HOST,
-                                       g.data() + s * elems, v.data() + s * elems, c.data() + (size_t)s * batch);
+            st[s] = f(s);
             if (st[s] != PVS_OK) err[s] = pvs_last_error();
         });
     for (auto &t : th) t.join();
     for (uint32_t s = 0; s < S; s++)
         if (st[s] != PVS_OK) return pvs_fail(st[s], "shard %u: %s", s, err[s].c_str());
+    return PVS_OK;
+}
+static const char *k_need_groups = "needs every row of a group on one device: give group_ids to every pvs_index_add of a multi-device index";
+
+// pvs_search_filtered on a multi-device index: the mask split into the shards' row orders, one masked search per shard (threads),
+// pages merged on the host under (distance asc, id asc, NULL last)
+pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                 const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (batch == 0) return PVS_OK;
+    std::vector<uint8_t> stage;
+    const uint8_t *hm = nullptr;
+    PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
+    const auto masks = split_rows<uint8_t>(ix, hm);
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> ids(S * elems);
+    std::vector<float> dist(S * elems);
+    std::vector<uint32_t> cnt((size_t)S * batch, 0);
+    PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
+        if (ix->shards[s]->n == 0) return PVS_OK;
+        return search_host(ix->shards[s], queries, qdtype, batch, k, metric, masks[s].data(), PVS_HOST, ids.data() + s * elems, dist.data() + s * elems,
+                           cnt.data() + (size_t)s * batch);
+    }));
+    ix->searches++;
+    return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
+}
+
+// pvs_score_batch on a multi-device index: one dense matrix per shard, scattered into global row order
+pvs_status multi_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric, float *out_dist,
+                             pvs_space out_space) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, 1, metric));
+    if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (out_space != PVS_HOST) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_score_batch on a multi-device index writes host memory only");
+    if (batch == 0) return PVS_OK;
+    std::vector<float> m;
+    for (uint32_t s = 0; s < ix->shards.size(); s++) {
+        pvs_index *sh = ix->shards[s];
+        if (sh->n == 0) continue;
+        m.resize(sh->n * (size_t)batch);
+        PVS_TRY(pvs_score_batch(sh, queries, qdtype, batch, metric, m.data(), PVS_HOST));
+        for (const MultiSegment &g : ix->segs)
+            if (g.shard == s) memcpy(out_dist + g.row0 * batch, m.data() + g.local0 * batch, g.n * (size_t)batch * 4);
+    }
+    return PVS_OK;
+}
+
+// Per-item pages across row shards.  Rows are placed BY GROUP (group_ids given to every add), so every aggregate, row weights
+// and candidate masks are shard-local; the shards' pages hold disjoint groups and merge under (value asc, group id asc, NULL
+// last).  (The merge below also folds a group that appears in two pages to its minimum: harmless here, and what MIN over
+// row-wise shards would need.)
+pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
+                               double *out_values, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (ix->n && !ix->by_group) return pvs_fail(PVS_ERR_UNSUPPORTED, "per-item search %s", k_need_groups);
+    if (batch == 0) return PVS_OK;
+    std::vector<uint8_t> stage;
+    const uint8_t *hm = nullptr;
+    PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
+    std::vector<std::vector<uint8_t>> masks;
+    std::vector<std::vector<float>> weights;
+    if (hm) masks = split_rows<uint8_t>(ix, hm);
+    if (row_weights) weights = split_rows<float>(ix, row_weights);
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> g(S * elems);
+    std::vector<double> v(S * elems);
+    std::vector<uint32_t> c((size_t)S * batch, 0);
+    PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
+        if (ix->shards[s]->n == 0) return PVS_OK;
+        return search_groups_impl(ix->shards[s], queries, qdtype, batch, k, metric, agg, row_weights ? weights[s].data() : nullptr,
+                                  hm ? masks[s].data() : nullptr, PVS_HOST, g.data() + s * elems, v.data() + s * elems,
+                                  c.data() + (size_t)s * batch);
+    }));
     struct GV {
         double v;
         int64_t g;
@@ -604,3 +755,111 @@ pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdt
     ix->searches++;
     return PVS_OK;
 }
+
+// similar_to on a multi-device index placed BY GROUP: the target vectors (read from the shards that own them) are scored against
+// every shard; the target rows are left out on their own shard; the shards' pages hold disjoint groups and merge on the host.
+pvs_status multi_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric, const SimilarArgs &a,
+                            int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    if (ix->n && !ix->by_group) return pvs_fail(PVS_ERR_UNSUPPORTED, "similar_to %s", k_need_groups);
+    std::vector<uint64_t> trow;
+    SimilarTargets tg;
+    PVS_TRY(similar_targets(ix, target_row_ids, n_targets, a, trow, tg));
+    const uint32_t S = (uint32_t)ix->shards.size();
+    std::vector<std::vector<uint32_t>> excluded(S);
+    for (uint32_t i = 0; i < n_targets; i++)
+        for (const SegRange &r : locate(ix, trow[i], 1)) excluded[r.shard].push_back((uint32_t)r.local0);
+    std::vector<std::vector<double>> conf, lang;
+    std::vector<std::vector<uint8_t>> kind;
+    if (a.row_conf) conf = split_rows<double>(ix, a.row_conf);
+    if (a.row_lang) lang = split_rows<double>(ix, a.row_lang);
+    if (a.row_kind) kind = split_rows<uint8_t>(ix, a.row_kind);
+    const size_t elems = k;
+    std::vector<int64_t> g(S * elems);
+    std::vector<double> v(S * elems);
+    std::vector<uint32_t> c(S, 0);
+    PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
+        if (ix->shards[s]->n == 0) return PVS_OK;
+        SimilarArgs mine = a;
+        mine.row_conf = a.row_conf ? conf[s].data() : nullptr;
+        mine.row_lang = a.row_lang ? lang[s].data() : nullptr;
+        mine.row_kind = a.row_kind ? kind[s].data() : nullptr;
+        return similar_core(ix->shards[s], tg, n_targets, excluded[s], k, metric, mine, g.data() + s * elems, v.data() + s * elems, &c[s]);
+    }));
+    ix->searches++;
+    return pvs_merge_group_pages(g.data(), v.data(), c.data(), S, 1, k, out_groups, out_values, out_count);
+}
+
+// pvs_rrf_search over multi-device branches placed BY GROUP: shard s of every branch is rank s of the sharded protocol
+// (pvs_rrf_search_sharded: pages of each branch's ranking, candidates' exact keys and ranks summed over the ranks); the ranks
+// are threads of this process and the all-gather is a rendezvous in host memory.  Every rank returns the same page.
+namespace {
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t world = 0, arrived = 0, readers = 0;
+    uint64_t gen = 0;
+    std::vector<uint8_t> buf;
+};
+struct RankCtx {
+    Rendezvous *z;
+    uint32_t rank;
+};
+int32_t rendezvous_gather(void *ctx, const void *send, void *recv, uint64_t bytes) {
+    RankCtx *r = (RankCtx *)ctx;
+    Rendezvous &z = *r->z;
+    std::unique_lock<std::mutex> lk(z.mu);
+    if (z.arrived == 0) z.buf.resize((size_t)z.world * bytes);  // (the previous round's readers are all gone: second wait below)
+    if (z.buf.size() != (size_t)z.world * bytes) return 1;     // ranks disagree on the message size
+    memcpy(z.buf.data() + (size_t)r->rank * bytes, send, bytes);
+    const uint64_t g = z.gen;
+    if (++z.arrived == z.world) {
+        z.arrived = 0;
+        z.readers = z.world;
+        z.gen++;
+        z.cv.notify_all();
+    } else {
+        z.cv.wait(lk, [&] { return z.gen != g; });
+    }
+    memcpy(recv, z.buf.data(), (size_t)z.world * bytes);
+    if (--z.readers == 0)
+        z.cv.notify_all();
+    else
+        z.cv.wait(lk, [&] { return z.readers == 0; });
+    return 0;
+}
+}  // namespace
+
+pvs_status multi_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores, uint32_t *out_count) {
+    const uint32_t S = (uint32_t)br[0].idx->shards.size();
+    for (uint32_t b = 0; b < nb; b++) {
+        pvs_index *ix = br[b].idx;
+        if (!ix || !is_multi(ix) || ix->shards.size() != S)
+            return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_rrf_search: either every branch is a single-device index or every branch a multi-device index over the same number of devices");
+        if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+        if (ix->n && !ix->by_group) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_rrf_search %s", k_need_groups);
+    }
+    std::vector<std::vector<std::vector<float>>> weights(nb);
+    for (uint32_t b = 0; b < nb; b++)
+        if (br[b].row_weights) weights[b] = split_rows<float>(br[b].idx, br[b].row_weights);
+    Rendezvous z;
+    z.world = S;
+    std::vector<RankCtx> rc(S);
+    std::vector<std::vector<int64_t>> og(S, std::vector<int64_t>(k));
+    std::vector<std::vector<double>> os(S, std::vector<double>(k));
+    std::vector<uint32_t> oc(S, 0);
+    PVS_TRY(per_shard(br[0].idx, [&](uint32_t s) -> pvs_status {
+        std::vector<pvs_rrf_branch> mine(br, br + nb);
+        for (uint32_t b = 0; b < nb; b++) {
+            mine[b].idx = br[b].idx->shards[s];
+            mine[b].row_weights = br[b].row_weights ? weights[b][s].data() : nullptr;
+        }
+        rc[s] = {&z, s};
+        return pvs_rrf_search_sharded(mine.data(), nb, k, nullptr, S, rendezvous_gather, &rc[s], og[s].data(), os[s].data(), &oc[s]);
+    }));
+    memcpy(out_groups, og[0].data(), (size_t)k * 8);
+    memcpy(out_scores, os[0].data(), (size_t)k * 8);
+    *out_count = oc[0];
+    return PVS_OK;
+}
+

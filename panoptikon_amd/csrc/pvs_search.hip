@@ -556,7 +556,7 @@ PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pv
                                           pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
                                           float *out_dist, uint32_t *out_count) {
     if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
-    if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "candidate masks are not served on a multi-device index");
+    if (ix && is_multi(ix)) return multi_search_filtered(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
     return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
 }
 

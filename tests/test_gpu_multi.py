@@ -147,9 +147,106 @@ def test_multi_device_min_groups_spanning_shards(pvs):
             eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, hq[j], grp, orc.AGG_MIN, k)
             assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), f"devices={devices} query {j}"
             assert np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64))
-        with pytest.raises(pvs.PvsError) as e:
-            ix.search_groups(hq, k, pvs.COSINE, pvs.AGG_AVG)
-        assert e.value.status == 6  # PVS_ERR_UNSUPPORTED, stated in pvs.h
+        ix.close()
+    # rows added WITHOUT group ids are placed in contiguous pieces: the per-item operators that need a group on one device say so
+    ix = pvs.VectorIndex(pvs.I8, dim, devices=_layouts(pvs)[0])
+    ix.set_scale(scale)
+    ix.add_f32(rows[:100])
+    with pytest.raises(pvs.PvsError) as e:
+        ix.add_f32(rows[100:200], group_ids=grp[100:200])   # group ids must come from the first add
+    assert e.value.status == 5  # PVS_ERR_STATE
+    ix.close()
+
+
+def _same_f32(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+
+
+def test_multi_device_per_item_operators_placed_by_group(pvs):
+    """with group ids at add time a multi-device index places every group on one shard, and MAX / AVG /
+    weighted per-item search, candidate masks, pvs_score_batch, similar_to(_ex) and pvs_rrf_search answer like one device —
+    each compared with the oracle over the WHOLE corpus, bit for bit."""
+    rng = np.random.default_rng(77)
+    dim, n, k = 128, 12_000, 40
+    rows = orc.synth_rows(91, 0, n, dim)
+    grp = np.sort(rng.integers(0, 2500, n)).astype(np.int64) * 3 + 1     # ~5 rows per file, files adjacent as in the reference
+    rows[np.nonzero(grp == grp[n // 3])[0]] = 0.0                          # one file with NULL cosine distances only
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    q = orc.synth_rows(93, 0, 5, dim)
+    hq = orc.quantize_int8(q, scale)
+    w = (rng.random(n) + 0.1).astype(np.float32)
+    mask = (rng.random(n) < 0.3).astype(np.uint8)
+    allowed = np.nonzero(mask)[0]
+    ids = np.arange(n, dtype=np.int64) * 2 + 10
+    conf = rng.random(n)
+    conf[rng.random(n) < 0.2] = np.nan
+    lang = rng.random(n)
+    kind = (rng.random(n) < 0.4).astype(np.uint8)
+    for devices in _layouts(pvs):
+        ix = pvs.VectorIndex(pvs.I8, dim, devices=devices)
+        ix.set_scale(scale)
+        for a in range(0, n, 5000):   # several adds; a file may straddle two calls
+            ix.add_f32(rows[a:a + 5000], row_ids=ids[a:a + 5000], group_ids=grp[a:a + 5000])
+        tag = f"devices={devices}"
+        # the global row order survives the placement
+        ri, rg = ix.read_ids(0, n, groups=True)
+        assert np.array_equal(ri, ids) and np.array_equal(rg, grp), tag
+        assert np.array_equal(ix.read_rows(4990, 30), codes[4990:5020]), tag
+        # plain search still sees every row
+        gi, gd, gc = ix.search(hq, k, pvs.COSINE)
+        ei, ed = orc.search(orc.I8, orc.COSINE, codes, hq, k, ids=ids)
+        assert (gc == k).all() and np.array_equal(gi, ei) and _same_f32(gd, ed), tag
+        # per-item search: every aggregate, weights, masks
+        for agg, oagg in ((pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_MAX, orc.AGG_MAX), (pvs.AGG_AVG, orc.AGG_AVG)):
+            og, ov, oc = ix.search_groups(hq, k, pvs.COSINE, agg)
+            for j in range(len(hq)):
+                eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes, hq[j], grp, oagg, k)
+                assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), f"{tag} agg {agg} query {j}"
+                assert np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), f"{tag} agg {agg} query {j}"
+        og, ov, oc = ix.search_groups(hq, k, pvs.L2, pvs.AGG_AVG, row_weights=w)
+        for j in range(len(hq)):
+            eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[j], grp, orc.AGG_AVG, k, weights=w)
+            assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg) and np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), tag
+        og, ov, oc = ix.search_groups_filtered(hq, k, mask, pvs.COSINE, pvs.AGG_MAX)
+        for j in range(len(hq)):
+            eg, ev = orc.search_groups(orc.I8, orc.COSINE, codes[allowed], hq[j], grp[allowed], orc.AGG_MAX, k)
+            assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg) and np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), tag
+        fi, fd, fc = ix.search_filtered(hq, k, mask, pvs.COSINE)
+        ei, ed = orc.search(orc.I8, orc.COSINE, codes[allowed], hq, k, ids=ids[allowed])
+        assert (fc == k).all() and np.array_equal(fi, ei) and _same_f32(fd, ed), tag
+        # the dense matrix in global row order
+        m = ix.score_batch(hq, pvs.L2)
+        for j in range(len(hq)):
+            assert np.array_equal(m[:, j].view(np.uint32), orc.score_all(orc.I8, orc.L2, codes, hq[j]).view(np.uint32)), tag
+        # similar_to: a whole file as target (its rows live on one shard), plain and with weights + gates
+        tfile = grp[n // 2]
+        targets = ids[grp == tfile]
+        trows = np.nonzero(grp == tfile)[0].tolist()
+        sg, sv = ix.similar_to(targets, k, pvs.L2, pvs.AGG_AVG)
+        eg, ev = orc.similar_to(orc.I8, orc.L2, codes, trows, grp, orc.AGG_AVG, k)
+        assert np.array_equal(sg, eg) and np.array_equal(sv.view(np.uint64), ev.view(np.uint64)), tag
+        sg, sv = ix.similar_to_ex(targets, k, pvs.COSINE, pvs.AGG_MIN, confidence=conf, language_confidence=lang, confidence_weight=1.5,
+                                  language_confidence_weight=0.5, row_kind=kind, xmodal_t2t=False)
+        eg, ev = orc.similar_to_ex(orc.I8, orc.COSINE, codes, trows, grp, orc.AGG_MIN, k, conf=conf, lang=lang, cw=1.5, lw=0.5, kind=kind,
+                                   xmodal_t2t=False)
+        assert np.array_equal(sg, eg), tag
+        assert np.allclose(sv, ev, rtol=1e-12, atol=0, equal_nan=True), tag   # device pow(): within 1 ulp of libm (pvs.h)
+        # OR arm: two multi-device branches over the same devices
+        rows2 = orc.synth_rows(95, 0, 7000, 64)
+        grp2 = np.sort(rng.integers(0, 2500, 7000)).astype(np.int64) * 3 + 1
+        ix2 = pvs.VectorIndex(pvs.F16, 64, devices=devices)
+        ix2.add_f32(rows2, group_ids=grp2)
+        q2 = orc.synth_rows(97, 0, 1, 64)[0]
+        br = [dict(index=ix, query=hq[0], metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=5, weight=1.0),
+              dict(index=ix2, query=q2, metric=pvs.L2, agg=pvs.AGG_AVG, rrf_k=10, weight=0.7, row_weights=None)]
+        fg, fs = pvs.rrf_search(br, 100)
+        ora = [dict(dtype=orc.I8, metric=orc.COSINE, corpus=codes, query=hq[0], groups=grp, agg=orc.AGG_MIN, rrf_k=5, weight=1.0),
+               dict(dtype=orc.F16, metric=orc.L2, corpus=rows2.astype(np.float16), query=q2, groups=grp2, agg=orc.AGG_AVG, rrf_k=10, weight=0.7)]
+        eg, es = orc.rrf_search(ora, 100)
+        assert np.array_equal(fg, eg) and np.array_equal(fs.view(np.uint64), es.view(np.uint64)), tag
+        ix2.close()
         ix.close()
 
 
