@@ -272,8 +272,12 @@ pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
  * distance: rows that tie on it are ordered by last_modified, newest first.  One int64 key per stored row (whatever the host
  * orders by: last_modified as a Unix time, say); afterwards every row page — pvs_search*, pvs_search_device, pvs_search_page,
  * pvs_search_bounded, the dense fallbacks — is ordered (distance asc, NULL last, key DESC, row id asc), and a tie at the k-th
- * distance takes the rows with the largest keys.  `n` must equal the index's row count; rows appended later drop the keys
- * (set them again).  keys == NULL removes them.  Single-device indexes. */
+ * distance takes the rows with the largest keys.  The per-item pages follow the same rule: pvs_search_groups[_filtered/_page]
+ * order by (value asc, NULL last, key DESC, group id asc) and pvs_rrf_search by (score desc, key DESC, group id asc), a group's
+ * key being the key of its first row (the rows of a file share files.last_modified) — for pvs_rrf_search taken from the first
+ * branch that carries keys and holds the group.  `n` must equal the index's row count; rows appended later drop the keys
+ * (set them again).  keys == NULL removes them.  Single-device indexes: the cross-shard merges (a multi-device index,
+ * pvs_search_sharded, pvs_search_groups_sharded, pvs_rrf_search_sharded, pvs_merge_*) break ties by id only. */
 pvs_status pvs_index_set_order_keys(pvs_index *idx, const int64_t *keys, uint64_t n, pvs_space space);
 
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort

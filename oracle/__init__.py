@@ -244,24 +244,30 @@ def aggregate(dist, group, agg: int, w=None):
     return og[:g].copy(), ov[:g].copy()
 
 
-def _rank_groups(groups, values, k):
-    """Page order of a raw aggregate (`ORDER BY order_rank ASC NULLS LAST`, model.rs:547-553): value asc, NaN
-    (NULL) last, ties by group id asc -> first k."""
+def _rank_groups(groups, values, k, keys=None):
+    """Page order of a raw aggregate (`ORDER BY order_rank ASC NULLS LAST, last_modified DESC`, model.rs:547-553): value asc,
+    NaN (NULL) last, then the second key descending when the rows carry one, ties by group id asc -> first k."""
     groups = np.asarray(groups)
     values = np.asarray(values, np.float64)
     isn = np.isnan(values)
-    order = np.lexsort((groups, np.where(isn, 0.0, values), isn))[:k]
+    cols = (groups, np.where(isn, 0.0, values), isn) if keys is None else (groups, -np.asarray(keys, np.int64), np.where(isn, 0.0, values), isn)
+    order = np.lexsort(cols)[:k]
     return groups[order], values[order]
 
 
-def search_groups(dtype: int, metric: int, corpus, query, group_ids, agg: int, k: int, weights=None):
-    """One query: score all rows, GROUP BY group id (rows of a group in row order), aggregate, rank."""
+def search_groups(dtype: int, metric: int, corpus, query, group_ids, agg: int, k: int, weights=None, order_keys=None):
+    """One query: score all rows, GROUP BY group id (rows of a group in row order), aggregate, rank.  order_keys: one int64 per
+    row (files.last_modified); a group's key is its first row's (the rows of a file share it)."""
     d = score_all(dtype, metric, corpus, query)
     grp = _c(group_ids, np.int64)
     order = np.argsort(grp, kind="stable")
     w = None if weights is None else _c(weights, np.float32)[order]
     g, v = aggregate(d[order], grp[order], agg, w=w)
-    return _rank_groups(g, v, k)
+    gk = None
+    if order_keys is not None:
+        first = np.concatenate([[True], grp[order][1:] != grp[order][:-1]])
+        gk = np.asarray(order_keys, np.int64)[order][first]
+    return _rank_groups(g, v, k, keys=gk)
 
 
 def similar_to(dtype: int, metric: int, corpus, target_rows, group_ids, agg: int, k: int):
@@ -344,8 +350,11 @@ def rrf_search(branches, k: int):
     """The reference's OR-composition with RRF, literally: per branch score every row, aggregate per group, rank
     ALL groups with row_number() (SQLite NULL placement), UNION the groups, fuse, ORDER BY score DESC (ties:
     group id), LIMIT k.  branches: dicts {dtype, metric, corpus, query, groups, agg, weights=None, descending=False,
-    rrf_k=1, weight=1.0}."""
+    rrf_k=1, weight=1.0, order_keys=None}.  order_keys (one int64 per row of the branch: files.last_modified): groups tying
+    on the fused score come out by key descending first (model.rs:547-553); a group's key is its first row's, taken from the
+    first branch that carries keys and holds the group."""
     per = []
+    gkeys = {}
     for b in branches:
         grp = _c(b["groups"], np.int64)
         d = score_all(b["dtype"], b["metric"], b["corpus"], b["query"])
@@ -353,6 +362,10 @@ def rrf_search(branches, k: int):
         w = None if b.get("weights") is None else _c(b["weights"], np.float32)[order]
         g, v = aggregate(d[order], grp[order], b.get("agg", AGG_MIN), w=w)
         per.append((g, row_number(v, g, descending=b.get("descending", False))))
+        if b.get("order_keys") is not None:
+            first = np.concatenate([[True], grp[order][1:] != grp[order][:-1]])
+            for gg, kk in zip(g.tolist(), np.asarray(b["order_keys"], np.int64)[order][first].tolist()):
+                gkeys.setdefault(gg, kk)
     allg = np.unique(np.concatenate([g for g, _ in per])) if per else np.empty(0, np.int64)
     ranks = np.full((len(per), len(allg)), -1, np.int64)
     for i, (g, r) in enumerate(per):
@@ -360,7 +373,13 @@ def rrf_search(branches, k: int):
     ks = [int(b.get("rrf_k", 1)) for b in branches]
     ws = [float(b.get("weight", 1.0)) for b in branches]
     score = np.array([rrf_score(ranks[:, i], ks, ws) for i in range(len(allg))])
-    order = np.lexsort((allg, -score))[:k]
+    if gkeys:
+        lo = np.iinfo(np.int64).min
+        tie = np.array([gkeys.get(g, lo) for g in allg.tolist()], np.int64)
+        neg = np.where(tie == lo, np.iinfo(np.int64).max, -np.where(tie == lo, 0, tie))  # key DESC, groups without a key last
+        order = np.lexsort((allg, neg, -score))[:k]
+    else:
+        order = np.lexsort((allg, -score))[:k]
     return allg[order], score[order]
 
 

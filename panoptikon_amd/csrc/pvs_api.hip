@@ -482,6 +482,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
+    hipFree(ix->d_grp_tinv);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
@@ -602,6 +603,8 @@ PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *key
     hipFree(ix->d_tinv);
     ix->d_trank = ix->d_tinv = nullptr;
     ix->order_rows = 0;
+    ix->h_order_keys.clear();
+    ix->groups_built_n = UINT64_MAX;  // the groups' tie order is rebuilt with the CSR
     if (!keys) return PVS_OK;
     if (n != ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "%llu order keys for %llu rows: one key per stored row", (unsigned long long)n, (unsigned long long)ix->n);
     if (n == 0) return PVS_OK;
@@ -626,6 +629,11 @@ PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *key
         ix->d_trank = ix->d_tinv = nullptr;
         return st;
     }
+    ix->h_order_keys.resize(n);
+    if (space == PVS_HOST)
+        memcpy(ix->h_order_keys.data(), keys, n * 8);
+    else
+        HIP_TRY(hipMemcpy(ix->h_order_keys.data(), keys, n * 8, hipMemcpyDeviceToHost));
     ix->order_rows = n;
     return PVS_OK;
 }

@@ -110,13 +110,16 @@ __device__ static inline unsigned long long f64_sort_key(double d) {
     if ((b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) return ~0ull;
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
-__global__ void k_group_keys(const double *vals, uint32_t n, unsigned long long *keys, uint32_t *idx) {
+// g_tinv (optional): the groups in tie order (second sort key DESC, group id ASC); the value sort is stable, so equal values come
+// out in that order — without it in group id order
+__global__ void k_group_keys(const double *vals, const uint32_t *g_tinv, uint32_t n, unsigned long long *keys, uint32_t *idx) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        unsigned long long k = f64_sort_key(vals[i]);
+        const uint32_t g = g_tinv ? g_tinv[i] : i;
+        unsigned long long k = f64_sort_key(vals[g]);
         if (k == ~0ull) k = ~0ull - 1;  // NULL aggregates: after every value ...
-        if (__builtin_bit_cast(unsigned long long, vals[i]) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
+        if (__builtin_bit_cast(unsigned long long, vals[g]) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
         keys[i] = k;
-        idx[i] = i;
+        idx[i] = g;
     }
 }
 __global__ void k_group_emit(const uint32_t *idx_sorted, const double *vals, const int64_t *group_ids, uint32_t n, uint32_t k,
@@ -150,7 +153,7 @@ __global__ void k_group_emit(const uint32_t *idx_sorted, const double *vals, con
 // ranks one column of group values: (value asc, group id asc — groups are stored in id order and
 // the radix sort is stable), NaN last; writes the first k.
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
-                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s) {
+                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s, const uint32_t *g_tinv) {
     if (n_groups > w.cap) {
         hipFree(w.keys_in);
         hipFree(w.keys_out);
@@ -171,7 +174,7 @@ pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint
     }
     if (n_groups) {
         hipLaunchKernelGGL(k_group_keys, dim3((n_groups + 255) / 256 > 4096 ? 4096 : (n_groups + 255) / 256), dim3(256), 0, s, d_vals,
-                           n_groups, w.keys_in, w.idx_in);
+                           g_tinv, n_groups, w.keys_in, w.idx_in);
         size_t tb = w.temp_bytes;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (int)n_groups, 0, 64, s));
     }

@@ -147,6 +147,10 @@ struct pvs_index {
     // Wherever a page is ordered by (distance, row) the row is replaced by its tie rank and mapped back on output.
     uint32_t *d_trank = nullptr, *d_tinv = nullptr;
     uint64_t order_rows = 0;  // rows the tie ranks cover (0: none set)
+    std::vector<int64_t> h_order_keys;  // host copy of the keys (the groups' tie order is built from it in ensure_groups)
+    // groups in tie order (key of the group's first row DESC, group id ASC), built with the CSR when the keys cover every row
+    uint32_t *d_grp_tinv = nullptr;
+    std::vector<int64_t> h_grp_ids, h_grp_key;  // per group, in id order (host: the page-first per-item path sorts with them)
     std::vector<int64_t> h_groups;  // optional group ids per row (host copy)
     std::vector<int64_t> h_ids_cache;  // host copy of row ids (lazy; similar_to's id -> row lookup)
     // group CSR on the device (built lazily, rebuilt after adds)

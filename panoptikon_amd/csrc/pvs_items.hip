@@ -13,8 +13,11 @@ pvs_status ensure_groups(pvs_index *ix) {
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
-    ix->d_grp_off = ix->d_grp_rows = nullptr;
+    hipFree(ix->d_grp_tinv);
+    ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = nullptr;
     ix->d_grp_ids = nullptr;
+    ix->h_grp_ids.clear();
+    ix->h_grp_key.clear();
     const uint64_t n = ix->n;
     std::vector<uint32_t> off, rows(n);
     std::vector<int64_t> gids;
@@ -45,6 +48,21 @@ pvs_status ensure_groups(pvs_index *ix) {
     HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
     if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
+    if (ix->order_rows == n && n) {
+        // second sort key of the per-item pages (pql/model.rs:547-553: ORDER BY order_rank, last_modified DESC): a group's key is
+        // its first row's (the rows of a file share files.last_modified); groups in (key DESC, group id ASC) order feed the stable
+        // value sort of pvs_group_rank
+        const uint32_t G = (uint32_t)gids.size();
+        std::vector<int64_t> gkey(G);
+        for (uint32_t g = 0; g < G; g++) gkey[g] = ix->h_order_keys[rows[off[g]]];
+        std::vector<uint32_t> tinv(G);
+        for (uint32_t g = 0; g < G; g++) tinv[g] = g;
+        std::stable_sort(tinv.begin(), tinv.end(), [&](uint32_t a, uint32_t b) { return gkey[a] > gkey[b]; });
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_tinv, (size_t)G * 4));
+        HIP_TRY(hipMemcpy(ix->d_grp_tinv, tinv.data(), (size_t)G * 4, hipMemcpyHostToDevice));
+        ix->h_grp_ids = gids;
+        ix->h_grp_key = std::move(gkey);
+    }
     ix->groups_built_n = n;
     return PVS_OK;
 }
@@ -159,7 +177,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
                                            c.stream, fw, skip_when));
         for (uint32_t q = 0; q < ncol; q++) {
-            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, c.gwork, d_og, d_ov, d_oc, c.stream));
+            PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, c.gwork, d_og, d_ov, d_oc, c.stream, ix->d_grp_tinv));
             HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(out_values + (size_t)q * k, d_ov, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(out_count + q, d_oc, 4, hipMemcpyDeviceToHost, c.stream));
@@ -205,6 +223,13 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     struct GV {
         double v;
         int64_t g;
+        int64_t key;  // second sort key of the group (0 when none is set)
+    };
+    const bool keyed = !ix->h_grp_key.empty();
+    auto group_key = [&](int64_t g) -> int64_t {
+        if (!keyed) return 0;
+        auto it = std::lower_bound(ix->h_grp_ids.begin(), ix->h_grp_ids.end(), g);
+        return ix->h_grp_key[(size_t)(it - ix->h_grp_ids.begin())];
     };
     std::vector<GV> gv;
     std::vector<int64_t> seen;
@@ -231,11 +256,12 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
             for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return seen[a] < seen[b]; });
             for (size_t i = 0; i < order.size(); i++)
-                if (i == 0 || seen[order[i]] != seen[order[i - 1]]) gv.push_back({(double)qd[order[i]], seen[order[i]]});
+                if (i == 0 || seen[order[i]] != seen[order[i - 1]]) gv.push_back({(double)qd[order[i]], seen[order[i]], group_key(seen[order[i]])});
             std::sort(gv.begin(), gv.end(), [](const GV &a, const GV &b) {
-                const bool na = a.v != a.v, nb = b.v != b.v;  // NULL last, then value, then group id
+                const bool na = a.v != a.v, nb = b.v != b.v;  // NULL last, then value, then the second key DESC, then group id
                 if (na != nb) return nb;
                 if (!na && a.v != b.v) return a.v < b.v;
+                if (a.key != b.key) return a.key > b.key;
                 return a.g < b.g;
             });
             const bool complete = cnt[q] == n || cnt[q] < kp;  // the page is the whole corpus / every candidate row
@@ -729,8 +755,64 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
     return PVS_OK;
 }
 
+static pvs_status rrf_search_impl(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores, uint32_t *out_count);
+
+// The fused page under the reference's final ordering (`ORDER BY order_rank DESC ..., last_modified DESC`, pql/model.rs:547-553)
+// when the branches' rows carry order keys (pvs_index_set_order_keys): groups that tie on the fused score — two files that swap
+// places between two branches already do — come out by key descending, then group id.  The page is taken far enough past k
+// that every group tying with the k-th score is on it (or the page is everything), re-ordered on the host and cut to k.  A
+// group's key: from the first branch (in branch order) that carries keys and holds the group.
 PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
                                      uint32_t *out_count) {
+    bool keyed = false;
+    if (br && nb >= 1 && nb <= (uint32_t)PVS_RRF_MAX_BRANCHES)
+        for (uint32_t b = 0; b < nb; b++) keyed |= br[b].idx && !is_multi(br[b].idx) && br[b].idx->order_rows == br[b].idx->n && br[b].idx->n;
+    if (!keyed) return rrf_search_impl(br, nb, k, out_groups, out_scores, out_count);
+    if (!out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
+    std::vector<int64_t> g;
+    std::vector<double> sc;
+    uint32_t cnt = 0;
+    for (uint64_t kk = std::max<uint64_t>(2ull * k, (uint64_t)k + 64);; kk *= 4) {
+        kk = std::min<uint64_t>(kk, 0x7fffffffu);
+        g.resize(kk);
+        sc.resize(kk);
+        PVS_TRY(rrf_search_impl(br, nb, (uint32_t)kk, g.data(), sc.data(), &cnt));
+        if (cnt < kk || cnt <= k || sc[cnt - 1] < sc[k - 1] || kk == 0x7fffffffu) break;  // (scores are never NaN: sums of finite terms)
+    }
+    struct E {
+        double s;
+        int64_t key, g;
+    };
+    std::vector<E> e(cnt);
+    for (uint32_t i = 0; i < cnt; i++) {
+        int64_t key = INT64_MIN;
+        for (uint32_t b = 0; b < nb; b++) {
+            const pvs_index *ix = br[b].idx;
+            if (ix->h_grp_key.empty()) continue;  // (built by ensure_groups inside the search above)
+            auto it = std::lower_bound(ix->h_grp_ids.begin(), ix->h_grp_ids.end(), g[i]);
+            if (it == ix->h_grp_ids.end() || *it != g[i]) continue;
+            key = ix->h_grp_key[(size_t)(it - ix->h_grp_ids.begin())];
+            break;
+        }
+        e[i] = {sc[i], key, g[i]};
+    }
+    std::sort(e.begin(), e.end(), [](const E &a, const E &b) {
+        if (a.s != b.s) return a.s > b.s;
+        if (a.key != b.key) return a.key > b.key;
+        return a.g < b.g;
+    });
+    const uint32_t nout = std::min(cnt, k);
+    for (uint32_t i = 0; i < k; i++) {
+        out_groups[i] = i < nout ? e[i].g : -1;
+        out_scores[i] = i < nout ? e[i].s : __builtin_nan("");
+    }
+    *out_count = nout;
+    return PVS_OK;
+}
+
+static pvs_status rrf_search_impl(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
+                                  uint32_t *out_count) {
     if (!br || !out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (nb < 1 || nb > (uint32_t)PVS_RRF_MAX_BRANCHES) return pvs_fail(PVS_ERR_INVALID_ARG, "1..%d branches", PVS_RRF_MAX_BRANCHES);
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");

@@ -194,7 +194,7 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
                                       int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1);
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
-                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s);
+                          int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s, const uint32_t *g_tinv = nullptr);
 void pvs_group_work_release(GroupWork &w);
 
 // ---- reciprocal-rank fusion of several ranked branches (pvs_rrf.hip)

@@ -1547,3 +1547,103 @@ def test_second_sort_key_orders_ties_like_the_reference(pvs):
     with pytest.raises(Exception):
         ix.set_order_keys(keys)  # one key per stored row
     ix.close()
+
+
+def test_second_sort_key_orders_tied_items_like_the_reference(pvs):
+    """The per-item page under the same final ordering: files whose aggregate ties come out newest first (the file's
+    last_modified = the key its rows carry), then by file id — through the page-first MIN path and the dense aggregate + group
+    rank, for MIN / MAX / AVG, with a candidate mask, and on a page cut inside a run of ties."""
+    rng = np.random.default_rng(7)
+    dim, distinct, files = 64, 40, 900
+    base = unit_rows(321, distinct, dim)
+    per_file = rng.integers(1, 4, files)
+    grp = np.repeat(np.arange(files, dtype=np.int64) * 7 + 3, per_file)
+    n = len(grp)
+    # every row of a file is a copy of ONE base vector: aggregates of different files tie exactly
+    file_vec = rng.integers(0, distinct, files)
+    rows = base[np.repeat(file_vec, per_file)]
+    fkey = rng.integers(0, 12, files).astype(np.int64) + 1_700_000_000
+    keys = np.repeat(fkey, per_file)
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, group_ids=grp)
+    ix.set_order_keys(keys)
+    corpus = orc.quantize_int8(rows, scale)
+    qs = base[[1, 20, 39]] + 0.02 * orc.synth_rows(322, 0, 3, dim)
+    hq = orc.quantize_int8(qs, scale)
+    mask = (rng.random(n) < 0.6).astype(np.uint8)
+    allowed = np.nonzero(mask)[0]
+    differs = 0
+    for path in (0, 1):
+        ix.set_path(path)
+        for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+            for agg, oagg in ((pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_MAX, orc.AGG_MAX), (pvs.AGG_AVG, orc.AGG_AVG)):
+                for k in (1, 13, 60):
+                    og, ov, oc = ix.search_groups(qs, k, metric, agg)
+                    for j in range(len(qs)):
+                        eg, ev = orc.search_groups(orc.I8, om, corpus, hq[j], grp, oagg, k, order_keys=keys)
+                        assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (path, metric, agg, k, j)
+                        assert np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64))
+                        pg, _ = orc.search_groups(orc.I8, om, corpus, hq[j], grp, oagg, k)
+                        differs += int(not np.array_equal(pg, eg))
+            og, ov, oc = ix.search_groups_filtered(qs, 25, mask, metric, pvs.AGG_MIN)
+            for j in range(len(qs)):
+                eg, ev = orc.search_groups(orc.I8, om, corpus[allowed], hq[j], grp[allowed], orc.AGG_MIN, 25, order_keys=keys[allowed])
+                assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (path, metric, "masked", j)
+    assert differs > 20, "the corpus must tie between files, or the test shows nothing"
+    ix.set_path(0)
+    # the OR arm: fused scores tie whenever two files swap places between the branches (and massively on this corpus); with the
+    # keys the ties come out newest first — through the small-input full ranking and, on a larger corpus, the bounded fusion
+    rows2 = base[np.repeat(rng.integers(0, distinct, files), per_file)]
+    ix2 = pvs.VectorIndex(pvs.I8, dim)
+    ix2.set_scale(scale)
+    ix2.add_f32(rows2, group_ids=grp)
+    corpus2 = orc.quantize_int8(rows2, scale)
+    for k in (1, 10, 200):
+        br = [dict(index=ix, query=hq[0], metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0),
+              dict(index=ix2, query=hq[1], metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0)]
+        fg, fs = pvs.rrf_search(br, k)
+        ora = [dict(dtype=orc.I8, metric=orc.L2, corpus=corpus, query=hq[0], groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0, order_keys=keys),
+               dict(dtype=orc.I8, metric=orc.L2, corpus=corpus2, query=hq[1], groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0)]
+        eg, es = orc.rrf_search(ora, k)
+        assert np.array_equal(fg, eg) and np.array_equal(fs.view(np.uint64), es.view(np.uint64)), k
+    ix2.close()
+    ix.close()
+
+
+def test_second_sort_key_in_the_bounded_fusion(pvs):
+    """The same tie-break where pvs_rrf_search takes its bounded path (>= 65536 groups): two branches over the same files whose
+    rankings are mirror images on a stretch of files make pairs of files tie on the fused score exactly."""
+    rng = np.random.default_rng(3)
+    files, dim, k = 70_000, 32, 60
+    rows = orc.synth_rows(77, 0, files, dim)
+    grp = np.arange(files, dtype=np.int64) * 2 + 1
+    keys = rng.integers(0, 5, files).astype(np.int64)
+    ixa = pvs.VectorIndex(pvs.F32, dim)
+    ixa.add(rows, group_ids=grp)
+    ixa.set_order_keys(keys)
+    ixb = pvs.VectorIndex(pvs.F32, dim)
+    ixb.add(rows, group_ids=grp)
+    qa = rows[5] + 0.01
+    d = orc.score_all(orc.F32, orc.L2, rows, qa)
+    top = np.argsort(d, kind="stable")[:40]
+    # branch b ranks the same 40 files in reverse order: its query is irrelevant, the row weights decide (SUM(d*w)/SUM(w) = d)
+    # -> use a second corpus whose distances to qb mirror the first: simply permute the rows of those files
+    rows_b = rows.copy()
+    rows_b[top] = rows[top[::-1]]
+    ixb.close()
+    ixb = pvs.VectorIndex(pvs.F32, dim)
+    ixb.add(rows_b, group_ids=grp)
+    br = [dict(index=ixa, query=qa, metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0),
+          dict(index=ixb, query=qa, metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0)]
+    fg, fs = pvs.rrf_search(br, k)
+    assert pvs.lib().pvs_rrf_last_path() == 1
+    ora = [dict(dtype=orc.F32, metric=orc.L2, corpus=rows, query=qa, groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0, order_keys=keys),
+           dict(dtype=orc.F32, metric=orc.L2, corpus=rows_b, query=qa, groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0)]
+    eg, es = orc.rrf_search(ora, k)
+    assert np.array_equal(fg, eg) and np.array_equal(fs.view(np.uint64), es.view(np.uint64))
+    pg, _ = orc.rrf_search([{**o, "order_keys": None} for o in ora], k)
+    assert not np.array_equal(pg, eg), "the fused scores must tie"
+    ixa.close()
+    ixb.close()

@@ -695,3 +695,50 @@ def test_row_page_with_order_keys_equals_sqlites_order_by_d_last_modified_desc()
     finally:
         sqlite_seam.unbind("ties")
         ix.close()
+
+
+@pytest.mark.gpu
+def test_item_page_with_order_keys_equals_sqlites_group_by_order_by():
+    """Per-item page against SQLite itself: `SELECT file_id, MIN(d) ... GROUP BY file_id ORDER BY 2 ASC NULLS LAST,
+    last_modified DESC, file_id LIMIT k` over the `d` column of pvs_dist (exact.rs:67-80 + model.rs:547-553) must be the page
+    pvs_search_groups returns once the rows carry their file's last_modified."""
+    import panoptikon_amd as pvs
+    from panoptikon_amd import sqlite_seam
+
+    rng = np.random.default_rng(22)
+    dim, distinct, files, k = 64, 30, 700, 50
+    base = orc.synth_rows(41, 0, distinct, dim)
+    per_file = rng.integers(1, 4, files)
+    fid = np.arange(1, files + 1, dtype=np.int64) * 5
+    grp = np.repeat(fid, per_file)
+    rows = base[np.repeat(rng.integers(0, distinct, files), per_file)]
+    n = len(rows)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+    fm = rng.integers(0, 9, files).astype(np.int64) + 1_700_000_000
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids, group_ids=grp)
+    ix.set_order_keys(np.repeat(fm, per_file))
+    conn = sqlite3.connect(":memory:")
+    conn.execute("CREATE TABLE files (id INTEGER PRIMARY KEY, last_modified INTEGER NOT NULL)")
+    conn.execute("CREATE TABLE emb (id INTEGER PRIMARY KEY, file_id INTEGER NOT NULL)")
+    conn.executemany("INSERT INTO files VALUES (?, ?)", list(zip(fid.tolist(), fm.tolist())))
+    conn.executemany("INSERT INTO emb VALUES (?, ?)", list(zip(ids.tolist(), grp.tolist())))
+    sqlite_seam.load(conn)
+    sqlite_seam.bind("items", ix)
+    try:
+        for qi in (0, 11, 29):
+            q = (base[qi] + 0.01 * orc.synth_rows(42, qi, 1, dim)[0]).astype(np.float32)
+            for fn, agg in (("MIN", pvs.AGG_MIN), ("MAX", pvs.AGG_MAX)):
+                sql = f"""SELECT e.file_id, {fn}(p.d) AS v FROM pvs_dist('items', ?, 'l2') p JOIN emb e ON e.id = p.id
+                          JOIN files f ON f.id = e.file_id GROUP BY e.file_id
+                          ORDER BY v ASC NULLS LAST, f.last_modified DESC, e.file_id LIMIT ?"""
+                want = conn.execute(sql, (q.tobytes(), k)).fetchall()
+                og, ov, oc = ix.search_groups(q, k, pvs.L2, agg)
+                assert oc[0] == k and og[0, :k].tolist() == [w[0] for w in want], (qi, fn)
+                assert ov[0, :k].tolist() == [w[1] for w in want]
+                assert len({w[1] for w in want}) < 6, "the page must consist of ties"
+    finally:
+        sqlite_seam.unbind("items")
+        ix.close()
