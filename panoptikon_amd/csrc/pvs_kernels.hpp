@@ -110,6 +110,9 @@ struct FinalizeArgs {
     // segment-overflow rerun: the scan already wrote flat lists into `cand` (ScanArgs.flat); only queries whose need_dense is 2
     // are finalised, the others keep the page they have
     const uint32_t *flat_cnt = nullptr;
+    // [batch] the thresholds pass B ran with, when they were taken BELOW the k-th sample value (search_enqueue: j-th of a smaller
+    // sample): pass C then proves that k rows lie at or below T (k-th smallest upper bound <= T) or hands the query back
+    const float *thr = nullptr;
     // second sort key (pvs_index_set_order_keys): ties on the distance are ordered by tie rank instead of by row
     const uint32_t *trank = nullptr, *tinv = nullptr;
     // Optional global-memory work area: with it (int8 rows) pass C keeps its bound keys, survivor list and large sorts in HBM/L2

@@ -226,6 +226,7 @@ struct FinK {
     uint32_t *w_ub, *w_surv;       // LIGHT: global work area (FinalizeArgs.w_*)
     unsigned long long *w_sort;
     const uint32_t *flat_cnt;      // segment-overflow rerun (FinalizeArgs.flat_cnt)
+    const float *thr;              // thresholds to certify (FinalizeArgs.thr), or nullptr
     const uint32_t *trank, *tinv;  // second sort key: tie rank of a row and its inverse (FinalizeArgs.trank)
 };
 
@@ -472,9 +473,19 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     __syncthreads();
     FIN_STAMP(2);
     uint32_t kub = 0xffffffffu;
-    if (cnt > a.k) kub = radix_kth(cnt, a.k, hist, s_misc + 2, [&](uint32_t i) { return s_ub[i]; });
+    if (cnt > a.k || (a.thr && cnt == a.k)) kub = radix_kth(cnt, a.k, hist, s_misc + 2, [&](uint32_t i) { return s_ub[i]; });
     const float kappa = (kub == 0xffffffffu) ? __builtin_inff() : f32_from_sort_key(kub);
     __syncthreads();
+    // A threshold taken below the k-th sample value (a.thr set) does not by itself guarantee k rows at or below it.  The scan emitted
+    // every row whose LOWER bound is <= T; if the k-th smallest UPPER bound among them is <= T, k rows have their reference key
+    // <= T, every row of the k best has its lower bound <= T, and the list is complete.  Otherwise: the dense path.
+    if (a.thr && want == a.k && !(kappa <= a.thr[q])) {
+        if (tid == 0) {
+            a.need_dense[q] = 1;
+            a.out_count[q] = 0;
+        }
+        return;
+    }
     FIN_STAMP(3);
     // survivors: lower bound <= k-th smallest upper bound
     for (uint32_t i = tid; i < cnt; i += 256) {
@@ -614,6 +625,7 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.seg_queries = f.seg_queries;
     k.seg_cap = f.seg_cap;
     k.flat_cnt = f.flat_cnt;
+    k.thr = f.thr;
     k.trank = f.trank;
     k.tinv = f.tinv;
     k.cand = f.cand;

@@ -94,7 +94,15 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
     static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
     if (frac_env > 0.0) frac = frac_env;
-    frac = std::min(0.5, std::max(frac, 2.5 * (double)k / (double)PVS_CAND_CAP));
+    // The threshold need not be the sample's k-th value: its j-th value (j < k) from a sample j/k the size expects the same number
+    // of candidates (j / frac') at j/k of pass A's cost, with a relative spread of 1/sqrt(j).  What is lost is the guarantee that k
+    // rows lie below T — pass C certifies that from the candidates' upper bounds (FinalizeArgs.thr) and hands the query to the
+    // dense path otherwise (never seen: it needs T below the corpus' k-th value while j sample rows lie below it).
+    static const uint32_t j_div = getenv("PVS_SAMPLE_J_DIV") ? (uint32_t)std::max(1, atoi(getenv("PVS_SAMPLE_J_DIV"))) : 4u;  // tuning experiments
+    uint32_t k_sel = k;
+    if (nb > 4 && ix->n >= (1ull << 20) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
+    frac *= (double)k_sel / (double)k;
+    frac = std::min(0.5, std::max(frac, 2.5 * (double)k_sel / (double)PVS_CAND_CAP));
     const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
     const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
     a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
@@ -106,12 +114,12 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // row groups per query: >= 16k keeps the threshold within ~3 % of the finest partition (two of the
     // k best rows rarely share a group) and >= 1024; each lane can supply 1..16
     a.gmin_per_lane = pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs);
-    while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k, 1024)) a.gmin_per_lane /= 2;
+    while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k_sel, 1024)) a.gmin_per_lane /= 2;
     a.groups_per_query = a.grid * spp * a.gmin_per_lane;
     span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
     HIP_TRY(pvs_launch_scan(a, c.stream));
     span_end(ix, c);
-    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k, c.d_thr, c.stream));
+    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, c.stream));
     if (flat_rerun) {
         HIP_TRY(pvs_launch_void_thresholds(c.d_thr, c.d_need_dense + qoff, nb, c.stream));  // queries not handed back emit nothing
         HIP_TRY(hipMemsetAsync(c.d_flat_cnt, 0, 4 * (size_t)PVS_SCAN_MAX_BATCH, c.stream));
@@ -163,6 +171,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.need_dense = c.d_need_dense + qoff;
     f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
     if (flat_rerun) f.flat_cnt = c.d_flat_cnt;
+    if (k_sel < k) f.thr = c.d_thr;  // thresholds below the k-th sample value: pass C certifies them
     if (order_tinv(ix)) {
         f.trank = ix->d_trank;
         f.tinv = ix->d_tinv;

@@ -1647,3 +1647,42 @@ def test_second_sort_key_in_the_bounded_fusion(pvs):
     assert not np.array_equal(pg, eg), "the fused scores must tie"
     ixa.close()
     ixb.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16"])
+def test_threshold_below_the_kth_sample_value_is_certified_or_handed_back(pvs, dtype):
+    """Batches over >= 2^20 rows take pass B's threshold from the j-th (j = k/4) value of a sample a quarter the size.  That
+    threshold does not guarantee k rows below it; pass C certifies it (k-th smallest upper bound among the candidates <= T) or
+    hands the query to the dense path.  Adversarial corpus: the 25 best rows of query 0 all sit in sampled tiles, one per row
+    group, so its threshold lies far below the corpus' 100-th value: the filter scan sees 25 candidates (int8) or,
+    with 100 more rows inside the error band of the threshold (f16), 125 candidates whose 100-th upper bound exceeds T.  Either
+    way the page must be the oracle's; the other queries of the batch stay on the filter path."""
+    dt, odt = (pvs.I8, orc.I8) if dtype == "i8" else (pvs.F16, orc.F16)
+    rng = np.random.default_rng(2024)
+    n, dim, k = (1 << 20) + 4096, 64, 100
+    rows = unit_rows(900, n, dim)
+    qs = unit_rows(901, 8, dim)
+    v1 = qs[0] / np.linalg.norm(qs[0])
+    planted = 4096 * np.arange(25)                              # first rows of 25 sampled tiles (the sample takes every 32nd workgroup tile
+    rows[planted] = v1 * 3.0                                    # of 32, 64 or 128 rows): 25 copies of the query's direction in 25 row groups
+    ortho = rng.standard_normal(dim).astype(np.float32)
+    ortho -= ortho.dot(v1) * v1
+    ortho /= np.linalg.norm(ortho)
+    band = rng.choice(np.setdiff1d(np.arange(5000, n), planted), 100, replace=False)  # 100 rows a small angle away: inside the f16 error band of T
+    rows[band] = (v1 + 0.02 * ortho) * 3.0
+    far = rng.choice(np.setdiff1d(np.arange(5000, n), np.concatenate([band, planted])), 300, replace=False)
+    rows[far] = (v1 + 0.5 * ortho) * 3.0                        # the rest of the page comes from here
+    scale = orc.compute_int8_scale(rows)
+    ix = make_index(pvs, dt, rows, scale)
+    hc = host_corpus(odt, rows, scale)
+    hq = orc.quantize_int8(qs, scale) if dt == pvs.I8 else qs
+    before = ix.stats()
+    got = ix.search(qs, k, pvs.COSINE)
+    after = ix.stats()
+    exp = orc.search(odt, orc.COSINE, hc, hq, k)
+    assert_same_page(got, exp)
+    handed_back = after.dense_queries - before.dense_queries
+    assert 1 <= handed_back <= 2, handed_back                  # query 0 (and nothing like the whole batch)
+    assert after.fast_queries - before.fast_queries >= 6
+    ix.close()
+
