@@ -116,7 +116,7 @@ typedef struct pvs_index_desc {
      *  - WITHOUT group_ids (then no add may give them): every add splits into n_devices contiguous pieces.  The
      *    index holds no groups, so the per-item entry points fail as they do on a single-device index without
      *    group ids; everything row-wise above is served.
-     * Not served on any multi-device index: pvs_index_set_order_keys, pvs_search_bounded with a lower bound, the
+     * Not served on any multi-device index: pvs_search_bounded with a lower bound, the
      * `_sharded` (multi-process) entry points, pvs_rrf_cols.  A pvs_index_add that fails after some shards took
      * their rows leaves the index unusable (PVS_ERR_STATE from every later call): destroy and rebuild it. */
     uint32_t n_devices;
@@ -276,8 +276,10 @@ pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
  * order by (value asc, NULL last, key DESC, group id asc) and pvs_rrf_search by (score desc, key DESC, group id asc), a group's
  * key being the key of its first row (the rows of a file share files.last_modified) — for pvs_rrf_search taken from the first
  * branch that carries keys and holds the group.  `n` must equal the index's row count; rows appended later drop the keys
- * (set them again).  keys == NULL removes them.  Single-device indexes: the cross-shard merges (a multi-device index,
- * pvs_search_sharded, pvs_search_groups_sharded, pvs_rrf_search_sharded, pvs_merge_*) break ties by id only. */
+ * (set them again).  keys == NULL removes them.  Across shards: a multi-device index takes the keys in global row order and
+ * honours them everywhere (every shard's page record carries the keys of its entries; the merges compare distance, key DESC,
+ * id); pvs_search_sharded does the same when EVERY rank's index carries keys.  pvs_search_groups_sharded,
+ * pvs_rrf_search_sharded and the stand-alone pvs_merge_* functions break ties by id only. */
 pvs_status pvs_index_set_order_keys(pvs_index *idx, const int64_t *keys, uint64_t n, pvs_space space);
 
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort

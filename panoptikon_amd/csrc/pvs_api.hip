@@ -479,6 +479,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_scan_l2);
     hipFree(ix->d_trank);
     hipFree(ix->d_tinv);
+    hipFree(ix->d_order_keys);
     hipFree(ix->d_grp_off);
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
@@ -595,13 +596,15 @@ PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
 }
 PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
-    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "order keys are served on single-device indexes");
+    if (is_multi(ix)) return multi_set_order_keys(ix, keys, n, space);
     PVS_TRY(pvs_sync(ix));  // (searches in flight read the tie ranks)
     std::lock_guard<std::mutex> lk(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipFree(ix->d_trank);
     hipFree(ix->d_tinv);
+    hipFree(ix->d_order_keys);
     ix->d_trank = ix->d_tinv = nullptr;
+    ix->d_order_keys = nullptr;
     ix->order_rows = 0;
     ix->h_order_keys.clear();
     ix->groups_built_n = UINT64_MAX;  // the groups' tie order is rebuilt with the CSR
@@ -618,6 +621,8 @@ PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *key
         }
         HIP_TRY(pvs_malloc_retry((void **)&ix->d_trank, n * 4));
         HIP_TRY(pvs_malloc_retry((void **)&ix->d_tinv, n * 4));
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_order_keys, n * 8));
+        HIP_TRY(hipMemcpy(ix->d_order_keys, src, n * 8, hipMemcpyDeviceToDevice));
         PVS_TRY(pvs_build_tie_ranks(src, n, ix->d_trank, ix->d_tinv, ix->admin_stream));
         return PVS_OK;
     };
@@ -626,7 +631,9 @@ PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *key
     if (st != PVS_OK) {
         hipFree(ix->d_trank);
         hipFree(ix->d_tinv);
+        hipFree(ix->d_order_keys);
         ix->d_trank = ix->d_tinv = nullptr;
+        ix->d_order_keys = nullptr;
         return st;
     }
     ix->h_order_keys.resize(n);

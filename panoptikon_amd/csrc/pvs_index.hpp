@@ -76,6 +76,7 @@ struct SearchCtx {
     int64_t *d_loc_ids = nullptr;
     float *d_loc_dist = nullptr;
     uint32_t *d_loc_cnt = nullptr, *h_all_flags = nullptr;
+    int64_t *d_loc_keys = nullptr;
     size_t h_all_flags_cap = 0;
     uint32_t sh_world = 0;
     int64_t *p_final_ids = nullptr;
@@ -98,11 +99,8 @@ struct MultiCtx {
     bool busy = false, pending = false;
     hipStream_t stream = nullptr;  // on the root device (devices[0]): merge + result copies
     hipEvent_t done = nullptr;
-    int64_t *d_all_ids = nullptr;  // root-side gather buffers [shards][batch][k]
-    float *d_all_dist = nullptr;
-    uint32_t *d_all_cnt = nullptr;
-    uint64_t elems_cap = 0;
-    uint32_t batch_cap = 0;
+    uint8_t *d_all_rec = nullptr;  // root-side gather buffer: one packed page record per shard (pvs_page_record_*)
+    size_t all_rec_cap = 0;
     std::vector<uint32_t> tickets;       // the shard contexts this search holds
     std::vector<void *> d_q;             // per shard: the queries copied to the shard's device (null on the root device)
     std::vector<size_t> q_cap;
@@ -146,6 +144,7 @@ struct pvs_index {
     // second sort key (pvs_index_set_order_keys): d_trank[row] = position of the row in (key DESC, id ASC) order, d_tinv its inverse.
     // Wherever a page is ordered by (distance, row) the row is replaced by its tie rank and mapped back on output.
     uint32_t *d_trank = nullptr, *d_tinv = nullptr;
+    int64_t *d_order_keys = nullptr;  // the keys themselves (device): the shard merges need the key of every page entry
     uint64_t order_rows = 0;  // rows the tie ranks cover (0: none set)
     std::vector<int64_t> h_order_keys;  // host copy of the keys (the groups' tie order is built from it in ensure_groups)
     // groups in tie order (key of the group's first row DESC, group id ASC), built with the CSR when the keys cover every row
@@ -236,6 +235,10 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
 pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
                             int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k);
+// flags + order keys of the context's local page (pvs_launch_page_finish with this index's ids and keys), on stream s
+pvs_status ctx_finish_local_page(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, hipStream_t s);
+// key of a group under pvs_index_set_order_keys (false: the index carries none / does not hold the group)
+bool index_group_key(const pvs_index *ix, int64_t g, int64_t *key);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
 // d_out[row * nb + q]: exact distances of the nb queries prepared in ctx c (prep_chunk) — matrix cores for int8, k_dense_exact otherwise
@@ -265,6 +268,7 @@ void multi_destroy(pvs_index *ix);
 pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, const int64_t *group_ids,
                      pvs_space space);
 pvs_status multi_set_scale(pvs_index *ix, float scale);
+pvs_status multi_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space);
 pvs_status multi_stats(pvs_index *ix, pvs_stats *out);
 pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host);
 pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids);

@@ -766,7 +766,7 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
                                      uint32_t *out_count) {
     bool keyed = false;
     if (br && nb >= 1 && nb <= (uint32_t)PVS_RRF_MAX_BRANCHES)
-        for (uint32_t b = 0; b < nb; b++) keyed |= br[b].idx && !is_multi(br[b].idx) && br[b].idx->order_rows == br[b].idx->n && br[b].idx->n;
+        for (uint32_t b = 0; b < nb; b++) keyed |= br[b].idx && br[b].idx->order_rows == br[b].idx->n && br[b].idx->n;
     if (!keyed) return rrf_search_impl(br, nb, k, out_groups, out_scores, out_count);
     if (!out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");
@@ -787,14 +787,8 @@ PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint
     std::vector<E> e(cnt);
     for (uint32_t i = 0; i < cnt; i++) {
         int64_t key = INT64_MIN;
-        for (uint32_t b = 0; b < nb; b++) {
-            const pvs_index *ix = br[b].idx;
-            if (ix->h_grp_key.empty()) continue;  // (built by ensure_groups inside the search above)
-            auto it = std::lower_bound(ix->h_grp_ids.begin(), ix->h_grp_ids.end(), g[i]);
-            if (it == ix->h_grp_ids.end() || *it != g[i]) continue;
-            key = ix->h_grp_key[(size_t)(it - ix->h_grp_ids.begin())];
-            break;
-        }
+        for (uint32_t b = 0; b < nb; b++)
+            if (index_group_key(br[b].idx, g[i], &key)) break;  // (the groups' keys were built by ensure_groups inside the search above)
         e[i] = {sc[i], key, g[i]};
     }
     std::sort(e.begin(), e.end(), [](const E &a, const E &b) {

@@ -160,14 +160,22 @@ pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq,
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
                             uint32_t *out_count, hipStream_t s);
-// A rank's page as ONE buffer, so that the shard exchange is one all-gather: [ids i64 x batch*k | dist f32 x batch*k |
-// counts u32 x batch | flags u32 x batch], padded to 16 bytes.
+// A rank's page as ONE buffer, so that the shard exchange is one all-gather (and one peer copy inside a multi-device index):
+// [ids i64 x batch*k | dist f32 x batch*k | counts u32 x batch | flags u32 x batch | order keys i64 x batch*k], padded to 16 bytes.
+// flags[q]: the query's hand-back code (pass C) in the low bits; bit 31 = the keys section is valid (the shard carries
+// pvs_index_set_order_keys keys for all its rows).  The merge breaks distance ties by key DESC when EVERY shard's page says so.
+constexpr uint32_t PVS_PAGE_KEYED = 0x80000000u;
 inline size_t pvs_page_record_off_dist(uint32_t batch, uint32_t k) { return (size_t)batch * k * 8; }
 inline size_t pvs_page_record_off_cnt(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12; }
 inline size_t pvs_page_record_off_flags(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12 + (size_t)batch * 4; }
-inline size_t pvs_page_record_bytes(uint32_t batch, uint32_t k) { return ((size_t)batch * k * 12 + (size_t)batch * 8 + 15) / 16 * 16; }
+inline size_t pvs_page_record_off_keys(uint32_t batch, uint32_t k) { return ((size_t)batch * k * 12 + (size_t)batch * 8 + 15) / 16 * 16; }
+inline size_t pvs_page_record_bytes(uint32_t batch, uint32_t k) { return pvs_page_record_off_keys(batch, k) + ((size_t)batch * k * 8 + 15) / 16 * 16; }
 hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
                                    float *out_dist, uint32_t *out_count, hipStream_t s);
+// Completes a page record whose ids / dist / counts are written: flags[q] = need_dense[q] (| PVS_PAGE_KEYED), and with order keys
+// (d_order_keys != nullptr: one per row, rows in ascending id order d_ids[0..n)) the key of every page entry, found by its id.
+hipError_t pvs_launch_page_finish(uint8_t *rec, uint32_t batch, uint32_t k, const uint32_t *need_dense, const int64_t *d_ids, uint64_t n,
+                                  const int64_t *d_order_keys, hipStream_t s);
 
 // ---- per-item aggregation and ranking (pvs_groups.hip)
 struct GroupWork {

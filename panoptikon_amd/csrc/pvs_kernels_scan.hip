@@ -666,25 +666,33 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
 // Rank-based merge of `world` sorted pages per query: the output slot of an entry is
 // the number of entries (over all shards) that precede it under (NaN last, distance,
 // id).  Shards hold disjoint id sets, so ranks are a permutation.
-__device__ static inline bool page_less(float da, int64_t ia, float db, int64_t ib) {
-    const uint32_t ka = f32_sort_key(da), kb = f32_sort_key(db);
-    if (ka != kb) return ka < kb;
+__device__ static inline bool page_less(float da, int64_t ka, int64_t ia, float db, int64_t kb, int64_t ib) {
+    const uint32_t sa = f32_sort_key(da), sb = f32_sort_key(db);
+    if (sa != sb) return sa < sb;
+    if (ka != kb) return ka > kb;  // second sort key DESC (all zero when the pages carry none)
     return ia < ib;
 }
-// The pages of `world` shards, either as three arrays [world][batch][k] / [world][batch] (one process, several GPUs: peer copies)
-// or as `world` packed records [ids | dist | counts | flags] of `rec` bytes each (one RCCL all-gather of one buffer per rank).
+// The pages of `world` shards, either as three arrays [world][batch][k] / [world][batch] (pvs_merge_topk_device) or as `world`
+// packed records (pvs_page_record_*) of `rec` bytes each (one RCCL all-gather of one buffer per rank; one peer copy per shard).
 struct MergePages {
     const uint8_t *ids, *dist, *cnt;   // rank 0's arrays
-    size_t stride_ids, stride_dist, stride_cnt;  // bytes from one rank's array to the next
+    const uint8_t *flags, *keys;       // packed records only (nullptr: no order keys)
+    size_t stride_ids, stride_dist, stride_cnt, stride_flags, stride_keys;  // bytes from one rank's array to the next
     __device__ const int64_t *ids_of(uint32_t w) const { return (const int64_t *)(ids + (size_t)w * stride_ids); }
     __device__ const float *dist_of(uint32_t w) const { return (const float *)(dist + (size_t)w * stride_dist); }
     __device__ const uint32_t *cnt_of(uint32_t w) const { return (const uint32_t *)(cnt + (size_t)w * stride_cnt); }
+    __device__ const uint32_t *flags_of(uint32_t w) const { return (const uint32_t *)(flags + (size_t)w * stride_flags); }
+    __device__ const int64_t *keys_of(uint32_t w) const { return (const int64_t *)(keys + (size_t)w * stride_keys); }
 };
 __global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
                                                uint32_t *out_count) {
     const uint32_t q = blockIdx.x;
     uint32_t total = 0;
-    for (uint32_t w = 0; w < world; w++) total += pg.cnt_of(w)[q];
+    bool keyed = pg.keys != nullptr;
+    for (uint32_t w = 0; w < world; w++) {
+        total += pg.cnt_of(w)[q];
+        if (keyed && pg.cnt_of(w)[q]) keyed = (pg.flags_of(w)[q] & PVS_PAGE_KEYED) != 0;  // every shard with entries must carry keys, or none is used
+    }
     const uint32_t nout = total < k ? total : k;
     for (uint32_t e = threadIdx.x; e < world * k; e += 256) {
         const uint32_t w = e / k, p = e % k;
@@ -692,15 +700,17 @@ __global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, ui
         const size_t off = (size_t)q * k;
         const float d = pg.dist_of(w)[off + p];
         const int64_t id = pg.ids_of(w)[off + p];
+        const int64_t key = keyed ? pg.keys_of(w)[off + p] : 0;
         uint32_t rank = p;
         for (uint32_t w2 = 0; w2 < world; w2++) {
             if (w2 == w) continue;
             const int64_t *i2 = pg.ids_of(w2) + off;
             const float *d2 = pg.dist_of(w2) + off;
+            const int64_t *k2 = keyed ? pg.keys_of(w2) + off : nullptr;
             uint32_t lo = 0, hi = pg.cnt_of(w2)[q];
-            while (lo < hi) {  // first entry of shard w2 that does not precede (d, id)
+            while (lo < hi) {  // first entry of shard w2 that does not precede (d, key, id)
                 const uint32_t mid = (lo + hi) >> 1;
-                if (page_less(d2[mid], i2[mid], d, id)) lo = mid + 1;
+                if (page_less(d2[mid], keyed ? k2[mid] : 0, i2[mid], d, key, id)) lo = mid + 1;
                 else hi = mid;
             }
             rank += lo;
@@ -722,6 +732,8 @@ hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_
     pg.ids = (const uint8_t *)ids;
     pg.dist = (const uint8_t *)dist;
     pg.cnt = (const uint8_t *)counts;
+    pg.flags = pg.keys = nullptr;
+    pg.stride_flags = pg.stride_keys = 0;
     pg.stride_ids = (size_t)batch * k * 8;
     pg.stride_dist = (size_t)batch * k * 4;
     pg.stride_cnt = (size_t)batch * 4;
@@ -735,7 +747,35 @@ hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uin
     pg.ids = all_rec;
     pg.dist = all_rec + pvs_page_record_off_dist(batch, k);
     pg.cnt = all_rec + pvs_page_record_off_cnt(batch, k);
-    pg.stride_ids = pg.stride_dist = pg.stride_cnt = rec_bytes;
+    pg.flags = all_rec + pvs_page_record_off_flags(batch, k);
+    pg.keys = all_rec + pvs_page_record_off_keys(batch, k);
+    pg.stride_ids = pg.stride_dist = pg.stride_cnt = pg.stride_flags = pg.stride_keys = rec_bytes;
     hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count);
+    return hipGetLastError();
+}
+
+// flags and order keys of a finished local page (pvs_launch_page_finish)
+__global__ void k_page_finish(uint8_t *rec, size_t off_flags, size_t off_keys, uint32_t batch, uint32_t k, const uint32_t *need_dense,
+                              const int64_t *ids_sorted, uint64_t n, const int64_t *order_keys) {
+    const int64_t *pid = (const int64_t *)rec;
+    uint32_t *flags = (uint32_t *)(rec + off_flags);
+    int64_t *keys = (int64_t *)(rec + off_keys);
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < batch) flags[e] = (need_dense[e] & ~PVS_PAGE_KEYED) | (order_keys ? PVS_PAGE_KEYED : 0u);
+    if (!order_keys || e >= batch * k) return;
+    const int64_t id = pid[e];
+    uint64_t lo = 0, hi = n;  // ids are strictly increasing in row order
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ids_sorted[mid] < id) lo = mid + 1;
+        else hi = mid;
+    }
+    keys[e] = (lo < n && ids_sorted[lo] == id) ? order_keys[lo] : 0;  // (padding entries: id -1)
+}
+hipError_t pvs_launch_page_finish(uint8_t *rec, uint32_t batch, uint32_t k, const uint32_t *need_dense, const int64_t *d_ids, uint64_t n,
+                                  const int64_t *d_order_keys, hipStream_t s) {
+    const uint32_t total = batch * k > batch ? batch * k : batch;
+    hipLaunchKernelGGL(k_page_finish, dim3((total + 255) / 256), dim3(256), 0, s, rec, pvs_page_record_off_flags(batch, k), pvs_page_record_off_keys(batch, k), batch, k,
+                       need_dense, d_ids, n, d_order_keys);
     return hipGetLastError();
 }

@@ -20,9 +20,7 @@ namespace {
 int root_device(const pvs_index *ix) { return ix->shards[0]->device; }
 
 void mctx_release(MultiCtx &m) {
-    hipFree(m.d_all_ids);
-    hipFree(m.d_all_dist);
-    hipFree(m.d_all_cnt);
+    hipFree(m.d_all_rec);
     hipFree(m.d_qroot);
     hipFree(m.d_out_ids);
     hipFree(m.d_out_dist);
@@ -67,35 +65,25 @@ pvs_status mctx_prepare(pvs_index *ix, MultiCtx &m, uint32_t batch, uint32_t k) 
     HIP_TRY(hipSetDevice(root_device(ix)));
     if (!m.stream) HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
     if (!m.done) HIP_TRY(hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
-    const uint64_t elems = (uint64_t)batch * k;
-    if (elems > m.elems_cap || batch > m.batch_cap) {
-        hipFree(m.d_all_ids);
-        hipFree(m.d_all_dist);
-        hipFree(m.d_all_cnt);
-        m.d_all_ids = nullptr;
-        m.d_all_dist = nullptr;
-        m.d_all_cnt = nullptr;
-        m.elems_cap = 0;
-        m.batch_cap = 0;
-        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_ids, elems * 8 * S));
-        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_dist, elems * 4 * S));
-        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_cnt, (size_t)batch * 4 * S));
-        m.elems_cap = elems;
-        m.batch_cap = batch;
+    const size_t need = pvs_page_record_bytes(batch, k) * S;
+    if (need > m.all_rec_cap) {
+        hipFree(m.d_all_rec);
+        m.d_all_rec = nullptr;
+        m.all_rec_cap = 0;
+        HIP_TRY(pvs_malloc_retry((void **)&m.d_all_rec, need));
+        m.all_rec_cap = need;
     }
     m.d_q.resize(S, nullptr);
     m.q_cap.resize(S, 0);
     return PVS_OK;
 }
 
-// shard s's page -> its slot of the root's gather buffers, on the shard's stream
+// shard s's page record (flags and order keys completed) -> its slot of the root's gather buffer: one peer copy on the shard's stream
 pvs_status ship_page(pvs_index *ix, MultiCtx &m, uint32_t s, SearchCtx &c, uint32_t batch, uint32_t k) {
     pvs_index *sh = ix->shards[s];
     const int root = root_device(ix);
-    const uint64_t elems = (uint64_t)batch * k;
-    HIP_TRY(hipMemcpyPeerAsync(m.d_all_ids + s * elems, root, c.d_loc_ids, sh->device, elems * 8, c.stream));
-    HIP_TRY(hipMemcpyPeerAsync(m.d_all_dist + s * elems, root, c.d_loc_dist, sh->device, elems * 4, c.stream));
-    HIP_TRY(hipMemcpyPeerAsync(m.d_all_cnt + (size_t)s * batch, root, c.d_loc_cnt, sh->device, (size_t)batch * 4, c.stream));
+    PVS_TRY(ctx_finish_local_page(sh, c, batch, k, c.stream));
+    HIP_TRY(hipMemcpyPeerAsync(m.d_all_rec + (size_t)s * c.rec_bytes, root, c.d_loc_rec, sh->device, c.rec_bytes, c.stream));
     return PVS_OK;
 }
 
@@ -138,7 +126,7 @@ pvs_status multi_enqueue(pvs_index *ix, MultiCtx &m, const void *d_queries, pvs_
         HIP_TRY(hipStreamWaitEvent(m.stream, c->done, 0));
     }
     HIP_TRY(hipSetDevice(root));
-    HIP_TRY(pvs_launch_merge(m.d_all_ids, m.d_all_dist, m.d_all_cnt, S, batch, k, d_out_ids, d_out_dist, d_out_count, m.stream));
+    HIP_TRY(pvs_launch_merge_packed(m.d_all_rec, pvs_page_record_bytes(batch, k), S, batch, k, d_out_ids, d_out_dist, d_out_count, m.stream));
     HIP_TRY(hipEventRecord(m.done, m.stream));
     m.p_queries = d_queries;
     m.p_qdtype = qdtype;
@@ -187,8 +175,8 @@ pvs_status multi_complete(pvs_index *ix, MultiCtx &m) {
     ix->fast_queries += m.p_batch - nd;
     if (redo) {
         HIP_TRY(hipSetDevice(root));
-        HIP_TRY(pvs_launch_merge(m.d_all_ids, m.d_all_dist, m.d_all_cnt, S, m.p_batch, m.p_k, m.p_out_ids, m.p_out_dist, m.p_out_count,
-                                 m.stream));
+        HIP_TRY(pvs_launch_merge_packed(m.d_all_rec, pvs_page_record_bytes(m.p_batch, m.p_k), S, m.p_batch, m.p_k, m.p_out_ids, m.p_out_dist,
+                                        m.p_out_count, m.stream));
         HIP_TRY(hipStreamSynchronize(m.stream));
     }
     return PVS_OK;
@@ -434,6 +422,30 @@ pvs_status multi_set_scale(pvs_index *ix, float scale) {
     return PVS_OK;
 }
 
+// pvs_index_set_order_keys on a multi-device index: the keys (global row order) split into the shards' row orders; every shard
+// orders its own pages with them and attaches the keys to its page records, the root's merge compares (distance, key DESC, id)
+pvs_status multi_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(multi_sync(ix));
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->order_rows = 0;
+    ix->h_order_keys.clear();
+    if (!keys) {
+        for (pvs_index *sh : ix->shards) PVS_TRY(pvs_index_set_order_keys(sh, nullptr, 0, PVS_HOST));
+        return PVS_OK;
+    }
+    if (n != ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "%llu order keys for %llu rows: one key per stored row", (unsigned long long)n, (unsigned long long)ix->n);
+    ix->h_order_keys.resize(n);
+    if (space == PVS_HOST)
+        memcpy(ix->h_order_keys.data(), keys, n * 8);
+    else if (n)
+        HIP_TRY(hipMemcpy(ix->h_order_keys.data(), keys, n * 8, hipMemcpyDeviceToHost));
+    const auto per = split_rows<int64_t>(ix, ix->h_order_keys.data());
+    for (size_t s = 0; s < ix->shards.size(); s++) PVS_TRY(pvs_index_set_order_keys(ix->shards[s], per[s].data(), per[s].size(), PVS_HOST));
+    ix->order_rows = n;
+    return PVS_OK;
+}
+
 pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
     pvs_stats s;
     memset(&s, 0, sizeof s);
@@ -616,6 +628,64 @@ pvs_status multi_score_all(pvs_index *ix, const void *query, pvs_dtype qdtype, p
     return PVS_OK;
 }
 
+// key of group g under pvs_index_set_order_keys (the key of the group's first row; built with the group CSR, ensure_groups)
+bool index_group_key(const pvs_index *ix, int64_t g, int64_t *key) {
+    if (is_multi(ix)) {
+        if (!ix->by_group || ix->order_rows != ix->n) return false;
+        return index_group_key(ix->shards[multi_group_shard(g, (uint32_t)ix->shards.size())], g, key);
+    }
+    if (ix->h_grp_key.empty()) return false;
+    auto it = std::lower_bound(ix->h_grp_ids.begin(), ix->h_grp_ids.end(), g);
+    if (it == ix->h_grp_ids.end() || *it != g) return false;
+    *key = ix->h_grp_key[(size_t)(it - ix->h_grp_ids.begin())];
+    return true;
+}
+
+// Host merge of the shards' per-item pages [S][batch][k]: duplicates of a group folded to their minimum, then (value asc, NULL
+// last, order key DESC when the index carries keys, group id asc) -> first k
+static void merge_group_pages_host(const pvs_index *ix, const std::vector<int64_t> &g, const std::vector<double> &v, const std::vector<uint32_t> &c,
+                                   uint32_t S, uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    struct GV {
+        double v;
+        int64_t g, key;
+    };
+    const size_t elems = (size_t)batch * k;
+    const bool keyed = ix->order_rows == ix->n && ix->n;
+    std::vector<GV> all;
+    for (uint32_t q = 0; q < batch; q++) {
+        all.clear();
+        for (uint32_t s = 0; s < S; s++)
+            for (uint32_t i = 0; i < c[(size_t)s * batch + q]; i++) {
+                GV e{v[s * elems + (size_t)q * k + i], g[s * elems + (size_t)q * k + i], 0};
+                if (keyed) (void)index_group_key(ix->shards[s], e.g, &e.key);
+                all.push_back(e);
+            }
+        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
+            if (a.g != b.g) return a.g < b.g;
+            const bool na = a.v != a.v, nb = b.v != b.v;
+            if (na != nb) return nb;
+            return a.v < b.v;
+        });
+        size_t w = 0;
+        for (size_t i = 0; i < all.size(); i++)
+            if (i == 0 || all[i].g != all[i - 1].g) all[w++] = all[i];
+        all.resize(w);
+        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
+            const bool na = a.v != a.v, nb = b.v != b.v;
+            if (na != nb) return nb;
+            if (!na && a.v != b.v) return a.v < b.v;
+            if (a.key != b.key) return a.key > b.key;
+            return a.g < b.g;
+        });
+        const uint32_t nout = (uint32_t)std::min<size_t>(k, all.size());
+        for (uint32_t i = 0; i < k; i++) {
+            out_groups[(size_t)q * k + i] = i < nout ? all[i].g : -1;
+            out_values[(size_t)q * k + i] = i < nout ? all[i].v : __builtin_nan("");
+        }
+        out_count[q] = nout;
+    }
+}
+
 // a candidate mask over the global rows as host bytes (device-space masks are read back: the per-shard masks are gathers)
 static pvs_status host_mask(pvs_index *ix, const uint8_t *mask, pvs_space space, std::vector<uint8_t> &stage, const uint8_t **out) {
     *out = mask;
@@ -666,7 +736,46 @@ pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype q
                            cnt.data() + (size_t)s * batch);
     }));
     ix->searches++;
-    return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
+    if (!(ix->order_rows == ix->n && ix->n)) return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
+    // with order keys: (distance asc, NULL last, key DESC, id asc); a row's key by its id through the global id list
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_ids_cache.size() != ix->n) {
+            ix->h_ids_cache.resize(ix->n);
+            PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
+        }
+    }
+    struct E {
+        uint32_t dk;
+        int64_t key, id;
+        float d;
+    };
+    std::vector<E> all;
+    for (uint32_t q = 0; q < batch; q++) {
+        all.clear();
+        for (uint32_t s = 0; s < S; s++)
+            for (uint32_t i = 0; i < cnt[(size_t)s * batch + q]; i++) {
+                const float d = dist[s * elems + (size_t)q * k + i];
+                const int64_t id = ids[s * elems + (size_t)q * k + i];
+                const size_t row = (size_t)(std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), id) - ix->h_ids_cache.begin());
+                uint32_t b;
+                memcpy(&b, &d, 4);
+                const uint32_t dk = d != d ? 0xffffffffu : ((b >> 31) ? ~b : (b | 0x80000000u));
+                all.push_back({dk, ix->h_order_keys[row], id, d});
+            }
+        std::sort(all.begin(), all.end(), [](const E &a, const E &b) {
+            if (a.dk != b.dk) return a.dk < b.dk;
+            if (a.key != b.key) return a.key > b.key;
+            return a.id < b.id;
+        });
+        const uint32_t nout = (uint32_t)std::min<size_t>(k, all.size());
+        for (uint32_t i = 0; i < k; i++) {
+            out_ids[(size_t)q * k + i] = i < nout ? all[i].id : -1;
+            out_dist[(size_t)q * k + i] = i < nout ? all[i].d : __builtin_nanf("");
+        }
+        out_count[q] = nout;
+    }
+    return PVS_OK;
 }
 
 // pvs_score_batch on a multi-device index: one dense matrix per shard, scattered into global row order
@@ -719,39 +828,7 @@ pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdt
                                   hm ? masks[s].data() : nullptr, PVS_HOST, g.data() + s * elems, v.data() + s * elems,
                                   c.data() + (size_t)s * batch);
     }));
-    struct GV {
-        double v;
-        int64_t g;
-    };
-    std::vector<GV> all;
-    for (uint32_t q = 0; q < batch; q++) {
-        all.clear();
-        for (uint32_t s = 0; s < S; s++)
-            for (uint32_t i = 0; i < c[(size_t)s * batch + q]; i++) all.push_back({v[s * elems + (size_t)q * k + i], g[s * elems + (size_t)q * k + i]});
-        // fold duplicates: smallest non-NULL value of the group
-        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
-            if (a.g != b.g) return a.g < b.g;
-            const bool na = a.v != a.v, nb = b.v != b.v;
-            if (na != nb) return nb;
-            return a.v < b.v;
-        });
-        size_t w = 0;
-        for (size_t i = 0; i < all.size(); i++)
-            if (i == 0 || all[i].g != all[i - 1].g) all[w++] = all[i];
-        all.resize(w);
-        std::sort(all.begin(), all.end(), [](const GV &a, const GV &b) {
-            const bool na = a.v != a.v, nb = b.v != b.v;
-            if (na != nb) return nb;
-            if (!na && a.v != b.v) return a.v < b.v;
-            return a.g < b.g;
-        });
-        const uint32_t nout = (uint32_t)std::min<size_t>(k, all.size());
-        for (uint32_t i = 0; i < k; i++) {
-            out_groups[(size_t)q * k + i] = i < nout ? all[i].g : -1;
-            out_values[(size_t)q * k + i] = i < nout ? all[i].v : __builtin_nan("");
-        }
-        out_count[q] = nout;
-    }
+    merge_group_pages_host(ix, g, v, c, S, batch, k, out_groups, out_values, out_count);
     ix->searches++;
     return PVS_OK;
 }
@@ -787,7 +864,8 @@ pvs_status multi_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32
         return similar_core(ix->shards[s], tg, n_targets, excluded[s], k, metric, mine, g.data() + s * elems, v.data() + s * elems, &c[s]);
     }));
     ix->searches++;
-    return pvs_merge_group_pages(g.data(), v.data(), c.data(), S, 1, k, out_groups, out_values, out_count);
+    merge_group_pages_host(ix, g, v, c, S, 1, k, out_groups, out_values, out_count);
+    return PVS_OK;
 }
 
 // pvs_rrf_search over multi-device branches placed BY GROUP: shard s of every branch is rank s of the sharded protocol

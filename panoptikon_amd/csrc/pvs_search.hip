@@ -756,10 +756,10 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
 
 // The shard exchange of a row search: this rank's flags join its page record, ONE all-gather of the records over xGMI, the
 // merge on every rank, the gathered flags to the host (every rank sees the same flags and so agrees on a redo).  Stream-ordered.
-static pvs_status exchange_pages(SearchCtx &c, pvs_comm *comm, uint32_t batch, uint32_t k, uint32_t world, int64_t *d_out_ids, float *d_out_dist,
+static pvs_status exchange_pages(pvs_index *ix, SearchCtx &c, pvs_comm *comm, uint32_t batch, uint32_t k, uint32_t world, int64_t *d_out_ids, float *d_out_dist,
                                  uint32_t *d_out_count, hipStream_t cs) {
     const size_t off_flags = pvs_page_record_off_flags(batch, k);
-    HIP_TRY(hipMemcpyAsync(c.d_loc_rec + off_flags, c.d_need_dense, (size_t)batch * 4, hipMemcpyDeviceToDevice, cs));
+    PVS_TRY(ctx_finish_local_page(ix, c, batch, k, cs));
     PVS_TRY(pvs_comm_gather_records_(comm, c.d_loc_rec, c.d_all_rec, c.rec_bytes, cs));
     HIP_TRY(pvs_launch_merge_packed(c.d_all_rec, c.rec_bytes, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
     HIP_TRY(hipMemcpy2DAsync(c.h_all_flags, (size_t)batch * 4, c.d_all_rec + off_flags, c.rec_bytes, (size_t)batch * 4, world, hipMemcpyDeviceToHost, cs));
@@ -782,7 +782,7 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
     if (st == PVS_OK && c->p_comm) {
         // every rank sees the same gathered flags, so they all agree on whether to redo
         bool redo = false;
-        for (uint64_t i = 0; i < (uint64_t)c->sh_world * c->p_batch; i++) redo |= c->h_all_flags[i] != 0;
+        for (uint64_t i = 0; i < (uint64_t)c->sh_world * c->p_batch; i++) redo |= (c->h_all_flags[i] & ~PVS_PAGE_KEYED) != 0;
         if (!redo) {
             ix->fast_queries += c->p_fast ? c->p_batch : 0;
         } else {
@@ -795,7 +795,7 @@ PVS_EXPORT pvs_status pvs_wait(pvs_index *ix, uint32_t ticket) {
                 hipError_t e2 = hipMemsetAsync(c->d_need_dense, 0, 4 * (size_t)c->p_batch, cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "memset: %s", hipGetErrorString(e2));
             }
-            if (st == PVS_OK) st = exchange_pages(*c, c->p_comm, c->p_batch, c->p_k, c->sh_world, c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
+            if (st == PVS_OK) st = exchange_pages(ix, *c, c->p_comm, c->p_batch, c->p_k, c->sh_world, c->p_final_ids, c->p_final_dist, c->p_final_count, cs);
             if (st == PVS_OK) {
                 hipError_t e2 = hipStreamSynchronize(cs);
                 if (e2 != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "sharded redo: %s", hipGetErrorString(e2));
@@ -825,6 +825,12 @@ pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k) {
     c.d_loc_ids = (int64_t *)c.d_loc_rec;
     c.d_loc_dist = (float *)(c.d_loc_rec + pvs_page_record_off_dist(batch, k));
     c.d_loc_cnt = (uint32_t *)(c.d_loc_rec + pvs_page_record_off_cnt(batch, k));
+    c.d_loc_keys = (int64_t *)(c.d_loc_rec + pvs_page_record_off_keys(batch, k));
+    return PVS_OK;
+}
+pvs_status ctx_finish_local_page(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, hipStream_t s) {
+    const bool keyed = ix->order_rows == ix->n && ix->n && ix->d_order_keys;
+    HIP_TRY(pvs_launch_page_finish(c.d_loc_rec, batch, k, c.d_need_dense, ix->d_ids, ix->n, keyed ? ix->d_order_keys : nullptr, s));
     return PVS_OK;
 }
 
@@ -871,7 +877,7 @@ PVS_EXPORT pvs_status pvs_search_sharded_async(pvs_index *ix, pvs_comm *comm, co
         hipStream_t cs = ix->comm_stream;
         HIP_TRY(hipStreamWaitEvent(cs, c->done, 0));  // c->done was just recorded behind the local search
         span_begin(ix, *c, 3, 0, cs);
-        PVS_TRY(exchange_pages(*c, comm, batch, k, world, d_out_ids, d_out_dist, d_out_count, cs));
+        PVS_TRY(exchange_pages(ix, *c, comm, batch, k, world, d_out_ids, d_out_dist, d_out_count, cs));
         span_end(ix, *c, cs);
         HIP_TRY(hipEventRecord(c->done, cs));
         {

@@ -615,3 +615,114 @@ def test_pass_c_in_global_memory_on_several_streams(pvs):
     finally:
         ix.set_streams(1)
         ix.close()
+
+
+def test_second_sort_key_across_the_shards_of_a_multi_device_index(pvs):
+    """pvs_index_set_order_keys on a multi-device index: every shard orders its pages with its rows' keys and ships the keys of the
+    page entries with the page record; the root's merge compares (distance, key DESC, id).  Tie-heavy int8 L2 corpus (few
+    distinct vectors): the row page, the masked row page, the per-item pages, similar_to and the RRF page must equal the oracle's
+    ordering over the whole corpus — and differ from the id-only ordering, or the test shows nothing."""
+    rng = np.random.default_rng(12)
+    dim, distinct, files, k = 64, 40, 1500, 60
+    base = orc.synth_rows(201, 0, distinct, dim)
+    per_file = rng.integers(1, 4, files)
+    grp = np.repeat(np.arange(files, dtype=np.int64) * 3 + 2, per_file)
+    rows = base[np.repeat(rng.integers(0, distinct, files), per_file)]
+    n = len(rows)
+    ids = np.arange(n, dtype=np.int64) * 2 + 7
+    fkey = rng.integers(0, 10, files).astype(np.int64) + 1_700_000_000
+    keys = np.repeat(fkey, per_file)
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    qs = base[[2, 17, 33]] + 0.02 * orc.synth_rows(202, 0, 3, dim)
+    hq = orc.quantize_int8(qs, scale)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    allowed = np.nonzero(mask)[0]
+    for devices in _layouts(pvs):
+        tag = f"devices={devices}"
+        ix = pvs.VectorIndex(pvs.I8, dim, devices=devices)
+        ix.set_scale(scale)
+        ix.add_f32(rows, row_ids=ids, group_ids=grp)
+        ix.set_order_keys(keys)
+        differs = 0
+        for path in (0, 1):
+            ix.set_path(path)
+            gi, gd, gc = ix.search(qs, k, pvs.L2)
+            fi, fd, fc = ix.search_filtered(qs, k, mask, pvs.L2)
+            for j in range(len(qs)):
+                d = orc.score_all(orc.I8, orc.L2, codes, hq[j])
+                ei, ed = orc.topk_ordered(d, k, ids, keys)
+                assert gc[j] == k and np.array_equal(gi[j], ei) and np.array_equal(gd[j].view(np.uint32), ed.view(np.uint32)), (tag, path, j)
+                pi, _ = orc.topk(d, k, ids=ids)
+                differs += int(not np.array_equal(pi, ei))
+                ei, ed = orc.topk_ordered(d[allowed], k, ids[allowed], keys[allowed])
+                assert fc[j] == k and np.array_equal(fi[j], ei), (tag, path, j, "masked")
+        ix.set_path(0)
+        assert differs >= 3, "the corpus must tie across shards"
+        for agg, oagg in ((pvs.AGG_MIN, orc.AGG_MIN), (pvs.AGG_AVG, orc.AGG_AVG)):
+            og, ov, oc = ix.search_groups(qs, k, pvs.L2, agg)
+            for j in range(len(qs)):
+                eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[j], grp, oagg, k, order_keys=keys)
+                assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg) and np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), (tag, agg, j)
+        # OR arm over two multi-device branches: score ties by key
+        rows2 = base[np.repeat(rng.integers(0, distinct, files), per_file)]
+        ix2 = pvs.VectorIndex(pvs.I8, dim, devices=devices)
+        ix2.set_scale(scale)
+        ix2.add_f32(rows2, row_ids=ids, group_ids=grp)
+        codes2 = orc.quantize_int8(rows2, scale)
+        br = [dict(index=ix, query=hq[0], metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0),
+              dict(index=ix2, query=hq[1], metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0)]
+        fg, fs = pvs.rrf_search(br, 80)
+        ora = [dict(dtype=orc.I8, metric=orc.L2, corpus=codes, query=hq[0], groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0, order_keys=keys),
+               dict(dtype=orc.I8, metric=orc.L2, corpus=codes2, query=hq[1], groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0)]
+        eg, es = orc.rrf_search(ora, 80)
+        assert np.array_equal(fg, eg) and np.array_equal(fs.view(np.uint64), es.view(np.uint64)), tag
+        # removing the keys restores the id order; adding rows drops them
+        ix.set_order_keys(None)
+        gi, gd, gc = ix.search(qs[:1], k, pvs.L2)
+        pi, _ = orc.topk(orc.score_all(orc.I8, orc.L2, codes, hq[0]), k, ids=ids)
+        assert np.array_equal(gi[0], pi), tag
+        ix2.close()
+        ix.close()
+
+
+def test_sharded_row_search_ships_order_keys_in_the_page_record(pvs):
+    """pvs_search_sharded with order keys: the page record carries the keys of its entries and the keyed flag (one rank here: the
+    merge is the identity, but the record layout, the key lookup by id and the flag handling on the redo path all run)."""
+    rng = np.random.default_rng(13)
+    dim, distinct, copies, k = 64, 30, 80, 50
+    base = orc.synth_rows(211, 0, distinct, dim)
+    rows = np.tile(base, (copies, 1))[rng.permutation(distinct * copies)]
+    rows[77] = 0.0
+    n = len(rows)
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    keys = rng.integers(0, 30, n).astype(np.int64)
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, row_ids=ids)
+    ix.set_order_keys(keys)
+    from panoptikon_amd import _lib as L
+
+    uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+    L.check(pvs.lib().pvs_comm_unique_id(uid))
+    comm = C.c_void_p()
+    L.check(pvs.lib().pvs_comm_create(uid, 1, 0, 0, C.byref(comm)))
+    qs = (base[[1, 9, 22]] + 0.02 * orc.synth_rows(212, 0, 3, dim)).astype(np.float32)
+    hq = orc.quantize_int8(qs, scale)
+    try:
+        dq = pvs.DeviceBuffer.from_numpy(qs, 0)
+        # cosine with k = 2400 = every row: the NULL row is inside the page, so the queries go through the dense redo + second exchange
+        for metric, om, kq in ((pvs.L2, orc.L2, k), (pvs.COSINE, orc.COSINE, k), (pvs.COSINE, orc.COSINE, n)):
+            b = len(qs)
+            oi, od, oc = pvs.DeviceBuffer(b * kq * 8, 0), pvs.DeviceBuffer(b * kq * 4, 0), pvs.DeviceBuffer(b * 4, 0)
+            L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dq.ptr, L.F32, b, kq, metric, oi.ptr, od.ptr, oc.ptr))
+            gi, gc = oi.to_numpy(np.int64, (b, kq)), oc.to_numpy(np.uint32, (b,))
+            for j in range(b):
+                d = orc.score_all(orc.I8, om, codes, hq[j])
+                ei, ed = orc.topk_ordered(d, kq, ids, keys)
+                assert gc[j] == len(ei) and np.array_equal(gi[j, : gc[j]], ei), (metric, kq, j)
+    finally:
+        pvs.lib().pvs_comm_destroy(comm)
+        ix.close()
