@@ -100,7 +100,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // dense path otherwise (never seen: it needs T below the corpus' k-th value while j sample rows lie below it).
     static const uint32_t j_div = getenv("PVS_SAMPLE_J_DIV") ? (uint32_t)std::max(1, atoi(getenv("PVS_SAMPLE_J_DIV"))) : 4u;  // tuning experiments
     uint32_t k_sel = k;
-    if (nb > 4 && ix->n >= (1ull << 20) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
+    if (nb > 4 && ix->n >= (1ull << 18) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
     frac *= (double)k_sel / (double)k;
     frac = std::min(0.5, std::max(frac, 2.5 * (double)k_sel / (double)PVS_CAND_CAP));
     const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
