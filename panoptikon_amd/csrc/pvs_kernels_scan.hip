@@ -356,6 +356,15 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     // ---- gather: the scan left this query's candidates in one segment per workgroup row stream (no atomics on its side);
     // prefix-sum the fill counts (offsets live in the not-yet-used bound array) and copy the segments into one flat list.
     uint2 *const flat = a.cand + (size_t)q * a.cand_cap;
+    // A list of <= FIN_STAGE candidates (the usual ~1.6k) never leaves the chip: the pairs and the rows' |a|^2 are staged in the
+    // parts of the LDS carve-out that nothing else uses at that size — pairs above the first FIN_STAGE sort records, |a|^2 in
+    // the upper half of the survivor list (m <= cnt <= FIN_STAGE) — instead of a global list that every later phase reads back
+    // (each read a round trip to L2: the gather, the bounds and the survivor pass were 12 + 6 + 5 us of a 35-us workgroup).
+    constexpr uint32_t FIN_STAGE = 4096;
+    static_assert(FIN_STAGE * 8 * 2 <= PVS_CAND_CAP * 4 && FIN_STAGE * 2 <= PVS_SURV_CAP, "staging areas overlap");
+    uint2 *const s_cand = (uint2 *)(smem + FIN_STAGE * 8);
+    float *const s_aa = (float *)(smem + PVS_CAND_CAP * 4 + FIN_STAGE * 4);
+    bool staged = false;
     uint32_t cnt = 0;
     bool seg_overflow_only = false;  // a segment overflowed although the query's candidates fit one list: the scan can be rerun into flat lists
     if (a.flat_cnt) {
@@ -421,6 +430,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         }
         uint32_t run = v - mine;
         const bool too_many = s_over != 0 || cnt > a.cand_cap;
+        staged = !LIGHT && !too_many && cnt <= FIN_STAGE;
+        auto put = [&](uint32_t at, uint2 v) __attribute__((always_inline)) {
+            if (staged) s_cand[at] = v;
+            else flat[at] = v;
+        };
         if (!too_many) {
             if (per <= PER_MAX) {
                 uint2 first[PER_MAX];
@@ -430,9 +444,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
 #pragma unroll
                 for (uint32_t i = 0; i < PER_MAX; i++)
                     if (cs[i]) {
-                        flat[run] = first[i];
+                        put(run, first[i]);
                         const uint2 *src = a.seg + ((size_t)(tid * per + i) * a.seg_queries + q) * a.seg_cap;
-                        for (uint32_t e = 1; e < cs[i]; e++) flat[run + e] = src[e];
+                        for (uint32_t e = 1; e < cs[i]; e++) put(run + e, src[e]);
                         run += cs[i];
                     }
             } else {
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     if (sg >= a.n_segments) break;
                     const uint32_t c = sc[sg];
                     const uint2 *src = a.seg + ((size_t)sg * a.seg_queries + q) * a.seg_cap;
-                    for (uint32_t e = 0; e < c; e++) flat[run + e] = src[e];
+                    for (uint32_t e = 0; e < c; e++) put(run + e, src[e]);
                     run += c;
                 }
             }
@@ -463,10 +477,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         return;
     }
     const QInfo qi = a.qinfo[q];
-    const uint2 *cand = flat;
+    auto cand_at = [&](uint32_t i) __attribute__((always_inline)) { return staged ? s_cand[i] : flat[i]; };
     for (uint32_t i = tid; i < cnt; i += 256) {
-        const uint2 c = cand[i];
+        const uint2 c = cand_at(i);
         const float aa = a.norm2[c.x];
+        if (staged) s_aa[i] = aa;
         s_ub[i] = f32_sort_key(cand_key<DT>(a, qi, c.y, aa) + cand_err(a, qi, aa));
     }
     if (tid == 0) s_misc[0] = 0;
@@ -489,8 +504,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     FIN_STAMP(3);
     // survivors: lower bound <= k-th smallest upper bound
     for (uint32_t i = tid; i < cnt; i += 256) {
-        const uint2 c = cand[i];
-        const float aa = a.norm2[c.x];
+        const uint2 c = cand_at(i);
+        const float aa = staged ? s_aa[i] : a.norm2[c.x];
         if (cand_key<DT>(a, qi, c.y, aa) - cand_err(a, qi, aa) <= kappa) {
             const uint32_t p = atomicAdd(&s_misc[0], 1u);
             if (p < PVS_SURV_CAP) s_surv[p] = i;  // candidate slot
@@ -525,9 +540,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     for (uint32_t i = tid; i < m2; i += 256) {
         unsigned long long v = ~0ull;
         if (i < m) {
-            const uint2 c = cand[s_surv[i]];
+            const uint32_t slot = s_surv[i];
+            const uint2 c = cand_at(slot);
             const uint32_t row = c.x;
-            const float aa = a.norm2[row];
+            const float aa = staged ? s_aa[slot] : a.norm2[row];
             float d = 0.f;
             bool closed = false;
             if constexpr (DT == PVS_I8) {
