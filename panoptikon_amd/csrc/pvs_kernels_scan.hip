@@ -150,6 +150,65 @@ __device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hi
     return prefix;
 }
 
+// The select with the keys of one query in NR registers per thread (per_query <= 256 * NR).  The keys of a query are floats of
+// similar magnitude: their common leading bits are found first (one min/max reduction) and the 8-bit digits start at the highest
+// bit in which two keys differ — usually three digit passes instead of four, and a first digit that actually spreads (a pass
+// whose keys all fall into one bin is 2,048 LDS atomics on one address).
+template <int NR>
+__device__ static inline uint32_t kth_in_registers(const float *v, uint32_t per_query, uint32_t k, uint32_t *hist, uint32_t *s_sel) {
+    __shared__ uint32_t s_mm[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t kreg[NR];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const uint32_t i = threadIdx.x + 256u * j;
+        kreg[j] = i < per_query ? f32_sort_key(v[i]) : 0xffffffffu;
+        if (i < per_query) {
+            lo = kreg[j] < lo ? kreg[j] : lo;
+            hi = kreg[j] > hi ? kreg[j] : hi;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off, 64), h2 = (uint32_t)__shfl_xor((int)hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) {
+        s_mm[wave] = lo;
+        s_mm[4 + wave] = hi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        lo = s_mm[w] < lo ? s_mm[w] : lo;
+        hi = s_mm[4 + w] > hi ? s_mm[4 + w] : hi;
+    }
+    const uint32_t diff = lo ^ hi;
+    if (diff == 0) return lo;  // every key equal
+    const int top = 31 - __builtin_clz(diff);  // highest bit in which two keys differ
+    uint32_t mask = top == 31 ? 0u : ~((2u << top) - 1u), prefix = hi & mask, kk = k;
+    int shift = top >= 7 ? top - 7 : 0;
+    for (int pass = 0;; pass++) {
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const uint32_t i = threadIdx.x + 256u * j;
+            if (i < per_query && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t b = radix_pick(hist, s_sel, pass, kk);
+        if (b >= 256) return 0xffffffffu;
+        prefix |= b << shift;  // (a last digit that overlaps the previous one re-states bits the filter already fixed)
+        mask |= 0xffu << shift;
+        if (shift == 0) break;
+        shift = shift >= 8 ? shift - 8 : 0;
+    }
+    return prefix;
+}
+
 __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_sel[4];
@@ -161,39 +220,13 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
     const float *v = vals + (size_t)q * per_query;
     uint32_t key = 0xffffffffu;
     if (per_query >= k) {
-        if (per_query <= 16384) {
-            // keys live in registers across the four passes (the loads are the latency that matters)
-            uint32_t kreg[64];
-#pragma unroll
-            for (int j = 0; j < 64; j++) {
-                const uint32_t i = threadIdx.x + 256u * j;
-                kreg[j] = i < per_query ? f32_sort_key(v[i]) : 0xffffffffu;
-            }
-            const int tid = threadIdx.x;
-            uint32_t prefix = 0, mask = 0, kk = k;
-            bool ok = true;
-            for (int pass = 0; pass < 4 && ok; pass++) {
-                const int shift = 24 - 8 * pass;
-                hist[tid] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 64; j++) {
-                    const uint32_t i = threadIdx.x + 256u * j;
-                    if (i < per_query && (kreg[j] & mask) == prefix) atomicAdd(&hist[(kreg[j] >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                const uint32_t b = radix_pick(hist, s_sel, pass, kk);
-                if (b >= 256) {
-                    ok = false;
-                } else {
-                    prefix |= b << shift;
-                    mask |= 0xffu << shift;
-                }
-            }
-            key = ok ? prefix : 0xffffffffu;
-        } else {
+        // keys live in registers across the passes (the loads are the latency that matters)
+        if (per_query <= 2048)
+            key = kth_in_registers<8>(v, per_query, k, hist, s_sel);
+        else if (per_query <= 16384)
+            key = kth_in_registers<64>(v, per_query, k, hist, s_sel);
+        else
             key = radix_kth(per_query, k, hist, s_sel, [&](uint32_t i) { return f32_sort_key(v[i]); });
-        }
     }
     if (threadIdx.x == 0) {
         float t = f32_from_sort_key(key);
