@@ -42,6 +42,7 @@ SOURCES = [
     "pvs_groups.hip",
     "pvs_rrf.hip",
     "pvs_rrf_sharded.hip",
+    "pvs_score_direct.hip",
     "pvs_comm.hip",
     "pvs_multi.hip",
     "pvs_microbench.hip",

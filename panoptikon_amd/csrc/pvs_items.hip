@@ -70,7 +70,20 @@ pvs_status ensure_groups(pvs_index *ix) {
 // d_out[row * nb + q], nb <= PVS_MAX_BATCH queries already prepared in ctx c (prep_chunk)
 pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
     const uint32_t kslabs = ix->stride / PVS_KSLAB_BYTES;
-    if (ix->dtype == PVS_I8 && pvs_scan_supported(PVS_I8, kslabs) && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
+    static const bool no_direct = getenv("PVS_NO_DIRECT_SCORE") != nullptr;  // tuning: compare with the matrix-core scorer
+    if (ix->dtype == PVS_I8 && nb <= 4 && !no_direct && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
+        // a handful of queries: a pure HBM stream, v_dot4 straight from global memory (pvs_score_direct.hip); same closed form
+        HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
+        span_begin(ix, c, 1, ix->n);
+        HIP_TRY(pvs_launch_score_i8_direct(metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c.d_qexact, c.d_qinfo, nb, d_out, nb,
+                                           c.d_cand_cnt, (uint32_t)ix->n_cu, c.stream));
+        span_end(ix, c);
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        spans_collect(ix, c);
+        if (!flag) return PVS_OK;  // else: some L2 sum left the exact range -> score in order below
+    } else if (ix->dtype == PVS_I8 && pvs_scan_supported(PVS_I8, kslabs) && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
         // matrix-core path: exact integer dots, closed-form finish (valid below 2^24)
         ScanArgs a;
         a.dtype = PVS_I8;

@@ -954,8 +954,21 @@ PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype 
             PVS_TRY(pvs_dense_reserve(c->dense, ix->n));
             dst = c->dense.d_dist;
         }
-        HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
-                                       c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
+        bool done = false;
+        if (ix->dtype == PVS_I8 && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
+            // int8 codes: the closed form of the exact integer sums straight from HBM (pvs_score_direct.hip, 6.3-6.6 TB/s against
+            // 5.0 for the in-order chains); an L2 sum beyond 2^24 raises the flag and the in-order scorer below answers instead
+            uint32_t flag = 0;
+            HIP_TRY(hipMemsetAsync(c->d_cand_cnt, 0, 4, c->stream));
+            HIP_TRY(pvs_launch_score_i8_direct(metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact, c->d_qinfo, 1, dst, 1,
+                                               c->d_cand_cnt, (uint32_t)ix->n_cu, c->stream));
+            HIP_TRY(hipMemcpyAsync(&flag, c->d_cand_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            done = flag == 0;
+        }
+        if (!done)
+            HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
+                                           c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
         if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return PVS_OK;
