@@ -278,8 +278,10 @@ pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
  * branch that carries keys and holds the group.  `n` must equal the index's row count; rows appended later drop the keys
  * (set them again).  keys == NULL removes them.  Across shards: a multi-device index takes the keys in global row order and
  * honours them everywhere (every shard's page record carries the keys of its entries; the merges compare distance, key DESC,
- * id); pvs_search_sharded does the same when EVERY rank's index carries keys.  pvs_search_groups_sharded,
- * pvs_rrf_search_sharded and the stand-alone pvs_merge_* functions break ties by id only. */
+ * id); pvs_search_sharded and pvs_search_groups_sharded do the same when EVERY rank's index carries keys (the page records
+ * carry the keys of their entries); pvs_rrf_search_sharded exchanges the candidates' keys (from the lowest branch that carries
+ * keys and holds the group, on whichever rank).  The stand-alone merges: pvs_merge_group_pages_keyed takes the keys,
+ * pvs_merge_topk[_device] break ties by id. */
 pvs_status pvs_index_set_order_keys(pvs_index *idx, const int64_t *keys, uint64_t n, pvs_space space);
 
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort
@@ -545,6 +547,12 @@ pvs_status pvs_search_groups_sharded(pvs_index *idx, pvs_comm *comm, const void 
 pvs_status pvs_merge_group_pages(const int64_t *groups, const double *values, const uint32_t *counts,
                                  uint32_t world, uint32_t batch, uint32_t k, int64_t *out_groups,
                                  double *out_values, uint32_t *out_count);
+/* The same with the second sort key of pvs_index_set_order_keys: keys [world][batch][k] = the key of every page entry's group
+ * (NULL: none) -> (value asc, NULL last, key DESC, group id asc).  What pvs_search_groups_sharded runs when every rank's
+ * index carries keys. */
+pvs_status pvs_merge_group_pages_keyed(const int64_t *groups, const double *values, const int64_t *keys, const uint32_t *counts,
+                                       uint32_t world, uint32_t batch, uint32_t k, int64_t *out_groups,
+                                       double *out_values, uint32_t *out_count);
 
 /* The device form of pvs_merge_topk (the kernel pvs_search_sharded runs after the all-gather):
  * every pointer is an HBM buffer on `device`; synchronous. */

@@ -113,6 +113,7 @@ SYMBOLS = {
     "pvs_similar_to": (_i32, [_vp, _vp, _u32, _u32, _i32, _i32, _vp, _vp, _vp]),
     "pvs_search_groups_sharded": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "pvs_merge_group_pages": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_merge_group_pages_keyed": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_search_groups_filtered": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "pvs_search_filtered": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pvs_device_synchronize": (_i32, [_i32]),

@@ -227,30 +227,36 @@ PVS_EXPORT pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, cons
     return PVS_OK;
 }
 
-PVS_EXPORT pvs_status pvs_merge_group_pages(const int64_t *groups, const double *values, const uint32_t *counts, uint32_t world,
-                                            uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+PVS_EXPORT pvs_status pvs_merge_group_pages_keyed(const int64_t *groups, const double *values, const int64_t *keys, const uint32_t *counts,
+                                                  uint32_t world, uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values,
+                                                  uint32_t *out_count) {
     if (!groups || !values || !counts || !out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     struct E {
         double v;
-        int64_t g;
+        int64_t key, g;
     };
-    auto less = [](const E &a, const E &b) {  // value asc, NULL last, then group id
+    auto less = [](const E &a, const E &b) {  // value asc, NULL last, then the second sort key DESC (all zero without keys), then group id
         const bool na = std::isnan(a.v), nb = std::isnan(b.v);
         if (na != nb) return nb;
         if (!na && a.v != b.v) return a.v < b.v;
+        if (a.key != b.key) return a.key > b.key;
         return a.g < b.g;
     };
     std::vector<E> all;
+    std::vector<int64_t> seen;
     for (uint32_t q = 0; q < batch; q++) {
         all.clear();
         for (uint32_t w = 0; w < world; w++) {
             const size_t off = ((size_t)w * batch + q) * k;
             const uint32_t c = std::min(counts[(size_t)w * batch + q], k);
-            for (uint32_t p = 0; p < c; p++) all.push_back({values[off + p], groups[off + p]});
+            for (uint32_t p = 0; p < c; p++) all.push_back({values[off + p], keys ? keys[off + p] : 0, groups[off + p]});
         }
+        seen.resize(all.size());
+        for (size_t i = 0; i < all.size(); i++) seen[i] = all[i].g;
+        std::sort(seen.begin(), seen.end());
+        for (size_t i = 1; i < seen.size(); i++)
+            if (seen[i] == seen[i - 1]) return pvs_fail(PVS_ERR_INVALID_ARG, "group %lld appears on two shards: shard by group", (long long)seen[i]);
         std::sort(all.begin(), all.end(), less);
-        for (size_t i = 1; i < all.size(); i++)
-            if (all[i].g == all[i - 1].g) return pvs_fail(PVS_ERR_INVALID_ARG, "group %lld appears on two shards: shard by group", (long long)all[i].g);
         const uint32_t nout = (uint32_t)std::min<size_t>(all.size(), k);
         for (uint32_t i = 0; i < k; i++) {
             out_groups[(size_t)q * k + i] = i < nout ? all[i].g : -1;
@@ -259,6 +265,10 @@ PVS_EXPORT pvs_status pvs_merge_group_pages(const int64_t *groups, const double 
         out_count[q] = nout;
     }
     return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_merge_group_pages(const int64_t *groups, const double *values, const uint32_t *counts, uint32_t world,
+                                            uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    return pvs_merge_group_pages_keyed(groups, values, nullptr, counts, world, batch, k, out_groups, out_values, out_count);
 }
 
 // --------------------------------------------------------------- .npy ingestion

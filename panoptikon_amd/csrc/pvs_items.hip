@@ -416,13 +416,25 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t world = (uint32_t)pvs_comm_world_(comm);
     const uint64_t elems = (uint64_t)batch * k;
-    // this rank's page as ONE record [groups i64 | values f64 | counts u32] (16-byte padded): the exchange is a single all-gather
-    const size_t off_v = elems * 8, off_c = elems * 16, rec = (elems * 16 + (size_t)batch * 4 + 15) / 16 * 16;
+    // this rank's page as ONE record [groups i64 | values f64 | order keys i64 | counts u32 | keyed u32] (16-byte padded): the
+    // exchange is a single all-gather.  keyed = 1: the index carries order keys (pvs_index_set_order_keys) and the keys section
+    // holds the key of every entry's group; the merge uses them when every rank says so.
+    const size_t off_v = elems * 8, off_k = elems * 16, off_c = elems * 24, off_f = off_c + (size_t)batch * 4,
+                 rec = (off_f + 4 + 15) / 16 * 16;
     uint8_t *d_rec = nullptr, *d_all = nullptr;
     std::vector<uint8_t> h_rec(rec, 0), h_all(rec * world);
+    std::vector<int64_t> lk(elems, 0);
+    uint32_t keyed = local_st == PVS_OK && ix->order_rows == ix->n && ix->n ? 1u : 0u;
+    if (keyed)
+        for (uint32_t q = 0; q < batch; q++)
+            for (uint32_t i = 0; i < lc[q] && i < k; i++) (void)index_group_key(ix, lg[(size_t)q * k + i], &lk[(size_t)q * k + i]);
+    if (local_st == PVS_OK && ix->n == 0) keyed = 2;  // an empty shard has no say
     memcpy(h_rec.data(), lg.data(), elems * 8);
     memcpy(h_rec.data() + off_v, lv.data(), elems * 8);
+    memcpy(h_rec.data() + off_k, lk.data(), elems * 8);
     memcpy(h_rec.data() + off_c, lc.data(), (size_t)batch * 4);
+    memcpy(h_rec.data() + off_f, &keyed, 4);
+    std::vector<int64_t> ak((size_t)world * elems);
     std::vector<int64_t> ag((size_t)world * elems);
     std::vector<double> av((size_t)world * elems);
     std::vector<uint32_t> ac((size_t)world * batch);
@@ -438,13 +450,22 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         for (uint32_t w = 0; w < world; w++) {
             memcpy(ag.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec, elems * 8);
             memcpy(av.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec + off_v, elems * 8);
+            memcpy(ak.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec + off_k, elems * 8);
             memcpy(ac.data() + (size_t)w * batch, h_all.data() + (size_t)w * rec + off_c, (size_t)batch * 4);
+        }
+        bool all_keyed = true, any_keyed = false;
+        for (uint32_t w = 0; w < world; w++) {
+            uint32_t f;
+            memcpy(&f, h_all.data() + (size_t)w * rec + off_f, 4);
+            all_keyed &= f != 0;
+            any_keyed |= f == 1;
         }
         if (local_st != PVS_OK) return pvs_fail(local_st, "%s", local_err.c_str());
         for (uint32_t w = 0; w < world; w++)
             if (ac[(size_t)w * batch] == PVS_PAGE_FAILED) return pvs_fail(PVS_ERR_COMM, "rank %u failed its shard of the per-item search", w);
         // 3. merge on every rank (tiny: world * k entries per query)
-        return pvs_merge_group_pages(ag.data(), av.data(), ac.data(), world, batch, k, out_groups, out_values, out_count);
+        return pvs_merge_group_pages_keyed(ag.data(), av.data(), all_keyed && any_keyed ? ak.data() : nullptr, ac.data(), world, batch, k, out_groups,
+                                           out_values, out_count);
     };
     pvs_status st = body();
     for (void *p : {(void *)d_rec, (void *)d_all}) pvs_scratch_free_on(p, ix->comm_stream);  // (an early error may have left work queued)

@@ -179,11 +179,42 @@ PVS_EXPORT pvs_status pvs_rrf_search_sharded(const pvs_rrf_branch *branches, uin
                 ws[b] = branches[b].weight;
             }
             if (m) PVS_TRY(pvs_rrf_fuse(ranks.data(), nb, m, ks.data(), ws.data(), score.data()));
+            // second sort key (pvs_index_set_order_keys): a candidate's key comes from the lowest branch that carries keys and holds the
+            // group — on whichever rank that shard lives.  Every rank offers (branch, key) for the candidates it can answer for and
+            // the lowest branch wins; without any keys all entries tie and the order below is (score DESC, group id).
+            std::vector<int64_t> ckey(m, INT64_MIN);
+            if (m) {
+                struct BK {
+                    uint64_t branch;
+                    int64_t key;
+                };
+                std::vector<BK> mine(m, BK{~0ull, 0}), allbk((size_t)m * world);
+                for (uint32_t i = 0; i < m; i++)
+                    for (uint32_t b = 0; b < nb; b++)
+                        if (index_group_key(branches[b].idx, cand[i], &mine[i].key)) {
+                            mine[i].branch = b;
+                            break;
+                        }
+                PVS_TRY(ex.gather(mine.data(), allbk.data(), (size_t)m * sizeof(BK)));
+                for (uint32_t i = 0; i < m; i++) {
+                    uint64_t best = ~0ull;
+                    for (uint32_t w = 0; w < world; w++) {
+                        const BK &e = allbk[(size_t)w * m + i];
+                        if (e.branch < best) {
+                            best = e.branch;
+                            ckey[i] = e.key;
+                        }
+                    }
+                }
+            }
             std::vector<uint32_t> top(m);
             std::iota(top.begin(), top.end(), 0u);
             const uint32_t kk = std::min<uint32_t>(k, m);
-            std::partial_sort(top.begin(), top.begin() + kk, top.end(),
-                              [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : cand[x] < cand[y]; });
+            std::partial_sort(top.begin(), top.begin() + kk, top.end(), [&](uint32_t x, uint32_t y) {
+                if (score[x] != score[y]) return score[x] > score[y];
+                if (ckey[x] != ckey[y]) return ckey[x] > ckey[y];
+                return cand[x] < cand[y];
+            });
             double U = 0.0;
             for (uint32_t b = 0; b < nb; b++) U += ws[b] / ((double)ks[b] + (double)R[b] + 1.0);
             U *= 1.0 + 1e-12;

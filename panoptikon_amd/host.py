@@ -173,8 +173,9 @@ def rrf_search(branches, k: int):
     return og[: oc.value], ov[: oc.value]
 
 
-def merge_group_pages(groups, values, counts, k: int):
-    """groups/values: [world][batch][k] (i64 / f64); counts: [world][batch] -> merged per-item pages."""
+def merge_group_pages(groups, values, counts, k: int, keys=None):
+    """groups/values: [world][batch][k] (i64 / f64); counts: [world][batch] -> merged per-item pages.  keys ([world][batch][k]
+    i64, optional): the second sort key of every entry's group (pvs_merge_group_pages_keyed)."""
     groups = np.ascontiguousarray(groups, np.int64)
     values = np.ascontiguousarray(values, np.float64)
     counts = np.ascontiguousarray(counts, np.uint32)
@@ -182,7 +183,11 @@ def merge_group_pages(groups, values, counts, k: int):
     og = np.empty((batch, k), np.int64)
     ov = np.empty((batch, k), np.float64)
     oc = np.empty(batch, np.uint32)
-    L.check(L.lib().pvs_merge_group_pages(_ptr(groups), _ptr(values), _ptr(counts), world, batch, k, _ptr(og), _ptr(ov), _ptr(oc)))
+    if keys is None:
+        L.check(L.lib().pvs_merge_group_pages(_ptr(groups), _ptr(values), _ptr(counts), world, batch, k, _ptr(og), _ptr(ov), _ptr(oc)))
+    else:
+        keys = np.ascontiguousarray(keys, np.int64)
+        L.check(L.lib().pvs_merge_group_pages_keyed(_ptr(groups), _ptr(values), _ptr(keys), _ptr(counts), world, batch, k, _ptr(og), _ptr(ov), _ptr(oc)))
     return og, ov, oc
 
 

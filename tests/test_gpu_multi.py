@@ -726,3 +726,58 @@ def test_sharded_row_search_ships_order_keys_in_the_page_record(pvs):
     finally:
         pvs.lib().pvs_comm_destroy(comm)
         ix.close()
+
+
+def test_sharded_fusion_orders_score_ties_by_order_key(pvs):
+    """pvs_rrf_search_sharded with order keys: branches sharded BY GROUP over three ranks (host threads over the all-gather
+    callback), tie-heavy int8 corpora, keys on the first branch's shards only; the fused page must be the oracle's under
+    (score DESC, key DESC, group id) — a candidate's key travels from whichever rank holds its group in the lowest keyed branch."""
+    rng = np.random.default_rng(31)
+    world, files, dim, k = 3, 3000, 64, 30
+    rows_a = orc.synth_rows(401, 0, files, dim)
+    grp = np.arange(files, dtype=np.int64) * 2 + 1          # one row per file
+    keys = rng.integers(0, 6, files).astype(np.int64)
+    scale = orc.compute_int8_scale(rows_a)
+    qv = orc.quantize_int8((rows_a[5] + 0.01)[None, :], scale)[0]
+    d = orc.score_all(orc.I8, orc.L2, orc.quantize_int8(rows_a, scale), qv)
+    top = np.argsort(d, kind="stable")[:40]
+    rows_b = rows_a.copy()
+    rows_b[top] = rows_a[top[::-1]]                          # the second branch ranks the same 40 files in reverse: pairs tie on the fused score
+    specs = [rows_a, rows_b]
+    q = [qv, qv]
+    ranges = pvs.shard_ranges_by_group(grp, world)
+    shards = [[] for _ in range(world)]
+    for i, rows in enumerate(specs):
+        for r, (a, b) in enumerate(ranges):
+            ix = pvs.VectorIndex(pvs.I8, dim, id_base=a)
+            ix.set_scale(scale)
+            ix.add_f32(rows[a:b], group_ids=grp[a:b])
+            if i == 0:
+                ix.set_order_keys(keys[a:b])
+            shards[r].append(dict(index=ix, query=q[i], metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=1, weight=1.0))
+    ora = [dict(dtype=orc.I8, metric=orc.L2, corpus=orc.quantize_int8(specs[i], scale), query=q[i], groups=grp, agg=orc.AGG_MIN, rrf_k=1, weight=1.0,
+                order_keys=keys if i == 0 else None) for i in range(2)]
+    eg, es = orc.rrf_search(ora, k)
+    pg, _ = orc.rrf_search([{**o, "order_keys": None} for o in ora], k)
+    assert not np.array_equal(pg, eg), "the fused scores must tie"
+    tg = _ThreadGather(world)
+    res, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            res[r] = pvs.rrf_search_sharded(shards[r], k, tg.for_rank(r))
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            tg.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(res[r][0], eg), f"rank {r}: groups differ"
+        assert np.array_equal(res[r][1].view(np.uint64), es.view(np.uint64)), f"rank {r}: scores not bit-exact"
+    for sh in shards:
+        for b in sh:
+            b["index"].close()
+

@@ -277,3 +277,41 @@ def test_shard_range_partitions_rows():
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert all(0 <= a <= b <= n for a, b in spans)
+
+
+def test_keyed_merge_of_per_item_pages():
+    """pvs_merge_group_pages_keyed: the shard merge of per-item pages under `ORDER BY value, last_modified DESC` (model.rs:547-553)
+    — (value asc, NULL last, key DESC, group id asc); without keys it is pvs_merge_group_pages."""
+    import panoptikon_amd as pvs
+
+    rng = np.random.default_rng(4)
+    world, batch, k = 3, 4, 12
+    groups = np.full((world, batch, k), -1, np.int64)
+    values = np.full((world, batch, k), np.nan)
+    keys = np.zeros((world, batch, k), np.int64)
+    counts = np.zeros((world, batch), np.uint32)
+    exp = []
+    for q in range(batch):
+        ent = []
+        for w in range(world):
+            c = int(rng.integers(0, k + 1))
+            g = rng.choice(np.arange(w, 300, world), c, replace=False)             # disjoint groups per shard
+            v = rng.integers(0, 4, c).astype(np.float64)                            # heavy ties
+            v[rng.random(c) < 0.15] = np.nan                                        # NULL aggregates
+            kk = rng.integers(0, 3, c).astype(np.int64)
+            order = np.lexsort((g, -kk, np.where(np.isnan(v), 0, v), np.isnan(v)))  # each shard's page in the keyed order
+            groups[w, q, :c], values[w, q, :c], keys[w, q, :c], counts[w, q] = g[order], v[order], kk[order], c
+            ent += list(zip(v[order], kk[order], g[order]))
+        ent.sort(key=lambda e: (np.isnan(e[0]), 0.0 if np.isnan(e[0]) else e[0], -e[1], e[2]))
+        exp.append(ent[:k])
+    og, ov, oc = pvs.merge_group_pages(groups, values, counts, k, keys=keys)
+    differs = 0
+    pg, _, _ = pvs.merge_group_pages(groups, values, counts, k)
+    for q in range(batch):
+        assert oc[q] == len(exp[q]) and og[q, : oc[q]].tolist() == [e[2] for e in exp[q]], q
+        a, e = ov[q, : oc[q]], np.array([e[0] for e in exp[q]])
+        assert np.array_equal(np.isnan(a), np.isnan(e)) and np.array_equal(a[~np.isnan(a)], e[~np.isnan(e)])
+        assert (og[q, oc[q]:] == -1).all()
+        differs += int(not np.array_equal(pg[q], og[q]))
+    assert differs, "the keys must matter in this test"
+
