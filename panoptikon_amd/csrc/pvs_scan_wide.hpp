@@ -9,8 +9,9 @@
 //
 // What bounds this pass is ENERGY.  At 256 queries x 10M x 768 the part sits at its 1,400 W limit and lowers its clock until
 // the work fits; ablations of this kernel add up instead of overlapping (tools/probe/wide_probe.hip, profiles/r03_*):
-// matrix cores 1.14 ms-equivalents, HBM + LDS-DMA transport 0.46, A-fragment reads from LDS 0.17, epilogue VALU 0.15 — sum
-// 1.91 = what the full kernel takes.  Stalls are free (the clock rises), instructions are not.  So:
+// matrix cores 0.92 ms-equivalents, HBM + LDS-DMA transport 0.52, A-fragment reads from LDS 0.19, epilogue VALU 0.16 — sum
+// 1.78 against 1.75 for the full kernel (the first form of this kernel, with v_mfma_i32_32x32x32_i8: 1.14 + 0.46 + 0.17 + 0.15
+// = 1.91).  Stalls are free (the clock rises), instructions are not.  So:
 //   * v_mfma_i32_16x16x64_i8, not 32x32x32: on int8 codes the matrix pipe sustains 4.1 POP/s through the 16x16 shape and 3.4
 //     through the 32x32 shape at the same board power (tools/probe/mfma_rate.hip) — K = 64 per instruction means a quarter of
 //     the accumulator traffic per operation;
