@@ -116,7 +116,7 @@ typedef struct pvs_index_desc {
      *  - WITHOUT group_ids (then no add may give them): every add splits into n_devices contiguous pieces.  The
      *    index holds no groups, so the per-item entry points fail as they do on a single-device index without
      *    group ids; everything row-wise above is served.
-     * Not served on any multi-device index: pvs_search_bounded with a lower bound, the
+     * Not served on any multi-device index: the
      * `_sharded` (multi-process) entry points, pvs_rrf_cols.  A pvs_index_add that fails after some shards took
      * their rows leaves the index unusable (PVS_ERR_STATE from every later call): destroy and rebuild it. */
     uint32_t n_devices;
@@ -247,6 +247,10 @@ pvs_status pvs_search_groups_page(pvs_index *idx, const void *queries, pvs_dtype
 pvs_status pvs_index_set_coalescing(pvs_index *idx, uint32_t window_us, uint32_t max_batch);
 pvs_status pvs_index_coalescing_stats(pvs_index *idx, uint64_t *out_calls, uint64_t *out_passes);
 
+/* pvs_search under apply_sort_bounds (pql/builder.rs:781-815): page 1 of the rows with gt < d < lt (each bound optional; NULL
+ * distances satisfy neither).  lt alone: the plain page cut where d reaches lt.  gt (a cursor: the last distance of an earlier
+ * page): the rows beyond it are a suffix of the plain ordering — growing pages of the filter scan until k of them are on the
+ * page; bounds more than 4,096 rows deep take the dense path (a multi-device index keeps growing the page). */
 pvs_status pvs_search_bounded(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
                               pvs_metric metric, int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids,
                               float *out_dist, uint32_t *out_count);

@@ -646,8 +646,8 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
 // pvs_search restricted by apply_sort_bounds (pql/builder.rs:781-815) on the distance: page 1 of the rows with gt < d < lt.
 // An upper bound alone (the usual similarity cut-off) changes nothing about WHICH rows are best: the k smallest distances
 // among the rows with d < lt are the k smallest of all rows, cut where d reaches lt — the plain search (filter scan) with the
-// page truncated; NULL distances never satisfy a comparison.  With a lower bound `gt` the first k rows of the plain ordering
-// are useless: every row is scored exactly and the ones outside the bounds leave the sort (dense path).
+// page truncated; NULL distances never satisfy a comparison.  With a lower bound `gt`: growing pages of the plain ordering
+// first (see below), the dense path — every row scored exactly, rows outside the bounds leave the sort — for deep bounds.
 PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                          int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist,
                                          uint32_t *out_count) {
@@ -669,9 +669,61 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
         }
         return PVS_OK;
     }
-    if (is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_search_bounded with a lower bound is not served on a multi-device index");
-    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    PVS_TRY(validate_search(is_multi(ix) ? ix->shards[0] : ix, queries, qdtype, batch, k, metric));
     if (batch == 0) return PVS_OK;
+    // Lower bound.  The rows with d > gt are a SUFFIX of the plain ordering (distance asc, NULL last; ties keep their order), and
+    // `gt` is in practice the last distance of an earlier page: few rows lie at or below it.  So: pages of the plain ordering
+    // (filter scan) of growing size until k rows inside the bounds are on the page, the page ran into `lt` / the NULL rows (no
+    // later row satisfies a comparison), or the page is everything.  Only a query whose bound lies deeper than PVS_MAX_K rows
+    // goes on to the dense path below (a multi-device index keeps growing the page instead).
+    std::vector<uint32_t> pending(batch);
+    for (uint32_t q = 0; q < batch; q++) pending[q] = q;
+    const size_t qbytes_h = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+    const uint64_t kmax = is_multi(ix) ? std::max<uint64_t>(ix->n, 1) : std::min<uint64_t>(PVS_MAX_K, std::max<uint64_t>(ix->n, 1));
+    for (uint64_t kp = std::min<uint64_t>(kmax, std::max<uint64_t>(2ull * k, 64)); !pending.empty(); kp = std::min<uint64_t>(kmax, kp * 4)) {
+        const uint32_t nb = (uint32_t)pending.size();
+        std::vector<uint8_t> pq(qbytes_h * nb);
+        for (uint32_t i = 0; i < nb; i++) memcpy(pq.data() + qbytes_h * i, (const uint8_t *)queries + qbytes_h * pending[i], qbytes_h);
+        std::vector<int64_t> pi((size_t)nb * kp);
+        std::vector<float> pd((size_t)nb * kp);
+        std::vector<uint32_t> pc(nb);
+        PVS_TRY(search_host_any(ix, pq.data(), qdtype, nb, (uint32_t)kp, metric, pi.data(), pd.data(), pc.data()));
+        std::vector<uint32_t> still;
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t q = pending[i];
+            const int64_t *ids = pi.data() + (size_t)i * kp;
+            const float *d = pd.data() + (size_t)i * kp;
+            uint32_t got = 0;
+            bool closed = pc[i] < kp;  // the page is every row there is
+            for (uint32_t e = 0; e < pc[i] && got < k; e++) {
+                if (d[e] != d[e] || (have_lt && !((double)d[e] < lt))) {  // NULL, or at / beyond lt: nothing later qualifies
+                    closed = true;
+                    break;
+                }
+                if (!((double)d[e] > gt)) continue;
+                out_ids[(size_t)q * k + got] = ids[e];
+                out_dist[(size_t)q * k + got] = d[e];
+                got++;
+            }
+            if (got < k && !closed && kp < kmax) {
+                still.push_back(q);
+                continue;
+            }
+            if (got < k && !closed && !is_multi(ix)) {  // deeper than the filter path pages: dense path below
+                still.push_back(q);
+                continue;
+            }
+            for (uint32_t e = got; e < k; e++) {
+                out_ids[(size_t)q * k + e] = -1;
+                out_dist[(size_t)q * k + e] = __builtin_nanf("");
+            }
+            out_count[q] = got;
+        }
+        pending.swap(still);
+        if (kp >= kmax) break;
+    }
+    if (pending.empty()) return PVS_OK;
+    if (is_multi(ix)) return pvs_fail(PVS_ERR_STATE, "bounded search did not close on a multi-device index");  // (unreachable: kmax = n)
     HIP_TRY(hipSetDevice(ix->device));
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);
@@ -697,16 +749,24 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
             HIP_TRY(hipMemsetAsync(c->d_out_ids, 0xff, 8 * (size_t)batch * k, c->stream));
             HIP_TRY(pvs_launch_fill_f32(c->d_out_dist, (uint64_t)batch * k, __builtin_nanf(""), c->stream));
         }
+        std::vector<uint8_t> is_pending(batch, 0);
+        for (uint32_t q : pending) is_pending[q] = 1;
         for (uint32_t qoff = 0; qoff < batch && ix->n; qoff += PVS_MAX_BATCH) {
             const uint32_t nb = std::min(PVS_MAX_BATCH, batch - qoff);
+            bool any = false;
+            for (uint32_t q = 0; q < nb; q++) any |= is_pending[qoff + q] != 0;
+            if (!any) continue;
             PVS_TRY(prep_chunk(ix, *c, c->d_qstage, qdtype, qoff, nb, 32 * ((nb + 31) / 32), metric));
             for (uint32_t q = 0; q < nb; q++)
-                PVS_TRY(dense_one(ix, *c, q, k, metric, c->d_out_ids + (size_t)(qoff + q) * k, c->d_out_dist + (size_t)(qoff + q) * k,
-                                  c->d_out_count + qoff + q, b));
+                if (is_pending[qoff + q])
+                    PVS_TRY(dense_one(ix, *c, q, k, metric, c->d_out_ids + (size_t)(qoff + q) * k, c->d_out_dist + (size_t)(qoff + q) * k,
+                                      c->d_out_count + qoff + q, b));
         }
-        HIP_TRY(hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
+        for (uint32_t q : pending) {  // (the other queries were answered from their pages above)
+            HIP_TRY(hipMemcpyAsync(out_ids + (size_t)q * k, c->d_out_ids + (size_t)q * k, 8 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_dist + (size_t)q * k, c->d_out_dist + (size_t)q * k, 4 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_count + q, c->d_out_count + q, 4, hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
         return PVS_OK;
     };

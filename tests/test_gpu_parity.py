@@ -1234,6 +1234,50 @@ def test_search_bounded_applies_sort_bounds_on_the_distance(pvs, dtype):
     ix.close()
 
 
+def test_search_bounded_with_a_lower_bound_pages_through_the_filter_scan(pvs):
+    """`order_rank > gt` as a cursor (the last distance of an earlier page): the rows beyond it are a suffix of the plain
+    ordering, so growing pages of the filter scan answer it; only a bound deeper than 4,096 rows needs the dense path.  A batch
+    with bounds at depth 0, 7, 150, 3,000 and 20,000 rows (one per query), with and without `lt`, ties on the bound itself
+    (int8 L2), and the same on a multi-device index."""
+    rng = np.random.default_rng(8)
+    n, dim, k = 300_000, 64, 40
+    rows = unit_rows(95, n, dim)
+    rows[:64] = rows[64:128]                      # duplicates: distances tie, also exactly on a bound
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    qs = orc.synth_rows(96, 0, 5, dim)
+    hq = orc.quantize_int8(qs, scale)
+    depth = [0, 7, 150, 3000, 20000]
+    for devices in (None, [0, 0]):
+        ix = pvs.VectorIndex(pvs.I8, dim, devices=devices) if devices else pvs.VectorIndex(pvs.I8, dim)
+        ix.set_scale(scale)
+        ix.add_f32(rows)
+        for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+            ds = [orc.score_all(orc.I8, om, codes, hq[j]) for j in range(5)]
+            # one call per query (each with its own bound), then the whole batch with one common bound
+            before = ix.stats().dense_queries
+            for j in range(5):
+                srt = np.sort(ds[j])
+                gt = float(srt[depth[j]]) if depth[j] else float(srt[0]) - 1.0
+                for lt in (None, float(srt[depth[j] + 25])):
+                    keep = np.array([orc.sort_bounds_keep(float(x), gt, lt) for x in ds[j].astype(np.float64)])
+                    ids = np.flatnonzero(keep)
+                    ei, ed = orc.topk(ds[j][ids], k, ids=ids.astype(np.int64))
+                    gi, gd, gc = ix.search_bounded(qs[j], k, metric, gt=gt, lt=lt)
+                    assert gc[0] == len(ei) and np.array_equal(gi[0, : len(ei)], ei), (devices, metric, j, lt)
+                    assert np.array_equal(gd[0, : len(ei)].view(np.uint32), ed.view(np.uint32))
+                    assert (gi[0, len(ei):] == -1).all()
+            if devices is None:
+                assert ix.stats().dense_queries - before <= 2, "only the 20,000-deep bound (without lt) may need the dense path"
+            gt = float(np.sort(ds[2])[150])
+            gi, gd, gc = ix.search_bounded(qs, k, metric, gt=gt)
+            for j in range(5):
+                ids = np.flatnonzero(ds[j].astype(np.float64) > gt)
+                ei, ed = orc.topk(ds[j][ids], k, ids=ids.astype(np.int64))
+                assert gc[j] == len(ei) and np.array_equal(gi[j, : len(ei)], ei), (devices, metric, "batch", j)
+        ix.close()
+
+
 def test_rrf_bounded_fusion_equals_the_full_ranking(pvs):
     """pvs_rrf_search's bounded path (pages of each branch's window ranking, exact ranks of the candidates by one counting pass,
     the bound sum_b w_b/(k_b + R_b + 1) on everything outside the pages) must return exactly what ranking every group returns:
