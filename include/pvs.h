@@ -222,9 +222,6 @@ pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype qu
                                pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space,
                                int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
-/* pvs_search under apply_sort_bounds (pql/builder.rs:781-815: `WHERE order_rank > gt AND order_rank < lt` with order_rank =
- * the distance, a SQL REAL): page 1 of the rows whose distance lies inside the bounds; have_gt / have_lt select them.
- * Rows with a NULL distance never pass a bound.  out_count[q] = min(k, rows inside the bounds). */
 /* Pagination (pql/builder.rs:578-582: `LIMIT ? OFFSET ?` behind the final ORDER BY; api/search.rs:51,777-783 executes
  * LIMIT = max(page_size, prefetch_rows <= 4096) at OFFSET (page-1)*page_size): entries [offset, offset+limit) of the same
  * ordering pvs_search / pvs_search_groups return — (distance asc, id asc, NULL last) resp. (value asc, group id asc, NULL
@@ -247,8 +244,9 @@ pvs_status pvs_search_groups_page(pvs_index *idx, const void *queries, pvs_dtype
 pvs_status pvs_index_set_coalescing(pvs_index *idx, uint32_t window_us, uint32_t max_batch);
 pvs_status pvs_index_coalescing_stats(pvs_index *idx, uint64_t *out_calls, uint64_t *out_passes);
 
-/* pvs_search under apply_sort_bounds (pql/builder.rs:781-815): page 1 of the rows with gt < d < lt (each bound optional; NULL
- * distances satisfy neither).  lt alone: the plain page cut where d reaches lt.  gt (a cursor: the last distance of an earlier
+/* pvs_search under apply_sort_bounds (pql/builder.rs:781-815: `WHERE order_rank > gt AND order_rank < lt` with order_rank = the
+ * distance, a SQL REAL): page 1 of the rows with gt < d < lt (have_gt / have_lt select the bounds; NULL distances satisfy
+ * neither); out_count[q] = min(k, rows inside the bounds).  lt alone: the plain page cut where d reaches lt.  gt (a cursor: the last distance of an earlier
  * page): the rows beyond it are a suffix of the plain ordering — growing pages of the filter scan until k of them are on the
  * page; bounds more than 4,096 rows deep take the dense path (a multi-device index keeps growing the page). */
 pvs_status pvs_search_bounded(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
