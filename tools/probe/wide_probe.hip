@@ -1,3 +1,4 @@
+#include <algorithm>
 // wide_probe.hip — times k_scan_wide (pvs_scan_wide.hpp) alone on a synthetic tiled corpus: back-to-back launches, sustained,
 // no pass A / C, no dense fallback in between (bench.py's ablation builds answer garbage and spend the step in the dense path,
 // which changes the power state the next scan runs in).  Candidate rate is set by bisection on the threshold.
@@ -48,7 +49,7 @@ int main(int argc, char **argv) {
     constexpr int KS = 3;
     const uint32_t stride = KS * 256, batch = 256 / PROBE_RW, grid = 256;
     const uint32_t wg_rows = WideGeo<KS, PVS_WIDE_NQ, PROBE_RW>::TILE_ROWS;
-    const uint64_t cap = (n_rows + 127) / 128 * 128 + 128;
+    const uint64_t cap = (n_rows + 127) / 128 * 128 + 128 + 1200000;  // (+ room for the PROBE_EXTRA timing experiment)
     uint8_t *rows, *qmat;
     float *aux, *thr;
     QInfo *qinfo;
@@ -127,6 +128,29 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         last = ms / launches;
         if (last < best) best = last;
+    }
+    {
+        unsigned long long *dbg;
+        CK(hipMalloc(&dbg, 256 * 8));
+        k.dense_out = (float *)dbg;
+        for (int i = 0; i < 20; i++) launch();
+        CK(hipDeviceSynchronize());
+        launch();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> t(256);
+        CK(hipMemcpy(t.data(), dbg, 256 * 8, hipMemcpyDeviceToHost));
+        unsigned long long mn = ~0ull, mx = 0;
+        for (auto v : t) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+        std::vector<unsigned long long> s2(t);
+        std::sort(s2.begin(), s2.end());
+        printf("end-time spread over 256 workgroups: %.1f us (p10 %.1f p50 %.1f p90 %.1f us before the last)\n", (mx - mn) / 100.0,
+               (mx - s2[25]) / 100.0, (mx - s2[128]) / 100.0, (mx - s2[230]) / 100.0);
+        double xcd[8] = {0};
+        for (int i = 0; i < 256; i++) xcd[i % 8] += (mx - t[i]) / 100.0 / 32;
+        printf("mean lead per XCD (us):");
+        for (int x = 0; x < 8; x++) printf(" %.1f", xcd[x]);
+        printf("\n");
+        k.dense_out = nullptr;
     }
     const double ops = 2.0 * n_rows * 768.0 * batch;  // (batch = 256 / PROBE_RW)
     printf("k_scan_wide<3,cos,B>: %.4f ms/launch sustained (best group %.4f)  %.2f TB/s  %.2f POP/s\n", last, best,
