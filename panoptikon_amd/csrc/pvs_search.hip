@@ -91,7 +91,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // scan.  Measured on MI355X (10Mx768 int8 x128 and 1Mx768 f16 x32): 1/16 beats 1/8, 1/32, 1/64;
     // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
     // holds ~k/frac rows: keep that 2.5x below its capacity.
-    double frac = nb <= 4 ? 1.0 / 64.0 : 1.0 / 16.0;
+    double frac = nb <= 4 ? 1.0 / 32.0 : 1.0 / 16.0;  // (single query, 10M rows: 1/64 leaves pass C 6,400 candidates = 100 us (f16) for 10 us of pass A)
     static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
     if (frac_env > 0.0) frac = frac_env;
     // The threshold need not be the sample's k-th value: its j-th value (j < k) from a sample j/k the size expects the same number
@@ -100,7 +100,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // dense path otherwise (never seen: it needs T below the corpus' k-th value while j sample rows lie below it).
     static const uint32_t j_div = getenv("PVS_SAMPLE_J_DIV") ? (uint32_t)std::max(1, atoi(getenv("PVS_SAMPLE_J_DIV"))) : 4u;  // tuning experiments
     uint32_t k_sel = k;
-    if (nb > 4 && ix->n >= (1ull << 18) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
+    if (ix->n >= (1ull << 18) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
     frac *= (double)k_sel / (double)k;
     frac = std::min(0.5, std::max(frac, 2.5 * (double)k_sel / (double)PVS_CAND_CAP));
     const uint64_t target_rows = std::min<uint64_t>(ix->n, std::max<uint64_t>((uint64_t)((double)ix->n * frac), 32768));
