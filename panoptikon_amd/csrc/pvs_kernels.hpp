@@ -113,6 +113,9 @@ struct FinalizeArgs {
     // [batch] the thresholds pass B ran with, when they were taken BELOW the k-th sample value (search_enqueue: j-th of a smaller
     // sample): pass C then proves that k rows lie at or below T (k-th smallest upper bound <= T) or hands the query back
     const float *thr = nullptr;
+    // pinned host mirrors of need_dense / cand_seen: the kernel writes its verdicts straight into host memory, so that no copy
+    // kernel (4-5 us each, plus a launch gap) follows every search just to fetch two words per query
+    uint32_t *h_flags = nullptr, *h_seen = nullptr;
     // second sort key (pvs_index_set_order_keys): ties on the distance are ordered by tie rank instead of by row
     const uint32_t *trank = nullptr, *tinv = nullptr;
     // Optional global-memory work area: with it (int8 rows) pass C keeps its bound keys, survivor list and large sorts in HBM/L2
@@ -174,8 +177,9 @@ inline size_t pvs_page_record_off_cnt(uint32_t batch, uint32_t k) { return (size
 inline size_t pvs_page_record_off_flags(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12 + (size_t)batch * 4; }
 inline size_t pvs_page_record_off_keys(uint32_t batch, uint32_t k) { return ((size_t)batch * k * 12 + (size_t)batch * 8 + 15) / 16 * 16; }
 inline size_t pvs_page_record_bytes(uint32_t batch, uint32_t k) { return pvs_page_record_off_keys(batch, k) + ((size_t)batch * k * 8 + 15) / 16 * 16; }
+// h_flags (optional, pinned host memory [world][batch]): the records' flag words, written by the merge itself
 hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
-                                   float *out_dist, uint32_t *out_count, hipStream_t s);
+                                   float *out_dist, uint32_t *out_count, hipStream_t s, uint32_t *h_flags = nullptr);
 // Completes a page record whose ids / dist / counts are written: flags[q] = need_dense[q] (| PVS_PAGE_KEYED), and with order keys
 // (d_order_keys != nullptr: one per row, rows in ascending id order d_ids[0..n)) the key of every page entry, found by its id.
 hipError_t pvs_launch_page_finish(uint8_t *rec, uint32_t batch, uint32_t k, const uint32_t *need_dense, const int64_t *d_ids, uint64_t n,

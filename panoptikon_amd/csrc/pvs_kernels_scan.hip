@@ -260,6 +260,7 @@ struct FinK {
     unsigned long long *w_sort;
     const uint32_t *flat_cnt;      // segment-overflow rerun (FinalizeArgs.flat_cnt)
     const float *thr;              // thresholds to certify (FinalizeArgs.thr), or nullptr
+    uint32_t *h_flags, *h_seen;    // pinned host mirrors of need_dense / cand_seen (FinalizeArgs.h_flags), or nullptr
     const uint32_t *trank, *tinv;  // second sort key: tie rank of a row and its inverse (FinalizeArgs.trank)
 };
 
@@ -501,10 +502,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     }
     FIN_STAMP(1);
     if (tid == 0 && a.cand_seen) a.cand_seen[q] = cnt;
+    if (tid == 0 && a.h_seen) a.h_seen[q] = cnt;
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
     if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
         if (tid == 0) {
             a.need_dense[q] = seg_overflow_only ? 2 : 1;
+            if (a.h_flags) a.h_flags[q] = seg_overflow_only ? 2 : 1;
             a.out_count[q] = 0;
         }
         return;
@@ -530,6 +533,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (a.thr && want == a.k && !(kappa <= a.thr[q])) {
         if (tid == 0) {
             a.need_dense[q] = 1;
+            if (a.h_flags) a.h_flags[q] = 1;
             a.out_count[q] = 0;
         }
         return;
@@ -549,6 +553,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (m > PVS_SURV_CAP) {  // massive near-ties: let the dense path answer
         if (tid == 0) {
             a.need_dense[q] = 1;
+            if (a.h_flags) a.h_flags[q] = 1;
             a.out_count[q] = 0;
         }
         return;
@@ -638,6 +643,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (nout < want || (nout > 0 && (uint32_t)(s_sort[nout - 1] >> 32) == 0xffffffffu)) {
         if (tid == 0) {
             a.need_dense[q] = 1;
+            if (a.h_flags) a.h_flags[q] = 1;
             a.out_count[q] = 0;
         }
         return;
@@ -655,6 +661,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (tid == 0) {
         a.out_count[q] = nout;
         a.need_dense[q] = 0;
+        if (a.h_flags) a.h_flags[q] = 0;
     }
 }
 
@@ -675,6 +682,8 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.seg_cap = f.seg_cap;
     k.flat_cnt = f.flat_cnt;
     k.thr = f.thr;
+    k.h_flags = f.h_flags;
+    k.h_seen = f.h_seen;
     k.trank = f.trank;
     k.tinv = f.tinv;
     k.cand = f.cand;
@@ -734,8 +743,10 @@ struct MergePages {
     __device__ const int64_t *keys_of(uint32_t w) const { return (const int64_t *)(keys + (size_t)w * stride_keys); }
 };
 __global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
-                                               uint32_t *out_count) {
+                                               uint32_t *out_count, uint32_t *h_flags) {
     const uint32_t q = blockIdx.x;
+    if (h_flags && pg.flags)  // every rank's verdicts [world][batch] straight into pinned host memory (no copy kernel behind the merge)
+        for (uint32_t w = threadIdx.x; w < world; w += 256) h_flags[(size_t)w * batch + q] = pg.flags_of(w)[q];
     uint32_t total = 0;
     bool keyed = pg.keys != nullptr;
     for (uint32_t w = 0; w < world; w++) {
@@ -786,12 +797,12 @@ hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_
     pg.stride_ids = (size_t)batch * k * 8;
     pg.stride_dist = (size_t)batch * k * 4;
     pg.stride_cnt = (size_t)batch * 4;
-    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count);
+    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 // packed records (pvs_page_record_*): rank w's record starts at all_rec + w * rec_bytes
 hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
-                                   float *out_dist, uint32_t *out_count, hipStream_t s) {
+                                   float *out_dist, uint32_t *out_count, hipStream_t s, uint32_t *h_flags) {
     MergePages pg;
     pg.ids = all_rec;
     pg.dist = all_rec + pvs_page_record_off_dist(batch, k);
@@ -799,7 +810,7 @@ hipError_t pvs_launch_merge_packed(const uint8_t *all_rec, size_t rec_bytes, uin
     pg.flags = all_rec + pvs_page_record_off_flags(batch, k);
     pg.keys = all_rec + pvs_page_record_off_keys(batch, k);
     pg.stride_ids = pg.stride_dist = pg.stride_cnt = pg.stride_flags = pg.stride_keys = rec_bytes;
-    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count);
+    hipLaunchKernelGGL(k_merge, dim3(batch), dim3(256), 0, s, pg, world, batch, k, out_ids, out_dist, out_count, h_flags);
     return hipGetLastError();
 }
 

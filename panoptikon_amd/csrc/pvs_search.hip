@@ -171,6 +171,8 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.need_dense = c.d_need_dense + qoff;
     f.cand_seen = c.d_need_dense + c.flags_cap + qoff;
     if (flat_rerun) f.flat_cnt = c.d_flat_cnt;
+    f.h_flags = c.h_need_dense + qoff;  // (hipHostMalloc: the same address on the device)
+    f.h_seen = c.h_need_dense + c.flags_cap + qoff;
     if (k_sel < k) f.thr = c.d_thr;  // thresholds below the k-th sample value: pass C certifies them
     if (order_tinv(ix)) {
         f.trank = ix->d_trank;
@@ -229,10 +231,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         }
         PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false));
     }
-    if (fast) {
-        HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(hipMemcpyAsync(c.h_need_dense + c.flags_cap, c.d_need_dense + c.flags_cap, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
-    }
+    // (pass C wrote its verdicts and candidate counts straight into c.h_need_dense: FinalizeArgs.h_flags)
     HIP_TRY(hipEventRecord(c.done, c.stream));
     return PVS_OK;
 }
@@ -818,11 +817,9 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
 // merge on every rank, the gathered flags to the host (every rank sees the same flags and so agrees on a redo).  Stream-ordered.
 static pvs_status exchange_pages(pvs_index *ix, SearchCtx &c, pvs_comm *comm, uint32_t batch, uint32_t k, uint32_t world, int64_t *d_out_ids, float *d_out_dist,
                                  uint32_t *d_out_count, hipStream_t cs) {
-    const size_t off_flags = pvs_page_record_off_flags(batch, k);
     PVS_TRY(ctx_finish_local_page(ix, c, batch, k, cs));
     PVS_TRY(pvs_comm_gather_records_(comm, c.d_loc_rec, c.d_all_rec, c.rec_bytes, cs));
-    HIP_TRY(pvs_launch_merge_packed(c.d_all_rec, c.rec_bytes, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs));
-    HIP_TRY(hipMemcpy2DAsync(c.h_all_flags, (size_t)batch * 4, c.d_all_rec + off_flags, c.rec_bytes, (size_t)batch * 4, world, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(pvs_launch_merge_packed(c.d_all_rec, c.rec_bytes, world, batch, k, d_out_ids, d_out_dist, d_out_count, cs, c.h_all_flags));
     return PVS_OK;
 }
 
