@@ -50,7 +50,11 @@ SOURCES = [
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-HIPFLAGS = ["--offload-arch=gfx950", "-ffp-contract=off"]
+# -pragma-unroll-threshold: the scan kernels keep a pass's query fragments in registers and index them with the (compile-time) chunk
+# and step of fully unrolled loops.  LLVM declines a `#pragma unroll` whose unrolled body exceeds 16k instructions — pass B of the
+# instances with 8+ k-slabs per row (f32 512-d and up, f16 1152-d and up) — and the fragment array then lives in scratch: the f32
+# 768-d scan for <= 64 queries ran at 3.1 TB/s instead of 6.5 (found in round 3 through .private_segment_fixed_size of every instance)
+HIPFLAGS = ["--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000"]
 HOSTFLAGS = ["-ffp-contract=off"]
 
 

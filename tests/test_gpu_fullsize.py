@@ -123,3 +123,31 @@ def test_config4_two_25M_row_indexes_or_composition_rrf(pvs, monkeypatch):
     assert np.array_equal(g_single, gg[0, : gc[0]]), "one branch: RRF order = MIN order"
     img.close()
     txt.close()
+
+
+def test_f32_small_batch_scan_keeps_its_query_fragments_in_registers(pvs):
+    """Performance canary with a wide margin.  The f32 768-d scan for <= 64 queries once ran with its query fragments in scratch
+    (LLVM declined the unroll that makes their indices constants: 1.22 ms per search at 1M rows instead of 0.62, nothing
+    functionally wrong — build.py now raises -pragma-unroll-threshold, tools/check_scratch.py lists such instances).  1M x 768 f32,
+    8 queries: a search (host-buffer entry, 3.07 GB to stream) must stay below 0.95 ms."""
+    import time
+
+    from panoptikon_amd import _lib as L
+
+    n, dim = 1_000_000, 768
+    ix = pvs.VectorIndex(pvs.F32, dim, capacity_rows=n)
+    stage = pvs.DeviceBuffer(n * dim * 4)
+    L.check(pvs.lib().pvs_synth_rows_f32(0, 3, 0, n, dim, stage.ptr))
+    ix.add((stage, n))
+    stage.free()
+    q = orc.synth_rows(5, 0, 8, dim)
+    for _ in range(5):
+        ix.search(q, 10, pvs.COSINE)
+    t = time.perf_counter()
+    reps = 30
+    for _ in range(reps):
+        ix.search(q, 10, pvs.COSINE)
+    ms = (time.perf_counter() - t) / reps * 1e3
+    ix.close()
+    assert ms < 0.95, f"{ms:.3f} ms per f32 search of 1M x 768 rows: the scan is not streaming (query fragments in scratch?)"
+

@@ -16,7 +16,7 @@ for name, dt, N in (("i8", pvs.I8, 10_000_000), ("i8", pvs.I8, 1_000_000), ("f32
         L.check(lib.pvs_synth_rows_f32(0, 1, off, 1_000_000, D, stage.ptr))
         ix.add_f32((stage, 1_000_000))
     stage.free()
-    for B in (1, 8):
+    for B in (1, 8, 128) if N == 10_000_000 else (1, 8):
         q = rng.standard_normal((64, B, D)).astype(np.float32)
         q /= np.linalg.norm(q, axis=2, keepdims=True)
         for i in range(5):
