@@ -517,6 +517,12 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) 
         return PVS_OK;
     };
     pvs_status st = one();
+    // The fusion steps that read the columns run on the index's search stream.  With one stream per context
+    // (pvs_index_set_streams > 1) that is another stream than this context's: the columns must be complete before they start.
+    if (st == PVS_OK && c->stream != ix->search_stream) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "scoring a branch: %s", hipGetErrorString(e));
+    }
     pvs_scratch_free_on(d_q, c->stream);  // (the scoring is still queued: the blocks are reusable once the stream has passed this point)
     pvs_scratch_free_on(d_m, c->stream);
     pvs_scratch_free_on(d_w, c->stream);
