@@ -9,6 +9,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 25_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 img = _build_i8(pvs, n, 512, 11, 0.00185, groups_of=lambda r: r // 3)
 txt = _build_i8(pvs, n, 1024, 12, 0.0013, groups_of=lambda r: (r // 3) * 2)
+if len(sys.argv) > 3:
+    img.set_streams(int(sys.argv[3]))
+    txt.set_streams(int(sys.argv[3]))
 qi, qt = orc.synth_rows(0x5EED0000, 0, 1, 512)[0], orc.synth_rows(0x5EED0011, 0, 1, 1024)[0]
 brs = [dict(index=img, query=qi, metric=pvs.COSINE, agg=pvs.AGG_MIN, rrf_k=5, weight=1.0),
        dict(index=txt, query=qt, metric=pvs.L2, agg=pvs.AGG_MIN, rrf_k=10, weight=0.7)]
