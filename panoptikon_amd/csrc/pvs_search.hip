@@ -107,6 +107,14 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     const uint32_t want_tiles = (uint32_t)std::max<uint64_t>(1, (target_rows + wg_rows - 1) / wg_rows);
     a.tile_step = std::max<uint32_t>(1, n_wgtiles / want_tiles);
     const uint32_t n_samp = (n_wgtiles + a.tile_step - 1) / a.tile_step;
+    if (k_sel < k) {
+        // the sample that is actually taken (tile granularity, the 32,768-row floor) may be a larger share of the corpus than planned:
+        // keep the expected number of candidates, k_sel / share, at 8 k (or what the candidate list holds with its 2.5x reserve) —
+        // pass C's certificate needs k of them below T with a margin of many standard deviations (1 / sqrt(k_sel) each)
+        const double share = std::min(1.0, (double)n_samp * wg_rows / (double)ix->n);
+        const double expect = std::min(8.0 * k, (double)PVS_CAND_CAP / 2.5);
+        k_sel = std::min<uint32_t>(k, std::max<uint32_t>(k_sel, (uint32_t)std::ceil(expect * share)));
+    }
     const uint32_t per_cu_a = pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs);
     const uint32_t spp = pvs_scan_segs_per_stream(a.dtype, a.qgroups, a.kslabs);  // lanes per query and workgroup stream (= its candidate segments)
     a.grid = std::min<uint32_t>({n_samp, (uint32_t)ix->n_cu * per_cu_a, GMAX / (spp * pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs))});
