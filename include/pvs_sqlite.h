@@ -81,13 +81,18 @@ typedef struct pvs_sqlite_api {
     const char *(*errmsg)(sqlite3 *);
     void (*result_text)(sqlite3_context *, const char *, int, void (*)(void *));
     /* since ABI v3 — what pvs_backfill writes codes with.  A host that passes a shorter struct gets everything except
-     * pvs_backfill. */
+     * pvs_backfill and pvs_ready_pair. */
     int (*bind_blob)(void *, int, const void *, int, void (*)(void *));
     int (*bind_int64)(void *, int, long long);
     int (*reset)(void *);
 } pvs_sqlite_api;
 
-/* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 / pvs_load / pvs_backfill on one connection.  api == NULL: use
+/* SQL function pvs_ready_pair(profile_name, setter_name, ...) -> NULL | '{"profile_id": p, "scale": s, "dim": d}': the reference's
+ * resolve_ready_pair (db/vector_quants.rs:1795-1869) for hosts that are not its Rust — the profile must be active, every
+ * setter that exists must have a `ready` (profile, setter) pair with a usable scale artifact and a dimension, and all pairs must
+ * share one (scale, dim); unknown setter names are skipped.  No GPU involved. */
+
+/* Registers pvs_dist / pvs_distance_cosine / pvs_distance_l2 / pvs_load / pvs_backfill / pvs_ready_pair on one connection.  api == NULL: use
  * the table a previous call (or a loadable-extension entry point) installed, or — explicit opt-in of a process that knows it
  * carries exactly one SQLite, exported — resolve the entry points by name from the process image.  Returns an SQLite
  * result code (0 = SQLITE_OK). */

@@ -723,6 +723,73 @@ void backfill_cursor_udf(sqlite3_context *ctx, int, sqlite3_value **) {
         g_api.result_int64(ctx, (long long)t_last_backfill.cursor);
 }
 
+// pvs_ready_pair(profile_name, setter_name, ...): resolve_ready_pair (db/vector_quants.rs:1795-1869) for hosts that are not the
+// reference's Rust — NULL unless the profile is active and every existing setter's (profile, setter) pair is `ready` with a usable
+// scale artifact and a dimension, all pairs sharing one (scale, dim); setter names without a `setters` row are skipped.  Returns
+// {"profile_id": .., "scale": .., "dim": ..} (scale printed with 9 significant digits: it round-trips the f32).  The probes are
+// the reference's; they run as nested statements on the calling connection, the arguments bound as the sqlite3_values they are.
+struct Stmt {
+    void *s = nullptr;  // (statements are opaque pointers in pvs_sqlite_api)
+    ~Stmt() {
+        if (s) g_api.finalize(s);
+    }
+};
+void ready_pair_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
+    if (argc < 2) {
+        g_api.result_error(ctx, "pvs_ready_pair(profile_name, setter_name, ...)", -1);
+        return;
+    }
+    sqlite3 *db = g_api.context_db_handle(ctx);
+    auto fail = [&](const char *what) {
+        char *m = g_api.mprintf("pvs_ready_pair: %s: %s", what, g_api.errmsg(db));
+        g_api.result_error(ctx, m ? m : "pvs_ready_pair failed", -1);
+        if (m) g_api.free(m);
+    };
+    Stmt prof, setter, cov;
+    if (g_api.prepare_v2(db, "SELECT id FROM vector_quant_profiles WHERE name = ?1 AND state = 'active'", -1, &prof.s, nullptr) != SQLITE_OK ||
+        g_api.prepare_v2(db, "SELECT id FROM setters WHERE name = ?1", -1, &setter.s, nullptr) != SQLITE_OK ||
+        g_api.prepare_v2(db, "SELECT artifact, dim FROM vector_quant_coverage WHERE profile_id = ?1 AND setter_id = ?2 AND state = 'ready'", -1,
+                         &cov.s, nullptr) != SQLITE_OK)
+        return fail("prepare");
+    if (g_api.bind_value(prof.s, 1, argv[0]) != SQLITE_OK) return fail("bind");
+    int rc = g_api.step(prof.s);
+    if (rc == SQLITE_DONE) return g_api.result_null(ctx);  // no active profile of that name
+    if (rc != SQLITE_ROW) return fail("profile probe");
+    const long long profile_id = g_api.column_int64(prof.s, 0);
+    bool have = false;
+    float scale = 0.f;
+    long long dim = 0;
+    for (int a = 1; a < argc; a++) {
+        if (g_api.reset(setter.s) != SQLITE_OK || g_api.bind_value(setter.s, 1, argv[a]) != SQLITE_OK) return fail("bind");
+        rc = g_api.step(setter.s);
+        if (rc == SQLITE_DONE) continue;  // unknown setter: skipped
+        if (rc != SQLITE_ROW) return fail("setter probe");
+        const long long sid = g_api.column_int64(setter.s, 0);
+        if (g_api.reset(cov.s) != SQLITE_OK || g_api.bind_int64(cov.s, 1, profile_id) != SQLITE_OK || g_api.bind_int64(cov.s, 2, sid) != SQLITE_OK)
+            return fail("bind");
+        rc = g_api.step(cov.s);
+        if (rc == SQLITE_DONE) return g_api.result_null(ctx);  // this pair is not ready
+        if (rc != SQLITE_ROW) return fail("coverage probe");
+        float sc = 0.f;
+        if (g_api.column_type(cov.s, 0) != SQLITE_BLOB || g_api.column_type(cov.s, 1) == SQLITE_NULL ||
+            pvs_artifact_scale((const uint8_t *)g_api.column_blob(cov.s, 0), (size_t)g_api.column_bytes(cov.s, 0), &sc) != PVS_OK)
+            return g_api.result_null(ctx);  // no dimension or no usable scale: not queryable whatever the state column says
+        const long long d = g_api.column_int64(cov.s, 1);
+        if (!have) {
+            have = true;
+            scale = sc;
+            dim = d;
+        } else if (scale != sc || dim != d) {
+            return g_api.result_null(ctx);  // siblings must share one artifact: a rebuild is pending
+        }
+    }
+    if (!have) return g_api.result_null(ctx);
+    char *m = g_api.mprintf("{\"profile_id\": %lld, \"scale\": %.9g, \"dim\": %lld}", profile_id, (double)scale, dim);
+    if (!m) return g_api.result_null(ctx);
+    g_api.result_text(ctx, m, -1, (void (*)(void *))(intptr_t)-1);
+    g_api.free(m);
+}
+
 int register_all(sqlite3 *db) {
     int rc = g_api.create_module_v2(db, "pvs_dist", &g_dist_module, nullptr, nullptr);
     if (rc != SQLITE_OK) return rc;
@@ -736,6 +803,8 @@ int register_all(sqlite3 *db) {
         rc = g_api.create_function_v2(db, "pvs_backfill", -1, SQLITE_UTF8, nullptr, backfill_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;
         rc = g_api.create_function_v2(db, "pvs_backfill_cursor", 0, SQLITE_UTF8, nullptr, backfill_cursor_udf, nullptr, nullptr, nullptr);
+        if (rc != SQLITE_OK) return rc;
+        rc = g_api.create_function_v2(db, "pvs_ready_pair", -1, SQLITE_UTF8, nullptr, ready_pair_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;
     }
     // not SQLITE_DETERMINISTIC: the result depends on the bound index's contents, which SQLite cannot see

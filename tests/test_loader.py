@@ -69,9 +69,31 @@ def build_db(n_items=300, dim=96, seed=3, ragged=True):
 
 
 def test_resolve_ready_pair_matrix():
-    from panoptikon_amd import loader
+    """resolve_ready_pair (db/vector_quants.rs:1795-1869) through both host forms: the Python probes of loader.py and the SQL
+    function pvs_ready_pair of the C extension must agree on every case (no GPU involved)."""
+    import json
+
+    from panoptikon_amd import loader as py_loader, sqlite_seam
 
     conn, good, scale, _ = build_db()
+    sqlite_seam.load(conn)
+
+    class loader:  # every probe below runs twice
+        default_profile_name = staticmethod(py_loader.default_profile_name)
+        active_profile_id = staticmethod(py_loader.active_profile_id)
+
+        @staticmethod
+        def resolve_ready_pair(c, profile, setter_names):
+            a = py_loader.resolve_ready_pair(c, profile, setter_names)
+            marks = ", ".join("?" * (1 + len(setter_names)))
+            row = c.execute(f"SELECT pvs_ready_pair({marks})", [profile, *setter_names]).fetchone()[0]
+            if a is None:
+                assert row is None, (profile, setter_names, row)
+            else:
+                b = json.loads(row)
+                assert b["profile_id"] == a.profile_id and b["dim"] == a.dim and np.float32(b["scale"]) == np.float32(a.scale), (a, row)
+            return a
+
     names = ["clip/m", "tclip/m"]
     p = loader.resolve_ready_pair(conn, "int8", names)
     assert p is not None and p.profile_id == 5 and p.dim == 96 and np.float32(p.scale) == np.float32(scale)
