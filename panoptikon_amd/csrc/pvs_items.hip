@@ -946,10 +946,10 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
         FanoutWeights fw;
         fw.on = weighted || gated;
         if (gated) {
-            HIP_TRY(pvs_malloc_retry((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
-            HIP_TRY(hipMemcpy(d_kind, a.row_kind, ix->n, hipMemcpyHostToDevice));
-            HIP_TRY(pvs_malloc_retry((void **)&d_tkind, n_targets));
-            HIP_TRY(hipMemcpy(d_tkind, tg.kind.data(), n_targets, hipMemcpyHostToDevice));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_kind, std::max<uint64_t>(ix->n, 1)));
+            HIP_TRY(hipMemcpyAsync(d_kind, a.row_kind, ix->n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_tkind, n_targets));
+            HIP_TRY(hipMemcpyAsync(d_tkind, tg.kind.data(), n_targets, hipMemcpyHostToDevice, c->stream));
             fw.kind = d_kind;
             fw.t_kind = d_tkind;
             fw.skip_i2i = a.skip_i2i;
@@ -958,11 +958,11 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
         if (weighted) {
             // NULL pointer = every confidence NULL (coalesced to 1 in the kernel)
             auto upload = [&](const double *src, uint64_t n, double **dst) -> pvs_status {
-                HIP_TRY(pvs_malloc_retry((void **)dst, std::max<uint64_t>(n, 1) * 8));
+                HIP_TRY(pvs_scratch_alloc((void **)dst, std::max<uint64_t>(n, 1) * 8));
                 if (src)
-                    HIP_TRY(hipMemcpy(*dst, src, n * 8, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpyAsync(*dst, src, n * 8, hipMemcpyHostToDevice, c->stream));
                 else
-                    HIP_TRY(hipMemset(*dst, 0xff, n * 8));  // all-ones bits = NaN
+                    HIP_TRY(hipMemsetAsync(*dst, 0xff, n * 8, c->stream));  // all-ones bits = NaN
                 return PVS_OK;
             };
             PVS_TRY(upload(a.row_conf, ix->n, &d_conf));
@@ -976,12 +976,12 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
             fw.cw = a.cw;
             fw.lw = a.lw;
         }
-        HIP_TRY(pvs_malloc_retry(&d_q, tg.hq.size()));
-        HIP_TRY(hipMemcpy(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice));
-        HIP_TRY(pvs_malloc_retry((void **)&d_ex, ix->n + 1));
+        HIP_TRY(pvs_scratch_alloc(&d_q, tg.hq.size()));
+        HIP_TRY(hipMemcpyAsync(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_ex, ix->n + 1));
         HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
         for (uint32_t r : excluded) HIP_TRY(hipMemsetAsync(d_ex + r, 1, 1, c->stream));
-        HIP_TRY(pvs_malloc_retry((void **)&d_m, std::max<size_t>((size_t)ix->n * n_targets * 4, 4)));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, std::max<size_t>((size_t)ix->n * n_targets * 4, 4)));
         const uint32_t pad = n_targets <= 32 ? 32 : n_targets <= 64 ? 64 : 128;
         PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m));
@@ -990,7 +990,7 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
     };
     pvs_status st = body();
     for (void *p : {(void *)d_q, (void *)d_m, (void *)d_ex, (void *)d_conf, (void *)d_lang, (void *)d_tconf, (void *)d_tlang, (void *)d_kind, (void *)d_tkind})
-        hipFree(p);
+        pvs_scratch_free_on(p, c->stream);  // (cached blocks: hipMalloc / hipFree per call cost more than the scoring at the reference's scale)
     ix->searches++;
     ctx_done(ix, c);
     return st;
