@@ -150,10 +150,10 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, 1, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(pvs_malloc_retry(&d_q, qbytes * batch));
+        HIP_TRY(pvs_scratch_alloc(&d_q, qbytes * batch));  // (cached blocks: hipMalloc / hipFree per call would stall every other host thread's searches)
         HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
         const uint32_t cq = dense_chunk_queries(ix, batch);
-        HIP_TRY(pvs_malloc_retry((void **)&d_m, (size_t)ix->n * cq * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)ix->n * cq * 4));
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
@@ -167,8 +167,8 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_q);
-    hipFree(d_m);
+    pvs_scratch_free_on(d_q, c->stream);
+    pvs_scratch_free_on(d_m, c->stream);
     ctx_done(ix, c);
     return st;
 }
@@ -183,10 +183,10 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
     double *d_ov = nullptr;
     uint32_t *d_oc = nullptr;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(pvs_malloc_retry((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
-        HIP_TRY(pvs_malloc_retry((void **)&d_og, (size_t)k * 8));
-        HIP_TRY(pvs_malloc_retry((void **)&d_ov, (size_t)k * 8));
-        HIP_TRY(pvs_malloc_retry((void **)&d_oc, 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_vals, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_og, (size_t)k * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_ov, (size_t)k * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
                                            c.stream, fw, skip_when));
         for (uint32_t q = 0; q < ncol; q++) {
@@ -199,10 +199,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_vals);
-    hipFree(d_og);
-    hipFree(d_ov);
-    hipFree(d_oc);
+    for (void *p : {(void *)d_vals, (void *)d_og, (void *)d_ov, (void *)d_oc}) pvs_scratch_free_on(p, c.stream);
     return st;
 }
 
@@ -354,12 +351,12 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(pvs_malloc_retry(&d_q, qbytes * batch));
+        HIP_TRY(pvs_scratch_alloc(&d_q, qbytes * batch));
         HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
         const uint8_t *dm = nullptr;  // candidate mask on the device
         if (mask && ix->n) {
             if (mask_space == PVS_HOST) {
-                HIP_TRY(pvs_malloc_retry((void **)&d_mask, ix->n));
+                HIP_TRY(pvs_scratch_alloc((void **)&d_mask, ix->n));
                 HIP_TRY(hipMemcpyAsync(d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
                 dm = d_mask;
             } else {
@@ -367,11 +364,11 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
             }
         }
         if (row_weights && ix->n) {
-            HIP_TRY(pvs_malloc_retry((void **)&d_w, ix->n * 4));
+            HIP_TRY(pvs_scratch_alloc((void **)&d_w, ix->n * 4));
             HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
         }
         const uint32_t cq = dense_chunk_queries(ix, batch);
-        HIP_TRY(pvs_malloc_retry((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
@@ -385,10 +382,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         return PVS_OK;
     };
     pvs_status st = body();
-    hipFree(d_q);
-    hipFree(d_m);
-    hipFree(d_w);
-    hipFree(d_mask);
+    for (void *p : {d_q, (void *)d_m, (void *)d_w, (void *)d_mask}) pvs_scratch_free_on(p, c->stream);
     ix->searches++;
     ix->dense_queries += batch;
     ctx_done(ix, c);
