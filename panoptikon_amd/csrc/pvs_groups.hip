@@ -150,6 +150,21 @@ __global__ void k_group_emit(const uint32_t *idx_sorted, const double *vals, con
     if (threadIdx.x == 0) *out_count = nout;
 }
 
+// the same keys in group order (no permutation): input of the page-first ranking (pvs_group_page_keys)
+__global__ void k_group_page_keys(const double *vals, uint32_t n, unsigned long long *keys) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned long long k = f64_sort_key(vals[i]);
+        if (k == ~0ull) k = ~0ull - 1;
+        if (__builtin_bit_cast(unsigned long long, vals[i]) == PVS_GROUP_ABSENT) k = ~0ull;
+        keys[i] = k;
+    }
+}
+hipError_t pvs_group_page_keys(const double *d_vals, uint32_t n_groups, unsigned long long *d_keys, hipStream_t s) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_group_page_keys, dim3((n_groups + 255) / 256 > 4096 ? 4096 : (n_groups + 255) / 256), dim3(256), 0, s, d_vals, n_groups, d_keys);
+    return hipGetLastError();
+}
+
 // ranks one column of group values: (value asc, group id asc — groups are stored in id order and
 // the radix sort is stable), NaN last; writes the first k.
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,

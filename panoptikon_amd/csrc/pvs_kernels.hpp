@@ -1,5 +1,6 @@
 // pvs_kernels.hpp — host-callable launchers of the HIP kernels (gfx950).
 #pragma once
+#include <cstring>
 #include "pvs_common.hpp"
 
 // ---- utility kernels (pvs_kernels_util.hip)
@@ -215,6 +216,16 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s, const uint32_t *g_tinv = nullptr);
 void pvs_group_work_release(GroupWork &w);
+// order-preserving u64 keys of one column of group values, in group order: value asc, NULL aggregates (~0 - 1) after every value,
+// absent groups (~0) last.  The value is recovered from its key (pvs_group_value_of_key).
+hipError_t pvs_group_page_keys(const double *d_vals, uint32_t n_groups, unsigned long long *d_keys, hipStream_t s);
+inline double pvs_group_value_of_key(unsigned long long k) {
+    if (k >= ~0ull - 1) return __builtin_nan("");
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
 
 // ---- reciprocal-rank fusion of several ranked branches (pvs_rrf.hip)
 constexpr int PVS_RRF_MAX_BRANCHES = 8;
@@ -227,6 +238,10 @@ struct PvsRrfParams {
 // given groups, and how many groups stand strictly before each of a handful of candidates (one counting pass over the keys)
 pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s);
 pvs_status pvs_rrf_sample_keys(const unsigned long long *d_keys, uint32_t n, uint32_t m, unsigned long long *h_out, hipStream_t s);
+// the same for ncol key columns [ncol][n] at once (one round trip each)
+pvs_status pvs_rrf_sample_keys_cols(const unsigned long long *d_keys, uint32_t n, uint32_t ncol, uint32_t m, unsigned long long *h_out, hipStream_t s);
+pvs_status pvs_rrf_pages_cols(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, uint32_t ncol, const unsigned long long *h_thr,
+                              uint32_t cap, int64_t *out_gids, unsigned long long *out_keys, uint32_t *out_count, hipStream_t s);
 pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, unsigned long long thr, uint32_t cap,
                         int64_t *out_gids, unsigned long long *out_keys, uint32_t *out_count, hipStream_t s);
 pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const int64_t *cand, uint32_t m,

@@ -231,6 +231,83 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
     pvs_scratch_free_on(d_k, s);
     return st;
 }
+// The page step for `ncol` key columns at once ([ncol][n] keys, one threshold each): three host round trips for the whole batch
+// (samples, counts, pages) instead of three per column.  Used by the per-item search's page-first ranking (pvs_items.hip).
+namespace {
+__global__ void k_sample_keys_cols(const unsigned long long *keys, uint32_t n, uint32_t ncol, uint32_t m, unsigned long long *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m * ncol) {
+        const uint32_t col = i / m, j = i % m;
+        out[i] = keys[(size_t)col * n + (uint64_t)j * n / m];
+    }
+}
+__global__ void k_page_compact_cols(const unsigned long long *keys, uint32_t n, const unsigned long long *thr, uint32_t cap, uint32_t *count,
+                                    uint32_t *slots) {
+    const uint32_t col = blockIdx.y;
+    const unsigned long long t = thr[col];
+    const unsigned long long *kc = keys + (size_t)col * n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (kc[i] <= t) {
+            const uint32_t p = atomicAdd(count + col, 1u);
+            if (p < cap) slots[(size_t)col * cap + p] = i;
+        }
+}
+__global__ void k_gather_page_cols(const int64_t *gids, const unsigned long long *keys, uint32_t n, const uint32_t *slots, const uint32_t *count,
+                                   uint32_t cap, int64_t *out_g, unsigned long long *out_k) {
+    const uint32_t col = blockIdx.y;
+    const uint32_t m = count[col] < cap ? count[col] : 0u;  // (an overflowed column is not read back)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t sl = slots[(size_t)col * cap + i];
+        out_g[(size_t)col * cap + i] = gids[sl];
+        out_k[(size_t)col * cap + i] = keys[(size_t)col * n + sl];
+    }
+}
+}  // namespace
+pvs_status pvs_rrf_sample_keys_cols(const unsigned long long *d_keys, uint32_t n, uint32_t ncol, uint32_t m, unsigned long long *h_out, hipStream_t s) {
+    unsigned long long *d = nullptr;
+    HIP_TRY(pvs_scratch_alloc((void **)&d, (size_t)m * ncol * 8));
+    hipLaunchKernelGGL(k_sample_keys_cols, dim3((m * ncol + 255) / 256), dim3(256), 0, s, d_keys, n, ncol, m, d);
+    hipError_t e = hipMemcpyAsync(h_out, d, (size_t)m * ncol * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    pvs_scratch_free_on(d, s);
+    if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "sample keys: %s", hipGetErrorString(e));
+    return PVS_OK;
+}
+// per column: every group with key <= thr[col]; out_*: [ncol][cap] host arrays, out_count[col] may exceed cap (column not written)
+pvs_status pvs_rrf_pages_cols(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, uint32_t ncol, const unsigned long long *h_thr,
+                              uint32_t cap, int64_t *out_gids, unsigned long long *out_keys, uint32_t *out_count, hipStream_t s) {
+    uint32_t *d_cnt = nullptr, *d_slots = nullptr;
+    unsigned long long *d_thr = nullptr, *d_k = nullptr;
+    int64_t *d_g = nullptr;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(pvs_scratch_alloc((void **)&d_cnt, (size_t)ncol * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_thr, (size_t)ncol * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_slots, (size_t)ncol * cap * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_g, (size_t)ncol * cap * 8));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_k, (size_t)ncol * cap * 8));
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)ncol * 4, s));
+        HIP_TRY(hipMemcpyAsync(d_thr, h_thr, (size_t)ncol * 8, hipMemcpyHostToDevice, s));
+        const unsigned gx = (unsigned)std::min<uint32_t>((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_page_compact_cols, dim3(gx, ncol), dim3(256), 0, s, d_keys, n, d_thr, cap, d_cnt, d_slots);
+        hipLaunchKernelGGL(k_gather_page_cols, dim3((cap + 255) / 256 > 64 ? 64 : (cap + 255) / 256, ncol), dim3(256), 0, s, d_gids, d_keys, n, d_slots,
+                           d_cnt, cap, d_g, d_k);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_count, d_cnt, (size_t)ncol * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // only the filled part of every column travels
+        for (uint32_t col = 0; col < ncol; col++) {
+            const uint32_t m = out_count[col] <= cap ? out_count[col] : 0u;
+            if (!m) continue;
+            HIP_TRY(hipMemcpyAsync(out_gids + (size_t)col * cap, d_g + (size_t)col * cap, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(out_keys + (size_t)col * cap, d_k + (size_t)col * cap, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    for (void *p : {(void *)d_cnt, (void *)d_thr, (void *)d_slots, (void *)d_g, (void *)d_k}) pvs_scratch_free_on(p, s);
+    return st;
+}
 // candidate group ids -> window key in this branch; present[c] = 0 when the branch (shard) does not hold the group
 pvs_status pvs_rrf_lookup(const unsigned long long *d_keys, const int64_t *d_gids, uint32_t n, const int64_t *cand, uint32_t m,
                           unsigned long long *out_keys, uint8_t *out_present, hipStream_t s) {

@@ -1730,3 +1730,45 @@ def test_threshold_below_the_kth_sample_value_is_certified_or_handed_back(pvs, d
     assert after.fast_queries - before.fast_queries >= 6
     ix.close()
 
+
+def test_per_item_page_from_many_groups_without_sorting_them_all(pvs):
+    """MAX / AVG / weighted per-item search over >= 65,536 files ranks through a page of the files at or below a sampled
+    threshold (aggregate_and_rank: rank_groups_page_first) instead of sorting every file per query: the page must be the
+    oracle's — values tying across files (int8 L2), NULL aggregates, a candidate mask, the second sort key, k from 1 to 3,000."""
+    rng = np.random.default_rng(17)
+    files, dim = 90_000, 32
+    per_file = rng.integers(1, 4, files)
+    grp = np.repeat(np.arange(files, dtype=np.int64) * 3 + 1, per_file)
+    n = len(grp)
+    base = unit_rows(411, 5000, dim)
+    rows = base[rng.integers(0, 5000, n)]                     # few distinct vectors: aggregates tie across files
+    rows[np.nonzero(grp == grp[n // 2])[0]] = 0.0               # a file of zero vectors: NULL cosine aggregate
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    keys = np.repeat(rng.integers(0, 7, files).astype(np.int64), per_file)
+    w = (rng.random(n) + 0.2).astype(np.float32)
+    mask = (rng.random(n) < 0.4).astype(np.uint8)
+    allowed = np.nonzero(mask)[0]
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows, group_ids=grp)
+    qs = base[np.arange(7, 7 + 24)] + 0.01 * orc.synth_rows(412, 0, 24, dim)   # 24 columns x 90k files: the page-first ranking
+    hq = orc.quantize_int8(qs, scale)
+    for with_keys in (False, True):
+        ix.set_order_keys(keys if with_keys else None)
+        ok = keys if with_keys else None
+        for k in (1, 50, 3000):
+            for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+                for agg, oagg, ww in ((pvs.AGG_MAX, orc.AGG_MAX, None), (pvs.AGG_AVG, orc.AGG_AVG, None), (pvs.AGG_AVG, orc.AGG_AVG, w)):
+                    og, ov, oc = ix.search_groups(qs, k, metric, agg, row_weights=ww)
+                    for j in (0, 11, 23):
+                        eg, ev = orc.search_groups(orc.I8, om, codes, hq[j], grp, oagg, k, weights=ww, order_keys=ok)
+                        assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (with_keys, k, metric, agg, ww is not None, j)
+                        a, e = ov[j, : oc[j]], ev
+                        assert np.array_equal(np.isnan(a), np.isnan(e)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), e[~np.isnan(e)].view(np.uint64))
+            og, ov, oc = ix.search_groups_filtered(qs, k, mask, pvs.L2, pvs.AGG_MAX)
+            for j in (0, 23):
+                eg, ev = orc.search_groups(orc.I8, orc.L2, codes[allowed], hq[j], grp[allowed], orc.AGG_MAX, k, order_keys=None if ok is None else ok[allowed])
+                assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (with_keys, k, "masked", j)
+    ix.close()
+
