@@ -30,18 +30,56 @@ struct Kbn {
 //                w = pow(coalesce(conf_t,1)*coalesce(conf_o,1), cw) * pow(coalesce(lang_o,1)*coalesce(lang_t,1), lw)
 //                (a factor is dropped when its exponent is 0) and the value is SUM(d*w)/SUM(w).
 __device__ static inline double coalesce1(double v) { return v != v ? 1.0 : v; }
-__global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout,
-                                                         const uint32_t *grp_off, const uint32_t *grp_rows, uint32_t n_groups,
-                                                         const float *weights, const uint8_t *exclude, int agg, FanoutWeights fw,
-                                                         double *out, uint32_t skip_when) {
-    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t ncol_out = fanout ? 1u : n_cols;
-    if (gid >= (uint64_t)n_groups * ncol_out) return;
-    const uint32_t g = (uint32_t)(gid / ncol_out), q = (uint32_t)(gid % ncol_out);
+// One value per (group, output column).  A workgroup owns a tile of TG consecutive groups x all output columns: it walks the
+// tile column-fastest (adjacent lanes read adjacent floats of one row of `dist`) and hands the values to the column-major output
+// through LDS, group-fastest (the direct store — adjacent lanes 8 B apart in columns that lie n_groups * 8 B apart — was one
+// partial cache line per lane: 1.1 ms for 4M rows x 32 queries, the largest kernel of the dense per-item search).
+// groups per workgroup tile: 32, or more when there are few columns (a tile is at least 256 values)
+static inline uint32_t agg_tile_groups(uint32_t ncol_out) { return ncol_out >= 8 ? 32u : 256u / ncol_out; }
+__device__ static inline double group_value(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
+                                            const uint32_t *grp_rows, const float *weights, const uint8_t *exclude, int agg, const FanoutWeights &fw,
+                                            uint32_t skip_when, uint32_t g, uint32_t q) {
     Kbn sum, wsum;
     double mn = __builtin_inf(), mx = -__builtin_inf();
     uint64_t cnt = 0, joined = 0;  // joined: (row, target) pairs that are part of the join at all
-    for (uint32_t e = grp_off[g]; e < grp_off[g + 1]; e++) {
+    const uint32_t e_begin = grp_off[g], e_end = grp_off[g + 1];
+    uint32_t e_slow = e_begin;
+    if (!fanout && !fw.on) {
+        // per-item search (one column per query): the loads of four rows of the group go out together — the one-row-at-a-time
+        // loop is a chain of two dependent loads per row (row index, then its distance), which is all this kernel waits for;
+        // the sums still run in row order
+        for (uint32_t e = e_begin; e < e_end; e += 4) {
+            const uint32_t m = e_end - e < 4 ? e_end - e : 4;
+            uint32_t rw[4];
+            float df4[4], w4[4];
+            uint8_t ex4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) rw[i] = (uint32_t)i < m ? grp_rows[e + i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool on = (uint32_t)i < m;
+                df4[i] = on ? dist[(size_t)rw[i] * ld + q] : 0.f;
+                w4[i] = on && weights ? weights[rw[i]] : 1.f;
+                ex4[i] = on && exclude ? exclude[rw[i]] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((uint32_t)i >= m) break;
+                if (exclude && (uint32_t)(ex4[i] != 0) == skip_when) continue;
+                joined++;
+                const double w = (double)w4[i];
+                if (weights) wsum.step(w);
+                if (df4[i] != df4[i]) continue;
+                const double d = (double)df4[i];
+                sum.step(weights ? d * w : d);
+                mn = fmin(mn, d);
+                mx = fmax(mx, d);
+                cnt++;
+            }
+        }
+        e_slow = e_end;
+    }
+    for (uint32_t e = e_slow; e < e_end; e++) {
         const uint32_t row = grp_rows[e];
         if (exclude && (uint32_t)(exclude[row] != 0) == skip_when) continue;  // similar_to: flagged rows; candidate mask: rows it leaves out
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
@@ -91,16 +129,35 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
         v = mx;
     else
         v = sum.value() / (double)cnt;
-    out[(size_t)q * n_groups + g] = v;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout,
+                                                         const uint32_t *grp_off, const uint32_t *grp_rows, uint32_t n_groups,
+                                                         const float *weights, const uint8_t *exclude, int agg, FanoutWeights fw,
+                                                         double *out, uint32_t skip_when, uint32_t TG) {
+    extern __shared__ double s_tile[];  // [ncol_out][TG]
+    const uint32_t ncol_out = fanout ? 1u : n_cols;
+    const uint32_t g0 = blockIdx.x * TG;
+    const uint32_t tg = n_groups - g0 < TG ? n_groups - g0 : TG;
+    for (uint32_t idx = threadIdx.x; idx < tg * ncol_out; idx += 256) {
+        const uint32_t gl = idx / ncol_out, q = idx % ncol_out;
+        s_tile[q * TG + gl] = group_value(dist, ld, n_cols, fanout, grp_off, grp_rows, weights, exclude, agg, fw, skip_when, g0 + gl, q);
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < TG * ncol_out; idx += 256) {
+        const uint32_t q = idx / TG, gl = idx % TG;
+        if (gl < tg) out[(size_t)q * n_groups + g0 + gl] = s_tile[idx];
+    }
 }
 
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
                                       int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when) {
     if (n_groups == 0) return hipSuccess;
-    const uint64_t total = (uint64_t)n_groups * (fanout ? 1u : n_cols);
-    hipLaunchKernelGGL(k_group_aggregate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dist, ld, n_cols, fanout, grp_off,
-                       grp_rows, n_groups, weights, exclude, agg, fw, out, skip_when);
+    const uint32_t ncol_out = fanout ? 1u : n_cols;
+    const uint32_t TG = agg_tile_groups(ncol_out);
+    hipLaunchKernelGGL(k_group_aggregate, dim3((n_groups + TG - 1) / TG), dim3(256), (size_t)ncol_out * TG * 8, s, dist, ld, n_cols, fanout,
+                       grp_off, grp_rows, n_groups, weights, exclude, agg, fw, out, skip_when, TG);
     return hipGetLastError();
 }
 
