@@ -113,12 +113,30 @@ __global__ void k_sample_keys(const unsigned long long *keys, uint32_t n, uint32
     if (i < m) out[i] = keys[(uint64_t)i * n / m];
 }
 // every group whose window key is <= thr, in any order: (slot, key)
-__global__ void k_page_compact(const unsigned long long *keys, uint32_t n, unsigned long long thr, uint32_t cap, uint32_t *count, uint32_t *slots) {
+// (hits are collected per workgroup in LDS and claim their slots with one global atomic: thousands of hits on one counter
+//  serialise in L2 — see k_page_compact_cols)
+__global__ __launch_bounds__(256) void k_page_compact(const unsigned long long *keys, uint32_t n, unsigned long long thr, uint32_t cap, uint32_t *count,
+                                                      uint32_t *slots) {
+    constexpr uint32_t LIST = 1024;
+    __shared__ uint32_t s_n, s_base, s_list[LIST];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         if (keys[i] <= thr) {
-            const uint32_t p = atomicAdd(count, 1u);
-            if (p < cap) slots[p] = i;
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            if (p < LIST) {
+                s_list[p] = i;
+            } else {
+                const uint32_t gp = atomicAdd(count, 1u);
+                if (gp < cap) slots[gp] = i;
+            }
         }
+    __syncthreads();
+    const uint32_t m = s_n < LIST ? s_n : LIST;
+    if (threadIdx.x == 0 && m) s_base = atomicAdd(count, m);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < m; j += blockDim.x)
+        if (s_base + j < cap) slots[s_base + j] = s_list[j];
 }
 __global__ void k_gather_page(const int64_t *gids, const unsigned long long *keys, const uint32_t *slots, uint32_t m, int64_t *out_g,
                               unsigned long long *out_k) {
@@ -231,6 +249,7 @@ pvs_status pvs_rrf_page(const unsigned long long *d_keys, const int64_t *d_gids,
     pvs_scratch_free_on(d_k, s);
     return st;
 }
+constexpr uint32_t CNT_PAD = 32;  // words between the counters of two columns (one 128-byte line each)
 // The page step for `ncol` key columns at once ([ncol][n] keys, one threshold each): three host round trips for the whole batch
 // (samples, counts, pages) instead of three per column.  Used by the per-item search's page-first ranking (pvs_items.hip).
 namespace {
@@ -241,19 +260,34 @@ __global__ void k_sample_keys_cols(const unsigned long long *keys, uint32_t n, u
         out[i] = keys[(size_t)col * n + (uint64_t)j * n / m];
     }
 }
-constexpr uint32_t CNT_PAD = 32;
-__global__ void k_page_compact_cols(const unsigned long long *keys, uint32_t n, const unsigned long long *thr, uint32_t cap, uint32_t *count,
-                                    uint32_t *slots) {
+__global__ __launch_bounds__(256) void k_page_compact_cols(const unsigned long long *keys, uint32_t n, const unsigned long long *thr, uint32_t cap,
+                                                           uint32_t *count, uint32_t *slots) {
+    // Hits are collected per workgroup in LDS and claim their slots with ONE global atomic (a few thousand hits per column on
+    // one counter serialise in L2: 0.4 ms for a 60-us pass over the keys; counters of different columns sit CNT_PAD words apart).
+    constexpr uint32_t LIST = 1024;
+    __shared__ uint32_t s_n, s_base, s_list[LIST];
     const uint32_t col = blockIdx.y;
     const unsigned long long t = thr[col];
     const unsigned long long *kc = keys + (size_t)col * n;
-    // (one counter per 128-byte line, CNT_PAD words apart: atomics on one line serialise in L2 — 32 columns x 4k hits on adjacent
-    //  words took 1.6 ms for a 60-us pass over the keys)
+    uint32_t *cnt = count + (size_t)col * CNT_PAD;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         if (kc[i] <= t) {
-            const uint32_t p = atomicAdd(count + (size_t)col * CNT_PAD, 1u);
-            if (p < cap) slots[(size_t)col * cap + p] = i;
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            if (p < LIST) {
+                s_list[p] = i;
+            } else {  // (a dense patch of hits: straight to the global counter)
+                const uint32_t gp = atomicAdd(cnt, 1u);
+                if (gp < cap) slots[(size_t)col * cap + gp] = i;
+            }
         }
+    __syncthreads();
+    const uint32_t m = s_n < LIST ? s_n : LIST;
+    if (threadIdx.x == 0 && m) s_base = atomicAdd(cnt, m);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < m; j += blockDim.x)
+        if (s_base + j < cap) slots[(size_t)col * cap + s_base + j] = s_list[j];
 }
 __global__ void k_gather_page_cols(const int64_t *gids, const unsigned long long *keys, uint32_t n, const uint32_t *slots, const uint32_t *count,
                                    uint32_t cap, int64_t *out_g, unsigned long long *out_k) {
