@@ -221,7 +221,7 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
                    ("pvs_rrf_search_sharded over RCCL (ncclAllGather of the padded pages, ncclAllReduce min / sum of thresholds and counts)" if comm4 is not None
                     else "pvs_rrf_search_sharded with the control socket as its all-gather (--allow-host-gather)")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "k_scan MODE 2 (exact int8 distances of every row, matrix core)", "launches": int(sum(p.scan_launches for p in profs)),
+                     "traffic": None, "kernel": "k_score_i8_direct (exact int8 distances of every row for one query: v_dot4 straight from HBM)", "launches": int(sum(p.scan_launches for p in profs)),
                      "avg_launch_ms": round(sum(p.scan_ms for p in profs) / max(sum(p.scan_launches for p in profs), 1), 4),
                      "algorithmic_bytes_per_query": int(bytes_per_query), "scoring_ms_per_query": round(scan_ms, 3),
                      "whole_query_frac_of_peak": round(bytes_per_query / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
