@@ -129,12 +129,23 @@ __device__ static inline uint32_t radix_pick(const uint32_t *hist, uint32_t *s_s
     return bin;
 }
 
+// lo / hi: the smallest and the largest key when the caller knows them (it usually produced the keys a moment ago): the digits then
+// start at the highest bit in which two keys differ — the keys of one query are floats of similar magnitude, their leading byte or
+// two are common — as in kth_in_registers.  lo > hi: unknown, four digits from the top.
 template <typename KeyAt>
-__device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hist, uint32_t *s_sel, KeyAt key_at) {
+__device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hist, uint32_t *s_sel, KeyAt key_at, uint32_t lo = 1, uint32_t hi = 0) {
     const int tid = threadIdx.x;
     uint32_t prefix = 0, mask = 0, kk = k;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 24 - 8 * pass;
+    int shift = 24;
+    if (lo <= hi) {
+        const uint32_t diff = lo ^ hi;
+        if (diff == 0) return lo;
+        const int top = 31 - __builtin_clz(diff);
+        mask = top == 31 ? 0u : ~((2u << top) - 1u);
+        prefix = hi & mask;
+        shift = top >= 7 ? top - 7 : 0;
+    }
+    for (int pass = 0;; pass++) {
         hist[tid] = 0;  // (every thread has read the previous digit's histogram before radix_pick's first barrier)
         __syncthreads();
         for (uint32_t i = tid; i < n; i += 256) {
@@ -144,10 +155,32 @@ __device__ static inline uint32_t radix_kth(uint32_t n, uint32_t k, uint32_t *hi
         __syncthreads();
         const uint32_t b = radix_pick(hist, s_sel, pass, kk);
         if (b >= 256) return 0xffffffffu;
-        prefix |= b << shift;
+        prefix |= b << shift;  // (a last digit that overlaps the previous one re-states bits the filter already fixed)
         mask |= 0xffu << shift;
+        if (shift == 0) break;
+        shift = shift >= 8 ? shift - 8 : 0;
     }
     return prefix;
+}
+// workgroup-wide minimum and maximum of per-thread values (256 threads); s_mm: 8 words of LDS
+__device__ static inline void wg_min_max(uint32_t &lo, uint32_t &hi, uint32_t *s_mm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, off, 64), h2 = (uint32_t)__shfl_xor((int)hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0) {
+        s_mm[wave] = lo;
+        s_mm[4 + wave] = hi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        lo = s_mm[w] < lo ? s_mm[w] : lo;
+        hi = s_mm[4 + w] > hi ? s_mm[4 + w] : hi;
+    }
 }
 
 // The select with the keys of one query in NR registers per thread (per_query <= 256 * NR).  The keys of a query are floats of
@@ -514,17 +547,23 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     }
     const QInfo qi = a.qinfo[q];
     auto cand_at = [&](uint32_t i) __attribute__((always_inline)) { return staged ? s_cand[i] : flat[i]; };
+    uint32_t ub_lo = 0xffffffffu, ub_hi = 0u;  // range of the upper-bound keys: the select below starts at their first differing bit
     for (uint32_t i = tid; i < cnt; i += 256) {
         const uint2 c = cand_at(i);
         const float aa = a.norm2[c.x];
         if (staged) s_aa[i] = aa;
-        s_ub[i] = f32_sort_key(cand_key<DT>(a, qi, c.y, aa) + cand_err(a, qi, aa));
+        const uint32_t ubk = f32_sort_key(cand_key<DT>(a, qi, c.y, aa) + cand_err(a, qi, aa));
+        s_ub[i] = ubk;
+        ub_lo = ubk < ub_lo ? ubk : ub_lo;
+        ub_hi = ubk > ub_hi ? ubk : ub_hi;
     }
     if (tid == 0) s_misc[0] = 0;
+    __shared__ uint32_t s_mm_fin[8];
+    wg_min_max(ub_lo, ub_hi, s_mm_fin);  // (its barrier also publishes s_ub and s_misc[0])
     __syncthreads();
     FIN_STAMP(2);
     uint32_t kub = 0xffffffffu;
-    if (cnt > a.k || (a.thr && cnt == a.k)) kub = radix_kth(cnt, a.k, hist, s_misc + 2, [&](uint32_t i) { return s_ub[i]; });
+    if (cnt > a.k || (a.thr && cnt == a.k)) kub = radix_kth(cnt, a.k, hist, s_misc + 2, [&](uint32_t i) { return s_ub[i]; }, ub_lo, ub_hi);
     const float kappa = (kub == 0xffffffffu) ? __builtin_inff() : f32_from_sort_key(kub);
     __syncthreads();
     // A threshold taken below the k-th sample value (a.thr set) does not by itself guarantee k rows at or below it.  The scan emitted
@@ -615,7 +654,17 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     }
     __syncthreads();
     FIN_STAMP(5);
-    // bitonic sort ascending on (distance key, row or tie rank)
+    // sort ascending on (distance key, row or tie rank).  The usual ~100 survivors: a rank sort — the entries are distinct, so an
+    // entry's slot is the number of smaller ones; one pass of broadcast LDS reads and one barrier where the bitonic network below
+    // takes 28 barrier-separated steps for 128 entries (4.4 us of a 30-us workgroup).
+    if (m2 <= 256) {
+        const unsigned long long mine = (uint32_t)tid < m ? s_sort[tid] : ~0ull;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) rank += s_sort[j] < mine ? 1u : 0u;
+        __syncthreads();
+        if ((uint32_t)tid < m) s_sort[rank] = mine;
+        __syncthreads();
+    } else
     for (uint32_t sz = 2; sz <= m2; sz <<= 1) {
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
             for (uint32_t i = tid; i < m2 / 2; i += 256) {
