@@ -1086,20 +1086,30 @@ pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_
     }
     const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
     tg.hq.resize((size_t)n_targets * ix->dim * qesz);
-    std::vector<uint8_t> rowbuf((size_t)ix->dim * ix->esz);
-    for (uint32_t i = 0; i < n_targets; i++) {
-        PVS_TRY(pvs_index_read_rows(ix, trow[i], 1, rowbuf.data()));
-        uint8_t *dst = tg.hq.data() + (size_t)i * ix->dim * qesz;
-        if (ix->dtype == PVS_F16) {
-            for (uint32_t e = 0; e < ix->dim; e++) {
-                _Float16 hv;
-                memcpy(&hv, rowbuf.data() + 2 * e, 2);
-                const float f = (float)hv;
-                memcpy(dst + 4 * e, &f, 4);
+    // the target's rows are usually consecutive (one item's vectors): one read per run of consecutive rows, not one per row (each
+    // read is a gather kernel, a copy and a synchronisation: eight of them were half of a similar_to call at the reference's scale)
+    const size_t row_bytes = (size_t)ix->dim * ix->esz;
+    std::vector<uint8_t> rowbuf;
+    for (uint32_t i = 0; i < n_targets;) {
+        uint32_t run = 1;
+        while (i + run < n_targets && trow[i + run] == trow[i] + run) run++;
+        rowbuf.resize(row_bytes * run);
+        PVS_TRY(pvs_index_read_rows(ix, trow[i], run, rowbuf.data()));
+        for (uint32_t r = 0; r < run; r++) {
+            const uint8_t *src = rowbuf.data() + row_bytes * r;
+            uint8_t *dst = tg.hq.data() + (size_t)(i + r) * ix->dim * qesz;
+            if (ix->dtype == PVS_F16) {
+                for (uint32_t e = 0; e < ix->dim; e++) {
+                    _Float16 hv;
+                    memcpy(&hv, src + 2 * e, 2);
+                    const float f = (float)hv;
+                    memcpy(dst + 4 * e, &f, 4);
+                }
+            } else {
+                memcpy(dst, src, row_bytes);
             }
-        } else {
-            memcpy(dst, rowbuf.data(), rowbuf.size());
         }
+        i += run;
     }
     const double null_v = __builtin_nan("");
     tg.conf.assign(n_targets, null_v);
