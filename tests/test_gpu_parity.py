@@ -1772,3 +1772,29 @@ def test_per_item_page_from_many_groups_without_sorting_them_all(pvs):
                 assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (with_keys, k, "masked", j)
     ix.close()
 
+
+def test_direct_int8_scorer_hands_sums_beyond_2_24_to_the_in_order_scorer(pvs):
+    """k_score_i8_direct (1..4 queries: pvs_score_all, small pvs_score_batch, per-branch RRF scoring) finishes with the closed form
+    of the exact integer sums, valid while they stay below 2^24.  Saturated codes at dim 1024 push an L2 sum to 4 x 1024 x 127^2:
+    the kernel raises its flag and the in-order scorer answers — the column must be the oracle's either way, bit for bit."""
+    dim, n = 1024, 4096
+    rng = np.random.default_rng(5)
+    codes = rng.integers(-30, 31, (n, dim)).astype(np.int8)
+    codes[7] = 127
+    codes[8] = -128
+    codes[9, ::2] = 127
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(0.01)
+    ix.add(codes)
+    qs = np.stack([np.full(dim, -127, np.int8), np.full(dim, 127, np.int8), rng.integers(-20, 21, dim).astype(np.int8)])
+    for metric, om in ((pvs.L2, orc.L2), (pvs.COSINE, orc.COSINE)):
+        exp = [orc.score_all(orc.I8, om, codes, qs[j]) for j in range(3)]
+        for j in range(3):
+            got = ix.score_all(qs[j], metric)
+            assert np.array_equal(got.view(np.uint32), exp[j].view(np.uint32)), (metric, j, "score_all")
+        m = ix.score_batch(qs, metric)
+        for j in range(3):
+            assert np.array_equal(m[:, j].view(np.uint32), exp[j].view(np.uint32)), (metric, j, "score_batch")
+    assert float(orc.score_all(orc.I8, orc.L2, codes, qs[0])[7]) ** 2 > 2 ** 24, "the corpus must leave the exact range"
+    ix.close()
+
