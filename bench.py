@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--allow-host-gather", action="store_true",
                     help="N ranks: when RCCL cannot be initialised (e.g. two ranks on one GPU) exchange the pages over the control "
                          "socket instead of failing (testing only; the line then says exchange=ctl-host-gather)")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="pvs_debug_set(KEY, VALUE) before the run (tuning sweeps: sample_div, sample_j_div, scan_no_wide128, ...; the line records it)")
     a = ap.parse_args()
     base = CONFIGS[a.config if a.config in CONFIGS else 2]
     for name, val in zip(("rows", "dim", "dtype", "batch", "k", "metric"), base):
@@ -425,6 +427,9 @@ def main():
     n_dev = pvs.device_count()
     if n_dev < 1:
         raise SystemExit("bench.py needs an MI355X (gfx950); libpvs has no CPU path")
+    for kv in args.debug:
+        key, _, val = kv.partition("=")
+        pvs.debug_set(key, int(val or 1))
     if args.config == 4:
         return run_config4(args, ctl, rank, world, local_rank % n_dev if world > 1 else 0, real_stdout)
     dev_list = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
@@ -630,7 +635,8 @@ def main():
         "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} ({which_config(N, D, args.dtype, B, K, args.metric)})",
                    "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
                    "parallelism": f"row-shard x{n_gpus}" + (" (one process)" if single else f" ({world} rank{'s' if world > 1 else ''})"),
-                   "exchange": gather_mode, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1},
+                   "exchange": gather_mode, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1,
+                   **({"debug_knobs": args.debug} if args.debug else {})},
         "roofline": roofline,
         "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries),
                  "scan_candidates_per_query": round(int(st.last_candidates) / max(B, 1), 1)},

@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define PVS_ABI_VERSION 2
+#define PVS_ABI_VERSION 3
 
 typedef int32_t pvs_status;
 enum {
@@ -134,9 +134,11 @@ typedef struct pvs_stats {
     uint64_t fast_queries;      /* queries answered by the filter-scan path */
     uint64_t dense_queries;     /* queries answered by the dense score+sort path */
     uint64_t last_candidates;   /* candidates emitted by the last filter scan (all queries) */
-    /* since ABI v3 (set struct_size = sizeof(pvs_stats) before the call; a caller that leaves it 0 gets the fields above) */
+    /* since ABI v3: written by pvs_index_stats_ex only (pvs_index_stats writes the fields above and never reads *out) */
     uint64_t rescanned_queries; /* fast-path queries whose chunk went through the scan twice: a candidate segment overflowed
                                  * (ties clustered in a few tile streams) and pass B was rerun into flat per-query lists */
+    uint64_t sparse_queries;    /* filtered / row-list queries answered by gather-and-score over the allowed rows only */
+    uint64_t null_tail_queries; /* cosine queries whose page ended in NULL rows, completed from the zero-norm row list (no dense pass) */
 } pvs_stats;
 
 /* ------------------------------------------------------------------ library */
@@ -170,7 +172,11 @@ pvs_status pvs_index_add_f32(pvs_index *idx, const float *rows, uint64_t n, cons
 pvs_status pvs_index_set_scale_artifact(pvs_index *idx, const uint8_t *artifact, size_t len);
 pvs_status pvs_index_set_scale(pvs_index *idx, float scale);
 
+/* Writes the ABI-v2 fields (up to last_candidates); *out is never read, so it need not be initialised. */
 pvs_status pvs_index_stats(pvs_index *idx, pvs_stats *out);
+/* Writes the first min(out_bytes, sizeof(pvs_stats)) bytes of the current struct (out_bytes >= the v2 size) and sets
+ * out->struct_size to that number: pass sizeof(pvs_stats) of the header you were compiled against. */
+pvs_status pvs_index_stats_ex(pvs_index *idx, pvs_stats *out, size_t out_bytes);
 
 /* Reads rows [row0, row0+n) back to the host as dense [n][dim] of the index dtype
  * (the stored payload: embeddings.embedding / embedding_quants.quant). */
@@ -282,8 +288,8 @@ pvs_status pvs_index_set_streams(pvs_index *idx, uint32_t n_streams);
  * honours them everywhere (every shard's page record carries the keys of its entries; the merges compare distance, key DESC,
  * id); pvs_search_sharded and pvs_search_groups_sharded do the same when EVERY rank's index carries keys (the page records
  * carry the keys of their entries); pvs_rrf_search_sharded exchanges the candidates' keys (from the lowest branch that carries
- * keys and holds the group, on whichever rank).  The stand-alone merges: pvs_merge_group_pages_keyed takes the keys,
- * pvs_merge_topk[_device] break ties by id. */
+ * keys and holds the group, on whichever rank).  The stand-alone merges take the keys of their entries:
+ * pvs_merge_group_pages_keyed, pvs_merge_topk_keyed[_device] (the unkeyed forms break ties by id). */
 pvs_status pvs_index_set_order_keys(pvs_index *idx, const int64_t *keys, uint64_t n, pvs_space space);
 
 /* Forces the execution path of pvs_search*: 0 = automatic, 1 = dense score + sort
@@ -534,6 +540,11 @@ pvs_status pvs_search_sharded_async(pvs_index *idx, pvs_comm *comm, const void *
 pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t *counts,
                           uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
                           float *out_dist, uint32_t *out_count);
+/* The same with the second sort key of pvs_index_set_order_keys: keys [world][batch][k] = the key of every page entry's row
+ * (NULL: none) -> (distance asc, NULL last, key DESC, id asc), the order of every other route of a keyed index. */
+pvs_status pvs_merge_topk_keyed(const int64_t *ids, const float *dist, const int64_t *keys, const uint32_t *counts,
+                                uint32_t world, uint32_t batch, uint32_t k, int64_t *out_ids,
+                                float *out_dist, uint32_t *out_count);
 
 /* Per-item search over row shards: shard BY GROUP — every row of a file/item on one rank —
  * so MIN/MAX/AVG and the weighted average stay shard-local; each rank runs pvs_search_groups on its
@@ -561,6 +572,10 @@ pvs_status pvs_merge_group_pages_keyed(const int64_t *groups, const double *valu
 pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist,
                                  const uint32_t *d_counts, uint32_t world, uint32_t batch, uint32_t k,
                                  int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
+/* ... with order keys d_keys [world][batch][k] (NULL: none), like pvs_merge_topk_keyed. */
+pvs_status pvs_merge_topk_keyed_device(int32_t device, const int64_t *d_ids, const float *d_dist, const int64_t *d_keys,
+                                       const uint32_t *d_counts, uint32_t world, uint32_t batch, uint32_t k,
+                                       int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 
 /* ------------------------------------------------- device memory + synthetic */
 /* Free and total HBM of `device` in bytes (hipMemGetInfo): capacity planning for shard sizes. */
@@ -585,6 +600,28 @@ typedef struct pvs_microbench_result {
     double mfma_i8_tops, mfma_f16_tflops;
 } pvs_microbench_result;
 pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
+
+/* ------------------------------------------------------- test and tuning hooks */
+/* Not part of the product contract: the test suite and the measurement scripts use these to force a code path (and so compare
+ * two product paths on the same input) or to sweep a tuning parameter.  Every knob is 0 in a process that never calls
+ * pvs_debug_set, and the library reads NO environment variable to decide which algorithm answers (the only variable it looks at
+ * is PVS_RCCL_PATH, a loader path for librccl).  Process-wide; set a knob while no search is in flight.
+ *   "sample_div" N            pass A samples 1/N of the corpus            "sample_j_div" N     threshold = (k/N)-th sample value
+ *   "no_light_finalize"       multi-stream: keep the LDS-heavy pass C      "force_light_finalize"  every int8 search: LDS-light pass C
+ *   "dense_per_query"         dense fallback one query per pass            "no_direct_score"    1..4 int8 queries on the matrix cores
+ *   "no_page_rank"            per-item search sorts every group            "scan_no_wide128"    128-query int8 passes on k_scan
+ *   "rrf_serial" / "rrf_full" / "rrf_trace"   pvs_rrf_search: branches on one thread / full ranking only / phase times on stderr
+ *   "rrf_digest"              pvs_rrf_search records stage digests (below)
+ *   "scratch_idle_cap_mb" N   idle scratch kept per device (default 16 GiB)  "scratch_bypass"   scratch straight from hipMalloc/hipFree
+ *   "no_sparse" / "sparse_max" N   filtered searches: never / up to N allowed rows on the gather-score path
+ *   "no_fused_agg"            per-item MAX/AVG/weighted through the dense matrix + k_group_aggregate
+ *   "no_fused_pass"           filter scan: pass A, k-th select and pass B as separate launches */
+pvs_status pvs_debug_set(const char *key, int64_t value);
+pvs_status pvs_debug_get(const char *key, int64_t *out_value);
+/* Stage digests of the process' last single-device pvs_rrf_search run under "rrf_digest": out[branch * 4 + stage], stage 0 = the
+ * `d` column, 1 = per-group aggregates, 2 = window keys, 3 = ranks (bounded fusion: the candidates' counted ranks; full ranking:
+ * every group's rank).  out: 8 * 4 words.  *out_path: 1 = bounded fusion, 2 = full ranking.  tools/rrf_stage_digest.py. */
+pvs_status pvs_debug_rrf_digests(uint64_t *out, uint32_t *out_branches, int32_t *out_path);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,8 @@ class Stats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_uint32), ("dim", C.c_uint32), ("rows", C.c_uint64),
                 ("capacity_rows", C.c_uint64), ("row_stride_bytes", C.c_uint64), ("hbm_bytes", C.c_uint64),
                 ("scale", C.c_float), ("searches", C.c_uint64), ("fast_queries", C.c_uint64),
-                ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64), ("rescanned_queries", C.c_uint64)]
+                ("dense_queries", C.c_uint64), ("last_candidates", C.c_uint64), ("rescanned_queries", C.c_uint64),
+                ("sparse_queries", C.c_uint64), ("null_tail_queries", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -86,6 +87,7 @@ SYMBOLS = {
     "pvs_index_set_scale_artifact": (_i32, [_vp, _vp, _sz]),
     "pvs_index_set_scale": (_i32, [_vp, _f]),
     "pvs_index_stats": (_i32, [_vp, C.POINTER(Stats)]),
+    "pvs_index_stats_ex": (_i32, [_vp, C.POINTER(Stats), _sz]),
     "pvs_index_read_rows": (_i32, [_vp, _u64, _u64, _vp]),
     "pvs_index_read_ids": (_i32, [_vp, _u64, _u64, _vp, _vp]),
     "pvs_index_set_profiling": (_i32, [_vp, _i32]),
@@ -152,11 +154,16 @@ SYMBOLS = {
     "pvs_search_sharded_async": (_i32, [_vp, _vp, _vp, _i32, _u32, _u32, _i32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "pvs_merge_topk": (_i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_merge_topk_device": (_i32, [_i32, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_merge_topk_keyed": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "pvs_merge_topk_keyed_device": (_i32, [_i32, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_device_malloc": (_i32, [_i32, _sz, C.POINTER(_vp)]),
     "pvs_device_free": (_i32, [_i32, _vp]),
     "pvs_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
     "pvs_synth_rows_f32": (_i32, [_i32, _u64, _u64, _u64, _u32, _vp]),
     "pvs_microbench": (_i32, [_i32, C.POINTER(MicrobenchResult)]),
+    "pvs_debug_set": (_i32, [C.c_char_p, _i64]),
+    "pvs_debug_get": (_i32, [C.c_char_p, C.POINTER(_i64)]),
+    "pvs_debug_rrf_digests": (_i32, [_vp, C.POINTER(_u32), C.POINTER(_i32)]),
 }
 
 _lib = None
@@ -176,6 +183,17 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def debug_set(key: str, value: int = 1) -> None:
+    """Test / tuning knob of the library (include/pvs.h, "test and tuning hooks"); 0 restores the product behaviour."""
+    check(lib().pvs_debug_set(key.encode(), int(value)))
+
+
+def debug_get(key: str) -> int:
+    v = _i64()
+    check(lib().pvs_debug_get(key.encode(), C.byref(v)))
+    return v.value
 
 
 def check(status: int) -> None:

@@ -18,12 +18,41 @@ pvs_status pvs_fail(pvs_status code, const char *fmt, ...) {
 }
 PVS_EXPORT const char *pvs_last_error(void) { return g_last_error.c_str(); }
 
+// ------------------------------------------------------------------ test / tuning knobs
+namespace {
+std::atomic<int64_t> g_dbg[PVS_DBG_COUNT];
+const char *const g_dbg_names[PVS_DBG_COUNT] = {
+    "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
+    "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
+    "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_fused_pass",
+};
+int dbg_key(const char *key) {
+    if (!key) return -1;
+    for (int i = 0; i < PVS_DBG_COUNT; i++)
+        if (strcmp(key, g_dbg_names[i]) == 0) return i;
+    return -1;
+}
+}  // namespace
+int64_t pvs_dbg(PvsDbg key) { return g_dbg[key].load(std::memory_order_relaxed); }
+PVS_EXPORT pvs_status pvs_debug_set(const char *key, int64_t value) {
+    const int i = dbg_key(key);
+    if (i < 0) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown debug key '%s'", key ? key : "(null)");
+    g_dbg[i].store(value);
+    return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_debug_get(const char *key, int64_t *out_value) {
+    const int i = dbg_key(key);
+    if (i < 0 || !out_value) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown debug key '%s'", key ? key : "(null)");
+    *out_value = g_dbg[i].load();
+    return PVS_OK;
+}
+
 // ------------------------------------------------------------------ scratch cache
 // Blocks for the host-orchestrated paths, kept per (device, size class) after use.  Three rules:
 //   * a block handed back while work that touches it may still be queued (pvs_scratch_free_on: the usual case — the caller
 //     enqueued kernels and returns) carries an event recorded on that stream and is only handed out again once the event has
 //     completed: another thread, on another stream, can never get a block a kernel is still reading or writing;
-//   * idle bytes per device are capped (PVS_SCRATCH_IDLE_CAP_MB, default 16 GiB): beyond the cap the least recently used idle
+//   * idle bytes per device are capped (pvs_debug_set("scratch_idle_cap_mb"), default 16 GiB): beyond the cap the least recently used idle
 //     blocks go back to the runtime — the dense fallback's n x per x 4 byte matrices come in dozens of size classes and would
 //     otherwise pile up multi-GB blocks nobody asks for again;
 //   * every device allocation of the library (pvs_malloc_retry) returns the idle blocks to the runtime and tries again before it
@@ -41,6 +70,7 @@ struct IdleBlock {
 std::mutex g_scratch_mu;
 std::map<std::pair<int, size_t>, std::vector<IdleBlock>> g_scratch_idle;  // (device, size class) -> idle blocks
 std::map<void *, ScratchBlock> g_scratch_live;
+std::map<void *, int> g_scratch_bypassed;  // blocks handed out under pvs_debug_set("scratch_bypass", 1)
 std::map<int, size_t> g_scratch_idle_bytes;  // per device
 uint64_t g_scratch_clock = 0;
 size_t scratch_class(size_t bytes) {
@@ -50,8 +80,8 @@ size_t scratch_class(size_t bytes) {
     return c;
 }
 size_t scratch_idle_cap() {
-    static const size_t cap = getenv("PVS_SCRATCH_IDLE_CAP_MB") ? (size_t)strtoull(getenv("PVS_SCRATCH_IDLE_CAP_MB"), nullptr, 10) << 20 : (size_t)16 << 30;
-    return cap;
+    const int64_t mb = pvs_dbg(PVS_DBG_SCRATCH_IDLE_CAP_MB);
+    return mb > 0 ? (size_t)mb << 20 : (size_t)16 << 30;
 }
 // (lock held) idle blocks of `device` beyond the cap, least recently used first, are moved to `drop`
 void scratch_evict_locked(int device, std::vector<IdleBlock> *drop) {
@@ -94,6 +124,13 @@ hipError_t pvs_scratch_alloc(void **out, size_t bytes) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const size_t cls = scratch_class(bytes ? bytes : 1);
+    if (pvs_dbg(PVS_DBG_SCRATCH_BYPASS)) {  // (race hunting: no block is ever handed out twice)
+        e = pvs_malloc_retry(out, cls);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        g_scratch_bypassed[*out] = dev;
+        return hipSuccess;
+    }
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         auto &v = g_scratch_idle[{dev, cls}];
@@ -134,9 +171,14 @@ void pvs_scratch_free_on(void *p, hipStream_t s, bool pending) {
     {
         std::lock_guard<std::mutex> lk(g_scratch_mu);
         auto it = g_scratch_live.find(p);
-        if (it == g_scratch_live.end()) {  // not ours
+        if (it == g_scratch_live.end()) {
             if (ev) (void)hipEventDestroy(ev);
-            return;
+            auto bt = g_scratch_bypassed.find(p);
+            if (bt != g_scratch_bypassed.end()) {  // pvs_debug_set("scratch_bypass", 1): straight back to the runtime (hipFree waits for the device)
+                g_scratch_bypassed.erase(bt);
+                (void)hipFree(p);
+            }
+            return;  // (else: not ours)
         }
         dev = it->second.device;
         g_scratch_idle[{dev, it->second.cls}].push_back({p, ev, ++g_scratch_clock});
@@ -324,7 +366,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
     }
-    static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;  // tests: the LDS-light pass C on every search
+    const bool force_light = pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE) != 0;  // tests: the LDS-light pass C on every search
     if ((ix->multi_stream || force_light) && ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
@@ -680,9 +722,12 @@ PVS_EXPORT pvs_status pvs_index_scan_kernel_name(pvs_index *ix, uint32_t batch, 
     return PVS_OK;
 }
 
-PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
+static const size_t STATS_V2_BYTES = offsetof(pvs_stats, rescanned_queries);  // what callers of the earlier struct hold
+PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) { return pvs_index_stats_ex(ix, out, STATS_V2_BYTES); }
+PVS_EXPORT pvs_status pvs_index_stats_ex(pvs_index *ix, pvs_stats *out, size_t out_bytes) {
     if (!ix || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
-    if (is_multi(ix)) return multi_stats(ix, out);
+    if (out_bytes < STATS_V2_BYTES) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_stats: out_bytes smaller than the ABI v2 struct");
+    if (is_multi(ix)) return multi_stats(ix, out, out_bytes);
     pvs_stats s;
     memset(&s, 0, sizeof s);
     s.struct_size = sizeof s;
@@ -698,8 +743,9 @@ PVS_EXPORT pvs_status pvs_index_stats(pvs_index *ix, pvs_stats *out) {
     s.dense_queries = ix->dense_queries.load();
     s.last_candidates = ix->last_candidates.load();
     s.rescanned_queries = ix->flat_reruns.load();
-    const size_t v2 = offsetof(pvs_stats, rescanned_queries);  // what callers of the earlier struct hold
-    const size_t want = out->struct_size >= v2 && out->struct_size <= sizeof s ? out->struct_size : v2;
+    s.sparse_queries = ix->sparse_queries.load();
+    s.null_tail_queries = ix->null_tail_queries.load();
+    const size_t want = std::min(out_bytes, sizeof s);
     s.struct_size = (uint32_t)want;
     memcpy(out, &s, want);
     return PVS_OK;
@@ -861,15 +907,20 @@ PVS_EXPORT pvs_status pvs_quantize_i8(const float *x, uint64_t n, float scale, i
     return st;
 }
 
-PVS_EXPORT pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist, const uint32_t *d_counts,
-                                            uint32_t world, uint32_t batch, uint32_t k, int64_t *d_out_ids, float *d_out_dist,
-                                            uint32_t *d_out_count) {
+PVS_EXPORT pvs_status pvs_merge_topk_keyed_device(int32_t device, const int64_t *d_ids, const float *d_dist, const int64_t *d_keys,
+                                                  const uint32_t *d_counts, uint32_t world, uint32_t batch, uint32_t k, int64_t *d_out_ids,
+                                                  float *d_out_dist, uint32_t *d_out_count) {
     if (!d_ids || !d_dist || !d_counts || !d_out_ids || !d_out_dist || !d_out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     if (world == 0 || batch == 0 || k == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "empty merge");
     PVS_TRY(use_device(device, nullptr));
-    HIP_TRY(pvs_launch_merge(d_ids, d_dist, d_counts, world, batch, k, d_out_ids, d_out_dist, d_out_count, nullptr));
+    HIP_TRY(pvs_launch_merge(d_ids, d_dist, d_counts, world, batch, k, d_out_ids, d_out_dist, d_out_count, nullptr, d_keys));
     HIP_TRY(hipStreamSynchronize(nullptr));
     return PVS_OK;
+}
+PVS_EXPORT pvs_status pvs_merge_topk_device(int32_t device, const int64_t *d_ids, const float *d_dist, const uint32_t *d_counts,
+                                            uint32_t world, uint32_t batch, uint32_t k, int64_t *d_out_ids, float *d_out_dist,
+                                            uint32_t *d_out_count) {
+    return pvs_merge_topk_keyed_device(device, d_ids, d_dist, nullptr, d_counts, world, batch, k, d_out_ids, d_out_dist, d_out_count);
 }
 
 // ------------------------------------------------ device memory + synthetic

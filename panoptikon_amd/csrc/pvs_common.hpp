@@ -49,6 +49,31 @@ void pvs_scratch_free(void *p);
 void pvs_scratch_trim(int device);
 hipError_t pvs_malloc_retry(void **out, size_t bytes);
 
+// Test / tuning knobs (pvs_debug_set in include/pvs.h).  Every knob is 0 in a process that never calls pvs_debug_set: the
+// library reads no environment variable to decide which algorithm answers (round 3 had fourteen getenv switches here).
+enum PvsDbg {
+    PVS_DBG_SAMPLE_DIV = 0,        // pass A samples 1/value of the corpus (0: the built-in choice)
+    PVS_DBG_SAMPLE_J_DIV,          // threshold = the (k / value)-th sample value (0: 4)
+    PVS_DBG_NO_LIGHT_FINALIZE,     // multi-stream indexes keep the LDS-heavy pass C
+    PVS_DBG_FORCE_LIGHT_FINALIZE,  // every int8 search uses the LDS-light pass C
+    PVS_DBG_DENSE_PER_QUERY,       // dense fallback: one query per corpus pass + full sort (the round-1 form)
+    PVS_DBG_NO_DIRECT_SCORE,       // 1..4 int8 queries: matrix-core MODE 2 instead of k_score_i8_direct
+    PVS_DBG_NO_PAGE_RANK,          // per-item search: always sort every group
+    PVS_DBG_RRF_SERIAL,            // pvs_rrf_search: branches one after the other on the calling thread
+    PVS_DBG_RRF_FULL,              // pvs_rrf_search: skip the bounded fusion, rank every group
+    PVS_DBG_RRF_TRACE,             // pvs_rrf_search: phase wall times on stderr
+    PVS_DBG_SCAN_NO_WIDE128,       // 128-query int8 passes stay on k_scan
+    PVS_DBG_SCRATCH_IDLE_CAP_MB,   // idle scratch bytes kept per device (0: 16 GiB)
+    PVS_DBG_SCRATCH_BYPASS,        // scratch blocks come from hipMalloc and go back with hipFree (race hunting)
+    PVS_DBG_RRF_DIGEST,            // pvs_rrf_search records per-stage digests (pvs_debug_rrf_digests)
+    PVS_DBG_NO_SPARSE,             // filtered searches never take the gather-score path
+    PVS_DBG_SPARSE_MAX,            // ... take it up to this many allowed rows (0: the built-in crossover)
+    PVS_DBG_NO_FUSED_AGG,          // per-item MAX/AVG/weighted: dense matrix + k_group_aggregate (the round-3 form)
+    PVS_DBG_NO_FUSED_PASS,         // filter scan: pass A, k-th select and pass B as separate launches
+    PVS_DBG_COUNT
+};
+int64_t pvs_dbg(PvsDbg key);
+
 // ------------------------------------------------------------ geometry
 // Rows live in HBM at a pitch that is a multiple of 256 B so that a row is a
 // whole number of 16-chunk (256 B) "k-slabs": the unit the scan kernel streams

@@ -197,15 +197,22 @@ PVS_EXPORT pvs_status pvs_sort_bounds(const double *order_rank, uint64_t n, int3
 // ------------------------------------------------------------ host k-way merge
 PVS_EXPORT pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world, uint32_t batch,
                                      uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    return pvs_merge_topk_keyed(ids, dist, nullptr, counts, world, batch, k, out_ids, out_dist, out_count);
+}
+// keys ([world][batch][k], optional): the second sort key of every entry (pvs_index_set_order_keys): (distance asc, NULL last,
+// key DESC, id asc) — the order every other route produces when the index carries keys
+PVS_EXPORT pvs_status pvs_merge_topk_keyed(const int64_t *ids, const float *dist, const int64_t *keys, const uint32_t *counts, uint32_t world,
+                                           uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
     if (!ids || !dist || !counts || !out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     struct E {
         float d;
-        int64_t id;
+        int64_t id, key;
     };
     auto less = [](const E &a, const E &b) {
         const bool na = std::isnan(a.d), nb = std::isnan(b.d);
         if (na != nb) return nb;
         if (!na && a.d != b.d) return a.d < b.d;
+        if (a.key != b.key) return a.key > b.key;
         return a.id < b.id;
     };
     std::vector<E> all;
@@ -214,7 +221,7 @@ PVS_EXPORT pvs_status pvs_merge_topk(const int64_t *ids, const float *dist, cons
         for (uint32_t w = 0; w < world; w++) {
             const size_t off = ((size_t)w * batch + q) * k;
             const uint32_t c = std::min(counts[(size_t)w * batch + q], k);
-            for (uint32_t p = 0; p < c; p++) all.push_back({dist[off + p], ids[off + p]});
+            for (uint32_t p = 0; p < c; p++) all.push_back({dist[off + p], ids[off + p], keys ? keys[off + p] : 0});
         }
         std::sort(all.begin(), all.end(), less);
         const uint32_t nout = (uint32_t)std::min<size_t>(all.size(), k);

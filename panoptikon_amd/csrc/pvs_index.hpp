@@ -172,6 +172,8 @@ struct pvs_index {
     bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     std::atomic<uint64_t> flat_reruns{0};  // queries that went through the scan twice (segment overflow -> flat candidate lists)
+    std::atomic<uint64_t> sparse_queries{0};     // filtered / row-list queries answered by gather-and-score (pvs_sparse.hip)
+    std::atomic<uint64_t> null_tail_queries{0};  // cosine pages completed from the zero-norm row list instead of the dense path
     // Request coalescing of the host-buffer entry point (pvs_index_set_coalescing): callers that arrive within a short window
     // share one corpus pass.  `pending` holds the requests not yet taken by a leader; one caller at a time is the leader.
     struct CoalesceReq {
@@ -269,7 +271,7 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
                      pvs_space space);
 pvs_status multi_set_scale(pvs_index *ix, float scale);
 pvs_status multi_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space);
-pvs_status multi_stats(pvs_index *ix, pvs_stats *out);
+pvs_status multi_stats(pvs_index *ix, pvs_stats *out, size_t out_bytes);
 pvs_status multi_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host);
 pvs_status multi_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids);
 pvs_status multi_search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
@@ -284,6 +286,8 @@ pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdt
                                double *out_values, uint32_t *out_count);
 pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                  const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+pvs_status multi_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric, int32_t have_gt,
+                                double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 pvs_status multi_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric, float *out_dist,
                              pvs_space out_space);
 pvs_status multi_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric, const SimilarArgs &a,

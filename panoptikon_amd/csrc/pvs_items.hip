@@ -70,7 +70,7 @@ pvs_status ensure_groups(pvs_index *ix) {
 // d_out[row * nb + q], nb <= PVS_MAX_BATCH queries already prepared in ctx c (prep_chunk)
 pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out) {
     const uint32_t kslabs = ix->stride / PVS_KSLAB_BYTES;
-    static const bool no_direct = getenv("PVS_NO_DIRECT_SCORE") != nullptr;  // tuning: compare with the matrix-core scorer
+    const bool no_direct = pvs_dbg(PVS_DBG_NO_DIRECT_SCORE) != 0;  // tuning: compare with the matrix-core scorer
     if (ix->dtype == PVS_I8 && nb <= 4 && !no_direct && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
         // a handful of queries: a pure HBM stream, v_dot4 straight from global memory (pvs_score_direct.hip); same closed form
         HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
@@ -238,7 +238,7 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
                                      const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
                                      double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1) {
     const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
-    static const bool no_page_rank = getenv("PVS_NO_PAGE_RANK") != nullptr;  // tuning: always sort every group
+    const bool no_page_rank = pvs_dbg(PVS_DBG_NO_PAGE_RANK) != 0;  // tuning: always sort every group
     double *d_vals = nullptr;
     int64_t *d_og = nullptr;
     double *d_ov = nullptr;
@@ -540,6 +540,34 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
 static thread_local int32_t g_rrf_last_path = 0;
 PVS_EXPORT int32_t pvs_rrf_last_path(void) { return g_rrf_last_path; }
 
+// Race hunting (pvs_debug_set("rrf_digest", 1); tools/rrf_stage_digest.py): 64-bit digests of the stages of the last single-device
+// pvs_rrf_search of the process, per branch: [0] the `d` column (every row's f32 distance), [1] the per-group aggregates (f64),
+// [2] the window keys, [3] the ranks — bounded fusion: (candidate group, exact counted rank) over the candidates of the last round;
+// full ranking: every group's rank in slot order.  A digest that moves between two runs of the same query names the stage.
+namespace {
+struct RrfDigestRec {
+    uint64_t v[PVS_RRF_MAX_BRANCHES][4];
+    uint32_t nb;
+    int32_t path;
+};
+std::mutex g_rrf_dig_mu;
+RrfDigestRec g_rrf_dig;
+inline uint64_t host_mix(uint64_t a, uint64_t b) {
+    uint64_t z = (a + 1) * 0x9E3779B97F4A7C15ull ^ b * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+}  // namespace
+PVS_EXPORT pvs_status pvs_debug_rrf_digests(uint64_t *out, uint32_t *out_branches, int32_t *out_path) {
+    if (!out || !out_branches || !out_path) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_rrf_dig_mu);
+    memcpy(out, g_rrf_dig.v, sizeof g_rrf_dig.v);
+    *out_branches = g_rrf_dig.nb;
+    *out_path = g_rrf_dig.path;
+    return PVS_OK;
+}
+
 // One branch of an OR-composition, scored (pvs_rrf_cols in the C ABI): every group's aggregate (f64, the reference's
 // arithmetic) and its window key.
 struct pvs_rrf_cols {
@@ -552,7 +580,7 @@ struct pvs_rrf_cols {
 typedef pvs_rrf_cols RrfBranchCols;
 
 // every row's exact distance (the dist_{cte} column), aggregated per group in row order
-static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) {
+static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out, uint64_t *dig = nullptr) {
     pvs_index *ix = b.idx;
     out->ix = ix;
     out->n_groups = ix->n_groups;
@@ -577,8 +605,11 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out) 
         HIP_TRY(pvs_scratch_alloc((void **)&out->d_keys, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
         PVS_TRY(prep_chunk(ix, *c, d_q, b.query_dtype, 0, 1, 32, b.metric));
         PVS_TRY(dense_chunk(ix, *c, 1, 32, b.metric, d_m));
+        if (dig) PVS_TRY(pvs_digest_device(d_m, ix->n, 4, &dig[0], c->stream));
         HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, b.agg, out->d_vals, c->stream));
+        if (dig) PVS_TRY(pvs_digest_device(out->d_vals, ix->n_groups, 8, &dig[1], c->stream));
         PVS_TRY(pvs_rrf_window_keys(out->d_vals, ix->n_groups, b.row_n_descending != 0, out->d_keys, c->stream));
+        if (dig) PVS_TRY(pvs_digest_device(out->d_keys, ix->n_groups, 8, &dig[2], c->stream));
         return PVS_OK;
     };
     pvs_status st = one();
@@ -717,7 +748,7 @@ static pvs_status per_branch(const pvs_rrf_branch *br, uint32_t nb, F &&f) {
     bool distinct = true;
     for (uint32_t a = 0; a < nb; a++)
         for (uint32_t b = a + 1; b < nb; b++) distinct &= br[a].idx != br[b].idx;
-    static const bool serial = getenv("PVS_RRF_SERIAL") != nullptr;  // tuning
+    const bool serial = pvs_dbg(PVS_DBG_RRF_SERIAL) != 0;  // tuning
     if (nb == 1 || !distinct || serial) {
         for (uint32_t b = 0; b < nb; b++) PVS_TRY(f(b));
         return PVS_OK;
@@ -738,9 +769,9 @@ static pvs_status per_branch(const pvs_rrf_branch *br, uint32_t nb, F &&f) {
     return PVS_OK;
 }
 
-// PVS_RRF_TRACE=1: host wall time of every phase of a composed query on stderr (tuning)
+// pvs_debug_set("rrf_trace", 1): host wall time of every phase of a composed query on stderr (tuning)
 struct RrfTrace {
-    bool on = getenv("PVS_RRF_TRACE") != nullptr;
+    bool on = pvs_dbg(PVS_DBG_RRF_TRACE) != 0;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char *what) {
         if (!on) return;
@@ -750,7 +781,7 @@ struct RrfTrace {
     }
 };
 static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint32_t k,
-                              int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done) {
+                              int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done, RrfDigestRec *dig = nullptr) {
     *done = false;
     const uint32_t nb = p.n_branches;
     uint64_t total_groups = 0;
@@ -830,6 +861,12 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
             return PVS_OK;
         }));
         tr.lap("lookups + exact ranks");
+        if (dig)
+            for (uint32_t b = 0; b < nb; b++) {
+                uint64_t h = 0;
+                for (uint32_t i = 0; i < m; i++) h += host_mix((uint64_t)cand[i], (uint64_t)ranks[b][i]);
+                dig->v[b][3] = h;
+            }
         struct GS {
             double s;
             int64_t g;
@@ -946,13 +983,24 @@ static pvs_status rrf_search_impl(const pvs_rrf_branch *br, uint32_t nb, uint32_
     unsigned long long *cat_key = nullptr, *cat_pay = nullptr;
     auto body = [&]() -> pvs_status {
         RrfTrace tr;
-        PVS_TRY(per_branch(br, nb, [&](uint32_t b) { return rrf_score_branch(br[b], &cols[b]); }));
+        const bool digest = pvs_dbg(PVS_DBG_RRF_DIGEST) != 0;
+        RrfDigestRec dig;
+        memset(&dig, 0, sizeof dig);
+        dig.nb = nb;
+        auto publish = [&](int path) {
+            if (!digest) return;
+            dig.path = path;
+            std::lock_guard<std::mutex> lk(g_rrf_dig_mu);
+            g_rrf_dig = dig;
+        };
+        PVS_TRY(per_branch(br, nb, [&](uint32_t b) { return rrf_score_branch(br[b], &cols[b], digest ? dig.v[b] : nullptr); }));
         tr.lap("score branches");
-        const bool force_full = getenv("PVS_RRF_FULL") != nullptr;  // tests and profiles: compare the two paths
+        const bool force_full = pvs_dbg(PVS_DBG_RRF_FULL) != 0;  // tests and profiles: compare the two paths
         if (!force_full) {
             bool done = false;
-            PVS_TRY(rrf_bounded(br, cols, p, k, out_groups, out_scores, out_count, &done));
+            PVS_TRY(rrf_bounded(br, cols, p, k, out_groups, out_scores, out_count, &done, digest ? &dig : nullptr));
             if (done) {
+                publish(1);
                 g_rrf_last_path = 1;
                 for (uint32_t i = *out_count; i < k; i++) {
                     out_groups[i] = -1;
@@ -972,8 +1020,10 @@ static pvs_status rrf_search_impl(const pvs_rrf_branch *br, uint32_t nb, uint32_
             if (ix->n == 0) continue;
             PVS_TRY(pvs_rrf_rank_branch(cols[b].d_vals, ix->d_grp_ids, ix->n_groups, br[b].row_n_descending != 0, b, cat_key + off, cat_pay + off,
                                         ix->search_stream));
+            if (digest) PVS_TRY(pvs_digest_device(cat_pay + off, ix->n_groups, 8, &dig.v[b][3], ix->search_stream));
             off += ix->n_groups;
         }
+        publish(2);
         return pvs_rrf_fuse_device(cat_key, cat_pay, off, p, k, out_groups, out_scores, out_count, br[0].idx->search_stream);
     };
     pvs_status st = body();

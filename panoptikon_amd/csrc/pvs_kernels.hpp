@@ -167,7 +167,7 @@ hipError_t pvs_launch_score_i8_direct(int metric, const uint8_t *rows, uint32_t 
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,
-                            uint32_t *out_count, hipStream_t s);
+                            uint32_t *out_count, hipStream_t s, const int64_t *keys = nullptr);
 // A rank's page as ONE buffer, so that the shard exchange is one all-gather (and one peer copy inside a multi-device index):
 // [ids i64 x batch*k | dist f32 x batch*k | counts u32 x batch | flags u32 x batch | order keys i64 x batch*k], padded to 16 bytes.
 // flags[q]: the query's hand-back code (pass C) in the low bits; bit 31 = the keys section is valid (the shard carries
@@ -234,6 +234,8 @@ struct PvsRrfParams {
     int32_t k[PVS_RRF_MAX_BRANCHES];
     double w[PVS_RRF_MAX_BRANCHES];
 };
+// order-independent 64-bit digest of n words of 4 or 8 bytes (synchronous; race hunting, pvs_debug_rrf_digests)
+pvs_status pvs_digest_device(const void *d, uint64_t n, int word_bytes, uint64_t *out_host, hipStream_t s);
 // bounded fusion: window keys of every group of a branch, a sample of them, the page of groups at or below a key, the keys of
 // given groups, and how many groups stand strictly before each of a handful of candidates (one counting pass over the keys)
 pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s);

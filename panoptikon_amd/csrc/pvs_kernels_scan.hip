@@ -16,10 +16,10 @@ bool pvs_scan_supported(int dtype, uint32_t kslabs) {
     return false;
 }
 // Which kernel serves the filter passes (modes 0 and 1) of a shape: k_scan_wide (pvs_scan_wide.hpp: int8, 256 queries at row
-// pitches up to 1 KiB, 128 queries up to 768 B) or k_scan.  PVS_SCAN_NO_WIDE128=1 keeps the 128-query passes on k_scan (A/B
+// pitches up to 1 KiB, 128 queries up to 768 B) or k_scan.  pvs_debug_set("scan_no_wide128", 1) keeps the 128-query passes on k_scan (A/B
 // timing of the two kernels; both are product paths, the GPU suite runs under either).
 bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs) {
-    static const bool no128 = getenv("PVS_SCAN_NO_WIDE128") != nullptr;
+    const bool no128 = pvs_dbg(PVS_DBG_SCAN_NO_WIDE128) != 0;
     if (dtype != PVS_I8 || (qgroups == 4 && no128)) return false;
     return pvs_scan_wide_serves(qgroups, kslabs, 1);
 }
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, ui
     bool keyed = pg.keys != nullptr;
     for (uint32_t w = 0; w < world; w++) {
         total += pg.cnt_of(w)[q];
-        if (keyed && pg.cnt_of(w)[q]) keyed = (pg.flags_of(w)[q] & PVS_PAGE_KEYED) != 0;  // every shard with entries must carry keys, or none is used
+        if (keyed && pg.flags && pg.cnt_of(w)[q]) keyed = (pg.flags_of(w)[q] & PVS_PAGE_KEYED) != 0;  // every shard with entries must carry keys, or none is used
     }
     const uint32_t nout = total < k ? total : k;
     for (uint32_t e = threadIdx.x; e < world * k; e += 256) {
@@ -836,13 +836,15 @@ __global__ __launch_bounds__(256) void k_merge(MergePages pg, uint32_t world, ui
     if (threadIdx.x == 0) out_count[q] = nout;
 }
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world, uint32_t batch,
-                            uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s) {
+                            uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count, hipStream_t s, const int64_t *keys) {
     MergePages pg;
     pg.ids = (const uint8_t *)ids;
     pg.dist = (const uint8_t *)dist;
     pg.cnt = (const uint8_t *)counts;
-    pg.flags = pg.keys = nullptr;
-    pg.stride_flags = pg.stride_keys = 0;
+    pg.flags = nullptr;
+    pg.keys = (const uint8_t *)keys;  // [world][batch][k] order keys of the entries (nullptr: ties by id)
+    pg.stride_flags = 0;
+    pg.stride_keys = (size_t)batch * k * 8;
     pg.stride_ids = (size_t)batch * k * 8;
     pg.stride_dist = (size_t)batch * k * 4;
     pg.stride_cnt = (size_t)batch * 4;

@@ -314,6 +314,11 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
             return pvs_fail(PVS_ERR_STATE, "group ids must be given from the first pvs_index_add of a multi-device index (earlier rows were placed without them)");
         ix->by_group = true;
         const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / row_bytes);
+        // Shards and the segment table advance chunk by chunk, ix->n only at the end: ANY failure after the first chunk was
+        // committed (a HIP error of the staging copy, host memory, a shard's add) leaves them ahead of ix->n — the next add would
+        // reuse the same global rows.  Such an index is poisoned (every later call fails), whatever the failure was.
+        bool committed = false;
+        auto body = [&]() -> pvs_status {
         std::vector<uint8_t> host_rows;  // device-space input is staged through the host (build-side cost, once per row)
         std::vector<std::vector<uint8_t>> buf(S);
         std::vector<std::vector<int64_t>> ids(S), grp(S);
@@ -347,10 +352,8 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
             for (uint32_t s = 0; s < S; s++) {
                 if (ids[s].empty()) continue;
                 pvs_status st = add_impl(ix->shards[s], buf[s].data(), from_f32, ids[s].size(), ids[s].data(), grp[s].data(), PVS_HOST);
-                if (st != PVS_OK) {
-                    ix->poisoned = true;  // (see below)
-                    return st;
-                }
+                committed = true;  // (a failed add may have taken part of its rows too)
+                if (st != PVS_OK) return st;
             }
             // consecutive calls extend the last run when they can
             for (const MultiSegment &r : runs) {
@@ -360,6 +363,18 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
                 else
                     ix->segs.push_back(r);
             }
+        }
+        return PVS_OK;
+        };
+        pvs_status st;
+        try {
+            st = body();
+        } catch (const std::bad_alloc &) {
+            st = pvs_fail(PVS_ERR_OOM, "out of host memory while placing rows by group");
+        }
+        if (st != PVS_OK) {
+            if (committed) ix->poisoned = true;
+            return st;
         }
         ix->n += n;
         ix->last_id = last;
@@ -446,7 +461,7 @@ pvs_status multi_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, 
     return PVS_OK;
 }
 
-pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
+pvs_status multi_stats(pvs_index *ix, pvs_stats *out, size_t out_bytes) {
     pvs_stats s;
     memset(&s, 0, sizeof s);
     s.struct_size = sizeof s;
@@ -456,9 +471,10 @@ pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
     s.scale = ix->scale_set ? ix->scale : 0.f;
     for (pvs_index *sh : ix->shards) {
         pvs_stats p;
-        p.struct_size = sizeof p;
-        PVS_TRY(pvs_index_stats(sh, &p));
+        PVS_TRY(pvs_index_stats_ex(sh, &p, sizeof p));
         s.rescanned_queries += p.rescanned_queries;
+        s.sparse_queries += p.sparse_queries;
+        s.null_tail_queries += p.null_tail_queries;
         s.rows += p.rows;
         s.capacity_rows += p.capacity_rows;
         s.hbm_bytes += p.hbm_bytes;
@@ -467,8 +483,7 @@ pvs_status multi_stats(pvs_index *ix, pvs_stats *out) {
     s.searches = ix->searches.load();
     s.fast_queries = ix->fast_queries.load();
     s.dense_queries = ix->dense_queries.load();
-    const size_t v2 = offsetof(pvs_stats, rescanned_queries);
-    const size_t want = out->struct_size >= v2 && out->struct_size <= sizeof s ? out->struct_size : v2;
+    const size_t want = std::min(out_bytes, sizeof s);
     s.struct_size = (uint32_t)want;
     memcpy(out, &s, want);
     return PVS_OK;
@@ -703,7 +718,13 @@ static pvs_status per_shard(pvs_index *ix, F f) {
     std::vector<std::thread> th;
     for (uint32_t s = 0; s < S; s++)
         th.emplace_back([&, s]() {
-            st[s] = f(s);
+            try {  // (an exception leaving a std::thread is std::terminate)
+                st[s] = f(s);
+            } catch (const std::bad_alloc &) {
+                st[s] = pvs_fail(PVS_ERR_OOM, "out of host memory");
+            } catch (...) {
+                st[s] = pvs_fail(PVS_ERR_STATE, "unexpected failure");
+            }
             if (st[s] != PVS_OK) err[s] = pvs_last_error();
         });
     for (auto &t : th) t.join();
@@ -712,6 +733,30 @@ static pvs_status per_shard(pvs_index *ix, F f) {
     return PVS_OK;
 }
 static const char *k_need_groups = "needs every row of a group on one device: give group_ids to every pvs_index_add of a multi-device index";
+
+// Host merge of the shards' row pages [S][batch][k] under (distance asc, NULL last, [order key DESC,] id asc); with order keys a
+// row's key is found by its id through the global id list (ids increase in global row order)
+static pvs_status merge_row_pages_host(pvs_index *ix, const std::vector<int64_t> &ids, const std::vector<float> &dist, const std::vector<uint32_t> &cnt,
+                                       uint32_t S, uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (!(ix->order_rows == ix->n && ix->n)) return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->h_ids_cache.size() != ix->n) {
+            ix->h_ids_cache.resize(ix->n);
+            PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
+        }
+    }
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> keys(S * elems, 0);
+    for (uint32_t s = 0; s < S; s++)
+        for (uint32_t q = 0; q < batch; q++)
+            for (uint32_t i = 0; i < cnt[(size_t)s * batch + q] && i < k; i++) {
+                const size_t e = s * elems + (size_t)q * k + i;
+                const size_t row = (size_t)(std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), ids[e]) - ix->h_ids_cache.begin());
+                if (row < ix->h_order_keys.size()) keys[e] = ix->h_order_keys[row];
+            }
+    return pvs_merge_topk_keyed(ids.data(), dist.data(), keys.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
+}
 
 // pvs_search_filtered on a multi-device index: the mask split into the shards' row orders, one masked search per shard (threads),
 // pages merged on the host under (distance asc, id asc, NULL last)
@@ -736,46 +781,29 @@ pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype q
                            cnt.data() + (size_t)s * batch);
     }));
     ix->searches++;
-    if (!(ix->order_rows == ix->n && ix->n)) return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
-    // with order keys: (distance asc, NULL last, key DESC, id asc); a row's key by its id through the global id list
-    {
-        std::lock_guard<std::mutex> lk(ix->mu);
-        if (ix->h_ids_cache.size() != ix->n) {
-            ix->h_ids_cache.resize(ix->n);
-            PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
-        }
-    }
-    struct E {
-        uint32_t dk;
-        int64_t key, id;
-        float d;
-    };
-    std::vector<E> all;
-    for (uint32_t q = 0; q < batch; q++) {
-        all.clear();
-        for (uint32_t s = 0; s < S; s++)
-            for (uint32_t i = 0; i < cnt[(size_t)s * batch + q]; i++) {
-                const float d = dist[s * elems + (size_t)q * k + i];
-                const int64_t id = ids[s * elems + (size_t)q * k + i];
-                const size_t row = (size_t)(std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), id) - ix->h_ids_cache.begin());
-                uint32_t b;
-                memcpy(&b, &d, 4);
-                const uint32_t dk = d != d ? 0xffffffffu : ((b >> 31) ? ~b : (b | 0x80000000u));
-                all.push_back({dk, ix->h_order_keys[row], id, d});
-            }
-        std::sort(all.begin(), all.end(), [](const E &a, const E &b) {
-            if (a.dk != b.dk) return a.dk < b.dk;
-            if (a.key != b.key) return a.key > b.key;
-            return a.id < b.id;
-        });
-        const uint32_t nout = (uint32_t)std::min<size_t>(k, all.size());
-        for (uint32_t i = 0; i < k; i++) {
-            out_ids[(size_t)q * k + i] = i < nout ? all[i].id : -1;
-            out_dist[(size_t)q * k + i] = i < nout ? all[i].d : __builtin_nanf("");
-        }
-        out_count[q] = nout;
-    }
-    return PVS_OK;
+    return merge_row_pages_host(ix, ids, dist, cnt, S, batch, k, out_ids, out_dist, out_count);
+}
+
+// pvs_search_bounded with a lower bound on a multi-device index (pql/builder.rs:781-815): one bounded search per shard — growing
+// pages of the filter scan, then that shard's dense path for a bound deeper than PVS_MAX_K rows — merged on the host.  Rows
+// outside (gt, lt) are candidates on no shard, so the first k of the merged pages are the first k of the whole index.
+pvs_status multi_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric, int32_t have_gt,
+                                double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (batch == 0) return PVS_OK;
+    const uint32_t S = (uint32_t)ix->shards.size();
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> ids(S * elems, -1);
+    std::vector<float> dist(S * elems, __builtin_nanf(""));
+    std::vector<uint32_t> cnt((size_t)S * batch, 0);
+    PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
+        if (ix->shards[s]->n == 0) return PVS_OK;
+        return pvs_search_bounded(ix->shards[s], queries, qdtype, batch, k, metric, have_gt, gt, have_lt, lt, ids.data() + s * elems, dist.data() + s * elems,
+                                  cnt.data() + (size_t)s * batch);
+    }));
+    ix->searches++;
+    return merge_row_pages_host(ix, ids, dist, cnt, S, batch, k, out_ids, out_dist, out_count);
 }
 
 // pvs_score_batch on a multi-device index: one dense matrix per shard, scattered into global row order
@@ -877,6 +905,7 @@ struct Rendezvous {
     std::condition_variable cv;
     uint32_t world = 0, arrived = 0, readers = 0;
     uint64_t gen = 0;
+    bool aborted = false;  // a rank left the protocol with an error: nobody may wait for it any more
     std::vector<uint8_t> buf;
 };
 struct RankCtx {
@@ -887,6 +916,7 @@ int32_t rendezvous_gather(void *ctx, const void *send, void *recv, uint64_t byte
     RankCtx *r = (RankCtx *)ctx;
     Rendezvous &z = *r->z;
     std::unique_lock<std::mutex> lk(z.mu);
+    if (z.aborted) return 1;
     if (z.arrived == 0) z.buf.resize((size_t)z.world * bytes);  // (the previous round's readers are all gone: second wait below)
     if (z.buf.size() != (size_t)z.world * bytes) return 1;     // ranks disagree on the message size
     memcpy(z.buf.data() + (size_t)r->rank * bytes, send, bytes);
@@ -897,14 +927,15 @@ int32_t rendezvous_gather(void *ctx, const void *send, void *recv, uint64_t byte
         z.gen++;
         z.cv.notify_all();
     } else {
-        z.cv.wait(lk, [&] { return z.gen != g; });
+        z.cv.wait(lk, [&] { return z.gen != g || z.aborted; });
+        if (z.gen == g) return 1;  // released by a departing rank, not by the round completing
     }
     memcpy(recv, z.buf.data(), (size_t)z.world * bytes);
     if (--z.readers == 0)
         z.cv.notify_all();
     else
-        z.cv.wait(lk, [&] { return z.readers == 0; });
-    return 0;
+        z.cv.wait(lk, [&] { return z.readers == 0 || z.aborted; });
+    return z.aborted ? 1 : 0;
 }
 }  // namespace
 
@@ -933,7 +964,13 @@ pvs_status multi_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, i
             mine[b].row_weights = br[b].row_weights ? weights[b][s].data() : nullptr;
         }
         rc[s] = {&z, s};
-        return pvs_rrf_search_sharded(mine.data(), nb, k, nullptr, S, rendezvous_gather, &rc[s], og[s].data(), os[s].data(), &oc[s]);
+        pvs_status st = pvs_rrf_search_sharded(mine.data(), nb, k, nullptr, S, rendezvous_gather, &rc[s], og[s].data(), os[s].data(), &oc[s]);
+        if (st != PVS_OK) {  // this rank is out of the protocol: release whoever waits for it in the rendezvous
+            std::lock_guard<std::mutex> lk(z.mu);
+            z.aborted = true;
+            z.cv.notify_all();
+        }
+        return st;
     }));
     memcpy(out_groups, og[0].data(), (size_t)k * 8);
     memcpy(out_scores, os[0].data(), (size_t)k * 8);

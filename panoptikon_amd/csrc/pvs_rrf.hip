@@ -193,7 +193,39 @@ __global__ __launch_bounds__(256) void k_rank_count(const unsigned long long *ke
     for (uint32_t i = threadIdx.x; i <= m; i += 256)
         if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
 }
+// 64-bit digest of an array of 4- or 8-byte words: the wrapping sum of mix(index, word) — order-independent, so the atomics that
+// build it cannot make it move; any single changed word changes it (race hunting: pvs_debug_set("rrf_digest", 1))
+__device__ inline unsigned long long digest_mix(unsigned long long i, unsigned long long w) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull ^ w * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_digest(const void *p, uint64_t n, int word_bytes, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        acc += digest_mix(i, word_bytes == 4 ? (unsigned long long)((const uint32_t *)p)[i] : ((const unsigned long long *)p)[i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
 }  // namespace
+
+pvs_status pvs_digest_device(const void *d, uint64_t n, int word_bytes, uint64_t *out_host, hipStream_t s) {
+    *out_host = 0;
+    if (n == 0) return PVS_OK;
+    unsigned long long *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, 8));  // (deliberately outside the scratch cache: the digests must not depend on what they examine)
+    hipError_t e = hipMemsetAsync(d_out, 0, 8, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_digest, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, s, d, n, word_bytes, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return pvs_fail(PVS_ERR_DEVICE, "digest: %s", hipGetErrorString(e));
+    return PVS_OK;
+}
 
 pvs_status pvs_rrf_window_keys(const double *d_vals, uint32_t n, int descending, unsigned long long *d_keys, hipStream_t s) {
     if (n == 0) return PVS_OK;
@@ -292,7 +324,9 @@ __global__ __launch_bounds__(256) void k_page_compact_cols(const unsigned long l
 __global__ void k_gather_page_cols(const int64_t *gids, const unsigned long long *keys, uint32_t n, const uint32_t *slots, const uint32_t *count,
                                    uint32_t cap, int64_t *out_g, unsigned long long *out_k) {
     const uint32_t col = blockIdx.y;
-    const uint32_t m = count[(size_t)col * CNT_PAD] < cap ? count[(size_t)col * CNT_PAD] : 0u;  // (an overflowed column is not read back)
+    // (an overflowed column — count > cap — is not read back; count == cap filled its slots exactly and IS: the host applies the same
+    //  predicate, pvs_rrf_pages_cols / rank_groups_page_first)
+    const uint32_t m = count[(size_t)col * CNT_PAD] <= cap ? count[(size_t)col * CNT_PAD] : 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const uint32_t sl = slots[(size_t)col * cap + i];
         out_g[(size_t)col * cap + i] = gids[sl];

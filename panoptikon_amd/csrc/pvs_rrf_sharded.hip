@@ -232,7 +232,14 @@ PVS_EXPORT pvs_status pvs_rrf_search_sharded(const pvs_rrf_branch *branches, uin
         }
         return pvs_fail(PVS_ERR_UNSUPPORTED, "the bounded fusion did not converge in 6 rounds (k close to the number of groups): fuse on one device");
     };
-    pvs_status st = body();
+    pvs_status st;
+    try {  // (the page / key vectors hold up to 2^26 entries: no exception may cross the C ABI or end a rank thread)
+        st = body();
+    } catch (const std::bad_alloc &) {
+        st = pvs_fail(PVS_ERR_OOM, "out of host memory in the sharded fusion");
+    } catch (...) {
+        st = pvs_fail(PVS_ERR_STATE, "unexpected failure in the sharded fusion");
+    }
     for (pvs_rrf_cols *c : cols) pvs_rrf_cols_destroy(c);
     return st;
 }

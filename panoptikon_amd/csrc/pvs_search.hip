@@ -92,13 +92,12 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // a handful of queries emit so little that 1/64 is enough.  The candidate list of a query
     // holds ~k/frac rows: keep that 2.5x below its capacity.
     double frac = nb <= 4 ? 1.0 / 32.0 : 1.0 / 16.0;  // (single query, 10M rows: 1/64 leaves pass C 6,400 candidates = 100 us (f16) for 10 us of pass A)
-    static const double frac_env = getenv("PVS_SAMPLE_DIV") ? 1.0 / atof(getenv("PVS_SAMPLE_DIV")) : 0.0;  // tuning experiments
-    if (frac_env > 0.0) frac = frac_env;
+    if (pvs_dbg(PVS_DBG_SAMPLE_DIV) > 0) frac = 1.0 / (double)pvs_dbg(PVS_DBG_SAMPLE_DIV);  // tuning experiments
     // The threshold need not be the sample's k-th value: its j-th value (j < k) from a sample j/k the size expects the same number
     // of candidates (j / frac') at j/k of pass A's cost, with a relative spread of 1/sqrt(j).  What is lost is the guarantee that k
     // rows lie below T — pass C certifies that from the candidates' upper bounds (FinalizeArgs.thr) and hands the query to the
     // dense path otherwise (never seen: it needs T below the corpus' k-th value while j sample rows lie below it).
-    static const uint32_t j_div = getenv("PVS_SAMPLE_J_DIV") ? (uint32_t)std::max(1, atoi(getenv("PVS_SAMPLE_J_DIV"))) : 4u;  // tuning experiments
+    const uint32_t j_div = pvs_dbg(PVS_DBG_SAMPLE_J_DIV) > 0 ? (uint32_t)pvs_dbg(PVS_DBG_SAMPLE_J_DIV) : 4u;  // tuning experiments
     uint32_t k_sel = k;
     if (ix->n >= (1ull << 18) && !flat_rerun) k_sel = std::min(k, std::max<uint32_t>(8, k / j_div));
     frac *= (double)k_sel / (double)k;
@@ -163,8 +162,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.seg_queries = batch_pad;
     f.seg_cap = pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs);
     f.cand = c.d_cand;
-    static const bool no_light = getenv("PVS_NO_LIGHT_FINALIZE") != nullptr;  // tuning
-    static const bool force_light = getenv("PVS_FORCE_LIGHT_FINALIZE") != nullptr;
+    const bool no_light = pvs_dbg(PVS_DBG_NO_LIGHT_FINALIZE) != 0, force_light = pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE) != 0;  // tuning / tests
     if ((ix->multi_stream || force_light) && c.d_fin_ub && !no_light) {
         f.w_ub = c.d_fin_ub;
         f.w_surv = c.d_fin_surv;
@@ -215,7 +213,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         float *od = d_out_dist + (size_t)qoff * k;
         uint32_t *oc = d_out_count + qoff;
         if (!fast) {
-            static const bool per_query = getenv("PVS_DENSE_PER_QUERY") != nullptr;
+            const bool per_query = pvs_dbg(PVS_DBG_DENSE_PER_QUERY) != 0;
             if (nb >= 2 && pvs_select_supported(k) && !per_query) {  // all of the chunk's queries per corpus pass, pages by radix select
                 const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nb, (1ull << 31) / (4 * std::max<uint64_t>(ix->n, 1))));
                 float *d_m = nullptr;
@@ -280,7 +278,7 @@ pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, 
     ix->fast_queries += batch - n_dense;
     if (!n_dense) return PVS_OK;
     if (ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "%u queries need the dense path but path=2 forbids it", n_dense);
-    static const bool no_batched = getenv("PVS_DENSE_PER_QUERY") != nullptr;  // tests: the round-1 form (one query per pass, full sort)
+    const bool no_batched = pvs_dbg(PVS_DBG_DENSE_PER_QUERY) != 0;  // tests: the round-1 form (one query per pass, full sort)
     if (n_dense >= 2 && pvs_select_supported(k) && !no_batched) {
         // Several queries at once: scored together into one [rows][queries] matrix (int8: up to 128 per corpus pass on the
         // matrix cores), pages by an exact radix select over all columns (pvs_select.hip) — not one corpus pass + one full
@@ -676,17 +674,21 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
         }
         return PVS_OK;
     }
-    PVS_TRY(validate_search(is_multi(ix) ? ix->shards[0] : ix, queries, qdtype, batch, k, metric));
+    // A multi-device index: every shard answers the bounded search over its rows (growing pages, then ITS dense path for a deep
+    // bound), the pages merge under the shared order — rows outside the bounds are no candidates on any shard, so the merge of the
+    // shards' first k is the first k of the whole index.
+    if (is_multi(ix)) return multi_search_bounded(ix, queries, qdtype, batch, k, metric, have_gt, gt, have_lt, lt, out_ids, out_dist, out_count);
+    PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (batch == 0) return PVS_OK;
     // Lower bound.  The rows with d > gt are a SUFFIX of the plain ordering (distance asc, NULL last; ties keep their order), and
     // `gt` is in practice the last distance of an earlier page: few rows lie at or below it.  So: pages of the plain ordering
     // (filter scan) of growing size until k rows inside the bounds are on the page, the page ran into `lt` / the NULL rows (no
     // later row satisfies a comparison), or the page is everything.  Only a query whose bound lies deeper than PVS_MAX_K rows
-    // goes on to the dense path below (a multi-device index keeps growing the page instead).
+    // goes on to the dense path below.
     std::vector<uint32_t> pending(batch);
     for (uint32_t q = 0; q < batch; q++) pending[q] = q;
     const size_t qbytes_h = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-    const uint64_t kmax = is_multi(ix) ? std::max<uint64_t>(ix->n, 1) : std::min<uint64_t>(PVS_MAX_K, std::max<uint64_t>(ix->n, 1));
+    const uint64_t kmax = std::min<uint64_t>(PVS_MAX_K, std::max<uint64_t>(ix->n, 1));
     for (uint64_t kp = std::min<uint64_t>(kmax, std::max<uint64_t>(2ull * k, 64)); !pending.empty(); kp = std::min<uint64_t>(kmax, kp * 4)) {
         const uint32_t nb = (uint32_t)pending.size();
         std::vector<uint8_t> pq(qbytes_h * nb);
@@ -701,7 +703,7 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
             const int64_t *ids = pi.data() + (size_t)i * kp;
             const float *d = pd.data() + (size_t)i * kp;
             uint32_t got = 0;
-            bool closed = pc[i] < kp;  // the page is every row there is
+            bool closed = pc[i] < kp || kp >= ix->n;  // the page is every row there is
             for (uint32_t e = 0; e < pc[i] && got < k; e++) {
                 if (d[e] != d[e] || (have_lt && !((double)d[e] < lt))) {  // NULL, or at / beyond lt: nothing later qualifies
                     closed = true;
@@ -712,11 +714,7 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
                 out_dist[(size_t)q * k + got] = d[e];
                 got++;
             }
-            if (got < k && !closed && kp < kmax) {
-                still.push_back(q);
-                continue;
-            }
-            if (got < k && !closed && !is_multi(ix)) {  // deeper than the filter path pages: dense path below
+            if (got < k && !closed) {  // grow the page; past kmax: deeper than the filter path pages, the dense path below
                 still.push_back(q);
                 continue;
             }
@@ -730,7 +728,6 @@ PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs
         if (kp >= kmax) break;
     }
     if (pending.empty()) return PVS_OK;
-    if (is_multi(ix)) return pvs_fail(PVS_ERR_STATE, "bounded search did not close on a multi-device index");  // (unreachable: kmax = n)
     HIP_TRY(hipSetDevice(ix->device));
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);

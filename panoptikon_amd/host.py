@@ -191,8 +191,9 @@ def merge_group_pages(groups, values, counts, k: int, keys=None):
     return og, ov, oc
 
 
-def merge_topk(ids, dist, counts, k: int):
-    """ids/dist: [world][batch][k]; counts: [world][batch] -> merged ([batch][k], ...)."""
+def merge_topk(ids, dist, counts, k: int, keys=None):
+    """ids/dist: [world][batch][k]; counts: [world][batch] -> merged ([batch][k], ...).  keys ([world][batch][k] i64, optional): the
+    second sort key of every entry's row (pvs_merge_topk_keyed: distance asc, NULL last, key DESC, id asc)."""
     ids = np.ascontiguousarray(ids, np.int64)
     dist = np.ascontiguousarray(dist, np.float32)
     counts = np.ascontiguousarray(counts, np.uint32)
@@ -200,7 +201,11 @@ def merge_topk(ids, dist, counts, k: int):
     oi = np.empty((batch, k), np.int64)
     od = np.empty((batch, k), np.float32)
     oc = np.empty(batch, np.uint32)
-    L.check(L.lib().pvs_merge_topk(_ptr(ids), _ptr(dist), _ptr(counts), world, batch, k, _ptr(oi), _ptr(od), _ptr(oc)))
+    if keys is None:
+        L.check(L.lib().pvs_merge_topk(_ptr(ids), _ptr(dist), _ptr(counts), world, batch, k, _ptr(oi), _ptr(od), _ptr(oc)))
+    else:
+        keys = np.ascontiguousarray(keys, np.int64)
+        L.check(L.lib().pvs_merge_topk_keyed(_ptr(ids), _ptr(dist), _ptr(keys), _ptr(counts), world, batch, k, _ptr(oi), _ptr(od), _ptr(oc)))
     return oi, od, oc
 
 

@@ -345,6 +345,5 @@ class VectorIndex:
 
     def stats(self) -> L.Stats:
         s = L.Stats()
-        s.struct_size = C.sizeof(L.Stats)
-        L.check(L.lib().pvs_index_stats(self._h, C.byref(s)))
+        L.check(L.lib().pvs_index_stats_ex(self._h, C.byref(s), C.sizeof(L.Stats)))
         return s

@@ -111,10 +111,12 @@ def test_config4_two_25M_row_indexes_or_composition_rrf(pvs, monkeypatch):
     for k in (100, 1000):
         g1, s1 = pvs.rrf_search(brs, k)
         assert pvs.lib().pvs_rrf_last_path() == 1, "the bounded fusion must serve configs[4]"
-        monkeypatch.setenv("PVS_RRF_FULL", "1")
-        g2, s2 = pvs.rrf_search(brs, k)
+        pvs.debug_set("rrf_full", 1)
+        try:
+            g2, s2 = pvs.rrf_search(brs, k)
+        finally:
+            pvs.debug_set("rrf_full", 0)
         assert pvs.lib().pvs_rrf_last_path() == 2
-        monkeypatch.delenv("PVS_RRF_FULL")
         assert np.array_equal(g1, g2) and np.array_equal(s1.view(np.uint64), s2.view(np.uint64)), k
         assert (np.diff(s1) <= 0).all()
     # each branch alone: the per-file page of the filter scan = the head of that branch's window
