@@ -223,10 +223,21 @@ pvs_status pvs_search(pvs_index *idx, const void *queries, pvs_dtype query_dtype
  * CTE every vector filter is joined to, `WHERE begin_cte.item_id IS NOT NULL`,
  * filters/image_embeddings.rs:140-199).  allowed_rows: one byte per stored row in row order (host or
  * device memory), 0 = the row is not a candidate.  Rows outside the mask are never returned, not even as
- * NULL-distance filler; out_count[q] = min(k, allowed rows). */
+ * NULL-distance filler; out_count[q] = min(k, allowed rows).
+ * Cost: the mask is counted first; when few rows are allowed (allowed x batch <= max(rows / 32, 16384)) the page comes from
+ * gather-and-score over the allowed rows only — exact distances in the reference's order, sorted; no corpus pass, NULL rows where
+ * the reference puts them — so the cost follows the candidate set as it does in the reference's join; otherwise the filter scan
+ * streams the corpus with the masked rows switched off.  pvs_stats.sparse_queries counts the former. */
 pvs_status pvs_search_filtered(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
                                pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space,
                                int64_t *out_ids, float *out_dist, uint32_t *out_count);
+/* The same with the candidate set as a LIST: rows = strictly ascending row positions (the index of a mask byte; add order),
+ * host or device memory.  A host that already holds the context CTE's item_data ids sends a few KB instead of one byte per
+ * stored row: a 1,000-row candidate set over 10M rows costs ~0.1 ms whatever k is.  A long list is turned into a mask for the
+ * filter scan; an unsorted list, duplicates or a position beyond the index is PVS_ERR_INVALID_ARG. */
+pvs_status pvs_search_rows(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch, uint32_t k,
+                           pvs_metric metric, const uint32_t *rows, uint64_t n_rows_listed, pvs_space rows_space,
+                           int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
 /* Pagination (pql/builder.rs:578-582: `LIMIT ? OFFSET ?` behind the final ORDER BY; api/search.rs:51,777-783 executes
  * LIMIT = max(page_size, prefetch_rows <= 4096) at OFFSET (page-1)*page_size): entries [offset, offset+limit) of the same

@@ -118,6 +118,7 @@ SYMBOLS = {
     "pvs_merge_group_pages_keyed": (_i32, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pvs_search_groups_filtered": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "pvs_search_filtered": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "pvs_search_rows": (_i32, [_vp, _vp, _i32, _u32, _u32, _i32, _vp, _u64, _i32, _vp, _vp, _vp]),
     "pvs_device_synchronize": (_i32, [_i32]),
     "pvs_device_mem_info": (_i32, [_i32, _vp, _vp]),
     "pvs_rrf_search": (_i32, [_vp, _u32, _u32, _vp, _vp, _vp]),

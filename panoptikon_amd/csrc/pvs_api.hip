@@ -337,7 +337,19 @@ void ctx_release(SearchCtx &c) {
     hipFree(c.d_all_rec);
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
     if (c.own_stream) hipStreamDestroy(c.own_stream);
+    if (c.h_io) hipHostFree(c.h_io);
     c = SearchCtx();
+}
+
+pvs_status ctx_pinned_io(SearchCtx &c, size_t bytes) {
+    if (bytes <= c.h_io_cap) return PVS_OK;
+    if (c.h_io) hipHostFree(c.h_io);
+    c.h_io = nullptr;
+    c.h_io_cap = 0;
+    const size_t cap = pvs_round_up(std::max<size_t>(bytes, 1 << 16), 1 << 16);
+    HIP_TRY(hipHostMalloc((void **)&c.h_io, cap, hipHostMallocDefault));
+    c.h_io_cap = cap;
+    return PVS_OK;
 }
 
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs) {
@@ -526,6 +538,8 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
     hipFree(ix->d_grp_tinv);
+    hipFree(ix->d_null_rows[0]);
+    hipFree(ix->d_null_rows[1]);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
@@ -648,6 +662,7 @@ PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *key
     ix->d_trank = ix->d_tinv = nullptr;
     ix->d_order_keys = nullptr;
     ix->order_rows = 0;
+    ix->order_epoch++;  // (the NULL-row list is kept in tie order: pvs_ensure_null_rows)
     ix->h_order_keys.clear();
     ix->groups_built_n = UINT64_MAX;  // the groups' tie order is rebuilt with the CSR
     if (!keys) return PVS_OK;

@@ -124,6 +124,10 @@ struct QInfo {
     float pad0, pad1;
 };
 
+// Does this query make EVERY row's distance NULL?  bb = sum q_i^2 in f32.  Cosine: a zero query (0/0) or one with a NaN component
+// (bb NaN); L2: a NaN component.  (bb = +inf — an inf component or an overflow — is not decidable from bb alone: not claimed.)
+__host__ __device__ static inline bool pvs_query_all_null(int metric, float bb) { return bb != bb || (metric == PVS_COSINE && bb == 0.f); }
+
 // ------------------------------------------------------ device helpers
 #if defined(__HIPCC__)
 

@@ -56,6 +56,10 @@ struct SearchCtx {
     uint32_t *d_out_count = nullptr;
     uint64_t out_cap = 0;  // elements (batch*k)
     uint32_t out_batch_cap = 0;
+    // pinned host block, mapped into the device's address space: small searches (pvs_search_rows) read their queries / row list
+    // from it and write their page into it — no staging copies, one synchronisation per call
+    uint8_t *h_io = nullptr;
+    size_t h_io_cap = 0;
     DenseWork dense;
     GroupWork gwork;              // per-context sort scratch of pvs_group_rank (searches in flight never share it)
     // deferred fallback bookkeeping (device variant)
@@ -157,6 +161,15 @@ struct pvs_index {
     uint32_t n_groups = 0;
     uint32_t *d_grp_off = nullptr, *d_grp_rows = nullptr;
     int64_t *d_grp_ids = nullptr;
+    // rows whose distance is NULL for every query, per metric ([0] cosine: zero vectors and non-finite components, [1] L2: NaN
+    // components), in tie order: the tail of a page that ends in NULL rows (pvs_sparse.hip: pvs_ensure_null_rows, built on first
+    // need per index state).  null_weird[m]: rows whose NULL-ness depends on the query (|a|^2 under/overflow; inf components under
+    // L2): with any of them the dense fallback stays for that metric.
+    uint32_t *d_null_rows[2] = {nullptr, nullptr};
+    uint32_t n_null[2] = {0, 0}, null_weird[2] = {0, 0};
+    std::atomic<uint64_t> null_built_n{UINT64_MAX};
+    uint64_t null_built_epoch = 0, order_epoch = 0;  // order_epoch: bumped by pvs_index_set_order_keys
+    std::mutex null_mu;
     float scale = 0.f;
     bool scale_set = false;
     uint32_t forced_path = 0;
@@ -218,6 +231,7 @@ void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on = nullptr);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
 void ctx_release(SearchCtx &c);
+pvs_status ctx_pinned_io(SearchCtx &c, size_t bytes);  // c.h_io holds >= bytes afterwards (contents are not preserved when it grows)
 // ---- pvs_search.hip
 // request coalescing (pvs_search.hip): runs the call directly or as part of a group of concurrent callers
 bool coalescing_applies(pvs_index *ix, uint32_t batch);
@@ -230,7 +244,8 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 // block == false: returns nullptr (and sets the error) when every context is taken
 SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket, bool block = true);
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                       const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+                       const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count,
+                       const uint32_t *rows = nullptr, uint64_t n_listed = 0, pvs_space rows_space = PVS_HOST);
 void ctx_done(pvs_index *ix, SearchCtx *c);
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
                           int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast);
@@ -241,6 +256,16 @@ pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k);
 pvs_status ctx_finish_local_page(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, hipStream_t s);
 // key of a group under pvs_index_set_order_keys (false: the index carries none / does not hold the group)
 bool index_group_key(const pvs_index *ix, int64_t g, int64_t *key);
+// ---- pvs_sparse.hip
+pvs_status pvs_ensure_null_rows(pvs_index *ix);
+pvs_status pvs_launch_null_tails(pvs_index *ix, SearchCtx &c, int metric, uint32_t *d_flags, uint32_t *h_flags, uint32_t nq, uint32_t k, int64_t *d_out_ids,
+                                 float *d_out_dist, uint32_t *d_out_count);
+pvs_status pvs_mask_count(const uint8_t *d_mask, uint64_t n, uint32_t *out_count, hipStream_t s);
+pvs_status pvs_mask_compact(const uint8_t *d_mask, uint64_t n, uint32_t *d_list, uint32_t count, hipStream_t s);
+pvs_status pvs_list_to_mask(const uint32_t *d_list, uint32_t m, uint64_t n, uint8_t *d_mask, hipStream_t s);  // validates; synchronous
+bool pvs_sparse_eligible(const pvs_index *ix, uint64_t m, uint32_t batch, uint32_t k);
+pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, const uint32_t *d_list,
+                             uint32_t m, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
 // d_out[row * nb + q]: exact distances of the nb queries prepared in ctx c (prep_chunk) — matrix cores for int8, k_dense_exact otherwise
@@ -286,6 +311,8 @@ pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdt
                                double *out_values, uint32_t *out_count);
 pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                  const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
+pvs_status multi_search_rows(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric, const uint32_t *rows,
+                             uint64_t n_listed, pvs_space rows_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 pvs_status multi_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric, int32_t have_gt,
                                 double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 pvs_status multi_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric, float *out_dist,

@@ -84,8 +84,10 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s);
 hipError_t pvs_launch_void_thresholds(float *thr, const uint32_t *need_dense, uint32_t n, hipStream_t s);
 
 // k-th smallest (1-based) of vals[q][0..per_query), +inf when fewer than k finite values
+// qinfo / metric (optional): a query that makes every distance NULL (pvs_query_all_null) gets -inf — pass B emits nothing for it
+// and pass C hands it straight to the NULL-tail step
 hipError_t pvs_launch_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out,
-                          hipStream_t s);
+                          hipStream_t s, const QInfo *qinfo = nullptr, int metric = 0);
 
 struct FinalizeArgs {
     int dtype, metric;
@@ -114,6 +116,11 @@ struct FinalizeArgs {
     // [batch] the thresholds pass B ran with, when they were taken BELOW the k-th sample value (search_enqueue: j-th of a smaller
     // sample): pass C then proves that k rows lie at or below T (k-th smallest upper bound <= T) or hands the query back
     const float *thr = nullptr;
+    // A page that ends in NULL rows (cosine): when the index's NULL set is query-independent (null_ok) and the threshold pass B ran
+    // with was +inf (thr_all[q]: every row with a comparable key was emitted), pass C writes the finite part of the page and hands
+    // the query back with flag 3 — the host appends the tail from the NULL list (pvs_launch_null_tails) — instead of flag 1 (dense)
+    const float *thr_all = nullptr;
+    int null_ok = 0;
     // pinned host mirrors of need_dense / cand_seen: the kernel writes its verdicts straight into host memory, so that no copy
     // kernel (4-5 us each, plus a launch gap) follows every search just to fetch two words per query
     uint32_t *h_flags = nullptr, *h_seen = nullptr;

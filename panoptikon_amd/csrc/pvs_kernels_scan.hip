@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "pvs_kernels.hpp"
+#include "pvs_rerank.hpp"
 #include "pvs_scan_dispatch.hpp"
 
 bool pvs_scan_supported(int dtype, uint32_t kslabs) {
@@ -242,11 +243,11 @@ __device__ static inline uint32_t kth_in_registers(const float *v, uint32_t per_
     return prefix;
 }
 
-__global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out) {
+__global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out, const QInfo *qinfo, int metric) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_sel[4];
     const uint32_t q = blockIdx.x;
-    if (q >= batch) {  // padding query: never admits a candidate
+    if (q >= batch || (qinfo && pvs_query_all_null(metric, qinfo[q].bb))) {  // padding query / every distance NULL: never admits a candidate
         if (threadIdx.x == 0) out[q] = -__builtin_inff();
         return;
     }
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(256) void k_kth(const float *vals, uint32_t per_que
     }
 }
 
-hipError_t pvs_launch_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out, hipStream_t s) {
+hipError_t pvs_launch_kth(const float *vals, uint32_t per_query, uint32_t batch, uint32_t k, float *out, hipStream_t s, const QInfo *qinfo, int metric) {
     const uint32_t bp = (batch + 31) / 32 * 32;
-    hipLaunchKernelGGL(k_kth, dim3(bp), dim3(256), 0, s, vals, per_query, batch, k, out);
+    hipLaunchKernelGGL(k_kth, dim3(bp), dim3(256), 0, s, vals, per_query, batch, k, out, qinfo, metric);
     return hipGetLastError();
 }
 
@@ -293,6 +294,8 @@ struct FinK {
     unsigned long long *w_sort;
     const uint32_t *flat_cnt;      // segment-overflow rerun (FinalizeArgs.flat_cnt)
     const float *thr;              // thresholds to certify (FinalizeArgs.thr), or nullptr
+    const float *thr_all;          // the thresholds pass B ran with (FinalizeArgs.thr_all)
+    int null_ok;                   // short pages may be completed from the NULL list (flag 3)
     uint32_t *h_flags, *h_seen;    // pinned host mirrors of need_dense / cand_seen (FinalizeArgs.h_flags), or nullptr
     const uint32_t *trank, *tinv;  // second sort key: tie rank of a row and its inverse (FinalizeArgs.trank)
 };
@@ -312,86 +315,6 @@ __device__ static inline float cand_key(const FinK &a, const QInfo &qi, uint32_t
     } else {
         return __builtin_bit_cast(float, payload);
     }
-}
-
-// Pass C's exact distance of one survivor, in the reference's order (sqlite-vec's scalar kernels: one rounding per multiply and
-// per add, components in sequence — oracle/pvs_oracle.c), written for a lane that is alone with a cold row: the row streams from
-// global memory in groups of 8 sixteen-byte chunks with the next group requested before the current one is consumed, the query
-// comes from LDS (s_q, zero-padded to a whole chunk) one vector read per chunk, and whole chunks are processed without a bounds
-// test per component — the padding of row and query is zero, and adding +0 products changes nothing a distance can show (at
-// most the sign of a zero dot product, which `1 - dot/den` does not see).  The generic form (exact_distance<DT> with the query in
-// global memory) compiled to a flat load of the query plus `s_waitcnt vmcnt(0)` per component: ~125 cycles per component,
-// 50-85 us of a 90-140 us finaliser for 768-d f16 rows.
-typedef unsigned int fin_u32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) fin_u32x4 *gchunk_ptr;
-template <int DT>
-__device__ static inline float rerank_distance(const uint8_t *rows, uint32_t stride, uint64_t r, const uint8_t *s_q, int dim, int metric, float aa,
-                                               float bb) {
-    constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;
-    constexpr int UN = 8;  // 2 x 8 loads in flight per lane (16, 24 and 48 measured the same or worse: the lanes of a wave touch 64 different lines per load)
-    const int nchunks = (dim + PER - 1) / PER;
-    const bool l2 = metric == PVS_L2;
-    float acc = 0.0f;
-    auto step = [&](float av, float qv) {
-        if (l2) {
-            const float t = __fsub_rn(av, qv);
-            acc = __fadd_rn(acc, __fmul_rn(t, t));
-        } else {
-            acc = __fadd_rn(acc, __fmul_rn(av, qv));
-        }
-    };
-    auto visit = [&](int c, const uint4 &v) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        if constexpr (DT == PVS_I8) {
-            const uint4 qv = ((const uint4 *)s_q)[c];
-            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int ai = (int)(int8_t)(w[j >> 2] >> ((j & 3) * 8)), qi = (int)(int8_t)(qw[j >> 2] >> ((j & 3) * 8));
-                if (l2) {  // (integers below 2^17: the f32 images and the product are exact, as in the reference)
-                    const float t = (float)(ai - qi);
-                    acc = __fadd_rn(acc, __fmul_rn(t, t));
-                } else {
-                    acc = __fadd_rn(acc, (float)(ai * qi));
-                }
-            }
-        } else if constexpr (DT == PVS_F16) {
-            const float4 q0 = ((const float4 *)s_q)[2 * c], q1 = ((const float4 *)s_q)[2 * c + 1];
-            const float qf[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-            for (int j = 0; j < 8; j++) step(h2f((uint16_t)(w[j >> 1] >> ((j & 1) * 16))), qf[j]);
-        } else {
-            const float4 q0 = ((const float4 *)s_q)[c];
-            const float qf[4] = {q0.x, q0.y, q0.z, q0.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) step(__builtin_bit_cast(float, w[j]), qf[j]);
-        }
-    };
-    auto load = [&](int c) {  // (an explicit global-memory load: pointers that arrive inside a by-value kernel argument struct compile to flat loads)
-        const fin_u32x4 v = *(gchunk_ptr)(uintptr_t)(rows + pvs_chunk_off(r, (uint32_t)c, stride));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    };
-    int c = 0;
-    if (nchunks >= UN) {
-        uint4 cur[UN], nxt[UN];
-#pragma unroll
-        for (int u = 0; u < UN; u++) cur[u] = load(u);
-        for (; c + UN <= nchunks; c += UN) {
-            const bool more = c + 2 * UN <= nchunks;
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < UN; u++) nxt[u] = load(c + UN + u);
-            }
-#pragma unroll
-            for (int u = 0; u < UN; u++) visit(c + u, cur[u]);
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < UN; u++) cur[u] = nxt[u];
-            }
-        }
-    }
-    for (; c < nchunks; c++) visit(c, load(c));
-    return l2 ? ref_l2_finish(acc) : ref_cosine_finish(acc, aa, bb);
 }
 
 // LIGHT (int8 rows, FinalizeArgs.w_*): bound keys, survivor list and sorts of more than 512 records live in global memory (they
@@ -420,6 +343,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     FIN_STAMP(0);
     int64_t *oid = a.out_ids + (size_t)q * a.k;
     float *od = a.out_dist + (size_t)q * a.k;
+    // a query that makes every distance NULL (zero / NaN-bearing): the whole page is the head of ALL rows in tie order — the
+    // NULL-tail step writes it (flag 3); nothing was emitted for it (k_kth gave it T = -inf)
+    if (a.null_ok && !a.flat_cnt && pvs_query_all_null(a.metric, a.qinfo[q].bb)) {
+        if (tid == 0) {
+            a.need_dense[q] = 3;
+            if (a.h_flags) a.h_flags[q] = 3;
+            a.out_count[q] = 0;
+            if (a.cand_seen) a.cand_seen[q] = 0;
+            if (a.h_seen) a.h_seen[q] = 0;
+        }
+        return;
+    }
     // ---- gather: the scan left this query's candidates in one segment per workgroup row stream (no atomics on its side);
     // prefix-sum the fill counts (offsets live in the not-yet-used bound array) and copy the segments into one flat list.
     uint2 *const flat = a.cand + (size_t)q * a.cand_cap;
@@ -537,7 +472,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (tid == 0 && a.cand_seen) a.cand_seen[q] = cnt;
     if (tid == 0 && a.h_seen) a.h_seen[q] = cnt;
     const uint64_t want = a.k < a.n_rows ? a.k : a.n_rows;
-    if (cnt > a.cand_cap || cnt < want) {  // overflowed, or NULL-distance rows are needed to fill the page
+    // a short page can be completed from the index's NULL list when every row with a comparable key was emitted (T = +inf)
+    // ... and the query is an ordinary one (a finite, for cosine non-zero, norm): a query with an infinite component turns rows
+    // NULL that no list knows
+    const float bb_q = a.qinfo[q].bb;
+    const bool can_complete = a.null_ok && a.thr_all && a.thr_all[q] == __builtin_inff() && bb_q < __builtin_inff() && (a.metric == PVS_L2 || bb_q > 0.f);
+    if (cnt > a.cand_cap || (cnt < want && !can_complete)) {  // overflowed, or NULL-distance rows are needed to fill the page
         if (tid == 0) {
             a.need_dense[q] = seg_overflow_only ? 2 : 1;
             if (a.h_flags) a.h_flags[q] = seg_overflow_only ? 2 : 1;
@@ -686,10 +626,24 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
         printf("finprof cand %u survivors %u: gather %llu ub-keys %llu kth %llu survive %llu rerank %llu sort %llu (x10 ns)\n", cnt, m, fp[1] - fp[0],
                fp[2] - fp[1], fp[3] - fp[2], fp[4] - fp[3], fp[5] - fp[4], fp[6] - fp[5]);
 #endif
-    const uint32_t nout = m < a.k ? m : a.k;
-    // A NULL distance inside the page (non-finite components) or a short page: NULL rows are ordered by id over
-    // the WHOLE corpus and the candidate list only holds rows whose scan key was comparable -> dense path.
-    if (nout < want || (nout > 0 && (uint32_t)(s_sort[nout - 1] >> 32) == 0xffffffffu)) {
+    // survivors with a NULL distance (a row with non-finite components that the scan emitted) sort last: they are rows of the NULL
+    // list, not of the finite part of the page
+    __shared__ uint32_t s_nfin;
+    if (tid == 0) s_nfin = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += 256) {
+        const bool fin = (uint32_t)(s_sort[i] >> 32) != 0xffffffffu;
+        const bool next_fin = i + 1 < m && (uint32_t)(s_sort[i + 1] >> 32) != 0xffffffffu;
+        if (fin && !next_fin) s_nfin = i + 1;
+    }
+    __syncthreads();
+    const uint32_t nfin = s_nfin;
+    const uint32_t nout = nfin < a.k ? nfin : a.k;
+    // A short page: NULL rows are ordered by tie order over the WHOLE corpus and the candidate list only holds rows whose scan key
+    // was comparable.  Cosine, a query-independent NULL set and T = +inf: the finite part is complete, the host appends the tail
+    // from the NULL list (flag 3).  Otherwise the dense path.
+    const bool tail = nout < want;
+    if (tail && !can_complete) {
         if (tid == 0) {
             a.need_dense[q] = 1;
             if (a.h_flags) a.h_flags[q] = 1;
@@ -709,8 +663,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     }
     if (tid == 0) {
         a.out_count[q] = nout;
-        a.need_dense[q] = 0;
-        if (a.h_flags) a.h_flags[q] = 0;
+        a.need_dense[q] = tail ? 3 : 0;
+        if (a.h_flags) a.h_flags[q] = tail ? 3 : 0;
     }
 }
 
@@ -731,6 +685,8 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     k.seg_cap = f.seg_cap;
     k.flat_cnt = f.flat_cnt;
     k.thr = f.thr;
+    k.thr_all = f.thr_all;
+    k.null_ok = f.null_ok;
     k.h_flags = f.h_flags;
     k.h_seen = f.h_seen;
     k.trank = f.trank;

@@ -784,6 +784,47 @@ pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype q
     return merge_row_pages_host(ix, ids, dist, cnt, S, batch, k, out_ids, out_dist, out_count);
 }
 
+// pvs_search_rows on a multi-device index: the global row list split into the shards' row orders (the segment table: both are
+// ascending), one search per shard over its own list, pages merged on the host
+pvs_status multi_search_rows(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric, const uint32_t *rows,
+                             uint64_t n_listed, pvs_space rows_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
+    PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
+    if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (n_listed > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "%llu candidate rows for an index of %llu rows", (unsigned long long)n_listed, (unsigned long long)ix->n);
+    if (batch == 0) return PVS_OK;
+    std::vector<uint32_t> stage;
+    const uint32_t *hl = rows;
+    if (rows_space == PVS_DEVICE && n_listed) {
+        stage.resize(n_listed);
+        HIP_TRY(hipMemcpy(stage.data(), rows, n_listed * 4, hipMemcpyDeviceToHost));
+        hl = stage.data();
+    }
+    const uint32_t S = (uint32_t)ix->shards.size();
+    std::vector<std::vector<uint32_t>> lists(S);
+    size_t seg = 0;
+    for (uint64_t i = 0; i < n_listed; i++) {
+        const uint64_t r = hl[i];
+        if (r >= ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "candidate rows must be row positions below the index's row count (%llu)", (unsigned long long)ix->n);
+        if (i && hl[i - 1] >= hl[i]) return pvs_fail(PVS_ERR_INVALID_ARG, "candidate rows must be strictly ascending");
+        while (seg < ix->segs.size() && ix->segs[seg].row0 + ix->segs[seg].n <= r) seg++;
+        const MultiSegment &g = ix->segs[seg];
+        lists[g.shard].push_back((uint32_t)(g.local0 + (r - g.row0)));
+    }
+    const size_t elems = (size_t)batch * k;
+    std::vector<int64_t> ids(S * elems, -1);
+    std::vector<float> dist(S * elems, __builtin_nanf(""));
+    std::vector<uint32_t> cnt((size_t)S * batch, 0);
+    static const uint32_t empty = 0;
+    PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
+        if (ix->shards[s]->n == 0) return PVS_OK;
+        return search_host(ix->shards[s], queries, qdtype, batch, k, metric, nullptr, PVS_HOST, ids.data() + s * elems, dist.data() + s * elems,
+                           cnt.data() + (size_t)s * batch, lists[s].empty() ? &empty : lists[s].data(), lists[s].size(), PVS_HOST);
+    }));
+    ix->searches++;
+    return merge_row_pages_host(ix, ids, dist, cnt, S, batch, k, out_ids, out_dist, out_count);
+}
+
 // pvs_search_bounded with a lower bound on a multi-device index (pql/builder.rs:781-815): one bounded search per shard — growing
 // pages of the filter scan, then that shard's dense path for a bound deeper than PVS_MAX_K rows — merged on the host.  Rows
 // outside (gt, lt) are candidates on no shard, so the first k of the merged pages are the first k of the whole index.

@@ -126,7 +126,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
     HIP_TRY(pvs_launch_scan(a, c.stream));
     span_end(ix, c);
-    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, c.stream));
+    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, c.stream, c.d_qinfo, metric));
     if (flat_rerun) {
         HIP_TRY(pvs_launch_void_thresholds(c.d_thr, c.d_need_dense + qoff, nb, c.stream));  // queries not handed back emit nothing
         HIP_TRY(hipMemsetAsync(c.d_flat_cnt, 0, 4 * (size_t)PVS_SCAN_MAX_BATCH, c.stream));
@@ -180,6 +180,10 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.h_flags = c.h_need_dense + qoff;  // (hipHostMalloc: the same address on the device)
     f.h_seen = c.h_need_dense + c.flags_cap + qoff;
     if (k_sel < k) f.thr = c.d_thr;  // thresholds below the k-th sample value: pass C certifies them
+    f.thr_all = c.d_thr;
+    // pages that end in NULL rows are completed from the index's NULL list of the metric (search_fallbacks, flag 3) when that set
+    // does not depend on the query (no "weird" row, pvs_sparse.hip): pvs_ensure_null_rows ran in search_enqueue
+    f.null_ok = ix->null_built_n.load(std::memory_order_acquire) == ix->n && ix->null_weird[metric == PVS_L2 ? 1 : 0] == 0;
     if (order_tinv(ix)) {
         f.trank = ix->d_trank;
         f.tinv = ix->d_tinv;
@@ -204,6 +208,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         HIP_TRY(hipEventRecord(c.done, c.stream));
         return PVS_OK;
     }
+    if (fast) PVS_TRY(pvs_ensure_null_rows(ix));  // (one pass over |a|^2 per index state; a no-op afterwards)
     const uint32_t pass_max = fast ? pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES) : PVS_MAX_BATCH;
     for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
         const uint32_t nb = std::min(pass_max, batch - qoff);
@@ -272,6 +277,25 @@ pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, 
         HIP_TRY(hipMemcpyAsync(c.h_need_dense, c.d_need_dense, 4 * (size_t)batch, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
         ix->flat_reruns += n_rerun;
+    }
+    // pages that end in NULL rows (flag 3): the finite part is written; the tail is the head of the index's NULL list in tie order
+    uint32_t n_tail = 0;
+    for (uint32_t q = 0; q < batch; q++) n_tail += c.h_need_dense[q] == 3 ? 1 : 0;
+    if (n_tail) {
+        const uint32_t pass_max = pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES);
+        for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
+            const uint32_t nb = std::min(pass_max, batch - qoff);
+            bool any = false;
+            for (uint32_t q = 0; q < nb; q++) any |= c.h_need_dense[qoff + q] == 3;
+            if (!any) continue;
+            const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : nb <= 128 ? 128 : 256;
+            PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));  // (the tail kernel reads the queries' norms: c.d_qinfo of THIS chunk)
+            HIP_TRY(hipMemcpyAsync(c.d_need_dense + qoff, c.h_need_dense + qoff, 4 * (size_t)nb, hipMemcpyHostToDevice, c.stream));
+            PVS_TRY(pvs_launch_null_tails(ix, c, metric, c.d_need_dense + qoff, c.h_need_dense + qoff, nb, k, d_out_ids + (size_t)qoff * k, d_out_dist + (size_t)qoff * k,
+                                          d_out_count + qoff));
+        }
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        ix->null_tail_queries += n_tail;
     }
     for (uint32_t q = 0; q < batch; q++) n_dense += c.h_need_dense[q] ? 1 : 0;
     ix->last_candidates = seen;
@@ -359,9 +383,6 @@ void ctx_done(pvs_index *ix, SearchCtx *c) {
     }
     ix->ctx_cv.notify_one();
 }
-
-pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count);
 
 static pvs_status search_host_any(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                   int64_t *out_ids, float *out_dist, uint32_t *out_count) {
@@ -574,14 +595,69 @@ PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pv
     return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
 }
 
+// mask: candidate mask over the rows (or nullptr); rows / n_listed: the candidates as a strictly ascending list of row positions
+// instead (pvs_search_rows) — answered by gather-and-score when it is short, turned into a mask for the filter scan otherwise
+// The page over an explicit candidate set: `rows` = strictly ascending row positions (add order, like a mask's index) — what the
+// reference's join against the context CTE leaves (filters/image_embeddings.rs:140-199).  A short list costs what the list costs.
+PVS_EXPORT pvs_status pvs_search_rows(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
+                                      const uint32_t *rows, uint64_t n_listed, pvs_space rows_space, int64_t *out_ids, float *out_dist,
+                                      uint32_t *out_count) {
+    if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (n_listed && !rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate rows");
+    if (is_multi(ix)) return multi_search_rows(ix, queries, qdtype, batch, k, metric, rows, n_listed, rows_space, out_ids, out_dist, out_count);
+    static const uint32_t empty = 0;
+    return search_host(ix, queries, qdtype, batch, k, metric, nullptr, PVS_HOST, out_ids, out_dist, out_count, rows ? rows : &empty, n_listed,
+                       rows ? rows_space : PVS_HOST);
+}
+
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
-                              const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+                       const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count, const uint32_t *rows,
+                       uint64_t n_listed, pvs_space rows_space) {
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
+    if (rows && mask) return pvs_fail(PVS_ERR_INVALID_ARG, "a candidate mask or a candidate row list, not both");
+    if (!rows && n_listed) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate rows");
+    if (n_listed > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "%llu candidate rows for an index of %llu rows", (unsigned long long)n_listed, (unsigned long long)ix->n);
+    const bool listed = rows != nullptr;
     if (batch == 0) return PVS_OK;
     HIP_TRY(hipSetDevice(ix->device));
     uint32_t t;
     SearchCtx *c = ctx_acquire(ix, &t);
+    // A short candidate list from host memory — the reference's everyday shape: one query, the few hundred rows its other filters
+    // left — goes through the context's pinned block end to end: queries and list are read from it by the kernels, the page is
+    // written into it; two host memcpys and ONE synchronisation instead of six staged copies and three.
+    if (listed && rows_space == PVS_HOST && ix->forced_path == 0 && (ix->n == 0 || pvs_sparse_eligible(ix, n_listed, batch, k))) {
+        const size_t qb = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4) * batch;
+        const uint32_t m = ix->n ? (uint32_t)n_listed : 0u;
+        const size_t off_q = 64, off_l = pvs_round_up(off_q + qb, 64), off_i = pvs_round_up(off_l + (size_t)m * 4, 64), off_d = off_i + (size_t)batch * k * 8,
+                     off_c = off_d + (size_t)batch * k * 4, need = off_c + (size_t)batch * 4;
+        if (need <= ((size_t)8 << 20)) {
+            pvs_status st = ctx_prepare(ix, *c, batch, k, false);
+            if (st == PVS_OK) st = ctx_pinned_io(*c, need);
+            if (st == PVS_OK && m == 0) {  // no candidate: empty pages, no device work
+                for (size_t i = 0; i < (size_t)batch * k; i++) {
+                    out_ids[i] = -1;
+                    out_dist[i] = __builtin_nanf("");
+                }
+                for (uint32_t q = 0; q < batch; q++) out_count[q] = 0;
+                ix->sparse_queries += batch;
+            } else if (st == PVS_OK) {
+                uint8_t *io = c->h_io;
+                memcpy(io + off_q, queries, qb);
+                if (m) memcpy(io + off_l, rows, (size_t)m * 4);
+                st = pvs_sparse_search(ix, *c, io + off_q, qdtype, batch, k, metric, (const uint32_t *)(io + off_l), m, (int64_t *)(io + off_i), (float *)(io + off_d),
+                                       (uint32_t *)(io + off_c));  // (returns after its one synchronisation)
+                if (st == PVS_OK) {
+                    memcpy(out_ids, io + off_i, (size_t)batch * k * 8);
+                    memcpy(out_dist, io + off_d, (size_t)batch * k * 4);
+                    memcpy(out_count, io + off_c, (size_t)batch * 4);
+                }
+            }
+            ix->searches++;
+            ctx_done(ix, c);
+            return st;
+        }
+    }
     pvs_status st = ctx_prepare(ix, *c, batch, k, true);
     const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
     void *d_q = nullptr;
@@ -606,8 +682,9 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         hipError_t e = hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "H2D queries: %s", hipGetErrorString(e));
     }
-    if (st == PVS_OK && mask && ix->n) {
+    if (st == PVS_OK && (mask || listed) && ix->n) {
         auto setup = [&]() -> pvs_status {
+            if (listed && pvs_sparse_eligible(ix, n_listed, batch, k) && ix->forced_path == 0) return PVS_OK;  // (no mask needed: gather-and-score below)
             if (ix->cap > c->mask_cap) {
                 hipFree(c->d_mask);
                 hipFree(c->d_aux_masked);
@@ -618,6 +695,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
                 HIP_TRY(pvs_malloc_retry((void **)&c->d_aux_masked, ix->cap / 32 * PVS_AUX_REC * 4));
                 c->mask_cap = ix->cap;
             }
+            if (listed) return PVS_OK;  // (the mask is filled from the list below)
             if (mask_space == PVS_HOST) {
                 HIP_TRY(hipMemcpyAsync(c->d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
                 c->cur_mask = c->d_mask;
@@ -628,13 +706,50 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         };
         st = setup();
     }
-    if (st == PVS_OK) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
-    if (st == PVS_OK) {
+    // A candidate mask that leaves few rows: gather-and-score over the allowed rows only (pvs_sparse.hip) — cost proportional to the
+    // candidate set, as in the reference, where the vector filter is joined to the context CTE (filters/image_embeddings.rs:140-199)
+    bool sparse = false;
+    uint32_t *d_list = nullptr;
+    if (st == PVS_OK && listed) {
+        const uint32_t m = (uint32_t)n_listed;
+        const uint32_t *dl = rows;
+        uint32_t *d_up = nullptr;
+        auto run = [&]() -> pvs_status {
+            if (rows_space == PVS_HOST && m) {
+                HIP_TRY(pvs_scratch_alloc((void **)&d_up, (size_t)m * 4));
+                HIP_TRY(hipMemcpyAsync(d_up, rows, (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+                dl = d_up;
+            }
+            if (ix->n == 0 || (pvs_sparse_eligible(ix, m, batch, k) && ix->forced_path == 0)) {
+                sparse = true;
+                return pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, dl, ix->n ? m : 0, c->d_out_ids, c->d_out_dist, c->d_out_count);
+            }
+            PVS_TRY(pvs_list_to_mask(dl, m, ix->n, c->d_mask, c->stream));  // (validates the list like the gather path does)
+            c->cur_mask = c->d_mask;
+            return PVS_OK;
+        };
+        st = run();
+        pvs_scratch_free_on(d_up, c->stream);
+    }
+    if (st == PVS_OK && !sparse && !listed && c->cur_mask && ix->n && ix->forced_path == 0) {
+        uint32_t allowed = 0;
+        st = pvs_mask_count(c->cur_mask, ix->n, &allowed, c->stream);
+        if (st == PVS_OK && pvs_sparse_eligible(ix, allowed, batch, k)) {
+            sparse = true;
+            hipError_t e = pvs_scratch_alloc((void **)&d_list, (size_t)std::max<uint32_t>(allowed, 1) * 4);
+            if (e != hipSuccess) st = pvs_fail(PVS_ERR_OOM, "candidate list: %s", hipGetErrorString(e));
+            if (st == PVS_OK) st = pvs_mask_compact(c->cur_mask, ix->n, d_list, allowed, c->stream);
+            if (st == PVS_OK) st = pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, d_list, allowed, c->d_out_ids, c->d_out_dist, c->d_out_count);
+            pvs_scratch_free_on(d_list, c->stream);
+        }
+    }
+    if (st == PVS_OK && !sparse) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
+    if (st == PVS_OK && !sparse) {
         hipError_t e = hipEventSynchronize(c->done);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     }
     if (st == PVS_OK) spans_collect(ix, *c);
-    if (st == PVS_OK && fast && ix->n)
+    if (st == PVS_OK && !sparse && fast && ix->n)
         st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count);
     if (st == PVS_OK) {
         hipError_t e = hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);

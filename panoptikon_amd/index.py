@@ -211,6 +211,22 @@ class VectorIndex:
         L.check(L.lib().pvs_search_filtered(self._h, _ptr(q), qd, b, k, metric, _ptr(m), L.HOST, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
 
+    def search_rows(self, queries, k: int, rows, metric: int = L.COSINE):
+        """pvs_search_rows: the page over an explicit candidate set, `rows` = strictly ascending row positions (uint32) or a
+        DeviceBuffer / (DeviceBuffer, count) holding them in HBM."""
+        q, qd = self._queries(queries)
+        b = q.shape[0]
+        ids = np.full((b, k), -1, np.int64)
+        dist = np.full((b, k), np.nan, np.float32)
+        cnt = np.zeros(b, np.uint32)
+        if isinstance(rows, tuple):
+            rp, n, space = rows[0].ptr, int(rows[1]), L.DEVICE
+        else:
+            r = np.ascontiguousarray(rows, dtype=np.uint32)
+            rp, n, space = (_ptr(r) if r.size else None), int(r.size), L.HOST
+        L.check(L.lib().pvs_search_rows(self._h, _ptr(q), qd, b, k, metric, rp, n, space, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
     def search_device(self, d_queries: DeviceBuffer, qdtype: int, batch: int, k: int, metric: int,
                       d_ids: DeviceBuffer, d_dist: DeviceBuffer, d_cnt: DeviceBuffer) -> int:
         t = C.c_uint32()
