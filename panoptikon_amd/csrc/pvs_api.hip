@@ -538,6 +538,9 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
     hipFree(ix->d_grp_tinv);
+    hipFree(ix->d_grp_trank);
+    hipFree(ix->d_tile_grp);
+    hipFree(ix->d_straddlers);
     hipFree(ix->d_null_rows[0]);
     hipFree(ix->d_null_rows[1]);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);

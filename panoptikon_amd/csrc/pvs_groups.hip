@@ -161,6 +161,42 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
     return hipGetLastError();
 }
 
+// one lane per (listed group, query): the lanes of a group are adjacent, so the group-major output row is written contiguously
+__global__ __launch_bounds__(256) void k_group_aggregate_list(const float *dist, uint32_t ld, uint32_t n_cols, const uint32_t *grp_off, const uint32_t *grp_rows,
+                                                              const uint32_t *list, uint32_t n_list, const float *weights, const uint8_t *exclude, int agg,
+                                                              double *out_t, uint32_t ld_out, uint32_t skip_when) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (uint64_t)n_list * n_cols) return;
+    const uint32_t li = (uint32_t)(idx / n_cols), q = (uint32_t)(idx % n_cols);
+    const uint32_t g = list[li];
+    out_t[(size_t)g * ld_out + q] = group_value(dist, ld, n_cols, 0, grp_off, grp_rows, weights, exclude, agg, FanoutWeights(), skip_when, g, q);
+}
+hipError_t pvs_launch_group_aggregate_list(const float *dist, uint32_t ld, uint32_t n_cols, const uint32_t *grp_off, const uint32_t *grp_rows,
+                                           const uint32_t *list, uint32_t n_list, const float *weights, const uint8_t *exclude, int agg, double *out_t,
+                                           uint32_t ld_out, hipStream_t s, uint32_t skip_when) {
+    if (n_list == 0 || n_cols == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)n_list * n_cols;
+    hipLaunchKernelGGL(k_group_aggregate_list, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, list, n_list, weights,
+                       exclude, agg, out_t, ld_out, skip_when);
+    return hipGetLastError();
+}
+// [n_groups][ncol] -> [ncol][n_groups] through a 32 x 32 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void k_group_transpose(const double *in, uint32_t n_groups, uint32_t ncol, double *out) {
+    __shared__ double t[32][33];
+    const uint32_t g0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (uint32_t r = ty; r < 32; r += 8)
+        if (g0 + r < n_groups && c0 + tx < ncol) t[r][tx] = in[(size_t)(g0 + r) * ncol + c0 + tx];
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8)
+        if (c0 + r < ncol && g0 + tx < n_groups) out[(size_t)(c0 + r) * n_groups + g0 + tx] = t[tx][r];
+}
+hipError_t pvs_launch_group_transpose(const double *vals_t, uint32_t n_groups, uint32_t ncol, double *vals, hipStream_t s) {
+    if (n_groups == 0 || ncol == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_group_transpose, dim3((n_groups + 31) / 32, (ncol + 31) / 32), dim3(256), 0, s, vals_t, n_groups, ncol, vals);
+    return hipGetLastError();
+}
+
 // order-preserving f64 -> u64, NaN last
 __device__ static inline unsigned long long f64_sort_key(double d) {
     unsigned long long b = __builtin_bit_cast(unsigned long long, d);
@@ -216,9 +252,199 @@ __global__ void k_group_page_keys(const double *vals, uint32_t n, unsigned long 
         keys[i] = k;
     }
 }
+// the same from group-major values [n_groups][ncol] into column-major keys [ncol][n_groups] (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_group_page_keys_t(const double *in, uint32_t n_groups, uint32_t ncol, unsigned long long *keys) {
+    __shared__ unsigned long long t[32][33];
+    const uint32_t g0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < 32; r += 8)
+        if (g0 + r < n_groups && c0 + tx < ncol) {
+            const double v = in[(size_t)(g0 + r) * ncol + c0 + tx];
+            unsigned long long k = f64_sort_key(v);
+            if (k == ~0ull) k = ~0ull - 1;
+            if (__builtin_bit_cast(unsigned long long, v) == PVS_GROUP_ABSENT) k = ~0ull;
+            t[r][tx] = k;
+        }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8)
+        if (c0 + r < ncol && g0 + tx < n_groups) keys[(size_t)(c0 + r) * n_groups + g0 + tx] = t[tx][r];
+}
+hipError_t pvs_group_page_keys_t(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, unsigned long long *d_keys, hipStream_t s) {
+    if (n_groups == 0 || ncol == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_group_page_keys_t, dim3((n_groups + 31) / 32, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, d_keys);
+    return hipGetLastError();
+}
 hipError_t pvs_group_page_keys(const double *d_vals, uint32_t n_groups, unsigned long long *d_keys, hipStream_t s) {
     if (n_groups == 0) return hipSuccess;
     hipLaunchKernelGGL(k_group_page_keys, dim3((n_groups + 255) / 256 > 4096 ? 4096 : (n_groups + 255) / 256), dim3(256), 0, s, d_vals, n_groups, d_keys);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Page-first ranking of GROUP-MAJOR values [n_groups][ncol] (the fused per-item scorer's layout), entirely on the device: no
+// transposition, no host round trip between its steps.
+//   k_gm_thresholds  per column: 4,096 sampled values -> keys, sorted in LDS, the j-th smallest is the column's threshold
+//   k_gm_compact     one pass over the values (a wave reads whole 256-byte group rows): every (key, group slot) at or below its
+//                    column's threshold, staged per column in LDS, appended with one global atomic per workgroup and column
+//   k_gm_topk        per column: the few thousand admitted entries sorted by (key, tie order) in LDS, the first k written out
+// A column whose page came out short (fewer than k admitted: an unlucky sample, NULL-heavy columns) or too long (> GM_CAP:
+// massive ties at the threshold) is flagged and ranked by the full sort instead.
+constexpr uint32_t GM_M = 4096, GM_CAP = 8192, GM_LIST = 48;
+__device__ static inline unsigned long long gm_key(double v) {
+    unsigned long long k = f64_sort_key(v);
+    if (k == ~0ull) k = ~0ull - 1;                                               // NULL aggregates: after every value ...
+    if (__builtin_bit_cast(unsigned long long, v) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
+    return k;
+}
+__global__ __launch_bounds__(256) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, uint32_t ncol, uint32_t j, unsigned long long *thr) {
+    __shared__ unsigned long long s[GM_M];
+    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < GM_M; i += 256) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * ncol + col]);
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= GM_M; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < GM_M / 2; i += 256) {
+                const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
+                const bool up = (lo & sz) == 0;
+                const unsigned long long x = s[lo], y = s[hi];
+                if ((x > y) == up) {
+                    s[lo] = y;
+                    s[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) thr[col] = s[j] >= ~0ull - 1 ? 0ull : s[j];  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
+}
+// grid (row blocks, ceil(ncol / 32)); a workgroup walks `per_wg` consecutive groups, lane = column of its 32-column chunk
+__global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32_t n_groups, uint32_t ncol, const unsigned long long *thr, uint32_t per_wg,
+                                                    uint32_t *count, unsigned long long *out_key, uint32_t *out_slot) {
+    __shared__ unsigned long long s_key[32][GM_LIST];
+    __shared__ uint32_t s_slot[32][GM_LIST];
+    __shared__ uint32_t s_n[32], s_base[32];
+    const uint32_t tid = threadIdx.x, cl = tid & 31u, col = blockIdx.y * 32 + cl;
+    if (tid < 32) s_n[tid] = 0;
+    __syncthreads();
+    const unsigned long long t = col < ncol ? thr[col] : 0ull;
+    const uint32_t g0 = blockIdx.x * per_wg, g1 = min(n_groups, g0 + per_wg);
+    if (col < ncol)
+        for (uint32_t g = g0 + (tid >> 5); g < g1; g += 8) {
+            const unsigned long long k = gm_key(vals_t[(size_t)g * ncol + col]);
+            if (k <= t) {
+                const uint32_t p = atomicAdd(&s_n[cl], 1u);
+                if (p < GM_LIST) {
+                    s_key[cl][p] = k;
+                    s_slot[cl][p] = g;
+                } else {  // (a dense patch of hits: straight to the global list)
+                    const uint32_t gp = atomicAdd(&count[(size_t)col * 32], 1u);
+                    if (gp < GM_CAP) {
+                        out_key[(size_t)col * GM_CAP + gp] = k;
+                        out_slot[(size_t)col * GM_CAP + gp] = g;
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    if (tid < 32 && blockIdx.y * 32 + tid < ncol) {
+        const uint32_t m = s_n[tid] < GM_LIST ? s_n[tid] : GM_LIST;
+        s_base[tid] = m ? atomicAdd(&count[(size_t)(blockIdx.y * 32 + tid) * 32], m) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 32 * GM_LIST; i += 256) {
+        const uint32_t c = i / GM_LIST, e = i % GM_LIST, cc = blockIdx.y * 32 + c;
+        const uint32_t m = s_n[c] < GM_LIST ? s_n[c] : GM_LIST;
+        if (cc < ncol && e < m && s_base[c] + e < GM_CAP) {
+            out_key[(size_t)cc * GM_CAP + s_base[c] + e] = s_key[c][e];
+            out_slot[(size_t)cc * GM_CAP + s_base[c] + e] = s_slot[c][e];
+        }
+    }
+}
+// one workgroup per column; grp_trank / grp_tinv: the groups' tie order (second sort key) or nullptr (group id order = slot order)
+__global__ __launch_bounds__(256) void k_gm_topk(const uint32_t *count, const unsigned long long *in_key, const uint32_t *in_slot, const int64_t *gids,
+                                                 const uint32_t *grp_trank, const uint32_t *grp_tinv, uint32_t k, int64_t *out_groups, double *out_values,
+                                                 uint32_t *out_flag) {
+    extern __shared__ unsigned long long s_k[];  // [m2] keys, then [m2] u32 ties
+    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+    const uint32_t m = count[(size_t)col * 32];
+    if (m < k || m > GM_CAP) {
+        if (tid == 0) out_flag[col] = 0;
+        return;
+    }
+    uint32_t m2 = 1;
+    while (m2 < m) m2 <<= 1;
+    uint32_t *s_t = (uint32_t *)(s_k + m2);
+    for (uint32_t i = tid; i < m2; i += 256) {
+        if (i < m) {
+            const uint32_t slot = in_slot[(size_t)col * GM_CAP + i];
+            s_k[i] = in_key[(size_t)col * GM_CAP + i];
+            s_t[i] = grp_trank ? grp_trank[slot] : slot;
+        } else {
+            s_k[i] = ~0ull;
+            s_t[i] = 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= m2; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < m2 / 2; i += 256) {
+                const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
+                const bool up = (lo & sz) == 0;
+                const unsigned long long x = s_k[lo], y = s_k[hi];
+                const uint32_t tx = s_t[lo], ty = s_t[hi];
+                const bool gt = x > y || (x == y && tx > ty);
+                if (gt == up) {
+                    s_k[lo] = y;
+                    s_k[hi] = x;
+                    s_t[lo] = ty;
+                    s_t[hi] = tx;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < k; i += 256) {
+        const uint32_t slot = grp_tinv ? grp_tinv[s_t[i]] : s_t[i];
+        out_groups[(size_t)col * k + i] = gids[slot];
+        const unsigned long long key = s_k[i];
+        double v;
+        if (key >= ~0ull - 1) {
+            v = __builtin_nan("");
+        } else {
+            const unsigned long long b = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
+            v = __builtin_bit_cast(double, b);
+        }
+        out_values[(size_t)col * k + i] = v;
+    }
+    if (tid == 0) out_flag[col] = 1;
+}
+// d_work: >= pvs_gm_rank_work_bytes(ncol) of device scratch; out_*: device-accessible (pinned) [ncol][k] / [ncol]; stream-ordered
+size_t pvs_gm_rank_work_bytes(uint32_t ncol) { return (size_t)ncol * (8 + 128 + (size_t)GM_CAP * 12) + 256; }
+bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k) {
+    const uint64_t target = std::max<uint64_t>(4ull * k, 2048);
+    return n_groups >= 65536 && (uint64_t)n_groups * ncol >= (2u << 20) && 2 * target <= GM_CAP * 3 / 4 && target * 4 < n_groups;
+}
+hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
+                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s) {
+    uint8_t *w = (uint8_t *)d_work;
+    unsigned long long *thr = (unsigned long long *)w;
+    uint32_t *count = (uint32_t *)(w + (((size_t)ncol * 8 + 127) & ~(size_t)127));
+    unsigned long long *keys = (unsigned long long *)((uint8_t *)count + (size_t)ncol * 128);
+    uint32_t *slots = (uint32_t *)((uint8_t *)keys + (size_t)ncol * GM_CAP * 8);
+    const uint64_t target = std::max<uint64_t>(4ull * k, 2048);
+    const uint32_t j = (uint32_t)std::min<uint64_t>(GM_M - 1, (uint64_t)((double)GM_M * 2.0 * (double)target / (double)n_groups) + 4);
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)ncol * 128, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(256), 0, s, d_vals_t, n_groups, ncol, j, thr);
+    const uint32_t per_wg = 2048;
+    hipLaunchKernelGGL(k_gm_compact, dim3((n_groups + per_wg - 1) / per_wg, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, thr, per_wg, count, keys,
+                       slots);
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute((const void *)k_gm_topk, hipFuncAttributeMaxDynamicSharedMemorySize, GM_CAP * 12);
+        if (e != hipSuccess) return e;
+        configured.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k_gm_topk, dim3(ncol), dim3(256), (size_t)GM_CAP * 12, s, count, keys, slots, d_gids, d_grp_trank, d_grp_tinv, k, out_groups, out_values,
+                       out_flag);
     return hipGetLastError();
 }
 

@@ -152,7 +152,7 @@ struct pvs_index {
     uint64_t order_rows = 0;  // rows the tie ranks cover (0: none set)
     std::vector<int64_t> h_order_keys;  // host copy of the keys (the groups' tie order is built from it in ensure_groups)
     // groups in tie order (key of the group's first row DESC, group id ASC), built with the CSR when the keys cover every row
-    uint32_t *d_grp_tinv = nullptr;
+    uint32_t *d_grp_tinv = nullptr, *d_grp_trank = nullptr;  // (d_grp_trank: the inverse)
     std::vector<int64_t> h_grp_ids, h_grp_key;  // per group, in id order (host: the page-first per-item path sorts with them)
     std::vector<int64_t> h_groups;  // optional group ids per row (host copy)
     std::vector<int64_t> h_ids_cache;  // host copy of row ids (lazy; similar_to's id -> row lookup)
@@ -161,6 +161,12 @@ struct pvs_index {
     uint32_t n_groups = 0;
     uint32_t *d_grp_off = nullptr, *d_grp_rows = nullptr;
     int64_t *d_grp_ids = nullptr;
+    // fused per-item scoring (k_scan MODE 2 with the per-group fold): possible when every group is one run of consecutive rows
+    // (group ids non-decreasing in row order: the reference's loader streams ORDER BY item_data.id, a file's vectors adjacent)
+    bool groups_are_runs = false;
+    uint4 *d_tile_grp = nullptr;        // [ceil(n / 32)] tile records (ScanK.tile_grp)
+    uint32_t *d_straddlers = nullptr;   // groups that cross a 32-row tile boundary
+    uint32_t n_straddlers = 0;
     // rows whose distance is NULL for every query, per metric ([0] cosine: zero vectors and non-finite components, [1] L2: NaN
     // components), in tie order: the tail of a page that ends in NULL rows (pvs_sparse.hip: pvs_ensure_null_rows, built on first
     // need per index state).  null_weird[m]: rows whose NULL-ness depends on the query (|a|^2 under/overflow; inf components under

@@ -14,8 +14,14 @@ pvs_status ensure_groups(pvs_index *ix) {
     hipFree(ix->d_grp_rows);
     hipFree(ix->d_grp_ids);
     hipFree(ix->d_grp_tinv);
-    ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = nullptr;
+    hipFree(ix->d_grp_trank);
+    hipFree(ix->d_tile_grp);
+    hipFree(ix->d_straddlers);
+    ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = ix->d_grp_trank = ix->d_straddlers = nullptr;
     ix->d_grp_ids = nullptr;
+    ix->d_tile_grp = nullptr;
+    ix->groups_are_runs = false;
+    ix->n_straddlers = 0;
     ix->h_grp_ids.clear();
     ix->h_grp_key.clear();
     const uint64_t n = ix->n;
@@ -48,6 +54,34 @@ pvs_status ensure_groups(pvs_index *ix) {
     HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
     if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
+    // Are the groups runs of consecutive rows (the CSR order is the row order)?  Then the per-item scorer can fold a group in
+    // the epilogue of the tile that holds it (k_scan MODE 2 + ScanK.tile_grp): per 32-row tile a record {group of its first row,
+    // rows that end their group, rows whose group crosses a tile boundary}, and the list of those crossing groups.
+    {
+        bool runs = n < (1ull << 31);
+        for (uint64_t i = 0; i < n && runs; i++) runs = rows[i] == (uint32_t)i;
+        if (runs && n) {
+            const uint64_t n_tiles = (n + 31) / 32;
+            std::vector<uint32_t> rec(n_tiles * 4, 0), strad;
+            const uint32_t G = (uint32_t)gids.size();
+            for (uint32_t g = 0; g < G; g++) {
+                const uint32_t a = off[g], b = off[g + 1] - 1;  // first and last row
+                rec[(size_t)(b >> 5) * 4 + 1] |= 1u << (b & 31);
+                if ((a >> 5) != (b >> 5)) {
+                    strad.push_back(g);
+                    for (uint32_t r = a; r <= b; r++) rec[(size_t)(r >> 5) * 4 + 2] |= 1u << (r & 31);
+                }
+                // tiles whose first row belongs to this group
+                for (uint64_t t = (a + 31) >> 5; t * 32 <= b; t++) rec[t * 4] = g;
+            }
+            HIP_TRY(pvs_malloc_retry((void **)&ix->d_tile_grp, rec.size() * 4));
+            HIP_TRY(hipMemcpy(ix->d_tile_grp, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(pvs_malloc_retry((void **)&ix->d_straddlers, (strad.size() + 1) * 4));
+            if (!strad.empty()) HIP_TRY(hipMemcpy(ix->d_straddlers, strad.data(), strad.size() * 4, hipMemcpyHostToDevice));
+            ix->n_straddlers = (uint32_t)strad.size();
+            ix->groups_are_runs = true;
+        }
+    }
     if (ix->order_rows == n && n) {
         // second sort key of the per-item pages (pql/model.rs:547-553: ORDER BY order_rank, last_modified DESC): a group's key is
         // its first row's (the rows of a file share files.last_modified); groups in (key DESC, group id ASC) order feed the stable
@@ -60,6 +94,10 @@ pvs_status ensure_groups(pvs_index *ix) {
         std::stable_sort(tinv.begin(), tinv.end(), [&](uint32_t a, uint32_t b) { return gkey[a] > gkey[b]; });
         HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_tinv, (size_t)G * 4));
         HIP_TRY(hipMemcpy(ix->d_grp_tinv, tinv.data(), (size_t)G * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> trank(G);  // its inverse: the tie position of a group (the device-side page ranking sorts by it)
+        for (uint32_t i = 0; i < G; i++) trank[tinv[i]] = i;
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_trank, (size_t)G * 4));
+        HIP_TRY(hipMemcpy(ix->d_grp_trank, trank.data(), (size_t)G * 4, hipMemcpyHostToDevice));
         ix->h_grp_ids = gids;
         ix->h_grp_key = std::move(gkey);
     }
@@ -175,7 +213,7 @@ PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dt
 
 // Columns of group values -> each column's first k groups, through pages of the groups at or below a sampled threshold (see
 // aggregate_and_rank).  done[q] = 0: the caller ranks every group of that column instead.  Three host round trips for all columns.
-static pvs_status rank_groups_page_first(pvs_index *ix, SearchCtx &c, const double *d_vals, uint32_t G, uint32_t ncol, uint32_t k,
+static pvs_status rank_groups_page_first(pvs_index *ix, SearchCtx &c, const double *d_vals, const double *d_vals_t, uint32_t G, uint32_t ncol, uint32_t k,
                                          int64_t *out_groups, double *out_values, uint32_t *out_count, std::vector<uint8_t> &done) {
     done.assign(ncol, 0);
     const uint64_t target = std::max<uint64_t>(4ull * k, 2048);
@@ -183,7 +221,10 @@ static pvs_status rank_groups_page_first(pvs_index *ix, SearchCtx &c, const doub
     unsigned long long *d_keys = nullptr;
     auto body = [&]() -> pvs_status {
         HIP_TRY(pvs_scratch_alloc((void **)&d_keys, (size_t)G * ncol * 8));
-        HIP_TRY(pvs_group_page_keys(d_vals, G * ncol, d_keys, c.stream));  // (elementwise: the columns are contiguous)
+        if (d_vals)
+            HIP_TRY(pvs_group_page_keys(d_vals, G * ncol, d_keys, c.stream));  // (elementwise: the columns are contiguous)
+        else
+            HIP_TRY(pvs_group_page_keys_t(d_vals_t, G, ncol, d_keys, c.stream));  // group-major values (the fused scorer): transposed on the way
         const uint32_t M = 4096;
         std::vector<unsigned long long> sample((size_t)M * ncol), thr(ncol);
         PVS_TRY(pvs_rrf_sample_keys_cols(d_keys, G, ncol, M, sample.data(), c.stream));
@@ -233,12 +274,13 @@ static pvs_status rank_groups_page_first(pvs_index *ix, SearchCtx &c, const doub
     return st;
 }
 
+static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals, const double *d_vals_t, uint32_t ncol, uint32_t k, int64_t *d_og, double *d_ov,
+                              uint32_t *d_oc, int64_t *out_groups, double *out_values, uint32_t *out_count);
 // shared tail: d_m [n][nb] (fanout == 0: nb output columns; else one) -> ranked groups on the host
 static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg,
                                      const float *d_weights, const uint8_t *d_exclude, uint32_t k, int64_t *out_groups,
                                      double *out_values, uint32_t *out_count, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1) {
     const uint32_t G = ix->n_groups, ncol = fanout ? 1u : nb;
-    const bool no_page_rank = pvs_dbg(PVS_DBG_NO_PAGE_RANK) != 0;  // tuning: always sort every group
     double *d_vals = nullptr;
     int64_t *d_og = nullptr;
     double *d_ov = nullptr;
@@ -250,17 +292,58 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         HIP_TRY(pvs_scratch_alloc((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
                                            c.stream, fw, skip_when));
+        return rank_values(ix, c, d_vals, nullptr, ncol, k, d_og, d_ov, d_oc, out_groups, out_values, out_count);
+    };
+    pvs_status st = body();
+    for (void *p : {(void *)d_vals, (void *)d_og, (void *)d_ov, (void *)d_oc}) pvs_scratch_free_on(p, c.stream);
+    return st;
+}
+
+// Columns of group values, column-major d_vals [ncol][G] or group-major d_vals_t [G][ncol] (the fused scorer's layout; exactly
+// one of the two is given) -> each column's first k groups on the host.
+static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals, const double *d_vals_t, uint32_t ncol, uint32_t k, int64_t *d_og, double *d_ov,
+                              uint32_t *d_oc, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    const uint32_t G = ix->n_groups;
+    const bool no_page_rank = pvs_dbg(PVS_DBG_NO_PAGE_RANK) != 0;  // tuning: always sort every group
+    double *d_cm = nullptr;
+    void *d_work = nullptr;
+    auto body = [&]() -> pvs_status {
         // Page first: the k best of millions of groups do not need all of them sorted (a stable 64-bit radix sort of 1.3M groups
         // is 0.3 ms per query column, ten times the aggregation).  A threshold key from a sample admits a few thousand groups per
         // column; where at least k come back, the k best are among them: sorted on the host under the page order (value, second
         // key DESC, group id).  Columns where that fails (an unlucky sample, fewer than k groups with a value) are fully sorted.
         std::vector<uint8_t> paged(ncol, 0);
-        // (three host round trips, ~0.35 ms whatever the size: worth it from ~2M group values to sort — one column of 230k groups,
-        //  similar_to at the reference's scale, sorts in 0.1 ms)
-        if (G >= 65536 && (uint64_t)G * ncol >= (2u << 20) && k <= 4096 && !no_page_rank)
-            PVS_TRY(rank_groups_page_first(ix, c, d_vals, G, ncol, k, out_groups, out_values, out_count, paged));
+        if (d_vals_t && !no_page_rank && pvs_gm_rank_supported(G, ncol, k)) {
+            // group-major values (the fused scorer): thresholds, pages and the per-column sort all on the device, the pages land
+            // in the context's pinned block — one synchronisation, no copies (round 3's page step: three host round trips, 64
+            // staged copies and a host sort per column = 2 of the 3.5 ms of a 32-query per-item search)
+            const size_t off_g = 64, off_v = off_g + (size_t)ncol * k * 8, off_f = off_v + (size_t)ncol * k * 8, need = off_f + (size_t)ncol * 4;
+            PVS_TRY(ctx_pinned_io(c, need));
+            HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(ncol)));
+            const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+            HIP_TRY(pvs_gm_rank(d_vals_t, G, ncol, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
+                                (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            const uint32_t *fl = (const uint32_t *)(c.h_io + off_f);
+            for (uint32_t q = 0; q < ncol; q++)
+                if (fl[q]) {
+                    memcpy(out_groups + (size_t)q * k, c.h_io + off_g + (size_t)q * k * 8, (size_t)k * 8);
+                    memcpy(out_values + (size_t)q * k, c.h_io + off_v + (size_t)q * k * 8, (size_t)k * 8);
+                    out_count[q] = k;
+                    paged[q] = 1;
+                }
+        } else if (G >= 65536 && (uint64_t)G * ncol >= (2u << 20) && k <= 4096 && !no_page_rank) {
+            // (three host round trips, ~0.35 ms whatever the size: worth it from ~2M group values to sort — one column of 230k groups,
+            //  similar_to at the reference's scale, sorts in 0.1 ms)
+            PVS_TRY(rank_groups_page_first(ix, c, d_vals, d_vals_t, G, ncol, k, out_groups, out_values, out_count, paged));
+        }
         for (uint32_t q = 0; q < ncol; q++) {
             if (paged[q]) continue;
+            if (!d_vals) {  // a column is sorted whole: it wants its values contiguous
+                HIP_TRY(pvs_scratch_alloc((void **)&d_cm, (size_t)std::max<uint32_t>(G, 1) * ncol * 8));
+                HIP_TRY(pvs_launch_group_transpose(d_vals_t, G, ncol, d_cm, c.stream));
+                d_vals = d_cm;
+            }
             PVS_TRY(pvs_group_rank(d_vals + (size_t)q * G, ix->d_grp_ids, G, k, c.gwork, d_og, d_ov, d_oc, c.stream, ix->d_grp_tinv));
             HIP_TRY(hipMemcpyAsync(out_groups + (size_t)q * k, d_og, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(out_values + (size_t)q * k, d_ov, (size_t)k * 8, hipMemcpyDeviceToHost, c.stream));
@@ -270,7 +353,8 @@ static pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d
         return PVS_OK;
     };
     pvs_status st = body();
-    for (void *p : {(void *)d_vals, (void *)d_og, (void *)d_ov, (void *)d_oc}) pvs_scratch_free_on(p, c.stream);
+    pvs_scratch_free_on(d_cm, c.stream);
+    pvs_scratch_free_on(d_work, c.stream);
     return st;
 }
 
@@ -391,6 +475,64 @@ PVS_EXPORT pvs_status pvs_search_groups_filtered(pvs_index *ix, const void *quer
                               out_count);
 }
 
+// Can the fused per-item scorer serve this chunk?  int8 rows inside the closed form's range on a row pitch k_scan has an instance
+// for, groups that are runs of rows, per-row arrays the scalar loads of the fold can read in aligned 32-row pieces.
+static bool fused_groups_ok(const pvs_index *ix, uint32_t nb, const uint8_t *d_mask, const float *d_w) {
+    if (pvs_dbg(PVS_DBG_NO_FUSED_AGG) || !ix->groups_are_runs || !ix->d_tile_grp) return false;
+    if (ix->dtype != PVS_I8 || !pvs_scan_supported(PVS_I8, ix->stride / PVS_KSLAB_BYTES) || (uint64_t)ix->dim * 127 * 127 >= (1u << 24)) return false;
+    if (((uintptr_t)d_mask & 3u) || ((uintptr_t)d_w & 3u)) return false;
+    (void)nb;
+    return true;
+}
+// One corpus pass over the queries prepared in c: d_vals_t [n_groups][nb] = every group's aggregate.  *done = false: an L2 sum left
+// the closed form's range (the caller scores in order instead).  d_m: the [n][nb] matrix the rows of tile-crossing groups go through.
+static pvs_status fused_group_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, int agg, const float *d_w, const uint8_t *d_mask,
+                                    float *d_m, double *d_vals_t, bool *done) {
+    *done = false;
+    ScanArgs a;
+    a.dtype = PVS_I8;
+    a.metric = metric;
+    a.kslabs = ix->stride / PVS_KSLAB_BYTES;
+    a.qgroups = batch_pad / 32;
+    a.rows = ix->d_rows;
+    a.aux = ix->d_scan_l2;  // MODE 2 streams |a|^2
+    a.stride = ix->stride;
+    a.n_rows = ix->n;
+    a.qmat = c.d_qmat;
+    a.qinfo = c.d_qinfo;
+    a.thr = c.d_thr;
+    a.gmin = c.d_gmin;
+    a.groups_per_query = 0;
+    a.mode = 2;
+    a.tile_step = 1;
+    const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);
+    const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+    const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+    a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
+    a.dense_out = d_m;
+    a.dense_ld = nb;
+    a.batch = nb;
+    a.dense_flag = c.d_cand_cnt;
+    a.tile_grp = ix->d_tile_grp;
+    a.fold_weights = d_w;
+    a.fold_mask = d_mask;
+    a.fold_out = d_vals_t;
+    a.fold_ld = nb;
+    a.fold_agg = agg;
+    HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
+    span_begin(ix, c, 1, ix->n);
+    HIP_TRY(pvs_launch_scan(a, c.stream));
+    span_end(ix, c);
+    HIP_TRY(pvs_launch_group_aggregate_list(d_m, nb, nb, ix->d_grp_off, ix->d_grp_rows, ix->d_straddlers, ix->n_straddlers, d_w, d_mask, agg, d_vals_t, nb,
+                                            c.stream, d_mask ? 0u : 1u));
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    spans_collect(ix, c);
+    *done = flag == 0;
+    return PVS_OK;
+}
+
 pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
                               double *out_values, uint32_t *out_count) {
@@ -419,6 +561,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     void *d_q = nullptr;
     float *d_m = nullptr, *d_w = nullptr;
     uint8_t *d_mask = nullptr;
+    double *d_vt = nullptr;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
@@ -429,6 +572,12 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
             if (mask_space == PVS_HOST) {
                 HIP_TRY(pvs_scratch_alloc((void **)&d_mask, ix->n));
                 HIP_TRY(hipMemcpyAsync(d_mask, mask, ix->n, hipMemcpyHostToDevice, c->stream));
+                dm = d_mask;
+            } else if ((ix->n & 31u) || ((uintptr_t)mask & 3u)) {
+                // (the fused scorer reads the mask in aligned 32-byte pieces through the scalar cache: a caller's device buffer of
+                //  exactly n bytes is copied into a block with slack behind it)
+                HIP_TRY(pvs_scratch_alloc((void **)&d_mask, ix->n));
+                HIP_TRY(hipMemcpyAsync(d_mask, mask, ix->n, hipMemcpyDeviceToDevice, c->stream));
                 dm = d_mask;
             } else {
                 dm = mask;
@@ -443,17 +592,36 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
-            if (ix->n) {
-                PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
-                PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
+            if (ix->n) PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+            // One pass: the scorer folds every group that lies inside a 32-row tile in its epilogue (k_scan MODE 2 + ScanK.tile_grp)
+            // and writes [groups][queries] values; only the rows of groups that cross a tile boundary go through the matrix.
+            bool fused_done = false;
+            if (ix->n && fused_groups_ok(ix, nb, dm, d_w)) {
+                HIP_TRY(pvs_scratch_alloc((void **)&d_vt, (size_t)std::max<uint32_t>(ix->n_groups, 1) * nb * 8));
+                PVS_TRY(fused_group_chunk(ix, *c, nb, pad, metric, agg, d_w, dm, d_m, d_vt, &fused_done));
+                if (fused_done) {
+                    int64_t *d_og = nullptr;
+                    double *d_ov = nullptr;
+                    uint32_t *d_oc = nullptr;
+                    HIP_TRY(pvs_scratch_alloc((void **)&d_og, (size_t)k * 8));
+                    HIP_TRY(pvs_scratch_alloc((void **)&d_ov, (size_t)k * 8));
+                    HIP_TRY(pvs_scratch_alloc((void **)&d_oc, 4));
+                    pvs_status rs = rank_values(ix, *c, nullptr, d_vt, nb, k, d_og, d_ov, d_oc, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k, out_count + q0);
+                    for (void *p : {(void *)d_og, (void *)d_ov, (void *)d_oc}) pvs_scratch_free_on(p, c->stream);
+                    PVS_TRY(rs);
+                }
+                pvs_scratch_free_on(d_vt, c->stream);
+                d_vt = nullptr;
             }
+            if (fused_done) continue;
+            if (ix->n) PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
             PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, dm, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
                                        out_count + q0, FanoutWeights(), dm ? 0u : 1u));
         }
         return PVS_OK;
     };
     pvs_status st = body();
-    for (void *p : {d_q, (void *)d_m, (void *)d_w, (void *)d_mask}) pvs_scratch_free_on(p, c->stream);
+    for (void *p : {d_q, (void *)d_m, (void *)d_w, (void *)d_mask, (void *)d_vt}) pvs_scratch_free_on(p, c->stream);
     ix->searches++;
     ix->dense_queries += batch;
     ctx_done(ix, c);

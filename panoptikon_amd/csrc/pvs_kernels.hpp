@@ -66,6 +66,14 @@ struct ScanArgs {
     uint2 *flat = nullptr;         // mode 1, segment-overflow rerun: candidates appended to [batch_pad][flat_cap] lists (ScanK.flat)
     uint32_t *flat_cnt = nullptr;  // [batch_pad], zeroed by the caller
     uint32_t flat_cap = 0;
+    // mode 2 with the per-group fold (ScanK.tile_grp, pvs_scan_dispatch.hpp): groups inside a 32-row tile are aggregated in the
+    // scorer's epilogue into fold_out[group][fold_ld]; rows of groups that cross a tile boundary go to dense_out as usual
+    const uint4 *tile_grp = nullptr;
+    const float *fold_weights = nullptr;
+    const uint8_t *fold_mask = nullptr;
+    double *fold_out = nullptr;
+    uint32_t fold_ld = 0;
+    int fold_agg = 0;
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 // geometry of the filter passes (modes 0 / 1) of a shape — it depends on which kernel serves them (pvs_scan_is_wide)
@@ -222,10 +230,24 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
                                       int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1);
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s, const uint32_t *g_tinv = nullptr);
+// The groups of `list` (indices into the group CSR) only, from the dense matrix, into the group-major output out_t[group][ld_out]:
+// the finishing step of the fused per-item scorer (groups that cross a 32-row tile boundary)
+hipError_t pvs_launch_group_aggregate_list(const float *dist, uint32_t ld, uint32_t n_cols, const uint32_t *grp_off, const uint32_t *grp_rows,
+                                           const uint32_t *list, uint32_t n_list, const float *weights, const uint8_t *exclude, int agg, double *out_t,
+                                           uint32_t ld_out, hipStream_t s, uint32_t skip_when);
+// page-first ranking of group-major values on the device (pvs_groups.hip): out_flag[col] = 1 -> out_groups / out_values [col][k] hold the
+// column's first k groups; 0 -> rank that column by the full sort.  d_grp_trank / d_grp_tinv: the groups' tie order or nullptr.
+size_t pvs_gm_rank_work_bytes(uint32_t ncol);
+bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k);
+hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
+                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s);
+// group-major values [n_groups][ncol] -> column-major [ncol][n_groups] (what pvs_group_rank and the page keys index)
+hipError_t pvs_launch_group_transpose(const double *vals_t, uint32_t n_groups, uint32_t ncol, double *vals, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);
 // order-preserving u64 keys of one column of group values, in group order: value asc, NULL aggregates (~0 - 1) after every value,
 // absent groups (~0) last.  The value is recovered from its key (pvs_group_value_of_key).
 hipError_t pvs_group_page_keys(const double *d_vals, uint32_t n_groups, unsigned long long *d_keys, hipStream_t s);
+hipError_t pvs_group_page_keys_t(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, unsigned long long *d_keys, hipStream_t s);  // group-major in, column-major keys out
 inline double pvs_group_value_of_key(unsigned long long k) {
     if (k >= ~0ull - 1) return __builtin_nan("");
     const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;

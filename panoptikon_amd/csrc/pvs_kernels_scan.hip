@@ -69,6 +69,12 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.dense_flag = a.dense_flag;
     k.dense_ld = a.dense_ld;
     k.batch = a.batch;
+    k.tile_grp = a.mode == 2 ? a.tile_grp : nullptr;
+    k.fold_weights = a.fold_weights;
+    k.fold_mask = a.fold_mask;
+    k.fold_out = a.fold_out;
+    k.fold_ld = a.fold_ld;
+    k.fold_agg = a.fold_agg;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
         e = wide            ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.qgroups, a.metric, a.mode, s)

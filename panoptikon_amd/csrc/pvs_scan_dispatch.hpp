@@ -23,6 +23,19 @@ struct ScanK {
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
     uint32_t dense_ld, batch;
+    // MODE 2 with the per-group fold (per-item search: GROUP BY file_id + rank_aggregate, filters/exact.rs:67-134, in the scorer's
+    // epilogue instead of a second pass over an N x batch matrix).  Set when tile_grp != nullptr; needs the rows of every group
+    // to be one run of consecutive rows.  Per 32-row tile one record {group index of the tile's first row, bit i: row i is the
+    // LAST row of its group, bit i: row i's group crosses a tile boundary, unused}.  A group inside one tile is folded in row
+    // order by the lane that holds its query (SQLite's KBN sums, bit for bit) and its value written to fold_out[group][query];
+    // the rows of a group that crosses a tile boundary are written to dense_out as before (a few percent of the rows) and
+    // folded by k_group_aggregate_list afterwards.
+    const uint4 *tile_grp;
+    const float *fold_weights;  // optional [n_rows]: SUM(d*w)/SUM(w)
+    const uint8_t *fold_mask;   // optional [n_rows]: 0 = the row is not a candidate (takes part in nothing)
+    double *fold_out;           // [n_groups][fold_ld]
+    uint32_t fold_ld;
+    int fold_agg;               // PVS_AGG_MIN / MAX / AVG (ignored with weights)
 };
 
 hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

@@ -478,8 +478,181 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             }
         };
         bool prev_valid = false;  // MODE 2: the dummy tile "-1" writes nothing
+        // MODE 2 with the per-group fold (ScanK.tile_grp): the previous tile's 32 rows x 32 queries of this wave, folded per group.
+        // Lane (j, h) holds query j and 16 of the 32 rows; the halves exchange theirs (one cross-lane move per value), then the
+        // lanes of half 0 walk the 32 rows IN ROW ORDER — SQLite's SUM / AVG are order-dependent compensated sums — under
+        // wave-uniform control flow: the tile record (which rows end a group, which belong to a group that crosses the tile
+        // boundary) and the optional per-row weights / candidate mask arrive through the scalar cache (s_load: lgkmcnt, so the
+        // counted vmcnt waits of the LDS-DMA stream never see them).  The value of a group that ends here goes to
+        // fold_out[group][query]: 32 lanes, 256 contiguous bytes.
+        auto fold_groups = [&](Epi &e, auto &&pv) {
+            if constexpr (MODE == 2) {
+                typedef const __attribute__((address_space(4))) uint32_t *cptr32;
+                const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(prev_row_base >> 5));  // 32-row tile of this wave (uniform)
+                const uint64_t row0 = (uint64_t)tile_u * 32u;
+                if (row0 >= a.n_rows) return;
+                float dm[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (COS) {
+                        dm[r] = ref_cosine_finish((float)pv(0, r), e.xh[r], qi[0].bb);
+                    } else {
+                        const double ss = (double)e.xh[r] + (double)qi[0].bb - 2.0 * (double)pv(0, r);
+                        if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
+                        dm[r] = ref_l2_finish((float)ss);
+                    }
+                }
+#if defined(PVS_FOLD_ABL) && PVS_FOLD_ABL == 1  // (tuning builds: what does each part of the fold cost — tools/r4_fold_ablation.sh)
+                {
+                    float acc_ = 0.f;
+                    for (int r = 0; r < 16; r++) acc_ += dm[r];
+                    if (acc_ == 12345.678f) a.dense_out[0] = acc_;
+                    return;
+                }
+#endif
+                float D[32];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float other = __shfl_xor(dm[r], 32, 64);
+                    const int t = (r & 3) + 8 * (r >> 2);
+                    D[t] = h ? other : dm[r];       // rows of half 0
+                    D[t + 4] = h ? dm[r] : other;   // rows of half 1
+                }
+                cptr32 tg = (cptr32)(uintptr_t)(a.tile_grp + tile_u);
+                uint32_t g_run = tg[0];
+                const uint32_t m_last = tg[1], m_spill = tg[2];
+                uint32_t m_allow = 0xffffffffu;
+                if (a.fold_mask) {
+                    cptr32 mk = (cptr32)(uintptr_t)(a.fold_mask + row0);
+                    m_allow = 0;
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; w8++) {
+                        const uint32_t v = mk[w8];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) m_allow |= ((v >> (8 * b)) & 0xffu) ? (1u << (4 * w8 + b)) : 0u;
+                    }
+                }
+                const uint32_t n_here = a.n_rows - row0 >= 32u ? 32u : (uint32_t)(a.n_rows - row0);
+                const uint32_t m_rows = n_here == 32u ? 0xffffffffu : ((1u << n_here) - 1u);
+                const uint32_t m_use = m_allow & ~m_spill & m_rows;  // rows folded here
+                const uint32_t m_sp = m_spill & m_rows;              // rows that go through the matrix
+                const uint32_t m_end = m_last & m_rows;
+#if defined(PVS_FOLD_ABL) && PVS_FOLD_ABL == 2
+                {
+                    float acc_ = 0.f;
+                    for (int r = 0; r < 32; r++) acc_ += D[r];
+                    if (acc_ == 12345.678f + (float)(g_run + m_end + m_sp + m_use)) a.dense_out[0] = acc_;
+                    return;
+                }
+#endif
+                const int q = myq[0];
+                const bool mine = h == 0 && q < (int)a.batch;
+                // rows of tile-crossing groups: into the matrix (k_group_aggregate_list folds them)
+                if (m_sp != 0) {
+#pragma unroll
+                    for (int i = 0; i < 32; i++)
+                        if (((m_sp >> i) & 1u) && mine) a.dense_out[(row0 + (uint64_t)i) * a.dense_ld + (uint32_t)q] = D[i];
+                }
+                // The fold proper is STRAIGHT-LINE code per row (one wave per SIMD runs this: every taken branch and every dependent
+                // f64 operation is paid in full).  Per row: the candidate next state of the compensated sums (SQLite's
+                // Kahan-Babuska-Neumaier step, filters/exact.rs:67-80 -> SUM / AVG) is computed unconditionally and SELECTED into the
+                // state when the row takes part (a candidate, not spilled, distance not NULL) — the state of a skipped row is
+                // untouched bit for bit; only the serial chains s -> s' and c -> c' link consecutive rows, the corrections are
+                // independent work the scheduler overlaps.  The one uniform branch per row is "a group ends here".
+                auto emit = [&](double v, bool any_joined, bool any_cnt) {
+                    if (!any_joined)
+                        v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);
+                    else if (!any_cnt)
+                        v = __builtin_nan("");
+                    if (mine) a.fold_out[(size_t)g_run * a.fold_ld + (uint32_t)q] = v;
+                    g_run++;
+                };
+                auto kbn_next = [](double s, double c, double r, double &s2, double &c2) {
+                    const double t = s + r;
+                    const double x = (s - t) + r, y = (r - t) + s;
+                    c2 = c + (fabs(s) > fabs(r) ? x : y);
+                    s2 = t;
+                };
+                if (a.fold_weights) {
+                    cptr32 wp = (cptr32)(uintptr_t)(a.fold_weights + row0);
+                    uint32_t wb[32];
+#pragma unroll
+                    for (int i = 0; i < 32; i++) wb[i] = wp[i];  // (one batch of scalar loads, not one round trip per row)
+                    double s_s = 0.0, s_c = 0.0, w_s = 0.0, w_c = 0.0;
+                    uint32_t cnt = 0, joined = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;  // uniform
+                        const double w = (double)__builtin_bit_cast(float, wb[i]);
+                        double n_s, n_c;
+                        kbn_next(w_s, w_c, w, n_s, n_c);   // SUM(w) runs over every joined row, NULL distance or not
+                        w_s = use ? n_s : w_s;
+                        w_c = use ? n_c : w_c;
+                        joined += use ? 1u : 0u;
+                        const float df = D[i];
+                        const bool val = use && df == df;
+                        kbn_next(s_s, s_c, (double)df * w, n_s, n_c);
+                        s_s = val ? n_s : s_s;
+                        s_c = val ? n_c : s_c;
+                        cnt += val ? 1u : 0u;
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u)) emit((s_s + s_c) / (w_s + w_c), joined != 0, cnt != 0);
+                            else g_run++;
+                            s_s = s_c = w_s = w_c = 0.0;
+                            cnt = joined = 0;
+                        }
+                    }
+                } else if (a.fold_agg == PVS_AGG_AVG) {
+                    double s_s = 0.0, s_c = 0.0;
+                    uint32_t cnt = 0, joined = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;
+                        joined += use ? 1u : 0u;
+                        const float df = D[i];
+                        const bool val = use && df == df;
+                        double n_s, n_c;
+                        kbn_next(s_s, s_c, (double)df, n_s, n_c);
+                        s_s = val ? n_s : s_s;
+                        s_c = val ? n_c : s_c;
+                        cnt += val ? 1u : 0u;
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u)) emit((s_s + s_c) / (double)cnt, joined != 0, cnt != 0);
+                            else g_run++;
+                            s_s = s_c = 0.0;
+                            cnt = joined = 0;
+                        }
+                    }
+                } else {
+                    const bool want_min = a.fold_agg == PVS_AGG_MIN;
+                    double ext = want_min ? __builtin_inf() : -__builtin_inf();
+                    uint32_t cnt = 0, joined = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;
+                        joined += use ? 1u : 0u;
+                        const float df = D[i];
+                        const bool val = use && df == df;
+                        const double d = (double)df;
+                        const double nx = want_min ? fmin(ext, d) : fmax(ext, d);
+                        ext = val ? nx : ext;
+                        cnt += val ? 1u : 0u;
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u)) emit(ext, joined != 0, cnt != 0);
+                            else g_run++;
+                            ext = want_min ? __builtin_inf() : -__builtin_inf();
+                            cnt = joined = 0;
+                        }
+                    }
+                }
+            }
+        };
         auto epi_rest = [&](Epi &e, auto &&pv) {
             if constexpr (MODE == 2) {
+                if (a.tile_grp) {
+                    if (prev_valid) fold_groups(e, pv);
+                    return;
+                }
                 // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
                 // closed form of the exact integer sums, valid while they stay below 2^24
                 // (oracle: orc_i8_cosine_from_sums / orc_i8_l2_from_sums).  xh = |a|^2 here.
