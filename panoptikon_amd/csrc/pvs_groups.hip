@@ -289,32 +289,73 @@ hipError_t pvs_group_page_keys(const double *d_vals, uint32_t n_groups, unsigned
 //   k_gm_topk        per column: the few thousand admitted entries sorted by (key, tie order) in LDS, the first k written out
 // A column whose page came out short (fewer than k admitted: an unlucky sample, NULL-heavy columns) or too long (> GM_CAP:
 // massive ties at the threshold) is flagged and ranked by the full sort instead.
-constexpr uint32_t GM_M = 4096, GM_CAP = 8192, GM_LIST = 48;
+constexpr uint32_t GM_M = 8192, GM_CAP = 8192, GM_LIST = 48, GM_SORT_THREADS = 1024;
+// first page: ~2 x target groups per column (the threshold is the j-th of GM_M samples: sigma ~ 1/sqrt(j) of that)
+static inline uint64_t gm_target(uint32_t k) { return std::max<uint64_t>(8ull * k, 1024); }
 __device__ static inline unsigned long long gm_key(double v) {
     unsigned long long k = f64_sort_key(v);
     if (k == ~0ull) k = ~0ull - 1;                                               // NULL aggregates: after every value ...
     if (__builtin_bit_cast(unsigned long long, v) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
     return k;
 }
-__global__ __launch_bounds__(256) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, uint32_t ncol, uint32_t j, unsigned long long *thr) {
-    __shared__ unsigned long long s[GM_M];
-    const uint32_t col = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t i = tid; i < GM_M; i += 256) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * ncol + col]);
-    __syncthreads();
-    for (uint32_t sz = 2; sz <= GM_M; sz <<= 1)
-        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            for (uint32_t i = tid; i < GM_M / 2; i += 256) {
-                const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
-                const bool up = (lo & sz) == 0;
-                const unsigned long long x = s[lo], y = s[hi];
-                if ((x > y) == up) {
-                    s[lo] = y;
-                    s[hi] = x;
-                }
-            }
-            __syncthreads();
+// The kth smallest (1-based) of n 64-bit keys in LDS: eight 8-bit digits from the top, one LDS histogram per digit; the bin that
+// holds the rank is found by the first wave (4 bins per lane, a shuffle scan).  Workgroup-wide call; hist: 256 words, misc: 4 words.
+__device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long long *keys, uint32_t n, uint32_t kth, uint32_t *hist, uint32_t *misc) {
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    unsigned long long prefix = 0, mask = 0;
+    uint32_t kk = kth;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (uint32_t i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += nt) {
+            const unsigned long long k = keys[i];
+            if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
         }
-    if (tid == 0) thr[col] = s[j] >= ~0ull - 1 ? 0ull : s[j];  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            uint32_t v = h0 + h1 + h2 + h3;
+            const uint32_t own = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)v, off, 64);
+                if ((int)tid >= off) v += up;
+            }
+            const uint32_t before = v - own;
+            if (before < kk && v >= kk) {  // exactly one lane
+                uint32_t r = kk - before, bin = 4 * tid;
+                if (r > h0) {
+                    r -= h0;
+                    bin++;
+                    if (r > h1) {
+                        r -= h1;
+                        bin++;
+                        if (r > h2) {
+                            r -= h2;
+                            bin++;
+                        }
+                    }
+                }
+                misc[0] = bin;
+                misc[1] = r;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)misc[0] << shift;
+        mask |= 0xffull << shift;
+        kk = misc[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, uint32_t ncol, uint32_t j, unsigned long long *thr) {
+    __shared__ unsigned long long s[GM_M];
+    __shared__ uint32_t hist[256], misc[4];
+    const uint32_t col = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < GM_M; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * ncol + col]);
+    __syncthreads();
+    const unsigned long long t = wg_radix_kth_u64(s, GM_M, j + 1, hist, misc);  // the sample's j-th smallest (0-based): no sort
+    if (tid == 0) thr[col] = t >= ~0ull - 1 ? 0ull : t;  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
 }
 // grid (row blocks, ceil(ncol / 32)); a workgroup walks `per_wg` consecutive groups, lane = column of its 32-column chunk
 __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32_t n_groups, uint32_t ncol, const unsigned long long *thr, uint32_t per_wg,
@@ -328,9 +369,15 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
     const unsigned long long t = col < ncol ? thr[col] : 0ull;
     const uint32_t g0 = blockIdx.x * per_wg, g1 = min(n_groups, g0 + per_wg);
     if (col < ncol)
-        for (uint32_t g = g0 + (tid >> 5); g < g1; g += 8) {
-            const unsigned long long k = gm_key(vals_t[(size_t)g * ncol + col]);
-            if (k <= t) {
+        for (uint32_t gb = g0 + (tid >> 5); gb < g1; gb += 32) {
+            double v4[4];  // four independent loads in flight per lane (one per iteration left the pass latency-bound: 1.9 TB/s)
+#pragma unroll
+            for (int u = 0; u < 4; u++) v4[u] = gb + 8 * u < g1 ? vals_t[(size_t)(gb + 8 * u) * ncol + col] : __builtin_bit_cast(double, PVS_GROUP_ABSENT);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+            const uint32_t g = gb + 8 * u;
+            const unsigned long long k = gm_key(v4[u]);
+            if (k <= t && g < g1) {
                 const uint32_t p = atomicAdd(&s_n[cl], 1u);
                 if (p < GM_LIST) {
                     s_key[cl][p] = k;
@@ -342,6 +389,7 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
                         out_slot[(size_t)col * GM_CAP + gp] = g;
                     }
                 }
+            }
             }
         }
     __syncthreads();
@@ -359,52 +407,73 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
         }
     }
 }
-// one workgroup per column; grp_trank / grp_tinv: the groups' tie order (second sort key) or nullptr (group id order = slot order)
-__global__ __launch_bounds__(256) void k_gm_topk(const uint32_t *count, const unsigned long long *in_key, const uint32_t *in_slot, const int64_t *gids,
+// one workgroup per column; grp_trank / grp_tinv: the groups' tie order (second sort key) or nullptr (group id order = slot order).
+// The k-th smallest key of the column's few thousand admitted entries by radix select; the entries below it and its ties — usually
+// k of them and a handful — are sorted by (key, tie order) in LDS; the first k are the page.
+constexpr uint32_t GM_SORT = 2048;
+__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *count, const unsigned long long *in_key, const uint32_t *in_slot, const int64_t *gids,
                                                  const uint32_t *grp_trank, const uint32_t *grp_tinv, uint32_t k, int64_t *out_groups, double *out_values,
                                                  uint32_t *out_flag) {
-    extern __shared__ unsigned long long s_k[];  // [m2] keys, then [m2] u32 ties
+    extern __shared__ unsigned long long s_k[];  // [GM_CAP] keys | [GM_SORT] selected keys | [GM_CAP] u32 ties | [GM_SORT] u32 selected ties
+    __shared__ uint32_t hist[256], misc[4], s_n;
+    unsigned long long *s_sk = s_k + GM_CAP;
+    uint32_t *s_t = (uint32_t *)(s_sk + GM_SORT), *s_st = s_t + GM_CAP;
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t m = count[(size_t)col * 32];
     if (m < k || m > GM_CAP) {
         if (tid == 0) out_flag[col] = 0;
         return;
     }
-    uint32_t m2 = 1;
-    while (m2 < m) m2 <<= 1;
-    uint32_t *s_t = (uint32_t *)(s_k + m2);
-    for (uint32_t i = tid; i < m2; i += 256) {
-        if (i < m) {
-            const uint32_t slot = in_slot[(size_t)col * GM_CAP + i];
-            s_k[i] = in_key[(size_t)col * GM_CAP + i];
-            s_t[i] = grp_trank ? grp_trank[slot] : slot;
-        } else {
-            s_k[i] = ~0ull;
-            s_t[i] = 0xffffffffu;
+    for (uint32_t i = tid; i < m; i += GM_SORT_THREADS) {
+        const uint32_t slot = in_slot[(size_t)col * GM_CAP + i];
+        s_k[i] = in_key[(size_t)col * GM_CAP + i];
+        s_t[i] = grp_trank ? grp_trank[slot] : slot;
+    }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const unsigned long long kth = wg_radix_kth_u64(s_k, m, k, hist, misc);
+    for (uint32_t i = tid; i < m; i += GM_SORT_THREADS)
+        if (s_k[i] <= kth) {
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            if (p < GM_SORT) {
+                s_sk[p] = s_k[i];
+                s_st[p] = s_t[i];
+            }
         }
+    __syncthreads();
+    const uint32_t ms = s_n;
+    if (ms > GM_SORT) {  // massive ties at the k-th value: the full sort orders them
+        if (tid == 0) out_flag[col] = 0;
+        return;
+    }
+    uint32_t m2 = 1;
+    while (m2 < ms) m2 <<= 1;
+    for (uint32_t i = ms + tid; i < m2; i += GM_SORT_THREADS) {
+        s_sk[i] = ~0ull;
+        s_st[i] = 0xffffffffu;
     }
     __syncthreads();
     for (uint32_t sz = 2; sz <= m2; sz <<= 1)
         for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            for (uint32_t i = tid; i < m2 / 2; i += 256) {
+            for (uint32_t i = tid; i < m2 / 2; i += GM_SORT_THREADS) {
                 const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
                 const bool up = (lo & sz) == 0;
-                const unsigned long long x = s_k[lo], y = s_k[hi];
-                const uint32_t tx = s_t[lo], ty = s_t[hi];
+                const unsigned long long x = s_sk[lo], y = s_sk[hi];
+                const uint32_t tx = s_st[lo], ty = s_st[hi];
                 const bool gt = x > y || (x == y && tx > ty);
                 if (gt == up) {
-                    s_k[lo] = y;
-                    s_k[hi] = x;
-                    s_t[lo] = ty;
-                    s_t[hi] = tx;
+                    s_sk[lo] = y;
+                    s_sk[hi] = x;
+                    s_st[lo] = ty;
+                    s_st[hi] = tx;
                 }
             }
             __syncthreads();
         }
-    for (uint32_t i = tid; i < k; i += 256) {
-        const uint32_t slot = grp_tinv ? grp_tinv[s_t[i]] : s_t[i];
+    for (uint32_t i = tid; i < k; i += GM_SORT_THREADS) {
+        const uint32_t slot = grp_tinv ? grp_tinv[s_st[i]] : s_st[i];
         out_groups[(size_t)col * k + i] = gids[slot];
-        const unsigned long long key = s_k[i];
+        const unsigned long long key = s_sk[i];
         double v;
         if (key >= ~0ull - 1) {
             v = __builtin_nan("");
@@ -419,8 +488,8 @@ __global__ __launch_bounds__(256) void k_gm_topk(const uint32_t *count, const un
 // d_work: >= pvs_gm_rank_work_bytes(ncol) of device scratch; out_*: device-accessible (pinned) [ncol][k] / [ncol]; stream-ordered
 size_t pvs_gm_rank_work_bytes(uint32_t ncol) { return (size_t)ncol * (8 + 128 + (size_t)GM_CAP * 12) + 256; }
 bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k) {
-    const uint64_t target = std::max<uint64_t>(4ull * k, 2048);
-    return n_groups >= 65536 && (uint64_t)n_groups * ncol >= (2u << 20) && 2 * target <= GM_CAP * 3 / 4 && target * 4 < n_groups;
+    const uint64_t target = gm_target(k);
+    return n_groups >= 65536 && (uint64_t)n_groups * ncol >= (2u << 20) && 2 * target <= GM_CAP / 2 && target * 8 < n_groups;
 }
 hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
                        const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s) {
@@ -429,21 +498,21 @@ hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol,
     uint32_t *count = (uint32_t *)(w + (((size_t)ncol * 8 + 127) & ~(size_t)127));
     unsigned long long *keys = (unsigned long long *)((uint8_t *)count + (size_t)ncol * 128);
     uint32_t *slots = (uint32_t *)((uint8_t *)keys + (size_t)ncol * GM_CAP * 8);
-    const uint64_t target = std::max<uint64_t>(4ull * k, 2048);
+    const uint64_t target = gm_target(k);
     const uint32_t j = (uint32_t)std::min<uint64_t>(GM_M - 1, (uint64_t)((double)GM_M * 2.0 * (double)target / (double)n_groups) + 4);
     hipError_t e = hipMemsetAsync(count, 0, (size_t)ncol * 128, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(256), 0, s, d_vals_t, n_groups, ncol, j, thr);
-    const uint32_t per_wg = 2048;
+    hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(GM_SORT_THREADS), 0, s, d_vals_t, n_groups, ncol, j, thr);
+    const uint32_t per_wg = 1024;
     hipLaunchKernelGGL(k_gm_compact, dim3((n_groups + per_wg - 1) / per_wg, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, thr, per_wg, count, keys,
                        slots);
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute((const void *)k_gm_topk, hipFuncAttributeMaxDynamicSharedMemorySize, GM_CAP * 12);
+        e = hipFuncSetAttribute((const void *)k_gm_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (GM_CAP + GM_SORT) * 12);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_gm_topk, dim3(ncol), dim3(256), (size_t)GM_CAP * 12, s, count, keys, slots, d_gids, d_grp_trank, d_grp_tinv, k, out_groups, out_values,
+    hipLaunchKernelGGL(k_gm_topk, dim3(ncol), dim3(GM_SORT_THREADS), (size_t)(GM_CAP + GM_SORT) * 12, s, count, keys, slots, d_gids, d_grp_trank, d_grp_tinv, k, out_groups, out_values,
                        out_flag);
     return hipGetLastError();
 }

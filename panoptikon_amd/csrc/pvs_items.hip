@@ -141,7 +141,7 @@ pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_
         a.tile_step = 1;
         const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);  // (MODE 2 always runs on k_scan)
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
-        const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+        const uint32_t per_cu = (a.kslabs > 4 || (a.qgroups == 1 && a.kslabs == 4)) ? 1 : 2;  // (MODE 2: two workgroups per CU at 32 queries up to 768-B rows, scan_fold2)
         a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
         a.dense_out = d_out;
         a.dense_ld = nb;
@@ -484,11 +484,11 @@ static bool fused_groups_ok(const pvs_index *ix, uint32_t nb, const uint8_t *d_m
     (void)nb;
     return true;
 }
-// One corpus pass over the queries prepared in c: d_vals_t [n_groups][nb] = every group's aggregate.  *done = false: an L2 sum left
-// the closed form's range (the caller scores in order instead).  d_m: the [n][nb] matrix the rows of tile-crossing groups go through.
+// One corpus pass over the queries prepared in c, enqueued: d_vals_t [n_groups][nb] = every group's aggregate.  An L2 sum that left
+// the closed form's range raises word 8 of c.h_io (the caller scores in order instead).  d_m: the [n][nb] matrix the rows of
+// tile-crossing groups go through.
 static pvs_status fused_group_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, int agg, const float *d_w, const uint8_t *d_mask,
-                                    float *d_m, double *d_vals_t, bool *done) {
-    *done = false;
+                                    float *d_m, double *d_vals_t) {
     ScanArgs a;
     a.dtype = PVS_I8;
     a.metric = metric;
@@ -503,33 +503,31 @@ static pvs_status fused_group_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, ui
     a.thr = c.d_thr;
     a.gmin = c.d_gmin;
     a.groups_per_query = 0;
-    a.mode = 2;
+    a.mode = 3;
     a.tile_step = 1;
     const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);
     const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
-    const uint32_t per_cu = (a.qgroups == 1 || a.kslabs > 4) ? 1 : 2;
+    const uint32_t per_cu = a.kslabs > 3 ? 1 : 2;  // (MODE 3: two workgroups per CU up to 768-B rows, also at 32 queries: scan_fold2)
     a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * per_cu);
     a.dense_out = d_m;
     a.dense_ld = nb;
     a.batch = nb;
-    a.dense_flag = c.d_cand_cnt;
+    // the out-of-range flag lives in the context's pinned block (word 8): the caller reads it after its own synchronisation, no
+    // copy and no extra round trip (the kernel touches it only when an L2 sum leaves the closed form's range)
+    uint32_t *flag = (uint32_t *)(c.h_io + 32);
+    *(volatile uint32_t *)flag = 0;
+    a.dense_flag = flag;
     a.tile_grp = ix->d_tile_grp;
     a.fold_weights = d_w;
     a.fold_mask = d_mask;
     a.fold_out = d_vals_t;
     a.fold_ld = nb;
     a.fold_agg = agg;
-    HIP_TRY(hipMemsetAsync(c.d_cand_cnt, 0, 4, c.stream));
     span_begin(ix, c, 1, ix->n);
     HIP_TRY(pvs_launch_scan(a, c.stream));
     span_end(ix, c);
     HIP_TRY(pvs_launch_group_aggregate_list(d_m, nb, nb, ix->d_grp_off, ix->d_grp_rows, ix->d_straddlers, ix->n_straddlers, d_w, d_mask, agg, d_vals_t, nb,
                                             c.stream, d_mask ? 0u : 1u));
-    uint32_t flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, c.d_cand_cnt, 4, hipMemcpyDeviceToHost, c.stream));
-    HIP_TRY(hipStreamSynchronize(c.stream));
-    spans_collect(ix, c);
-    *done = flag == 0;
     return PVS_OK;
 }
 
@@ -565,8 +563,22 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(pvs_scratch_alloc(&d_q, qbytes * batch));
-        HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+        // the context's pinned block: [0, 64) flag words of the kernels, then the pages of the device-side ranking (rank_values),
+        // then the queries — read by the query-prep kernel straight from host memory (no staged copy).  Sized ONCE here: kernels
+        // in flight hold pointers into it.
+        const size_t io_pages = 64 + (size_t)std::min<uint32_t>(batch, PVS_MAX_BATCH) * ((size_t)k * 16 + 4);
+        const size_t io_q = pvs_round_up(io_pages, 256);
+        const void *q_dev = nullptr;
+        if (qbytes * batch <= ((size_t)4 << 20)) {
+            PVS_TRY(ctx_pinned_io(*c, io_q + qbytes * batch));
+            memcpy(c->h_io + io_q, queries, qbytes * batch);
+            q_dev = c->h_io + io_q;
+        } else {
+            PVS_TRY(ctx_pinned_io(*c, io_pages));
+            HIP_TRY(pvs_scratch_alloc(&d_q, qbytes * batch));
+            HIP_TRY(hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream));
+            q_dev = d_q;
+        }
         const uint8_t *dm = nullptr;  // candidate mask on the device
         if (mask && ix->n) {
             if (mask_space == PVS_HOST) {
@@ -592,14 +604,14 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         for (uint32_t q0 = 0; q0 < batch; q0 += cq) {
             const uint32_t nb = std::min(cq, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
-            if (ix->n) PVS_TRY(prep_chunk(ix, *c, d_q, qdtype, q0, nb, pad, metric));
+            if (ix->n) PVS_TRY(prep_chunk(ix, *c, q_dev, qdtype, q0, nb, pad, metric));
             // One pass: the scorer folds every group that lies inside a 32-row tile in its epilogue (k_scan MODE 2 + ScanK.tile_grp)
             // and writes [groups][queries] values; only the rows of groups that cross a tile boundary go through the matrix.
             bool fused_done = false;
             if (ix->n && fused_groups_ok(ix, nb, dm, d_w)) {
                 HIP_TRY(pvs_scratch_alloc((void **)&d_vt, (size_t)std::max<uint32_t>(ix->n_groups, 1) * nb * 8));
-                PVS_TRY(fused_group_chunk(ix, *c, nb, pad, metric, agg, d_w, dm, d_m, d_vt, &fused_done));
-                if (fused_done) {
+                PVS_TRY(fused_group_chunk(ix, *c, nb, pad, metric, agg, d_w, dm, d_m, d_vt));
+                {
                     int64_t *d_og = nullptr;
                     double *d_ov = nullptr;
                     uint32_t *d_oc = nullptr;
@@ -609,6 +621,9 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
                     pvs_status rs = rank_values(ix, *c, nullptr, d_vt, nb, k, d_og, d_ov, d_oc, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k, out_count + q0);
                     for (void *p : {(void *)d_og, (void *)d_ov, (void *)d_oc}) pvs_scratch_free_on(p, c->stream);
                     PVS_TRY(rs);
+                    // (rank_values waited for the stream: the scorer's out-of-range flag — a word of the pinned block — is final)
+                    fused_done = *(volatile uint32_t *)(c->h_io + 32) == 0;
+                    spans_collect(ix, *c);
                 }
                 pvs_scratch_free_on(d_vt, c->stream);
                 d_vt = nullptr;

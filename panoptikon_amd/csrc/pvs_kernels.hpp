@@ -49,7 +49,7 @@ struct ScanArgs {
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;
     const QInfo *qinfo;
-    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8)
+    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8), 3 = dense exact folded per group
     float *dense_out = nullptr;       // mode 2: [n_rows][dense_ld]
     uint32_t *dense_flag = nullptr;   // mode 2
     uint32_t dense_ld = 0, batch = 0;
@@ -66,7 +66,7 @@ struct ScanArgs {
     uint2 *flat = nullptr;         // mode 1, segment-overflow rerun: candidates appended to [batch_pad][flat_cap] lists (ScanK.flat)
     uint32_t *flat_cnt = nullptr;  // [batch_pad], zeroed by the caller
     uint32_t flat_cap = 0;
-    // mode 2 with the per-group fold (ScanK.tile_grp, pvs_scan_dispatch.hpp): groups inside a 32-row tile are aggregated in the
+    // mode 3: the per-group fold (ScanK.tile_grp, pvs_scan_dispatch.hpp): groups inside a 32-row tile are aggregated in the
     // scorer's epilogue into fold_out[group][fold_ld]; rows of groups that cross a tile boundary go to dense_out as usual
     const uint4 *tile_grp = nullptr;
     const float *fold_weights = nullptr;

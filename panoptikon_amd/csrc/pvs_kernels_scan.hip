@@ -69,7 +69,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.dense_flag = a.dense_flag;
     k.dense_ld = a.dense_ld;
     k.batch = a.batch;
-    k.tile_grp = a.mode == 2 ? a.tile_grp : nullptr;
+    k.tile_grp = a.tile_grp;
     k.fold_weights = a.fold_weights;
     k.fold_mask = a.fold_mask;
     k.fold_out = a.fold_out;

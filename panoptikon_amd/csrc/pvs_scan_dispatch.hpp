@@ -23,8 +23,8 @@ struct ScanK {
     float *dense_out;        // MODE 2: exact distances, [n_rows][dense_ld] (query-minor)
     uint32_t *dense_flag;    // MODE 2: set when an int8 L2 sum left the exact range (host reruns that batch in order)
     uint32_t dense_ld, batch;
-    // MODE 2 with the per-group fold (per-item search: GROUP BY file_id + rank_aggregate, filters/exact.rs:67-134, in the scorer's
-    // epilogue instead of a second pass over an N x batch matrix).  Set when tile_grp != nullptr; needs the rows of every group
+    // MODE 3 = MODE 2 with the per-group fold (per-item search: GROUP BY file_id + rank_aggregate, filters/exact.rs:67-134, in the scorer's
+    // epilogue instead of a second pass over an N x batch matrix).  Needs the rows of every group
     // to be one run of consecutive rows.  Per 32-row tile one record {group index of the tile's first row, bit i: row i is the
     // LAST row of its group, bit i: row i's group crosses a tile boundary, unused}.  A group inside one tile is folded in row
     // order by the lane that holds its query (SQLite's KBN sums, bit for bit) and its value written to fold_out[group][query];

@@ -113,7 +113,12 @@ constexpr int steps_per_slab() { return DT == PVS_F32 ? 4 : 8; }
 // Pipeline unit = "chunk" of SPB consecutive k-slabs of one workgroup tile: one counted
 // vmcnt wait + one s_barrier per chunk.  For the headline shape (768-B rows, 128 queries) a
 // chunk is the whole 24 KiB tile: 24 MFMAs run back to back between barriers.
-template <int QG, int KSLABS>
+// MODE 2 at 32 queries (QG == 1: four 32-row sub-tiles per workgroup) runs with a TWO-chunk ring instead of four: 67 KiB of LDS, so
+// two workgroups share a CU and one wave's epilogue — the closed-form distances in f64 and, for the per-item search, the sequential
+// per-group fold: thousands of cycles of dependent VALU work per tile — runs while the other workgroup's waves issue MFMAs and
+// wait for their DMA.  (One wave per SIMD paid that epilogue in full: 0.94 ms for 4M x 768 x 32 AVG against 0.46 without it.)
+constexpr bool scan_fold2(int QG, int KSLABS, int MODE) { return (MODE == 2 || MODE == 3) && QG == 1 && KSLABS <= 3; }
+template <int QG, int KSLABS, int MODE = 0>
 struct Geo {
     static constexpr int WAVES = 4;
     static constexpr int RT = WAVES / QG;        // row sub-tiles per workgroup
@@ -124,7 +129,7 @@ struct Geo {
     static constexpr int CPT = KSLABS / SPB;                                       // chunks per tile
     // chunks in the ring (measured at 128 queries x 768 B: 2-chunk rings with 2 or 3 workgroups per CU 1.295 / 1.398 ms against 1.28;
     // one k-slab per chunk with 6 / 8 / 9 chunks 1.35)
-    static constexpr int NC = RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8));
+    static constexpr int NC = scan_fold2(QG, KSLABS, MODE) ? 2 : RT > 1 ? 4 : (SPB == 3 ? 3 : (SPB == 2 ? 4 : 8));
     static constexpr int NS = NC * SPB;                                            // slabs in the ring
     static constexpr int PC = NC - 1;                                              // chunks in flight
     static constexpr int NCN = 2 + (PC + CPT - 1) / CPT;  // row-scalar ring slots, one per TILE (every chunk of a tile re-lands the
@@ -136,11 +141,14 @@ struct Geo {
     static_assert((PC - 1) * VM_PER_CHUNK <= 63, "vmcnt is a 6-bit counter");
 };
 
-constexpr int scan_waves_per_simd(int QG, int KSLABS) { return (QG == 1 || KSLABS > 4) ? 1 : 2; }
+// (MODE 3 — the per-group fold — holds 32 distances and the f64 sum state on top of the query fragments: one wave per SIMD beyond 768-B rows)
+constexpr int scan_waves_per_simd(int QG, int KSLABS, int MODE) {
+    return scan_fold2(QG, KSLABS, MODE) ? 2 : (QG == 1 || KSLABS > 4 || (MODE == 3 && KSLABS > 3)) ? 1 : 2;
+}
 
 template <int DT, int KSLABS, int QG, int METRIC, int MODE>
-__global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(ScanK a) {
-    using G = Geo<QG, KSLABS>;
+__global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_scan(ScanK a) {
+    using G = Geo<QG, KSLABS, MODE>;
     using A = Acc<DT>;
     using elem_t = typename A::elem;
     constexpr int RT = G::RT, SLAB_ROWS = G::SLAB_ROWS, SLAB_BYTES = G::SLAB_BYTES, NS = G::NS, NC = G::NC, PC = G::PC,
@@ -486,16 +494,25 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
         // counted vmcnt waits of the LDS-DMA stream never see them).  The value of a group that ends here goes to
         // fold_out[group][query]: 32 lanes, 256 contiguous bytes.
         auto fold_groups = [&](Epi &e, auto &&pv) {
-            if constexpr (MODE == 2) {
+            if constexpr (MODE == 3) {
                 typedef const __attribute__((address_space(4))) uint32_t *cptr32;
                 const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(prev_row_base >> 5));  // 32-row tile of this wave (uniform)
                 const uint64_t row0 = (uint64_t)tile_u * 32u;
                 if (row0 >= a.n_rows) return;
                 float dm[16];
+                // cosine: sqrt(|a|^2) in f64 once per ROW, not once per (row, query) — lane L takes row L & 31 of the tile (its |a|^2
+                // sits in the tile record the previous tile left in LDS) and the sixteen a lane needs come over the cross-lane
+                // network; the same correctly rounded value ref_cosine_finish computes, a third of its instructions gone
+                double sa_mine = 0.0, sb = 0.0;
+                if (COS) {
+                    sa_mine = __dsqrt_rn((double)((const float *)(normring + p_nslot * (WAVES * 256) + rec_wave * 256))[j]);
+                    sb = __dsqrt_rn((double)qi[0].bb);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     if (COS) {
-                        dm[r] = ref_cosine_finish((float)pv(0, r), e.xh[r], qi[0].bb);
+                        const double sa = __shfl(sa_mine, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+                        dm[r] = (float)(1.0 - (double)(float)pv(0, r) / (sa * sb));
                     } else {
                         const double ss = (double)e.xh[r] + (double)qi[0].bb - 2.0 * (double)pv(0, r);
                         if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
@@ -648,11 +665,9 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
             }
         };
         auto epi_rest = [&](Epi &e, auto &&pv) {
-            if constexpr (MODE == 2) {
-                if (a.tile_grp) {
-                    if (prev_valid) fold_groups(e, pv);
-                    return;
-                }
+            if constexpr (MODE == 3) {
+                if (prev_valid) fold_groups(e, pv);
+            } else if constexpr (MODE == 2) {
                 // dense exact int8 distances (the reference's dist_{cte}.d for a batch of queries):
                 // closed form of the exact integer sums, valid while they stay below 2^24
                 // (oracle: orc_i8_cosine_from_sums / orc_i8_l2_from_sums).  xh = |a|^2 here.
@@ -844,13 +859,13 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS)) void k_scan(S
 template <int DT, int KS, int QG, int METRIC, int MODE>
 static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
     static std::atomic<bool> configured{false};
-    constexpr int lds = Geo<QG, KS>::LDS_BYTES;
+    constexpr int lds = Geo<QG, KS, MODE>::LDS_BYTES;
     if (!configured.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_scan<DT, KS, QG, METRIC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS>::WAVES * 64), lds, s, k);
+    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS, MODE>::WAVES * 64), lds, s, k);
     return hipGetLastError();
 }
 template <int DT, int KS, int QG>
@@ -858,8 +873,10 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     if constexpr (DT == PVS_I8) {
         if (mode == 2)
             return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 2>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 2>(k, s);
+        if (mode == 3)
+            return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 3>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 3>(k, s);
     } else {
-        if (mode == 2) return hipErrorInvalidValue;  // float order matters: no closed form
+        if (mode == 2 || mode == 3) return hipErrorInvalidValue;  // float order matters: no closed form
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
