@@ -549,7 +549,11 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         std::lock_guard<std::mutex> lk(ix->mu);
         PVS_TRY(ensure_groups(ix));
     }
-    if (agg == PVS_AGG_MIN && !row_weights) {
+    // MIN (the reference's default): from a handful of queries up the one-pass scorer with the per-group fold is cheaper than row
+    // pages of the filter scan regrouped on the host (4M x 768 int8, 32 queries: 0.95 ms against 3.1); one to three queries keep
+    // the filter scan, whose pass streams at the full HBM rate for them
+    const bool min_fused = batch >= 4 && fused_groups_ok(ix, batch, nullptr, nullptr) && pvs_dbg(PVS_DBG_NO_FUSED_AGG) == 0;
+    if (agg == PVS_AGG_MIN && !row_weights && !min_fused) {
         bool done = false;
         PVS_TRY(groups_min_fast(ix, queries, qdtype, batch, k, metric, mask, mask_space, out_groups, out_values, out_count, &done));
         if (done) return PVS_OK;
@@ -560,6 +564,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     float *d_m = nullptr, *d_w = nullptr;
     uint8_t *d_mask = nullptr;
     double *d_vt = nullptr;
+    uint32_t dense_q = 0;
     auto body = [&]() -> pvs_status {
         PVS_TRY(ctx_prepare(ix, *c, batch, k, false));
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
@@ -629,6 +634,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
                 d_vt = nullptr;
             }
             if (fused_done) continue;
+            dense_q += nb;
             if (ix->n) PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
             PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, dm, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,
                                        out_count + q0, FanoutWeights(), dm ? 0u : 1u));
@@ -638,7 +644,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
     pvs_status st = body();
     for (void *p : {d_q, (void *)d_m, (void *)d_w, (void *)d_mask, (void *)d_vt}) pvs_scratch_free_on(p, c->stream);
     ix->searches++;
-    ix->dense_queries += batch;
+    ix->dense_queries += dense_q;  // (queries answered through the N x B matrix; the one-pass scorer writes none)
     ctx_done(ix, c);
     return st;
 }

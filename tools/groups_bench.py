@@ -35,8 +35,13 @@ def timed(f, reps=5):
     return (time.perf_counter() - t) / reps * 1e3, r
 
 
-ms, _ = timed(lambda: ix.search_groups(q, K, pvs.COSINE, pvs.AGG_MIN))
-res["min_filter_scan_ms"] = round(ms, 3)
+for bq in (1, 4, B):
+    pvs.debug_set("no_fused_agg", 1)
+    ms_s, r1 = timed(lambda: ix.search_groups(q[:bq], K, pvs.COSINE, pvs.AGG_MIN))
+    pvs.debug_set("no_fused_agg", 0)
+    ms_f, r2 = timed(lambda: ix.search_groups(q[:bq], K, pvs.COSINE, pvs.AGG_MIN))
+    res[f"min_b{bq}"] = {"filter_scan_ms": round(ms_s, 3), "product_ms": round(ms_f, 3), "same_pages": bool(np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1].view(np.uint64), r2[1].view(np.uint64)))}
+    print("min", bq, res[f"min_b{bq}"], flush=True)
 for name, kw in (("avg", dict(agg=pvs.AGG_AVG)), ("max", dict(agg=pvs.AGG_MAX)), ("weighted", dict(agg=pvs.AGG_AVG, row_weights=w))):
     for metric, mn in ((pvs.COSINE, "cosine"), (pvs.L2, "l2")):
         pvs.debug_set("no_fused_agg", 0)
