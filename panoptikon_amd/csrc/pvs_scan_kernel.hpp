@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                         dm[r] = (float)(1.0 - (double)(float)pv(0, r) / (sa * sb));
                     } else {
                         const double ss = (double)e.xh[r] + (double)qi[0].bb - 2.0 * (double)pv(0, r);
-                        if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
+                        // (padding rows behind the last stored row carry a NaN norm: they are no reason to leave the closed form)
+                        if (!(ss < 16777216.0) && row0 + (uint64_t)((r & 3) + 8 * (r >> 2) + 4 * h) < a.n_rows && myq[0] < (int)a.batch) atomicOr(a.dense_flag, 1u);
                         dm[r] = ref_l2_finish((float)ss);
                     }
                 }
