@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--allow-host-gather", action="store_true",
                     help="N ranks: when RCCL cannot be initialised (e.g. two ranks on one GPU) exchange the pages over the control "
                          "socket instead of failing (testing only; the line then says exchange=ctl-host-gather)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the two secondary timed regions of the default run (single-query 10M x 768 f16; 256 int8 queries per pass)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="pvs_debug_set(KEY, VALUE) before the run (tuning sweeps: sample_div, sample_j_div, scan_no_wide128, ...; the line records it)")
     a = ap.parse_args()
@@ -641,6 +643,100 @@ def main():
         "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries),
                  "scan_candidates_per_query": round(int(st.last_candidates) / max(B, 1), 1)},
     }
+
+    # ------------------------------------------------- the north star's other two shapes (own timed regions, headline fields untouched)
+    def timed_region(ixh, dt_name, b, steps, warmup):
+        """`steps` batches of b queries through pvs_search_device on index ixh (one stream), kernel durations from HIP events in the
+        timed region: the same measurement as the headline's, as one self-contained record."""
+        esz2 = {"i8": 1, "f16": 2, "f32": 4}[dt_name]
+        qb = pvs.DeviceBuffer(b * D * 4, device)
+        L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b, D, qb.ptr))
+        o = [(pvs.DeviceBuffer(b * K * 8, device), pvs.DeviceBuffer(b * K * 4, device), pvs.DeviceBuffer(b * 4, device)) for _ in range(2)]
+        pend = []
+
+        def one(i):
+            if len(pend) >= 2:
+                ixh.wait(pend.pop(0))
+            pend.append(ixh.search_device(qb, L.F32, b, K, metric, *o[i % 2]))
+
+        for i in range(warmup):
+            one(i)
+        while pend:
+            ixh.wait(pend.pop(0))
+        L.check(lib.pvs_device_synchronize(device))
+        ixh.set_profiling(True)
+        ixh.profile(reset=True)
+        t = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        while pend:
+            ixh.wait(pend.pop(0))
+        L.check(lib.pvs_device_synchronize(device))
+        el = time.perf_counter() - t
+        ixh.set_profiling(False)
+        p = ixh.profile()
+        st2 = ixh.stats()
+        sms = p.scan_ms / max(p.scan_launches, 1)
+        nrows = int(st2.rows)
+        by = nrows * D * esz2
+        gbs = by / (sms * 1e-3) / 1e9 if p.scan_launches else 0.0
+        ops = 2.0 * nrows * D * b
+        pk = I8_MFMA_PEAK_TOPS if dt_name == "i8" else F16_MFMA_PEAK_TFLOPS
+        for bufs in o:
+            for x in bufs:
+                x.free()
+        qb.free()
+        return {"config": {"workload": f"{nrows}x{D} {dt_name} corpus, batch {b}, {args.metric}, k={K}", "rows": nrows, "dim": D, "batch": b, "k": K},
+                "metric": "knn_queries_per_sec", "value": round(steps * b / el, 1), "unit": "queries/s", "steps": steps, "warmup": warmup,
+                "ms_per_step": round(el / steps * 1e3, 4), "dtype": dt_name, "data": "synthetic",
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": f"{ixh.scan_kernel_name(b)} (pass B, filter scan)", "launches": int(p.scan_launches), "avg_launch_ms": round(sms, 4),
+                             "algorithmic_bytes_per_launch": int(by), "kernel_events": "timed region",
+                             "mfma": {"achieved": round(ops / (sms * 1e-3) / 1e12, 1) if p.scan_launches else 0.0, "peak": pk,
+                                      "unit": "TOP/s" if dt_name == "i8" else "TFLOP/s", "frac": round(ops / (sms * 1e-3) / 1e12 / pk, 4) if p.scan_launches else 0.0}},
+                "path": {"fast_queries": int(st2.fast_queries), "dense_queries": int(st2.dense_queries)}}
+
+    secondary = []
+    want_secondary = (rank == 0 and world == 1 and not single and not args.force_comm and not args.no_secondary and n_streams == 1
+                      and (N, D, args.dtype, B, K, args.metric) == CONFIGS[2])
+    if want_secondary:
+        try:
+            # (b) 256 int8 queries per pass over the same corpus: the configuration the int8 MFMA target is reachable on
+            rec = timed_region(ix, "i8", 256, 20, 3)
+            rec["what"] = "north-star MFMA target shape: 256 int8 queries per corpus pass (k_scan_wide, one workgroup per CU)"
+            secondary.append(rec)
+            # (a) single query over 10M x 768 f16: the north star's >= 70 % of HBM target
+            free_b, tot_b = L.C.c_uint64(), L.C.c_uint64()
+            L.check(lib.pvs_device_mem_info(device, L.C.byref(free_b), L.C.byref(tot_b)))
+            if free_b.value > 40 << 30:
+                t_b = time.time()
+                ix16 = pvs.VectorIndex(pvs.F16, D, device=device, capacity_rows=N)
+                st16 = pvs.DeviceBuffer(chunk * D * 4, device)
+                for off in range(0, N, chunk):
+                    m = min(chunk, N - off)
+                    L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, off, m, D, st16.ptr))
+                    ix16.add_f32((st16, m))
+                st16.free()
+                ix16.sync()
+                rec = timed_region(ix16, "f16", 1, 30, 3)
+                rec["what"] = "north-star HBM target shape: single query over 10M x 768 f16 (>= 70 % of the HBM roofline asked)"
+                rec["build_seconds"] = round(time.time() - t_b, 1)
+                if not args.no_verify:  # the page of the timed query against the device's dense path (the reference's algorithm in HBM)
+                    qf = np.empty((1, D), np.float32)
+                    qtmp = pvs.DeviceBuffer(D * 4, device)
+                    L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, 1, D, qtmp.ptr))
+                    qf[:] = qtmp.to_numpy(np.float32, (1, D))
+                    qtmp.free()
+                    fi, fd, fc = ix16.search(qf, K, metric)
+                    ix16.set_path(1)
+                    di2, dd2, dc2 = ix16.search(qf, K, metric)
+                    ix16.set_path(0)
+                    rec["parity"] = {"filter_path_equals_device_dense_path": bool(np.array_equal(fi, di2) and np.array_equal(fd.view(np.uint32), dd2.view(np.uint32)))}
+                secondary.append(rec)
+                ix16.close()
+        except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
+            secondary.append({"error": str(e)})
+        result["secondary"] = secondary
 
     # ------------------------------------------------- verification (untimed)
     def oracle_page_over(ixh, row_base, n_rows, qh, odt, omet, threads):

@@ -1037,6 +1037,16 @@ def test_full_size_properties(pvs, dtype, n, b):
                     acc_i[t], acc_d[t] = orc.topk(np.concatenate([acc_d[t], cd[t]]), k, ids=np.concatenate([acc_i[t], ci[t]]))
             for t, qi in enumerate((0, b - 1)):
                 assert np.array_equal(gi[qi], acc_i[t]) and np.array_equal(gd[qi].view(np.uint32), acc_d[t].view(np.uint32)), f"query {qi} vs the oracle over {n} rows"
+        if dt != pvs.I8 and n == 1_000_000:
+            # configs[1] (1M x 768 f16 x 32) and its f32 form: the CPU oracle over the WHOLE corpus (sequential-f32 restatement of
+            # sqlite-vec's scalar loops, ~3 s), both metrics, every query of the f32 batch / 8 queries spread over the f16 one
+            which = list(range(b)) if b <= 8 else [0, 5, 11, 16, 21, 26, 30, b - 1]
+            slab = ix.read_rows(0, n)
+            odt = orc.F16 if dt == pvs.F16 else orc.F32
+            omet = orc.COSINE if metric == pvs.COSINE else orc.L2
+            ei, ed = orc.search(odt, omet, slab, q[which], k, threads=orc.max_threads())
+            for t, qi in enumerate(which):
+                assert np.array_equal(gi[qi], ei[t]) and np.array_equal(gd[qi].view(np.uint32), ed[t].view(np.uint32)), f"{dtype} query {qi} vs the oracle over {n} rows"
     # row shards of the same corpus, merged: equals the whole-corpus page (ids are global row indexes)
     nq = min(16, b)
     gi, gd, gc = ix.search(q[:nq], k, pvs.COSINE)
