@@ -134,6 +134,7 @@ int32_t pvs_sqlite_load(void *db, const char *sql, pvs_index *idx, uint32_t chun
  * (the SQL guards `length(e.embedding) = c.dim * 4`).  `device`: HIP ordinal, -1 = current.  Also reachable from SQL:
  *     SELECT pvs_backfill(select_sql, upsert_sql, profile_id, device [, select parameter ...])   -> rows written
  *     SELECT pvs_backfill_cursor()                 -> largest id written by this connection's last pvs_backfill (NULL: none)
+ *     SELECT pvs_backfill_phases()                 -> 'select_ms,quantize_ms,upsert_ms' of that call (where the time went)
  * Returns pvs_status; PVS_ERR_STATE when the registered SQLite entry points lack bind_blob / bind_int64 / reset. */
 typedef struct pvs_sqlite_backfill_result {
     uint64_t written; /* rows upserted */

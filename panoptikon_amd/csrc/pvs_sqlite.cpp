@@ -37,6 +37,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -601,6 +602,14 @@ void load_info_udf(sqlite3_context *ctx, int, sqlite3_value **argv) {
 // device.  `sel` is prepared and bound by the caller; it is stepped to completion BEFORE the first write (it reads
 // embedding_quants itself — NOT EXISTS — and the reference fetches the whole chunk first too).
 thread_local pvs_sqlite_backfill_result t_last_backfill = {0, -1};
+// where the last pvs_backfill of this thread spent its time: stepping the host's SELECT (SQLite page reads + one copy per blob),
+// the device codec (upload, quantize_int8, download), the host's UPSERT (three b-tree inserts per row in the reference's schema)
+thread_local double t_backfill_phase_ms[3] = {0, 0, 0};
+static inline double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t profile_id, int32_t device, pvs_sqlite_backfill_result *res,
                         std::string *err) {
@@ -608,6 +617,8 @@ pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t 
     std::vector<float> scales;
     std::vector<uint8_t> payload;
     uint64_t row_bytes = 0;
+    const double t0 = now_ms();
+    t_backfill_phase_ms[0] = t_backfill_phase_ms[1] = t_backfill_phase_ms[2] = 0;
     for (;;) {
         const int rc = g_api.step(sel);
         if (rc == SQLITE_DONE) break;
@@ -640,6 +651,8 @@ pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t 
     }
     res->written = 0;
     res->cursor = -1;
+    const double t1 = now_ms();
+    t_backfill_phase_ms[0] = t1 - t0;
     if (ids.empty()) return PVS_OK;
     const uint64_t dim = row_bytes / 4, n = ids.size();
     std::vector<int8_t> codes(n * dim);
@@ -653,6 +666,8 @@ pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t 
         }
         i = j;
     }
+    const double t2 = now_ms();
+    t_backfill_phase_ms[1] = t2 - t1;
     void *up = nullptr;
     if (g_api.prepare_v2(db, upsert_sql, -1, &up, nullptr) != SQLITE_OK || !up) {
         *err = std::string("the upsert does not prepare: ") + g_api.errmsg(db);
@@ -672,7 +687,14 @@ pvs_status backfill_run(sqlite3 *db, void *sel, const char *upsert_sql, int64_t 
         res->cursor = std::max(res->cursor, ids[i]);
     }
     g_api.finalize(up);
+    t_backfill_phase_ms[2] = now_ms() - t2;
     return st;
+}
+// SELECT pvs_backfill_phases() -> 'select_ms,quantize_ms,upsert_ms' of this connection thread's last pvs_backfill (measurement aid)
+void backfill_phases_udf(sqlite3_context *ctx, int, sqlite3_value **) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "%.3f,%.3f,%.3f", t_backfill_phase_ms[0], t_backfill_phase_ms[1], t_backfill_phase_ms[2]);
+    g_api.result_text(ctx, buf, -1, (void (*)(void *))(intptr_t)-1);  // SQLITE_TRANSIENT
 }
 
 void backfill_udf(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
@@ -803,6 +825,8 @@ int register_all(sqlite3 *db) {
         rc = g_api.create_function_v2(db, "pvs_backfill", -1, SQLITE_UTF8, nullptr, backfill_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;
         rc = g_api.create_function_v2(db, "pvs_backfill_cursor", 0, SQLITE_UTF8, nullptr, backfill_cursor_udf, nullptr, nullptr, nullptr);
+    if (rc == SQLITE_OK)
+        rc = g_api.create_function_v2(db, "pvs_backfill_phases", 0, SQLITE_UTF8, nullptr, backfill_phases_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;
         rc = g_api.create_function_v2(db, "pvs_ready_pair", -1, SQLITE_UTF8, nullptr, ready_pair_udf, nullptr, nullptr, nullptr);
         if (rc != SQLITE_OK) return rc;

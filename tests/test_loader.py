@@ -230,7 +230,7 @@ def test_sqlite_extension_loads_and_registers_without_a_gpu():
     assert [r[0] for r in conn.execute("SELECT name FROM pragma_module_list WHERE name = 'pvs_dist'")] == ["pvs_dist"]
     assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_distance%'")} == {"pvs_distance_cosine", "pvs_distance_l2"}
     assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_load%'")} == {"pvs_load", "pvs_load_info"}
-    assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_backfill%'")} == {"pvs_backfill", "pvs_backfill_cursor"}
+    assert {r[0] for r in conn.execute("SELECT name FROM pragma_function_list WHERE name LIKE 'pvs_backfill%'")} == {"pvs_backfill", "pvs_backfill_cursor", "pvs_backfill_phases"}
     assert conn.execute("SELECT pvs_load_info('nope')").fetchone()[0] is None
     assert conn.execute("SELECT pvs_backfill_cursor()").fetchone()[0] is None
     # backfill: errors that need no device (the select is read, and refused, before anything is quantized)

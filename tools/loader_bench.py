@@ -67,6 +67,7 @@ def main():
             conn.commit()
         t0 = time.time()
         cursor, total = 0, 0
+        phases = [0.0, 0.0, 0.0]
         while True:
             conn.execute("BEGIN IMMEDIATE")
             n = conn.execute("SELECT pvs_backfill(?, ?, 5, 0, 5, 1, ?, ?)", (_BACKFILL_SELECT, _BACKFILL_UPSERT, cursor, chunk)).fetchone()[0]
@@ -74,10 +75,14 @@ def main():
             if n == 0:
                 break
             cursor = conn.execute("SELECT pvs_backfill_cursor()").fetchone()[0]
+            for i, v in enumerate(conn.execute("SELECT pvs_backfill_phases()").fetchone()[0].split(",")):
+                phases[i] += float(v)
             total += n
         dt = time.time() - t0
         assert total == args.rows
-        out[label] = {"seconds": round(dt, 3), "rows_per_s": round(args.rows / dt), "vs_reference_29k_rows_per_s": round(args.rows / dt / 29100, 1)}
+        out[label] = {"seconds": round(dt, 3), "rows_per_s": round(args.rows / dt), "vs_reference_29k_rows_per_s": round(args.rows / dt / 29100, 1),
+                      "inside_pvs_backfill_ms": {"stepping_the_select": round(phases[0], 1), "device_codec_incl_copies": round(phases[1], 1),
+                                                  "upserts": round(phases[2], 1)}}
     print(json.dumps(out))
 
 
