@@ -626,7 +626,7 @@ pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
  *   "scratch_idle_cap_mb" N   idle scratch kept per device (default 16 GiB)  "scratch_bypass"   scratch straight from hipMalloc/hipFree
  *   "no_sparse" / "sparse_max" N   filtered searches: never / up to N allowed rows on the gather-score path
  *   "no_fused_agg"            per-item MAX/AVG/weighted through the dense matrix + k_group_aggregate
- *   "no_fused_pass"           filter scan: pass A, k-th select and pass B as separate launches */
+ *   "no_side_finalize"        pvs_search_device: pass C on the search's own stream instead of the index's side stream */
 pvs_status pvs_debug_set(const char *key, int64_t value);
 pvs_status pvs_debug_get(const char *key, int64_t *out_value);
 /* Stage digests of the process' last single-device pvs_rrf_search run under "rrf_digest": out[branch * 4 + stage], stage 0 = the

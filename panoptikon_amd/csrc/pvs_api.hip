@@ -24,7 +24,7 @@ std::atomic<int64_t> g_dbg[PVS_DBG_COUNT];
 const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
-    "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_fused_pass",
+    "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -333,6 +333,7 @@ void ctx_release(SearchCtx &c) {
     pvs_dense_release(c.dense);
     pvs_group_work_release(c.gwork);
     if (c.done) hipEventDestroy(c.done);
+    if (c.scanned) hipEventDestroy(c.scanned);
     hipFree(c.d_loc_rec);
     hipFree(c.d_all_rec);
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
@@ -364,6 +365,8 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
     }
     c.cur_mask = nullptr;
     if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    if (!c.scanned) HIP_TRY(hipEventCreateWithFlags(&c.scanned, hipEventDisableTiming));
+    c.side_finalize = false;
     if (!c.d_qmat) {
         HIP_TRY(pvs_malloc_retry((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_qmat, (size_t)PVS_SCAN_MAX_BATCH * ix->stride));
@@ -379,7 +382,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
     }
     const bool force_light = pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE) != 0;  // tests: the LDS-light pass C on every search
-    if ((ix->multi_stream || force_light) && ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan)
+    if (ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan — several streams, or the side stream of a pipelined caller)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
@@ -445,6 +448,7 @@ PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **o
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) ix->n_cu = p.multiProcessorCount;
     hipError_t e = hipStreamCreateWithFlags(&ix->admin_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->search_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->fin_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ix;
@@ -545,6 +549,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_null_rows[1]);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
+    if (ix->fin_stream) hipStreamDestroy(ix->fin_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
     pvs_scratch_trim(ix->device);
     delete ix;

@@ -26,6 +26,8 @@ struct SearchCtx {
     hipStream_t stream = nullptr;      // the stream this context launches on (shared or own)
     hipStream_t own_stream = nullptr;
     hipEvent_t done = nullptr;         // recorded after the last launch of a search
+    hipEvent_t scanned = nullptr;      // recorded behind pass B when pass C runs on the index's side stream
+    bool side_finalize = false;        // this search's pass C went to ix->fin_stream (c.done was recorded there)
     bool busy = false;
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
@@ -185,6 +187,7 @@ struct pvs_index {
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
     hipStream_t search_stream = nullptr;
+    hipStream_t fin_stream = nullptr;   // pass C of a pipelined caller's search: runs beside the NEXT search's scan (search_enqueue)
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
     bool by_group = false;  // multi-device parent: rows are placed by group (group_ids given to every add): per-item operators are shard-local
@@ -254,7 +257,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
                        const uint32_t *rows = nullptr, uint64_t n_listed = 0, pvs_space rows_space = PVS_HOST);
 void ctx_done(pvs_index *ix, SearchCtx *c);
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
-                          int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast);
+                          int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast, bool side_finalize = false);
 pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
                             int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 pvs_status ctx_reserve_local_pages(SearchCtx &c, uint32_t batch, uint32_t k);

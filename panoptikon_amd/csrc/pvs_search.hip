@@ -63,7 +63,7 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 // few tile streams) — with pass B appending to per-query flat lists through atomic counters; the other queries' thresholds
 // are voided so that they emit nothing, and pass C finalises the handed-back ones only.
 static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff, uint32_t nb, uint32_t batch_pad, uint32_t k, int metric,
-                                     int64_t *oid, float *od, uint32_t *oc, bool flat_rerun) {
+                                     int64_t *oid, float *od, uint32_t *oc, bool flat_rerun, bool side = false) {
     ScanArgs a;
     a.dtype = (int)ix->dtype;
     a.metric = metric;
@@ -163,7 +163,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     f.seg_cap = pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs);
     f.cand = c.d_cand;
     const bool no_light = pvs_dbg(PVS_DBG_NO_LIGHT_FINALIZE) != 0, force_light = pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE) != 0;  // tuning / tests
-    if ((ix->multi_stream || force_light) && c.d_fin_ub && !no_light) {
+    if ((ix->multi_stream || force_light || side) && c.d_fin_ub && !no_light) {
         f.w_ub = c.d_fin_ub;
         f.w_surv = c.d_fin_surv;
         f.w_sort = c.d_fin_sort;
@@ -188,15 +188,25 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
         f.trank = ix->d_trank;
         f.tinv = ix->d_tinv;
     }
-    span_begin(ix, c, 2, 0);
-    HIP_TRY(pvs_launch_finalize(f, c.stream));
-    span_end(ix, c);
+    // Pass C of a pipelined caller's search goes to the index's side stream, behind an event recorded after pass B: the LDS-light
+    // finaliser (6 KB, ~100 registers) fits beside k_scan_wide's one workgroup per CU (148 KB, 2 x 92 registers per SIMD), so it
+    // runs under the scan of the caller's NEXT search instead of in front of it (38 us of a 1.3-ms step at configs[2]).
+    hipStream_t fs = c.stream;
+    if (side && f.w_ub) {
+        HIP_TRY(hipEventRecord(c.scanned, c.stream));
+        HIP_TRY(hipStreamWaitEvent(ix->fin_stream, c.scanned, 0));
+        fs = ix->fin_stream;
+        c.side_finalize = true;
+    }
+    span_begin(ix, c, 2, 0, fs);
+    HIP_TRY(pvs_launch_finalize(f, fs));
+    span_end(ix, c, fs);
     return PVS_OK;
 }
 
 // Enqueues the whole search on c.stream.  Outputs are device buffers.
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
-                                 int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast) {
+                                 int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast, bool side_finalize) {
     const bool fast = fast_path_ok(ix, k);
     *used_fast = fast;
     if (!fast && ix->forced_path == 2) return pvs_fail(PVS_ERR_UNSUPPORTED, "filter-scan path not available for this index / k");
@@ -240,10 +250,13 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
             for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
             continue;
         }
-        PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false));
+        // (one chunk only: a second chunk's query prep would overwrite what the first one's pass C still reads)
+        const bool side = side_finalize && batch <= pass_max && ix->dtype == PVS_I8 && !ix->multi_stream && c.stream == ix->search_stream &&
+                          !pvs_dbg(PVS_DBG_NO_SIDE_FINALIZE);
+        PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false, side));
     }
     // (pass C wrote its verdicts and candidate counts straight into c.h_need_dense: FinalizeArgs.h_flags)
-    HIP_TRY(hipEventRecord(c.done, c.stream));
+    HIP_TRY(hipEventRecord(c.done, c.side_finalize ? ix->fin_stream : c.stream));
     return PVS_OK;
 }
 
@@ -909,9 +922,10 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
     if (!c) return PVS_ERR_STATE;
     pvs_status st = ctx_prepare(ix, *c, batch, k, false);
     bool fast = false;
-    if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast);
+    if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast, true);
     if (st != PVS_OK) {
         (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(ix->fin_stream);
         ctx_done(ix, c);
         return st;
     }
