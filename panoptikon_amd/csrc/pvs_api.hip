@@ -381,7 +381,6 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
     }
-    const bool force_light = pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE) != 0;  // tests: the LDS-light pass C on every search
     if (ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan — several streams, or the side stream of a pipelined caller)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
@@ -545,6 +544,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     hipFree(ix->d_grp_trank);
     hipFree(ix->d_tile_grp);
     hipFree(ix->d_straddlers);
+    hipFree(ix->d_row_gidx);
     hipFree(ix->d_null_rows[0]);
     hipFree(ix->d_null_rows[1]);
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);

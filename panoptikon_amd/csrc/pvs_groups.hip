@@ -413,14 +413,15 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
 constexpr uint32_t GM_SORT = 2048;
 __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *count, const unsigned long long *in_key, const uint32_t *in_slot, const int64_t *gids,
                                                  const uint32_t *grp_trank, const uint32_t *grp_tinv, uint32_t k, int64_t *out_groups, double *out_values,
-                                                 uint32_t *out_flag) {
+                                                 uint32_t *out_flag, uint32_t *out_cnt, int allow_short) {
     extern __shared__ unsigned long long s_k[];  // [GM_CAP] keys | [GM_SORT] selected keys | [GM_CAP] u32 ties | [GM_SORT] u32 selected ties
     __shared__ uint32_t hist[256], misc[4], s_n;
     unsigned long long *s_sk = s_k + GM_CAP;
     uint32_t *s_t = (uint32_t *)(s_sk + GM_SORT), *s_st = s_t + GM_CAP;
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     const uint32_t m = count[(size_t)col * 32];
-    if (m < k || m > GM_CAP) {
+    // (allow_short: the column holds EVERY group of a short candidate list — fewer than k is the whole answer, not an unlucky page)
+    if ((m < k && !allow_short) || m > GM_CAP || (allow_short && m > GM_SORT && k >= m)) {
         if (tid == 0) out_flag[col] = 0;
         return;
     }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *cou
     }
     if (tid == 0) s_n = 0;
     __syncthreads();
-    const unsigned long long kth = wg_radix_kth_u64(s_k, m, k, hist, misc);
+    const unsigned long long kth = k < m ? wg_radix_kth_u64(s_k, m, k, hist, misc) : ~0ull;
     for (uint32_t i = tid; i < m; i += GM_SORT_THREADS)
         if (s_k[i] <= kth) {
             const uint32_t p = atomicAdd(&s_n, 1u);
@@ -470,7 +471,13 @@ __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *cou
             }
             __syncthreads();
         }
+    const uint32_t nout = ms < k ? ms : k;
     for (uint32_t i = tid; i < k; i += GM_SORT_THREADS) {
+        if (i >= nout) {
+            out_groups[(size_t)col * k + i] = -1;
+            out_values[(size_t)col * k + i] = __builtin_nan("");
+            continue;
+        }
         const uint32_t slot = grp_tinv ? grp_tinv[s_st[i]] : s_st[i];
         out_groups[(size_t)col * k + i] = gids[slot];
         const unsigned long long key = s_sk[i];
@@ -483,7 +490,19 @@ __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *cou
         }
         out_values[(size_t)col * k + i] = v;
     }
-    if (tid == 0) out_flag[col] = 1;
+    if (tid == 0) {
+        out_flag[col] = 1;
+        if (out_cnt) out_cnt[col] = nout;
+    }
+}
+// column-major values [ncol][n_sub] of the sub-groups of a candidate list -> k_gm_topk's per-column entry lists (every sub-group)
+__global__ void k_sub_entries(const double *vals, uint32_t n_sub, uint32_t ncol, const uint32_t *sub_slot, uint32_t *count, unsigned long long *out_key,
+                              uint32_t *out_slot) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (i == 0) count[(size_t)col * 32] = n_sub;
+    if (i >= n_sub) return;
+    out_key[(size_t)col * GM_CAP + i] = gm_key(vals[(size_t)col * n_sub + i]);
+    out_slot[(size_t)col * GM_CAP + i] = sub_slot[i];
 }
 // d_work: >= pvs_gm_rank_work_bytes(ncol) of device scratch; out_*: device-accessible (pinned) [ncol][k] / [ncol]; stream-ordered
 size_t pvs_gm_rank_work_bytes(uint32_t ncol) { return (size_t)ncol * (8 + 128 + (size_t)GM_CAP * 12) + 256; }
@@ -513,7 +532,27 @@ hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol,
         configured.store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_gm_topk, dim3(ncol), dim3(GM_SORT_THREADS), (size_t)(GM_CAP + GM_SORT) * 12, s, count, keys, slots, d_gids, d_grp_trank, d_grp_tinv, k, out_groups, out_values,
-                       out_flag);
+                       out_flag, (uint32_t *)nullptr, 0);
+    return hipGetLastError();
+}
+// The pages of the <= GM_CAP sub-groups of a candidate list (pvs_sparse.hip): d_vals [ncol][n_sub] column-major, sub_slot[j] = the
+// group slot of sub-group j.  out_flag[col] = 0: the column could not be sorted in LDS (more than 2,048 groups tie at the page's edge).
+bool pvs_sub_rank_supported(uint32_t n_sub) { return n_sub <= GM_CAP; }
+hipError_t pvs_sub_rank(const double *d_vals, uint32_t n_sub, uint32_t ncol, uint32_t k, const uint32_t *d_sub_slot, const int64_t *d_gids, const uint32_t *d_grp_trank,
+                        const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, uint32_t *out_cnt, hipStream_t s) {
+    uint8_t *w = (uint8_t *)d_work;
+    uint32_t *count = (uint32_t *)(w + (((size_t)ncol * 8 + 127) & ~(size_t)127));
+    unsigned long long *keys = (unsigned long long *)((uint8_t *)count + (size_t)ncol * 128);
+    uint32_t *slots = (uint32_t *)((uint8_t *)keys + (size_t)ncol * GM_CAP * 8);
+    hipLaunchKernelGGL(k_sub_entries, dim3((std::max<uint32_t>(n_sub, 1) + 255) / 256, ncol), dim3(256), 0, s, d_vals, n_sub, ncol, d_sub_slot, count, keys, slots);
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_gm_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (GM_CAP + GM_SORT) * 12);
+        if (e != hipSuccess) return e;
+        configured.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k_gm_topk, dim3(ncol), dim3(GM_SORT_THREADS), (size_t)(GM_CAP + GM_SORT) * 12, s, count, keys, slots, d_gids, d_grp_trank, d_grp_tinv, k, out_groups, out_values,
+                       out_flag, out_cnt, 1);
     return hipGetLastError();
 }
 

@@ -165,6 +165,7 @@ struct pvs_index {
     int64_t *d_grp_ids = nullptr;
     // fused per-item scoring (k_scan MODE 2 with the per-group fold): possible when every group is one run of consecutive rows
     // (group ids non-decreasing in row order: the reference's loader streams ORDER BY item_data.id, a file's vectors adjacent)
+    uint32_t *d_row_gidx = nullptr;     // [n] the group slot of every row (the per-item form of the sparse candidate path sorts by it)
     bool groups_are_runs = false;
     uint4 *d_tile_grp = nullptr;        // [ceil(n / 32)] tile records (ScanK.tile_grp)
     uint32_t *d_straddlers = nullptr;   // groups that cross a 32-row tile boundary
@@ -273,6 +274,9 @@ pvs_status pvs_mask_count(const uint8_t *d_mask, uint64_t n, uint32_t *out_count
 pvs_status pvs_mask_compact(const uint8_t *d_mask, uint64_t n, uint32_t *d_list, uint32_t count, hipStream_t s);
 pvs_status pvs_list_to_mask(const uint32_t *d_list, uint32_t m, uint64_t n, uint8_t *d_mask, hipStream_t s);  // validates; synchronous
 bool pvs_sparse_eligible(const pvs_index *ix, uint64_t m, uint32_t batch, uint32_t k);
+pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int agg,
+                                    const float *d_weights, const uint32_t *d_list, uint32_t m, int64_t *out_groups, double *out_values, uint32_t *out_count,
+                                    bool *handled);
 pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, const uint32_t *d_list,
                              uint32_t m, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 // ---- pvs_items.hip

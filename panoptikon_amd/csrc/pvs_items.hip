@@ -17,7 +17,8 @@ pvs_status ensure_groups(pvs_index *ix) {
     hipFree(ix->d_grp_trank);
     hipFree(ix->d_tile_grp);
     hipFree(ix->d_straddlers);
-    ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = ix->d_grp_trank = ix->d_straddlers = nullptr;
+    hipFree(ix->d_row_gidx);
+    ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = ix->d_grp_trank = ix->d_straddlers = ix->d_row_gidx = nullptr;
     ix->d_grp_ids = nullptr;
     ix->d_tile_grp = nullptr;
     ix->groups_are_runs = false;
@@ -54,6 +55,13 @@ pvs_status ensure_groups(pvs_index *ix) {
     HIP_TRY(hipMemcpy(ix->d_grp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (n) HIP_TRY(hipMemcpy(ix->d_grp_rows, rows.data(), n * 4, hipMemcpyHostToDevice));
     if (!gids.empty()) HIP_TRY(hipMemcpy(ix->d_grp_ids, gids.data(), gids.size() * 8, hipMemcpyHostToDevice));
+    if (n && n < (1ull << 32)) {  // row -> group slot
+        std::vector<uint32_t> gidx(n);
+        for (uint32_t g = 0; g + 1 < off.size(); g++)
+            for (uint32_t e = off[g]; e < off[g + 1]; e++) gidx[rows[e]] = g;
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_row_gidx, n * 4));
+        HIP_TRY(hipMemcpy(ix->d_row_gidx, gidx.data(), n * 4, hipMemcpyHostToDevice));
+    }
     // Are the groups runs of consecutive rows (the CSR order is the row order)?  Then the per-item scorer can fold a group in
     // the epilogue of the tile that holds it (k_scan MODE 2 + ScanK.tile_grp): per 32-row tile a record {group of its first row,
     // rows that end their group, rows whose group crosses a tile boundary}, and the list of those crossing groups.
@@ -603,6 +611,22 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         if (row_weights && ix->n) {
             HIP_TRY(pvs_scratch_alloc((void **)&d_w, ix->n * 4));
             HIP_TRY(hipMemcpyAsync(d_w, row_weights, ix->n * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        // A candidate mask that leaves few rows: score and aggregate those rows only (pvs_sparse.hip), like the row form
+        if (dm && ix->n && ix->forced_path == 0 && !pvs_dbg(PVS_DBG_NO_SPARSE)) {
+            uint32_t allowed = 0;
+            PVS_TRY(pvs_mask_count(dm, ix->n, &allowed, c->stream));
+            if (pvs_sparse_eligible(ix, allowed, batch, k)) {
+                uint32_t *d_list = nullptr;
+                HIP_TRY(pvs_scratch_alloc((void **)&d_list, (size_t)std::max<uint32_t>(allowed, 1) * 4));
+                pvs_status ss = pvs_mask_compact(dm, ix->n, d_list, allowed, c->stream);
+                bool handled = false;
+                if (ss == PVS_OK)
+                    ss = pvs_sparse_search_groups(ix, *c, q_dev, qdtype, batch, k, metric, agg, d_w, d_list, allowed, out_groups, out_values, out_count, &handled);
+                pvs_scratch_free_on(d_list, c->stream);
+                PVS_TRY(ss);
+                if (handled) return PVS_OK;
+            }
         }
         const uint32_t cq = dense_chunk_queries(ix, batch);
         HIP_TRY(pvs_scratch_alloc((void **)&d_m, std::max<size_t>((size_t)ix->n * cq * 4, 16)));

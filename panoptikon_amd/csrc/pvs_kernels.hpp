@@ -241,6 +241,10 @@ size_t pvs_gm_rank_work_bytes(uint32_t ncol);
 bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k);
 hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
                        const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s);
+// the same for the few sub-groups of a candidate list, all of them in one LDS sort per column (column-major values [ncol][n_sub])
+bool pvs_sub_rank_supported(uint32_t n_sub);
+hipError_t pvs_sub_rank(const double *d_vals, uint32_t n_sub, uint32_t ncol, uint32_t k, const uint32_t *d_sub_slot, const int64_t *d_gids, const uint32_t *d_grp_trank,
+                        const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, uint32_t *out_cnt, hipStream_t s);
 // group-major values [n_groups][ncol] -> column-major [ncol][n_groups] (what pvs_group_rank and the page keys index)
 hipError_t pvs_launch_group_transpose(const double *vals_t, uint32_t n_groups, uint32_t ncol, double *vals, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);

@@ -239,6 +239,25 @@ __global__ __launch_bounds__(256) void k_sparse_sort(const float *d, uint32_t ld
     if (tid == 0) out_count[q] = nout;
 }
 
+// per-item form: the group slot of every listed row (the sort key that brings a group's rows together, in row order), its position
+__global__ void k_list_group_keys(const uint32_t *list, uint32_t m, const uint32_t *row_gidx, const float *weights, uint32_t *key, uint32_t *pos, float *w_sub) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    key[i] = row_gidx[list[i]];
+    pos[i] = i;
+    if (w_sub) w_sub[i] = weights[list[i]];
+}
+// sorted keys -> 1 where a new group starts
+__global__ void k_group_heads(const uint32_t *key_s, uint32_t m, uint8_t *head) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) head[i] = i == 0 || key_s[i] != key_s[i - 1];
+}
+__global__ void k_sub_slots(const uint32_t *key_s, const uint32_t *sub_off, uint32_t n_sub, uint32_t m, uint32_t *sub_slot, uint32_t *sub_off_end) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_sub) sub_slot[j] = key_s[sub_off[j]];
+    if (j == 0) *sub_off_end = m;  // the CSR's closing offset
+}
+
 constexpr uint32_t SPARSE_SORT_MAX = 8192;  // rows one in-LDS sort takes (64 KiB of records)
 constexpr uint32_t SPARSE_SELECT_KMAX = 8192;  // pvs_select.hip's largest page
 }  // namespace
@@ -508,5 +527,102 @@ pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries,
     if (st != PVS_OK) (void)hipStreamSynchronize(s);
     for (void *p : {(void *)d_m, (void *)d_flag, (void *)d_skey, (void *)d_spos, (void *)d_skey2, (void *)d_stinv, (void *)d_sids, tmp}) pvs_scratch_free(p);
     if (st == PVS_OK) ix->sparse_queries += batch;
+    return st;
+}
+
+// The per-item page over the rows of d_list (device, ascending, from a compacted candidate mask): gather-and-score, the listed rows
+// brought together per group (a stable sort by group slot keeps a group's rows in row order: SQLite's aggregates are order
+// dependent), k_group_aggregate over that CSR, one LDS sort per query column.  *handled = false: more sub-groups than one LDS
+// sort takes, or massive ties at the page's edge — the caller runs the corpus pass instead.  Outputs: host arrays [batch][k].
+pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int agg,
+                                    const float *d_weights, const uint32_t *d_list, uint32_t m, int64_t *out_groups, double *out_values, uint32_t *out_count,
+                                    bool *handled) {
+    *handled = false;
+    hipStream_t s = c.stream;
+    if (m == 0) {
+        for (size_t i = 0; i < (size_t)batch * k; i++) {
+            out_groups[i] = -1;
+            out_values[i] = __builtin_nan("");
+        }
+        for (uint32_t q = 0; q < batch; q++) out_count[q] = 0;
+        *handled = true;
+        ix->sparse_queries += batch;
+        return PVS_OK;
+    }
+    if (!ix->d_row_gidx) return PVS_OK;
+    uint32_t *d_key = nullptr, *d_pos = nullptr, *d_key_s = nullptr, *d_pos_s = nullptr, *d_sub_off = nullptr, *d_sub_slot = nullptr, *d_num = nullptr;
+    uint8_t *d_head = nullptr;
+    float *d_wsub = nullptr, *d_m = nullptr;
+    double *d_vals = nullptr;
+    void *tmp = nullptr, *d_work = nullptr;
+    const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+    auto body = [&]() -> pvs_status {
+        for (uint32_t **p : {&d_key, &d_pos, &d_key_s, &d_pos_s}) HIP_TRY(pvs_scratch_alloc((void **)p, (size_t)m * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_sub_off, ((size_t)m + 1) * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_sub_slot, (size_t)m * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_head, m));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_num, 4));
+        if (d_weights) HIP_TRY(pvs_scratch_alloc((void **)&d_wsub, (size_t)m * 4));
+        hipLaunchKernelGGL(k_list_group_keys, dim3((m + 255) / 256), dim3(256), 0, s, d_list, m, ix->d_row_gidx, d_weights, d_key, d_pos, d_wsub);
+        size_t tb = 0, tb2 = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_key, d_key_s, d_pos, d_pos_s, (int)m));
+        hipcub::CountingInputIterator<uint32_t> it(0);
+        HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, tb2, it, d_head, d_sub_off, d_num, (int)m, s));
+        HIP_TRY(pvs_scratch_alloc(&tmp, std::max<size_t>(std::max(tb, tb2), 16)));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tb, d_key, d_key_s, d_pos, d_pos_s, (int)m, 0, 32, s));  // stable: positions ascending inside a group
+        hipLaunchKernelGGL(k_group_heads, dim3((m + 255) / 256), dim3(256), 0, s, d_key_s, m, d_head);
+        HIP_TRY(hipcub::DeviceSelect::Flagged(tmp, tb2, it, d_head, d_sub_off, d_num, (int)m, s));
+        uint32_t n_sub = 0;
+        HIP_TRY(hipMemcpyAsync(&n_sub, d_num, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!pvs_sub_rank_supported(n_sub)) return PVS_OK;  // (not handled)
+        hipLaunchKernelGGL(k_sub_slots, dim3((n_sub + 255) / 256), dim3(256), 0, s, d_key_s, d_sub_off, n_sub, m, d_sub_slot, d_sub_off + n_sub);
+        const uint32_t chunk = std::min<uint32_t>(batch, PVS_MAX_BATCH);
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)m * chunk * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_vals, (size_t)n_sub * chunk * 8));
+        HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(chunk)));
+        const size_t off_g = 64, off_v = off_g + (size_t)chunk * k * 8, off_f = off_v + (size_t)chunk * k * 8, off_c = off_f + (size_t)chunk * 4, need = off_c + (size_t)chunk * 4;
+        PVS_TRY(ctx_pinned_io(c, need));
+        const uint32_t qbytes = ix->dim * (ix->dtype == PVS_I8 ? 1u : 4u), qpad = (qbytes + 63u) & ~63u;
+        *(volatile uint32_t *)c.h_io = 0;  // (the scorer's list-validity word: the list comes from a compacted mask, it stays 0)
+        for (uint32_t q0 = 0; q0 < batch; q0 += chunk) {
+            const uint32_t nb = std::min(chunk, batch - q0);
+            const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+            PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, q0, nb, pad, metric));
+            uint32_t qt = 1;
+            while (qt * 2 <= nb && qt * 2 * qpad <= 32768 && qt * 2 <= 64) qt *= 2;
+            const dim3 g((m + 256 / qt - 1) / (256 / qt), (nb + qt - 1) / qt);
+            const size_t lds = (size_t)qt * qpad;
+#define PVS_SPARSE_SCORE(DT)                                                                                                                                  \
+    hipLaunchKernelGGL(k_sparse_score<DT>, g, dim3(256), lds, s, ix->d_rows, ix->stride, (int)ix->dim, metric, ix->d_norm2, d_list, m, ix->n, c.d_qexact, c.d_qinfo, \
+                       nb, qt, qpad, d_m, nb, (uint32_t *)c.h_io)
+            if (ix->dtype == PVS_I8)
+                PVS_SPARSE_SCORE(PVS_I8);
+            else if (ix->dtype == PVS_F16)
+                PVS_SPARSE_SCORE(PVS_F16);
+            else
+                PVS_SPARSE_SCORE(PVS_F32);
+#undef PVS_SPARSE_SCORE
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, 0, d_sub_off, d_pos_s, n_sub, d_wsub, nullptr, agg, d_vals, s));
+            HIP_TRY(pvs_sub_rank(d_vals, n_sub, nb, k, d_sub_slot, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
+                                 (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), (uint32_t *)(c.h_io + off_c), s));
+            HIP_TRY(hipStreamSynchronize(s));
+            const uint32_t *fl = (const uint32_t *)(c.h_io + off_f), *cn = (const uint32_t *)(c.h_io + off_c);
+            for (uint32_t q = 0; q < nb; q++)
+                if (!fl[q]) return PVS_OK;  // (not handled: the caller's corpus pass answers the whole call)
+            memcpy(out_groups + (size_t)q0 * k, c.h_io + off_g, (size_t)nb * k * 8);
+            memcpy(out_values + (size_t)q0 * k, c.h_io + off_v, (size_t)nb * k * 8);
+            memcpy(out_count + q0, cn, (size_t)nb * 4);
+        }
+        *handled = true;
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) (void)hipStreamSynchronize(s);
+    for (void *p : {(void *)d_key, (void *)d_pos, (void *)d_key_s, (void *)d_pos_s, (void *)d_sub_off, (void *)d_sub_slot, (void *)d_head, (void *)d_num, (void *)d_wsub,
+                    (void *)d_m, (void *)d_vals, tmp, d_work})
+        pvs_scratch_free(p);
+    if (st == PVS_OK && *handled) ix->sparse_queries += batch;
     return st;
 }

@@ -349,3 +349,120 @@ def test_a_thousand_listed_rows_of_ten_million_cost_what_the_list_costs(pvs):
     ix.close()
     assert st.dense_queries == 0, "neither route may use the dense path (the short page is completed from the NULL list)"
     assert ms_list < 0.15, f"{ms_list:.3f} ms for a 1,000-row candidate list"
+
+
+def _check_groups(got, exp, tag):
+    og, ov, oc = got
+    eg, ev = exp
+    assert oc == len(eg), (tag, oc, len(eg))
+    assert np.array_equal(og[:oc], eg), tag
+    a = ov[:oc]
+    assert np.array_equal(np.isnan(a), np.isnan(ev)), tag
+    assert np.array_equal(a[~np.isnan(a)].view(np.uint64), ev[~np.isnan(ev)].view(np.uint64)), tag
+    assert (og[oc:] == -1).all() and np.isnan(ov[oc:]).all(), tag
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+@pytest.mark.parametrize("runs", [True, False])
+def test_per_item_pages_over_a_sparse_candidate_mask(pvs, dtype, runs):
+    """pvs_search_groups_filtered under a mask that leaves few rows: the listed rows scored, brought together per file in row
+    order, aggregated (MIN / MAX / AVG / weighted AVG) and ranked without a corpus pass — against the oracle over the allowed rows;
+    the corpus-pass answer (pvs_debug_set("no_sparse", 1)) is the same page, bit for bit."""
+    dt = _dt(pvs, dtype)
+    rng = np.random.default_rng(7 + int(runs))
+    dim = 768 if dtype == "i8" else 96
+    sizes = rng.choice([1, 2, 3, 5, 9, 40], 6000)
+    grp = np.repeat(np.arange(len(sizes), dtype=np.int64) * 3 + 11, sizes)
+    if not runs:
+        grp = grp[rng.permutation(len(grp))]  # a file's rows scattered over the corpus
+    n = len(grp)
+    base = orc.synth_rows(901, 0, 300, dim)
+    rows = (base[rng.integers(0, 300, n)] + 0.05 * orc.synth_rows(902, 0, n, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 40)] = 0.0            # NULL cosine distances
+    rows[100:140] = rows[99]                      # exact ties
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(dt, dim)
+    if dt == pvs.I8:
+        ix.set_scale(scale)
+    ix.add_f32(rows, group_ids=grp)
+    hc = _host(dt, rows, scale)
+    w = (rng.random(n) + 0.1).astype(np.float32)
+    keys = (grp % 5).astype(np.int64)
+    for nb, frac in ((1, 0.004), (3, 0.02), (40, 0.002)):
+        q = orc.synth_rows(903 + nb, 0, nb, dim)
+        hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+        mask = (rng.random(n) < frac).astype(np.uint8)
+        mask[100:140] = 1
+        allowed = np.nonzero(mask)[0]
+        for keyed in (False, True):
+            ix.set_order_keys(keys if keyed else None)
+            for metric in (pvs.COSINE, pvs.L2):
+                for agg, oagg, ww in ((pvs.AGG_MIN, orc.AGG_MIN, None), (pvs.AGG_MAX, orc.AGG_MAX, None), (pvs.AGG_AVG, orc.AGG_AVG, None), (pvs.AGG_AVG, orc.AGG_AVG, w)):
+                    for k in (10, 700):
+                        s0 = ix.stats()
+                        got = ix.search_groups_filtered(hq, k, mask, metric, agg, row_weights=ww)
+                        s1 = ix.stats()
+                        assert s1.sparse_queries == s0.sparse_queries + nb and s1.dense_queries == s0.dense_queries, (nb, keyed, metric, agg, k)
+                        for j in sorted({0, nb - 1}):
+                            exp = orc.search_groups(dt, metric, hc[allowed], hq[j], grp[allowed], oagg, k, weights=None if ww is None else ww[allowed],
+                                                    order_keys=keys[allowed] if keyed else None)
+                            _check_groups((got[0][j], got[1][j], got[2][j]), exp, (dtype, runs, nb, keyed, metric, agg, ww is not None, k, j))
+                    pvs.debug_set("no_sparse", 1)
+                    try:
+                        old = ix.search_groups_filtered(hq, 10, mask, metric, agg, row_weights=ww)
+                    finally:
+                        pvs.debug_set("no_sparse", 0)
+                    new = ix.search_groups_filtered(hq, 10, mask, metric, agg, row_weights=ww)
+                    assert np.array_equal(old[0], new[0]) and np.array_equal(old[2], new[2])
+                    assert np.array_equal(old[1].view(np.uint64), new[1].view(np.uint64))
+    # nothing allowed: empty pages
+    og, ov, oc = ix.search_groups_filtered(hq, 5, np.zeros(n, np.uint8), pvs.COSINE, pvs.AGG_AVG)
+    assert (oc == 0).all() and (og == -1).all() and np.isnan(ov).all()
+
+
+def test_per_item_page_of_a_thousand_rows_of_four_million(pvs):
+    """The per-item form of the item-2 case: a 1,000-row candidate mask over 4M x 768 int8 (1M files of 4 rows), AVG, k = 100 —
+    the cost of the mask (one byte per row streamed and compacted) plus the listed rows, not of the corpus; same page as the
+    corpus pass.  Times printed, the sparse one checked with a margin."""
+    import ctypes as C
+
+    from panoptikon_amd import _lib as L
+
+    n, dim, k = 4_000_000, 768, 100
+    scale = 0.0015
+    ix = pvs.VectorIndex(pvs.I8, dim, capacity_rows=n)
+    ix.set_scale(scale)
+    stage = pvs.DeviceBuffer(1_000_000 * dim * 4)
+    for off in range(0, n, 1_000_000):
+        L.check(pvs.lib().pvs_synth_rows_f32(0, 20260929, off, 1_000_000, dim, stage.ptr))
+        g = (np.arange(off, off + 1_000_000, dtype=np.int64) // 4)
+        L.check(pvs.lib().pvs_index_add_f32(ix._h, stage.ptr, 1_000_000, None, g.ctypes.data_as(C.c_void_p), L.DEVICE))
+    stage.free()
+    rng = np.random.default_rng(1)
+    lst = np.sort(rng.choice(n, 1000, replace=False))
+    mask = np.zeros(n, np.uint8)
+    mask[lst] = 1
+    q = orc.synth_rows(0x5EED0001, 0, 4, dim)
+    hq = orc.quantize_int8(q, scale)
+    got = ix.search_groups_filtered(hq, k, mask, pvs.COSINE, pvs.AGG_AVG)
+    sub = np.stack([ix.read_rows(int(r), 1)[0] for r in lst])
+    for j in range(4):
+        exp = orc.search_groups(pvs.I8, pvs.COSINE, sub, hq[j], lst // 4, orc.AGG_AVG, k)
+        _check_groups((got[0][j], got[1][j], got[2][j]), exp, ("4M", j))
+    def timed(reps):
+        t = time.perf_counter()
+        for _ in range(reps):
+            ix.search_groups_filtered(hq, k, mask, pvs.COSINE, pvs.AGG_AVG)
+        return (time.perf_counter() - t) / reps * 1e3
+    timed(5)
+    ms_sparse = timed(20)
+    pvs.debug_set("no_sparse", 1)
+    try:
+        old = ix.search_groups_filtered(hq, k, mask, pvs.COSINE, pvs.AGG_AVG)
+        timed(2)
+        ms_scan = timed(5)
+    finally:
+        pvs.debug_set("no_sparse", 0)
+    assert np.array_equal(old[0], got[0]) and np.array_equal(old[1].view(np.uint64), got[1].view(np.uint64))
+    print(f"\nper-item page, 1,000 allowed rows of 4M x 768 int8, 4 queries, host mask: sparse {ms_sparse:.3f} ms, corpus pass {ms_scan:.3f} ms")
+    assert ms_sparse < ms_scan
