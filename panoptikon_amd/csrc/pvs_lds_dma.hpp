@@ -21,6 +21,24 @@ __device__ static inline void dma16(const void *sbase, uint32_t voff, uint32_t l
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+// N contiguous 1-KiB pieces behind one M0 write: the immediate offset moves the global source and the LDS destination alike
+// (tools/probe/dma_offset_test.hip)
+template <int N>
+__device__ static inline void dma16_group(const void *sbase, uint32_t voff, uint32_t lds_dst) {
+    static_assert(N >= 1 && N <= 4, "13-bit signed immediate");
+    uint32_t keep;
+    if constexpr (N == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else if constexpr (N == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 nt\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ static inline void dma4(const void *sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile(

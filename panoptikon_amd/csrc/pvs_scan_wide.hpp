@@ -220,9 +220,18 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
             }
         };
         auto issue_part = [&](int part) __attribute__((always_inline)) {  // compile-time part: 0..PPW-1 = this wave's row pieces, PPW = the tile record (wave 0)
-            if (part < PPW)
-                dma16(is_src + part * 1024, voff, is_dst + part * 1024);
-            else if (wave == 0)
+            if (part < PPW) {  // the wave's pieces are contiguous at both ends: one M0 write per 4 KiB (the immediate offset moves source and destination)
+                if (part % 4 == 0) {
+                    if (PPW - part >= 4)
+                        dma16_group<4>(is_src + part * 1024, voff, is_dst + part * 1024);
+                    else if (PPW - part == 3)
+                        dma16_group<3>(is_src + part * 1024, voff, is_dst + part * 1024);
+                    else if (PPW - part == 2)
+                        dma16_group<2>(is_src + part * 1024, voff, is_dst + part * 1024);
+                    else
+                        dma16_group<1>(is_src + part * 1024, voff, is_dst + part * 1024);
+                }
+            } else if (wave == 0)
                 dma16(is_srec, recvoff, is_rec);
         };
 #pragma unroll
