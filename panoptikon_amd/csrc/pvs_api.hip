@@ -25,6 +25,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
+    "prelude_stream",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -334,6 +335,7 @@ void ctx_release(SearchCtx &c) {
     pvs_group_work_release(c.gwork);
     if (c.done) hipEventDestroy(c.done);
     if (c.scanned) hipEventDestroy(c.scanned);
+    if (c.preluded) hipEventDestroy(c.preluded);
     hipFree(c.d_loc_rec);
     hipFree(c.d_all_rec);
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
@@ -366,6 +368,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
     c.cur_mask = nullptr;
     if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     if (!c.scanned) HIP_TRY(hipEventCreateWithFlags(&c.scanned, hipEventDisableTiming));
+    if (!c.preluded) HIP_TRY(hipEventCreateWithFlags(&c.preluded, hipEventDisableTiming));
     c.side_finalize = false;
     if (!c.d_qmat) {
         HIP_TRY(pvs_malloc_retry((void **)&c.d_qin, (size_t)PVS_SCAN_MAX_BATCH * ix->dim * 4));
@@ -448,6 +451,7 @@ PVS_EXPORT pvs_status pvs_index_create(const pvs_index_desc *desc, pvs_index **o
     hipError_t e = hipStreamCreateWithFlags(&ix->admin_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->search_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->fin_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->pre_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ix;
@@ -550,6 +554,7 @@ PVS_EXPORT void pvs_index_destroy(pvs_index *ix) {
     if (ix->admin_stream) hipStreamDestroy(ix->admin_stream);
     if (ix->search_stream) hipStreamDestroy(ix->search_stream);
     if (ix->fin_stream) hipStreamDestroy(ix->fin_stream);
+    if (ix->pre_stream) hipStreamDestroy(ix->pre_stream);
     if (ix->comm_stream) hipStreamDestroy(ix->comm_stream);
     pvs_scratch_trim(ix->device);
     delete ix;

@@ -26,6 +26,7 @@ struct SearchCtx {
     hipStream_t stream = nullptr;      // the stream this context launches on (shared or own)
     hipStream_t own_stream = nullptr;
     hipEvent_t done = nullptr;         // recorded after the last launch of a search
+    hipEvent_t preluded = nullptr;     // recorded behind the k-th select when query prep / pass A / the select run on the index's prelude stream
     hipEvent_t scanned = nullptr;      // recorded behind pass B when pass C runs on the index's side stream
     bool side_finalize = false;        // this search's pass C went to ix->fin_stream (c.done was recorded there)
     bool busy = false;
@@ -188,6 +189,7 @@ struct pvs_index {
     SearchCtx ctx[NCTX];
     hipStream_t admin_stream = nullptr;
     hipStream_t search_stream = nullptr;
+    hipStream_t pre_stream = nullptr;   // query prep, pass A and the k-th select of a pipelined caller's search: they fill the tail of the PREVIOUS search's pass B
     hipStream_t fin_stream = nullptr;   // pass C of a pipelined caller's search: runs beside the NEXT search's scan (search_enqueue)
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
@@ -250,7 +252,7 @@ pvs_status coalesce_call(pvs_index *ix, int kind, int agg, const void *queries, 
 pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric);
 bool fast_path_ok(const pvs_index *ix, uint32_t k);
 pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb, uint32_t batch_pad,
-                      int metric);
+                      int metric, hipStream_t on = nullptr);
 // block == false: returns nullptr (and sets the error) when every context is taken
 SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket, bool block = true);
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,

@@ -49,11 +49,11 @@ static pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k,
 }
 
 pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t qoff, uint32_t nb,
-                             uint32_t batch_pad, int metric) {
+                             uint32_t batch_pad, int metric, hipStream_t on) {
     const size_t qesz = qdtype == PVS_I8 ? 1 : 4;
     const uint8_t *qsrc = (const uint8_t *)d_queries + (size_t)qoff * ix->dim * qesz;
     HIP_TRY(pvs_launch_prep_queries((int)ix->dtype, qdtype, qsrc, nb, batch_pad, ix->dim, ix->stride, ix->scale, metric, c.d_qmat,
-                                    c.d_qexact, c.d_qinfo, c.d_need_dense + qoff, c.stream));
+                                    c.d_qexact, c.d_qinfo, c.d_need_dense + qoff, on ? on : c.stream));
     return PVS_OK;
 }
 
@@ -63,7 +63,8 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 // few tile streams) — with pass B appending to per-query flat lists through atomic counters; the other queries' thresholds
 // are voided so that they emit nothing, and pass C finalises the handed-back ones only.
 static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff, uint32_t nb, uint32_t batch_pad, uint32_t k, int metric,
-                                     int64_t *oid, float *od, uint32_t *oc, bool flat_rerun, bool side = false) {
+                                     int64_t *oid, float *od, uint32_t *oc, bool flat_rerun, bool side = false, hipStream_t prelude = nullptr) {
+    // prelude: pass A and the k-th select go to that stream (the caller queued the query prep there), pass B waits for them
     ScanArgs a;
     a.dtype = (int)ix->dtype;
     a.metric = metric;
@@ -123,10 +124,15 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     a.gmin_per_lane = pvs_scan_gmin_max(a.dtype, a.qgroups, a.kslabs);
     while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k_sel, 1024)) a.gmin_per_lane /= 2;
     a.groups_per_query = a.grid * spp * a.gmin_per_lane;
-    span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows);
-    HIP_TRY(pvs_launch_scan(a, c.stream));
-    span_end(ix, c);
-    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, c.stream, c.d_qinfo, metric));
+    hipStream_t ps = prelude ? prelude : c.stream;
+    span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows, ps);
+    HIP_TRY(pvs_launch_scan(a, ps));
+    span_end(ix, c, ps);
+    HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, ps, c.d_qinfo, metric));
+    if (prelude) {
+        HIP_TRY(hipEventRecord(c.preluded, prelude));
+        HIP_TRY(hipStreamWaitEvent(c.stream, c.preluded, 0));
+    }
     if (flat_rerun) {
         HIP_TRY(pvs_launch_void_thresholds(c.d_thr, c.d_need_dense + qoff, nb, c.stream));  // queries not handed back emit nothing
         HIP_TRY(hipMemsetAsync(c.d_flat_cnt, 0, 4 * (size_t)PVS_SCAN_MAX_BATCH, c.stream));
@@ -223,7 +229,16 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
     for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
         const uint32_t nb = std::min(pass_max, batch - qoff);
         const uint32_t batch_pad = nb <= 32 ? 32 : nb <= 64 ? 64 : nb <= 128 ? 128 : 256;
-        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric));
+        // Experiment, off by default (pvs_debug_set("prelude_stream", 1)): query prep, pass A and the k-th select of a pipelined
+        // caller's search on a stream of their own, so that pass A's workgroups (a whole CU's LDS each, like pass B's) start where the
+        // PREVIOUS search's pass B has finished its share (its workgroups end 80-140 us apart) and this search's pass B follows that
+        // one directly.  Measured at configs[2] (same box, alternating): pass B 1.20 ms instead of 1.22, but the step 1.354-1.374 ms
+        // instead of 1.303-1.312 (93.2-94.6 k q/s against 97.6-98.2 k; 3 or 4 searches in flight: the same) — the two cross-queue
+        // event waits per search cost more than the ~60 us of sample + select they hide.
+        const bool side = fast && side_finalize && batch <= pass_max && ix->dtype == PVS_I8 && !ix->multi_stream && c.stream == ix->search_stream &&
+                          !pvs_dbg(PVS_DBG_NO_SIDE_FINALIZE);
+        hipStream_t prelude = side && !c.cur_mask && pvs_dbg(PVS_DBG_PRELUDE_STREAM) ? ix->pre_stream : nullptr;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric, prelude));
         int64_t *oid = d_out_ids + (size_t)qoff * k;
         float *od = d_out_dist + (size_t)qoff * k;
         uint32_t *oc = d_out_count + qoff;
@@ -250,10 +265,8 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
             for (uint32_t q = 0; q < nb; q++) PVS_TRY(dense_one(ix, c, q, k, metric, oid + (size_t)q * k, od + (size_t)q * k, oc + q));
             continue;
         }
-        // (one chunk only: a second chunk's query prep would overwrite what the first one's pass C still reads)
-        const bool side = side_finalize && batch <= pass_max && ix->dtype == PVS_I8 && !ix->multi_stream && c.stream == ix->search_stream &&
-                          !pvs_dbg(PVS_DBG_NO_SIDE_FINALIZE);
-        PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false, side));
+        // (side: one chunk only — a second chunk's query prep would overwrite what the first one's pass C still reads)
+        PVS_TRY(enqueue_fast_chunk(ix, c, qoff, nb, batch_pad, k, metric, oid, od, oc, false, side, prelude));
     }
     // (pass C wrote its verdicts and candidate counts straight into c.h_need_dense: FinalizeArgs.h_flags)
     HIP_TRY(hipEventRecord(c.done, c.side_finalize ? ix->fin_stream : c.stream));
@@ -925,6 +938,7 @@ PVS_EXPORT pvs_status pvs_search_device(pvs_index *ix, const void *d_queries, pv
     if (st == PVS_OK) st = search_enqueue(ix, *c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count, &fast, true);
     if (st != PVS_OK) {
         (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(ix->pre_stream);
         (void)hipStreamSynchronize(ix->fin_stream);
         ctx_done(ix, c);
         return st;
