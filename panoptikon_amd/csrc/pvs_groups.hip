@@ -598,3 +598,120 @@ void pvs_group_work_release(GroupWork &w) {
     hipFree(w.temp);
     w = GroupWork();
 }
+
+// ---- per-item pages of a multi-device index, merged on devices[0] (pvs_multi.hip: multi_search_groups / multi_similar_to) ----------
+// The second sort key of every entry of a shard's page [batch][k]: the group's slot by binary search in the shard's id-ordered
+// group list, its key from the per-group key array (pvs_index_set_order_keys; a group's key is its first row's).
+__global__ __launch_bounds__(256) void k_page_group_keys(const int64_t *page_groups, const uint32_t *counts, uint32_t batch, uint32_t k, const int64_t *grp_ids,
+                                                         uint32_t G, const int64_t *grp_key, int64_t *out_keys) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch * k) return;
+    const uint32_t q = t / k, i = t - q * k;
+    int64_t key = 0;
+    if (i < counts[q] && G) {
+        const int64_t g = page_groups[t];
+        uint32_t lo = 0, hi = G;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (grp_ids[mid] < g) lo = mid + 1; else hi = mid;
+        }
+        if (lo < G && grp_ids[lo] == g) key = grp_key[lo];
+    }
+    out_keys[t] = key;
+}
+hipError_t pvs_launch_page_group_keys(const int64_t *page_groups, const uint32_t *counts, uint32_t batch, uint32_t k, const int64_t *grp_ids, uint32_t G,
+                                      const int64_t *grp_key, int64_t *out_keys, hipStream_t s) {
+    if (batch * k == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_page_group_keys, dim3((batch * k + 255) / 256), dim3(256), 0, s, page_groups, counts, batch, k, grp_ids, G, grp_key, out_keys);
+    return hipGetLastError();
+}
+// S shard pages [S][batch][k] (groups, f64 values, keys or nullptr, counts [S][batch]) -> the first k of their union per query under
+// the page order (value ascending, NULL last, key DESCENDING, group id ascending).  The shards hold disjoint groups (placement by
+// group), so there is nothing to fold.  One workgroup per query, one LDS sort: S * k <= PVS_GROUP_MERGE_MAX entries.
+constexpr uint32_t GMERGE_THREADS = 256;
+__global__ __launch_bounds__(256) void k_merge_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch,
+                                                           uint32_t k, uint32_t cap, int64_t *out_g, double *out_v, uint32_t *out_c) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t gm_smem[];
+    uint64_t *const s_v = (uint64_t *)gm_smem;   // [cap] sortable value bits
+    uint64_t *const s_k = s_v + cap;              // [cap] ~key (so that ascending = key descending)
+    int64_t *const s_g = (int64_t *)(s_k + cap);  // [cap]
+    uint32_t *const s_at = (uint32_t *)(s_g + cap);  // [cap] where the entry came from (its value is written back as it was stored)
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const size_t elems = (size_t)batch * k;
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < S; s++) total += min(cnt[(size_t)s * batch + q], k);
+    for (uint32_t e = tid; e < cap; e += GMERGE_THREADS) {
+        // entry e of the concatenation of the shards' pages
+        uint32_t s = 0, base = 0;
+        bool have = false;
+        for (; s < S; s++) {
+            const uint32_t c = min(cnt[(size_t)s * batch + q], k);
+            if (e < base + c) {
+                have = true;
+                break;
+            }
+            base += c;
+        }
+        if (have) {
+            const size_t at = s * elems + (size_t)q * k + (e - base);
+            const double val = v[at] == 0.0 ? 0.0 : v[at];  // (-0 and +0 tie, as they do under the host's comparison)
+            uint64_t b = (uint64_t)__double_as_longlong(val);
+            b = val != val ? ~0ull - 1 : ((b >> 63) ? ~b : (b | 0x8000000000000000ull));  // NULL: behind every value, in front of the padding
+            s_v[e] = b;
+            s_k[e] = key ? ~((uint64_t)key[at] ^ 0x8000000000000000ull) : 0;
+            s_g[e] = g[at];
+            s_at[e] = (uint32_t)at;
+        } else {
+            s_v[e] = ~0ull;
+            s_k[e] = ~0ull;
+            s_g[e] = 0x7fffffffffffffffll;
+            s_at[e] = 0;
+        }
+    }
+    __syncthreads();
+    for (uint32_t sz = 2; sz <= cap; sz <<= 1)
+        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
+            for (uint32_t i = tid; i < cap; i += GMERGE_THREADS) {
+                const uint32_t j = i ^ st;
+                if (j > i) {
+                    const bool up = (i & sz) == 0;
+                    const bool gt = s_v[i] != s_v[j] ? s_v[i] > s_v[j] : s_k[i] != s_k[j] ? s_k[i] > s_k[j] : s_g[i] > s_g[j];
+                    if (gt == up) {
+                        const uint64_t a = s_v[i], b = s_k[i];
+                        const int64_t c = s_g[i];
+                        const uint32_t d = s_at[i];
+                        s_v[i] = s_v[j]; s_k[i] = s_k[j]; s_g[i] = s_g[j]; s_at[i] = s_at[j];
+                        s_v[j] = a; s_k[j] = b; s_g[j] = c; s_at[j] = d;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const uint32_t nout = min(total, k);
+    for (uint32_t i = tid; i < k; i += GMERGE_THREADS) {
+        if (i < nout) {
+            out_g[(size_t)q * k + i] = s_g[i];
+            out_v[(size_t)q * k + i] = v[s_at[i]];
+        } else {
+            out_g[(size_t)q * k + i] = -1;
+            out_v[(size_t)q * k + i] = __builtin_nan("");
+        }
+    }
+    if (tid == 0) out_c[q] = nout;
+}
+bool pvs_merge_group_pages_supported(uint32_t S, uint32_t k) { return (uint64_t)S * k <= 4096; }
+hipError_t pvs_launch_merge_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch, uint32_t k,
+                                        int64_t *out_g, double *out_v, uint32_t *out_c, hipStream_t s) {
+    if (batch == 0) return hipSuccess;
+    uint32_t cap = 64;
+    while (cap < S * k) cap <<= 1;
+    const size_t lds = (size_t)cap * 28;
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_merge_group_pages, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 28);
+        if (e != hipSuccess) return e;
+        configured.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(k_merge_group_pages, dim3(batch), dim3(GMERGE_THREADS), lds, s, g, v, key, cnt, S, batch, k, cap, out_g, out_v, out_c);
+    return hipGetLastError();
+}

@@ -193,6 +193,18 @@ struct pvs_index {
     hipStream_t fin_stream = nullptr;   // pass C of a pipelined caller's search: runs beside the NEXT search's scan (search_enqueue)
     hipStream_t comm_stream = nullptr;  // multi-stream mode: every collective of every context, in program order
     bool multi_stream = false;
+    // multi-device parent, per-item work on the devices: every shard's global rows in its local order, resident on devices[0]
+    // (pvs_launch_take_rows splits device-space masks there), and pinned page blocks the shards' per-item pages land in and
+    // devices[0] merges from (pvs_launch_merge_group_pages)
+    std::vector<uint32_t *> d_shard_rows;
+    uint64_t shard_rows_n = 0;
+    struct PageBlock {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        bool busy = false;
+    };
+    std::vector<PageBlock> page_blocks;
+    int64_t *d_grp_key = nullptr;  // per group, in id order: its second sort key (with pvs_index_set_order_keys)
     bool by_group = false;  // multi-device parent: rows are placed by group (group_ids given to every add): per-item operators are shard-local
     bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};

@@ -18,6 +18,8 @@ pvs_status ensure_groups(pvs_index *ix) {
     hipFree(ix->d_tile_grp);
     hipFree(ix->d_straddlers);
     hipFree(ix->d_row_gidx);
+    hipFree(ix->d_grp_key);
+    ix->d_grp_key = nullptr;
     ix->d_grp_off = ix->d_grp_rows = ix->d_grp_tinv = ix->d_grp_trank = ix->d_straddlers = ix->d_row_gidx = nullptr;
     ix->d_grp_ids = nullptr;
     ix->d_tile_grp = nullptr;
@@ -106,6 +108,8 @@ pvs_status ensure_groups(pvs_index *ix) {
         for (uint32_t i = 0; i < G; i++) trank[tinv[i]] = i;
         HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_trank, (size_t)G * 4));
         HIP_TRY(hipMemcpy(ix->d_grp_trank, trank.data(), (size_t)G * 4, hipMemcpyHostToDevice));
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_grp_key, (size_t)std::max<uint32_t>(G, 1) * 8));
+        HIP_TRY(hipMemcpy(ix->d_grp_key, gkey.data(), (size_t)G * 8, hipMemcpyHostToDevice));
         ix->h_grp_ids = gids;
         ix->h_grp_key = std::move(gkey);
     }

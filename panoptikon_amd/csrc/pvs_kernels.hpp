@@ -15,6 +15,8 @@ hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint3
                                   uint8_t *rows, uint32_t stride, hipStream_t s);
 hipError_t pvs_launch_rows_gather(const uint8_t *rows, uint32_t stride, uint32_t row_bytes, uint64_t row0, uint64_t n, uint8_t *dst,
                                   hipStream_t s);
+hipError_t pvs_launch_pick_rows(const void *src, uint32_t row_bytes, const uint32_t *idx, uint64_t m, void *dst, hipStream_t s);
+hipError_t pvs_launch_take_rows(const void *in, uint32_t elem_bytes, const uint32_t *global_row, uint64_t n_local, void *out, hipStream_t s);
 hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s);
 hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s);
 hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s);
@@ -246,6 +248,11 @@ bool pvs_sub_rank_supported(uint32_t n_sub);
 hipError_t pvs_sub_rank(const double *d_vals, uint32_t n_sub, uint32_t ncol, uint32_t k, const uint32_t *d_sub_slot, const int64_t *d_gids, const uint32_t *d_grp_trank,
                         const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, uint32_t *out_cnt, hipStream_t s);
 // group-major values [n_groups][ncol] -> column-major [ncol][n_groups] (what pvs_group_rank and the page keys index)
+hipError_t pvs_launch_page_group_keys(const int64_t *page_groups, const uint32_t *counts, uint32_t batch, uint32_t k, const int64_t *grp_ids, uint32_t G,
+                                      const int64_t *grp_key, int64_t *out_keys, hipStream_t s);
+bool pvs_merge_group_pages_supported(uint32_t S, uint32_t k);
+hipError_t pvs_launch_merge_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch, uint32_t k,
+                                        int64_t *out_g, double *out_v, uint32_t *out_c, hipStream_t s);
 hipError_t pvs_launch_group_transpose(const double *vals_t, uint32_t n_groups, uint32_t ncol, double *vals, hipStream_t s);
 void pvs_group_work_release(GroupWork &w);
 // order-preserving u64 keys of one column of group values, in group order: value asc, NULL aggregates (~0 - 1) after every value,

@@ -489,3 +489,47 @@ hipError_t pvs_launch_mask_aux(const float *aux, const uint8_t *mask, uint64_t n
     hipLaunchKernelGGL(k_mask_aux, dim3(g), dim3(256), 0, s, aux, mask, n, cap, out);
     return hipGetLastError();
 }
+
+// ---- multi-device index, by-group placement of device-resident rows (pvs_multi.hip): the rows of one add that belong to one shard,
+// picked by index out of the caller's buffer (row-major, row_bytes each) into a dense block
+__global__ __launch_bounds__(256) void k_pick_rows(const uint8_t *src, uint32_t row_bytes, const uint32_t *idx, uint64_t m, uint8_t *dst) {
+    if ((row_bytes & 15u) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+        const uint32_t per = row_bytes >> 4;
+        const uint64_t total = m * per;
+        for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+            const uint64_t r = t / per;
+            const uint32_t c = (uint32_t)(t - r * per);
+            ((uint4 *)dst)[t] = ((const uint4 *)(src + (uint64_t)idx[r] * row_bytes))[c];
+        }
+    } else {
+        const uint64_t total = m * row_bytes;
+        for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+            const uint64_t r = t / row_bytes;
+            dst[t] = src[(uint64_t)idx[r] * row_bytes + (t - r * row_bytes)];
+        }
+    }
+}
+hipError_t pvs_launch_pick_rows(const void *src, uint32_t row_bytes, const uint32_t *idx, uint64_t m, void *dst, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    const uint64_t total = m * (uint64_t)row_bytes / 16 + 1;
+    const unsigned g = (unsigned)std::min<uint64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_pick_rows, dim3(g), dim3(256), 0, s, (const uint8_t *)src, row_bytes, idx, m, (uint8_t *)dst);
+    return hipGetLastError();
+}
+// a per-row array over the GLOBAL rows of a multi-device index -> one shard's local row order: out[l] = in[global_row[l]]
+// (global_row: the shard's rows of the segment table, expanded once per index state)
+template <typename T>
+__global__ __launch_bounds__(256) void k_take_rows(const T *in, const uint32_t *global_row, uint64_t n_local, T *out) {
+    for (uint64_t l = (uint64_t)blockIdx.x * 256 + threadIdx.x; l < n_local; l += (uint64_t)gridDim.x * 256) out[l] = in[global_row[l]];
+}
+hipError_t pvs_launch_take_rows(const void *in, uint32_t elem_bytes, const uint32_t *global_row, uint64_t n_local, void *out, hipStream_t s) {
+    if (n_local == 0) return hipSuccess;
+    const unsigned g = (unsigned)std::min<uint64_t>((n_local + 255) / 256, 16384);
+    if (elem_bytes == 1)
+        hipLaunchKernelGGL(k_take_rows<uint8_t>, dim3(g), dim3(256), 0, s, (const uint8_t *)in, global_row, n_local, (uint8_t *)out);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(k_take_rows<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t *)in, global_row, n_local, (uint32_t *)out);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}

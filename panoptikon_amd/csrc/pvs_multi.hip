@@ -12,6 +12,13 @@
 // Sharding rule: every pvs_index_add call splits its rows into n_devices contiguous pieces.  Row ids stay strictly
 // increasing inside every shard (all a shard needs); global "row order" (pvs_index_read_rows / read_ids /
 // pvs_score_all) is the order of the add calls, kept as a segment table.
+//
+// Per-item work (placement BY GROUP: every row of a file on one shard, multi_add): device-resident rows are placed by a pick
+// kernel per shard on the source device + a peer copy; candidate masks resident on devices[0] are split there by one gather per
+// shard over the expanded segment table (ensure_shard_rows) and reach the shards by peer copies; the shards write their per-item
+// pages into a pinned block, look up the second sort key of the entries on their own device, and devices[0] merges the pages in
+// one LDS sort per query (k_merge_group_pages; S * k <= 4,096, else the host merge).  Row weights arrive in host memory by the
+// ABI and are split there.
 #include <thread>
 
 #include "pvs_index.hpp"
@@ -284,6 +291,12 @@ void multi_destroy(pvs_index *ix) {
         if (!ix->shards.empty()) (void)hipSetDevice(root_device(ix));
         mctx_release(m);
     }
+    if (!ix->shards.empty()) {
+        (void)hipSetDevice(root_device(ix));
+        for (uint32_t *p : ix->d_shard_rows) hipFree(p);
+        for (auto &b : ix->page_blocks)
+            if (b.p) hipHostFree(b.p);
+    }
     for (pvs_index *sh : ix->shards) pvs_index_destroy(sh);
     ix->shards.clear();
     delete ix;
@@ -319,20 +332,18 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
         // reuse the same global rows.  Such an index is poisoned (every later call fails), whatever the failure was.
         bool committed = false;
         auto body = [&]() -> pvs_status {
-        std::vector<uint8_t> host_rows;  // device-space input is staged through the host (build-side cost, once per row)
+        // Device-resident rows never visit the host: the host decides the shard of every row from the group ids it is given
+        // anyway (a list of row positions per shard, 4 bytes a row), a kernel on the source device picks each shard's rows into
+        // a dense block, and the block goes to the shard by a peer copy (or stays, when the shard lives on the source device).
         std::vector<std::vector<uint8_t>> buf(S);
+        std::vector<std::vector<uint32_t>> pick(S);
         std::vector<std::vector<int64_t>> ids(S), grp(S);
         for (uint64_t off = 0; off < n; off += chunk) {
             const uint64_t m = std::min(chunk, n - off);
             const uint8_t *src = (const uint8_t *)rows + off * row_bytes;
-            if (space == PVS_DEVICE) {
-                host_rows.resize(m * row_bytes);
-                HIP_TRY(hipSetDevice(src_dev));
-                HIP_TRY(hipMemcpy(host_rows.data(), src, m * row_bytes, hipMemcpyDeviceToHost));
-                src = host_rows.data();
-            }
             for (uint32_t s = 0; s < S; s++) {
                 buf[s].clear();
+                pick[s].clear();
                 ids[s].clear();
                 grp[s].clear();
             }
@@ -340,7 +351,10 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
             std::vector<uint64_t> taken(S, 0);
             for (uint64_t i = 0; i < m; i++) {
                 const uint32_t s = multi_group_shard(group_ids[off + i], S);
-                buf[s].insert(buf[s].end(), src + i * row_bytes, src + (i + 1) * row_bytes);
+                if (space == PVS_DEVICE)
+                    pick[s].push_back((uint32_t)i);
+                else
+                    buf[s].insert(buf[s].end(), src + i * row_bytes, src + (i + 1) * row_bytes);
                 ids[s].push_back(row_ids ? row_ids[off + i] : ix->id_base + (int64_t)(ix->n + off + i));
                 grp[s].push_back(group_ids[off + i]);
                 const uint64_t local = ix->shards[s]->n + taken[s]++;
@@ -351,7 +365,41 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
             }
             for (uint32_t s = 0; s < S; s++) {
                 if (ids[s].empty()) continue;
-                pvs_status st = add_impl(ix->shards[s], buf[s].data(), from_f32, ids[s].size(), ids[s].data(), grp[s].data(), PVS_HOST);
+                pvs_status st;
+                if (space == PVS_DEVICE) {
+                    const uint64_t ms = ids[s].size();
+                    uint32_t *d_pick = nullptr;
+                    void *d_block = nullptr, *d_there = nullptr;
+                    auto place = [&]() -> pvs_status {
+                        HIP_TRY(hipSetDevice(src_dev));
+                        HIP_TRY(pvs_scratch_alloc((void **)&d_pick, ms * 4));
+                        HIP_TRY(pvs_scratch_alloc(&d_block, ms * row_bytes));
+                        HIP_TRY(hipMemcpy(d_pick, pick[s].data(), ms * 4, hipMemcpyHostToDevice));
+                        HIP_TRY(pvs_launch_pick_rows(src, (uint32_t)row_bytes, d_pick, ms, d_block, nullptr));
+                        HIP_TRY(hipStreamSynchronize(nullptr));
+                        const void *there = d_block;
+                        if (ix->shards[s]->device != src_dev) {
+                            HIP_TRY(hipSetDevice(ix->shards[s]->device));
+                            HIP_TRY(pvs_scratch_alloc(&d_there, ms * row_bytes));
+                            HIP_TRY(hipMemcpyPeer(d_there, ix->shards[s]->device, d_block, src_dev, ms * row_bytes));
+                            there = d_there;
+                        }
+                        return add_impl(ix->shards[s], there, from_f32, ms, ids[s].data(), grp[s].data(), PVS_DEVICE);
+                    };
+                    st = place();
+                    // (add_impl returns with the rows ingested: the blocks are idle — after a failure, once the devices drained)
+                    if (d_there) {
+                        (void)hipSetDevice(ix->shards[s]->device);
+                        if (st != PVS_OK) (void)hipDeviceSynchronize();
+                        pvs_scratch_free(d_there);
+                    }
+                    (void)hipSetDevice(src_dev);
+                    if (st != PVS_OK) (void)hipDeviceSynchronize();
+                    pvs_scratch_free(d_pick);
+                    pvs_scratch_free(d_block);
+                } else {
+                    st = add_impl(ix->shards[s], buf[s].data(), from_f32, ids[s].size(), ids[s].data(), grp[s].data(), PVS_HOST);
+                }
                 committed = true;  // (a failed add may have taken part of its rows too)
                 if (st != PVS_OK) return st;
             }
@@ -658,8 +706,8 @@ bool index_group_key(const pvs_index *ix, int64_t g, int64_t *key) {
 
 // Host merge of the shards' per-item pages [S][batch][k]: duplicates of a group folded to their minimum, then (value asc, NULL
 // last, order key DESC when the index carries keys, group id asc) -> first k
-static void merge_group_pages_host(const pvs_index *ix, const std::vector<int64_t> &g, const std::vector<double> &v, const std::vector<uint32_t> &c,
-                                   uint32_t S, uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+static void merge_group_pages_host(const pvs_index *ix, const int64_t *g, const double *v, const uint32_t *c, uint32_t S, uint32_t batch, uint32_t k,
+                                   int64_t *out_groups, double *out_values, uint32_t *out_count) {
     struct GV {
         double v;
         int64_t g, key;
@@ -760,16 +808,162 @@ static pvs_status merge_row_pages_host(pvs_index *ix, const std::vector<int64_t>
 
 // pvs_search_filtered on a multi-device index: the mask split into the shards' row orders, one masked search per shard (threads),
 // pages merged on the host under (distance asc, id asc, NULL last)
+// ---- per-item work of a multi-device index on the devices --------------------------------------------------------------------
+// Every shard's global rows in its local order, resident on devices[0] (built from the segment table once per index state): a
+// per-row array the caller holds on devices[0] — a candidate mask — is split by one gather per shard there and travels to the
+// shard by a peer copy; it never visits the host.
+static pvs_status ensure_shard_rows(pvs_index *ix) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->shard_rows_n == ix->n && ix->d_shard_rows.size() == ix->shards.size()) return PVS_OK;
+    HIP_TRY(hipSetDevice(root_device(ix)));
+    for (uint32_t *p : ix->d_shard_rows) hipFree(p);
+    ix->d_shard_rows.assign(ix->shards.size(), nullptr);
+    ix->shard_rows_n = 0;
+    std::vector<std::vector<uint32_t>> rows(ix->shards.size());
+    for (size_t s = 0; s < rows.size(); s++) rows[s].reserve(ix->shards[s]->n);
+    for (const MultiSegment &g : ix->segs)
+        for (uint64_t i = 0; i < g.n; i++) rows[g.shard].push_back((uint32_t)(g.row0 + i));
+    for (size_t s = 0; s < rows.size(); s++) {
+        HIP_TRY(pvs_malloc_retry((void **)&ix->d_shard_rows[s], std::max<size_t>(rows[s].size(), 1) * 4));
+        if (!rows[s].empty()) HIP_TRY(hipMemcpy(ix->d_shard_rows[s], rows[s].data(), rows[s].size() * 4, hipMemcpyHostToDevice));
+    }
+    ix->shard_rows_n = ix->n;
+    return PVS_OK;
+}
+// is this device pointer resident on devices[0]?
+static bool on_root(const pvs_index *ix, const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.device == root_device(ix);
+}
+// shard s's part of a per-row byte array on devices[0], on the shard's device (scratch: *to_free holds what to give back)
+static pvs_status shard_mask_device(pvs_index *ix, uint32_t s, const uint8_t *d_mask_root, const uint8_t **out, void **to_free_root, void **to_free_there) {
+    pvs_index *sh = ix->shards[s];
+    const int root = root_device(ix);
+    uint8_t *lm = nullptr;
+    HIP_TRY(hipSetDevice(root));
+    HIP_TRY(pvs_scratch_alloc((void **)&lm, sh->n + 64));
+    *to_free_root = lm;
+    HIP_TRY(pvs_launch_take_rows(d_mask_root, 1, ix->d_shard_rows[s], sh->n, lm, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    *out = lm;
+    if (sh->device != root) {
+        uint8_t *there = nullptr;
+        HIP_TRY(hipSetDevice(sh->device));
+        HIP_TRY(pvs_scratch_alloc((void **)&there, sh->n + 64));
+        *to_free_there = there;
+        HIP_TRY(hipMemcpyPeer(there, sh->device, lm, root, sh->n));
+        *out = there;
+    }
+    return PVS_OK;
+}
+// Pinned page blocks (host memory every device reads and writes at the same address): the shards' per-item pages land in one,
+// devices[0] merges from it.  A small pool: concurrent callers each hold their own.
+struct PageLease {
+    pvs_index *ix = nullptr;
+    int slot = -1;
+    uint8_t *p = nullptr;
+    ~PageLease() {
+        if (slot >= 0) {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            ix->page_blocks[(size_t)slot].busy = false;
+        }
+    }
+};
+static pvs_status page_lease(pvs_index *ix, size_t bytes, PageLease &l) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int slot = -1;
+    for (size_t i = 0; i < ix->page_blocks.size(); i++)
+        if (!ix->page_blocks[i].busy) {
+            slot = (int)i;
+            break;
+        }
+    if (slot < 0) {
+        ix->page_blocks.emplace_back();
+        slot = (int)ix->page_blocks.size() - 1;
+    }
+    auto &b = ix->page_blocks[(size_t)slot];
+    if (b.cap < bytes) {
+        HIP_TRY(hipSetDevice(root_device(ix)));
+        if (b.p) hipHostFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t cap = pvs_round_up(bytes, 1 << 16);
+        HIP_TRY(hipHostMalloc((void **)&b.p, cap, hipHostMallocPortable | hipHostMallocMapped));
+        b.cap = cap;
+    }
+    b.busy = true;
+    l.ix = ix;
+    l.slot = slot;
+    l.p = b.p;
+    return PVS_OK;
+}
+// [S][batch][k] groups | values | keys, [S][batch] counts, then the merged page
+struct GroupPages {
+    int64_t *g = nullptr, *key = nullptr, *og = nullptr;
+    double *v = nullptr, *ov = nullptr;
+    uint32_t *c = nullptr, *oc = nullptr;
+    static size_t bytes(uint32_t S, uint32_t batch, uint32_t k) { return ((size_t)S * 24 + 16) * batch * k + ((size_t)S + 1) * batch * 4 + 64; }
+    void carve(uint8_t *p, uint32_t S, uint32_t batch, uint32_t k) {
+        const size_t e = (size_t)batch * k;
+        g = (int64_t *)p;
+        v = (double *)(g + S * e);
+        key = (int64_t *)(v + S * e);
+        og = key + S * e;
+        ov = (double *)(og + e);
+        c = (uint32_t *)(ov + e);
+        oc = c + (size_t)S * batch;
+    }
+};
+// the shards' pages -> the caller's page: on devices[0] when one LDS sort takes them (S * k <= 4,096), else on the host
+static pvs_status merge_group_pages(pvs_index *ix, GroupPages &pg, bool keyed, uint32_t S, uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values,
+                                    uint32_t *out_count) {
+    if (!pvs_merge_group_pages_supported(S, k) || pvs_dbg(PVS_DBG_MULTI_HOST_PAGES)) {
+        merge_group_pages_host(ix, pg.g, pg.v, pg.c, S, batch, k, out_groups, out_values, out_count);
+        return PVS_OK;
+    }
+    HIP_TRY(hipSetDevice(root_device(ix)));
+    HIP_TRY(pvs_launch_merge_group_pages(pg.g, pg.v, keyed ? pg.key : nullptr, pg.c, S, batch, k, pg.og, pg.ov, pg.oc, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(out_groups, pg.og, (size_t)batch * k * 8);
+    memcpy(out_values, pg.ov, (size_t)batch * k * 8);
+    memcpy(out_count, pg.oc, (size_t)batch * 4);
+    return PVS_OK;
+}
+// the second sort key of every entry of shard s's page, looked up on the shard's device
+static pvs_status shard_page_keys(pvs_index *ix, uint32_t s, GroupPages &pg, uint32_t batch, uint32_t k) {
+    pvs_index *sh = ix->shards[s];
+    const size_t e = (size_t)batch * k;
+    if (!sh->d_grp_key || !sh->d_grp_ids) {
+        memset(pg.key + s * e, 0, e * 8);
+        return PVS_OK;
+    }
+    HIP_TRY(hipSetDevice(sh->device));
+    HIP_TRY(pvs_launch_page_group_keys(pg.g + s * e, pg.c + (size_t)s * batch, batch, k, sh->d_grp_ids, sh->n_groups, sh->d_grp_key, pg.key + s * e, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return PVS_OK;
+}
+
 pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                  const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
     if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
     PVS_TRY(validate_search(ix->shards[0], queries, qdtype, batch, k, metric));
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (batch == 0) return PVS_OK;
+    // (a mask resident on devices[0] is split there and reaches the shards by peer copies: see shard_mask_device)
+    const bool dev_mask = mask && mask_space == PVS_DEVICE && ix->n && ix->n < (1ull << 32) && on_root(ix, mask) && !pvs_dbg(PVS_DBG_MULTI_HOST_PAGES);
     std::vector<uint8_t> stage;
     const uint8_t *hm = nullptr;
-    PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
-    const auto masks = split_rows<uint8_t>(ix, hm);
+    std::vector<std::vector<uint8_t>> masks;
+    if (dev_mask) {
+        PVS_TRY(ensure_shard_rows(ix));
+    } else {
+        PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
+        masks = split_rows<uint8_t>(ix, hm);
+    }
     const uint32_t S = (uint32_t)ix->shards.size();
     const size_t elems = (size_t)batch * k;
     std::vector<int64_t> ids(S * elems);
@@ -777,8 +971,24 @@ pvs_status multi_search_filtered(pvs_index *ix, const void *queries, pvs_dtype q
     std::vector<uint32_t> cnt((size_t)S * batch, 0);
     PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
         if (ix->shards[s]->n == 0) return PVS_OK;
-        return search_host(ix->shards[s], queries, qdtype, batch, k, metric, masks[s].data(), PVS_HOST, ids.data() + s * elems, dist.data() + s * elems,
-                           cnt.data() + (size_t)s * batch);
+        if (!dev_mask)
+            return search_host(ix->shards[s], queries, qdtype, batch, k, metric, masks[s].data(), PVS_HOST, ids.data() + s * elems, dist.data() + s * elems,
+                               cnt.data() + (size_t)s * batch);
+        const uint8_t *m = nullptr;
+        void *free_root = nullptr, *free_there = nullptr;
+        pvs_status st = shard_mask_device(ix, s, mask, &m, &free_root, &free_there);
+        if (st == PVS_OK)
+            st = search_host(ix->shards[s], queries, qdtype, batch, k, metric, m, PVS_DEVICE, ids.data() + s * elems, dist.data() + s * elems,
+                             cnt.data() + (size_t)s * batch);
+        if (free_there) {
+            (void)hipSetDevice(ix->shards[s]->device);
+            pvs_scratch_free(free_there);
+        }
+        if (free_root) {
+            (void)hipSetDevice(root_device(ix));
+            pvs_scratch_free(free_root);
+        }
+        return st;
     }));
     ix->searches++;
     return merge_row_pages_host(ix, ids, dist, cnt, S, batch, k, out_ids, out_dist, out_count);
@@ -879,25 +1089,51 @@ pvs_status multi_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdt
     if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (ix->n && !ix->by_group) return pvs_fail(PVS_ERR_UNSUPPORTED, "per-item search %s", k_need_groups);
     if (batch == 0) return PVS_OK;
+    // a candidate mask resident on devices[0] is split there (one gather per shard) and reaches the shards by peer copies; any other
+    // mask goes through the host as before
+    const bool dev_mask = mask && mask_space == PVS_DEVICE && ix->n && ix->n < (1ull << 32) && on_root(ix, mask) && !pvs_dbg(PVS_DBG_MULTI_HOST_PAGES);
     std::vector<uint8_t> stage;
     const uint8_t *hm = nullptr;
-    PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
+    if (!dev_mask) PVS_TRY(host_mask(ix, mask, mask_space, stage, &hm));
+    if (dev_mask) PVS_TRY(ensure_shard_rows(ix));
     std::vector<std::vector<uint8_t>> masks;
     std::vector<std::vector<float>> weights;
     if (hm) masks = split_rows<uint8_t>(ix, hm);
-    if (row_weights) weights = split_rows<float>(ix, row_weights);
+    if (row_weights) weights = split_rows<float>(ix, row_weights);  // (the ABI takes the weights in host memory: each shard uploads its part)
     const uint32_t S = (uint32_t)ix->shards.size();
     const size_t elems = (size_t)batch * k;
-    std::vector<int64_t> g(S * elems);
-    std::vector<double> v(S * elems);
-    std::vector<uint32_t> c((size_t)S * batch, 0);
+    const bool keyed = ix->order_rows == ix->n && ix->n;
+    PageLease lease;
+    PVS_TRY(page_lease(ix, GroupPages::bytes(S, batch, k), lease));
+    GroupPages pg;
+    pg.carve(lease.p, S, batch, k);
+    memset(pg.c, 0, (size_t)S * batch * 4);
+    const bool dev_merge = pvs_merge_group_pages_supported(S, k) && !pvs_dbg(PVS_DBG_MULTI_HOST_PAGES);
     PVS_TRY(per_shard(ix, [&](uint32_t s) -> pvs_status {
         if (ix->shards[s]->n == 0) return PVS_OK;
-        return search_groups_impl(ix->shards[s], queries, qdtype, batch, k, metric, agg, row_weights ? weights[s].data() : nullptr,
-                                  hm ? masks[s].data() : nullptr, PVS_HOST, g.data() + s * elems, v.data() + s * elems,
-                                  c.data() + (size_t)s * batch);
+        const uint8_t *m = hm ? masks[s].data() : nullptr;
+        pvs_space ms = PVS_HOST;
+        void *free_root = nullptr, *free_there = nullptr;
+        pvs_status st = PVS_OK;
+        if (dev_mask) {
+            st = shard_mask_device(ix, s, mask, &m, &free_root, &free_there);
+            ms = PVS_DEVICE;
+        }
+        if (st == PVS_OK)
+            st = search_groups_impl(ix->shards[s], queries, qdtype, batch, k, metric, agg, row_weights ? weights[s].data() : nullptr, m, ms, pg.g + s * elems,
+                                    pg.v + s * elems, pg.c + (size_t)s * batch);
+        if (st == PVS_OK && keyed && dev_merge) st = shard_page_keys(ix, s, pg, batch, k);
+        if (free_there) {
+            (void)hipSetDevice(ix->shards[s]->device);
+            pvs_scratch_free(free_there);  // (the search returned: nothing in flight reads the mask)
+        }
+        if (free_root) {
+            (void)hipSetDevice(root_device(ix));
+            pvs_scratch_free(free_root);
+        }
+        return st;
     }));
-    merge_group_pages_host(ix, g, v, c, S, batch, k, out_groups, out_values, out_count);
+    PVS_TRY(merge_group_pages(ix, pg, keyed, S, batch, k, out_groups, out_values, out_count));
     ix->searches++;
     return PVS_OK;
 }
@@ -933,7 +1169,19 @@ pvs_status multi_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32
         return similar_core(ix->shards[s], tg, n_targets, excluded[s], k, metric, mine, g.data() + s * elems, v.data() + s * elems, &c[s]);
     }));
     ix->searches++;
-    merge_group_pages_host(ix, g, v, c, S, 1, k, out_groups, out_values, out_count);
+    {
+        const bool keyed = ix->order_rows == ix->n && ix->n;
+        PageLease lease;
+        PVS_TRY(page_lease(ix, GroupPages::bytes(S, 1, k), lease));
+        GroupPages pg;
+        pg.carve(lease.p, S, 1, k);
+        memcpy(pg.g, g.data(), S * elems * 8);
+        memcpy(pg.v, v.data(), S * elems * 8);
+        memcpy(pg.c, c.data(), (size_t)S * 4);
+        if (keyed && pvs_merge_group_pages_supported(S, k) && !pvs_dbg(PVS_DBG_MULTI_HOST_PAGES))
+            for (uint32_t s = 0; s < S; s++) PVS_TRY(shard_page_keys(ix, s, pg, 1, k));
+        PVS_TRY(merge_group_pages(ix, pg, keyed, S, 1, k, out_groups, out_values, out_count));
+    }
     return PVS_OK;
 }
 

@@ -781,3 +781,90 @@ def test_sharded_fusion_orders_score_ties_by_order_key(pvs):
         for b in sh:
             b["index"].close()
 
+
+
+def test_per_item_work_of_a_multi_device_index_stays_on_the_devices(pvs):
+    """rows handed over in HBM are placed by group without visiting the host (a pick kernel per shard + a peer
+    copy), a candidate mask resident on devices[0] is split there by one gather per shard, and the shards' per-item pages are
+    merged by a kernel on devices[0] (with the second sort key looked up on the shards' devices) — all bit-identical to the
+    oracle over the whole corpus and to the host route (pvs_debug_set("multi_host_pages", 1))."""
+    from panoptikon_amd import _lib as L
+
+    rng = np.random.default_rng(31)
+    dim, files, k = 96, 3000, 50
+    per_file = rng.integers(1, 6, files)
+    grp = np.repeat(np.arange(files, dtype=np.int64) * 5 + 3, per_file)
+    n = len(grp)
+    base = orc.synth_rows(401, 0, 60, dim)
+    rows = (base[rng.integers(0, 60, n)] + 0.01 * orc.synth_rows(402, 0, n, dim) * (rng.random((n, 1)) < 0.5)).astype(np.float32)  # ties across files
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    keys = np.repeat(rng.integers(0, 6, files).astype(np.int64), per_file)
+    scale = orc.compute_int8_scale(rows)
+    codes = orc.quantize_int8(rows, scale)
+    q = base[[1, 7, 30, 44]] + 0.02 * orc.synth_rows(403, 0, 4, dim)
+    hq = orc.quantize_int8(q, scale)
+    mask = (rng.random(n) < 0.4).astype(np.uint8)
+    allowed = np.nonzero(mask)[0]
+    w = (rng.random(n) + 0.2).astype(np.float32)
+    for devices in _layouts(pvs):
+        tag = f"devices={devices}"
+        ix = pvs.VectorIndex(pvs.I8, dim, devices=devices)
+        ix.set_scale(scale)
+        # rows resident on devices[0], in three adds (a file may straddle two)
+        for a in range(0, n, 4000):
+            b = min(n, a + 4000)
+            dev = pvs.DeviceBuffer.from_numpy(rows[a:b], devices[0])
+            L.check(pvs.lib().pvs_index_add_f32(ix._h, dev.ptr, b - a, ids[a:b].ctypes.data_as(C.c_void_p), grp[a:b].ctypes.data_as(C.c_void_p), L.DEVICE))
+            dev.free()
+        ri, rg = ix.read_ids(0, n, groups=True)
+        assert np.array_equal(ri, ids) and np.array_equal(rg, grp), tag
+        assert np.array_equal(ix.read_rows(3990, 40), codes[3990:4030]), tag
+        dmask = pvs.DeviceBuffer.from_numpy(mask, devices[0])
+        for keyed in (False, True):
+            ix.set_order_keys(keys if keyed else None)
+            ok = keys if keyed else None
+            for agg, oagg, ww in ((pvs.AGG_MIN, orc.AGG_MIN, None), (pvs.AGG_MAX, orc.AGG_MAX, None), (pvs.AGG_AVG, orc.AGG_AVG, w)):
+                res = {}
+                for host_route in (0, 1):
+                    pvs.debug_set("multi_host_pages", host_route)
+                    try:
+                        og = np.empty((len(hq), k), np.int64)
+                        ov = np.empty((len(hq), k), np.float64)
+                        oc = np.zeros(len(hq), np.uint32)
+                        wp = None if ww is None else ww.ctypes.data_as(C.c_void_p)
+                        L.check(pvs.lib().pvs_search_groups_filtered(ix._h, hq.ctypes.data_as(C.c_void_p), pvs.I8, len(hq), k, pvs.L2, agg, wp, dmask.ptr, L.DEVICE,
+                                                                     og.ctypes.data_as(C.c_void_p), ov.ctypes.data_as(C.c_void_p), oc.ctypes.data_as(C.c_void_p)))
+                        full = ix.search_groups(hq, k, pvs.L2, agg, row_weights=ww)
+                    finally:
+                        pvs.debug_set("multi_host_pages", 0)
+                    res[host_route] = (og, ov, oc, full)
+                    for j in range(len(hq)):
+                        eg, ev = orc.search_groups(orc.I8, orc.L2, codes[allowed], hq[j], grp[allowed], oagg, k, weights=None if ww is None else ww[allowed],
+                                                   order_keys=None if ok is None else ok[allowed])
+                        assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg), (tag, keyed, agg, host_route, j)
+                        assert np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), (tag, keyed, agg, host_route, j)
+                        eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[j], grp, oagg, k, weights=ww, order_keys=ok)
+                        assert full[2][j] == len(eg) and np.array_equal(full[0][j, : len(eg)], eg), (tag, keyed, agg, host_route, j, "unmasked")
+                        assert np.array_equal(full[1][j, : len(eg)].view(np.uint64), ev.view(np.uint64)), (tag, keyed, agg, host_route, j, "unmasked")
+                for x, y in zip(res[0][:3], res[1][:3]):
+                    assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (tag, keyed, agg, "device route == host route")
+            # the row page under the device-resident mask
+            fi = np.empty((len(hq), k), np.int64)
+            fd = np.empty((len(hq), k), np.float32)
+            fc = np.zeros(len(hq), np.uint32)
+            L.check(pvs.lib().pvs_search_filtered(ix._h, hq.ctypes.data_as(C.c_void_p), pvs.I8, len(hq), k, pvs.L2, dmask.ptr, L.DEVICE,
+                                                  fi.ctypes.data_as(C.c_void_p), fd.ctypes.data_as(C.c_void_p), fc.ctypes.data_as(C.c_void_p)))
+            for j in range(len(hq)):
+                d = orc.score_all(orc.I8, orc.L2, codes, hq[j])
+                if keyed:
+                    ei, ed = orc.topk_ordered(d[allowed], k, ids[allowed], keys[allowed])
+                else:
+                    ei, ed = orc.topk(d[allowed], k, ids=ids[allowed])
+                assert fc[j] == k and np.array_equal(fi[j], ei) and np.array_equal(fd[j].view(np.uint32), ed.view(np.uint32)), (tag, keyed, j, "row page")
+        # k beyond one LDS sort of the merge (S * k > 4,096): the host merge answers, same contract
+        kk = 2100
+        og, ov, oc = ix.search_groups(hq[:1], kk, pvs.L2, pvs.AGG_AVG)
+        eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[0], grp, orc.AGG_AVG, kk, order_keys=keys)
+        assert oc[0] == len(eg) and np.array_equal(og[0, : oc[0]], eg) and np.array_equal(ov[0, : oc[0]].view(np.uint64), ev.view(np.uint64)), tag
+        dmask.free()
+        ix.close()
