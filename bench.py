@@ -228,7 +228,8 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
                      "traffic": None, "kernel": "k_score_i8_direct (exact int8 distances of every row for one query: v_dot4 straight from HBM)", "launches": int(sum(p.scan_launches for p in profs)),
                      "avg_launch_ms": round(sum(p.scan_ms for p in profs) / max(sum(p.scan_launches for p in profs), 1), 4),
                      "algorithmic_bytes_per_query": int(bytes_per_query), "scoring_ms_per_query": round(scan_ms, 3),
-                     "whole_query_frac_of_peak": round(bytes_per_query / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                     "whole_query_frac_of_peak": round(bytes_per_query / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "kernel_events": "timed region" if not args.no_kernel_events else "off"},
         "path": {"rrf_path": {1: "bounded fusion", 2: "every group ranked"}.get(int(lib.pvs_rrf_last_path()), "sharded bounded fusion")},
     }
     if not args.no_verify:
@@ -292,6 +293,24 @@ def run_config4(args, ctl, rank, world, device, real_stdout):
                    "ranks; their RRF scores and order (completeness of the page rests on the fusion's bound, proven against the full oracle at N = 1)")
         if rank == 0:
             result["parity"] = {"checked_queries": 1, "groups_and_scores_bit_exact": exact, "how": how, "oracle_seconds": round(time.time() - t_or, 1)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle's literal composition on one host core over a bounded sample of both corpora (the same files in both
+        # branches), extrapolated linearly in the rows: score every row, MIN per file, row_number per branch, RRF, top k
+        import oracle as orc  # (the checker: the cpu_baseline leg only)
+
+        S = min(args.cpu_sample_rows, n_local)
+        gq = queries[0]
+        ora = []
+        for j, b in enumerate(branches):
+            ora.append(dict(dtype=orc.I8, metric=orc.COSINE if b["metric"] == pvs.COSINE else orc.L2, corpus=b["index"].read_rows(0, S),
+                            query=orc.quantize_int8(gq[j][None, :], scales[j])[0], groups=(np.arange(r0, r0 + S, dtype=np.int64) // per_file) * specs[j][5],
+                            agg=orc.AGG_MIN, rrf_k=b["rrf_k"], weight=b["weight"]))
+        t1 = time.perf_counter()
+        orc.rrf_search(ora, K)
+        dt1 = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": round(1.0 / dt1 * S / N, 5), "unit": "queries/s", "cores": 1, "kind": "port",
+                                  "sample": f"oracle composition (scores, MIN per file, row_number, RRF, top-{K}) over the first {S} rows of both corpora, one query "
+                                            f"({dt1:.1f}s measured), extrapolated linearly to {N} rows per branch"}
     if rank == 0:
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()

@@ -12,9 +12,8 @@ except Exception as e:
 PY
 }
 (timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $O/pytest_parity.log 2>&1; echo "rc=$?" >> $O/pytest_parity.log); tail -2 $O/pytest_parity.log | head -1
-for spec in "b128:" "b128_old:PVS_SCAN_NO_WIDE128=1" "b128_l2:--metric l2" "b256:--batch 256" "b128_again:" "b128_old_again:PVS_SCAN_NO_WIDE128=1"; do
-  name=${spec%%:*}; args=${spec#*:}; envs=""
-  case "$args" in PVS_*) envs=$args; args="";; esac
-  env $envs timeout 400 python bench.py $args --steps 30 --warmup 5 --no-cpu-baseline --no-peaks > $O/$name.json 2> $O/$name.err || tail -3 $O/$name.err
+for spec in "b128:" "b128_old:--debug scan_no_wide128=1" "b128_l2:--metric l2" "b256:--batch 256" "b128_again:" "b128_old_again:--debug scan_no_wide128=1"; do
+  name=${spec%%:*}; args=${spec#*:}
+  timeout 400 python bench.py --no-secondary $args --steps 30 --warmup 5 --no-cpu-baseline --no-peaks > $O/$name.json 2> $O/$name.err || tail -3 $O/$name.err
   line $O/$name.json
 done

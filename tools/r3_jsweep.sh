@@ -14,7 +14,7 @@ PY
 for b in 128 256; do
   for spec in "1:16" "2:16" "4:16" "8:16" "4:12" "4:24" "12:16"; do
     j=${spec%%:*}; div=${spec#*:}
-    PVS_SAMPLE_J_DIV=$j PVS_SAMPLE_DIV=$div timeout 300 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-peaks --check-queries 2 > $O/b${b}_j${j}_div$div.json 2> $O/b${b}_j${j}_div$div.err || tail -3 $O/b${b}_j${j}_div$div.err
+    timeout 300 python bench.py --debug sample_j_div=$j --debug sample_div=$div --no-secondary --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-peaks --check-queries 2 > $O/b${b}_j${j}_div$div.json 2> $O/b${b}_j${j}_div$div.err || tail -3 $O/b${b}_j${j}_div$div.err
     line $O/b${b}_j${j}_div$div.json
   done
 done

@@ -13,7 +13,7 @@ PY
 }
 for b in 128 256; do
   for div in 8 12 16 24 32 48; do
-    PVS_SAMPLE_DIV=$div timeout 300 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-peaks --no-verify > $O/b${b}_div$div.json 2> $O/b${b}_div$div.err || tail -3 $O/b${b}_div$div.err
+    timeout 300 python bench.py --debug sample_div=$div --no-secondary --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-peaks --no-verify > $O/b${b}_div$div.json 2> $O/b${b}_div$div.err || tail -3 $O/b${b}_div$div.err
     line $O/b${b}_div$div.json
   done
 done

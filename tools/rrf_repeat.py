@@ -19,10 +19,7 @@ ref = None
 bad = 0
 for it in range(reps):
     for full in (False, True):
-        if full:
-            os.environ["PVS_RRF_FULL"] = "1"
-        else:
-            os.environ.pop("PVS_RRF_FULL", None)
+        pvs.debug_set("rrf_full", 1 if full else 0)
         g, s = pvs.rrf_search(brs, 100)
         if ref is None:
             ref = (g.copy(), s.copy())
