@@ -384,7 +384,7 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
     }
-    if (ix->dtype == PVS_I8 && !c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan — several streams, or the side stream of a pipelined caller)
+    if (!c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan — several streams, or the side stream of a pipelined caller)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));

@@ -55,7 +55,7 @@ enum PvsDbg {
     PVS_DBG_SAMPLE_DIV = 0,        // pass A samples 1/value of the corpus (0: the built-in choice)
     PVS_DBG_SAMPLE_J_DIV,          // threshold = the (k / value)-th sample value (0: 4)
     PVS_DBG_NO_LIGHT_FINALIZE,     // multi-stream indexes keep the LDS-heavy pass C
-    PVS_DBG_FORCE_LIGHT_FINALIZE,  // every int8 search uses the LDS-light pass C
+    PVS_DBG_FORCE_LIGHT_FINALIZE,  // every search uses the LDS-light pass C
     PVS_DBG_DENSE_PER_QUERY,       // dense fallback: one query per corpus pass + full sort (the round-1 form)
     PVS_DBG_NO_DIRECT_SCORE,       // 1..4 int8 queries: matrix-core MODE 2 instead of k_score_i8_direct
     PVS_DBG_NO_PAGE_RANK,          // per-item search: always sort every group

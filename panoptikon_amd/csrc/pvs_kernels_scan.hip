@@ -323,7 +323,7 @@ __device__ static inline float cand_key(const FinK &a, const QInfo &qi, uint32_t
     }
 }
 
-// LIGHT (int8 rows, FinalizeArgs.w_*): bound keys, survivor list and sorts of more than 512 records live in global memory (they
+// LIGHT (FinalizeArgs.w_*; float rows keep their query — and nothing else — in dynamic LDS): bound keys, survivor list and sorts of more than 512 records live in global memory (they
 // stay in L2: a few KB per query), LDS holds the histogram and a 512-record sort buffer — ~6 KB, so the workgroup fits beside
 // k_scan's two workgroups on a CU and pass C of one search runs under the scan of the next one (several streams per index).
 constexpr uint32_t FIN_SMALL_SORT = 512;
@@ -550,8 +550,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
     if (LIGHT && m2 > FIN_SMALL_SORT) s_sort = a.w_sort + (size_t)q * PVS_SURV_CAP;  // (many near-ties or a large k: sort in global memory)
     const uint8_t *qe = (const uint8_t *)a.qexact + (size_t)q * a.dim * (DT == PVS_I8 ? 1 : 4);
     // the query of this workgroup, zero-padded to a whole 16-byte chunk, in LDS beyond everything s_sort overlays (rerank_distance)
-    uint8_t *const s_q = smem + PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
-    if constexpr (!LIGHT) {
+    // (LIGHT, float rows: the query is all the dynamic LDS there is; int8 rows rerank from the exact integer sums and keep none)
+    uint8_t *const s_q = LIGHT ? smem : smem + PVS_CAND_CAP * 4 + PVS_SURV_CAP * 4 + 64;
+    if constexpr (!LIGHT || DT != PVS_I8) {
         const uint32_t qbytes = a.dim * (DT == PVS_I8 ? 1u : 4u), padded = (qbytes + 63u) & ~63u;
         if constexpr (DT == PVS_I8) {
             for (uint32_t i = tid; i < padded; i += 256) s_q[i] = i < qbytes ? qe[i] : (uint8_t)0;
@@ -588,8 +589,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinK a) {
                     }
                 }
             }
-            if (!closed) {  // (LIGHT keeps no query in LDS: the generic in-order form, rare — sums beyond 2^24)
-                if constexpr (LIGHT)
+            if (!closed) {  // (LIGHT, int8 rows: no query in LDS — the generic in-order form, rare: sums beyond 2^24)
+                if constexpr (LIGHT && DT == PVS_I8)
                     d = exact_distance<DT>(a.rows, a.stride, row, qe, (int)a.dim, a.metric, aa, qi.bb);
                 else
                     d = rerank_distance<DT>(a.rows, a.stride, row, s_q, (int)a.dim, a.metric, aa, qi.bb);
@@ -720,8 +721,13 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
         configured.store(true, std::memory_order_release);
     }
     if ((((uint64_t)f.dim * (f.dtype == PVS_I8 ? 1u : 4u)) + 63u & ~63ull) > (uint64_t)FIN_QMAX) return hipErrorInvalidValue;  // (no scan instance is that wide)
-    if (f.dtype == PVS_I8 && f.w_ub && f.w_surv && f.w_sort)
+    const bool light = f.w_ub && f.w_surv && f.w_sort;
+    if (light && f.dtype == PVS_I8)
         hipLaunchKernelGGL((k_finalize<PVS_I8, true>), dim3(f.batch), dim3(256), 0, s, k);
+    else if (light && f.dtype == PVS_F16)
+        hipLaunchKernelGGL((k_finalize<PVS_F16, true>), dim3(f.batch), dim3(256), ((size_t)f.dim * 4 + 63) & ~(size_t)63, s, k);
+    else if (light)
+        hipLaunchKernelGGL((k_finalize<PVS_F32, true>), dim3(f.batch), dim3(256), ((size_t)f.dim * 4 + 63) & ~(size_t)63, s, k);
     else if (f.dtype == PVS_I8)
         hipLaunchKernelGGL((k_finalize<PVS_I8, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
     else if (f.dtype == PVS_F16)

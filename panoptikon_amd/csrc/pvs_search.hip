@@ -235,7 +235,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         // one directly.  Measured at configs[2] (same box, alternating): pass B 1.20 ms instead of 1.22, but the step 1.354-1.374 ms
         // instead of 1.303-1.312 (93.2-94.6 k q/s against 97.6-98.2 k; 3 or 4 searches in flight: the same) — the two cross-queue
         // event waits per search cost more than the ~60 us of sample + select they hide.
-        const bool side = fast && side_finalize && batch <= pass_max && ix->dtype == PVS_I8 && !ix->multi_stream && c.stream == ix->search_stream &&
+        const bool side = fast && side_finalize && batch <= pass_max && !ix->multi_stream && c.stream == ix->search_stream &&
                           !pvs_dbg(PVS_DBG_NO_SIDE_FINALIZE);
         hipStream_t prelude = side && !c.cur_mask && pvs_dbg(PVS_DBG_PRELUDE_STREAM) ? ix->pre_stream : nullptr;
         PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, qoff, nb, batch_pad, metric, prelude));

@@ -174,6 +174,13 @@ def test_search_matches_oracle(pvs, dtype, metric, n, dim, batch, k, path):
         assert st.fast_queries == batch and st.dense_queries == 0, "filter-scan path must serve these shapes"
     if dt == pvs.I8:  # pre-quantized codes (QuantResolved.query_quant) give the same page
         assert_same_page(ix.search(hq, k, m), exp)
+    if path == "auto" and batch <= 128:
+        # the LDS-light pass C (what a pipelined caller's search runs beside the next search's scan; every element type since round 4)
+        pvs.debug_set("force_light_finalize", 1)
+        try:
+            assert_same_page(ix.search(queries, k, m), exp)
+        finally:
+            pvs.debug_set("force_light_finalize", 0)
     ix.close()
 
 
