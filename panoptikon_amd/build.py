@@ -43,7 +43,7 @@ SOURCES = [
     "pvs_rrf.hip",
     "pvs_rrf_sharded.hip",
     "pvs_score_direct.hip",
-    "pvs_sparse.hip",
+    "pvs_sparse.hip", "pvs_rrf_device.hip",
     "pvs_comm.hip",
     "pvs_multi.hip",
     "pvs_microbench.hip",

@@ -70,6 +70,7 @@ enum PvsDbg {
     PVS_DBG_SPARSE_MAX,            // ... take it up to this many allowed rows (0: the built-in crossover)
     PVS_DBG_NO_FUSED_AGG,          // per-item MAX/AVG/weighted: dense matrix + k_group_aggregate (the round-3 form)
     PVS_DBG_NO_SIDE_FINALIZE,      // pvs_search_device: pass C stays on the search's own stream
+    PVS_DBG_RRF_HOST_ROUNDS,       // pvs_rrf_search: every round of the bounded fusion in its host form (the round-3 route)
     PVS_DBG_MULTI_HOST_PAGES,      // multi-device index: per-item pages merged on the host, device-space masks split on the host (the round-3 route)
     PVS_DBG_PRELUDE_STREAM,        // pvs_search_device: query prep, pass A and the k-th select on a stream of their own (measured slower: search_enqueue)
     PVS_DBG_COUNT

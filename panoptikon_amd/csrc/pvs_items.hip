@@ -997,6 +997,66 @@ struct RrfTrace {
         t0 = t1;
     }
 };
+// One round of the bounded fusion on the device (pvs_rrf_device.hip): pages, union, exact ranks, fused scores and the first k on
+// one stream behind the branches' scoring, one synchronisation.  *usable = false: a size limit of the device form was hit (a
+// flag) — the host form redoes the round.  Otherwise R[] holds the page sizes and, when the bound is met, the page is written.
+static pvs_status rrf_round_on_device(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint64_t target, uint32_t k,
+                                      int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *usable, bool *done, uint32_t *out_m) {
+    *usable = false;
+    const uint32_t nb = p.n_branches;
+    pvs_index *root = br[0].idx;
+    HIP_TRY(hipSetDevice(root->device));
+    hipStream_t s = root->search_stream;
+    const unsigned long long *keys[PVS_RRF_MAX_BRANCHES];
+    const int64_t *gids[PVS_RRF_MAX_BRANCHES];
+    uint32_t n[PVS_RRF_MAX_BRANCHES];
+    std::vector<hipEvent_t> evs;
+    uint32_t t;
+    SearchCtx *c = ctx_acquire(root, &t);  // (its pinned block takes the round's output)
+    void *d_work = nullptr;
+    auto body = [&]() -> pvs_status {
+        for (uint32_t b = 0; b < nb; b++) {
+            keys[b] = cols[b].d_keys;
+            gids[b] = br[b].idx->d_grp_ids;
+            n[b] = cols[b].n_groups;
+            if (br[b].idx->search_stream != s) {  // the branch's keys are queued on its own index's stream
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                evs.push_back(e);
+                HIP_TRY(hipEventRecord(e, br[b].idx->search_stream));
+                HIP_TRY(hipStreamWaitEvent(s, e, 0));
+            }
+        }
+        PVS_TRY(ctx_pinned_io(*c, pvs_rrf_round_device_out_bytes(nb, k)));
+        HIP_TRY(pvs_scratch_alloc(&d_work, pvs_rrf_round_device_work_bytes(nb)));
+        HIP_TRY(pvs_rrf_round_device(keys, gids, n, nb, p, (uint32_t)target, k, d_work, c->h_io, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        uint32_t flags = 0, R[PVS_RRF_MAX_BRANCHES], m = 0, n_out = 0;
+        const int64_t *g = nullptr;
+        const double *sc = nullptr;
+        pvs_rrf_round_device_result(c->h_io, nb, k, &flags, R, &m, &n_out, &g, &sc);
+        if (flags) return PVS_OK;
+        *usable = true;
+        *out_m = m;
+        double U = 0.0;  // the most a group outside every page can score (rrf_bounded)
+        for (uint32_t b = 0; b < nb; b++) U += p.w[b] / ((double)p.k[b] + (double)R[b] + 1.0);
+        U *= 1.0 + 1e-12;
+        if (m >= k && n_out == k && sc[k - 1] > U) {
+            memcpy(out_groups, g, (size_t)k * 8);
+            memcpy(out_scores, sc, (size_t)k * 8);
+            *out_count = k;
+            *done = true;
+        }
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) (void)hipStreamSynchronize(s);
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    pvs_scratch_free(d_work);
+    ctx_done(root, c);
+    return st;
+}
+
 static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCols> &cols, const PvsRrfParams &p, uint32_t k,
                               int64_t *out_groups, double *out_scores, uint32_t *out_count, bool *done, RrfDigestRec *dig = nullptr) {
     *done = false;
@@ -1016,6 +1076,16 @@ static pvs_status rrf_bounded(const pvs_rrf_branch *br, std::vector<RrfBranchCol
         std::vector<int64_t> cand;
         for (uint32_t b = 0; b < nb; b++)
             if (cols[b].n_groups && target * 4 >= cols[b].n_groups) return PVS_OK;  // a page that would hold a quarter of the branch: full ranking
+        // the first round entirely on the device (the stage digests read the host form's intermediate results: that form then)
+        if (round == 0 && !dig && !pvs_dbg(PVS_DBG_RRF_HOST_ROUNDS) && pvs_rrf_round_device_supported(nb, target, k)) {
+            bool usable = false;
+            uint32_t m = 0;
+            PVS_TRY(rrf_round_on_device(br, cols, p, target, k, out_groups, out_scores, out_count, &usable, done, &m));
+            tr.lap("round on the device");
+            if (tr.on) fprintf(stderr, "[rrf] round 0 on the device: target %llu, %u candidates%s\n", (unsigned long long)target, m, usable ? "" : " (size limit: host form)");
+            if (*done) return PVS_OK;
+            if (usable) continue;  // the bound was not met: larger pages
+        }
         std::vector<std::vector<int64_t>> page(nb);
         std::vector<uint8_t> overflow(nb, 0);
         PVS_TRY(per_branch(br, nb, [&](uint32_t b) -> pvs_status {

@@ -274,6 +274,14 @@ struct PvsRrfParams {
     int32_t k[PVS_RRF_MAX_BRANCHES];
     double w[PVS_RRF_MAX_BRANCHES];
 };
+// one round of the bounded fusion on the device (pvs_rrf_device.hip): everything behind the window keys, one synchronisation
+bool pvs_rrf_round_device_supported(uint32_t nb, uint64_t target, uint32_t k);
+size_t pvs_rrf_round_device_work_bytes(uint32_t nb);
+size_t pvs_rrf_round_device_out_bytes(uint32_t nb, uint32_t k);
+hipError_t pvs_rrf_round_device(const unsigned long long *const *d_keys, const int64_t *const *d_gids, const uint32_t *n, uint32_t nb, const PvsRrfParams &p,
+                                uint32_t target, uint32_t k, void *d_work, uint8_t *h_out, hipStream_t s);
+void pvs_rrf_round_device_result(const uint8_t *h_out, uint32_t nb, uint32_t k, uint32_t *flags, uint32_t *R, uint32_t *m, uint32_t *n_out, const int64_t **groups,
+                                 const double **scores);
 // order-independent 64-bit digest of n words of 4 or 8 bytes (synchronous; race hunting, pvs_debug_rrf_digests)
 pvs_status pvs_digest_device(const void *d, uint64_t n, int word_bytes, uint64_t *out_host, hipStream_t s);
 // bounded fusion: window keys of every group of a branch, a sample of them, the page of groups at or below a key, the keys of

@@ -1331,6 +1331,14 @@ def test_rrf_bounded_fusion_equals_the_full_ranking(pvs):
         eg, es = orc.rrf_search(ora[:nb], k)
         assert np.array_equal(gg, eg), (k, nb)
         assert np.array_equal(gs.view(np.uint64), es.view(np.uint64)), (k, nb)
+        # round 4: the first round runs on the device (pvs_rrf_device.hip); the host form of the rounds returns the same page
+        pvs.debug_set("rrf_host_rounds", 1)
+        try:
+            hg, hs = pvs.rrf_search(dev[:nb], k)
+        finally:
+            pvs.debug_set("rrf_host_rounds", 0)
+        assert pvs.lib().pvs_rrf_last_path() == path
+        assert np.array_equal(hg, gg) and np.array_equal(hs.view(np.uint64), gs.view(np.uint64)), (k, nb, "host rounds")
     # a negative weight voids the bound: the full ranking answers, same contract
     dev[1]["weight"], ora[1]["weight"] = -0.25, -0.25
     gg, gs = pvs.rrf_search(dev[:2], 50)
