@@ -821,6 +821,10 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out, 
         HIP_TRY(pvs_scratch_alloc((void **)&out->d_vals, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
         HIP_TRY(pvs_scratch_alloc((void **)&out->d_keys, (size_t)std::max<uint32_t>(ix->n_groups, 1) * 8));
         PVS_TRY(prep_chunk(ix, *c, d_q, b.query_dtype, 0, 1, 32, b.metric));
+        // (Folding MIN / MAX per file into k_score_i8_direct's epilogue — the tile records of the one-pass per-item scorer, a 5-step
+        //  segmented scan per tile — was built and measured at configs[4]: 6.81-6.88 ms per composed query against 6.68-6.72 with
+        //  the two kernels below.  The scorer's waves have no slack for it, while the aggregate of one branch runs under the other
+        //  branch's scoring for free.)
         PVS_TRY(dense_chunk(ix, *c, 1, 32, b.metric, d_m));
         if (dig) PVS_TRY(pvs_digest_device(d_m, ix->n, 4, &dig[0], c->stream));
         HIP_TRY(pvs_launch_group_aggregate(d_m, 1, 1, 0, ix->d_grp_off, ix->d_grp_rows, ix->n_groups, d_w, nullptr, b.agg, out->d_vals, c->stream));

@@ -123,16 +123,25 @@ __global__ __launch_bounds__(256) void k_rd_compact(RdBranch b) {
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const unsigned long long thr = *b.thr;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < b.n; i += gridDim.x * 256)
-        if (b.keys[i] <= thr) {
-            const uint32_t p = atomicAdd(&s_n, 1u);
-            if (p < LIST) {
-                s_list[p] = i;
-            } else {
-                const uint32_t gp = atomicAdd(b.cnt, 1u);
-                if (gp < RD_CUT) b.slots[gp] = i;
+    const uint32_t step = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < b.n; i0 += 4 * step) {
+        unsigned long long k4[4];  // four independent loads in flight per lane (one per iteration leaves the pass latency-bound)
+#pragma unroll
+        for (int u = 0; u < 4; u++) k4[u] = i0 + u * step < b.n ? b.keys[i0 + u * step] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * step;
+            if (i < b.n && k4[u] <= thr) {
+                const uint32_t p = atomicAdd(&s_n, 1u);
+                if (p < LIST) {
+                    s_list[p] = i;
+                } else {
+                    const uint32_t gp = atomicAdd(b.cnt, 1u);
+                    if (gp < RD_CUT) b.slots[gp] = i;
+                }
             }
         }
+    }
     __syncthreads();
     const uint32_t m = s_n < LIST ? s_n : LIST;
     if (threadIdx.x == 0 && m) s_base = atomicAdd(b.cnt, m);
@@ -298,9 +307,16 @@ __global__ __launch_bounds__(1024) void k_rd_count(RdBranch b) {  // (80 KB of c
     for (uint32_t i = threadIdx.x; i <= m; i += RD_T) sh[i] = 0;
     __syncthreads();
     const unsigned long long kmax = sk[m - 1];
-    for (uint32_t g = blockIdx.x * RD_T + threadIdx.x; g < b.n; g += gridDim.x * RD_T) {
-        const unsigned long long k = b.keys[g];
-        if (k > kmax) continue;
+    const uint32_t step = gridDim.x * RD_T;
+    for (uint32_t g0 = blockIdx.x * RD_T + threadIdx.x; g0 < b.n; g0 += 4 * step) {
+      unsigned long long k4[4];  // four independent loads in flight per lane
+#pragma unroll
+      for (int u = 0; u < 4; u++) k4[u] = g0 + u * step < b.n ? b.keys[g0 + u * step] : ~0ull;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t g = g0 + u * step;
+        const unsigned long long k = k4[u];
+        if (g >= b.n || k > kmax) continue;
         const int64_t gid = b.gids[g];
         uint32_t lo = 0, hi = m;  // first candidate with (key, file id) > this file's
         while (lo < hi) {
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_rd_count(RdBranch b) {  // (80 KB of c
             else hi = mid;
         }
         if (lo < m) atomicAdd(&sh[lo], 1u);
+      }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= m; i += RD_T)
@@ -477,7 +494,7 @@ hipError_t pvs_rrf_round_device(const unsigned long long *const *d_keys, const i
     hipLaunchKernelGGL(k_rd_order, dim3(nb), dim3(RD_T), RD_CAND * 20, s, a);
     for (uint32_t b = 0; b < nb; b++)
         if (a.br[b].n) {
-            const unsigned g = (unsigned)std::min<uint64_t>(((uint64_t)a.br[b].n + RD_T - 1) / RD_T, 512);
+            const unsigned g = (unsigned)std::min<uint64_t>(((uint64_t)a.br[b].n + RD_T - 1) / RD_T, 256);
             hipLaunchKernelGGL(k_rd_count, dim3(g), dim3(RD_T), RD_CAND * 20 + 16, s, a.br[b]);
         }
     hipLaunchKernelGGL(k_rd_ranks, dim3(nb), dim3(RD_T), 0, s, a);
