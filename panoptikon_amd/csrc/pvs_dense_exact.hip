@@ -14,7 +14,11 @@
 // queries sit in LDS too and come back as broadcast reads.  (They must not be VMEM loads: a
 // wave's loads return in order, so a query load issued behind the prefetch DMA would wait
 // for the whole next slab and serialise the pipeline.)  Up to four queries share one pass
-// over the rows (four independent chains per lane).
+// over the rows (four independent chains per lane); float rows take EIGHT per pass (round 4): the chains of a pair of
+// queries are the two halves of v_pk_mul_f32 / v_pk_add_f32 (one IEEE rounding per half and instruction, the same chain
+// as the scalar form), the queries sit in LDS interleaved by pairs so that one broadcast ds_read_b128 delivers the
+// packed operands of two components.  At 8 queries the pass stays HBM-bound for f32 rows (9 LDS reads and 32 packed
+// VALU per 16-B chunk and lane); f16 rows become LDS-bound (17 reads per chunk) and gain less.
 //
 // Roofline: HBM.  Algorithmic bytes per launch = rows x row pitch.  VALU work per 16 KiB
 // slab and wave, f16 rows: 128 components x (1 convert + 2 per query) instructions.
@@ -48,8 +52,11 @@ __device__ static inline float elem_f32(const uint4 &v, int e) {
         return __builtin_bit_cast(float, w[e]);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int DT, int NQ, int METRIC>
 __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
+    constexpr bool PK = NQ >= 8;  // query pairs on the packed f32 pipe; LDS copy of the queries interleaved by pairs
     constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;  // components per 16-B chunk
     constexpr int EPS = 16 * PER;                                    // components per 256-B slab row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -58,7 +65,14 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
     const float *const qlds = (const float *)(smem + DENSE_RING_LDS);
     {
         float *w = (float *)(smem + DENSE_RING_LDS);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * a.qpad_ld; i += 256) w[i] = a.qpad[i];
+        if constexpr (PK) {  // [pair][component][2]
+            for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * a.qpad_ld; i += 256) {
+                const uint32_t q = i / a.qpad_ld, x = i - q * a.qpad_ld;
+                w[((size_t)(q >> 1) * a.qpad_ld + x) * 2 + (q & 1)] = a.qpad[i];
+            }
+        } else {
+            for (uint32_t i = threadIdx.x; i < (uint32_t)NQ * a.qpad_ld; i += 256) w[i] = a.qpad[i];
+        }
         __syncthreads();  // the only workgroup barrier
     }
     const uint32_t gw = blockIdx.x * 4 + wave;  // this wave's first pair of row tiles
@@ -93,6 +107,9 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
     float acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
+    v2f acc2[NQ / 2 + 1];
+#pragma unroll
+    for (int p = 0; p < NQ / 2; p++) acc2[p] = v2f{0.0f, 0.0f};
     const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 256u;
     const uint32_t jx = (uint32_t)lane & 15u;
     uint32_t cp = 0, cs = 0;  // consume cursor
@@ -102,26 +119,55 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
         if (it + 1 < n_items) issue((it + 1) & 1u);  // streams in while this item is consumed
         const uint8_t *tile = wbuf + (it & 1u) * 16384u + row_in;
         const float *q0 = qlds + (size_t)cs * EPS;
+        if constexpr (PK) {
+            const float *q0p = qlds + (size_t)cs * EPS * 2;
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
-            float4 qv4[NQ][PER / 4];
+            for (int c = 0; c < 16; c++) {
+                const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
+                float4 qv4[NQ / 2][PER / 2];  // pair p, components 2x, 2x+1: (q0 c0, q1 c0, q0 c1, q1 c1)
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
+                for (int p = 0; p < NQ / 2; p++)
 #pragma unroll
-                for (int x = 0; x < PER / 4; x++) qv4[q][x] = *(const float4 *)(q0 + (size_t)q * a.qpad_ld + c * PER + 4 * x);  // broadcast
+                    for (int x = 0; x < PER / 2; x++) qv4[p][x] = *(const float4 *)(q0p + ((size_t)p * a.qpad_ld + c * PER + 2 * x) * 2);  // broadcast
 #pragma unroll
-            for (int e = 0; e < PER; e++) {
-                const float av = elem_f32<DT>(v, e);
+                for (int e = 0; e < PER; e++) {
+                    const float av = elem_f32<DT>(v, e);
+                    const v2f av2 = v2f{av, av};
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const float4 &t4 = qv4[q][e >> 2];
-                    const float qv = (e & 3) == 0 ? t4.x : (e & 3) == 1 ? t4.y : (e & 3) == 2 ? t4.z : t4.w;
-                    if (METRIC == PVS_COSINE) {
-                        acc[q] = __fadd_rn(acc[q], __fmul_rn(av, qv));
-                    } else {
-                        const float t = __fsub_rn(av, qv);
-                        acc[q] = __fadd_rn(acc[q], __fmul_rn(t, t));
+                    for (int p = 0; p < NQ / 2; p++) {
+                        const float4 &t4 = qv4[p][e >> 1];
+                        const v2f qv = (e & 1) == 0 ? v2f{t4.x, t4.y} : v2f{t4.z, t4.w};
+                        if (METRIC == PVS_COSINE) {
+                            acc2[p] = acc2[p] + av2 * qv;  // (-ffp-contract=off: one rounding per multiply, one per add)
+                        } else {
+                            const v2f t = av2 - qv;
+                            acc2[p] = acc2[p] + t * t;
+                        }
+                    }
+                }
+            }
+        } else {
+    #pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
+                float4 qv4[NQ][PER / 4];
+    #pragma unroll
+                for (int q = 0; q < NQ; q++)
+    #pragma unroll
+                    for (int x = 0; x < PER / 4; x++) qv4[q][x] = *(const float4 *)(q0 + (size_t)q * a.qpad_ld + c * PER + 4 * x);  // broadcast
+    #pragma unroll
+                for (int e = 0; e < PER; e++) {
+                    const float av = elem_f32<DT>(v, e);
+    #pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const float4 &t4 = qv4[q][e >> 2];
+                        const float qv = (e & 3) == 0 ? t4.x : (e & 3) == 1 ? t4.y : (e & 3) == 2 ? t4.z : t4.w;
+                        if (METRIC == PVS_COSINE) {
+                            acc[q] = __fadd_rn(acc[q], __fmul_rn(av, qv));
+                        } else {
+                            const float t = __fsub_rn(av, qv);
+                            acc[q] = __fadd_rn(acc[q], __fmul_rn(t, t));
+                        }
                     }
                 }
             }
@@ -132,12 +178,15 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
                 const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const float d = METRIC == PVS_COSINE ? ref_cosine_finish(acc[q], aa, a.qinfo[q].bb) : ref_l2_finish(acc[q]);
+                    const float sum = PK ? acc2[q >> 1][q & 1] : acc[q];
+                    const float d = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, a.qinfo[q].bb) : ref_l2_finish(sum);
                     a.out[row * a.out_ld + a.out_col + q] = d;
                 }
             }
 #pragma unroll
             for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < NQ / 2; p++) acc2[p] = v2f{0.0f, 0.0f};
             cs = 0;
             cp++;
         }
@@ -176,6 +225,8 @@ hipError_t launch_nq(const DenseK &k, uint32_t nq, int metric, uint32_t grid, hi
         case 1: return launch_metric<DT, 1>(k, metric, grid, s);
         case 2: return launch_metric<DT, 2>(k, metric, grid, s);
         case 4: return launch_metric<DT, 4>(k, metric, grid, s);
+        case 8:
+            if constexpr (DT != PVS_I8) return launch_metric<DT, 8>(k, metric, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -204,6 +255,7 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
     const size_t qsz = dtype == PVS_I8 ? 1 : 4;
     for (uint32_t q0 = 0; q0 < nq;) {
         uint32_t g = nq - q0 >= 4 ? 4 : nq - q0 >= 2 ? 2 : 1;
+        if (dtype != PVS_I8 && nq - q0 >= 8 && !pvs_dbg(PVS_DBG_DENSE_NQ4)) g = 8;
         while (g > 1 && (uint64_t)g * k.qpad_ld * 4 > (uint64_t)DENSE_Q_LDS) g >>= 1;  // queries must fit beside the ring
         if ((uint64_t)g * k.qpad_ld * 4 > (uint64_t)DENSE_Q_LDS) return hipErrorInvalidValue;  // row pitch > 32 KiB (dim > 8192 f32)
         hipLaunchKernelGGL(k_pad_queries, dim3(g), dim3(256), 0, s, (const void *)((const uint8_t *)qexact + (size_t)q0 * dim * qsz),

@@ -32,9 +32,10 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
 
 // ---- exact per-row distances (pvs_dense_exact.hip): the reference's dist_{cte}.d for `nq` prepared
 // queries (qexact [nq][dim] int8 codes or f32, qinfo [nq]) -> out[row * out_ld + out_col + q].
-// Sequential f32 accumulation per row, rows streamed HBM -> LDS; up to PVS_DENSE_NQ queries share a pass.
+// Sequential f32 accumulation per row, rows streamed HBM -> LDS; up to PVS_DENSE_NQ queries share a pass
+// (pairs of queries on the packed f32 pipe at 8).
 // qpad_scratch: pvs_dense_exact_scratch_bytes() of device memory, reused launch after launch on `s`.
-constexpr uint32_t PVS_DENSE_NQ = 4;
+constexpr uint32_t PVS_DENSE_NQ = 8;  // float rows; int8 rows (the out-of-range fallback) take 4
 uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz);
 hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,

@@ -399,9 +399,11 @@ def test_score_batch_dense_matrix(pvs, dtype):
 
 
 @pytest.mark.parametrize("dtype,dim,n,b", [("f32", 3000, 700, 7), ("f16", 1536, 1000, 3), ("i8", 1100, 900, 6), ("f32", 5, 65, 1),
-                                              ("f16", 4099, 129, 5)])
+                                              ("f16", 4099, 129, 5), ("f32", 768, 1500, 19), ("f16", 1000, 800, 13), ("f32", 1024, 333, 8),
+                                              ("f32", 1030, 200, 9), ("f16", 2050, 131, 16)])
 def test_dense_exact_wide_rows_and_query_groups(pvs, dtype, dim, n, b):
-    """Every row against b queries through the streaming exact kernel: query groups of 4/2/1 per pass,
+    """Every row against b queries through the streaming exact kernel: query groups of 8 (float rows: pairs of queries on the
+    packed f32 pipe) / 4 / 2 / 1 per pass,
     row pitches whose padded queries no longer fit four at a time beside the LDS ring, int8 rows whose
     sums leave the closed-form range (dim * 127^2 >= 2^24), odd dims and a ragged last tile pair."""
     dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
@@ -429,6 +431,44 @@ def test_dense_exact_wide_rows_and_query_groups(pvs, dtype, dim, n, b):
         one = ix.score_all(hq[0], metric)
         ok = ~np.isnan(one)
         assert np.array_equal(one[ok].view(np.uint32), got[ok, 0].view(np.uint32))
+    ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_dense_exact_packed_pairs_equal_the_scalar_chains(pvs, dtype):
+    """The 8-query instance of k_dense_exact runs two queries' chains in the halves of v_pk_mul_f32 / v_pk_add_f32: every
+    distance must equal the 4-query form's (pvs_debug_set("dense_nq4", 1)) and the oracle's bit for bit, including products and
+    partial sums that are subnormal, rows of huge components (inf sums) and NaN components."""
+    dt = {"f16": pvs.F16, "f32": pvs.F32}[dtype]
+    n, dim, b = 2500, 300, 24
+    rng = np.random.default_rng(77)
+    rows = unit_rows(91, n, dim)
+    tiny = 6.0e-8 if dt == pvs.F16 else 1.0e-22  # (f16: its smallest subnormal)
+    rows[5] *= tiny / max(np.abs(rows[5]).max(), 1e-30)
+    rows[6] = tiny
+    rows[7] = 3.0e4 if dt == pvs.F16 else 3.0e19
+    rows[8, 3] = np.nan
+    rows[9] = 0.0
+    queries = orc.synth_rows(0x5EED0007, 0, b, dim)
+    queries[1] *= 1.0e-20
+    queries[2] = 1.0e-23
+    queries[3] *= 1.0e19
+    queries[4] = 0.0
+    ix = make_index(pvs, dt, rows, None)
+    hc = host_corpus(dt, rows, None)
+    for metric in (pvs.COSINE, pvs.L2):
+        got = ix.score_batch(queries, metric)
+        pvs.debug_set("dense_nq4", 1)
+        try:
+            old = ix.score_batch(queries, metric)
+        finally:
+            pvs.debug_set("dense_nq4", 0)
+        assert np.array_equal(got.view(np.uint32), old.view(np.uint32)), (dtype, metric)
+        for q in range(b):
+            exp = orc.score_all(dt, metric, hc, queries[q])
+            assert np.array_equal(np.isnan(got[:, q]), np.isnan(exp)), (dtype, metric, q)
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok, q].view(np.uint32), exp[ok].view(np.uint32)), (dtype, metric, q)
     ix.close()
 
 
