@@ -25,7 +25,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
-    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4",
+    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -266,6 +266,22 @@ void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipStream_
     t.rows = rows;
     (void)hipEventRecord(t.a, st);
     c.spans.push_back(t);
+}
+bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t *ev_start, hipEvent_t *ev_stop) {
+    if (!ix->profiling) return false;
+    TimedSpan t;
+    if (!c.span_pool.empty()) {
+        t = c.span_pool.back();
+        c.span_pool.pop_back();
+    } else if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) {
+        return false;
+    }
+    t.kind = kind;
+    t.rows = rows;
+    c.spans.push_back(t);
+    *ev_start = t.a;
+    *ev_stop = t.b;
+    return true;
 }
 void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on) {
     if (!ix->profiling || c.spans.empty()) return;

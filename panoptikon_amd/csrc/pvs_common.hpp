@@ -74,6 +74,7 @@ enum PvsDbg {
     PVS_DBG_MULTI_HOST_PAGES,      // multi-device index: per-item pages merged on the host, device-space masks split on the host (the round-3 route)
     PVS_DBG_PRELUDE_STREAM,        // pvs_search_device: query prep, pass A and the k-th select on a stream of their own (measured slower: search_enqueue)
     PVS_DBG_DENSE_NQ4,             // k_dense_exact: at most 4 float queries per pass (the form before the packed 8-query instance)
+    PVS_DBG_MARKER_EVENTS,         // filter-scan searches: profiling spans and the pass-B -> pass-C dependency as hipEventRecord markers around the kernels (the round-3 form) instead of events bound to the dispatches
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -252,6 +252,9 @@ pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, 
 pvs_status check_ids(pvs_index *ix, const int64_t *row_ids, uint64_t n, int64_t *last, int64_t implicit_id0 = INT64_MIN);
 void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipStream_t on = nullptr);
 void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on = nullptr);
+// a span whose two events are bound to ONE dispatch by the launcher (ScanArgs.ev_start / ev_stop) instead of being recorded around
+// it: returns false (events untouched) when the index is not profiling
+bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t *ev_start, hipEvent_t *ev_stop);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
 void ctx_release(SearchCtx &c);

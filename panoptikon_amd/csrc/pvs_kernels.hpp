@@ -77,6 +77,9 @@ struct ScanArgs {
     double *fold_out = nullptr;
     uint32_t fold_ld = 0;
     int fold_agg = 0;
+    // optional events bound to the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of THIS kernel, and something a
+    // second stream can wait for, without a marker packet in the queue)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
 // geometry of the filter passes (modes 0 / 1) of a shape — it depends on which kernel serves them (pvs_scan_is_wide)
@@ -143,6 +146,7 @@ struct FinalizeArgs {
     uint32_t *w_ub = nullptr;             // [batch][cand_cap]
     uint32_t *w_surv = nullptr;           // [batch][PVS_SURV_CAP]
     unsigned long long *w_sort = nullptr; // [batch][PVS_SURV_CAP]
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // bound to the dispatch (ScanArgs.ev_start)
 };
 hipError_t pvs_launch_finalize(const FinalizeArgs &a, hipStream_t s);
 

@@ -3,6 +3,7 @@
 // shard-page merge.  gfx950.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
 #include "pvs_kernels.hpp"
 #include "pvs_rerank.hpp"
 #include "pvs_scan_dispatch.hpp"
@@ -75,6 +76,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.fold_out = a.fold_out;
     k.fold_ld = a.fold_ld;
     k.fold_agg = a.fold_agg;
+    k.ev_start = a.ev_start;
+    k.ev_stop = a.ev_stop;
     hipError_t e = hipErrorInvalidValue;
     if (a.dtype == PVS_I8)
         e = wide            ? pvs_scan_dispatch_i8_wide(k, a.kslabs, a.qgroups, a.metric, a.mode, s)
@@ -722,18 +725,27 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &f, hipStream_t s) {
     }
     if ((((uint64_t)f.dim * (f.dtype == PVS_I8 ? 1u : 4u)) + 63u & ~63ull) > (uint64_t)FIN_QMAX) return hipErrorInvalidValue;  // (no scan instance is that wide)
     const bool light = f.w_ub && f.w_surv && f.w_sort;
+    const size_t qlds = ((size_t)f.dim * 4 + 63) & ~(size_t)63;
+#define PVS_FIN_LAUNCH(kernel, lds)                                                                                  \
+    do {                                                                                                             \
+        if (f.ev_start || f.ev_stop)                                                                                 \
+            hipExtLaunchKernelGGL(kernel, dim3(f.batch), dim3(256), lds, s, f.ev_start, f.ev_stop, 0, k);            \
+        else                                                                                                         \
+            hipLaunchKernelGGL(kernel, dim3(f.batch), dim3(256), lds, s, k);                                         \
+    } while (0)
     if (light && f.dtype == PVS_I8)
-        hipLaunchKernelGGL((k_finalize<PVS_I8, true>), dim3(f.batch), dim3(256), 0, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_I8, true>), 0);
     else if (light && f.dtype == PVS_F16)
-        hipLaunchKernelGGL((k_finalize<PVS_F16, true>), dim3(f.batch), dim3(256), ((size_t)f.dim * 4 + 63) & ~(size_t)63, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_F16, true>), qlds);
     else if (light)
-        hipLaunchKernelGGL((k_finalize<PVS_F32, true>), dim3(f.batch), dim3(256), ((size_t)f.dim * 4 + 63) & ~(size_t)63, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_F32, true>), qlds);
     else if (f.dtype == PVS_I8)
-        hipLaunchKernelGGL((k_finalize<PVS_I8, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_I8, false>), FIN_LDS);
     else if (f.dtype == PVS_F16)
-        hipLaunchKernelGGL((k_finalize<PVS_F16, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_F16, false>), FIN_LDS);
     else
-        hipLaunchKernelGGL((k_finalize<PVS_F32, false>), dim3(f.batch), dim3(256), FIN_LDS, s, k);
+        PVS_FIN_LAUNCH((k_finalize<PVS_F32, false>), FIN_LDS);
+#undef PVS_FIN_LAUNCH
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // pvs_scan_dispatch.hpp — entry points of the scan-kernel translation units.
 #pragma once
+#include <hip/hip_ext.h>
 #include "pvs_kernels.hpp"
 struct ScanK {
     const uint8_t *rows;
@@ -36,7 +37,20 @@ struct ScanK {
     double *fold_out;           // [n_groups][fold_ld]
     uint32_t fold_ld;
     int fold_agg;               // PVS_AGG_MIN / MAX / AVG (ignored with weights)
+    // host side only (16 bytes of kernel argument nobody reads): events bound to THIS dispatch by hipExtLaunchKernelGGL — the kernel's
+    // start / stop timestamps come from its own completion signal, no marker packet goes into the queue (two hipEventRecord around
+    // every kernel of a search cost 30-45 us of a 1.29-ms step at configs[2])
+    hipEvent_t ev_start, ev_stop;
 };
+
+// one launch site for both forms
+#define PVS_SCAN_LAUNCH(kernel, grid, block, lds, stream, karg)                                                           \
+    do {                                                                                                                  \
+        if ((karg).ev_start || (karg).ev_stop)                                                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, (karg).ev_start, (karg).ev_stop, 0, karg);           \
+        else                                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, karg);                                                   \
+    } while (0)
 
 hipError_t pvs_scan_dispatch_i8(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);
 hipError_t pvs_scan_dispatch_f16_small(const ScanK &k, uint32_t kslabs, uint32_t qg, int metric, int mode, hipStream_t s);

@@ -866,7 +866,7 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS, MODE>::WAVES * 64), lds, s, k);
+    PVS_SCAN_LAUNCH((k_scan<DT, KS, QG, METRIC, MODE>), dim3(k.grid), dim3(Geo<QG, KS, MODE>::WAVES * 64), lds, s, k);
     return hipGetLastError();
 }
 template <int DT, int KS, int QG>

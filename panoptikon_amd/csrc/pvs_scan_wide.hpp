@@ -482,7 +482,7 @@ static hipError_t scan_wide_launch_one(const ScanK &k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_scan_wide<KS, NQ, RW, METRIC, MODE>), dim3(k.grid), dim3(512), lds, s, k);
+    PVS_SCAN_LAUNCH((k_scan_wide<KS, NQ, RW, METRIC, MODE>), dim3(k.grid), dim3(512), lds, s, k);
     return hipGetLastError();
 }
 template <int KS, int RW>

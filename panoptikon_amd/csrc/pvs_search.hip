@@ -125,9 +125,16 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     while (a.gmin_per_lane > 1 && (uint64_t)a.grid * spp * (a.gmin_per_lane / 2) >= std::max<uint64_t>(16ull * k_sel, 1024)) a.gmin_per_lane /= 2;
     a.groups_per_query = a.grid * spp * a.gmin_per_lane;
     hipStream_t ps = prelude ? prelude : c.stream;
-    span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows, ps);
-    HIP_TRY(pvs_launch_scan(a, ps));
-    span_end(ix, c, ps);
+    const bool bound_ev = pvs_dbg(PVS_DBG_MARKER_EVENTS) == 0;  // (1: the round-3 form, two hipEventRecord around every kernel)
+    if (bound_ev) {
+        (void)span_bound(ix, c, 0, (uint64_t)n_samp * wg_rows, &a.ev_start, &a.ev_stop);
+        HIP_TRY(pvs_launch_scan(a, ps));
+        a.ev_start = a.ev_stop = nullptr;
+    } else {
+        span_begin(ix, c, 0, (uint64_t)n_samp * wg_rows, ps);
+        HIP_TRY(pvs_launch_scan(a, ps));
+        span_end(ix, c, ps);
+    }
     HIP_TRY(pvs_launch_kth(c.d_gmin, a.groups_per_query, nb, k_sel, c.d_thr, ps, c.d_qinfo, metric));
     if (prelude) {
         HIP_TRY(hipEventRecord(c.preluded, prelude));
@@ -147,9 +154,19 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     a.grid = std::min<uint32_t>({n_wgtiles, (uint32_t)ix->n_cu * per_cu,
                                  (uint32_t)((uint64_t)PVS_SEG_PAIRS * PVS_SEG_CAP / ((uint64_t)batch_pad * spp * pvs_scan_seg_cap(a.dtype, a.qgroups, a.kslabs)))});
     a.n_segments = a.grid * spp;
-    span_begin(ix, c, 1, ix->n);
-    HIP_TRY(pvs_launch_scan(a, c.stream));
-    span_end(ix, c);
+    // side: pass C waits for pass B on another stream — the event it waits for is bound to pass B's dispatch as well
+    const bool side_c = side && c.d_fin_ub && pvs_dbg(PVS_DBG_NO_LIGHT_FINALIZE) == 0;
+    hipEvent_t scanned = nullptr;
+    if (bound_ev) {
+        if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop) && side_c) a.ev_stop = c.scanned;
+        scanned = a.ev_stop;
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        a.ev_start = a.ev_stop = nullptr;
+    } else {
+        span_begin(ix, c, 1, ix->n);
+        HIP_TRY(pvs_launch_scan(a, c.stream));
+        span_end(ix, c);
+    }
     // pass C
     FinalizeArgs f;
     f.dtype = (int)ix->dtype;
@@ -199,14 +216,22 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     // runs under the scan of the caller's NEXT search instead of in front of it (38 us of a 1.3-ms step at configs[2]).
     hipStream_t fs = c.stream;
     if (side && f.w_ub) {
-        HIP_TRY(hipEventRecord(c.scanned, c.stream));
-        HIP_TRY(hipStreamWaitEvent(ix->fin_stream, c.scanned, 0));
+        if (!scanned) {
+            HIP_TRY(hipEventRecord(c.scanned, c.stream));
+            scanned = c.scanned;
+        }
+        HIP_TRY(hipStreamWaitEvent(ix->fin_stream, scanned, 0));
         fs = ix->fin_stream;
         c.side_finalize = true;
     }
-    span_begin(ix, c, 2, 0, fs);
-    HIP_TRY(pvs_launch_finalize(f, fs));
-    span_end(ix, c, fs);
+    if (bound_ev) {
+        (void)span_bound(ix, c, 2, 0, &f.ev_start, &f.ev_stop);
+        HIP_TRY(pvs_launch_finalize(f, fs));
+    } else {
+        span_begin(ix, c, 2, 0, fs);
+        HIP_TRY(pvs_launch_finalize(f, fs));
+        span_end(ix, c, fs);
+    }
     return PVS_OK;
 }
 
