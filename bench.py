@@ -640,7 +640,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-        "kernel": f"{ix.scan_kernel_name(B)} (pass B, filter scan)", "launches": int(prof.scan_launches),
+        "kernel": (lambda nm: nm if nm.startswith("k_direct_topk") else nm + " (pass B, filter scan)")(ix.scan_kernel_name(B)), "launches": int(prof.scan_launches),
         "avg_launch_ms": round(scan_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
         "mfma": {"achieved": round(ops_per_launch / (scan_ms * 1e-3) / 1e12, 1) if prof.scan_launches else 0.0,
                  "peak": mfma_peak, "unit": "TOP/s" if dtype == pvs.I8 else "TFLOP/s",
@@ -725,7 +725,7 @@ def main():
                 "metric": "knn_queries_per_sec", "value": round(steps * b / el, 1), "unit": "queries/s", "steps": steps, "warmup": warmup,
                 "ms_per_step": round(el / steps * 1e3, 4), "dtype": dt_name, "data": "synthetic",
                 "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                             "kernel": f"{ixh.scan_kernel_name(b)} (pass B, filter scan)", "launches": int(p.scan_launches), "avg_launch_ms": round(sms, 4),
+                             "kernel": (lambda nm: nm if nm.startswith("k_direct_topk") else nm + " (pass B, filter scan)")(ixh.scan_kernel_name(b)), "launches": int(p.scan_launches), "avg_launch_ms": round(sms, 4),
                              "algorithmic_bytes_per_launch": int(by), "kernel_events": "timed region",
                              "mfma": {"achieved": round(ops / (sms * 1e-3) / 1e12, 1) if p.scan_launches else 0.0, "peak": pk,
                                       "unit": "TOP/s" if dt_name == "i8" else "TFLOP/s", "frac": round(ops / (sms * 1e-3) / 1e12 / pk, 4) if p.scan_launches else 0.0}},

@@ -38,6 +38,7 @@ SOURCES = [
     "pvs_scan_f32_large.hip",
     "pvs_dense.hip",
     "pvs_dense_exact.hip",
+    "pvs_direct.hip",
     "pvs_select.hip",
     "pvs_groups.hip",
     "pvs_rrf.hip",

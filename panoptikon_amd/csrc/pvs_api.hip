@@ -25,7 +25,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
-    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events",
+    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -35,6 +35,7 @@ int dbg_key(const char *key) {
 }
 }  // namespace
 int64_t pvs_dbg(PvsDbg key) { return g_dbg[key].load(std::memory_order_relaxed); }
+void pvs_dbg_add(PvsDbg key, int64_t v) { g_dbg[key].fetch_add(v, std::memory_order_relaxed); }
 PVS_EXPORT pvs_status pvs_debug_set(const char *key, int64_t value) {
     const int i = dbg_key(key);
     if (i < 0) return pvs_fail(PVS_ERR_INVALID_ARG, "unknown debug key '%s'", key ? key : "(null)");
@@ -325,6 +326,7 @@ void ctx_release(SearchCtx &c) {
     hipFree(c.d_qin);
     hipFree(c.d_qmat);
     hipFree(c.d_qpad);
+    hipFree(c.d_direct);
     hipFree(c.d_qstage);
     hipFree(c.d_mask);
     hipFree(c.d_aux_masked);
@@ -756,6 +758,11 @@ PVS_EXPORT pvs_status pvs_index_scan_kernel_name(pvs_index *ix, uint32_t batch, 
     if (!ix || !out || out_len < 2 || batch < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "bad argument");
     const pvs_index *sh = is_multi(ix) && !ix->shards.empty() ? ix->shards[0] : ix;
     const uint32_t ks = sh->stride / PVS_KSLAB_BYTES;
+    const char *dtn = sh->dtype == PVS_I8 ? "i8" : sh->dtype == PVS_F16 ? "f16" : "f32";
+    if (batch == 1 && !is_multi(ix) && pvs_direct_route(sh, 100)) {  // (a page of <= 256 rows: search_enqueue)
+        snprintf(out, out_len, "k_direct_topk<%s, %u B> (one launch: exact distances + page)", dtn, sh->stride);
+        return PVS_OK;
+    }
     if (!pvs_scan_supported((int)sh->dtype, ks)) {
         snprintf(out, out_len, "dense path");
         return PVS_OK;

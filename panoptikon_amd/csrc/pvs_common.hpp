@@ -75,9 +75,13 @@ enum PvsDbg {
     PVS_DBG_PRELUDE_STREAM,        // pvs_search_device: query prep, pass A and the k-th select on a stream of their own (measured slower: search_enqueue)
     PVS_DBG_DENSE_NQ4,             // k_dense_exact: at most 4 float queries per pass (the form before the packed 8-query instance)
     PVS_DBG_MARKER_EVENTS,         // filter-scan searches: profiling spans and the pass-B -> pass-C dependency as hipEventRecord markers around the kernels (the round-3 form) instead of events bound to the dispatches
+    PVS_DBG_NO_DIRECT_TOPK,        // single queries always take the filter scan (never the one-launch exact search, pvs_direct.hip)
+    PVS_DBG_DIRECT_MAX_MB,         // ... take the one-launch search up to this many MB of rows (0: the built-in crossover)
+    PVS_DBG_DIRECT_QUERIES,        // (a counter, read with pvs_debug_get) single queries answered by the one-launch search, process-wide
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);
+void pvs_dbg_add(PvsDbg key, int64_t v);  // counters among the keys
 
 // ------------------------------------------------------------ geometry
 // Rows live in HBM at a pitch that is a multiple of 256 B so that a row is a

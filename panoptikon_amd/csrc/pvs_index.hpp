@@ -33,6 +33,7 @@ struct SearchCtx {
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
     float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
+    void *d_direct = nullptr;     // one-launch single-query search (pvs_direct.hip): workgroup lists + ticket, allocated on first use
     const uint8_t *cur_mask = nullptr;  // pvs_search_filtered: candidate mask of the search in flight (device, [rows])
     uint8_t *d_mask = nullptr;          // its staging copy when the caller's mask is in host memory
     float *d_aux_masked = nullptr;      // [cap/32][PVS_AUX_REC] row-scalar stream with NaN on rows outside the mask
@@ -208,6 +209,7 @@ struct pvs_index {
     bool by_group = false;  // multi-device parent: rows are placed by group (group_ids given to every add): per-item operators are shard-local
     bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
+    std::atomic<uint64_t> direct_queries{0};  // single queries answered by the one-launch search (counted in fast_queries too; pvs_debug_get("direct_queries"))
     std::atomic<uint64_t> flat_reruns{0};  // queries that went through the scan twice (segment overflow -> flat candidate lists)
     std::atomic<uint64_t> sparse_queries{0};     // filtered / row-list queries answered by gather-and-score (pvs_sparse.hip)
     std::atomic<uint64_t> null_tail_queries{0};  // cosine pages completed from the zero-norm row list instead of the dense path
@@ -254,6 +256,8 @@ void span_begin(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipStream_
 void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on = nullptr);
 // a span whose two events are bound to ONE dispatch by the launcher (ScanArgs.ev_start / ev_stop) instead of being recorded around
 // it: returns false (events untouched) when the index is not profiling
+// would ONE unmasked query for a page of k rows take the one-launch search (pvs_direct.hip) on this index?
+bool pvs_direct_route(const pvs_index *ix, uint32_t k);
 bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t *ev_start, hipEvent_t *ev_stop);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);

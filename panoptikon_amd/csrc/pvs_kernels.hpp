@@ -41,6 +41,38 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
                                   float *out, uint32_t out_ld, uint32_t out_col, uint32_t n_cu, hipStream_t s);
 
+// ---- one launch for one query (pvs_direct.hip): exact distance of every row in the reference's in-order arithmetic + the page,
+// selected while the rows stream; flags as pass C writes them (0 done, 3 page ends in NULL rows, 1 dense path)
+constexpr uint32_t PVS_DIRECT_MAX_K = 256;
+constexpr uint64_t PVS_DIRECT_CROSSOVER_MB = 8192;  // rows x pitch up to which one query takes the one-launch search (search_enqueue)
+struct DirectArgs {
+    int dtype, metric;
+    const uint8_t *rows;
+    const float *norm2;
+    const int64_t *ids;
+    uint32_t stride, dim;
+    uint64_t n_rows;
+    const void *qexact;  // [dim] int8 codes (int8 index) or f32: SearchCtx::d_qexact after prep_chunk
+    const QInfo *qinfo;
+    const uint32_t *trank = nullptr, *tinv = nullptr;
+    uint32_t k;
+    void *work;          // pvs_direct_work_bytes(n_cu), zeroed once
+    int64_t *out_ids;
+    float *out_dist;
+    uint32_t *out_count, *need_dense, *h_flags, *h_seen;
+    // optional mirror of the page in pinned host memory (written when the page is complete: flag 0), so that a host caller needs
+    // no copy back
+    int64_t *h_out_ids = nullptr;
+    float *h_out_dist = nullptr;
+    uint32_t *h_out_count = nullptr;
+    int null_ok = 0;
+    uint32_t n_cu;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+bool pvs_direct_supported(uint32_t stride, uint32_t esz, uint32_t k);
+uint64_t pvs_direct_work_bytes(uint32_t n_cu);
+hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s);
+
 // ---- filter scan (pvs_kernels_scan.hip)
 struct ScanArgs {
     int dtype, metric;

@@ -235,6 +235,63 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     return PVS_OK;
 }
 
+// One query, no candidate mask, a page of <= 256 rows over a corpus below the crossover: ONE launch scores every row exactly and
+// selects the page on the way (pvs_direct.hip) — the filter scan's five dependent launches are most of such a search's latency.
+// Measured (tools/direct_crossover.py, 768-d, p50 of pvs_search, k = 10 / 100): it wins at every size tried — int8 1M rows 0.197 / 0.229 ms against
+// 0.239 / 0.236, 8M 1.000 / 1.000 against 1.017 / 1.017; f16 4M 1.01 / 1.00 against 1.09 / 1.10; f32 4M (11.7 GB) 1.94 / 1.88 against 2.01 / 2.04 — by the
+// fixed cost it saves; the crossover keeps the north-star shape (10M x 768 f16, 15 GB, filter scan at 0.82 of HBM) where it was.
+bool pvs_direct_route(const pvs_index *ix, uint32_t k) {
+    if (ix->forced_path != 0 || ix->n == 0 || pvs_dbg(PVS_DBG_NO_DIRECT_TOPK)) return false;
+    if (!pvs_direct_supported(ix->stride, ix->esz, k)) return false;
+    const uint64_t lim_mb = pvs_dbg(PVS_DBG_DIRECT_MAX_MB) > 0 ? (uint64_t)pvs_dbg(PVS_DBG_DIRECT_MAX_MB) : PVS_DIRECT_CROSSOVER_MB;
+    return ix->n * (uint64_t)ix->stride <= (lim_mb << 20);
+}
+static bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k) { return batch == 1 && !c.cur_mask && pvs_direct_route(ix, k); }
+static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t k, int metric, int64_t *oid, float *od,
+                                 uint32_t *oc, uint8_t *h_page = nullptr) {
+    if (!c.d_direct) {
+        const uint64_t bytes = pvs_direct_work_bytes((uint32_t)ix->n_cu);
+        HIP_TRY(pvs_malloc_retry(&c.d_direct, bytes));
+        HIP_TRY(hipMemsetAsync(c.d_direct, 0, bytes, c.stream));
+    }
+    PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, 0, 1, 32, metric));
+    DirectArgs d;
+    d.dtype = (int)ix->dtype;
+    d.metric = metric;
+    d.rows = ix->d_rows;
+    d.norm2 = ix->d_norm2;
+    d.ids = ix->d_ids;
+    d.stride = ix->stride;
+    d.dim = ix->dim;
+    d.n_rows = ix->n;
+    d.qexact = c.d_qexact;
+    d.qinfo = c.d_qinfo;
+    if (order_tinv(ix)) {
+        d.trank = ix->d_trank;
+        d.tinv = ix->d_tinv;
+    }
+    d.k = k;
+    d.work = c.d_direct;
+    d.out_ids = oid;
+    d.out_dist = od;
+    d.out_count = oc;
+    d.need_dense = c.d_need_dense;
+    d.h_flags = c.h_need_dense;
+    d.h_seen = c.h_need_dense + c.flags_cap;
+    d.null_ok = ix->null_built_n.load(std::memory_order_acquire) == ix->n && ix->null_weird[metric == PVS_L2 ? 1 : 0] == 0;
+    d.n_cu = (uint32_t)ix->n_cu;
+    if (h_page) {  // [ids k x 8 | distances k x 4 | count]
+        d.h_out_ids = (int64_t *)h_page;
+        d.h_out_dist = (float *)(h_page + (size_t)k * 8);
+        d.h_out_count = (uint32_t *)(h_page + (size_t)k * 12);
+    }
+    (void)span_bound(ix, c, 1, ix->n, &d.ev_start, &d.ev_stop);
+    HIP_TRY(pvs_launch_direct_topk(d, c.stream));
+    ix->direct_queries++;
+    pvs_dbg_add(PVS_DBG_DIRECT_QUERIES, 1);
+    return PVS_OK;
+}
+
 // Enqueues the whole search on c.stream.  Outputs are device buffers.
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k,
                                  int metric, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast, bool side_finalize) {
@@ -250,6 +307,13 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
         return PVS_OK;
     }
     if (fast) PVS_TRY(pvs_ensure_null_rows(ix));  // (one pass over |a|^2 per index state; a no-op afterwards)
+    if (direct_ok(ix, c, batch, k)) {  // (whether or not a scan instance exists for the row pitch)
+        if (!fast) PVS_TRY(pvs_ensure_null_rows(ix));
+        *used_fast = true;
+        PVS_TRY(enqueue_direct(ix, c, d_queries, qdtype, k, metric, d_out_ids, d_out_dist, d_out_count));
+        HIP_TRY(hipEventRecord(c.done, c.stream));
+        return PVS_OK;
+    }
     const uint32_t pass_max = fast ? pvs_scan_max_batch((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES) : PVS_MAX_BATCH;
     for (uint32_t qoff = 0; qoff < batch; qoff += pass_max) {
         const uint32_t nb = std::min(pass_max, batch - qoff);
@@ -711,6 +775,47 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
     }
     pvs_status st = ctx_prepare(ix, *c, batch, k, true);
     const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
+    if (st == PVS_OK && !mask && !listed && direct_ok(ix, *c, batch, k)) {
+        // One query over a small or medium corpus (pvs_direct.hip): the query is read from this context's pinned, device-mapped block,
+        // the page is mirrored into it — no staging copy either way, one synchronisation.  A page that needs the fallbacks (NULL
+        // tail, dense path) takes the ordinary route below from the device copy of what the kernel wrote.
+        const size_t off_p = pvs_round_up(64 + qbytes, 64), need = off_p + (size_t)k * 12 + 4;
+        auto run = [&]() -> pvs_status {
+            PVS_TRY(ctx_pinned_io(*c, need));
+            uint8_t *io = c->h_io;
+            memcpy(io + 64, queries, qbytes);
+            PVS_TRY(pvs_ensure_null_rows(ix));
+            PVS_TRY(enqueue_direct(ix, *c, io + 64, qdtype, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, io + off_p));
+            HIP_TRY(hipEventRecord(c->done, c->stream));
+            HIP_TRY(hipEventSynchronize(c->done));
+            spans_collect(ix, *c);
+            if (c->h_need_dense[0] == 0) {
+                memcpy(out_ids, io + off_p, (size_t)k * 8);
+                memcpy(out_dist, io + off_p + (size_t)k * 8, (size_t)k * 4);
+                const uint32_t cnt = *(const uint32_t *)(io + off_p + (size_t)k * 12);
+                out_count[0] = cnt;
+                for (uint32_t i = cnt; i < k; i++) {  // (k > rows: the page's unused tail)
+                    out_ids[i] = -1;
+                    out_dist[i] = __builtin_nanf("");
+                }
+                ix->fast_queries++;
+                ix->last_candidates = 0;
+                return PVS_OK;
+            }
+            // (the query is needed on the device by the fallbacks: the pinned block is device-addressable)
+            PVS_TRY(search_fallbacks(ix, *c, io + 64, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count));
+            HIP_TRY(hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_count, c->d_out_count, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return PVS_OK;
+        };
+        st = run();
+        if (st != PVS_OK) (void)hipStreamSynchronize(c->stream);
+        ix->searches++;
+        ctx_done(ix, c);
+        return st;
+    }
     void *d_q = nullptr;
     if (st == PVS_OK) {
         // (hipMalloc/hipFree per call would cost ~0.1 ms and hipFree synchronises the whole device,

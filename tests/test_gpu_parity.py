@@ -174,6 +174,13 @@ def test_search_matches_oracle(pvs, dtype, metric, n, dim, batch, k, path):
         assert st.fast_queries == batch and st.dense_queries == 0, "filter-scan path must serve these shapes"
     if dt == pvs.I8:  # pre-quantized codes (QuantResolved.query_quant) give the same page
         assert_same_page(ix.search(hq, k, m), exp)
+    if path == "auto" and batch == 1:  # a single query took the one-launch exact search (pvs_direct.hip): the filter scan as well
+        pvs.debug_set("no_direct_topk", 1)
+        try:
+            assert_same_page(ix.search(queries, k, m), exp)
+        finally:
+            pvs.debug_set("no_direct_topk", 0)
+        assert ix.stats().dense_queries == 0
     if path == "auto" and batch <= 128:
         # the LDS-light pass C (what a pipelined caller's search runs beside the next search's scan; every element type since round 4)
         pvs.debug_set("force_light_finalize", 1)
@@ -669,8 +676,16 @@ def test_massive_ties_fall_back_to_dense(pvs):
         ix = make_index(pvs, dt, rows, scale)
         hc = host_corpus(dt, rows, scale)
         hq = orc.quantize_int8(base[:1] * 0.7 + base[2:3] * 0.3, scale) if dt == pvs.I8 else (base[:1] * 0.7 + base[2:3] * 0.3)
+        # a single query takes the one-launch exact search (pvs_direct.hip): ties cost it nothing
         _check(pvs, ix, dt, pvs.COSINE, hc, hq, 10)
         _check(pvs, ix, dt, pvs.L2, hc, hq, 100)
+        assert ix.stats().dense_queries == 0
+        pvs.debug_set("no_direct_topk", 1)  # the filter scan's own behaviour
+        try:
+            _check(pvs, ix, dt, pvs.COSINE, hc, hq, 10)
+            _check(pvs, ix, dt, pvs.L2, hc, hq, 100)
+        finally:
+            pvs.debug_set("no_direct_topk", 0)
         assert ix.stats().dense_queries >= 1, "ties beyond the survivor capacity must be answered by the dense path"
         ix.close()
 
@@ -692,7 +707,13 @@ def test_unrepresentative_sample_overflows_to_dense(pvs):
     ix = make_index(pvs, pvs.I8, rows, scale)
     hc = orc.quantize_int8(rows, scale)
     hq = orc.quantize_int8(q[None, :], scale)
-    _check(pvs, ix, pvs.I8, pvs.COSINE, hc, hq, 100)
+    _check(pvs, ix, pvs.I8, pvs.COSINE, hc, hq, 100)  # (a single query: the one-launch exact search, no sample involved)
+    assert ix.stats().dense_queries == 0
+    pvs.debug_set("no_direct_topk", 1)  # the filter scan's own behaviour
+    try:
+        _check(pvs, ix, pvs.I8, pvs.COSINE, hc, hq, 100)
+    finally:
+        pvs.debug_set("no_direct_topk", 0)
     st = ix.stats()
     assert st.dense_queries == 1, "candidate overflow must hand the query to the dense path"
     ix.close()
