@@ -626,7 +626,13 @@ pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
  *   "scratch_idle_cap_mb" N   idle scratch kept per device (default 16 GiB)  "scratch_bypass"   scratch straight from hipMalloc/hipFree
  *   "no_sparse" / "sparse_max" N   filtered searches: never / up to N allowed rows on the gather-score path
  *   "no_fused_agg"            per-item MAX/AVG/weighted through the dense matrix + k_group_aggregate
- *   "no_side_finalize"        pvs_search_device: pass C on the search's own stream instead of the index's side stream */
+ *   "no_side_finalize"        pvs_search_device: pass C on the search's own stream instead of the index's side stream
+ *   "rrf_host_rounds" / "multi_host_pages" / "prelude_stream"   round-3 host forms of the RRF rounds / the multi-device per-item merge; the prelude-stream experiment
+ *   "dense_nq4"               k_dense_exact: at most 4 float queries per pass (not the packed 8-query instance)
+ *   "marker_events"           profiling spans as hipEventRecord markers around the kernels instead of events bound to the dispatches
+ *   "no_direct_topk"          a single query always takes the filter scan, never the one-launch exact search (pvs_direct.hip)
+ *   "direct_max_mb" N         ... takes the one-launch search up to N MB of rows (default 8192)
+ *   "direct_queries"          (read-only counter) single queries answered by the one-launch search, process-wide */
 pvs_status pvs_debug_set(const char *key, int64_t value);
 pvs_status pvs_debug_get(const char *key, int64_t *out_value);
 /* Stage digests of the process' last single-device pvs_rrf_search run under "rrf_digest": out[branch * 4 + stage], stage 0 = the

@@ -36,6 +36,7 @@ struct DirectK {
     const QInfo *qinfo;
     const uint32_t *trank, *tinv;  // second sort key (pvs_index_set_order_keys) or nullptr
     const int64_t *ids;
+    const uint8_t *mask;          // candidate mask or nullptr
     unsigned long long *wg_keys;  // [grid][k]: a workgroup's best keys, ascending
     uint32_t *wg_cnt;             // [grid]
     uint32_t *ticket;             // zero between launches (the last workgroup resets it)
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         if (++cs == a.kslabs) {
             const uint64_t row = (gw + (uint64_t)cp * a.n_waves) * 64 + lane;
             bool valid = row < a.n_rows;
+            if (valid && a.mask) valid = a.mask[row] != 0;
             unsigned long long key = ~0ull;
             if (valid) {
                 float d;
@@ -529,6 +531,7 @@ hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s) {
     k.trank = d.trank;
     k.tinv = d.tinv;
     k.ids = d.ids;
+    k.mask = d.mask;
     const uint32_t n_pairs = (uint32_t)((d.n_rows + 63) / 64);
     const uint32_t grid = std::min<uint32_t>({(n_pairs + 3) / 4, std::max<uint32_t>(d.n_cu, 1), 256u});
     uint8_t *w = (uint8_t *)d.work;

@@ -55,6 +55,7 @@ struct DirectArgs {
     const void *qexact;  // [dim] int8 codes (int8 index) or f32: SearchCtx::d_qexact after prep_chunk
     const QInfo *qinfo;
     const uint32_t *trank = nullptr, *tinv = nullptr;
+    const uint8_t *mask = nullptr;  // optional candidate mask [n_rows]: a row whose byte is 0 takes part in nothing
     uint32_t k;
     void *work;          // pvs_direct_work_bytes(n_cu), zeroed once
     int64_t *out_ids;

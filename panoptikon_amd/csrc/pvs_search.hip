@@ -235,7 +235,7 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     return PVS_OK;
 }
 
-// One query, no candidate mask, a page of <= 256 rows over a corpus below the crossover: ONE launch scores every row exactly and
+// One query, a page of <= 256 rows over a corpus below the crossover: ONE launch scores every row exactly and
 // selects the page on the way (pvs_direct.hip) — the filter scan's five dependent launches are most of such a search's latency.
 // Measured (tools/direct_crossover.py, 768-d, p50 of pvs_search, k = 10 / 100): it wins at every size tried — int8 1M rows 0.197 / 0.229 ms against
 // 0.239 / 0.236, 8M 1.000 / 1.000 against 1.017 / 1.017; f16 4M 1.01 / 1.00 against 1.09 / 1.10; f32 4M (11.7 GB) 1.94 / 1.88 against 2.01 / 2.04 — by the
@@ -246,7 +246,7 @@ bool pvs_direct_route(const pvs_index *ix, uint32_t k) {
     const uint64_t lim_mb = pvs_dbg(PVS_DBG_DIRECT_MAX_MB) > 0 ? (uint64_t)pvs_dbg(PVS_DBG_DIRECT_MAX_MB) : PVS_DIRECT_CROSSOVER_MB;
     return ix->n * (uint64_t)ix->stride <= (lim_mb << 20);
 }
-static bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k) { return batch == 1 && !c.cur_mask && pvs_direct_route(ix, k); }
+static bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k) { return batch == 1 && pvs_direct_route(ix, k); }
 static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t k, int metric, int64_t *oid, float *od,
                                  uint32_t *oc, uint8_t *h_page = nullptr) {
     if (!c.d_direct) {
@@ -270,6 +270,7 @@ static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_quer
         d.trank = ix->d_trank;
         d.tinv = ix->d_tinv;
     }
+    d.mask = c.cur_mask;  // (pvs_search_filtered: rows outside the mask are skipped)
     d.k = k;
     d.work = c.d_direct;
     d.out_ids = oid;

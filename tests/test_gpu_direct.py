@@ -178,7 +178,7 @@ def test_direct_search_honours_the_second_sort_key(pvs):
 
 
 def test_direct_search_is_not_taken_where_it_does_not_apply(pvs):
-    """Batches, pages beyond 256 rows, candidate masks and a corpus above the crossover stay on the filter scan."""
+    """Batches, pages beyond 256 rows and a corpus above the crossover stay on the filter scan."""
     n, dim = 5000, 128
     rows = orc.synth_rows(31, 0, n, dim)
     ix = _index(pvs, pvs.F32, rows, None)
@@ -186,9 +186,6 @@ def test_direct_search_is_not_taken_where_it_does_not_apply(pvs):
     before = _direct_searches(pvs)
     ix.search(q, 10, pvs.COSINE)                     # two queries
     ix.search(q[0], 257, pvs.COSINE)                 # k > 256
-    mask = np.ones(n, np.uint8)
-    mask[::2] = 0
-    ix.search_filtered(q[0], 10, mask, pvs.COSINE)   # candidate mask
     pvs.debug_set("direct_max_mb", 1)                # crossover below this corpus (2.5 MB)
     try:
         ix.search(q[0], 10, pvs.COSINE)
@@ -229,3 +226,40 @@ def test_direct_search_int8_sums_beyond_the_closed_form(pvs):
     assert ix2.stats().dense_queries == 0
     ix.close()
     ix2.close()
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
+def test_direct_search_with_a_candidate_mask(pvs, dtype):
+    """pvs_search_filtered with a mask too dense for the gather path: the one-launch search skips the rows outside the mask; a page
+    the allowed rows cannot fill ends where they end (NULL rows of the mask first, in id order)."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    n, dim = 60000, 200  # (masks that leave more than 16,384 rows: fewer go to the gather path, pvs_sparse.hip)
+    rows = orc.synth_rows(41, 0, n, dim)
+    rows[[7, 8, 9000]] = 0.0
+    scale = orc.compute_int8_scale(rows)
+    ids = np.arange(n, dtype=np.int64) * 5 + 1
+    ix = _index(pvs, dt, rows, scale, ids)
+    hc = _host(dt, rows, scale)
+    q = orc.synth_rows(42, 0, 1, dim)[0]
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    rng = np.random.default_rng(8)
+    for frac, k in ((0.4, 10), (0.4, 256), (0.9, 100)):
+        mask = (rng.random(n) < frac).astype(np.uint8)
+        mask[7] = 1
+        allowed = np.nonzero(mask)[0]
+        for m in (pvs.COSINE, pvs.L2):
+            ei, ed = orc.search(dt, m, hc[allowed], hq, k, ids=ids[allowed], threads=4)
+            before = _direct_searches(pvs)
+            gi, gd, gc = ix.search_filtered(q, k, mask, m)
+            assert _direct_searches(pvs) == before + 1
+            assert gc[0] == k and np.array_equal(gi[0, :k], ei[0])
+            assert np.array_equal(gd[0, :k].view(np.uint32), ed[0].view(np.uint32))
+    # the zero vectors (NULL cosine distance) are allowed and the page reaches them only if it is long enough: same page as the oracle's either way
+    mask = np.zeros(n, np.uint8)
+    mask[rng.choice(n, 17000, replace=False)] = 1  # (dense enough to stay off the gather path)
+    mask[[7, 8, 9000]] = 1
+    allowed = np.nonzero(mask)[0]
+    ei, ed = orc.search(dt, orc.COSINE, hc[allowed], hq, 256, ids=ids[allowed], threads=4)
+    gi, gd, gc = ix.search_filtered(q, 256, mask, pvs.COSINE)
+    assert gc[0] == 256 and np.array_equal(gi[0], ei[0]) and np.array_equal(gd[0].view(np.uint32), ed[0].view(np.uint32))
+    ix.close()
