@@ -85,7 +85,7 @@ def parse():
                     help="N ranks: when RCCL cannot be initialised (e.g. two ranks on one GPU) exchange the pages over the control "
                          "socket instead of failing (testing only; the line then says exchange=ctl-host-gather)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the two secondary timed regions of the default run (single-query 10M x 768 f16; 256 int8 queries per pass)")
+                    help="skip the secondary timed regions of the default run (single-query 10M x 768 f16; 256 int8 queries per pass; one query over 690k x 768 int8)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="pvs_debug_set(KEY, VALUE) before the run (tuning sweeps: sample_div, sample_j_div, scan_no_wide128, ...; the line records it)")
     a = ap.parse_args()
@@ -680,7 +680,7 @@ def main():
     }
 
     # ------------------------------------------------- the north star's other two shapes (own timed regions, headline fields untouched)
-    def timed_region(ixh, dt_name, b, steps, warmup):
+    def timed_region(ixh, dt_name, b, steps, warmup, K=K):
         """`steps` batches of b queries through pvs_search_device on index ixh (one stream), kernel durations from HIP events in the
         timed region: the same measurement as the headline's, as one self-contained record."""
         esz2 = {"i8": 1, "f16": 2, "f32": 4}[dt_name]
@@ -769,6 +769,43 @@ def main():
                     rec["parity"] = {"filter_path_equals_device_dense_path": bool(np.array_equal(fi, di2) and np.array_equal(fd.view(np.uint32), dd2.view(np.uint32)))}
                 secondary.append(rec)
                 ix16.close()
+            # (c) the reference's own shape: ONE query (its API answers one per request, api/search.rs:524-694), a page of 10 rows
+            # (DEFAULT_LIMIT), over an index of its measured size (690k vectors, docs/vector-quant-measurements.md) — served by the
+            # one-launch exact search (csrc/pvs_direct.hip): queries/s of the pipelined entry point + the latency of pvs_search
+            n_ref, k_ref = 690_000, 10
+            ixr = pvs.VectorIndex(pvs.I8, D, device=device, capacity_rows=n_ref)
+            ixr.set_scale(scale)
+            str_ = pvs.DeviceBuffer(n_ref * D * 4, device)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, 0, n_ref, D, str_.ptr))
+            ixr.add_f32((str_, n_ref))
+            str_.free()
+            ixr.sync()
+            rec = timed_region(ixr, "i8", 1, 200, 10, K=k_ref)
+            rec["what"] = "the reference's request shape: one query, page of 10, 690k x 768 int8 (one launch: exact distances + page)"
+            qf = np.empty((1, D), np.float32)
+            qtmp = pvs.DeviceBuffer(D * 4, device)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, 1, D, qtmp.ptr))
+            qf[:] = qtmp.to_numpy(np.float32, (1, D))
+            qtmp.free()
+            for _ in range(10):
+                ixr.search(qf, k_ref, metric)
+            lat = []
+            for _ in range(300):
+                t_l = time.perf_counter()
+                hi_, hd_, hc_ = ixr.search(qf, k_ref, metric)
+                lat.append(time.perf_counter() - t_l)
+            lat = np.sort(np.array(lat)) * 1e3
+            rec["pvs_search_latency_ms"] = {"p50": round(float(lat[150]), 4), "p99": round(float(lat[296]), 4), "calls": 300,
+                                            "how": "host-buffer entry point, one caller: query from and page into pinned memory, one synchronisation"}
+            rec["path"]["direct_queries"] = int(pvs.debug_get("direct_queries"))
+            if not args.no_verify:
+                import oracle as orc_r
+
+                rows_r = ixr.read_rows(0, n_ref)
+                ei_r, ed_r = orc_r.search(orc_r.I8, orc_r.COSINE if metric == pvs.COSINE else orc_r.L2, rows_r, orc_r.quantize_int8(qf, scale), k_ref, threads=min(os.cpu_count() or 1, 64))
+                rec["parity"] = {"oracle_rows": n_ref, "ids_and_distances_bit_exact": bool(np.array_equal(hi_[0, :k_ref], ei_r[0]) and np.array_equal(hd_[0, :k_ref].view(np.uint32), ed_r[0].view(np.uint32)))}
+            secondary.append(rec)
+            ixr.close()
         except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
             secondary.append({"error": str(e)})
         result["secondary"] = secondary
