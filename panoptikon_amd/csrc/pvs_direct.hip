@@ -66,8 +66,8 @@ struct MiscLds {
     unsigned long long fin[256];  // the page's keys
     uint32_t hist[256];
     uint32_t misc[8], wcnt[4];
-    uint32_t ticket, pool_n, more, total, outn;
-    unsigned long long kmin, kmax;
+    uint32_t ticket, pool_n, more, total, outn, have;
+    unsigned long long kmin, kmax, slot;
 };
 static_assert(sizeof(MiscLds) <= DIR_MISC_LDS, "misc LDS");
 
@@ -80,6 +80,28 @@ __device__ static inline float dir_elem(const uint4 &v, int e) {
         return h2f((uint16_t)(w[e >> 1] >> ((e & 1) * 16)));
     else
         return __builtin_bit_cast(float, w[e]);
+}
+
+__device__ static inline uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+__device__ static inline unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ static inline unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
 }
 
 // LDS traffic of ONE wave: its instructions reach the LDS in order, so a read sees every earlier write of the same wave once the
@@ -123,8 +145,10 @@ __device__ static inline void wg_sort(unsigned long long *s, uint32_t n, uint32_
 
 // kth smallest (1-based) of the keys of `keys` that are not ~0, as an offset from kmin: 8-bit digits of (key - kmin) from byte
 // `shift0 / 8` down (every key's offset is below 2^(shift0 + 8)).  Workgroup-wide; hist: 256 words, misc: 2 words.
+// A digit whose bin holds ONE key ends the search: that key is fetched by a last scan (three or four passes instead of seven for
+// keys that spread over 50 bits).  slot: one 64-bit LDS word.
 __device__ static inline unsigned long long wg_radix_kth_range(const unsigned long long *keys, uint32_t n, uint32_t kth, unsigned long long kmin, int shift0,
-                                                               uint32_t *hist, uint32_t *misc) {
+                                                               uint32_t *hist, uint32_t *misc, unsigned long long *slot) {
     const uint32_t tid = threadIdx.x;
     unsigned long long prefix = 0, mask = 0;
     uint32_t kk = kth;
@@ -175,8 +199,18 @@ __device__ static inline unsigned long long wg_radix_kth_range(const unsigned lo
     return prefix;
 }
 
+#ifdef PVS_DIR_PROF  // tuning build: wall clock (100 MHz s_memrealtime) at the phase boundaries of the LAST workgroup
+#define DIR_STAMP(i) dp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define DIR_STAMP(i) do { } while (0)
+#endif
+
 template <int DT, int METRIC>
 __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
+#ifdef PVS_DIR_PROF
+    unsigned long long dp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DIR_STAMP(0);
     constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;  // components per 16-B chunk
     constexpr int EPS = 16 * PER;                                    // components per 256-B slab row
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -191,6 +225,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         for (uint32_t i = tid; i < a.qpad_ld; i += 256) qlds[i] = i < a.dim ? ((const float *)a.qexact)[i] : 0.f;
     }
     __syncthreads();
+    DIR_STAMP(1);
     const float bb = a.qinfo[0].bb;
     // a query that makes every distance NULL (zero / NaN-bearing): the whole page is the head of ALL rows in tie order — the
     // NULL-tail step writes it (flag 3, as pass C says it); nothing to scan
@@ -234,10 +269,37 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
     // the wave's list: cnt keys, every one below thr once k are held
     uint32_t cnt = 0;
     unsigned long long thr = ~0ull;
-    auto cut = [&]() {  // keep the k smallest, ascending
-        for (uint32_t i = cnt + lane; i < a.capw; i += 64) sel[i] = ~0ull;
+    // keep the k smallest, ascending.  A rank sort: the keys are distinct, so a key's slot is the number of smaller ones — every lane
+    // holds up to 8 keys in registers and walks the list once with broadcast reads (capw^2 / 64 compares per lane: 1 us at 128
+    // slots where the bitonic network's 28 wait-separated steps took 6)
+    auto cut = [&]() {
+        unsigned long long mk[8];
+        uint32_t rk[8];
+        const uint32_t per = a.capw >> 6;  // 2, 4 or 8
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t slot = lane + 64u * (uint32_t)j;
+            mk[j] = ((uint32_t)j < per && slot < cnt) ? sel[slot] : ~0ull;
+            rk[j] = 0;
+        }
+        for (uint32_t i = cnt + lane; i < ((cnt + 7u) & ~7u); i += 64) sel[i] = ~0ull;  // (pads compare "not smaller")
         wave_lds_sync();
-        wave_sort(sel, a.capw, lane);
+        const ulonglong2 *rd = (const ulonglong2 *)sel;  // (nothing is written while the ranks are counted)
+        for (uint32_t i = 0; i < cnt; i += 8) {  // eight keys per step, four broadcast 16-byte reads in flight
+            const ulonglong2 x0 = rd[(i >> 1) + 0], x1 = rd[(i >> 1) + 1], x2 = rd[(i >> 1) + 2], x3 = rd[(i >> 1) + 3];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < per) {
+                    const unsigned long long m = mk[j];
+                    rk[j] += (x0.x < m ? 1u : 0u) + (x0.y < m ? 1u : 0u) + (x1.x < m ? 1u : 0u) + (x1.y < m ? 1u : 0u) + (x2.x < m ? 1u : 0u) +
+                             (x2.y < m ? 1u : 0u) + (x3.x < m ? 1u : 0u) + (x3.y < m ? 1u : 0u);
+                }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)j < per && mk[j] != ~0ull && rk[j] < a.k) sel[rk[j]] = mk[j];
+        wave_lds_sync();
         if (cnt > a.k) cnt = a.k;
         if (cnt == a.k) thr = sel[a.k - 1];
     };
@@ -328,25 +390,52 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         }
     }
     wait_vm<0>();
+    DIR_STAMP(2);
     cut();  // ascending, cnt <= k
+    DIR_STAMP(3);
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.bad, 1u);
     __syncthreads();
 
-    // ---- the workgroup's k best: four sorted lists padded to kp each, one sort of 4 kp keys in the (now idle) ring
+    // ---- the workgroup's k best: the four sorted lists merge by rank — a key's slot is its index in its own list plus, for each
+    // other list, the number of smaller keys there (a binary search; the keys are distinct) — into the (now idle) ring
     unsigned long long *const mb = (unsigned long long *)smem;
     MiscLds &ml = *(MiscLds *)(smem + DIR_RING_LDS + DIR_Q_LDS + DIR_SEL_LDS);
     if (lane == 0) ml.wcnt[wave] = cnt;
-    for (uint32_t i = lane; i < a.kp; i += 64) mb[(size_t)wave * a.kp + i] = i < cnt ? sel[i] : ~0ull;
     __syncthreads();
-    wg_sort(mb, 4 * a.kp, tid);
+    {
+        const unsigned long long *lists = (const unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS);
+        for (uint32_t x = tid; x < 4 * a.kp; x += 256) {
+            const uint32_t w = x / a.kp, i = x - w * a.kp;
+            if (i >= ml.wcnt[w]) continue;
+            const unsigned long long key = lists[(size_t)w * a.capw + i];
+            uint32_t rank = i;
+            for (uint32_t o = 0; o < 4; o++) {
+                if (o == w) continue;
+                const unsigned long long *lo_ = lists + (size_t)o * a.capw;
+                uint32_t lo = 0, hi = ml.wcnt[o];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (lo_[mid] < key)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < a.k) mb[rank] = key;
+        }
+    }
+    __syncthreads();
     const uint32_t wtot = min(ml.wcnt[0] + ml.wcnt[1] + ml.wcnt[2] + ml.wcnt[3], a.k);
     unsigned long long *const mine = a.wg_keys + (size_t)blockIdx.x * a.k;
     for (uint32_t i = tid; i < wtot; i += 256) mine[i] = mb[i];
     if (tid == 0) a.wg_cnt[blockIdx.x] = wtot;
     __threadfence();
     __syncthreads();
+    DIR_STAMP(4);
     if (tid == 0) ml.ticket = atomicAdd(a.ticket, 1u);
     __syncthreads();
+    DIR_STAMP(5);
     if (ml.ticket != gridDim.x - 1) return;
     __threadfence();
 
@@ -357,6 +446,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
     uint32_t *const s_cntg = s_len + 256;                               // [256] its length
     if (tid == 0) {
         ml.total = 0;
+        ml.have = 0;
         ml.outn = 0;
         ml.kmin = ~0ull;
         ml.kmax = 0;
@@ -370,7 +460,11 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         const uint32_t cg = tid < G ? a.wg_cnt[tid] : 0;
         s_len[tid] = min(cg, c0);
         s_cntg[tid] = cg;
-        if (cg) atomicAdd(&ml.total, cg);
+        const uint32_t tsum = wave_sum_u32(cg), hsum = wave_sum_u32(min(cg, c0));  // (one LDS atomic per wave, not per thread)
+        if (lane == 0) {
+            atomicAdd(&ml.total, tsum);
+            atomicAdd(&ml.have, hsum);
+        }
     }
     for (uint32_t x = tid; x < G * c0; x += 256) {
         const uint32_t g = x / c0, i = x - g * c0;
@@ -378,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
     }
     if (tid == 0) ml.pool_n = G * c0;
     __syncthreads();
+    DIR_STAMP(6);
     const uint32_t total = ml.total;
     const uint32_t want = (uint32_t)(a.k < a.n_rows ? a.k : a.n_rows);
     const uint32_t kk = min(total, a.k);  // rows on the finite part of the page
@@ -401,19 +496,21 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
                     real++;
                 }
             }
-            if (real) {
+            (void)real;
+            lo = wave_min_u64(lo);
+            hi = wave_max_u64(hi);
+            if (lane == 0 && lo != ~0ull) {
                 atomicMin(&ml.kmin, lo);
                 atomicMax(&ml.kmax, hi);
             }
             scanned = pn;
         }
         __syncthreads();
-        uint32_t have = 0;
-        for (uint32_t g = 0; g < G; g++) have += s_len[g];  // (G <= 256 LDS reads, broadcast)
+        const uint32_t have = ml.have;  // real keys in the pool
         if (have >= kk) {
             const unsigned long long kmin = ml.kmin, range = ml.kmax - kmin;
             const int top = range ? 63 - __builtin_clzll(range) : 0;
-            T = kmin + wg_radix_kth_range(pool, pn, kk, kmin, (top / 8) * 8, ml.hist, ml.misc) + 1;
+            T = kmin + wg_radix_kth_range(pool, pn, kk, kmin, (top / 8) * 8, ml.hist, ml.misc, &ml.slot) + 1;
         }
         if (tid == 0) ml.more = 0;
         __syncthreads();
@@ -427,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
                 if (at + take <= DIR_POOL) {
                     for (uint32_t i = 0; i < take; i++) pool[at + i] = lst[len + i];
                     s_len[tid] = len + take;
+                    atomicAdd(&ml.have, take);
                 }
                 atomicAdd(&ml.more, 1u);
             }
@@ -440,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         __syncthreads();  // (ml.more is reset in the next round)
         if (more == 0) break;
     }
+    DIR_STAMP(7);
     const bool can_complete = a.null_ok && bb < __builtin_inff() && (METRIC == PVS_L2 || bb > 0.f);
     const bool tail = kk < want;
     if (overflow || (tail && !can_complete)) {
@@ -464,7 +563,11 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
     {
         const unsigned long long v = ml.fin[tid];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < 256; j++) rank += ml.fin[j] < v ? 1u : 0u;
+        const ulonglong2 *f2 = (const ulonglong2 *)ml.fin;  // (entries beyond the page's kk keys are ~0: never smaller)
+        for (uint32_t j = 0; j < kk; j += 4) {
+            const ulonglong2 x0 = f2[(j >> 1)], x1 = f2[(j >> 1) + 1];
+            rank += (x0.x < v ? 1u : 0u) + (x0.y < v ? 1u : 0u) + (x1.x < v ? 1u : 0u) + (x1.y < v ? 1u : 0u);
+        }
         __syncthreads();
         if (v != ~0ull) ml.fin[rank] = v;
         __syncthreads();
@@ -486,6 +589,12 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
             a.out_dist[i] = __builtin_nanf("");
         }
     }
+#ifdef PVS_DIR_PROF
+    DIR_STAMP(8);
+    if (tid == 0)
+        printf("dirprof G %u k %u: fill %llu stream %llu cut %llu wgmerge+publish %llu ticket %llu pool-load %llu select-loop %llu page %llu (x10 ns)\n", G, a.k,
+               dp[1] - dp[0], dp[2] - dp[1], dp[3] - dp[2], dp[4] - dp[3], dp[5] - dp[4], dp[6] - dp[5], dp[7] - dp[6], dp[8] - dp[7]);
+#endif
     if (tid == 0) {
         if (a.h_out_count && !tail) a.h_out_count[0] = kk;
         a.out_count[0] = kk;
