@@ -263,3 +263,53 @@ def test_direct_search_with_a_candidate_mask(pvs, dtype):
     gi, gd, gc = ix.search_filtered(q, 256, mask, pvs.COSINE)
     assert gc[0] == 256 and np.array_equal(gi[0], ei[0]) and np.array_equal(gd[0].view(np.uint32), ed[0].view(np.uint32))
     ix.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PVS_FUZZ_SEEDS", "30"))))
+def test_randomized_single_queries_against_the_oracle(pvs, seed):
+    """Seeded sweep over what the one-launch search sees: element type / metric / rows / dim / k, duplicated rows (ties), zero rows
+    (NULL cosine distance), huge and tiny components, an order key on every other seed, a candidate mask on every third."""
+    rng = np.random.default_rng(31000 + seed)
+    dt = [pvs.I8, pvs.F16, pvs.F32][seed % 3]
+    m = [pvs.COSINE, pvs.L2][(seed // 3) % 2]
+    n = int(rng.choice([1, 2, 63, 64, 65, 129, 1000, 4097, 20000, 70001]))
+    dim = int(rng.choice([1, 3, 17, 64, 65, 100, 257, 384, 768, 1000, 1100, 1536]))
+    k = int(rng.choice([1, 2, 10, 64, 65, 100, 256]))
+    rows = orc.synth_rows(32000 + seed, 0, n, dim) if dim > 1 else rng.standard_normal((n, 1)).astype(np.float32)
+    if n > 8:
+        src = rng.integers(0, n, 5)
+        rows[rng.integers(0, n, 5)] = rows[src]
+        rows[int(rng.integers(0, n))] = 0.0
+        run = int(rng.integers(0, n - 4))
+        rows[run:run + 4] = rows[run]  # a short run of exact copies stored side by side
+    if dt != pvs.I8 and n > 4:
+        rows[int(rng.integers(0, n))] *= np.float32(300.0 if dt == pvs.F16 else 1e18)
+        rows[int(rng.integers(0, n))] *= np.float32(1e-3 if dt == pvs.F16 else 1e-18)
+    q = orc.synth_rows(33000 + seed, 0, 1, dim)[0] if dim > 1 else rng.standard_normal(1).astype(np.float32)
+    if n > 8 and seed % 4 == 1:
+        q = rows[int(rng.integers(0, n))].copy()  # the query is a stored row: distance 0 (or a tiny negative one) at the top
+    scale = orc.compute_int8_scale(rows)
+    ids = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+    ix = _index(pvs, dt, rows, scale, ids)
+    keys = None
+    if seed % 2 == 1:
+        keys = rng.integers(0, 6, n).astype(np.int64) + 1_700_000_000
+        ix.set_order_keys(keys)
+    hc = _host(dt, rows, scale)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    om = orc.COSINE if m == pvs.COSINE else orc.L2
+    d = orc.score_all(dt, om, hc, hq)
+    allowed = np.arange(n)
+    mask = None
+    if seed % 3 == 2 and n > 100:
+        mask = (rng.random(n) < 0.7).astype(np.uint8)
+        allowed = np.nonzero(mask)[0]
+    ei, ed = orc.topk_ordered(d[allowed], k, ids[allowed], keys[allowed] if keys is not None else np.zeros(len(allowed), np.int64))
+    kk = min(k, len(allowed))
+    gi, gd, gc = ix.search(q, k, m) if mask is None else ix.search_filtered(q, k, mask, m)
+    assert gc[0] == kk, (gc, kk)
+    assert np.array_equal(gi[0, :kk], ei[:kk]), (seed, n, dim, k)
+    assert np.array_equal(np.isnan(gd[0, :kk]), np.isnan(ed[:kk]))
+    fin = ~np.isnan(ed[:kk])
+    assert np.array_equal(gd[0, :kk][fin].view(np.uint32), ed[:kk][fin].view(np.uint32)), (seed, n, dim, k)
+    ix.close()
