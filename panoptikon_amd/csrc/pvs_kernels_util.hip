@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
     // the reference's bMag: sequential f32 sum of squares of what it scores.  int8 codes: integer
     // terms, exact in any order while < 2^24 -> parallel integer sum; otherwise (and for floats)
     // one lane walks the vector in order, from a coalesced LDS copy.
-    __shared__ float s_q[4096];
+    __shared__ __attribute__((aligned(16))) float s_q[4096];
     __shared__ long long s_isum[4];
     float bb = 0.f;
     bool have_bb = false;
@@ -420,12 +420,20 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
             have_bb = true;
         }
     } else if (dim <= 4096) {
+        // the products (one rounding each) by every thread, the chain of additions — the only sequential part — by one lane from
+        // 16-byte LDS reads: the same roundings in the same order as the reference's loop, in a third of the time
         const float *qe = (const float *)qexact + (uint64_t)b * dim;
-        for (uint32_t i = tid; i < dim; i += 256) s_q[i] = qe[i];
+        const uint32_t dim4 = (dim + 3u) & ~3u;
+        for (uint32_t i = tid; i < dim4; i += 256) s_q[i] = i < dim ? __fmul_rn(qe[i], qe[i]) : 0.f;
         __syncthreads();
         if (tid == 0) {
             float acc = 0.f;
-            for (uint32_t i = 0; i < dim; i++) acc = __fadd_rn(acc, __fmul_rn(s_q[i], s_q[i]));
+            const uint32_t full = dim & ~3u;
+            for (uint32_t i = 0; i < full; i += 4) {
+                const float4 v = *(const float4 *)(s_q + i);
+                acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, v.x), v.y), v.z), v.w);
+            }
+            for (uint32_t i = full; i < dim; i++) acc = __fadd_rn(acc, s_q[i]);  // (never the zero padding: -0 + 0 would lose a sign)
             bb = acc;
         }
         have_bb = true;
