@@ -9,9 +9,9 @@
 // 64 rows per wave, no workgroup barrier in the loop), and
 //   * every wave keeps the best rows it has seen in an LDS list of 64-bit keys (distance sort key | tie rank or row): a row enters
 //     when its key is below the wave's current k-th best (one ballot per 64 rows, usually empty), a full list is cut back to its
-//     k smallest by a wave-wide bitonic sort (a handful of times per wave);
+//     k smallest by a wave-wide rank sort (a handful of times per wave);
 //   * at the end the four waves' lists merge into the workgroup's k best, the workgroup publishes them (sorted) and takes a
-//     ticket; the LAST workgroup merges all lists: the first 64 keys of each go to an LDS pool, a radix select finds the pool's
+//     ticket; the LAST workgroup merges all lists: the first few keys of each go to an LDS pool, a radix select finds the pool's
 //     k-th key T, a list whose next unread key is below T hands over 64 more, until no list has anything below T — exact whatever
 //     the placement of the best rows (a run of near-duplicates stored side by side sits in one workgroup), and the page is the
 //     pool's k smallest, sorted; written with the same key order as pass C ((distance, tie rank | row), NULL distances never on it).
@@ -110,39 +110,6 @@ __device__ static inline void wave_lds_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-// ascending bitonic sort of n (a power of two) keys by one wave
-__device__ static inline void wave_sort(volatile unsigned long long *s, uint32_t n, uint32_t lane) {
-    for (uint32_t sz = 2; sz <= n; sz <<= 1)
-        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            for (uint32_t i = lane; i < n / 2; i += 64) {
-                const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
-                const bool up = (lo & sz) == 0;
-                const unsigned long long x = s[lo], y = s[hi];
-                if ((x > y) == up) {
-                    s[lo] = y;
-                    s[hi] = x;
-                }
-            }
-            wave_lds_sync();
-        }
-}
-// ... by the workgroup (256 threads)
-__device__ static inline void wg_sort(unsigned long long *s, uint32_t n, uint32_t tid) {
-    for (uint32_t sz = 2; sz <= n; sz <<= 1)
-        for (uint32_t st = sz >> 1; st > 0; st >>= 1) {
-            for (uint32_t i = tid; i < n / 2; i += 256) {
-                const uint32_t lo = 2 * i - (i & (st - 1)), hi = lo + st;
-                const bool up = (lo & sz) == 0;
-                const unsigned long long x = s[lo], y = s[hi];
-                if ((x > y) == up) {
-                    s[lo] = y;
-                    s[hi] = x;
-                }
-            }
-            __syncthreads();
-        }
-}
-
 // kth smallest (1-based) of the keys of `keys` that are not ~0, as an offset from kmin: 8-bit digits of (key - kmin) from byte
 // `shift0 / 8` down (every key's offset is below 2^(shift0 + 8)).  Workgroup-wide; hist: 256 words, misc: 2 words.
 // A digit whose bin holds ONE key ends the search: that key is fetched by a last scan (three or four passes instead of seven for
