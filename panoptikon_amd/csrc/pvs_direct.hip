@@ -47,6 +47,7 @@ struct DirectK {
     int64_t *h_out_ids;  // pinned mirror of the page (or nullptr)
     float *h_out_dist;
     uint32_t *h_out_count;
+    uint32_t *h_out_rows;
     uint64_t n_rows;
     uint32_t stride, kslabs, dim, qpad_ld, n_pairs, n_waves, k, kp, capw;
     int null_ok, q_is_i8;
@@ -543,13 +544,15 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
         if (i < kk) {
             const unsigned long long v = ml.fin[i];
             const uint32_t r = (uint32_t)v;
-            const int64_t id = a.ids[a.tinv ? a.tinv[r] : r];
+            const uint32_t srow = a.tinv ? a.tinv[r] : r;
+            const int64_t id = a.ids[srow];
             const float d = f32_from_sort_key((uint32_t)(v >> 32));
             a.out_ids[i] = id;
             a.out_dist[i] = d;
             if (a.h_out_ids && !tail) {
                 a.h_out_ids[i] = id;
                 a.h_out_dist[i] = d;
+                if (a.h_out_rows) a.h_out_rows[i] = srow;
             }
         } else {
             a.out_ids[i] = -1;
@@ -624,6 +627,7 @@ hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s) {
     k.h_out_ids = d.h_out_ids;
     k.h_out_dist = d.h_out_dist;
     k.h_out_count = d.h_out_count;
+    k.h_out_rows = d.h_out_rows;
     k.n_rows = d.n_rows;
     k.stride = d.stride;
     k.kslabs = d.stride / PVS_KSLAB_BYTES;

@@ -276,7 +276,9 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 SearchCtx *ctx_acquire(pvs_index *ix, uint32_t *ticket, bool block = true);
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                        const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count,
-                       const uint32_t *rows = nullptr, uint64_t n_listed = 0, pvs_space rows_space = PVS_HOST);
+                       const uint32_t *rows = nullptr, uint64_t n_listed = 0, pvs_space rows_space = PVS_HOST, uint32_t *out_row_idx = nullptr);
+// out_row_idx (optional, [batch][k]): the stored-row number of every page entry where the route knows it for free (the one-launch
+// search), 0xffffffff elsewhere
 void ctx_done(pvs_index *ix, SearchCtx *c);
 pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric,
                           int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count, bool *used_fast, bool side_finalize = false);

@@ -396,7 +396,7 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     }
     std::vector<int64_t> ids;
     std::vector<float> dist;
-    std::vector<uint32_t> cnt(batch);
+    std::vector<uint32_t> cnt(batch), rowidx;
     struct GV {
         double v;
         int64_t g;
@@ -413,7 +413,9 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     for (;;) {
         ids.assign((size_t)batch * kp, -1);
         dist.assign((size_t)batch * kp, 0.f);
-        PVS_TRY(search_host(ix, queries, qdtype, batch, (uint32_t)kp, metric, mask, mask_space, ids.data(), dist.data(), cnt.data()));
+        rowidx.resize((size_t)batch * kp);
+        PVS_TRY(search_host(ix, queries, qdtype, batch, (uint32_t)kp, metric, mask, mask_space, ids.data(), dist.data(), cnt.data(), nullptr, 0, PVS_HOST,
+                            rowidx.data()));
         bool all_ok = true;
         for (uint32_t q = 0; q < batch && all_ok; q++) {
             const int64_t *qi = ids.data() + (size_t)q * kp;
@@ -423,8 +425,13 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
             for (uint32_t i = 0; i < cnt[q]; i++) {
                 int64_t g = qi[i];  // identity groups: the group id is the row id
                 if (!ix->h_groups.empty()) {
-                    const auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), qi[i]);
-                    g = ix->h_groups[(size_t)(it - ix->h_ids_cache.begin())];
+                    const uint32_t r = rowidx[(size_t)q * kp + i];  // (the one-launch search hands the stored row over: no search among the ids)
+                    if (r < n) {
+                        g = ix->h_groups[r];
+                    } else {
+                        const auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), qi[i]);
+                        g = ix->h_groups[(size_t)(it - ix->h_ids_cache.begin())];
+                    }
                 }
                 seen.push_back(g);
             }

@@ -66,6 +66,7 @@ struct DirectArgs {
     int64_t *h_out_ids = nullptr;
     float *h_out_dist = nullptr;
     uint32_t *h_out_count = nullptr;
+    uint32_t *h_out_rows = nullptr;  // ... and the stored-row number of every entry (per-item callers look their groups up by row)
     int null_ok = 0;
     uint32_t n_cu;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

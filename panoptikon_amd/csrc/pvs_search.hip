@@ -285,6 +285,7 @@ static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_quer
         d.h_out_ids = (int64_t *)h_page;
         d.h_out_dist = (float *)(h_page + (size_t)k * 8);
         d.h_out_count = (uint32_t *)(h_page + (size_t)k * 12);
+        d.h_out_rows = (uint32_t *)(h_page + (size_t)k * 12 + 64);
     }
     (void)span_bound(ix, c, 1, ix->n, &d.ev_start, &d.ev_stop);
     HIP_TRY(pvs_launch_direct_topk(d, c.stream));
@@ -728,8 +729,9 @@ PVS_EXPORT pvs_status pvs_search_rows(pvs_index *ix, const void *queries, pvs_dt
 
 pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                        const uint8_t *mask, pvs_space mask_space, int64_t *out_ids, float *out_dist, uint32_t *out_count, const uint32_t *rows,
-                       uint64_t n_listed, pvs_space rows_space) {
+                       uint64_t n_listed, pvs_space rows_space, uint32_t *out_row_idx) {
     PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
+    if (out_row_idx) memset(out_row_idx, 0xff, (size_t)batch * k * 4);
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if (rows && mask) return pvs_fail(PVS_ERR_INVALID_ARG, "a candidate mask or a candidate row list, not both");
     if (!rows && n_listed) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate rows");
@@ -780,7 +782,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         // One query over a small or medium corpus (pvs_direct.hip): the query is read from this context's pinned, device-mapped block,
         // the page is mirrored into it — no staging copy either way, one synchronisation.  A page that needs the fallbacks (NULL
         // tail, dense path) takes the ordinary route below from the device copy of what the kernel wrote.
-        const size_t off_p = pvs_round_up(64 + qbytes, 64), need = off_p + (size_t)k * 12 + 4;
+        const size_t off_p = pvs_round_up(64 + qbytes, 64), need = off_p + (size_t)k * 16 + 128;  // [ids | distances | count .. | rows]
         auto run = [&]() -> pvs_status {
             PVS_TRY(ctx_pinned_io(*c, need));
             uint8_t *io = c->h_io;
@@ -795,6 +797,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
                 memcpy(out_dist, io + off_p + (size_t)k * 8, (size_t)k * 4);
                 const uint32_t cnt = *(const uint32_t *)(io + off_p + (size_t)k * 12);
                 out_count[0] = cnt;
+                if (out_row_idx) memcpy(out_row_idx, io + off_p + (size_t)k * 12 + 64, (size_t)cnt * 4);
                 for (uint32_t i = cnt; i < k; i++) {  // (k > rows: the page's unused tail)
                     out_ids[i] = -1;
                     out_dist[i] = __builtin_nanf("");
