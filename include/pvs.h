@@ -635,7 +635,6 @@ pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
  *   "marker_events"           profiling spans as hipEventRecord markers around the kernels instead of events bound to the dispatches
  *   "no_direct_topk"          a single query always takes the filter scan, never the one-launch exact search (pvs_direct.hip)
  *   "direct_max_mb" N         ... takes the one-launch search up to N MB of rows (default 8192)
- *   "direct_lds_i8"           ... over int8 rows always stages them through LDS (never the register-staged kernel for k <= 128)
  *   "direct_queries"          (read-only counter) single queries answered by the one-launch search, process-wide */
 pvs_status pvs_debug_set(const char *key, int64_t value);
 pvs_status pvs_debug_get(const char *key, int64_t *out_value);

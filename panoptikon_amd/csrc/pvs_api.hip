@@ -25,7 +25,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "sample_div",      "sample_j_div", "no_light_finalize", "force_light_finalize", "dense_per_query",     "no_direct_score",
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
-    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries", "direct_lds_i8",
+    "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;

@@ -78,7 +78,6 @@ enum PvsDbg {
     PVS_DBG_NO_DIRECT_TOPK,        // single queries always take the filter scan (never the one-launch exact search, pvs_direct.hip)
     PVS_DBG_DIRECT_MAX_MB,         // ... take the one-launch search up to this many MB of rows (0: the built-in crossover)
     PVS_DBG_DIRECT_QUERIES,        // (a counter, read with pvs_debug_get) single queries answered by the one-launch search, process-wide
-    PVS_DBG_DIRECT_LDS_I8,         // one-launch search, int8 rows: always the LDS-staged kernel (never the register-staged k_direct_topk_i8r)
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -66,7 +66,7 @@ constexpr uint32_t DIR_CHUNK = 64;                  // keys a list hands over at
 struct MiscLds {
     unsigned long long fin[256];  // the page's keys
     uint32_t hist[256];
-    uint32_t misc[8], wcnt[8];
+    uint32_t misc[8], wcnt[4];
     uint32_t ticket, pool_n, more, total, outn, have;
     unsigned long long kmin, kmax, slot;
 };
@@ -173,52 +173,197 @@ __device__ static inline unsigned long long wg_radix_kth_range(const unsigned lo
 #define DIR_STAMP(i) do { } while (0)
 #endif
 
-// Keep the k smallest keys of a wave's list, ascending.  A rank sort: the keys are distinct, so a key's slot is the number of smaller
-// ones — every lane holds up to 8 keys in registers and walks the list once with broadcast reads (capw^2 / 64 compares per lane: 1 us
-// at 128 slots where a bitonic network's 28 wait-separated steps took 6).  cnt: keys held (in / out); thr: the k-th key once k are held.
-__device__ static inline void wave_cut(volatile unsigned long long *sel, uint32_t capw, uint32_t k, uint32_t lane, uint32_t &cnt, unsigned long long &thr) {
-    unsigned long long mk[8];
-    uint32_t rk[8];
-    const uint32_t per = capw >> 6;  // 2, 4 or 8
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t slot = lane + 64u * (uint32_t)j;
-        mk[j] = ((uint32_t)j < per && slot < cnt) ? sel[slot] : ~0ull;
-        rk[j] = 0;
+template <int DT, int METRIC>
+__global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
+#ifdef PVS_DIR_PROF
+    unsigned long long dp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    DIR_STAMP(0);
+    constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;  // components per 16-B chunk
+    constexpr int EPS = 16 * PER;                                    // components per 256-B slab row
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *const qlds = (float *)(smem + DIR_RING_LDS);
+    volatile unsigned long long *const sel = (volatile unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS) + (size_t)wave * a.capw;
+    if constexpr (DT == PVS_I8) {  // codes stay codes: the integer dot product below is exact, the distance its closed form
+        int8_t *qb = (int8_t *)qlds;
+        for (uint32_t i = tid; i < a.stride; i += 256) qb[i] = i < a.dim ? ((const int8_t *)a.qexact)[i] : (int8_t)0;
+    } else {
+        for (uint32_t i = tid; i < a.qpad_ld; i += 256) qlds[i] = i < a.dim ? ((const float *)a.qexact)[i] : 0.f;
     }
-    for (uint32_t i = cnt + lane; i < ((cnt + 7u) & ~7u); i += 64) sel[i] = ~0ull;  // (pads compare "not smaller")
-    wave_lds_sync();
-    const ulonglong2 *rd = (const ulonglong2 *)sel;  // (nothing is written while the ranks are counted)
-    for (uint32_t i = 0; i < cnt; i += 8) {  // eight keys per step, four broadcast 16-byte reads in flight
-        const ulonglong2 x0 = rd[(i >> 1) + 0], x1 = rd[(i >> 1) + 1], x2 = rd[(i >> 1) + 2], x3 = rd[(i >> 1) + 3];
+    __syncthreads();
+    DIR_STAMP(1);
+    const float bb = a.qinfo[0].bb;
+    // a query that makes every distance NULL (zero / NaN-bearing): the whole page is the head of ALL rows in tie order — the
+    // NULL-tail step writes it (flag 3, as pass C says it); nothing to scan
+    if (a.null_ok && pvs_query_all_null(METRIC, bb)) {
+        if (blockIdx.x == 0 && tid == 0) {
+            a.need_dense[0] = 3;
+            if (a.h_flags) a.h_flags[0] = 3;
+            if (a.h_seen) a.h_seen[0] = 0;
+            a.out_count[0] = 0;
+        }
+        return;
+    }
+
+    const uint32_t gw = blockIdx.x * 4 + wave;  // this wave's first pair of row tiles
+    const uint32_t my_pairs = gw < a.n_pairs ? (a.n_pairs - gw + a.n_waves - 1) / a.n_waves : 0;
+    const uint32_t n_items = my_pairs * a.kslabs;
+    uint8_t *const wbuf = smem + wave * DIR_WAVE_LDS;
+    const uint32_t wlds = lds_addr(wbuf);
+    const uint32_t voff = lane * 16u;
+    auto uni = [](const uint8_t *p) {
+        const uint64_t v = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    uint32_t ip = 0, is = 0;
+    auto issue = [&](uint32_t buf) {
+        const uint64_t pair = gw + (uint64_t)ip * a.n_waves;
+        const uint8_t *bA = uni(a.rows + pair * 64 * a.stride + (uint64_t)is * 8192);
+        const uint8_t *bB = uni(bA + 32ull * a.stride);
+        const uint32_t dst = wlds + buf * 16384u;
+#pragma unroll
+        for (int e = 0; e < 8; e++) dma16(bA + e * 1024, voff, dst + e * 1024);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dma16(bB + e * 1024, voff, dst + 8192 + e * 1024);
+        if (++is == a.kslabs) {
+            is = 0;
+            ip++;
+        }
+    };
+
+    // the wave's list: cnt keys, every one below thr once k are held
+    uint32_t cnt = 0;
+    unsigned long long thr = ~0ull;
+    // keep the k smallest, ascending.  A rank sort: the keys are distinct, so a key's slot is the number of smaller ones — every lane
+    // holds up to 8 keys in registers and walks the list once with broadcast reads (capw^2 / 64 compares per lane: 1 us at 128
+    // slots where the bitonic network's 28 wait-separated steps took 6)
+    auto cut = [&]() {
+        unsigned long long mk[8];
+        uint32_t rk[8];
+        const uint32_t per = a.capw >> 6;  // 2, 4 or 8
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t slot = lane + 64u * (uint32_t)j;
+            mk[j] = ((uint32_t)j < per && slot < cnt) ? sel[slot] : ~0ull;
+            rk[j] = 0;
+        }
+        for (uint32_t i = cnt + lane; i < ((cnt + 7u) & ~7u); i += 64) sel[i] = ~0ull;  // (pads compare "not smaller")
+        wave_lds_sync();
+        const ulonglong2 *rd = (const ulonglong2 *)sel;  // (nothing is written while the ranks are counted)
+        for (uint32_t i = 0; i < cnt; i += 8) {  // eight keys per step, four broadcast 16-byte reads in flight
+            const ulonglong2 x0 = rd[(i >> 1) + 0], x1 = rd[(i >> 1) + 1], x2 = rd[(i >> 1) + 2], x3 = rd[(i >> 1) + 3];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < per) {
+                    const unsigned long long m = mk[j];
+                    rk[j] += (x0.x < m ? 1u : 0u) + (x0.y < m ? 1u : 0u) + (x1.x < m ? 1u : 0u) + (x1.y < m ? 1u : 0u) + (x2.x < m ? 1u : 0u) +
+                             (x2.y < m ? 1u : 0u) + (x3.x < m ? 1u : 0u) + (x3.y < m ? 1u : 0u);
+                }
+        }
+        wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if ((uint32_t)j < per) {
-                const unsigned long long m = mk[j];
-                rk[j] += (x0.x < m ? 1u : 0u) + (x0.y < m ? 1u : 0u) + (x1.x < m ? 1u : 0u) + (x1.y < m ? 1u : 0u) + (x2.x < m ? 1u : 0u) +
-                         (x2.y < m ? 1u : 0u) + (x3.x < m ? 1u : 0u) + (x3.y < m ? 1u : 0u);
-            }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        if ((uint32_t)j < per && mk[j] != ~0ull && rk[j] < k) sel[rk[j]] = mk[j];
-    wave_lds_sync();
-    if (cnt > k) cnt = k;
-    if (cnt == k) thr = sel[k - 1];
-}
+            if ((uint32_t)j < per && mk[j] != ~0ull && rk[j] < a.k) sel[rk[j]] = mk[j];
+        wave_lds_sync();
+        if (cnt > a.k) cnt = a.k;
+        if (cnt == a.k) thr = sel[a.k - 1];
+    };
 
-// Everything after a workgroup's waves have streamed their rows (each wave's list cut to its k best, ascending): workgroup merge,
-// publish + ticket, and in the LAST workgroup the merge of all lists and the page.  W waves per workgroup; sel region = W lists of
-// a.capw keys at smem + DIR_RING_LDS + DIR_Q_LDS; the ring region (unused by now) holds the merge buffers.
-template <int W, int METRIC>
-__device__ static inline void direct_tail(const DirectK &a, uint8_t *smem, uint32_t tid, uint32_t lane, uint32_t wave, uint32_t cnt, float bb
-#ifdef PVS_DIR_PROF
-                                          , unsigned long long (&dp)[10]
-#endif
-) {
-    const volatile unsigned long long *const sel = (const volatile unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS) + (size_t)wave * a.capw;
-    (void)sel;
+    float acc = 0.0f;
+    int acci = 0;
+    bool bad = false;  // int8: a row whose sums leave the closed form's range
+    const uint32_t row_in = (lane >> 5) * 8192u + (lane & 31) * 256u;
+    const uint32_t jx = lane & 15u;
+    uint32_t cp = 0, cs = 0;
+    if (n_items) issue(0);
+    for (uint32_t it = 0; it < n_items; it++) {
+        wait_vm<0>();
+        if (it + 1 < n_items) issue((it + 1) & 1u);
+        const uint8_t *tile = wbuf + (it & 1u) * 16384u + row_in;
+        if constexpr (DT == PVS_I8) {
+            // int8 rows: v_dot4_i32_i8 against the query's codes (16 components per chunk in four instructions instead of sixteen
+            // convert / multiply / add triples); the reference's f32 chain of integer-valued terms equals the integer sum while it
+            // stays below 2^24 (checked per row below, as pass C and k_score_i8_direct do)
+            const uint8_t *q0b = (const uint8_t *)qlds + (size_t)cs * 256;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
+                const uint4 qv = *(const uint4 *)(q0b + c * 16);  // broadcast
+                acci = __builtin_amdgcn_sdot4((int)v.x, (int)qv.x, acci, false);
+                acci = __builtin_amdgcn_sdot4((int)v.y, (int)qv.y, acci, false);
+                acci = __builtin_amdgcn_sdot4((int)v.z, (int)qv.z, acci, false);
+                acci = __builtin_amdgcn_sdot4((int)v.w, (int)qv.w, acci, false);
+            }
+        } else {
+        const float *q0 = qlds + (size_t)cs * EPS;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
+            float4 qv4[PER / 4];
+#pragma unroll
+            for (int x = 0; x < PER / 4; x++) qv4[x] = *(const float4 *)(q0 + c * PER + 4 * x);  // broadcast
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                const float av = dir_elem<DT>(v, e);
+                const float4 &t4 = qv4[e >> 2];
+                const float qv = (e & 3) == 0 ? t4.x : (e & 3) == 1 ? t4.y : (e & 3) == 2 ? t4.z : t4.w;
+                if (METRIC == PVS_COSINE) {
+                    acc = __fadd_rn(acc, __fmul_rn(av, qv));
+                } else {
+                    const float t = __fsub_rn(av, qv);
+                    acc = __fadd_rn(acc, __fmul_rn(t, t));
+                }
+            }
+        }
+        }
+        if (++cs == a.kslabs) {
+            const uint64_t row = (gw + (uint64_t)cp * a.n_waves) * 64 + lane;
+            bool valid = row < a.n_rows;
+            if (valid && a.mask) valid = a.mask[row] != 0;
+            unsigned long long key = ~0ull;
+            if (valid) {
+                float d;
+                if constexpr (DT == PVS_I8) {
+                    const float aa = a.norm2[row], lim = 16777216.0f;
+                    if (METRIC == PVS_COSINE) {
+                        d = ref_cosine_finish((float)acci, aa, bb);
+                        bad |= !(aa < lim && bb < lim);
+                    } else {
+                        const double ss = (double)aa + (double)bb - 2.0 * (double)acci;
+                        d = ref_l2_finish((float)ss);
+                        bad |= !(aa < lim && bb < lim && ss < (double)lim);
+                    }
+                } else {
+                    const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
+                    d = METRIC == PVS_COSINE ? ref_cosine_finish(acc, aa, bb) : ref_l2_finish(acc);
+                }
+                valid = d == d;  // a NULL distance is never on the finite part of a page
+                key = ((unsigned long long)f32_sort_key(d) << 32) | (a.trank ? a.trank[row] : (uint32_t)row);
+            }
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            if (cnt + 64 > a.capw) cut();
+            const bool pass = valid && key < thr;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (m) {
+                if (pass) sel[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+                cnt += (uint32_t)__popcll(m);
+            }
+            acc = 0.0f;
+            acci = 0;
+            cs = 0;
+            cp++;
+        }
+    }
+    wait_vm<0>();
+    DIR_STAMP(2);
+    cut();  // ascending, cnt <= k
+    DIR_STAMP(3);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.bad, 1u);
+    __syncthreads();
+
     // ---- the workgroup's k best: the four sorted lists merge by rank — a key's slot is its index in its own list plus, for each
     // other list, the number of smaller keys there (a binary search; the keys are distinct) — into the (now idle) ring
     unsigned long long *const mb = (unsigned long long *)smem;
@@ -227,12 +372,12 @@ __device__ static inline void direct_tail(const DirectK &a, uint8_t *smem, uint3
     __syncthreads();
     {
         const unsigned long long *lists = (const unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS);
-        for (uint32_t x = tid; x < (uint32_t)W * a.kp; x += 64u * W) {
+        for (uint32_t x = tid; x < 4 * a.kp; x += 256) {
             const uint32_t w = x / a.kp, i = x - w * a.kp;
             if (i >= ml.wcnt[w]) continue;
             const unsigned long long key = lists[(size_t)w * a.capw + i];
             uint32_t rank = i;
-            for (uint32_t o = 0; o < (uint32_t)W; o++) {
+            for (uint32_t o = 0; o < 4; o++) {
                 if (o == w) continue;
                 const unsigned long long *lo_ = lists + (size_t)o * a.capw;
                 uint32_t lo = 0, hi = ml.wcnt[o];
@@ -249,12 +394,9 @@ __device__ static inline void direct_tail(const DirectK &a, uint8_t *smem, uint3
         }
     }
     __syncthreads();
-    uint32_t wsum = 0;
-#pragma unroll
-    for (int w = 0; w < W; w++) wsum += ml.wcnt[w];
-    const uint32_t wtot = min(wsum, a.k);
+    const uint32_t wtot = min(ml.wcnt[0] + ml.wcnt[1] + ml.wcnt[2] + ml.wcnt[3], a.k);
     unsigned long long *const mine = a.wg_keys + (size_t)blockIdx.x * a.k;
-    for (uint32_t i = tid; i < wtot; i += 64u * W) mine[i] = mb[i];
+    for (uint32_t i = tid; i < wtot; i += 256) mine[i] = mb[i];
     if (tid == 0) a.wg_cnt[blockIdx.x] = wtot;
     __threadfence();
     __syncthreads();
@@ -263,7 +405,6 @@ __device__ static inline void direct_tail(const DirectK &a, uint8_t *smem, uint3
     __syncthreads();
     DIR_STAMP(5);
     if (ml.ticket != gridDim.x - 1) return;
-    if (W > 4 && tid >= 256) return;  // (whole waves leave: a barrier no longer waits for them) — the last merge is written for 256 threads
     __threadfence();
 
     // ---- the last workgroup: every list's head in an LDS pool, lists extended while they still hold keys at or below the pool's k-th
@@ -434,300 +575,6 @@ __device__ static inline void direct_tail(const DirectK &a, uint8_t *smem, uint3
 }
 
 template <int DT, int METRIC>
-__global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
-#ifdef PVS_DIR_PROF
-    unsigned long long dp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    DIR_STAMP(0);
-    constexpr int PER = DT == PVS_I8 ? 16 : DT == PVS_F16 ? 8 : 4;  // components per 16-B chunk
-    constexpr int EPS = 16 * PER;                                    // components per 256-B slab row
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *const qlds = (float *)(smem + DIR_RING_LDS);
-    volatile unsigned long long *const sel = (volatile unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS) + (size_t)wave * a.capw;
-    if constexpr (DT == PVS_I8) {  // codes stay codes: the integer dot product below is exact, the distance its closed form
-        int8_t *qb = (int8_t *)qlds;
-        for (uint32_t i = tid; i < a.stride; i += 256) qb[i] = i < a.dim ? ((const int8_t *)a.qexact)[i] : (int8_t)0;
-    } else {
-        for (uint32_t i = tid; i < a.qpad_ld; i += 256) qlds[i] = i < a.dim ? ((const float *)a.qexact)[i] : 0.f;
-    }
-    __syncthreads();
-    DIR_STAMP(1);
-    const float bb = a.qinfo[0].bb;
-    // a query that makes every distance NULL (zero / NaN-bearing): the whole page is the head of ALL rows in tie order — the
-    // NULL-tail step writes it (flag 3, as pass C says it); nothing to scan
-    if (a.null_ok && pvs_query_all_null(METRIC, bb)) {
-        if (blockIdx.x == 0 && tid == 0) {
-            a.need_dense[0] = 3;
-            if (a.h_flags) a.h_flags[0] = 3;
-            if (a.h_seen) a.h_seen[0] = 0;
-            a.out_count[0] = 0;
-        }
-        return;
-    }
-
-    const uint32_t gw = blockIdx.x * 4 + wave;  // this wave's first pair of row tiles
-    const uint32_t my_pairs = gw < a.n_pairs ? (a.n_pairs - gw + a.n_waves - 1) / a.n_waves : 0;
-    const uint32_t n_items = my_pairs * a.kslabs;
-    uint8_t *const wbuf = smem + wave * DIR_WAVE_LDS;
-    const uint32_t wlds = lds_addr(wbuf);
-    const uint32_t voff = lane * 16u;
-    auto uni = [](const uint8_t *p) {
-        const uint64_t v = (uint64_t)(uintptr_t)p;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-        return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
-    };
-    uint32_t ip = 0, is = 0;
-    auto issue = [&](uint32_t buf) {
-        const uint64_t pair = gw + (uint64_t)ip * a.n_waves;
-        const uint8_t *bA = uni(a.rows + pair * 64 * a.stride + (uint64_t)is * 8192);
-        const uint8_t *bB = uni(bA + 32ull * a.stride);
-        const uint32_t dst = wlds + buf * 16384u;
-#pragma unroll
-        for (int e = 0; e < 8; e++) dma16(bA + e * 1024, voff, dst + e * 1024);
-#pragma unroll
-        for (int e = 0; e < 8; e++) dma16(bB + e * 1024, voff, dst + 8192 + e * 1024);
-        if (++is == a.kslabs) {
-            is = 0;
-            ip++;
-        }
-    };
-
-    // the wave's list: cnt keys, every one below thr once k are held
-    uint32_t cnt = 0;
-    unsigned long long thr = ~0ull;
-    auto cut = [&]() { wave_cut(sel, a.capw, a.k, lane, cnt, thr); };
-
-    float acc = 0.0f;
-    int acci = 0;
-    bool bad = false;  // int8: a row whose sums leave the closed form's range
-    const uint32_t row_in = (lane >> 5) * 8192u + (lane & 31) * 256u;
-    const uint32_t jx = lane & 15u;
-    uint32_t cp = 0, cs = 0;
-    if (n_items) issue(0);
-    for (uint32_t it = 0; it < n_items; it++) {
-        wait_vm<0>();
-        if (it + 1 < n_items) issue((it + 1) & 1u);
-        const uint8_t *tile = wbuf + (it & 1u) * 16384u + row_in;
-        if constexpr (DT == PVS_I8) {
-            // int8 rows: v_dot4_i32_i8 against the query's codes (16 components per chunk in four instructions instead of sixteen
-            // convert / multiply / add triples); the reference's f32 chain of integer-valued terms equals the integer sum while it
-            // stays below 2^24 (checked per row below, as pass C and k_score_i8_direct do)
-            const uint8_t *q0b = (const uint8_t *)qlds + (size_t)cs * 256;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
-                const uint4 qv = *(const uint4 *)(q0b + c * 16);  // broadcast
-                acci = __builtin_amdgcn_sdot4((int)v.x, (int)qv.x, acci, false);
-                acci = __builtin_amdgcn_sdot4((int)v.y, (int)qv.y, acci, false);
-                acci = __builtin_amdgcn_sdot4((int)v.z, (int)qv.z, acci, false);
-                acci = __builtin_amdgcn_sdot4((int)v.w, (int)qv.w, acci, false);
-            }
-        } else {
-        const float *q0 = qlds + (size_t)cs * EPS;
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const uint4 v = *(const uint4 *)(tile + ((((uint32_t)c) ^ jx) << 4));
-            float4 qv4[PER / 4];
-#pragma unroll
-            for (int x = 0; x < PER / 4; x++) qv4[x] = *(const float4 *)(q0 + c * PER + 4 * x);  // broadcast
-#pragma unroll
-            for (int e = 0; e < PER; e++) {
-                const float av = dir_elem<DT>(v, e);
-                const float4 &t4 = qv4[e >> 2];
-                const float qv = (e & 3) == 0 ? t4.x : (e & 3) == 1 ? t4.y : (e & 3) == 2 ? t4.z : t4.w;
-                if (METRIC == PVS_COSINE) {
-                    acc = __fadd_rn(acc, __fmul_rn(av, qv));
-                } else {
-                    const float t = __fsub_rn(av, qv);
-                    acc = __fadd_rn(acc, __fmul_rn(t, t));
-                }
-            }
-        }
-        }
-        if (++cs == a.kslabs) {
-            const uint64_t row = (gw + (uint64_t)cp * a.n_waves) * 64 + lane;
-            bool valid = row < a.n_rows;
-            if (valid && a.mask) valid = a.mask[row] != 0;
-            unsigned long long key = ~0ull;
-            if (valid) {
-                float d;
-                if constexpr (DT == PVS_I8) {
-                    const float aa = a.norm2[row], lim = 16777216.0f;
-                    if (METRIC == PVS_COSINE) {
-                        d = ref_cosine_finish((float)acci, aa, bb);
-                        bad |= !(aa < lim && bb < lim);
-                    } else {
-                        const double ss = (double)aa + (double)bb - 2.0 * (double)acci;
-                        d = ref_l2_finish((float)ss);
-                        bad |= !(aa < lim && bb < lim && ss < (double)lim);
-                    }
-                } else {
-                    const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
-                    d = METRIC == PVS_COSINE ? ref_cosine_finish(acc, aa, bb) : ref_l2_finish(acc);
-                }
-                valid = d == d;  // a NULL distance is never on the finite part of a page
-                key = ((unsigned long long)f32_sort_key(d) << 32) | (a.trank ? a.trank[row] : (uint32_t)row);
-            }
-            cnt = __builtin_amdgcn_readfirstlane(cnt);
-            if (cnt + 64 > a.capw) cut();
-            const bool pass = valid && key < thr;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-            if (m) {
-                if (pass) sel[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
-                cnt += (uint32_t)__popcll(m);
-            }
-            acc = 0.0f;
-            acci = 0;
-            cs = 0;
-            cp++;
-        }
-    }
-    wait_vm<0>();
-    DIR_STAMP(2);
-    cut();  // ascending, cnt <= k
-    DIR_STAMP(3);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.bad, 1u);
-    __syncthreads();
-
-#ifdef PVS_DIR_PROF
-    direct_tail<4, METRIC>(a, smem, tid, lane, wave, cnt, bb, dp);
-#else
-    direct_tail<4, METRIC>(a, smem, tid, lane, wave, cnt, bb);
-#endif
-}
-
-// ---- int8 rows, pages of up to 128 rows: the rows come straight from HBM into registers (k_score_i8_direct's stream: every wave
-// reads its own 32-row layout tiles with coalesced 16-byte loads, 16 lanes per row, two slabs in flight in registers — eight waves
-// per CU hold twice the bytes in flight of the LDS-staged form above and need no LDS for the rows), v_dot4_i32_i8 against the
-// query's codes in LDS, the sixteen lanes of a row added up with four DPP steps; integer sums are exact in any order, the distance
-// is their closed form (checked per row).  Selection, merges and page: wave_cut / direct_tail, eight lists per workgroup.
-typedef int dv4i __attribute__((ext_vector_type(4)));
-__device__ static inline int dir_row16_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
-    return v;
-}
-
-template <int METRIC>
-__global__ __launch_bounds__(512, 1) void k_direct_topk_i8r(DirectK a) {
-#ifdef PVS_DIR_PROF
-    unsigned long long dp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    DIR_STAMP(0);
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint8_t *const s_q = smem + DIR_RING_LDS;  // [stride] query codes, zero padded
-    volatile unsigned long long *const sel = (volatile unsigned long long *)(smem + DIR_RING_LDS + DIR_Q_LDS) + (size_t)wave * a.capw;
-    for (uint32_t i = tid; i < a.stride; i += 512) s_q[i] = i < a.dim ? (uint8_t)((const int8_t *)a.qexact)[i] : (uint8_t)0;
-    __syncthreads();
-    DIR_STAMP(1);
-    const float bb = a.qinfo[0].bb;
-    if (a.null_ok && pvs_query_all_null(METRIC, bb)) {  // (see k_direct_topk)
-        if (blockIdx.x == 0 && tid == 0) {
-            a.need_dense[0] = 3;
-            if (a.h_flags) a.h_flags[0] = 3;
-            if (a.h_seen) a.h_seen[0] = 0;
-            a.out_count[0] = 0;
-        }
-        return;
-    }
-    const uint32_t n_tiles = (uint32_t)((a.n_rows + 31) / 32);
-    const uint32_t t_step = a.n_waves;
-    const uint32_t pc = lane & 15, rsub = lane >> 4;
-    uint32_t qoff[4];  // query chunk this lane needs for load j of a slab: logical chunk pc ^ ((4 j + rsub) & 15)
-#pragma unroll
-    for (int j = 0; j < 4; j++) qoff[j] = (pc ^ (uint32_t)(4 * j + rsub)) * 16u;
-    const size_t tile_bytes = 32u * (size_t)a.stride;
-    auto load_slab = [&](uint32_t tile, uint32_t sl, dv4i(&dst)[8]) __attribute__((always_inline)) {
-        const uint8_t *p = a.rows + (size_t)tile * tile_bytes + (size_t)sl * 8192u + (size_t)lane * 16u;
-#pragma unroll
-        for (int j = 0; j < 8; j++) dst[j] = __builtin_nontemporal_load((const dv4i *)(p + j * 1024));
-    };
-    uint32_t cnt = 0;
-    unsigned long long thr = ~0ull;
-    bool bad = false;
-    uint32_t tile = blockIdx.x * 8 + wave;
-    if (tile < n_tiles) {
-        dv4i cur[8], nxt[8];
-        load_slab(tile, 0, cur);
-        while (tile < n_tiles) {
-            int acc[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) acc[j] = 0;
-            for (uint32_t sl = 0; sl < a.kslabs; sl++) {
-                const bool last = sl + 1 == a.kslabs;
-                const uint32_t nt = last ? tile + t_step : tile, ns = last ? 0u : sl + 1;
-                const bool more = nt < n_tiles;
-                if (more) load_slab(nt, ns, nxt);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const dv4i qv = *(const dv4i *)(s_q + sl * 256u + qoff[j & 3]);
-                    int x = acc[j];
-                    x = __builtin_amdgcn_sdot4(cur[j].x, qv.x, x, false);
-                    x = __builtin_amdgcn_sdot4(cur[j].y, qv.y, x, false);
-                    x = __builtin_amdgcn_sdot4(cur[j].z, qv.z, x, false);
-                    x = __builtin_amdgcn_sdot4(cur[j].w, qv.w, x, false);
-                    acc[j] = x;
-                }
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) cur[j] = nxt[j];
-                }
-            }
-            // row totals: lane (pc == j, j < 8) keeps row 4 j + rsub of the tile
-            int mine = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int t = dir_row16_sum(acc[j]);
-                mine = (int)pc == j ? t : mine;
-            }
-            const uint64_t row = (uint64_t)tile * 32u + 4u * pc + rsub;
-            bool valid = pc < 8 && row < a.n_rows;
-            if (valid && a.mask) valid = a.mask[row] != 0;
-            unsigned long long key = ~0ull;
-            if (valid) {
-                const float aa = a.norm2[row], lim = 16777216.0f;
-                float d;
-                if (METRIC == PVS_COSINE) {
-                    d = ref_cosine_finish((float)mine, aa, bb);
-                    bad |= !(aa < lim && bb < lim);
-                } else {
-                    const double ss = (double)aa + (double)bb - 2.0 * (double)mine;
-                    d = ref_l2_finish((float)ss);
-                    bad |= !(aa < lim && bb < lim && ss < (double)lim);
-                }
-                valid = d == d;
-                key = ((unsigned long long)f32_sort_key(d) << 32) | (a.trank ? a.trank[row] : (uint32_t)row);
-            }
-            cnt = __builtin_amdgcn_readfirstlane(cnt);
-            if (cnt + 64 > a.capw) wave_cut(sel, a.capw, a.k, lane, cnt, thr);
-            const bool pass = valid && key < thr;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-            if (m) {
-                if (pass) sel[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
-                cnt += (uint32_t)__popcll(m);
-            }
-            tile += t_step;
-        }
-    }
-    DIR_STAMP(2);
-    wave_cut(sel, a.capw, a.k, lane, cnt, thr);
-    DIR_STAMP(3);
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.bad, 1u);
-    __syncthreads();
-#ifdef PVS_DIR_PROF
-    direct_tail<8, METRIC>(a, smem, tid, lane, wave, cnt, bb, dp);
-#else
-    direct_tail<8, METRIC>(a, smem, tid, lane, wave, cnt, bb);
-#endif
-}
-
-template <int DT, int METRIC>
 hipError_t direct_launch(const DirectK &k, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
@@ -739,20 +586,6 @@ hipError_t direct_launch(const DirectK &k, uint32_t grid, hipStream_t s, hipEven
         hipExtLaunchKernelGGL((k_direct_topk<DT, METRIC>), dim3(grid), dim3(256), DIR_LDS, s, ev_start, ev_stop, 0, k);
     else
         hipLaunchKernelGGL((k_direct_topk<DT, METRIC>), dim3(grid), dim3(256), DIR_LDS, s, k);
-    return hipGetLastError();
-}
-template <int METRIC>
-hipError_t direct_launch_i8r(const DirectK &k, uint32_t grid, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    static std::atomic<bool> configured{false};
-    if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_direct_topk_i8r<METRIC>, hipFuncAttributeMaxDynamicSharedMemorySize, DIR_LDS);
-        if (e != hipSuccess) return e;
-        configured.store(true, std::memory_order_release);
-    }
-    if (ev_start || ev_stop)
-        hipExtLaunchKernelGGL((k_direct_topk_i8r<METRIC>), dim3(grid), dim3(512), DIR_LDS, s, ev_start, ev_stop, 0, k);
-    else
-        hipLaunchKernelGGL((k_direct_topk_i8r<METRIC>), dim3(grid), dim3(512), DIR_LDS, s, k);
     return hipGetLastError();
 }
 template <int DT>
@@ -809,13 +642,6 @@ hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s) {
     k.capw = std::max<uint32_t>(2 * kp, 128);
     k.null_ok = d.null_ok;
     k.q_is_i8 = d.dtype == PVS_I8 ? 1 : 0;
-    if (d.dtype == PVS_I8 && k.capw <= 256 && d.stride <= (uint32_t)DIR_Q_LDS && !pvs_dbg(PVS_DBG_DIRECT_LDS_I8)) {
-        // int8 rows, k <= 128: rows straight from HBM into registers, eight waves per workgroup (k_direct_topk_i8r)
-        const uint32_t n_tiles = (uint32_t)((d.n_rows + 31) / 32);
-        const uint32_t g8 = std::min<uint32_t>({(n_tiles + 7) / 8, std::max<uint32_t>(d.n_cu, 1), 256u});
-        k.n_waves = g8 * 8;
-        return d.metric == PVS_COSINE ? direct_launch_i8r<PVS_COSINE>(k, g8, s, d.ev_start, d.ev_stop) : direct_launch_i8r<PVS_L2>(k, g8, s, d.ev_start, d.ev_stop);
-    }
     return d.dtype == PVS_I8    ? direct_metric<PVS_I8>(k, d.metric, grid, s, d.ev_start, d.ev_stop)
            : d.dtype == PVS_F16 ? direct_metric<PVS_F16>(k, d.metric, grid, s, d.ev_start, d.ev_stop)
                                 : direct_metric<PVS_F32>(k, d.metric, grid, s, d.ev_start, d.ev_stop);
