@@ -19,8 +19,8 @@ for name, dt in (("i8", pvs.I8), ("f32", pvs.F32)):
     stage.free()
     q = rng.standard_normal((64, 1, D)).astype(np.float32)
     for agg, an in ((pvs.AGG_MIN, "MIN"), (pvs.AGG_AVG, "AVG"), (pvs.AGG_MAX, "MAX")):
-        for nd in (0, 1) if agg == pvs.AGG_MIN else (0,):
-            pvs.debug_set("no_direct_topk", nd)
+        for nd in (0, 1):
+            pvs.debug_set("no_direct_topk" if agg == pvs.AGG_MIN else "no_fused_agg", nd)
             for i in range(5):
                 ix.search_groups(q[i], 10, pvs.COSINE, agg)
             ts = []
@@ -28,6 +28,7 @@ for name, dt in (("i8", pvs.I8), ("f32", pvs.F32)):
                 t = time.perf_counter()
                 ix.search_groups(q[i % 64], 10, pvs.COSINE, agg)
                 ts.append(time.perf_counter() - t)
-            print(f"{name} per-item {an} k=10{' (filter scan)' if nd else ''}: p50 {np.sort(ts)[50]*1e3:.4f} ms", flush=True)
+            print(f"{name} per-item {an} k=10{(' (filter scan)' if agg == pvs.AGG_MIN else ' (dense column + k_group_aggregate)') if nd else ''}: p50 {np.sort(ts)[50]*1e3:.4f} ms", flush=True)
         pvs.debug_set("no_direct_topk", 0)
+        pvs.debug_set("no_fused_agg", 0)
     ix.close()
