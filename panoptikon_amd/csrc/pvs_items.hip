@@ -344,6 +344,27 @@ static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals,
                     out_count[q] = k;
                     paged[q] = 1;
                 }
+        } else if (d_vals && !no_page_rank && ncol <= 32 && pvs_gm_rank_supported(G, 1, k)) {
+            // column-major values (the dense-matrix route: float indexes, similar_to's fan-out): every column is itself a group-major
+            // matrix of ONE column — the same device page ranking, column by column on the stream, one synchronisation for all
+            const size_t off_g = 64, off_v = off_g + (size_t)ncol * k * 8, off_f = off_v + (size_t)ncol * k * 8, need = off_f + (size_t)ncol * 4;
+            PVS_TRY(ctx_pinned_io(c, need));
+            const size_t wb = (pvs_gm_rank_work_bytes(1) + 255) & ~(size_t)255;
+            HIP_TRY(pvs_scratch_alloc(&d_work, wb * ncol));
+            const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+            for (uint32_t q = 0; q < ncol; q++)
+                HIP_TRY(pvs_gm_rank(d_vals + (size_t)q * G, G, 1, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr,
+                                    (uint8_t *)d_work + wb * q, (int64_t *)(c.h_io + off_g) + (size_t)q * k, (double *)(c.h_io + off_v) + (size_t)q * k,
+                                    (uint32_t *)(c.h_io + off_f) + q, c.stream));
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            const uint32_t *fl = (const uint32_t *)(c.h_io + off_f);
+            for (uint32_t q = 0; q < ncol; q++)
+                if (fl[q]) {
+                    memcpy(out_groups + (size_t)q * k, c.h_io + off_g + (size_t)q * k * 8, (size_t)k * 8);
+                    memcpy(out_values + (size_t)q * k, c.h_io + off_v + (size_t)q * k * 8, (size_t)k * 8);
+                    out_count[q] = k;
+                    paged[q] = 1;
+                }
         } else if (G >= 65536 && (uint64_t)G * ncol >= (2u << 20) && k <= 4096 && !no_page_rank) {
             // (three host round trips, ~0.35 ms whatever the size: worth it from ~2M group values to sort — one column of 230k groups,
             //  similar_to at the reference's scale, sorts in 0.1 ms)
