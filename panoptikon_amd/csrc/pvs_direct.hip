@@ -123,11 +123,27 @@ __device__ static inline unsigned long long wg_radix_kth_range(const unsigned lo
     for (int shift = shift0; shift >= 0; shift -= 8) {
         hist[tid] = 0;
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += 256) {
-            const unsigned long long k = keys[i];
-            if (k == ~0ull) continue;
-            const unsigned long long o = k - kmin;
-            if ((o & mask) == prefix) atomicAdd(&hist[(uint32_t)(o >> shift) & 255u], 1u);
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {  // (a wave whose live lanes share the digit adds their count with one atomic: pvs_wg_select.hpp)
+            const uint32_t i = i0 + tid;
+            unsigned long long o = 0;
+            bool in = false;
+            if (i < n) {
+                const unsigned long long k = keys[i];
+                o = k - kmin;
+                in = k != ~0ull && (o & mask) == prefix;
+            }
+            const uint32_t digit = (uint32_t)(o >> shift) & 255u;
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(in);
+            if (act) {
+                const int first = __builtin_ctzll(act);
+                const uint32_t d0 = (uint32_t)__shfl((int)digit, first, 64);
+                const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
+                if (same == act) {
+                    if ((int)(tid & 63u) == first) atomicAdd(&hist[d0], (uint32_t)__popcll(act));
+                } else if (in) {
+                    atomicAdd(&hist[digit], 1u);
+                }
+            }
         }
         __syncthreads();
         if (tid < 64) {

@@ -9,14 +9,65 @@
 // holds the rank is found by the first wave (4 bins per lane, a shuffle scan).  Workgroup-wide call; hist: 256 words, misc: 4 words.
 __device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long long *keys, uint32_t n, uint32_t kth, uint32_t *hist, uint32_t *misc) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    unsigned long long prefix = 0, mask = 0;
-    uint32_t kk = kth;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        for (uint32_t i = tid; i < 256; i += nt) hist[i] = 0;
-        __syncthreads();
+    // The digits every key shares are skipped (the AND and the OR of all keys differ from the first bit in which two keys differ), and
+    // a digit whose chosen bin holds ONE key ends the search — that key is fetched by a last scan: three or four passes instead of eight
+    // for keys that spread over a few dozen bits (round 4).
+    __shared__ unsigned long long s_and, s_or, s_one;
+    if (tid == 0) {
+        s_and = ~0ull;
+        s_or = 0;
+    }
+    __syncthreads();
+    {
+        unsigned long long a = ~0ull, o = 0;
         for (uint32_t i = tid; i < n; i += nt) {
             const unsigned long long k = keys[i];
-            if ((k & mask) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+            a &= k;
+            o |= k;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a &= __shfl_xor(a, off, 64);
+            o |= __shfl_xor(o, off, 64);
+        }
+        if ((tid & 63u) == 0) {
+            atomicAnd(&s_and, a);
+            atomicOr(&s_or, o);
+        }
+    }
+    __syncthreads();
+    const unsigned long long diff = s_and ^ s_or;
+    if (diff == 0) return s_and;  // (all keys equal)
+    const int shift0 = ((63 - __builtin_clzll(diff)) / 8) * 8;
+    unsigned long long mask = shift0 >= 56 ? 0ull : ~0ull << (shift0 + 8);
+    unsigned long long prefix = s_and & mask;
+    uint32_t kk = kth;
+    for (int shift = shift0; shift >= 0; shift -= 8) {
+        for (uint32_t i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        // Keys of one search share their upper bits (distances, aggregates and window keys of a narrow range): in the first passes
+        // every key falls into ONE bin and a plain LDS atomic per key serialises — 8k keys: ~10 us per pass, most of a 27-us select.
+        // A wave whose live lanes all hold the same digit adds their count with one atomic (round 4); mixed digits keep the plain form.
+        for (uint32_t i0 = 0; i0 < n; i0 += nt) {
+            const uint32_t i = i0 + tid;
+            unsigned long long k = 0;
+            bool in = false;
+            if (i < n) {
+                k = keys[i];
+                in = (k & mask) == prefix;
+            }
+            const uint32_t digit = (uint32_t)(k >> shift) & 255u;
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(in);
+            if (act) {
+                const int first = __builtin_ctzll(act);
+                const uint32_t d0 = (uint32_t)__shfl((int)digit, first, 64);
+                const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
+                if (same == act) {
+                    if ((int)(tid & 63u) == first) atomicAdd(&hist[d0], (uint32_t)__popcll(act));
+                } else if (in) {
+                    atomicAdd(&hist[digit], 1u);
+                }
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -45,13 +96,23 @@ __device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long
                 }
                 misc[0] = bin;
                 misc[1] = r;
+                misc[2] = hist[bin];
             }
         }
         __syncthreads();
         prefix |= (unsigned long long)misc[0] << shift;
         mask |= 0xffull << shift;
         kk = misc[1];
+        const bool single = misc[2] == 1 && shift > 0;
         __syncthreads();
+        if (single) {
+            for (uint32_t i = tid; i < n; i += nt) {
+                const unsigned long long k = keys[i];
+                if ((k & mask) == prefix) s_one = k;  // exactly one key
+            }
+            __syncthreads();
+            return s_one;
+        }
     }
     return prefix;
 }
