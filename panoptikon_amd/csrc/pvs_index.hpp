@@ -305,7 +305,10 @@ pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries,
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
 // d_out[row * nb + q]: exact distances of the nb queries prepared in ctx c (prep_chunk) — matrix cores for int8, k_dense_exact otherwise
-pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out);
+// h_flag (optional): a pinned, device-mapped word — the int8 scorers raise it instead of the context's device word and the call does
+// not wait for them (the caller looks at it after its own synchronisation and, if raised, calls again with inorder_only)
+pvs_status dense_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, float *d_out, uint32_t *h_flag = nullptr,
+                       bool inorder_only = false);
 pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                               pvs_agg agg, const float *row_weights, const uint8_t *mask, pvs_space mask_space, int64_t *out_groups,
                               double *out_values, uint32_t *out_count);

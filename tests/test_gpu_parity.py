@@ -582,6 +582,28 @@ def test_similar_to_matches_self_join(pvs, dtype):
     ix.close()
 
 
+def test_similar_to_int8_sums_beyond_the_closed_form(pvs):
+    """similar_to scores int8 rows by integer sums and the closed form of the reference's f32 chain and does not wait for the
+    scorer's out-of-range flag (a pinned word, read after the ranking): saturated codes at 1,100 dimensions raise it, the call is
+    redone with the in-order chains — same groups and f64 values as the oracle; targets stored side by side and apart (the
+    exclusion mask is filled run by run)."""
+    rng = np.random.default_rng(1101)
+    n, dim, k = 1200, 1100, 25
+    hc = rng.choice(np.array([-128, -127, 126, 127], np.int8), size=(n, dim))
+    groups = (np.arange(n, dtype=np.int64) // 3) * 5 + 2
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(1.0)
+    ix.add(hc, row_ids=ids, group_ids=groups)
+    for targets in ([300, 301, 302], [9, 10, 11, 600, 602, 1199]):
+        for metric in (pvs.L2, pvs.COSINE):
+            gg, gv = ix.similar_to(ids[targets], k, metric, pvs.AGG_AVG)
+            eg, ev = orc.similar_to(orc.I8, metric, hc, targets, groups, orc.AGG_AVG, k)
+            assert np.array_equal(gg, eg), (targets, metric)
+            assert np.array_equal(gv.view(np.uint64), ev.view(np.uint64))
+    ix.close()
+
+
 def test_similar_to_confidence_weighted(pvs):
     """item_similarity.rs:503-581: SUM(d*w)/SUM(w) over the fan-out with w from the two rows' confidences.
     pow() runs in the device math library: values agree to 1e-13 relative, the ranking exactly."""
