@@ -1285,29 +1285,32 @@ PVS_EXPORT pvs_status pvs_score_all(pvs_index *ix, const void *query, pvs_dtype 
     SearchCtx *c = ctx_acquire(ix, &t);
     pvs_status st = ctx_prepare(ix, *c, 1, 1, false);
     auto body = [&]() -> pvs_status {
+        // the query is read from the context's pinned, device-mapped block (no staged H2D copy), the int8 scorer's out-of-range flag is a
+        // word of that block, and a host-space column is copied back behind the scorer without waiting for the flag first: ONE
+        // synchronisation per call (three before: flag round trip, column copy)
         const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
-        HIP_TRY(hipMemcpyAsync(c->d_qin, query, qbytes, hipMemcpyHostToDevice, c->stream));
-        PVS_TRY(prep_chunk(ix, *c, c->d_qin, qdtype, 0, 1, 32, metric));
+        PVS_TRY(ctx_pinned_io(*c, 4096 + qbytes));
+        uint8_t *io = c->h_io;
+        memcpy(io + 64, query, qbytes);
+        PVS_TRY(prep_chunk(ix, *c, io + 64, qdtype, 0, 1, 32, metric));
         float *dst = out_dist;
         if (out_space == PVS_HOST) {
             PVS_TRY(pvs_dense_reserve(c->dense, ix->n));
             dst = c->dense.d_dist;
         }
-        bool done = false;
         if (ix->dtype == PVS_I8 && (uint64_t)ix->dim * 127 * 127 < (1u << 24)) {
             // int8 codes: the closed form of the exact integer sums straight from HBM (pvs_score_direct.hip, 6.3-6.6 TB/s against
             // 5.0 for the in-order chains); an L2 sum beyond 2^24 raises the flag and the in-order scorer below answers instead
-            uint32_t flag = 0;
-            HIP_TRY(hipMemsetAsync(c->d_cand_cnt, 0, 4, c->stream));
+            volatile uint32_t *hf = (volatile uint32_t *)(io + 40);
+            *hf = 0;
             HIP_TRY(pvs_launch_score_i8_direct(metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact, c->d_qinfo, 1, dst, 1,
-                                               c->d_cand_cnt, (uint32_t)ix->n_cu, c->stream));
-            HIP_TRY(hipMemcpyAsync(&flag, c->d_cand_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+                                               (uint32_t *)(io + 40), (uint32_t)ix->n_cu, c->stream));
+            if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            done = flag == 0;
+            if (*hf == 0) return PVS_OK;
         }
-        if (!done)
-            HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
-                                           c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
+        HIP_TRY(pvs_launch_dense_exact((int)ix->dtype, metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c->d_qexact,
+                                       c->d_qinfo, 1, c->d_qpad, dst, 1, 0, (uint32_t)ix->n_cu, c->stream));
         if (out_space == PVS_HOST) HIP_TRY(hipMemcpyAsync(out_dist, dst, ix->n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return PVS_OK;

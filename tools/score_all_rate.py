@@ -5,7 +5,7 @@ import panoptikon_amd as pvs
 from panoptikon_amd import _lib as L
 lib = pvs.lib()
 D = 768
-for N in (100_000, 690_000, 4_000_000, 10_000_000):
+for N in (100_000, 690_000, 4_000_000):
     ix = pvs.VectorIndex(pvs.I8, D, capacity_rows=N)
     ix.set_scale(1.0 / 127 * 0.2)
     ch = min(N, 1_000_000)
