@@ -820,8 +820,34 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         ctx_done(ix, c);
         return st;
     }
+    // The page of a host caller is written by the kernels straight into the context's pinned, device-mapped block (pass C, the merges
+    // and the fallbacks address it like HBM) and copied out by the CPU after the search's one synchronisation — three staged D2H copies
+    // and a second synchronisation less per call; small query batches are read from that block too instead of an H2D copy.
+    int64_t *o_ids = c->d_out_ids;
+    float *o_dist = c->d_out_dist;
+    uint32_t *o_cnt = c->d_out_count;
+    bool pinned_out = false, pinned_q = false;
+    const size_t page_bytes = (size_t)batch * k * 12 + (size_t)batch * 4;
+    const size_t q_all = qbytes * batch;
+    if (st == PVS_OK && page_bytes <= ((size_t)2 << 20)) {
+        const size_t off_q = pvs_round_up(8192 + page_bytes, 256);
+        st = ctx_pinned_io(*c, off_q + (q_all <= ((size_t)256 << 10) ? q_all : 0) + 256);
+        if (st == PVS_OK) {
+            uint8_t *io = c->h_io;
+            o_ids = (int64_t *)(io + 8192);
+            o_dist = (float *)(io + 8192 + (size_t)batch * k * 8);
+            o_cnt = (uint32_t *)(io + 8192 + (size_t)batch * k * 12);
+            pinned_out = true;
+            if (q_all <= ((size_t)256 << 10)) {
+                memcpy(io + off_q, queries, q_all);
+                pinned_q = true;
+            }
+        }
+    }
     void *d_q = nullptr;
-    if (st == PVS_OK) {
+    if (st == PVS_OK && pinned_q) {
+        d_q = c->h_io + pvs_round_up(8192 + page_bytes, 256);
+    } else if (st == PVS_OK) {
         // (hipMalloc/hipFree per call would cost ~0.1 ms and hipFree synchronises the whole device,
         // stalling the other host threads' searches)
         if (qbytes * batch > c->qstage_cap) {
@@ -838,7 +864,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         d_q = c->d_qstage;
     }
     bool fast = false;
-    if (st == PVS_OK) {
+    if (st == PVS_OK && !pinned_q) {
         hipError_t e = hipMemcpyAsync(d_q, queries, qbytes * batch, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "H2D queries: %s", hipGetErrorString(e));
     }
@@ -882,7 +908,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
             }
             if (ix->n == 0 || (pvs_sparse_eligible(ix, m, batch, k) && ix->forced_path == 0)) {
                 sparse = true;
-                return pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, dl, ix->n ? m : 0, c->d_out_ids, c->d_out_dist, c->d_out_count);
+                return pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, dl, ix->n ? m : 0, o_ids, o_dist, o_cnt);
             }
             PVS_TRY(pvs_list_to_mask(dl, m, ix->n, c->d_mask, c->stream));  // (validates the list like the gather path does)
             c->cur_mask = c->d_mask;
@@ -899,24 +925,34 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
             hipError_t e = pvs_scratch_alloc((void **)&d_list, (size_t)std::max<uint32_t>(allowed, 1) * 4);
             if (e != hipSuccess) st = pvs_fail(PVS_ERR_OOM, "candidate list: %s", hipGetErrorString(e));
             if (st == PVS_OK) st = pvs_mask_compact(c->cur_mask, ix->n, d_list, allowed, c->stream);
-            if (st == PVS_OK) st = pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, d_list, allowed, c->d_out_ids, c->d_out_dist, c->d_out_count);
+            if (st == PVS_OK) st = pvs_sparse_search(ix, *c, d_q, qdtype, batch, k, metric, d_list, allowed, o_ids, o_dist, o_cnt);
             pvs_scratch_free_on(d_list, c->stream);
         }
     }
-    if (st == PVS_OK && !sparse) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, &fast);
+    if (st == PVS_OK && !sparse) st = search_enqueue(ix, *c, d_q, qdtype, batch, k, metric, o_ids, o_dist, o_cnt, &fast);
     if (st == PVS_OK && !sparse) {
         hipError_t e = hipEventSynchronize(c->done);
         if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
     }
     if (st == PVS_OK) spans_collect(ix, *c);
     if (st == PVS_OK && !sparse && fast && ix->n)
-        st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count);
+        st = search_fallbacks(ix, *c, d_q, qdtype, batch, k, metric, o_ids, o_dist, o_cnt);
     if (st == PVS_OK) {
-        hipError_t e = hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
+        if (pinned_out) {
+            hipError_t e = sparse ? hipStreamSynchronize(c->stream) : hipSuccess;  // (the other routes have waited for c->done / their fallbacks)
+            if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "search failed on device: %s", hipGetErrorString(e));
+            if (st == PVS_OK) {
+                memcpy(out_ids, o_ids, 8 * (size_t)batch * k);
+                memcpy(out_dist, o_dist, 4 * (size_t)batch * k);
+                memcpy(out_count, o_cnt, 4 * (size_t)batch);
+            }
+        } else {
+            hipError_t e = hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)batch * k, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) st = pvs_fail(PVS_ERR_DEVICE, "D2H results: %s", hipGetErrorString(e));
+        }
     }
     ix->searches++;
     ctx_done(ix, c);
