@@ -917,7 +917,10 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
         st = run();
         pvs_scratch_free_on(d_up, c->stream);
     }
-    if (st == PVS_OK && !sparse && !listed && c->cur_mask && ix->n && ix->forced_path == 0) {
+    // (one query over a corpus the one-launch search streams in ~0.1 ms: it skips masked rows at no cost, counting the mask first — a
+    //  kernel, a 4-byte copy and a round trip, 75 us — could only find a gather path that is no faster there)
+    const bool direct_small = direct_ok(ix, *c, batch, k) && ix->n * (uint64_t)ix->stride <= ((uint64_t)1 << 30) && !pvs_dbg(PVS_DBG_SPARSE_MAX);
+    if (st == PVS_OK && !sparse && !listed && c->cur_mask && ix->n && ix->forced_path == 0 && !direct_small) {
         uint32_t allowed = 0;
         st = pvs_mask_count(c->cur_mask, ix->n, &allowed, c->stream);
         if (st == PVS_OK && pvs_sparse_eligible(ix, allowed, batch, k)) {
