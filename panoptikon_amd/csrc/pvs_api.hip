@@ -373,6 +373,17 @@ pvs_status ctx_pinned_io(SearchCtx &c, size_t bytes) {
     return PVS_OK;
 }
 
+// FinalizeArgs.w_*: the work area of the LDS-light pass C (beside another search's scan — several streams, or the side stream of a
+// pipelined caller).  ~40 MB per context: allocated by the first search of the context that takes that route (enqueue_fast_chunk),
+// not for contexts that only ever run direct, sparse or dense searches.
+pvs_status ctx_fin_buffers(SearchCtx &c) {
+    if (c.d_fin_ub && c.d_fin_surv && c.d_fin_sort) return PVS_OK;
+    if (!c.d_fin_ub) HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
+    if (!c.d_fin_surv) HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
+    if (!c.d_fin_sort) HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
+    return PVS_OK;
+}
+
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs) {
     // Searches are queued on ONE stream by default: consecutive batches run back to back with no
     // host turnaround between them and their scan kernels never compete for the same CUs.
@@ -401,11 +412,6 @@ pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, 
         HIP_TRY(pvs_malloc_retry((void **)&c.d_seg_cnt, 4 * (size_t)PVS_SEG_PAIRS * (PVS_SEG_CAP / PVS_WIDE_SEG_CAP)));  // (the 256-query kernel: twice the lists at half the slots)
         HIP_TRY(pvs_malloc_retry((void **)&c.d_cand, sizeof(uint2) * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
         HIP_TRY(pvs_malloc_retry((void **)&c.d_flat_cnt, 4 * (size_t)PVS_SCAN_MAX_BATCH));
-    }
-    if (!c.d_fin_ub) {  // (FinalizeArgs.w_*: pass C beside another search's scan — several streams, or the side stream of a pipelined caller)
-        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_ub, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_CAND_CAP));
-        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_surv, 4 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
-        HIP_TRY(pvs_malloc_retry((void **)&c.d_fin_sort, 8 * (size_t)PVS_SCAN_MAX_BATCH * PVS_SURV_CAP));
     }
     if (batch > c.flags_cap) {
         hipFree(c.d_need_dense);

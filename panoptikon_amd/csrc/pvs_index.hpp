@@ -261,6 +261,7 @@ bool pvs_direct_route(const pvs_index *ix, uint32_t k);
 bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t *ev_start, hipEvent_t *ev_stop);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
+pvs_status ctx_fin_buffers(SearchCtx &c);  // the LDS-light pass C's work area, on first use
 void ctx_release(SearchCtx &c);
 pvs_status ctx_pinned_io(SearchCtx &c, size_t bytes);  // c.h_io holds >= bytes afterwards (contents are not preserved when it grows)
 // ---- pvs_search.hip
@@ -297,6 +298,10 @@ pvs_status pvs_mask_count(const uint8_t *d_mask, uint64_t n, uint32_t *out_count
 pvs_status pvs_mask_compact(const uint8_t *d_mask, uint64_t n, uint32_t *d_list, uint32_t count, hipStream_t s);
 pvs_status pvs_list_to_mask(const uint32_t *d_list, uint32_t m, uint64_t n, uint8_t *d_mask, hipStream_t s);  // validates; synchronous
 bool pvs_sparse_eligible(const pvs_index *ix, uint64_t m, uint32_t batch, uint32_t k);
+// bytes of a context's pinned block that the per-item pages of `chunk` query columns occupy: [64 flag words | groups k x 8 | values k x 8 |
+// handled flags | counts] per column — the ONE place that sizes it (search_groups_impl puts the queries behind it, pvs_sparse_search_groups
+// and the device page ranking write into it; ADVICE r4: two copies of this sum once disagreed by 4 bytes per column)
+static inline size_t pvs_group_pages_bytes(uint32_t chunk, uint32_t k) { return 64 + (size_t)chunk * ((size_t)k * 16 + 8); }
 pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int agg,
                                     const float *d_weights, const uint32_t *d_list, uint32_t m, int64_t *out_groups, double *out_values, uint32_t *out_count,
                                     bool *handled);

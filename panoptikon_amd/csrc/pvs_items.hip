@@ -624,7 +624,9 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
         // the context's pinned block: [0, 64) flag words of the kernels, then the pages of the device-side ranking (rank_values),
         // then the queries — read by the query-prep kernel straight from host memory (no staged copy).  Sized ONCE here: kernels
         // in flight hold pointers into it.
-        const size_t io_pages = 64 + (size_t)std::min<uint32_t>(batch, PVS_MAX_BATCH) * ((size_t)k * 16 + 4);
+        // (per query column: k groups + k values, a handled flag AND a count — pvs_sparse_search_groups lays its pages out as
+        //  [64 | groups | values | flags | counts]; with 4 bytes per column its counts ran into the queries behind the pages)
+        const size_t io_pages = pvs_group_pages_bytes(std::min<uint32_t>(batch, PVS_MAX_BATCH), k);
         const size_t io_q = pvs_round_up(io_pages, 256);
         const void *q_dev = nullptr;
         if (qbytes * batch <= ((size_t)4 << 20)) {

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                     } else {
                         const double ss = (double)e.xh[r] + (double)qi[0].bb - 2.0 * (double)pv(0, r);
                         // (padding rows behind the last stored row carry a NaN norm: they are no reason to leave the closed form)
-                        if (!(ss < 16777216.0) && row0 + (uint64_t)((r & 3) + 8 * (r >> 2) + 4 * h) < a.n_rows && myq[0] < (int)a.batch) atomicOr(a.dense_flag, 1u);
+                        if (!(ss < 16777216.0) && row0 + (uint64_t)((r & 3) + 8 * (r >> 2) + 4 * h) < a.n_rows && myq[0] < (int)a.batch) *a.dense_flag = 1u;  // (plain store: the word may be pinned host memory; 1 is the only value written)
                         dm[r] = ref_l2_finish((float)ss);
                     }
                 }
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                                     d = ref_cosine_finish((float)pv(g, r), e.xh[r], qi[g].bb);
                                 } else {
                                     const double ss = (double)e.xh[r] + (double)qi[g].bb - 2.0 * (double)pv(g, r);
-                                    if (!(ss < 16777216.0)) atomicOr(a.dense_flag, 1u);
+                                    if (!(ss < 16777216.0)) *a.dense_flag = 1u;  // (plain store: the word may be pinned host memory; 1 is the only value written)
                                     d = ref_l2_finish((float)ss);
                                 }
                                 a.dense_out[(size_t)row * a.dense_ld + myq[g]] = d;

@@ -65,6 +65,7 @@ pvs_status prep_chunk(pvs_index *ix, SearchCtx &c, const void *d_queries, int qd
 static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff, uint32_t nb, uint32_t batch_pad, uint32_t k, int metric,
                                      int64_t *oid, float *od, uint32_t *oc, bool flat_rerun, bool side = false, hipStream_t prelude = nullptr) {
     // prelude: pass A and the k-th select go to that stream (the caller queued the query prep there), pass B waits for them
+    if ((ix->multi_stream || side || pvs_dbg(PVS_DBG_FORCE_LIGHT_FINALIZE)) && !pvs_dbg(PVS_DBG_NO_LIGHT_FINALIZE)) PVS_TRY(ctx_fin_buffers(c));  // (first such search of the context)
     ScanArgs a;
     a.dtype = (int)ix->dtype;
     a.metric = metric;
@@ -437,7 +438,7 @@ pvs_status search_fallbacks(pvs_index *ix, SearchCtx &c, const void *d_queries, 
             HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)ix->n * per * 4));
             HIP_TRY(pvs_scratch_alloc((void **)&d_qmap, (size_t)n_dense * 4));
             for (uint32_t i = 0; i < n_dense; i++)
-                HIP_TRY(hipMemcpyAsync(d_qd + (size_t)i * qbytes, (const uint8_t *)d_queries + (size_t)dq[i] * qbytes, qbytes, hipMemcpyDeviceToDevice, c.stream));
+                HIP_TRY(hipMemcpyAsync(d_qd + (size_t)i * qbytes, (const uint8_t *)d_queries + (size_t)dq[i] * qbytes, qbytes, hipMemcpyDefault, c.stream));
             HIP_TRY(hipMemcpyAsync(d_qmap, dq.data(), (size_t)n_dense * 4, hipMemcpyHostToDevice, c.stream));
             for (uint32_t off = 0; off < n_dense; off += per) {
                 const uint32_t nb = std::min(per, n_dense - off);

@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256) void k_sparse_score(const uint8_t *rows, uint3
     // the list is validated here (no separate pass, no round trip before the gather): a position beyond the index is never
     // dereferenced, an unsorted list is reported; the caller discards the page when the flag is raised
     if (row >= n_rows) {
-        if (q == 0) atomicOr(flag, 2u);
+        if (q == 0) flag[1] = 2u;  // (plain stores: the words live in pinned host memory, an atomic there needs PCIe atomics)
         out[(size_t)pos * ld + q] = __builtin_nanf("");
         return;
     }
-    if (q == 0 && pos && list[pos - 1] >= row) atomicOr(flag, 1u);
+    if (q == 0 && pos && list[pos - 1] >= row) flag[0] = 1u;
     const float aa = norm2[row];
     out[(size_t)pos * ld + q] = rerank_distance<DT>(rows, stride, row, s_q + (size_t)ql * qpad, dim, metric, aa, qinfo[q].bb);
 }
@@ -469,8 +469,9 @@ pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries,
     // the validity flag of the list: a word of the context's pinned block (written by the scorer, read here after the one
     // synchronisation at the end: no copy, no extra round trip)
     PVS_TRY(ctx_pinned_io(c, 64));
-    volatile uint32_t *h_flag = (volatile uint32_t *)c.h_io;
-    *h_flag = 0;
+    volatile uint32_t *h_flag = (volatile uint32_t *)c.h_io;  // word 0: unsorted, word 1: beyond the index (one word per condition: plain stores)
+    h_flag[0] = 0;
+    h_flag[1] = 0;
     auto bad_list = [&](uint32_t flag) -> pvs_status {
         if (flag & 2u) return pvs_fail(PVS_ERR_INVALID_ARG, "candidate rows must be row positions below the index's row count (%llu)", (unsigned long long)ix->n);
         if (flag & 1u) return pvs_fail(PVS_ERR_INVALID_ARG, "candidate rows must be strictly ascending");
@@ -541,7 +542,7 @@ pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries,
             }
         }
         HIP_TRY(hipStreamSynchronize(s));
-        return bad_list(*h_flag);
+        return bad_list(h_flag[0] | h_flag[1]);
     };
     pvs_status st = body();
     if (st != PVS_OK) (void)hipStreamSynchronize(s);
@@ -602,9 +603,11 @@ pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_q
         HIP_TRY(pvs_scratch_alloc((void **)&d_vals, (size_t)n_sub * chunk * 8));
         HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(chunk)));
         const size_t off_g = 64, off_v = off_g + (size_t)chunk * k * 8, off_f = off_v + (size_t)chunk * k * 8, off_c = off_f + (size_t)chunk * 4, need = off_c + (size_t)chunk * 4;
+        if (need != pvs_group_pages_bytes(chunk, k)) return pvs_fail(PVS_ERR_STATE, "per-item page layout and pvs_group_pages_bytes disagree");
         PVS_TRY(ctx_pinned_io(c, need));
         const uint32_t qbytes = ix->dim * (ix->dtype == PVS_I8 ? 1u : 4u), qpad = (qbytes + 63u) & ~63u;
-        *(volatile uint32_t *)c.h_io = 0;  // (the scorer's list-validity word: the list comes from a compacted mask, it stays 0)
+        ((volatile uint32_t *)c.h_io)[0] = 0;  // (the scorer's list-validity words
+        ((volatile uint32_t *)c.h_io)[1] = 0;  //: the list comes from a compacted mask, it stays 0)
         for (uint32_t q0 = 0; q0 < batch; q0 += chunk) {
             const uint32_t nb = std::min(chunk, batch - q0);
             const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
