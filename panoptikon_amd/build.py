@@ -39,6 +39,9 @@ SOURCES = [
     "pvs_dense.hip",
     "pvs_dense_exact.hip",
     "pvs_direct.hip",
+    "pvs_direct_i8.hip",
+    "pvs_direct_f16.hip",
+    "pvs_direct_f32.hip",
     "pvs_select.hip",
     "pvs_groups.hip",
     "pvs_rrf.hip",

@@ -26,6 +26,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "no_page_rank",    "rrf_serial",   "rrf_full",          "rrf_trace",            "scan_no_wide128",     "scratch_idle_cap_mb",
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
     "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
+    "direct_unit", "direct_static_pct", "direct_max_nq",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -765,8 +766,8 @@ PVS_EXPORT pvs_status pvs_index_scan_kernel_name(pvs_index *ix, uint32_t batch, 
     const pvs_index *sh = is_multi(ix) && !ix->shards.empty() ? ix->shards[0] : ix;
     const uint32_t ks = sh->stride / PVS_KSLAB_BYTES;
     const char *dtn = sh->dtype == PVS_I8 ? "i8" : sh->dtype == PVS_F16 ? "f16" : "f32";
-    if (batch == 1 && !is_multi(ix) && pvs_direct_route(sh, 100)) {  // (a page of <= 256 rows: search_enqueue)
-        snprintf(out, out_len, "k_direct_topk<%s, %u B> (one launch: exact distances + page)", dtn, sh->stride);
+    if (batch <= PVS_DIRECT_MAX_NQ && !is_multi(ix) && pvs_direct_route(sh, 10, batch)) {  // (the API's default page: search_enqueue decides per k)
+        snprintf(out, out_len, "k_direct_topk<%s, %u B, %u queries> (one launch: exact distances + pages)", dtn, sh->stride, batch <= 1 ? 1u : batch <= 2 ? 2u : batch <= 4 ? 4u : 8u);
         return PVS_OK;
     }
     if (!pvs_scan_supported((int)sh->dtype, ks)) {

@@ -78,6 +78,9 @@ enum PvsDbg {
     PVS_DBG_NO_DIRECT_TOPK,        // single queries always take the filter scan (never the one-launch exact search, pvs_direct.hip)
     PVS_DBG_DIRECT_MAX_MB,         // ... take the one-launch search up to this many MB of rows (0: the built-in crossover)
     PVS_DBG_DIRECT_QUERIES,        // (a counter, read with pvs_debug_get) single queries answered by the one-launch search, process-wide
+    PVS_DBG_DIRECT_UNIT,           // one-launch search: 64-row pairs per work unit (0: >= 48 KB of rows)
+    PVS_DBG_DIRECT_STATIC_PCT,     // ... share of a wave's units that is dealt instead of dequeued, in percent (0: 50; 100: round 4's dealing; -1: one dealt unit)
+    PVS_DBG_DIRECT_MAX_NQ,         // ... at most this many queries per launch (0: what the instance table takes; 1: round 4's single-query form only)
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -257,7 +257,7 @@ void span_end(pvs_index *ix, SearchCtx &c, hipStream_t on = nullptr);
 // a span whose two events are bound to ONE dispatch by the launcher (ScanArgs.ev_start / ev_stop) instead of being recorded around
 // it: returns false (events untouched) when the index is not profiling
 // would ONE unmasked query for a page of k rows take the one-launch search (pvs_direct.hip) on this index?
-bool pvs_direct_route(const pvs_index *ix, uint32_t k);
+bool pvs_direct_route(const pvs_index *ix, uint32_t k, uint32_t batch = 1);
 bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t *ev_start, hipEvent_t *ev_stop);
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);

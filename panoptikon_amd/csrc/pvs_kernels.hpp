@@ -41,9 +41,10 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
                                   float *out, uint32_t out_ld, uint32_t out_col, uint32_t n_cu, hipStream_t s);
 
-// ---- one launch for one query (pvs_direct.hip): exact distance of every row in the reference's in-order arithmetic + the page,
+// ---- one launch for 1..8 queries (pvs_direct.hip): exact distance of every row in the reference's in-order arithmetic + the pages,
 // selected while the rows stream; flags as pass C writes them (0 done, 3 page ends in NULL rows, 1 dense path)
 constexpr uint32_t PVS_DIRECT_MAX_K = 256;
+constexpr uint32_t PVS_DIRECT_MAX_NQ = 8;            // queries per launch (int8 rows; float rows: 4)
 constexpr uint64_t PVS_DIRECT_CROSSOVER_MB = 8192;  // rows x pitch up to which one query takes the one-launch search (search_enqueue)
 struct DirectArgs {
     int dtype, metric;
@@ -52,26 +53,27 @@ struct DirectArgs {
     const int64_t *ids;
     uint32_t stride, dim;
     uint64_t n_rows;
-    const void *qexact;  // [dim] int8 codes (int8 index) or f32: SearchCtx::d_qexact after prep_chunk
-    const QInfo *qinfo;
+    const void *qexact;  // [nq][dim] int8 codes (int8 index) or f32: SearchCtx::d_qexact after prep_chunk
+    const QInfo *qinfo;  // [nq]
     const uint32_t *trank = nullptr, *tinv = nullptr;
     const uint8_t *mask = nullptr;  // optional candidate mask [n_rows]: a row whose byte is 0 takes part in nothing
     uint32_t k;
+    uint32_t nq = 1;     // queries (pvs_direct_supported says how many a (dtype, pitch, k) takes)
     void *work;          // pvs_direct_work_bytes(n_cu), zeroed once
-    int64_t *out_ids;
+    int64_t *out_ids;    // [nq][k]
     float *out_dist;
-    uint32_t *out_count, *need_dense, *h_flags, *h_seen;
-    // optional mirror of the page in pinned host memory (written when the page is complete: flag 0), so that a host caller needs
-    // no copy back
-    int64_t *h_out_ids = nullptr;
+    uint32_t *out_count, *need_dense, *h_flags, *h_seen;  // [nq]
+    // optional mirror of the pages in pinned host memory (a page is written when it is complete: flag 0), so that a host caller
+    // needs no copy back
+    int64_t *h_out_ids = nullptr;  // [nq][k]
     float *h_out_dist = nullptr;
-    uint32_t *h_out_count = nullptr;
-    uint32_t *h_out_rows = nullptr;  // ... and the stored-row number of every entry (per-item callers look their groups up by row)
+    uint32_t *h_out_count = nullptr;  // [nq]
+    uint32_t *h_out_rows = nullptr;  // [nq][k] ... and the stored-row number of every entry (per-item callers look their groups up by row)
     int null_ok = 0;
     uint32_t n_cu;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
-bool pvs_direct_supported(uint32_t stride, uint32_t esz, uint32_t k);
+bool pvs_direct_supported(int dtype, uint32_t stride, uint32_t esz, uint32_t k, uint32_t nq);
 uint64_t pvs_direct_work_bytes(uint32_t n_cu);
 hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s);
 

@@ -236,26 +236,30 @@ static pvs_status enqueue_fast_chunk(pvs_index *ix, SearchCtx &c, uint32_t qoff,
     return PVS_OK;
 }
 
-// One query, a page of <= 256 rows over a corpus below the crossover: ONE launch scores every row exactly and
-// selects the page on the way (pvs_direct.hip) — the filter scan's five dependent launches are most of such a search's latency.
-// Measured (tools/direct_crossover.py, 768-d, p50 of pvs_search, k = 10 / 100): it wins at every size tried — int8 1M rows 0.197 / 0.229 ms against
+// One to eight queries, pages of <= 256 rows, over a corpus below the crossover: ONE launch scores every row exactly and selects
+// the pages on the way (pvs_direct.hip) — the filter scan's five dependent launches are most of such a search's latency.
+// Measured (round 4, tools/direct_crossover.py, 768-d, p50 of pvs_search, k = 10 / 100): one query wins at every size tried — int8 1M rows 0.197 / 0.229 ms against
 // 0.239 / 0.236, 8M 1.000 / 1.000 against 1.017 / 1.017; f16 4M 1.01 / 1.00 against 1.09 / 1.10; f32 4M (11.7 GB) 1.94 / 1.88 against 2.01 / 2.04 — by the
 // fixed cost it saves; the crossover keeps the north-star shape (10M x 768 f16, 15 GB, filter scan at 0.82 of HBM) where it was.
-bool pvs_direct_route(const pvs_index *ix, uint32_t k) {
+// Round 5: 2..8 queries (a PQL `or` of a few vector filters over one space, pql/builder.rs:638-661; coalesced callers) share the
+// launch: the stream stays HBM-bound (a lane's row chunk feeds NQ chains), the pages are finalised by NQ workgroups at once.
+bool pvs_direct_route(const pvs_index *ix, uint32_t k, uint32_t batch) {
     if (ix->forced_path != 0 || ix->n == 0 || pvs_dbg(PVS_DBG_NO_DIRECT_TOPK)) return false;
-    if (!pvs_direct_supported(ix->stride, ix->esz, k)) return false;
+    if (batch > 1 && pvs_dbg(PVS_DBG_DIRECT_MAX_NQ) > 0 && (int64_t)batch > pvs_dbg(PVS_DBG_DIRECT_MAX_NQ)) return false;
+    if (!pvs_direct_supported((int)ix->dtype, ix->stride, ix->esz, k, batch)) return false;
     const uint64_t lim_mb = pvs_dbg(PVS_DBG_DIRECT_MAX_MB) > 0 ? (uint64_t)pvs_dbg(PVS_DBG_DIRECT_MAX_MB) : PVS_DIRECT_CROSSOVER_MB;
     return ix->n * (uint64_t)ix->stride <= (lim_mb << 20);
 }
-static bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k) { return batch == 1 && pvs_direct_route(ix, k); }
-static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t k, int metric, int64_t *oid, float *od,
+static bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k) { return batch >= 1 && batch <= PVS_DIRECT_MAX_NQ && pvs_direct_route(ix, k, batch); }
+// h_page: the context's pinned block for the pages [ids batch x k x 8 | distances batch x k x 4 | counts (64 B) | stored rows batch x k x 4]
+static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int64_t *oid, float *od,
                                  uint32_t *oc, uint8_t *h_page = nullptr) {
     if (!c.d_direct) {
         const uint64_t bytes = pvs_direct_work_bytes((uint32_t)ix->n_cu);
         HIP_TRY(pvs_malloc_retry(&c.d_direct, bytes));
         HIP_TRY(hipMemsetAsync(c.d_direct, 0, bytes, c.stream));
     }
-    PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, 0, 1, 32, metric));
+    PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, 0, batch, 32, metric));
     DirectArgs d;
     d.dtype = (int)ix->dtype;
     d.metric = metric;
@@ -273,6 +277,7 @@ static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_quer
     }
     d.mask = c.cur_mask;  // (pvs_search_filtered: rows outside the mask are skipped)
     d.k = k;
+    d.nq = batch;
     d.work = c.d_direct;
     d.out_ids = oid;
     d.out_dist = od;
@@ -282,16 +287,17 @@ static pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_quer
     d.h_seen = c.h_need_dense + c.flags_cap;
     d.null_ok = ix->null_built_n.load(std::memory_order_acquire) == ix->n && ix->null_weird[metric == PVS_L2 ? 1 : 0] == 0;
     d.n_cu = (uint32_t)ix->n_cu;
-    if (h_page) {  // [ids k x 8 | distances k x 4 | count]
+    if (h_page) {
+        const size_t bk = (size_t)batch * k;
         d.h_out_ids = (int64_t *)h_page;
-        d.h_out_dist = (float *)(h_page + (size_t)k * 8);
-        d.h_out_count = (uint32_t *)(h_page + (size_t)k * 12);
-        d.h_out_rows = (uint32_t *)(h_page + (size_t)k * 12 + 64);
+        d.h_out_dist = (float *)(h_page + bk * 8);
+        d.h_out_count = (uint32_t *)(h_page + bk * 12);
+        d.h_out_rows = (uint32_t *)(h_page + bk * 12 + 64);
     }
     (void)span_bound(ix, c, 1, ix->n, &d.ev_start, &d.ev_stop);
     HIP_TRY(pvs_launch_direct_topk(d, c.stream));
-    ix->direct_queries++;
-    pvs_dbg_add(PVS_DBG_DIRECT_QUERIES, 1);
+    ix->direct_queries += batch;
+    pvs_dbg_add(PVS_DBG_DIRECT_QUERIES, batch);
     return PVS_OK;
 }
 
@@ -313,7 +319,7 @@ pvs_status search_enqueue(pvs_index *ix, SearchCtx &c, const void *d_queries, in
     if (direct_ok(ix, c, batch, k)) {  // (whether or not a scan instance exists for the row pitch)
         if (!fast) PVS_TRY(pvs_ensure_null_rows(ix));
         *used_fast = true;
-        PVS_TRY(enqueue_direct(ix, c, d_queries, qdtype, k, metric, d_out_ids, d_out_dist, d_out_count));
+        PVS_TRY(enqueue_direct(ix, c, d_queries, qdtype, batch, k, metric, d_out_ids, d_out_dist, d_out_count));
         HIP_TRY(hipEventRecord(c.done, c.stream));
         return PVS_OK;
     }
@@ -780,38 +786,44 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
     pvs_status st = ctx_prepare(ix, *c, batch, k, true);
     const size_t qbytes = (size_t)ix->dim * (qdtype == PVS_I8 ? 1 : 4);
     if (st == PVS_OK && !mask && !listed && direct_ok(ix, *c, batch, k)) {
-        // One query over a small or medium corpus (pvs_direct.hip): the query is read from this context's pinned, device-mapped block,
-        // the page is mirrored into it — no staging copy either way, one synchronisation.  A page that needs the fallbacks (NULL
-        // tail, dense path) takes the ordinary route below from the device copy of what the kernel wrote.
-        const size_t off_p = pvs_round_up(64 + qbytes, 64), need = off_p + (size_t)k * 16 + 128;  // [ids | distances | count .. | rows]
+        // One to eight queries over a small or medium corpus (pvs_direct.hip): the queries are read from this context's pinned,
+        // device-mapped block, the pages are mirrored into it — no staging copy either way, one synchronisation.  Pages that need the
+        // fallbacks (NULL tail, dense path) take the ordinary route below from the device copy of what the kernel wrote.
+        const size_t bk = (size_t)batch * k;
+        const size_t off_p = pvs_round_up(64 + qbytes * batch, 64), need = off_p + bk * 16 + 128;  // [ids | distances | counts .. | rows]
         auto run = [&]() -> pvs_status {
             PVS_TRY(ctx_pinned_io(*c, need));
             uint8_t *io = c->h_io;
-            memcpy(io + 64, queries, qbytes);
+            memcpy(io + 64, queries, qbytes * batch);
             PVS_TRY(pvs_ensure_null_rows(ix));
-            PVS_TRY(enqueue_direct(ix, *c, io + 64, qdtype, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, io + off_p));
+            PVS_TRY(enqueue_direct(ix, *c, io + 64, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, io + off_p));
             HIP_TRY(hipEventRecord(c->done, c->stream));
             HIP_TRY(hipEventSynchronize(c->done));
             spans_collect(ix, *c);
-            if (c->h_need_dense[0] == 0) {
-                memcpy(out_ids, io + off_p, (size_t)k * 8);
-                memcpy(out_dist, io + off_p + (size_t)k * 8, (size_t)k * 4);
-                const uint32_t cnt = *(const uint32_t *)(io + off_p + (size_t)k * 12);
-                out_count[0] = cnt;
-                if (out_row_idx) memcpy(out_row_idx, io + off_p + (size_t)k * 12 + 64, (size_t)cnt * 4);
-                for (uint32_t i = cnt; i < k; i++) {  // (k > rows: the page's unused tail)
-                    out_ids[i] = -1;
-                    out_dist[i] = __builtin_nanf("");
+            bool complete = true;
+            for (uint32_t q = 0; q < batch; q++) complete = complete && c->h_need_dense[q] == 0;
+            if (complete) {
+                memcpy(out_ids, io + off_p, bk * 8);
+                memcpy(out_dist, io + off_p + bk * 8, bk * 4);
+                const uint32_t *cnts = (const uint32_t *)(io + off_p + bk * 12);
+                for (uint32_t q = 0; q < batch; q++) {
+                    const uint32_t cnt = cnts[q];
+                    out_count[q] = cnt;
+                    if (out_row_idx) memcpy(out_row_idx + (size_t)q * k, io + off_p + bk * 12 + 64 + (size_t)q * k * 4, (size_t)cnt * 4);
+                    for (uint32_t i = cnt; i < k; i++) {  // (k > rows: the page's unused tail)
+                        out_ids[(size_t)q * k + i] = -1;
+                        out_dist[(size_t)q * k + i] = __builtin_nanf("");
+                    }
                 }
-                ix->fast_queries++;
+                ix->fast_queries += batch;
                 ix->last_candidates = 0;
                 return PVS_OK;
             }
-            // (the query is needed on the device by the fallbacks: the pinned block is device-addressable)
+            // (the queries are needed on the device by the fallbacks: the pinned block is device-addressable)
             PVS_TRY(search_fallbacks(ix, *c, io + 64, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count));
-            HIP_TRY(hipMemcpyAsync(out_ids, c->d_out_ids, 8 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(out_dist, c->d_out_dist, 4 * (size_t)k, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(out_count, c->d_out_count, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_ids, c->d_out_ids, 8 * bk, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_dist, c->d_out_dist, 4 * bk, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(out_count, c->d_out_count, 4 * (size_t)batch, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             return PVS_OK;
         };

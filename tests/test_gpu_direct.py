@@ -178,23 +178,240 @@ def test_direct_search_honours_the_second_sort_key(pvs):
 
 
 def test_direct_search_is_not_taken_where_it_does_not_apply(pvs):
-    """Batches, pages beyond 256 rows and a corpus above the crossover stay on the filter scan."""
+    """More than eight queries, pages beyond 256 rows, batches whose lists do not fit the LDS and a corpus above the crossover stay
+    on the filter scan."""
     n, dim = 5000, 128
     rows = orc.synth_rows(31, 0, n, dim)
     ix = _index(pvs, pvs.F32, rows, None)
-    q = orc.synth_rows(32, 0, 2, dim)
+    q = orc.synth_rows(32, 0, 9, dim)
     before = _direct_searches(pvs)
-    ix.search(q, 10, pvs.COSINE)                     # two queries
+    ix.search(q, 10, pvs.COSINE)                     # nine queries
+    ix.search(q[:5], 10, pvs.COSINE)                 # five f32 queries: float rows take four per launch
+    ix.search(q[:4], 200, pvs.COSINE)                # four pages of 200 rows: the wave lists do not fit
     ix.search(q[0], 257, pvs.COSINE)                 # k > 256
     pvs.debug_set("direct_max_mb", 1)                # crossover below this corpus (2.5 MB)
     try:
         ix.search(q[0], 10, pvs.COSINE)
     finally:
         pvs.debug_set("direct_max_mb", 0)
+    pvs.debug_set("direct_max_nq", 1)                # round 4's form: single queries only
+    try:
+        ix.search(q[:2], 10, pvs.COSINE)
+    finally:
+        pvs.debug_set("direct_max_nq", 0)
     assert _direct_searches(pvs) == before
     ei, ed = orc.search(orc.F32, orc.COSINE, rows, q[0], 10)
     gi, gd, gc = ix.search(q[0], 10, pvs.COSINE)
     assert _direct_searches(pvs) == before + 1 and np.array_equal(gi[0], ei[0])
+    ix.search(q[:2], 10, pvs.COSINE)
+    assert _direct_searches(pvs) == before + 3
+    ix.close()
+
+
+def _lists_fit(dtype, dim, k, batch):
+    """Mirror of plan_capw (csrc/pvs_direct.hip): does a batch share one launch?"""
+    esz = {"i8": 1, "f16": 2, "f32": 4}[dtype]
+    stride = (dim * esz + 255) // 256 * 256
+    w = 1 if batch <= 1 else 2 if batch <= 2 else 4 if batch <= 4 else 8
+    if batch > 8 or k > 256 or (dtype != "i8" and w > 4):
+        return False
+    qbytes = w * (stride if esz == 1 else stride // esz * 4)
+    if qbytes + 1024 > 30 * 1024:
+        return False
+    kp = 16
+    while kp < k:
+        kp *= 2
+    capw = min(max(2 * kp, 128), (30 * 1024 - qbytes) // (32 * w) // 32 * 32, 512)
+    return capw >= k + 64 and w * k <= 1024
+
+
+BATCH_SHAPES = [
+    # dtype, metric, n, dim, k, batch
+    ("i8", "cosine", 30011, 768, 10, 2),
+    ("i8", "l2", 30011, 768, 100, 3),
+    ("i8", "cosine", 69001, 768, 10, 4),
+    ("i8", "l2", 20000, 768, 30, 8),
+    ("i8", "cosine", 5000, 512, 32, 7),
+    ("i8", "cosine", 100, 96, 10, 8),       # fewer workgroups than queries: finalisers take several queries each
+    ("i8", "l2", 1, 33, 1, 5),
+    ("i8", "cosine", 4099, 1536, 64, 4),
+    ("f16", "cosine", 20000, 768, 10, 4),
+    ("f16", "l2", 9000, 1152, 17, 2),
+    ("f16", "cosine", 129, 64, 60, 3),
+    ("f32", "cosine", 10000, 512, 10, 4),   # BASELINE configs[0] x 4
+    ("f32", "l2", 4097, 768, 64, 4),
+    ("f32", "cosine", 3000, 1536, 33, 2),
+    ("f32", "l2", 63, 300, 7, 3),
+    ("f32", "cosine", 30000, 384, 200, 2),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,n,dim,k,batch", BATCH_SHAPES)
+def test_few_query_direct_search_matches_oracle_and_filter_scan(pvs, dtype, metric, n, dim, k, batch):
+    """2..8 queries share ONE launch (a PQL `or` of a few vector filters, pql/builder.rs:638-661; coalesced callers): every page
+    bit for bit the oracle's and the filter scan's, through the host entry point and the stream-ordered one."""
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    m = pvs.COSINE if metric == "cosine" else pvs.L2
+    assert _lists_fit(dtype, dim, k, batch)
+    rows = orc.synth_rows(170 + dim, 0, n, dim)
+    queries = orc.synth_rows(0x5EED0200, 0, batch, dim)
+    if n > 100:
+        queries[batch - 1] = rows[n // 2]  # a stored row as a query: distance 0 at the top
+    scale = orc.compute_int8_scale(rows)
+    ids = np.arange(n, dtype=np.int64) * 3 + 11
+    ix = _index(pvs, dt, rows, scale, ids)
+    hc = _host(dt, rows, scale)
+    hq = orc.quantize_int8(queries, scale) if dt == pvs.I8 else queries
+    k_eff = min(k, n)
+    ei, ed = orc.search(dt, m, hc, hq, k, ids=ids, threads=4)
+    before, dense_before = _direct_searches(pvs), ix.stats().dense_queries
+    gi, gd, gc = ix.search(queries, k, m)
+    assert _direct_searches(pvs) == before + batch, "a few queries over a small corpus share the one-launch search"
+    assert ix.stats().dense_queries == dense_before
+    for j in range(batch):
+        _same((gi[j:j + 1], gd[j:j + 1], gc[j:j + 1]), ei[j], ed[j], k_eff)
+    # the stream-ordered entry point (device buffers in and out)
+    dq = pvs.DeviceBuffer.from_numpy(np.ascontiguousarray(hq))
+    d_out = [pvs.DeviceBuffer(batch * k * 8), pvs.DeviceBuffer(batch * k * 4), pvs.DeviceBuffer(batch * 4)]
+    ix.wait(ix.search_device(dq, pvs.I8 if dt == pvs.I8 else pvs.F32, batch, k, m, *d_out))
+    si, sd, sc = d_out[0].to_numpy(np.int64, (batch, k)), d_out[1].to_numpy(np.float32, (batch, k)), d_out[2].to_numpy(np.uint32, (batch,))
+    assert _direct_searches(pvs) == before + 2 * batch
+    for j in range(batch):
+        _same((si[j:j + 1], sd[j:j + 1], sc[j:j + 1]), ei[j], ed[j], k_eff)
+    for b in [dq] + d_out:
+        b.free()
+    pvs.debug_set("no_direct_topk", 1)
+    try:
+        ri, rd, rc = ix.search(queries, k, m)
+    finally:
+        pvs.debug_set("no_direct_topk", 0)
+    assert _direct_searches(pvs) == before + 2 * batch
+    for j in range(batch):
+        _same((ri[j:j + 1], rd[j:j + 1], rc[j:j + 1]), ei[j], ed[j], k_eff)
+    ix.close()
+
+
+def test_few_query_direct_search_with_null_pages_keys_masks_and_a_zero_query(pvs):
+    """A batch in which one query is zero (every cosine distance NULL), pages that end in NULL rows, the second sort key, a
+    candidate mask — per query what the single-query search says."""
+    rng = np.random.default_rng(77)
+    n, dim = 40000, 200
+    rows = orc.synth_rows(410, 0, n, dim)
+    rows[[7, 8, 9000]] = 0.0
+    rows[20000:20040] = rows[19999]
+    ids = np.arange(n, dtype=np.int64) * 5 + 1
+    keys = rng.integers(0, 6, n).astype(np.int64) + 1_700_000_000
+    q = orc.synth_rows(420, 0, 4, dim)
+    q[2] = 0.0
+    q[3] = rows[19999]
+    for dtype in ("i8", "f32"):
+        dt = {"i8": pvs.I8, "f32": pvs.F32}[dtype]
+        scale = orc.compute_int8_scale(rows)
+        ix = _index(pvs, dt, rows, scale, ids)
+        for keyed in (False, True):
+            ix.set_order_keys(keys if keyed else None)
+            for m in (pvs.COSINE, pvs.L2):
+                for k in (10, 64):
+                    before, dense_before = _direct_searches(pvs), ix.stats().dense_queries
+                    gi, gd, gc = ix.search(q, k, m)
+                    assert _direct_searches(pvs) == before + 4
+                    for j in range(4):
+                        oi, od, oc = ix.search(q[j], k, m)
+                        assert gc[j] == oc[0] and np.array_equal(gi[j], oi[0]), (dtype, keyed, m, k, j)
+                        assert np.array_equal(gd[j].view(np.uint32), od[0].view(np.uint32))
+                    mask = (rng.random(n) < 0.6).astype(np.uint8)
+                    mask[[7, 8]] = 1
+                    fi, fd, fc = ix.search_filtered(q, k, mask, m)
+                    for j in range(4):
+                        oi, od, oc = ix.search_filtered(q[j], k, mask, m)
+                        assert fc[j] == oc[0] and np.array_equal(fi[j], oi[0]), (dtype, keyed, m, k, j, "masked")
+                        assert np.array_equal(fd[j].view(np.uint32), od[0].view(np.uint32))
+                    assert ix.stats().dense_queries == dense_before
+        # a mask that leaves fewer rows than the page: the page ends where the allowed rows end, no dense pass (ADVICE r4)
+        few = np.zeros(n, np.uint8)
+        few[rng.choice(n, 17000, replace=False)] = 1
+        few[[7, 8, 9000]] = 1
+        dense_before, tails_before = ix.stats().dense_queries, ix.stats().null_tail_queries
+        short = np.zeros(n, np.uint8)
+        short[100:130] = 1  # 30 allowed rows, k = 64 (sparse route) ... and through the scan:
+        pvs.debug_set("no_sparse", 1)
+        try:
+            si, sd, sc = ix.search_filtered(q[0], 64, short, pvs.L2)
+        finally:
+            pvs.debug_set("no_sparse", 0)
+        hc = _host(dt, rows, scale)
+        hq0 = orc.quantize_int8(q[0], scale) if dt == pvs.I8 else q[0]
+        allowed = np.nonzero(short)[0]
+        ei, ed = orc.search(dt, orc.L2, hc[allowed], hq0, 64, ids=ids[allowed])
+        assert sc[0] == 30 and np.array_equal(si[0, :30], ei[0]) and np.array_equal(sd[0, :30].view(np.uint32), ed[0].view(np.uint32))
+        assert ix.stats().dense_queries == dense_before and ix.stats().null_tail_queries == tails_before, "fewer allowed rows than k is a complete page, not a NULL tail"
+        ix.close()
+
+
+def test_few_query_direct_search_one_query_beyond_the_closed_form(pvs):
+    """int8: a batch in which ONE query's sums leave the closed form's range goes to the dense path for that query only."""
+    rng = np.random.default_rng(1101)
+    n, dim = 900, 1100
+    hc = rng.integers(-20, 21, size=(n, dim)).astype(np.int8)
+    hq = rng.integers(-20, 21, size=(3, dim)).astype(np.int8)
+    hq[1] = rng.choice(np.array([-128, 127], np.int8), size=dim)  # |q|^2 = 1,100 x 127^2 > 2^24
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(1.0)
+    ix.add(hc)
+    for m in (pvs.COSINE, pvs.L2):
+        ei, ed = orc.search(orc.I8, m, hc, hq, 10)
+        before, dense_before = _direct_searches(pvs), ix.stats().dense_queries
+        gi, gd, gc = ix.search(hq, 10, m)
+        assert _direct_searches(pvs) == before + 3 and ix.stats().dense_queries == dense_before + 1
+        for j in range(3):
+            _same((gi[j:j + 1], gd[j:j + 1], gc[j:j + 1]), ei[j], ed[j], 10)
+    ix.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PVS_FUZZ_SEEDS", "30"))))
+def test_randomized_few_query_batches_against_the_oracle(pvs, seed):
+    """Seeded sweep over 2..8-query batches: element type / metric / rows / dim / k / batch, ties, zero rows, an order key on every
+    other seed; whatever route the library picks (one launch where the lists fit, the filter scan otherwise), every page is the
+    oracle's."""
+    rng = np.random.default_rng(51000 + seed)
+    dtype = ["i8", "f16", "f32"][seed % 3]
+    dt = {"i8": pvs.I8, "f16": pvs.F16, "f32": pvs.F32}[dtype]
+    m = [pvs.COSINE, pvs.L2][(seed // 3) % 2]
+    n = int(rng.choice([2, 63, 64, 65, 129, 1000, 4097, 20000, 70001, 300000]))
+    dim = int(rng.choice([3, 17, 64, 100, 257, 384, 768, 1000, 1536]))
+    k = int(rng.choice([1, 2, 10, 32, 33, 64, 100]))
+    batch = int(rng.integers(2, 9))
+    rows = orc.synth_rows(52000 + seed, 0, n, dim)
+    if n > 8:
+        rows[rng.integers(0, n, 5)] = rows[rng.integers(0, n, 5)]
+        rows[int(rng.integers(0, n))] = 0.0
+        run = int(rng.integers(0, n - 4))
+        rows[run:run + 4] = rows[run]
+    q = orc.synth_rows(53000 + seed, 0, batch, dim)
+    if n > 8:
+        q[int(rng.integers(0, batch))] = rows[int(rng.integers(0, n))]
+    scale = orc.compute_int8_scale(rows)
+    ids = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+    ix = _index(pvs, dt, rows, scale, ids)
+    keys = None
+    if seed % 2 == 1:
+        keys = rng.integers(0, 6, n).astype(np.int64) + 1_700_000_000
+        ix.set_order_keys(keys)
+    hc = _host(dt, rows, scale)
+    hq = orc.quantize_int8(q, scale) if dt == pvs.I8 else q
+    om = orc.COSINE if m == pvs.COSINE else orc.L2
+    before = _direct_searches(pvs)
+    gi, gd, gc = ix.search(q, k, m)
+    assert _direct_searches(pvs) == before + (batch if _lists_fit(dtype, dim, k, batch) else 0), (dtype, dim, k, batch)
+    kk = min(k, n)
+    for j in range(batch):
+        d = orc.score_all(dt, om, hc, hq[j])
+        ei, ed = orc.topk_ordered(d, k, ids, keys if keys is not None else np.zeros(n, np.int64))
+        assert gc[j] == kk, (seed, j, gc[j], kk)
+        assert np.array_equal(gi[j, :kk], ei[:kk]), (seed, n, dim, k, batch, j)
+        assert np.array_equal(np.isnan(gd[j, :kk]), np.isnan(ed[:kk]))
+        fin = ~np.isnan(ed[:kk])
+        assert np.array_equal(gd[j, :kk][fin].view(np.uint32), ed[:kk][fin].view(np.uint32)), (seed, n, dim, k, batch, j)
     ix.close()
 
 
