@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
+from routes import lists_fit
 
 pytestmark = pytest.mark.gpu
 
@@ -81,9 +82,9 @@ def test_search_rows_equals_the_oracle_over_the_listed_rows(pvs, dtype):
                 mask = np.zeros(n, np.uint8)
                 mask[lst] = 1
                 mi, md, mc = ix.search_filtered(hq[:b], k, mask, metric)
-                # (ONE query for a page of <= 256 rows over a corpus this small is not worth counting its mask for: the one-launch
+                # (a few queries for pages of <= 256 rows over a corpus this small are not worth counting the mask for: the one-launch
                 #  search skips the masked rows while it streams, csrc/pvs_search.hip direct_small)
-                served += 0 if (b == 1 and k <= 256) else b
+                served += 0 if lists_fit(dtype, dim, k, b) else b
                 assert np.array_equal(mi, gi) and np.array_equal(mc, gc) and np.array_equal(md.view(np.uint32), gd.view(np.uint32))
         st = ix.stats()
         assert st.dense_queries == dense_before, "a short candidate list must never reach the dense path"
@@ -405,8 +406,9 @@ def test_per_item_pages_over_a_sparse_candidate_mask(pvs, dtype, runs):
                         s0 = ix.stats()
                         got = ix.search_groups_filtered(hq, k, mask, metric, agg, row_weights=ww)
                         s1 = ix.stats()
-                        # (MIN for one query is a row page of the one-launch search, which skips the masked rows while it streams)
-                        via_direct = agg == pvs.AGG_MIN and nb == 1 and k == 10
+                        # (MIN for up to three queries is a row page of 16 k rows — ~8 rows per file — from the one-launch search where its
+                        #  lists fit, which skips the masked rows while it streams)
+                        via_direct = agg == pvs.AGG_MIN and nb < 4 and lists_fit(dtype, dim, 16 * k, nb)
                         assert s1.sparse_queries == s0.sparse_queries + (0 if via_direct else nb) and s1.dense_queries == s0.dense_queries, (nb, keyed, metric, agg, k)
                         for j in sorted({0, nb - 1}):
                             exp = orc.search_groups(dt, metric, hc[allowed], hq[j], grp[allowed], oagg, k, weights=None if ww is None else ww[allowed],
