@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define PVS_ABI_VERSION 3
+#define PVS_ABI_VERSION 4
 
 typedef int32_t pvs_status;
 enum {
@@ -166,6 +166,26 @@ pvs_status pvs_index_add(pvs_index *idx, const void *rows, uint64_t n, const int
  * nearest-even, f32 unchanged. */
 pvs_status pvs_index_add_f32(pvs_index *idx, const float *rows, uint64_t n, const int64_t *row_ids,
                              const int64_t *group_ids, pvs_space rows_space);
+
+/* ABI v4 — rows leave and change without a rebuild.  The reference deletes vectors whenever a file disappears
+ * (`embeddings ... ON DELETE CASCADE`, migrations/index/20250117193000_init.sql:29-33; db/files.rs:175-192,
+ * db/file_scans.rs:480) and upserts quant codes per item_data id (db/vector_quants.rs:1109-1111, 1347-1438).
+ *
+ * pvs_index_remove_rows: removes the rows with the listed ids (any order, duplicates allowed; ids the index does not
+ * hold are ignored; *out_removed, optional, counts the rows that went).  The index is COMPACTED on the device: row i
+ * afterwards is its i-th surviving row — order kept, ids still strictly increasing, later adds append as before.
+ * Group ids and order keys the index holds move with their rows; per-row arrays the CALLER keeps (candidate masks,
+ * row weights, pvs_similar_opts arrays) follow the same renumbering.  Every search afterwards sees an ordinary index
+ * (nothing on a search path tests a row for being alive).  Searches in flight are waited for; exclusive like
+ * pvs_index_add.  Multi-device indexes: every shard compacts its rows, the global order is the surviving rows' order.
+ *
+ * pvs_index_replace_rows[_f32]: overwrites the vectors of rows the index already holds (same ids, same positions,
+ * same groups and keys): rows = dense [n][dim] of the index dtype (or f32, converted like pvs_index_add_f32),
+ * row_ids strictly increasing, every id must be in the index (PVS_ERR_INVALID_ARG otherwise).  Multi-device
+ * indexes take host rows. */
+pvs_status pvs_index_remove_rows(pvs_index *idx, const int64_t *row_ids, uint64_t n, uint64_t *out_removed);
+pvs_status pvs_index_replace_rows(pvs_index *idx, const void *rows, uint64_t n, const int64_t *row_ids, pvs_space rows_space);
+pvs_status pvs_index_replace_rows_f32(pvs_index *idx, const float *rows, uint64_t n, const int64_t *row_ids, pvs_space rows_space);
 
 /* int8 only: the 4-byte scale artifact.  Same rejections as artifact_scale
  * (db/vector_quants.rs:1456-1460): len != 4, non-finite, <= 0 -> INVALID_ARG. */

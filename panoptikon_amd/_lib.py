@@ -84,6 +84,9 @@ SYMBOLS = {
     "pvs_index_destroy": (None, [_vp]),
     "pvs_index_add": (_i32, [_vp, _vp, _u64, _vp, _vp, _i32]),
     "pvs_index_add_f32": (_i32, [_vp, _vp, _u64, _vp, _vp, _i32]),
+    "pvs_index_remove_rows": (_i32, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "pvs_index_replace_rows": (_i32, [_vp, _vp, _u64, _vp, _i32]),
+    "pvs_index_replace_rows_f32": (_i32, [_vp, _vp, _u64, _vp, _i32]),
     "pvs_index_set_scale_artifact": (_i32, [_vp, _vp, _sz]),
     "pvs_index_set_scale": (_i32, [_vp, _f]),
     "pvs_index_stats": (_i32, [_vp, C.POINTER(Stats)]),

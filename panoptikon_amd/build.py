@@ -50,6 +50,7 @@ SOURCES = [
     "pvs_sparse.hip", "pvs_rrf_device.hip",
     "pvs_comm.hip",
     "pvs_multi.hip",
+    "pvs_lifecycle.hip",
     "pvs_microbench.hip",
     "pvs_host.cpp",
 ]

@@ -537,6 +537,8 @@ hipError_t pvs_launch_take_rows(const void *in, uint32_t elem_bytes, const uint3
         hipLaunchKernelGGL(k_take_rows<uint8_t>, dim3(g), dim3(256), 0, s, (const uint8_t *)in, global_row, n_local, (uint8_t *)out);
     else if (elem_bytes == 4)
         hipLaunchKernelGGL(k_take_rows<uint32_t>, dim3(g), dim3(256), 0, s, (const uint32_t *)in, global_row, n_local, (uint32_t *)out);
+    else if (elem_bytes == 8)
+        hipLaunchKernelGGL(k_take_rows<uint64_t>, dim3(g), dim3(256), 0, s, (const uint64_t *)in, global_row, n_local, (uint64_t *)out);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

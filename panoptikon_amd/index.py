@@ -143,6 +143,25 @@ class VectorIndex:
             raise ValueError("rows must be [n][dim]")
         L.check(L.lib().pvs_index_add_f32(self._h, _ptr(rows), rows.shape[0], _ptr(ids), _ptr(grp), L.HOST))
 
+    def remove_rows(self, row_ids) -> int:
+        """pvs_index_remove_rows: the rows with these ids leave the index (compacted on the device); returns how many went."""
+        ids = np.ascontiguousarray(row_ids, np.int64).ravel()
+        out = C.c_uint64(0)
+        L.check(L.lib().pvs_index_remove_rows(self._h, _ptr(ids) if ids.size else None, int(ids.size), C.byref(out)))
+        return int(out.value)
+
+    def replace_rows(self, rows, row_ids):
+        """pvs_index_replace_rows[_f32]: new vectors for rows the index already holds (f32 rows are converted like add_f32)."""
+        ids = np.ascontiguousarray(row_ids, np.int64).ravel()
+        rows = np.ascontiguousarray(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim or rows.shape[0] != ids.size:
+            raise ValueError("rows must be [len(row_ids)][dim]")
+        if rows.dtype == np.float32 and self.dtype != L.F32:
+            L.check(L.lib().pvs_index_replace_rows_f32(self._h, _ptr(rows), rows.shape[0], _ptr(ids), L.HOST))
+        else:
+            rows = np.ascontiguousarray(rows, _NP[self.dtype])
+            L.check(L.lib().pvs_index_replace_rows(self._h, _ptr(rows), rows.shape[0], _ptr(ids), L.HOST))
+
     # ----------------------------------------------------------- query side
     def _queries(self, queries):
         q = np.ascontiguousarray(queries)

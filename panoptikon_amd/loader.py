@@ -332,6 +332,61 @@ def append_new_rows(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Seq
     return li.rows - before
 
 
+def reconcile_deletions(conn: sqlite3.Connection, li: LoadedIndex, setter_names: Sequence[str]) -> Optional[int]:
+    """After an epoch bump whose prefix check failed: if what changed is that rows the index holds are GONE from the database
+    (`embeddings ... ON DELETE CASCADE` when a file disappears: migrations/index/20250117193000_init.sql:29-33, db/files.rs:175-192),
+    remove exactly those rows from the device index (pvs_index_remove_rows: compaction in HBM, milliseconds) instead of reloading
+    everything from SQLite.  Returns the number of rows removed, or None when the change is not of that kind and the caller must
+    rebuild.
+
+    Safe against reused ids (`item_data.id` is not AUTOINCREMENT, see _prefix_intact): an ANCHOR is needed — the newest row of the
+    loaded tail window that is still in the database with the same (id, item_id, payload crc).  Ids at or below the anchor were never
+    reused (a reused id is larger than every id that survived), so a loaded id at or below it is either still there, unchanged, or
+    gone; loaded rows ABOVE the anchor are dropped too (whatever sits at those ids now is new content: append_new_rows brings it in).
+    No anchor in the window, or an id at or below the anchor that the index never held: rebuild."""
+    sids = _existing_setter_ids(conn, setter_names)
+    if not sids or not li.tail:
+        return None
+    marks = ",".join("?" * len(sids))
+    if li.kind == "exact":
+        frm = (f"FROM item_data d JOIN embeddings e ON e.id = d.id WHERE d.setter_id IN ({marks}) AND d.id <= ? "
+               f"AND length(e.embedding) = ?")
+        args = [*sids, li.last_id, li.dim * 4]
+        payload = "e.embedding"
+    else:
+        frm = (f"FROM vector_quant_coverage c JOIN item_data d ON d.setter_id = c.setter_id "
+               f"JOIN embedding_quants q ON q.id = d.id AND q.profile_id = c.profile_id AND q.rev = c.artifact_rev "
+               f"WHERE c.profile_id = ? AND c.setter_id IN ({marks}) AND d.id <= ? AND length(q.quant) = ?")
+        args = [li.profile_id, *sids, li.last_id, li.dim]
+        payload = "q.quant"
+    now = {int(r[0]): (int(r[1]), zlib.crc32(bytes(r[2]))) for r in
+           conn.execute(f"SELECT d.id, d.item_id, {payload} {frm} AND d.id >= ? ORDER BY d.id", [*args, li.tail[0][0]])}
+    anchor = None
+    for rid, item, crc in reversed(li.tail):
+        if now.get(rid) == (item, crc):
+            anchor = rid
+            break
+    if anchor is None:
+        return None
+    current = np.fromiter((int(r[0]) for r in conn.execute(f"SELECT d.id {frm} AND d.id <= ? ORDER BY d.id", [*args, anchor])), np.int64)
+    loaded, groups = li.index.read_ids(0, li.rows, groups=True)
+    keep = np.isin(loaded, current, assume_unique=True) & (loaded <= anchor)
+    if int(keep.sum()) != len(current):  # a row at or below the anchor that the index never held
+        return None
+    gone = loaded[~keep]
+    removed = li.index.remove_rows(gone) if len(gone) else 0
+    if removed != len(gone):
+        return None
+    # the fingerprint of what is left
+    li.rows = int(keep.sum())
+    li.last_id = int(anchor)
+    li.sum_id = int(np.sum(loaded[keep] & _FP_MASK, dtype=np.int64))
+    li.sum_item = int(np.sum(groups[keep] & _FP_MASK, dtype=np.int64))
+    li.tail = [(int(r[0]), int(r[1]), zlib.crc32(bytes(r[2]))) for r in conn.execute(
+        f"SELECT d.id, d.item_id, {payload} {frm} AND d.id <= ? ORDER BY d.id DESC LIMIT {TAIL_WINDOW}", [*args, anchor])][::-1]
+    return removed
+
+
 class IndexCache:
     """Device indexes keyed by what makes them stale.  ``epoch`` is the host's index epoch for the database
     (db/epochs.rs:38-46: bumped by every index-DB write); quant indexes additionally key on the coverage
@@ -359,6 +414,10 @@ class IndexCache:
                 pair = resolve_ready_pair(conn, profile_name, names)
                 still_ok = pair is not None and np.float32(pair.scale) == np.float32(hit[1].scale) and pair.dim == hit[1].dim
             if still_ok and append_new_rows(conn, hit[1], names) is not None:
+                self._items[key] = (epoch, hit[1])
+                return hit[1]
+            # rows the index holds were deleted: take exactly those out of HBM, then append what is new
+            if still_ok and reconcile_deletions(conn, hit[1], names) is not None and append_new_rows(conn, hit[1], names) is not None:
                 self._items[key] = (epoch, hit[1])
                 return hit[1]
         # absent, or the loaded prefix changed: drop every entry of this (database, kind, setters) and rebuild

@@ -175,20 +175,30 @@ def test_loaded_indexes_answer_like_the_oracle_and_follow_the_epoch():
     assert ex2 is ex and ex2.rows == len(good) + 1, "an intact prefix is appended to, not rebuilt"
     gi, gd, gc = ex2.index.search(q[:1], 1, pvs.L2)
     assert gi[0, 0] == 99999 and gd[0, 0] == 0.0
-    # a row the index holds disappears (ON DELETE CASCADE of an item): the prefix changed -> rebuild
+    # a row the index holds disappears (ON DELETE CASCADE of an item): exactly that row leaves the device index (round 5:
+    # pvs_index_remove_rows; until then: a rebuild from SQLite)
     victim = int(ids[5])
     conn.execute("DELETE FROM embeddings WHERE id = ?", (victim,))
     conn.execute("DELETE FROM item_data WHERE id = ?", (victim,))
     ex3 = cache.get(conn, "idx", 2, names)
-    assert ex3 is not ex and ex3.rows == len(good)
+    assert ex3 is ex and ex3.rows == len(good), "a deletion is applied in place"
     gi, gd, gc = ex3.index.search(rows[5:6], 3, pvs.L2)
     assert victim not in gi[0]
+    keep = ids != victim
+    ei, ed = orc.search(orc.F32, orc.L2, np.concatenate([rows[keep], q[:1]]), q, 10, ids=np.concatenate([ids[keep], [99999]]))
+    gi, gd, gc = ex3.index.search(q, 10, pvs.L2)
+    assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+    assert cache.get(conn, "idx", 2, names) is ex3 and loader._prefix_intact(conn, ex3, names)
     # the quant index follows: one more code row at the current revision is appended
     conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (99999, 5, 2, ?)",
                  (orc.quantize_int8(q[:1], scale)[0].tobytes(),))
     conn.execute("DELETE FROM embedding_quants WHERE id = ?", (victim,))
     qu2 = cache.get(conn, "idx", 2, names, profile_name="int8")
-    assert qu2 is not qu and qu2.rows == len(good)  # victim gone (rebuild), new row present
+    assert qu2 is qu and qu2.rows == len(good)  # victim gone (removed in place), new row present (appended)
+    gi, gd, gc = qu2.index.search(q, 10, pvs.COSINE)
+    ei, ed = orc.search(orc.I8, orc.COSINE, np.concatenate([codes[keep], orc.quantize_int8(q[:1], scale)]), orc.quantize_int8(q, scale), 10,
+                        ids=np.concatenate([ids[keep], [99999]]))
+    assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
     conn.execute("INSERT INTO item_data (id, item_id, setter_id, data_type, idx) VALUES (100001, 2, 1, 'clip', 2)")
     conn.execute("INSERT INTO embeddings (id, embedding) VALUES (100001, ?)", (q[1].astype('<f4').tobytes(),))
     conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (100001, 5, 2, ?)",
@@ -296,8 +306,20 @@ class _StubIndex:
 
     def add_f32(self, mat, row_ids=None, group_ids=None):
         self.ids += list(map(int, row_ids))
+        self.grp = getattr(self, "grp", []) + list(map(int, group_ids))
 
     add = add_f32
+
+    def read_ids(self, row0=0, n=None, groups=False):
+        ids, grp = np.array(self.ids, np.int64), np.array(self.grp, np.int64)
+        return (ids, grp) if groups else ids
+
+    def remove_rows(self, row_ids):
+        gone = set(map(int, row_ids))
+        keep = [i for i, r in enumerate(self.ids) if r not in gone]
+        removed = len(self.ids) - len(keep)
+        self.ids, self.grp = [self.ids[i] for i in keep], [self.grp[i] for i in keep]
+        return removed
 
     def close(self):
         pass
@@ -344,6 +366,47 @@ def test_reused_rowids_force_a_rebuild(monkeypatch):
         assert loader.append_new_rows(conn, li0, names) is None, f"{kind}: another item under a reused id"
         monkeypatch.undo()
         monkeypatch.setattr(pvs_index, "VectorIndex", _StubIndex)
+        conn.execute("ROLLBACK TO t")
+        conn.execute("RELEASE t")
+
+
+def test_deletions_are_reconciled_in_place_and_reused_ids_come_back_as_new_rows(monkeypatch):
+    """loader.reconcile_deletions (round 5): rows deleted from the database leave the loaded index one by one; an id that was deleted
+    and handed out again (item_data.id is not AUTOINCREMENT) sits ABOVE the anchor — the newest loaded row that is still there
+    unchanged — so its old row is dropped and append_new_rows brings the new content in; no anchor in the tail window: rebuild."""
+    from panoptikon_amd import index as pvs_index
+    from panoptikon_amd import loader
+
+    monkeypatch.setattr(pvs_index, "VectorIndex", _StubIndex)
+    conn, good, scale, codes = build_db(ragged=False)
+    names = ["clip/m", "tclip/m"]
+    for kind in ("exact", "quant"):
+        li = loader.load_exact_index(conn, names) if kind == "exact" else loader.load_quant_index(conn, "int8", names)
+        all_ids = [m[0] for m in good]
+        conn.execute("SAVEPOINT t")
+        # three scattered rows and the newest row go; the newest id is handed out again with another payload
+        victims = [all_ids[3], all_ids[40], all_ids[41], all_ids[-1]]
+        for v in victims:
+            conn.execute("DELETE FROM embeddings WHERE id = ?", (v,))
+            conn.execute("DELETE FROM embedding_quants WHERE id = ?", (v,))
+            conn.execute("DELETE FROM item_data WHERE id = ?", (v,))
+        cur = conn.execute("INSERT INTO item_data (item_id, setter_id, data_type, idx) VALUES (?, ?, 'clip', 0)", (good[-1][1], good[-1][2]))
+        assert cur.lastrowid == all_ids[-1]
+        vec = -good[-1][3]
+        conn.execute("INSERT INTO embeddings (id, embedding) VALUES (?, ?)", (all_ids[-1], vec.astype("<f4").tobytes()))
+        conn.execute("INSERT INTO embedding_quants (id, profile_id, rev, quant) VALUES (?, 5, 2, ?)",
+                     (all_ids[-1], orc.quantize_int8(vec[None, :], scale)[0].tobytes()))
+        assert loader.append_new_rows(conn, li, names) is None
+        assert loader.reconcile_deletions(conn, li, names) == 4, kind  # (the reused id's OLD row goes too)
+        assert li.index.ids == [i for i in all_ids if i not in victims] and li.last_id == all_ids[-2]
+        assert loader.append_new_rows(conn, li, names) == 1 and li.index.ids[-1] == all_ids[-1]
+        assert loader._prefix_intact(conn, li, names) and li.rows == len(good) - 3
+        # every row of the tail window gone: no anchor, the caller rebuilds
+        for v in [t[0] for t in li.tail]:
+            conn.execute("DELETE FROM embeddings WHERE id = ?", (v,))
+            conn.execute("DELETE FROM embedding_quants WHERE id = ?", (v,))
+            conn.execute("DELETE FROM item_data WHERE id = ?", (v,))
+        assert loader.reconcile_deletions(conn, li, names) is None
         conn.execute("ROLLBACK TO t")
         conn.execute("RELEASE t")
 
