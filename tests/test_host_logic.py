@@ -33,6 +33,57 @@ def test_abi_exports_every_declared_symbol():
     assert "oracle" not in deps and "torch" not in deps
 
 
+def test_abi_layout_manifest_matches_the_headers_the_ctypes_mirrors_and_the_rust_stubs():
+    """include/abi_layout.txt (tools/abi_layout.py: sizeof / offsetof of every struct that crosses the C ABI, printed by a C program
+    compiled against the headers) is current; the ctypes mirrors lay their fields out identically; the `#[repr(C)]` stubs of
+    INTEGRATION.md — the binding a Rust host would add (the reference declares its native dependency's layouts by hand too,
+    db/sql_functions.rs:83-128) — produce the same offsets under Rust's repr(C) rules."""
+    import ctypes as C
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_layout
+
+    fresh = abi_layout.generate()
+    committed = open(abi_layout.MANIFEST).read()
+    assert fresh == committed, "include/abi_layout.txt is stale: python tools/abi_layout.py --write"
+    man = abi_layout.parse_manifest(committed)
+    for name in ("pvs_index_desc", "pvs_stats", "pvs_profile", "pvs_similar_opts", "pvs_rrf_branch", "pvs_ready_pair", "pvs_quant_resolved",
+                 "pvs_microbench_result", "pvs_sqlite_api", "pvs_sqlite_load_result", "pvs_sqlite_backfill_result"):
+        assert name in man and man[name]["fields"], name
+    # ctypes mirrors (panoptikon_amd/_lib.py)
+    mirrors = {"pvs_index_desc": L.IndexDesc, "pvs_stats": L.Stats, "pvs_profile": L.Profile, "pvs_similar_opts": L.SimilarOpts,
+               "pvs_rrf_branch": L.RrfBranch, "pvs_ready_pair": L.ReadyPair, "pvs_quant_resolved": L.QuantResolved,
+               "pvs_microbench_result": L.MicrobenchResult}
+    for name, cls in mirrors.items():
+        assert C.sizeof(cls) == man[name]["size"], name
+        got = [(f, getattr(cls, f).offset, getattr(cls, f).size) for f, _ in cls._fields_]
+        assert got == man[name]["fields"], (name, got, man[name]["fields"])
+    # the Rust stubs: repr(C) = C's rules (each field at the next multiple of its alignment, the struct padded to its largest)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    width = {"u8": 1, "i8": 1, "u32": 4, "i32": 4, "f32": 4, "u64": 8, "i64": 8, "f64": 8, "usize": 8}
+    rust_to_c = {"PvsIndexDesc": "pvs_index_desc", "PvsStats": "pvs_stats", "PvsProfile": "pvs_profile", "PvsSimilarOpts": "pvs_similar_opts",
+                 "PvsRrfBranch": "pvs_rrf_branch", "PvsReadyPair": "pvs_ready_pair", "PvsQuantResolved": "pvs_quant_resolved"}
+    seen = set()
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        rname, body = m.group(1), m.group(2)
+        if rname not in rust_to_c:
+            continue  # (opaque handles)
+        seen.add(rname)
+        off, align_max, fields = 0, 1, []
+        for decl in [d for d in re.split(r",(?![^<(]*[>)])", body) if ":" in d]:
+            fname, ftype = [x.strip() for x in decl.split(":", 1)]
+            size = 8 if ftype.startswith(("*", "Option<")) else width[ftype]
+            off = (off + size - 1) // size * size
+            fields.append((fname, off, size))
+            off += size
+            align_max = max(align_max, size)
+        total = (off + align_max - 1) // align_max * align_max
+        c = man[rust_to_c[rname]]
+        assert fields == c["fields"] and total == c["size"], (rname, fields, c)
+    assert seen == set(rust_to_c), f"INTEGRATION.md lacks the stubs {sorted(set(rust_to_c) - seen)}"
+
+
 def test_product_fails_loudly_without_a_gpu():
     if pvs.device_count() > 0:
         pytest.skip("a GPU is present")
