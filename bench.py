@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E datasheet (MI355X_MICROARCH.md)
 I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA, datasheet (2x the 2.5 PF bf16 dense peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0
+NOMINAL_SCLK_MHZ = 2400.0   # the shader clock the datasheet peaks are quoted at
 SEED_CORPUS = 20260928
 SEED_QUERY = 0x5EED0000
 
@@ -659,6 +660,10 @@ def main():
             roofline["under_load"] = sample_clock_and_power(lambda i: step(i), drain, seconds=1.5)
         except Exception as e:  # noqa: BLE001
             roofline["under_load"] = {"error": str(e)}
+        ul = roofline["under_load"]
+        if ul.get("sclk_mhz") and prof.scan_launches:
+            roofline["power"] = {"sclk_mhz": ul["sclk_mhz"], "socket_power_w": ul["socket_power_w"], "nominal_sclk_mhz": NOMINAL_SCLK_MHZ,
+                                 "mfma_frac_of_clock_scaled_peak": round(roofline["mfma"]["frac"] * NOMINAL_SCLK_MHZ / ul["sclk_mhz"], 4)}
     if not args.no_peaks and rank == 0 and hasattr(lib, "pvs_microbench"):
         try:
             roofline["measured_peaks"] = pvs.microbench(device)
@@ -680,7 +685,7 @@ def main():
     }
 
     # ------------------------------------------------- the north star's other two shapes (own timed regions, headline fields untouched)
-    def timed_region(ixh, dt_name, b, steps, warmup, K=K):
+    def timed_region(ixh, dt_name, b, steps, warmup, K=K, load_sample=False):
         """`steps` batches of b queries through pvs_search_device on index ixh (one stream), kernel durations from HIP events in the
         timed region: the same measurement as the headline's, as one self-contained record."""
         esz2 = {"i8": 1, "f16": 2, "f32": 4}[dt_name]
@@ -717,10 +722,27 @@ def main():
         gbs = by / (sms * 1e-3) / 1e9 if p.scan_launches else 0.0
         ops = 2.0 * nrows * D * b
         pk = I8_MFMA_PEAK_TOPS if dt_name == "i8" else F16_MFMA_PEAK_TFLOPS
+        under = None
+        if load_sample and not args.no_peaks:
+            # the clock and the socket power the part holds under THIS region's loop (the 256-query pass sits at the board power
+            # limit): untimed, the same searches loop for ~1.5 s while rocm-smi is polled from a side thread
+            def drain2():
+                while pend:
+                    ixh.wait(pend.pop(0))
+            try:
+                under = sample_clock_and_power(one, drain2, seconds=1.5)
+            except Exception as e:  # noqa: BLE001
+                under = {"error": str(e)}
         for bufs in o:
             for x in bufs:
                 x.free()
         qb.free()
+        power = None
+        if under and under.get("sclk_mhz"):
+            # achieved / (peak x sclk / 2400 MHz): how much of what the matrix cores (or, for an HBM-bound kernel, nothing: HBM does
+            # not follow sclk) could do AT THE CLOCK THE BOARD HOLDS under this load
+            power = {"sclk_mhz": under["sclk_mhz"], "socket_power_w": under["socket_power_w"], "nominal_sclk_mhz": NOMINAL_SCLK_MHZ,
+                     "mfma_frac_of_clock_scaled_peak": round(ops / (sms * 1e-3) / 1e12 / (pk * under["sclk_mhz"] / NOMINAL_SCLK_MHZ), 4) if p.scan_launches else 0.0}
         return {"config": {"workload": f"{nrows}x{D} {dt_name} corpus, batch {b}, {args.metric}, k={K}", "rows": nrows, "dim": D, "batch": b, "k": K},
                 "metric": "knn_queries_per_sec", "value": round(steps * b / el, 1), "unit": "queries/s", "steps": steps, "warmup": warmup,
                 "ms_per_step": round(el / steps * 1e3, 4), "dtype": dt_name, "data": "synthetic",
@@ -728,7 +750,8 @@ def main():
                              "kernel": (lambda nm: nm if nm.startswith("k_direct_topk") else nm + " (pass B, filter scan)")(ixh.scan_kernel_name(b)), "launches": int(p.scan_launches), "avg_launch_ms": round(sms, 4),
                              "algorithmic_bytes_per_launch": int(by), "kernel_events": "timed region",
                              "mfma": {"achieved": round(ops / (sms * 1e-3) / 1e12, 1) if p.scan_launches else 0.0, "peak": pk,
-                                      "unit": "TOP/s" if dt_name == "i8" else "TFLOP/s", "frac": round(ops / (sms * 1e-3) / 1e12 / pk, 4) if p.scan_launches else 0.0}},
+                                      "unit": "TOP/s" if dt_name == "i8" else "TFLOP/s", "frac": round(ops / (sms * 1e-3) / 1e12 / pk, 4) if p.scan_launches else 0.0},
+                             **({"under_load": under} if under else {}), **({"power": power} if power else {})},
                 "path": {"fast_queries": int(st2.fast_queries), "dense_queries": int(st2.dense_queries)}}
 
     secondary = []
@@ -737,7 +760,7 @@ def main():
     if want_secondary:
         try:
             # (b) 256 int8 queries per pass over the same corpus: the configuration the int8 MFMA target is reachable on
-            rec = timed_region(ix, "i8", 256, 20, 3)
+            rec = timed_region(ix, "i8", 256, 20, 3, load_sample=True)
             rec["what"] = "north-star MFMA target shape: 256 int8 queries per corpus pass (k_scan_wide, one workgroup per CU)"
             secondary.append(rec)
             # (a) single query over 10M x 768 f16: the north star's >= 70 % of HBM target
@@ -753,7 +776,7 @@ def main():
                     ix16.add_f32((st16, m))
                 st16.free()
                 ix16.sync()
-                rec = timed_region(ix16, "f16", 1, 30, 3)
+                rec = timed_region(ix16, "f16", 1, 30, 3, load_sample=True)
                 rec["what"] = "north-star HBM target shape: single query over 10M x 768 f16 (>= 70 % of the HBM roofline asked)"
                 rec["build_seconds"] = round(time.time() - t_b, 1)
                 if not args.no_verify:  # the page of the timed query against the device's dense path (the reference's algorithm in HBM)
@@ -767,6 +790,21 @@ def main():
                     di2, dd2, dc2 = ix16.search(qf, K, metric)
                     ix16.set_path(0)
                     rec["parity"] = {"filter_path_equals_device_dense_path": bool(np.array_equal(fi, di2) and np.array_equal(fd.view(np.uint32), dd2.view(np.uint32)))}
+                    # ... and against the CPU oracle over all 10M rows (read back from HBM chunk by chunk, widened f16 -> f32 as the
+                    # oracle scores them)
+                    import oracle as orc_h
+
+                    t_o = time.time()
+                    thr_h = min(os.cpu_count() or 1, 256)
+                    oi = np.empty(0, np.int64)
+                    od = np.empty(0, np.float32)
+                    omet_h = orc_h.COSINE if metric == pvs.COSINE else orc_h.L2
+                    for off in range(0, N, args.chunk_rows):
+                        m = min(args.chunk_rows, N - off)
+                        ci, cd = orc_h.search(orc_h.F16, omet_h, ix16.read_rows(off, m), qf, K, ids=np.arange(off, off + m, dtype=np.int64), threads=thr_h)
+                        oi, od = orc_h.topk(np.concatenate([od, cd[0]]), K, ids=np.concatenate([oi, ci[0]]))
+                    rec["parity"].update({"oracle_rows": N, "oracle_threads": thr_h, "oracle_seconds": round(time.time() - t_o, 1),
+                                          "ids_and_distances_bit_exact": bool(np.array_equal(fi[0, :K], oi) and np.array_equal(fd[0, :K].view(np.uint32), od.view(np.uint32)))})
                 secondary.append(rec)
                 ix16.close()
             # (c) the reference's own shape: ONE query (its API answers one per request, api/search.rs:524-694), a page of 10 rows
@@ -804,6 +842,32 @@ def main():
                 rows_r = ixr.read_rows(0, n_ref)
                 ei_r, ed_r = orc_r.search(orc_r.I8, orc_r.COSINE if metric == pvs.COSINE else orc_r.L2, rows_r, orc_r.quantize_int8(qf, scale), k_ref, threads=min(os.cpu_count() or 1, 64))
                 rec["parity"] = {"oracle_rows": n_ref, "ids_and_distances_bit_exact": bool(np.array_equal(hi_[0, :k_ref], ei_r[0]) and np.array_equal(hd_[0, :k_ref].view(np.uint32), ed_r[0].view(np.uint32)))}
+            secondary.append(rec)
+            lat1 = rec["pvs_search_latency_ms"]["p50"]
+            # (d) a FEW queries at that scale — a PQL `or` of vector filters over one space (pql/builder.rs:638-661), callers that
+            # arrive together (16 read connections, db/connection.rs:235): four queries share the one launch (round 5)
+            rec = timed_region(ixr, "i8", 4, 200, 10, K=k_ref)
+            rec["what"] = "a few queries at the reference's scale: four queries, pages of 10, 690k x 768 int8, ONE launch (k_direct_topk, 4-query instance)"
+            qf4 = np.empty((4, D), np.float32)
+            qtmp = pvs.DeviceBuffer(4 * D * 4, device)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, 4, D, qtmp.ptr))
+            qf4[:] = qtmp.to_numpy(np.float32, (4, D))
+            qtmp.free()
+            for _ in range(10):
+                ixr.search(qf4, k_ref, metric)
+            lat = []
+            for _ in range(300):
+                t_l = time.perf_counter()
+                hi4, hd4, hc4 = ixr.search(qf4, k_ref, metric)
+                lat.append(time.perf_counter() - t_l)
+            lat = np.sort(np.array(lat)) * 1e3
+            rec["pvs_search_latency_ms"] = {"p50": round(float(lat[150]), 4), "p99": round(float(lat[296]), 4), "calls": 300,
+                                            "vs_single_query_p50": round(float(lat[150]) / lat1, 3) if lat1 else None,
+                                            "how": "host-buffer entry point, one caller, four queries per call"}
+            rec["path"]["direct_queries"] = int(pvs.debug_get("direct_queries"))
+            if not args.no_verify:
+                ei4, ed4 = orc_r.search(orc_r.I8, orc_r.COSINE if metric == pvs.COSINE else orc_r.L2, rows_r, orc_r.quantize_int8(qf4, scale), k_ref, threads=min(os.cpu_count() or 1, 64))
+                rec["parity"] = {"oracle_rows": n_ref, "ids_and_distances_bit_exact": bool(np.array_equal(hi4[:, :k_ref], ei4) and np.array_equal(hd4[:, :k_ref].view(np.uint32), ed4.view(np.uint32)))}
             secondary.append(rec)
             ixr.close()
         except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
