@@ -8,11 +8,18 @@ import sys
 import time
 
 
+KERNEL = r"_Z\d+k_scan\w*?ELi1EEv5ScanK\S*"  # k_scan / k_scan_wide, MODE 1 (pass B); --kernel REGEX names another (e.g. k_direct_topk)
+if "--kernel" in sys.argv:
+    i = sys.argv.index("--kernel")
+    KERNEL = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
+
+
 def per_launch(md, counter):
     """sum over the per-XCD/SE slices of one dispatch: avg per slice * slices / launches"""
     best = None
     for line in open(md):
-        m = re.match(r"\| `(_Z\d+k_scan\w*?ELi1EEv5ScanK\S*) grid=(\d+)` \| (\w+) \| (\d+) \| ([\d.e+]+) \| ([\d.e+]+) \|", line)  # k_scan / k_scan_wide, MODE 1
+        m = re.match(r"\| `(" + KERNEL + r") grid=(\d+)` \| (\w+) \| (\d+) \| ([\d.e+]+) \| ([\d.e+]+) \|", line)
         if m and m.group(3) == counter:
             total = float(m.group(6))
             if best is None or total > best[1]:
