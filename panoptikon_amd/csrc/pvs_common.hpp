@@ -126,7 +126,7 @@ static inline uint64_t pvs_round_up(uint64_t v, uint64_t m) { return (v + m - 1)
 // Per-query constants produced by the query-prep kernel and consumed by the
 // scan epilogue / finaliser.  key = monotone surrogate of the reference distance
 // (cosine: -dot/|a| ; L2: |a|^2 + |q|^2 - 2 dot); err = eA + eC*|a| + eR*|a|^2 is a
-// rigorous bound on |key - key_ref|, so [key-err, key+err] brackets
+// rigorous bound on |key - key_ref| (HISTORY.md §4.2), so [key-err, key+err] brackets
 // the value the reference ordering is monotone in.
 struct QInfo {
     float bb;      // sum q_i^2, accumulated sequentially in f32 (the reference's bMag)

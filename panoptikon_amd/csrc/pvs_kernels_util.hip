@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtyp
         qi.dscale = dscale;
         qi.pad0 = 0.f;
         qi.pad1 = 0.f;
-        // Error budget of the scan key: f32 accumulation of K terms is within
+        // Error budget of the scan key (HISTORY.md §4.2): f32 accumulation of K terms is within
         // K*2^-24 of sum|terms| in either evaluation order; an f16 query image adds 2^-11 |a||q|;
         // f32 index: rows narrowed to f16 toward zero after a per-row power-of-two scaling (2^-10, plus sqrt(D) 2^-26 for
         // the components the scaling leaves below the f16 normal range) and the f16 query image (2^-11): 1.5e-3 |a||q|.

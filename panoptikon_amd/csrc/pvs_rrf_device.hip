@@ -1,4 +1,4 @@
-// pvs_rrf_device.hip — one round of the bounded RRF fusion (pvs_items.hip: rrf_bounded) with every step on the
+// pvs_rrf_device.hip — one round of the bounded RRF fusion (pvs_items.hip: rrf_bounded; HISTORY.md §4.4) with every step on the
 // device and ONE synchronisation: the reference's `row_number() OVER (ORDER BY agg)` per branch, UNION, `SUM(w / (k + rank))`,
 // `ORDER BY score DESC LIMIT k` (pql/builder.rs:757-771, 1284-1301) for the files that can reach the page.
 //

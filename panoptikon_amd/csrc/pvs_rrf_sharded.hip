@@ -6,7 +6,7 @@
 // shards a 50M-row space over 8 GPUs (BASELINE configs[4]) calls pvs_rrf_search_sharded on every rank with its shard of each
 // branch; every rank returns the same page, bit for bit the reference's.
 //
-// Protocol (what panoptikon_amd/sharded.py prototyped in Python over a host socket):
+// Protocol (what panoptikon_amd/sharded.py prototyped in Python over a host socket; HISTORY.md §4.4):
 //   thresholds   each shard proposes a window key from a sample; the MINIMUM over shards is used (ncclAllReduce min), so "at or
 //                below T_b" is the same set whichever shard a group lives on, and R_b = the sum of the shards' page sizes is the
 //                number of groups ranked before everything outside the pages;

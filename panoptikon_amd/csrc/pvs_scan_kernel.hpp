@@ -5,7 +5,7 @@
 // Replaces, for a batch of queries, the reference's per-row
 //   vec_distance_{cosine,L2}(payload, ?)          (image_embeddings.rs:321-362,
 //   ... ORDER BY order_rank ASC ... LIMIT k          text_embeddings.rs:386-418, builder.rs:578-582)
-// The reference scores every row and sorts everything.  Here:
+// The reference scores every row and sorts everything.  Here (HISTORY.md §4.1-4.2):
 //   pass A (MODE 0)  scan a strided sample of row tiles, keep per-lane minima of an UPPER
 //           bound of the key -> the k-th smallest of those group minima is a valid upper
 //           bound T of the k-th best key of the whole corpus;
@@ -33,7 +33,7 @@
 // candidate set is exactly what the per-row test alone would emit.  Only wave-tiles where some lane passes run the
 // per-row test, with the row scalars read back from LDS (their ring keeps a tile's scalars one tile longer than its rows).
 //
-// What the measurements say (10M x 768 int8 on MI355X):
+// What the measurements say (10M x 768 int8 on MI355X; HISTORY.md §4.1b, §5):
 //   * 128 queries: 1.25-1.31 ms = 5.9-6.1 TB/s; a pure read stream (plain loads or LDS-DMA, pvs_microbench) reaches 7.1 TB/s on the
 //     box and the 32-query instance 6.7.  The part runs this pass at its 1,400 W limit with the clock lowered: ring depth, prefetch
 //     depth, DMA placement, workgroups per CU and a barrier-free rewrite all measured the same (profiles/r02_tile_phase_profile_b256.txt),
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
             asm volatile("" : "+v"(qi[g].bb), "+v"(qi[g].dscale), "+v"(qi[g].eA), "+v"(qi[g].eR), "+v"(thr[g]));
         }
         wait_vm<0>();
-        // Filter tests folded into one per-lane constant (key/err algebra of DESIGN.md §4.2):
+        // Filter tests folded into one per-lane constant (key/err algebra of HISTORY.md §4.2):
         //   cosine  key = -dscale*acc/|a|, err = eA
         //           pass: key-err <= thr  <=>  acc/|a| >= -(thr+eA)/dscale
         //   L2      key = |a|^2 + bb - 2 dscale acc, err = eA + eR|a|^2
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         // stream never touches; their operands are read at issue (tools/probe/sstore_nowait_test.hip: 84M back-to-back stores
         // with the SGPRs rewritten right behind them), so nothing waits per candidate; s_dcache_wb at the end of the kernel
         // writes the scalar cache back for pass C.  What a candidate costs matters eight-fold: the emitting wave's extra
-        // cycles are what the other waves of the workgroup wait for at the next per-tile barrier (§4.1b of DESIGN.md).
+        // cycles are what the other waves of the workgroup wait for at the next per-tile barrier (§4.1b of HISTORY.md).
         // Two stages, so that the common case — one passing row in one lane — costs one pipelined sweep and one branch chain on
         // SCALAR masks instead of 16 dependent (convert, scale, compare, branch-on-VCC) sequences: stage 1 compares all 16
         // sums with the lane's pre-test bound `eb` (no row scalar, v_cmp straight into an SGPR pair per row); stage 2 runs the

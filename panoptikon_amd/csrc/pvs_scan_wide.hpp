@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void k_scan_wide(ScanK a) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(qi[q].bb), "+v"(qi[q].dscale), "+v"(qi[q].eA), "+v"(qi[q].eR), "+v"(thr[q]));
         wait_vm<0>();
-        // Filter test folded into per-lane constants (key / err algebra of DESIGN.md §4.2, as in k_scan):
+        // Filter test folded into per-lane constants (key / err algebra of HISTORY.md §4.2, as in k_scan):
         //   cosine  pass iff d * (1/|a|) >= tS              tS = -(thr + eA) / dscale
         //   L2      pass iff c1 |a|^2 + m2d d <= tS         tS = thr + eA - bb, c1 = 1 - eR, m2d = -2 dscale
         // and the necessary condition on d alone from the tile's extreme row scalars (t0 = min, t1 = max of |a| resp. |a|^2):

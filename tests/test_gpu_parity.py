@@ -1137,6 +1137,15 @@ def test_full_size_properties(pvs, dtype, n, b):
             ei, ed = orc.search(odt, omet, slab, q[which], k, threads=orc.max_threads())
             for t, qi in enumerate(which):
                 assert np.array_equal(gi[qi], ei[t]) and np.array_equal(gd[qi].view(np.uint32), ed[t].view(np.uint32)), f"{dtype} query {qi} vs the oracle over {n} rows"
+        if dt == pvs.F16 and n == 10_000_000 and metric == pvs.COSINE:
+            # the north star's HBM shape (one query over 10M x 768 f16) against the CPU oracle over the WHOLE corpus, chunk by chunk
+            # (round 5: until then this shape was checked against the device's dense path only)
+            acc_i, acc_d = np.empty(0, np.int64), np.empty(0, np.float32)
+            for off in range(0, n, 1_000_000):
+                ci, cd = orc.search(orc.F16, orc.COSINE, ix.read_rows(off, 1_000_000), q[:1], k, ids=np.arange(off, off + 1_000_000, dtype=np.int64),
+                                    threads=orc.max_threads())
+                acc_i, acc_d = orc.topk(np.concatenate([acc_d, cd[0]]), k, ids=np.concatenate([acc_i, ci[0]]))
+            assert np.array_equal(gi[0], acc_i) and np.array_equal(gd[0].view(np.uint32), acc_d.view(np.uint32)), f"f16 single query vs the oracle over {n} rows"
     # row shards of the same corpus, merged: equals the whole-corpus page (ids are global row indexes)
     nq = min(16, b)
     gi, gd, gc = ix.search(q[:nq], k, pvs.COSINE)
@@ -1277,7 +1286,7 @@ def test_near_tied_scores_with_coherent_rounding(pvs, dtype):
     component and every query component is positive, so the narrowing errors of a row all push its dot product the
     same way, and thousands of rows score within 1e-4 of each other — a page is exact only if the interval the
     filter puts around its key really contains the error (checked by hand: with the f32 bound set 30x too small this
-    test fails; the factor-of-two questions are settled by the analysis in DESIGN.md, not by tests)."""
+    test fails; the factor-of-two questions are settled by the analysis in HISTORY.md §4.2, not by tests)."""
     dt = pvs.F16 if dtype == "f16" else pvs.F32
     rng = np.random.default_rng(53)
     n, dim, k = 12000, 384, 60  # (a row pitch both dtypes have a scan instance for)

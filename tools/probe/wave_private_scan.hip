@@ -1,4 +1,4 @@
-// Probe for a barrier-free filter scan: every wave owns its stream of 32-row tiles, the corpus is stored
+// Probe for a barrier-free filter scan (HISTORY.md §9): every wave owns its stream of 32-row tiles, the corpus is stored
 // "fragment-linear" (one contiguous KiB per MFMA step: 64 lanes x 16 B, lane l = h*32 + row), A fragments go straight from HBM into
 // registers (double-buffered: the next tile is in flight while the current one is multiplied), the B fragments of 128 queries sit
 // read-only in LDS (96 KB), four accumulator chains per wave, no s_barrier after the prologue.  The epilogue is the v_max3 fold
