@@ -81,6 +81,8 @@ enum PvsDbg {
     PVS_DBG_DIRECT_UNIT,           // one-launch search: 64-row pairs per work unit (0: >= 48 KB of rows)
     PVS_DBG_DIRECT_STATIC_PCT,     // ... share of a wave's units that is dealt instead of dequeued, in percent (0: 50; 100: round 4's dealing; -1: one dealt unit)
     PVS_DBG_DIRECT_MAX_NQ,         // ... at most this many queries per launch (0: what the instance table takes; 1: round 4's single-query form only)
+    PVS_DBG_DENSE_FULL_SORT,       // dense path: always sort every row (the form before the page-first threshold, round 5)
+    PVS_DBG_DENSE_PAGE_FIRST,      // (a counter) dense pages answered by the sampled threshold + a sort of the admitted rows
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

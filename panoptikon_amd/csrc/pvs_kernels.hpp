@@ -189,10 +189,16 @@ hipError_t pvs_launch_finalize(const FinalizeArgs &a, hipStream_t s);
 // ---- dense score + sort (pvs_dense.hip)
 struct DenseWork {
     float *d_dist = nullptr;       // [n]
-    uint32_t *d_keys_in = nullptr, *d_keys_out = nullptr, *d_vals_in = nullptr, *d_vals_out = nullptr;
+    uint32_t *d_keys_in = nullptr, *d_keys_out = nullptr, *d_vals_in = nullptr, *d_vals_out = nullptr;  // the full sort's buffers (allocated when a page needs it)
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
-    uint64_t cap_rows = 0;
+    uint64_t cap_rows = 0, sort_rows = 0;
+    // page first (round 5): a sampled threshold admits ~1.3 k rows, only those are sorted
+    uint32_t *d_sample = nullptr, *d_sample_out = nullptr, *d_ctl = nullptr, *h_ctl = nullptr;  // ctl: [0] threshold key, [1] admitted rows
+    unsigned long long *d_comp = nullptr, *d_comp_out = nullptr;
+    void *d_temp_page = nullptr;
+    size_t temp_page_bytes = 0;
+    uint32_t comp_cap = 0;
 };
 pvs_status pvs_dense_reserve(DenseWork &w, uint64_t n);
 void pvs_dense_release(DenseWork &w);
