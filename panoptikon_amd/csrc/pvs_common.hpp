@@ -83,6 +83,7 @@ enum PvsDbg {
     PVS_DBG_DIRECT_MAX_NQ,         // ... at most this many queries per launch (0: what the instance table takes; 1: round 4's single-query form only)
     PVS_DBG_DENSE_FULL_SORT,       // dense path: always sort every row (the form before the page-first threshold, round 5)
     PVS_DBG_DENSE_PAGE_FIRST,      // (a counter) dense pages answered by the sampled threshold + a sort of the admitted rows
+    PVS_DBG_NO_FLAG_POLL,          // pvs_search (one-launch route): wait for the stream's completion event instead of polling the kernel's flag words in pinned memory
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

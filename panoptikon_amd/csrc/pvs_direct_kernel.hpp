@@ -1080,8 +1080,14 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
             if (a.h_out_count && !tail) a.h_out_count[q] = kk;
             a.out_count[q] = kk;
             a.need_dense[q] = tail ? 3 : 0;
-            if (a.h_flags) a.h_flags[q] = tail ? 3 : 0;
             if (a.h_seen) a.h_seen[q] = 0;
+        }
+        if (a.h_flags) {
+            // the host polls this query's flag word in pinned memory instead of waiting for the kernel's completion signal: the
+            // page and the count must be visible in host memory before the flag is
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) a.h_flags[q] = tail ? 3 : 0;
         }
     }
     DIR_STAMP(5);

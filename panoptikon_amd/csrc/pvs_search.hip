@@ -796,9 +796,33 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
             uint8_t *io = c->h_io;
             memcpy(io + 64, queries, qbytes * batch);
             PVS_TRY(pvs_ensure_null_rows(ix));
+            // The kernel raises one flag word per query in pinned memory behind a system-scope fence (pages and counts first): the
+            // caller polls those words instead of sleeping on the stream's completion signal — the wake-up through the runtime costs
+            // more than the page's trip over PCIe.  Profiling (event spans) and pvs_debug_set("no_flag_poll", 1) keep the event wait.
+            const bool poll = !ix->profiling && !pvs_dbg(PVS_DBG_NO_FLAG_POLL);
+            volatile uint32_t *hf = c->h_need_dense;
+            if (poll)
+                for (uint32_t q = 0; q < batch; q++) hf[q] = 0xffffffffu;
             PVS_TRY(enqueue_direct(ix, *c, io + 64, qdtype, batch, k, metric, c->d_out_ids, c->d_out_dist, c->d_out_count, io + off_p));
-            HIP_TRY(hipEventRecord(c->done, c->stream));
-            HIP_TRY(hipEventSynchronize(c->done));
+            bool seen = false;
+            if (poll) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint64_t spin = 0;; spin++) {
+                    bool all = true;
+                    for (uint32_t q = 0; q < batch; q++) all = all && hf[q] != 0xffffffffu;
+                    if (all) {
+                        seen = true;
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                    if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;  // (a long search: sleep on the event)
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            if (!seen) {
+                HIP_TRY(hipEventRecord(c->done, c->stream));
+                HIP_TRY(hipEventSynchronize(c->done));
+            }
             spans_collect(ix, *c);
             bool complete = true;
             for (uint32_t q = 0; q < batch; q++) complete = complete && c->h_need_dense[q] == 0;
