@@ -23,7 +23,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = [
     "pvs_api.hip",
     "pvs_search.hip",
+    "pvs_search_host.hip",
+    "pvs_search_device.hip",
     "pvs_items.hip",
+    "pvs_rrf_search.hip",
+    "pvs_similar.hip",
     "pvs_kernels_util.hip",
     "pvs_kernels_scan.hip",
     "pvs_scan_i8.hip",

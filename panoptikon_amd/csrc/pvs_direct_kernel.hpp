@@ -1083,8 +1083,9 @@ __global__ __launch_bounds__(256, 1) void k_direct_topk(DirectK a) {
             if (a.h_seen) a.h_seen[q] = 0;
         }
         if (a.h_flags) {
-            // the host polls this query's flag word in pinned memory instead of waiting for the kernel's completion signal: the
-            // page and the count must be visible in host memory before the flag is
+            // the host polls this query's flag word in pinned memory instead of waiting for the kernel's completion signal; the fence
+            // puts the page in front of the flag as far as this stack honours it — the host checks every word of the page itself
+            // (search_host: poisoned words), so a late line delays the caller, never misleads it
             __threadfence_system();
             __syncthreads();
             if (tid == 0) a.h_flags[q] = tail ? 3 : 0;

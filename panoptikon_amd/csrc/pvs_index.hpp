@@ -262,6 +262,16 @@ bool span_bound(pvs_index *ix, SearchCtx &c, int kind, uint64_t rows, hipEvent_t
 void spans_collect(pvs_index *ix, SearchCtx &c);
 pvs_status ctx_prepare(pvs_index *ix, SearchCtx &c, uint32_t batch, uint32_t k, bool host_outputs);
 pvs_status ctx_fin_buffers(SearchCtx &c);  // the LDS-light pass C's work area, on first use
+// ---- pvs_search.hip (shared with pvs_search_host.hip / pvs_search_device.hip)
+// the tie order of the second sort key, when it covers the index's rows (pvs_index_set_order_keys)
+static inline const uint32_t *order_tinv(const pvs_index *ix) { return ix->order_rows == ix->n && ix->n ? ix->d_tinv : nullptr; }
+// one query through the dense path; q is the query's index inside the current chunk
+pvs_status dense_one(pvs_index *ix, SearchCtx &c, uint32_t q, uint32_t k, int metric, int64_t *out_ids, float *out_dist, uint32_t *out_count,
+                     DenseBounds bounds = DenseBounds());
+bool direct_ok(const pvs_index *ix, const SearchCtx &c, uint32_t batch, uint32_t k);
+// h_page: the context's pinned block for the pages [ids | distances | counts (64 B) | stored rows], or nullptr
+pvs_status enqueue_direct(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int64_t *oid, float *od,
+                          uint32_t *oc, uint8_t *h_page = nullptr);
 void ctx_release(SearchCtx &c);
 pvs_status ctx_pinned_io(SearchCtx &c, size_t bytes);  // c.h_io holds >= bytes afterwards (contents are not preserved when it grows)
 // ---- pvs_search.hip
@@ -309,6 +319,10 @@ pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries,
                              uint32_t m, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 // ---- pvs_items.hip
 pvs_status ensure_groups(pvs_index *ix);
+// d_m [n][nb] distances -> per-group aggregates -> the page (fanout != 0: ONE output column over all nb target vectors: similar_to)
+pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uint32_t nb, uint32_t fanout, int agg, const float *d_weights,
+                              const uint8_t *d_exclude, uint32_t k, int64_t *out_groups, double *out_values, uint32_t *out_count,
+                              FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1);
 // d_out[row * nb + q]: exact distances of the nb queries prepared in ctx c (prep_chunk) — matrix cores for int8, k_dense_exact otherwise
 // h_flag (optional): a pinned, device-mapped word — the int8 scorers raise it instead of the context's device word and the call does
 // not wait for them (the caller looks at it after its own synchronisation and, if raised, calls again with inorder_only)
