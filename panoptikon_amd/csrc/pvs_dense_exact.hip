@@ -35,6 +35,10 @@ struct DenseK {
     float *out;  // out[row * out_ld + out_col + q]
     uint64_t n_rows;
     uint32_t stride, kslabs, qpad_ld, out_ld, out_col, n_pairs, n_waves;
+    // work distribution (round 5, as k_direct_topk): units of >= 48 KB of rows, the first static_rounds per wave dealt, the rest
+    // dequeued from four counters (one per wave slot, 256 B apart; zeroed by k_pad_queries in front of every launch)
+    uint32_t *ctr;
+    uint32_t unit, n_units, static_rounds, dyn;
 };
 
 constexpr int DENSE_WAVE_LDS = 2 * 16384;
@@ -75,10 +79,11 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
         }
         __syncthreads();  // the only workgroup barrier
     }
-    const uint32_t gw = blockIdx.x * 4 + wave;  // this wave's first pair of row tiles
-    if (gw >= a.n_pairs) return;
-    const uint32_t my_pairs = (a.n_pairs - gw + a.n_waves - 1) / a.n_waves;
-    const uint32_t n_items = my_pairs * a.kslabs;
+    // Work is dequeued, not dealt (round 5): equal shares end at very different times (690k x 768 int8: 65 / 80 / 117 us min / mean /
+    // max over workgroups for a stream whose bytes take 80) — see pvs_direct_kernel.hpp for the measurements and the reasons behind
+    // the named accumulation registers the asynchronous values live in.
+    const uint32_t gw = blockIdx.x * 4 + wave;
+    if (gw >= a.n_units) return;
     uint8_t *const wbuf = smem + wave * DENSE_WAVE_LDS;
     const uint32_t wlds = lds_addr(wbuf);
     const uint32_t voff = (uint32_t)lane * 16u;
@@ -88,36 +93,78 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
     };
-    uint32_t ip = 0, is = 0;  // issue cursor: pair, k-slab
-    auto issue = [&](uint32_t buf) {
-        const uint64_t pair = gw + (uint64_t)ip * a.n_waves;
-        const uint8_t *bA = uni(a.rows + pair * 64 * a.stride + (uint64_t)is * 8192);  // k-slab of tile 2*pair: 8 KiB contiguous
-        const uint8_t *bB = uni(bA + 32ull * a.stride);                                // ... of tile 2*pair+1
-        const uint32_t dst = wlds + buf * 16384u;
+    uint32_t ipair = 0, iend = 0, islab = 0, round = 0, nxt_unit = 0, issued = 0, consumed = 0, last_pair = 0;
+    bool nxt_ok = false, pending = false, more_dyn = a.dyn != 0;
+    auto unit_range = [&](uint32_t u) {
+        ipair = u * a.unit;
+        iend = min(ipair + a.unit, a.n_pairs);
+        islab = 0;
+    };
+    auto fetch_next = [&]() {
+        round++;
+        if (round < a.static_rounds) {
+            nxt_unit = gw + round * a.n_waves;
+            nxt_ok = nxt_unit < a.n_units;
+        } else if (more_dyn) {
+            if (lane == 0) dequeue_async(a.ctr + 64 * wave);
+            pending = true;
+            nxt_ok = false;
+        } else {
+            nxt_ok = false;
+        }
+    };
+    auto issue_one = [&]() -> bool {
+        if (ipair == iend) {
+            if (!nxt_ok) return false;
+            unit_range(nxt_unit);
+            fetch_next();
+        }
+        const uint8_t *bA = uni(a.rows + (uint64_t)ipair * 64 * a.stride + (uint64_t)islab * 8192);  // k-slab of tile 2*pair: 8 KiB contiguous
+        const uint8_t *bB = uni(bA + 32ull * a.stride);                                                // ... of tile 2*pair+1
+        const uint32_t dst = wlds + (issued & 1u) * 16384u;
 #pragma unroll
         for (int e = 0; e < 8; e++) dma16(bA + e * 1024, voff, dst + e * 1024);
 #pragma unroll
         for (int e = 0; e < 8; e++) dma16(bB + e * 1024, voff, dst + 8192 + e * 1024);
-        if (++is == a.kslabs) {
-            is = 0;
-            ip++;
+        last_pair = ipair;
+        issued++;
+        if (++islab == a.kslabs) {
+            islab = 0;
+            ipair++;
         }
+        return true;
     };
+    unit_range(gw);
+    fetch_next();
+    (void)issue_one();
+    uint32_t cpair = last_pair;
 
-    float acc[NQ];
+    float acc[NQ], bbv[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
+    for (int q = 0; q < NQ; q++) {
+        acc[q] = 0.0f;
+        bbv[q] = a.qinfo[q].bb;  // (read once, in front of the loop: inside it the load waited for the whole prefetched stage, NQ times per pair)
+    }
     v2f acc2[NQ / 2 + 1];
 #pragma unroll
     for (int p = 0; p < NQ / 2; p++) acc2[p] = v2f{0.0f, 0.0f};
     const uint32_t row_in = (uint32_t)(lane >> 5) * 8192u + (uint32_t)(lane & 31) * 256u;
     const uint32_t jx = (uint32_t)lane & 15u;
-    uint32_t cp = 0, cs = 0;  // consume cursor
-    issue(0);
-    for (uint32_t it = 0; it < n_items; it++) {
-        wait_vm<0>();  // item `it` has landed (and nothing else is outstanding)
-        if (it + 1 < n_items) issue((it + 1) & 1u);  // streams in while this item is consumed
-        const uint8_t *tile = wbuf + (it & 1u) * 16384u + row_in;
+    uint32_t cs = 0;
+    while (consumed < issued) {
+        const uint32_t deq = wait_all_and_dequeued();  // the stage has landed (and nothing else is outstanding)
+        if (pending) {
+            const uint32_t u = a.static_rounds * a.n_waves + 4u * (uint32_t)__builtin_amdgcn_readfirstlane((int)deq) + (uint32_t)wave;
+            pending = false;
+            nxt_unit = u;
+            nxt_ok = u < a.n_units;
+            more_dyn = nxt_ok;
+        }
+        const bool last_slab = cs + 1 == a.kslabs;
+        const uint64_t row = (uint64_t)cpair * 64 + (uint32_t)lane;
+        if (METRIC == PVS_COSINE && last_slab && row < a.n_rows) row_scalars_async(a.norm2 + row, nullptr, nullptr);  // (in front of the next stage's DMA)
+        const bool fed = issue_one();  // streams in while this item is consumed
+        const uint8_t *tile = wbuf + (consumed & 1u) * 16384u + row_in;
         const float *q0 = qlds + (size_t)cs * EPS;
         if constexpr (PK) {
             const float *q0p = qlds + (size_t)cs * EPS * 2;
@@ -172,14 +219,21 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
                 }
             }
         }
+        consumed++;
         if (++cs == a.kslabs) {
-            const uint64_t row = (gw + (uint64_t)cp * a.n_waves) * 64 + (uint32_t)lane;
+            uint32_t r_aa = 0, r_1, r_2;
+            if (METRIC == PVS_COSINE) {
+                if (fed)
+                    row_scalars_wait<16>(r_aa, r_1, r_2);
+                else
+                    row_scalars_wait<0>(r_aa, r_1, r_2);
+            }
             if (row < a.n_rows) {
-                const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
+                const float aa = METRIC == PVS_COSINE ? __builtin_bit_cast(float, r_aa) : 0.f;
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const float sum = PK ? acc2[q >> 1][q & 1] : acc[q];
-                    const float d = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, a.qinfo[q].bb) : ref_l2_finish(sum);
+                    const float d = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, bbv[q]) : ref_l2_finish(sum);
                     a.out[row * a.out_ld + a.out_col + q] = d;
                 }
             }
@@ -188,15 +242,16 @@ __global__ __launch_bounds__(256, 1) void k_dense_exact(DenseK a) {
 #pragma unroll
             for (int p = 0; p < NQ / 2; p++) acc2[p] = v2f{0.0f, 0.0f};
             cs = 0;
-            cp++;
+            cpair = last_pair;
         }
     }
     wait_vm<0>();
 }
 
 // [nq][dim] int8 codes or f32 -> [nq][ld] f32, zero padded
-__global__ __launch_bounds__(256) void k_pad_queries(const void *qexact, int is_i8, uint32_t dim, uint32_t ld, float *qpad) {
+__global__ __launch_bounds__(256) void k_pad_queries(const void *qexact, int is_i8, uint32_t dim, uint32_t ld, float *qpad, uint32_t *ctr) {
     const uint32_t q = blockIdx.x;
+    if (q == 0 && threadIdx.x < 4) ctr[64 * threadIdx.x] = 0;  // the dequeue counters of the launch behind this one
     for (uint32_t i = threadIdx.x; i < ld; i += 256) {
         float v = 0.f;
         if (i < dim) v = is_i8 ? (float)((const int8_t *)qexact)[(size_t)q * dim + i] : ((const float *)qexact)[(size_t)q * dim + i];
@@ -232,7 +287,8 @@ hipError_t launch_nq(const DenseK &k, uint32_t nq, int metric, uint32_t grid, hi
 }
 }  // namespace
 
-uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz) { return (uint64_t)PVS_DENSE_NQ * (stride / esz) * 4; }
+static inline uint64_t dense_q_bytes(uint32_t stride, uint32_t esz) { return pvs_round_up((uint64_t)PVS_DENSE_NQ * (stride / esz) * 4, 256); }
+uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz) { return dense_q_bytes(stride, esz) + 1024; }  // the padded queries, then four dequeue counters 256 B apart
 
 hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
@@ -252,6 +308,11 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
     k.n_pairs = (uint32_t)((n + 63) / 64);
     const uint32_t grid = std::min<uint32_t>((k.n_pairs + 3) / 4, std::max<uint32_t>(n_cu, 1));
     k.n_waves = grid * 4;
+    k.ctr = (uint32_t *)((uint8_t *)qpad_scratch + dense_q_bytes(stride, esz));
+    k.unit = std::max<uint32_t>(1, (49152u + 64u * stride - 1) / (64u * stride));
+    k.n_units = (k.n_pairs + k.unit - 1) / k.unit;
+    k.static_rounds = std::max<uint32_t>(1, k.n_units / k.n_waves / 2);
+    k.dyn = (uint64_t)k.static_rounds * k.n_waves < k.n_units ? 1u : 0u;
     const size_t qsz = dtype == PVS_I8 ? 1 : 4;
     for (uint32_t q0 = 0; q0 < nq;) {
         uint32_t g = nq - q0 >= 4 ? 4 : nq - q0 >= 2 ? 2 : 1;
@@ -259,7 +320,7 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
         while (g > 1 && (uint64_t)g * k.qpad_ld * 4 > (uint64_t)DENSE_Q_LDS) g >>= 1;  // queries must fit beside the ring
         if ((uint64_t)g * k.qpad_ld * 4 > (uint64_t)DENSE_Q_LDS) return hipErrorInvalidValue;  // row pitch > 32 KiB (dim > 8192 f32)
         hipLaunchKernelGGL(k_pad_queries, dim3(g), dim3(256), 0, s, (const void *)((const uint8_t *)qexact + (size_t)q0 * dim * qsz),
-                           dtype == PVS_I8 ? 1 : 0, dim, k.qpad_ld, qpad_scratch);
+                           dtype == PVS_I8 ? 1 : 0, dim, k.qpad_ld, qpad_scratch, k.ctr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         k.qinfo = qinfo + q0;

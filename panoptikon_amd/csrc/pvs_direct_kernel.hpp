@@ -128,38 +128,8 @@ __device__ static inline void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Global loads and a returning atomic that the compiler's waitcnt insertion does not see (like the LDS-DMA), so that they can
-// travel IN FRONT of a stage's 16 DMA instructions and be read behind a counted wait: a compiler-visible load there makes hipcc
-// wait for vmcnt(0) — the whole prefetched stage — at the value's first use, and hipcc turns atomicAdd(p, 1) of one lane into a
-// wave-aggregated atomic followed by s_waitcnt vmcnt(0) + v_readfirstlane on the spot (the dequeue's round trip, once per unit).
-// Their destinations are ACCUMULATION registers a250..a255 named in the instructions: an asm output operand in an ordinary VGPR is
-// "defined" for the compiler the moment the asm statement ends, and it is free to copy it (a loop-carried variable, a live-range
-// split) before the data has arrived — the first build of this kernel read stale norms and unit numbers that way.  Nothing else
-// in these kernels comes near a250 (they use at most 60 accumulation registers as spill space); the values are read back with
-// v_accvgpr_read behind the wait, inside the same asm statement.
-__device__ static inline void row_scalars_async(const float *norm2, const uint8_t *mask, const uint32_t *trank) {
-    if (norm2) asm volatile("global_load_dword a250, %0, off" ::"v"(norm2) : "memory", "a250");
-    if (mask) asm volatile("global_load_ubyte a251, %0, off" ::"v"(mask) : "memory", "a251");
-    if (trank) asm volatile("global_load_dword a252, %0, off" ::"v"(trank) : "memory", "a252");
-}
-// loads return in order: with N younger memory instructions allowed in flight the older ones have landed
-template <int N>
-__device__ static inline void row_scalars_wait(uint32_t &aa, uint32_t &mk, uint32_t &rk) {
-    asm volatile("s_waitcnt vmcnt(%3)\n\tv_accvgpr_read_b32 %0, a250\n\tv_accvgpr_read_b32 %1, a251\n\tv_accvgpr_read_b32 %2, a252"
-                 : "=v"(aa), "=v"(mk), "=v"(rk)
-                 : "n"(N)
-                 : "memory");
-}
-__device__ static inline void dequeue_async(uint32_t *counter) {  // ONE lane executes this
-    const uint32_t one = 1;
-    asm volatile("v_accvgpr_write_b32 a254, %1\n\tglobal_atomic_add a255, %0, a254, off sc0" ::"v"(counter), "v"(one) : "memory", "a254", "a255");
-}
-// everything this wave has in flight has landed; returns what the last dequeue_async fetched (lane 0's)
-__device__ static inline uint32_t wait_all_and_dequeued() {
-    uint32_t v;
-    asm volatile("s_waitcnt vmcnt(0)\n\tv_accvgpr_read_b32 %0, a255" : "=v"(v) : : "memory");
-    return v;
-}
+// (row_scalars_async / row_scalars_wait / dequeue_async / wait_all_and_dequeued: pvs_lds_dma.hpp — values that travel in front of a
+//  stage's DMA instructions live in named accumulation registers)
 
 // count of the n (a multiple of 8, padded with ~0) keys of `keys` that are smaller than m: broadcast 16-byte reads, eight keys per step
 __device__ static inline uint32_t rank_in(const unsigned long long *keys, uint32_t n, unsigned long long m) {

@@ -80,6 +80,47 @@ __device__ static inline double group_value(const float *dist, uint32_t ld, uint
         }
         e_slow = e_end;
     }
+    if (fanout && fanout <= 8 && !fw.on) {
+        // similar_to without pair weights: the same batching for the fan-out join — four rows' indices, flags and up to 8 distances
+        // each go out together (the row-at-a-time loop below: three dependent loads per row, 32 us for 86k groups of 8 rows);
+        // the sums run in (row, target) order as before
+        for (uint32_t e = e_begin; e < e_end; e += 4) {
+            const uint32_t m = e_end - e < 4 ? e_end - e : 4;
+            uint32_t rw[4];
+            float d4[4][8], w4[4];
+            uint8_t ex4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) rw[i] = (uint32_t)i < m ? grp_rows[e + i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool on = (uint32_t)i < m;
+                w4[i] = on && weights ? weights[rw[i]] : 1.f;
+                ex4[i] = on && exclude ? exclude[rw[i]] : (uint8_t)0;
+#pragma unroll
+                for (int c = 0; c < 8; c++) d4[i][c] = on && (uint32_t)c < fanout ? dist[(size_t)rw[i] * ld + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if ((uint32_t)i >= m) break;
+                if (exclude && (uint32_t)(ex4[i] != 0) == skip_when) continue;
+                const double w = (double)w4[i];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    if ((uint32_t)c >= fanout) break;
+                    joined++;
+                    if (weights) wsum.step(w);
+                    const float df = d4[i][c];
+                    if (df != df) continue;
+                    const double d = (double)df;
+                    sum.step(weights ? d * w : d);
+                    mn = fmin(mn, d);
+                    mx = fmax(mx, d);
+                    cnt++;
+                }
+            }
+        }
+        e_slow = e_end;
+    }
     for (uint32_t e = e_slow; e < e_end; e++) {
         const uint32_t row = grp_rows[e];
         if (exclude && (uint32_t)(exclude[row] != 0) == skip_when) continue;  // similar_to: flagged rows; candidate mask: rows it leaves out
@@ -305,7 +346,7 @@ __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double 
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
     for (uint32_t i = tid; i < GM_M; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * ncol + col]);
     __syncthreads();
-    const unsigned long long t = wg_radix_kth_u64(s, GM_M, j + 1, hist, misc);  // the sample's j-th smallest (0-based): no sort
+    const unsigned long long t = wg_radix_kth_u64(s, GM_M, j + 1, hist, misc, 16);  // the sample's j-th smallest (0-based), give or take 16 samples
     if (tid == 0) thr[col] = t >= ~0ull - 1 ? 0ull : t;  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
 }
 // grid (row blocks, ceil(ncol / 32)); a workgroup walks `per_wg` consecutive groups, lane = column of its 32-column chunk
@@ -358,6 +399,47 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
         }
     }
 }
+// ONE column (similar_to's fan-out aggregate; every column of the column-major route, ranked one by one): k_gm_compact gives a lane
+// to each of 32 columns, so a single column walked its groups with 8 threads per workgroup (33 us for 86k groups).  Here a thread
+// takes a group, a wave appends its hits with one atomic.
+__global__ __launch_bounds__(256) void k_gm_compact1(const double *vals, uint32_t n_groups, const unsigned long long *thr, uint32_t *count, unsigned long long *out_key,
+                                                     uint32_t *out_slot) {
+    // a workgroup takes 1,024 consecutive groups (four coalesced loads per thread in flight); its hits — a percent or two of them —
+    // are staged in LDS and appended with ONE global atomic (an atomic per wave on the one counter serialised: 13 us for 86k groups)
+    __shared__ unsigned long long s_key[1024];
+    __shared__ uint32_t s_slot[1024], s_n, s_base;
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long t = thr[0];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t g0 = blockIdx.x * 1024;
+    double v4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t g = g0 + u * 256 + tid;
+        v4[u] = g < n_groups ? vals[g] : __builtin_bit_cast(double, PVS_GROUP_ABSENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const unsigned long long k = gm_key(v4[u]);
+        if (k <= t && k != ~0ull) {
+            const uint32_t p = atomicAdd(&s_n, 1u);
+            s_key[p] = k;
+            s_slot[p] = g0 + u * 256 + tid;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = s_n;
+    if (m == 0) return;
+    if (tid == 0) s_base = atomicAdd(count, m);
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t i = tid; i < m; i += 256)
+        if (base + i < GM_CAP) {
+            out_key[base + i] = s_key[i];
+            out_slot[base + i] = s_slot[i];
+        }
+}
 // one workgroup per column; grp_trank / grp_tinv: the groups' tie order (second sort key) or nullptr (group id order = slot order).
 // The k-th smallest key of the column's few thousand admitted entries by radix select; the entries below it and its ties — usually
 // k of them and a handful — are sorted by (key, tie order) in LDS; the first k are the page.
@@ -383,7 +465,7 @@ __global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_topk(const uint32_t *cou
     }
     if (tid == 0) s_n = 0;
     __syncthreads();
-    const unsigned long long kth = k < m ? wg_radix_kth_u64(s_k, m, k, hist, misc) : ~0ull;
+    const unsigned long long kth = k < m ? wg_radix_kth_u64(s_k, m, k, hist, misc, 64) : ~0ull;  // (an upper bound of the k-th: the sort below is what is exact)
     for (uint32_t i = tid; i < m; i += GM_SORT_THREADS)
         if (s_k[i] <= kth) {
             const uint32_t p = atomicAdd(&s_n, 1u);
@@ -477,8 +559,11 @@ hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol,
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(GM_SORT_THREADS), 0, s, d_vals_t, n_groups, ncol, j, thr);
     const uint32_t per_wg = 1024;
-    hipLaunchKernelGGL(k_gm_compact, dim3((n_groups + per_wg - 1) / per_wg, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, thr, per_wg, count, keys,
-                       slots);
+    if (ncol == 1)
+        hipLaunchKernelGGL(k_gm_compact1, dim3((n_groups + 1023) / 1024), dim3(256), 0, s, d_vals_t, n_groups, thr, count, keys, slots);
+    else
+        hipLaunchKernelGGL(k_gm_compact, dim3((n_groups + per_wg - 1) / per_wg, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, thr, per_wg, count, keys,
+                           slots);
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute((const void *)k_gm_topk, hipFuncAttributeMaxDynamicSharedMemorySize, (GM_CAP + GM_SORT) * 12);

@@ -339,12 +339,13 @@ struct SimilarArgs {  // similar_to's options; the row_* arrays are host arrays 
     bool skip_i2i, skip_t2t;
 };
 struct SimilarTargets {
-    std::vector<uint8_t> hq;         // [n_targets][dim] the target vectors as a query batch (int8 codes or f32)
+    std::vector<uint8_t> hq;         // [n_targets][dim] the target vectors as a query batch (int8 codes or f32) ...
+    std::vector<uint32_t> own_rows;  // ... or (hq empty) the targets are these rows of the index similar_core runs on: gathered on the device
     std::vector<double> conf, lang;  // [n_targets] NaN = NULL
     std::vector<uint8_t> kind;       // [n_targets]
 };
 pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, const SimilarArgs &a, std::vector<uint64_t> &trow,
-                           SimilarTargets &tg);
+                           SimilarTargets &tg, bool vectors_stay_on_device = false);
 pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targets, const std::vector<uint32_t> &excluded, uint32_t k,
                         pvs_metric metric, const SimilarArgs &a, int64_t *out_groups, double *out_values, uint32_t *out_count);
 // ---- pvs_multi.hip (entry points of a multi-device index; the public functions dispatch here when is_multi())

@@ -16,6 +16,9 @@ hipError_t pvs_launch_rows_ingest(int mode, const void *src, uint32_t dim, uint3
 hipError_t pvs_launch_rows_gather(const uint8_t *rows, uint32_t stride, uint32_t row_bytes, uint64_t row0, uint64_t n, uint8_t *dst,
                                   hipStream_t s);
 hipError_t pvs_launch_pick_rows(const void *src, uint32_t row_bytes, const uint32_t *idx, uint64_t m, void *dst, hipStream_t s);
+// stored rows rows[idx[i]] (tiled layout) -> a dense query batch out[i][dim]: int8 codes as they are, f16 / f32 rows as f32 (similar_to:
+// the target item's vectors never leave the device); idx may live in pinned host memory
+hipError_t pvs_launch_rows_to_queries(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, const uint32_t *idx, uint32_t m, void *out, hipStream_t s);
 hipError_t pvs_launch_take_rows(const void *in, uint32_t elem_bytes, const uint32_t *global_row, uint64_t n_local, void *out, hipStream_t s);
 hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s);
 hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s);

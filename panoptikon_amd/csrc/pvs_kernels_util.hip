@@ -517,6 +517,32 @@ __global__ __launch_bounds__(256) void k_pick_rows(const uint8_t *src, uint32_t 
         }
     }
 }
+template <int DT>
+__global__ __launch_bounds__(256) void k_rows_to_queries(const uint8_t *rows, uint32_t stride, uint32_t dim, const uint32_t *idx, void *out) {
+    const uint32_t i = blockIdx.x;
+    const uint64_t r = idx[i];
+    constexpr uint32_t ESZ = DT == PVS_I8 ? 1 : DT == PVS_F16 ? 2 : 4;
+    for (uint32_t e = threadIdx.x; e < dim; e += 256) {
+        const uint32_t b = e * ESZ;
+        const uint8_t *p = rows + pvs_chunk_off(r, b >> 4, stride) + (b & 15u);
+        if constexpr (DT == PVS_I8)
+            ((int8_t *)out)[(size_t)i * dim + e] = (int8_t)*p;
+        else if constexpr (DT == PVS_F16)
+            ((float *)out)[(size_t)i * dim + e] = h2f(*(const uint16_t *)p);
+        else
+            ((float *)out)[(size_t)i * dim + e] = *(const float *)p;
+    }
+}
+hipError_t pvs_launch_rows_to_queries(int dtype, const uint8_t *rows, uint32_t stride, uint32_t dim, const uint32_t *idx, uint32_t m, void *out, hipStream_t s) {
+    if (m == 0) return hipSuccess;
+    if (dtype == PVS_I8)
+        hipLaunchKernelGGL(k_rows_to_queries<PVS_I8>, dim3(m), dim3(256), 0, s, rows, stride, dim, idx, out);
+    else if (dtype == PVS_F16)
+        hipLaunchKernelGGL(k_rows_to_queries<PVS_F16>, dim3(m), dim3(256), 0, s, rows, stride, dim, idx, out);
+    else
+        hipLaunchKernelGGL(k_rows_to_queries<PVS_F32>, dim3(m), dim3(256), 0, s, rows, stride, dim, idx, out);
+    return hipGetLastError();
+}
 hipError_t pvs_launch_pick_rows(const void *src, uint32_t row_bytes, const uint32_t *idx, uint64_t m, void *dst, hipStream_t s) {
     if (m == 0) return hipSuccess;
     const uint64_t total = m * (uint64_t)row_bytes / 16 + 1;

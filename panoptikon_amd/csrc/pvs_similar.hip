@@ -61,8 +61,21 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
             fw.cw = a.cw;
             fw.lw = a.lw;
         }
-        HIP_TRY(pvs_scratch_alloc(&d_q, tg.hq.size()));
-        HIP_TRY(hipMemcpyAsync(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice, c->stream));
+        // what the ranking will ask of the pinned block + the target rows' numbers (sized once: kernels in flight hold pointers into it)
+        const size_t io_rows = 4096 + (size_t)n_targets * k * 16 + (size_t)n_targets * 4;
+        PVS_TRY(ctx_pinned_io(*c, io_rows + (size_t)n_targets * 4 + 64));
+        const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
+        HIP_TRY(pvs_scratch_alloc(&d_q, std::max<size_t>((size_t)n_targets * ix->dim * qesz, 16)));
+        if (tg.hq.empty()) {
+            // the targets are rows of THIS index: their vectors become the query batch on the device (one small kernel reading the row
+            // numbers from pinned memory) — until round 5 they were read back to the host and uploaded again: a gather, two copies and a
+            // synchronisation, ~0.1 ms of a 0.3-ms call
+            uint32_t *h_rows = (uint32_t *)(c->h_io + ((io_rows + 63) & ~(size_t)63));
+            for (uint32_t i = 0; i < n_targets; i++) h_rows[i] = tg.own_rows[i];
+            HIP_TRY(pvs_launch_rows_to_queries((int)ix->dtype, ix->d_rows, ix->stride, ix->dim, h_rows, n_targets, d_q, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice, c->stream));
+        }
         HIP_TRY(pvs_scratch_alloc((void **)&d_ex, ix->n + 1));
         HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
         {  // one fill per RUN of excluded rows (an item's vectors are stored side by side: eight targets were eight 1-byte fills, 35 us)
@@ -80,7 +93,6 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
         PVS_TRY(prep_chunk(ix, *c, d_q, ix->dtype == PVS_I8 ? PVS_I8 : PVS_F32, 0, n_targets, pad, metric));
         // the int8 scorers' out-of-range flag goes to a pinned word and is looked at after the ranking's own synchronisation: one
         // host round trip less per call (45 us of a 0.36-ms similar_to); raised (never with real embeddings), the call is redone in order
-        PVS_TRY(ctx_pinned_io(*c, 4096 + (size_t)n_targets * k * 16 + (size_t)n_targets * 4));  // (what the ranking will ask for: no reallocation under the kernel)
         uint32_t *h_flag = (uint32_t *)(c->h_io + 40);
         *(volatile uint32_t *)h_flag = 0;
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m, h_flag));
@@ -103,7 +115,7 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
 // similar_to, first half: the target rows named by id -> their global row, stored vector (the query batch: int8 codes as they
 // are, f16/f32 as f32) and confidence / language / kind values.  Works on both index kinds (pvs_index_read_rows / _read_ids).
 pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, const SimilarArgs &a, std::vector<uint64_t> &trow,
-                           SimilarTargets &tg) {
+                           SimilarTargets &tg, bool vectors_stay_on_device) {
     trow.resize(n_targets);
     {
         std::lock_guard<std::mutex> lk(ix->mu);
@@ -124,6 +136,10 @@ pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_
         }
     }
     const size_t qesz = ix->dtype == PVS_I8 ? 1 : 4;
+    if (vectors_stay_on_device) {  // (a single-device index: similar_core gathers them itself)
+        tg.hq.clear();
+        tg.own_rows.assign(trow.begin(), trow.end());
+    } else {
     tg.hq.resize((size_t)n_targets * ix->dim * qesz);
     // the target's rows are usually consecutive (one item's vectors): one read per run of consecutive rows, not one per row (each
     // read is a gather kernel, a copy and a synchronisation: eight of them were half of a similar_to call at the reference's scale)
@@ -149,6 +165,7 @@ pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_
             }
         }
         i += run;
+    }
     }
     const double null_v = __builtin_nan("");
     tg.conf.assign(n_targets, null_v);
@@ -176,7 +193,7 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
     HIP_TRY(hipSetDevice(ix->device));
     std::vector<uint64_t> trow;
     SimilarTargets tg;
-    PVS_TRY(similar_targets(ix, target_row_ids, n_targets, a, trow, tg));
+    PVS_TRY(similar_targets(ix, target_row_ids, n_targets, a, trow, tg, true));
     std::vector<uint32_t> excluded(trow.begin(), trow.end());
     return similar_core(ix, tg, n_targets, excluded, k, metric, a, out_groups, out_values, out_count);
 }

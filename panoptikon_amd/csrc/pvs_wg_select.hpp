@@ -7,7 +7,9 @@
 
 // The kth smallest (1-based) of n 64-bit keys in LDS: eight 8-bit digits from the top, one LDS histogram per digit; the bin that
 // holds the rank is found by the first wave (4 bins per lane, a shuffle scan).  Workgroup-wide call; hist: 256 words, misc: 4 words.
-__device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long long *keys, uint32_t n, uint32_t kth, uint32_t *hist, uint32_t *misc) {
+// slack > 0: stop at the first digit whose chosen bin holds at most `slack` keys and return the UPPER END of that bin (>= the exact
+// key, at most `slack` - 1 keys too many at or below it) — enough for a page threshold, and a pass or two fewer.
+__device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long long *keys, uint32_t n, uint32_t kth, uint32_t *hist, uint32_t *misc, uint32_t slack = 0) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     // The digits every key shares are skipped (the AND and the OR of all keys differ from the first bit in which two keys differ), and
     // a digit whose chosen bin holds ONE key ends the search — that key is fetched by a last scan: three or four passes instead of eight
@@ -104,7 +106,9 @@ __device__ static inline unsigned long long wg_radix_kth_u64(const unsigned long
         mask |= 0xffull << shift;
         kk = misc[1];
         const bool single = misc[2] == 1 && shift > 0;
+        const bool near = slack && misc[2] <= slack && shift > 0;
         __syncthreads();
+        if (near) return prefix | (~0ull >> (64 - shift));
         if (single) {
             for (uint32_t i = tid; i < n; i += nt) {
                 const unsigned long long k = keys[i];
