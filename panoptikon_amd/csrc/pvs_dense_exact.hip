@@ -288,7 +288,8 @@ hipError_t launch_nq(const DenseK &k, uint32_t nq, int metric, uint32_t grid, hi
 }  // namespace
 
 static inline uint64_t dense_q_bytes(uint32_t stride, uint32_t esz) { return pvs_round_up((uint64_t)PVS_DENSE_NQ * (stride / esz) * 4, 256); }
-uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz) { return dense_q_bytes(stride, esz) + 1024; }  // the padded queries, then four dequeue counters 256 B apart
+// the padded queries, then four dequeue counters 256 B apart, then the wide pass's transposed queries (float rows)
+uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz) { return dense_q_bytes(stride, esz) + 1024 + pvs_exact_wide_scratch_bytes(stride, esz); }
 
 hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
@@ -315,6 +316,16 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
     k.dyn = (uint64_t)k.static_rounds * k.n_waves < k.n_units ? 1u : 0u;
     const size_t qsz = dtype == PVS_I8 ? 1 : 4;
     for (uint32_t q0 = 0; q0 < nq;) {
+        const uint32_t wide = dtype != PVS_I8 && !pvs_dbg(PVS_DBG_NO_EXACT_WIDE) ? pvs_exact_wide_fit(stride, esz) : 0u;
+        if (wide && nq - q0 > PVS_DENSE_NQ) {
+            // nine and more queries over float rows: 16 or 32 per pass, four rows per lane (pvs_exact_wide.hip)
+            const uint32_t g = std::min<uint32_t>(nq - q0, wide);
+            hipError_t e = pvs_launch_exact_wide(dtype, metric, rows, stride, dim, n, norm2, (const float *)qexact + (size_t)q0 * dim, qinfo + q0, g,
+                                                 (float *)((uint8_t *)qpad_scratch + dense_q_bytes(stride, esz) + 1024), out, out_ld, out_col + q0, n_cu, s);
+            if (e != hipSuccess) return e;
+            q0 += g;
+            continue;
+        }
         uint32_t g = nq - q0 >= 4 ? 4 : nq - q0 >= 2 ? 2 : 1;
         if (dtype != PVS_I8 && nq - q0 >= 8 && !pvs_dbg(PVS_DBG_DENSE_NQ4)) g = 8;
         while (g > 1 && (uint64_t)g * k.qpad_ld * 4 > (uint64_t)DENSE_Q_LDS) g >>= 1;  // queries must fit beside the ring

@@ -1,0 +1,216 @@
+// pvs_exact_wide.hip — the reference's component-by-component f32 distance (filters/exact.rs:106-134; sqlite-vec's
+// vec_distance_cosine / vec_distance_L2, restated in oracle/pvs_oracle.c orc_vec_distance_*) of every stored FLOAT row to 16 or 32
+// queries in one pass over the rows (round 5).
+//
+// k_dense_exact (pvs_dense_exact.hip) holds 8 queries per pass, one row per lane, and reads the query components from LDS: every
+// packed multiply needs 8 bytes of query per lane, a broadcast ds_read_b128 feeds two of them and costs 8 LDS cycles for the
+// whole CU, so the four SIMDs wait for the one LDS pipe — 4M x 768 f16 rows x 8 queries: 1.9 ms where the packed VALU work is
+// 0.7, and 32 queries are four such passes.  What lowers the LDS traffic per multiply is reuse: here a lane owns R = 4 rows, so
+// a query component read from LDS once feeds four packed multiplies — per component 8 broadcast reads (32 queries) against
+// 4 x 16 x 2 packed instructions: the LDS pipe is half used and the kernel is bound by the packed f32 pipe, which is the chain
+// the reference computes: per row, component and query pair one multiply and one add (cosine) or a subtract, a multiply and an
+// add (L2), each with its own IEEE rounding, in component order.  Rows come straight from HBM (a lane reads 16 bytes of each of
+// its rows per step, one step ahead of the arithmetic; the 8 steps of a 128-byte line follow each other); LDS holds only the
+// transposed, zero-padded queries qT[component][NQ].
+// (Tried first: the query components as wave-uniform scalar operands — s_load into SGPR pairs that v_pk_mul_f32 takes directly,
+//  no LDS at all, 76 VGPRs.  The instruction stream was ideal, but a scalar load that misses the 16 KB scalar cache takes ~1,000
+//  cycles, every line of the 96 KB of queries is used once per wave and SMEM returns out of order (lgkmcnt(0) only), so nothing
+//  hides it: 32 queries x 4M x 768 f16 took 6.8 ms, the same as four LDS passes.)
+//
+// Roofline: VALU (packed f32).  4M x 768 x 32 queries, cosine: 98.3 G component-queries = 1.54 G wave instructions of 4 cycles
+// = 2.5 ms at 2.4 GHz on 1,024 SIMDs; HBM traffic is the rows once (6.1 GB for f16: 0.8 ms).
+#include "pvs_kernels.hpp"
+
+namespace {
+
+struct WideK {
+    const uint8_t *rows;
+    const float *norm2;
+    const float *qT;  // [qld][NQ] f32: component-major, zero padded in both directions
+    const QInfo *qinfo;
+    float *out;  // out[row * out_ld + out_col + q]
+    uint64_t n_rows;
+    uint32_t stride, kslabs, out_ld, out_col, nq, n_tiles, qld;
+    uint32_t *ctr;  // the next row block to hand out (zeroed by k_transpose_queries in front of the launch)
+    uint32_t n_blocks, n_waves;
+};
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int WIDE_WAVES = 8;  // per workgroup: they share the LDS copy of the queries
+
+template <int DT, int NQ, int METRIC, int R>
+__global__ __launch_bounds__(64 * WIDE_WAVES) void k_exact_wide(WideK a) {
+    constexpr int PER = DT == PVS_F16 ? 8 : 4;  // components per 16-byte chunk
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [qld][NQ]
+    for (uint32_t i = threadIdx.x; i < a.qld * (NQ / 4); i += 64 * WIDE_WAVES) ((float4 *)qs)[i] = ((const float4 *)a.qT)[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // A workgroup stays (its LDS copy of the queries is filled once); its waves take row blocks of 64 R rows independently: the
+    // first one dealt, the rest from a counter, the next block's number asked for while the current one is computed.  (One
+    // workgroup per 8 blocks, the first form: the CU's only LDS slot was held until the slowest of 8 waves had finished and the
+    // next workgroup filled its LDS again — 1.4 of 2 waves per SIMD resident on average, SQ_WAVE_CYCLES.)
+    uint32_t blk = blockIdx.x * WIDE_WAVES + wave;
+    while (blk < a.n_blocks) {
+    uint32_t nxt = 0;
+    if (lane == 0) nxt = atomicAdd(a.ctr, 1u);
+    const uint64_t row0 = (uint64_t)blk * (64 * R) + lane;  // the lane's rows: row0 + 64 r
+    const uint32_t rr = lane & 31u, jx = rr & 15u;
+    // addresses: one wave-uniform base (the wave's first tile) + a 32-bit lane offset per row (a wave's 2R tiles span < 4 GiB)
+    const uint32_t tile0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((row0 - lane) >> 5));
+    const uint8_t *wbase = a.rows + (uint64_t)tile0 * 32 * a.stride;
+    uint32_t voff[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t tile = min(tile0 + 2 * r + (lane >> 5), a.n_tiles - 1);  // (lanes past the last tile re-read it and write nothing)
+        voff[r] = (tile - tile0) * 32 * a.stride + rr * 256u;
+    }
+    v2f acc[R][NQ / 2];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int p = 0; p < NQ / 2; p++) acc[r][p] = v2f{0.0f, 0.0f};
+    // A step = one 128-byte line of each of the lane's rows (8 chunks, 8 loads to the same line back to back): a line is fetched
+    // once.  (16 bytes per row and step — the first form — touched each line 8 times, thousands of instructions apart, with 2,048
+    // lines per CU in flight against a 32 KB L1: every touch was a new fetch, 1.3 TB/s of useful bytes.)
+    const uint32_t n_steps = a.kslabs * 2;
+    uint4 v[R][8];
+#pragma unroll 1
+    for (uint32_t step = 0; step < n_steps; step++) {
+        const uint32_t off = (step >> 1) * 8192u, h8 = (step & 1u) * 8u;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[r][c] = *(const uint4 *)(wbase + (voff[r] + off + (((h8 + (uint32_t)c) ^ jx) << 4)));
+        // the next step's lines are touched now (one dword per row, the value unused): the registers hold one step only, and a touch
+        // started under this step's arithmetic turns the next step's 8R loads into cache hits
+        uint32_t touch[R];
+        {
+            const uint32_t ns = min(step + 1, n_steps - 1);
+            const uint32_t noff = (ns >> 1) * 8192u + ((((ns & 1u) * 8u) ^ (jx & 8u)) << 4);
+#pragma unroll
+            for (int r = 0; r < R; r++) touch[r] = *(const uint32_t *)(wbase + (voff[r] + noff));
+        }
+        const float *qstep = qs + (size_t)step * 8 * PER * NQ;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                float4 q4[NQ / 4];  // one component of all queries: (q0, q1 | q2, q3) per read, the same address in every lane
+#pragma unroll
+                for (int x = 0; x < NQ / 4; x++) q4[x] = *(const float4 *)(qstep + (c * PER + e) * NQ + 4 * x);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t w[4] = {v[r][c].x, v[r][c].y, v[r][c].z, v[r][c].w};
+                    float av;
+                    if constexpr (DT == PVS_F16)
+                        av = h2f((uint16_t)(w[e >> 1] >> ((e & 1) * 16)));
+                    else
+                        av = __builtin_bit_cast(float, w[e]);
+                    const v2f av2 = v2f{av, av};
+#pragma unroll
+                    for (int p = 0; p < NQ / 2; p++) {
+                        const float4 &t4 = q4[p >> 1];
+                        const v2f qv = (p & 1) == 0 ? v2f{t4.x, t4.y} : v2f{t4.z, t4.w};
+                        if (METRIC == PVS_COSINE) {
+                            acc[r][p] = acc[r][p] + av2 * qv;  // (-ffp-contract=off: one rounding per multiply, one per add)
+                        } else {
+                            const v2f t = av2 - qv;
+                            acc[r][p] = acc[r][p] + t * t;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" ::"v"(touch[r]));
+    }
+    blk = a.n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint64_t row = row0 + 64 * r;
+        if (row < a.n_rows) {
+            const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
+            float *o = a.out + row * a.out_ld + a.out_col;
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if ((uint32_t)q < a.nq) {
+                    const float sum = acc[r][q >> 1][q & 1];
+                    o[q] = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, a.qinfo[q].bb) : ref_l2_finish(sum);
+                }
+        }
+    }
+    }
+}
+
+// [nq][dim] f32 queries -> qT[ld][NQ] f32 (component-major), zero padded
+__global__ __launch_bounds__(256) void k_transpose_queries(const float *q, uint32_t nq, uint32_t dim, uint32_t ld, uint32_t NQ, float *qT, uint32_t *ctr) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *ctr = 0;
+    if (i >= ld * NQ) return;
+    const uint32_t x = i / NQ, qq = i - x * NQ;
+    qT[i] = qq < nq && x < dim ? q[(size_t)qq * dim + x] : 0.f;
+}
+
+template <int DT, int NQ, int METRIC>
+hipError_t launch_wide_one(const WideK &k, hipStream_t s) {
+    constexpr int WIDE_R = 64 / NQ;  // rows per lane: R x NQ = 64 chains per lane
+    const size_t lds = (size_t)k.qld * NQ * 4;
+    static std::atomic<bool> configured{false};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_exact_wide<DT, NQ, METRIC, WIDE_R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured.store(true, std::memory_order_release);
+    }
+    WideK kk = k;
+    kk.n_blocks = (uint32_t)((k.n_rows + 64 * WIDE_R - 1) / (64 * WIDE_R));
+    const uint32_t grid = std::min<uint32_t>((kk.n_blocks + WIDE_WAVES - 1) / WIDE_WAVES, std::max<uint32_t>(k.n_waves, 1));  // (k.n_waves: the CU count on entry)
+    kk.n_waves = grid * WIDE_WAVES;
+    hipLaunchKernelGGL((k_exact_wide<DT, NQ, METRIC, WIDE_R>), dim3(grid), dim3(64 * WIDE_WAVES), lds, s, kk);
+    return hipGetLastError();
+}
+template <int DT, int NQ>
+hipError_t launch_wide(const WideK &k, int metric, hipStream_t s) {
+    return metric == PVS_COSINE ? launch_wide_one<DT, NQ, PVS_COSINE>(k, s) : launch_wide_one<DT, NQ, PVS_L2>(k, s);
+}
+
+}  // namespace
+
+// queries per pass the LDS copy allows for this row pitch: 32, 16 or 0 (rows wider than 2,560 components: k_dense_exact's passes)
+uint32_t pvs_exact_wide_fit(uint32_t stride, uint32_t esz) {
+    const uint64_t ld = stride / esz;
+    return ld * 32 * 4 <= 160 * 1024 ? 32u : ld * 16 * 4 <= 160 * 1024 ? 16u : 0u;
+}
+uint64_t pvs_exact_wide_scratch_bytes(uint32_t stride, uint32_t esz) { return pvs_round_up((uint64_t)PVS_EXACT_WIDE_NQ * (stride / esz) * 4, 256) + 256; }  // qT, then the block counter
+
+// nq <= PVS_EXACT_WIDE_NQ queries (f32, [nq][dim]) against every row; qT_scratch: pvs_exact_wide_scratch_bytes() of device memory
+hipError_t pvs_launch_exact_wide(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n, const float *norm2,
+                                 const float *queries, const QInfo *qinfo, uint32_t nq, float *qT_scratch, float *out, uint32_t out_ld, uint32_t out_col,
+                                 uint32_t n_cu, hipStream_t s) {
+    if (n == 0 || nq == 0) return hipSuccess;
+    if (dtype == PVS_I8 || nq > PVS_EXACT_WIDE_NQ) return hipErrorInvalidValue;
+    const uint32_t esz = pvs_esz((uint32_t)dtype), ld = stride / esz, NQ = nq <= 16 ? 16 : 32;
+    uint32_t *ctr = (uint32_t *)((uint8_t *)qT_scratch + pvs_round_up((uint64_t)PVS_EXACT_WIDE_NQ * ld * 4, 256));
+    hipLaunchKernelGGL(k_transpose_queries, dim3((ld * NQ + 255) / 256), dim3(256), 0, s, queries, nq, dim, ld, NQ, qT_scratch, ctr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    WideK k;
+    k.rows = rows;
+    k.norm2 = norm2;
+    k.qT = qT_scratch;
+    k.qinfo = qinfo;
+    k.out = out;
+    k.n_rows = n;
+    k.stride = stride;
+    k.kslabs = stride / PVS_KSLAB_BYTES;
+    k.out_ld = out_ld;
+    k.out_col = out_col;
+    k.nq = nq;
+    k.n_tiles = (uint32_t)((n + 31) / 32);
+    k.qld = ld;
+    k.ctr = ctr;
+    k.n_waves = n_cu;
+    k.n_blocks = 0;
+    if ((uint64_t)ld * NQ * 4 > 160 * 1024) return hipErrorInvalidValue;  // (pvs_exact_wide_fits: the caller asked first)
+    if (dtype == PVS_F16) return NQ == 16 ? launch_wide<PVS_F16, 16>(k, metric, s) : launch_wide<PVS_F16, 32>(k, metric, s);
+    return NQ == 16 ? launch_wide<PVS_F32, 16>(k, metric, s) : launch_wide<PVS_F32, 32>(k, metric, s);
+}

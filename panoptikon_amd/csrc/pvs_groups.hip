@@ -340,11 +340,12 @@ __device__ static inline unsigned long long gm_key(double v) {
     if (__builtin_bit_cast(unsigned long long, v) == PVS_GROUP_ABSENT) k = ~0ull;  // ... absent groups: never emitted
     return k;
 }
-__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, uint32_t ncol, uint32_t j, unsigned long long *thr) {
+// (value of group g in column col: vals[g * gs + col * cs] — group-major gs = ncol, cs = 1; column-major gs = 1, cs = n_groups)
+__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, size_t gs, size_t cs, uint32_t j, unsigned long long *thr) {
     __shared__ unsigned long long s[GM_M];
     __shared__ uint32_t hist[256], misc[4];
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t i = tid; i < GM_M; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * ncol + col]);
+    for (uint32_t i = tid; i < GM_M; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * gs + col * cs]);
     __syncthreads();
     const unsigned long long t = wg_radix_kth_u64(s, GM_M, j + 1, hist, misc, 16);  // the sample's j-th smallest (0-based), give or take 16 samples
     if (tid == 0) thr[col] = t >= ~0ull - 1 ? 0ull : t;  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
@@ -402,8 +403,14 @@ __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32
 // ONE column (similar_to's fan-out aggregate; every column of the column-major route, ranked one by one): k_gm_compact gives a lane
 // to each of 32 columns, so a single column walked its groups with 8 threads per workgroup (33 us for 86k groups).  Here a thread
 // takes a group, a wave appends its hits with one atomic.
-__global__ __launch_bounds__(256) void k_gm_compact1(const double *vals, uint32_t n_groups, const unsigned long long *thr, uint32_t *count, unsigned long long *out_key,
-                                                     uint32_t *out_slot) {
+__global__ __launch_bounds__(256) void k_gm_compact1(const double *vals_cm, uint32_t n_groups, const unsigned long long *thr_all, uint32_t *count_all,
+                                                     unsigned long long *out_key_all, uint32_t *out_slot_all) {
+    // grid.y = column of COLUMN-MAJOR values [ncol][n_groups]
+    const double *vals = vals_cm + (size_t)blockIdx.y * n_groups;
+    const unsigned long long *thr = thr_all + blockIdx.y;
+    uint32_t *count = count_all + (size_t)blockIdx.y * 32;
+    unsigned long long *out_key = out_key_all + (size_t)blockIdx.y * GM_CAP;
+    uint32_t *out_slot = out_slot_all + (size_t)blockIdx.y * GM_CAP;
     // a workgroup takes 1,024 consecutive groups (four coalesced loads per thread in flight); its hits — a percent or two of them —
     // are staged in LDS and appended with ONE global atomic (an atomic per wave on the one counter serialised: 13 us for 86k groups)
     __shared__ unsigned long long s_key[1024];
@@ -547,7 +554,7 @@ bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k) {
     return n_groups >= 65536 && 2 * target <= GM_CAP / 2 && target * 8 < n_groups;
 }
 hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
-                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s) {
+                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s, bool column_major) {
     uint8_t *w = (uint8_t *)d_work;
     unsigned long long *thr = (unsigned long long *)w;
     uint32_t *count = (uint32_t *)(w + (((size_t)ncol * 8 + 127) & ~(size_t)127));
@@ -557,10 +564,12 @@ hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol,
     const uint32_t j = (uint32_t)std::min<uint64_t>(GM_M - 1, (uint64_t)((double)GM_M * 2.0 * (double)target / (double)n_groups) + 4);
     hipError_t e = hipMemsetAsync(count, 0, (size_t)ncol * 128, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(GM_SORT_THREADS), 0, s, d_vals_t, n_groups, ncol, j, thr);
+    if (ncol == 1) column_major = true;  // (the same thing)
+    hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(GM_SORT_THREADS), 0, s, d_vals_t, n_groups, column_major ? (size_t)1 : (size_t)ncol,
+                       column_major ? (size_t)n_groups : (size_t)1, j, thr);
     const uint32_t per_wg = 1024;
-    if (ncol == 1)
-        hipLaunchKernelGGL(k_gm_compact1, dim3((n_groups + 1023) / 1024), dim3(256), 0, s, d_vals_t, n_groups, thr, count, keys, slots);
+    if (column_major)
+        hipLaunchKernelGGL(k_gm_compact1, dim3((n_groups + 1023) / 1024, ncol), dim3(256), 0, s, d_vals_t, n_groups, thr, count, keys, slots);
     else
         hipLaunchKernelGGL(k_gm_compact, dim3((n_groups + per_wg - 1) / per_wg, (ncol + 31) / 32), dim3(256), 0, s, d_vals_t, n_groups, ncol, thr, per_wg, count, keys,
                            slots);

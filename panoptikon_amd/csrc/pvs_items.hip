@@ -359,18 +359,16 @@ static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals,
                     out_count[q] = k;
                     paged[q] = 1;
                 }
-        } else if (d_vals && !no_page_rank && ncol <= 32 && pvs_gm_rank_supported(G, 1, k)) {
-            // column-major values (the dense-matrix route: float indexes, similar_to's fan-out): every column is itself a group-major
-            // matrix of ONE column — the same device page ranking, column by column on the stream, one synchronisation for all
+        } else if (d_vals && !no_page_rank && ncol <= 256 && pvs_gm_rank_supported(G, ncol, k)) {
+            // column-major values (the dense-matrix route: float indexes, similar_to's fan-out): the same device page ranking with the
+            // strides swapped — three launches for all columns (until round 5: four per column, 62 us each, 2 of the 10 ms of a
+            // 32-query per-item search over 4M float rows)
             const size_t off_g = 64, off_v = off_g + (size_t)ncol * k * 8, off_f = off_v + (size_t)ncol * k * 8, need = off_f + (size_t)ncol * 4;
             PVS_TRY(ctx_pinned_io(c, need));
-            const size_t wb = (pvs_gm_rank_work_bytes(1) + 255) & ~(size_t)255;
-            HIP_TRY(pvs_scratch_alloc(&d_work, wb * ncol));
+            HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(ncol)));
             const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
-            for (uint32_t q = 0; q < ncol; q++)
-                HIP_TRY(pvs_gm_rank(d_vals + (size_t)q * G, G, 1, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr,
-                                    (uint8_t *)d_work + wb * q, (int64_t *)(c.h_io + off_g) + (size_t)q * k, (double *)(c.h_io + off_v) + (size_t)q * k,
-                                    (uint32_t *)(c.h_io + off_f) + q, c.stream));
+            HIP_TRY(pvs_gm_rank(d_vals, G, ncol, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
+                                (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), c.stream, true));
             HIP_TRY(hipStreamSynchronize(c.stream));
             const uint32_t *fl = (const uint32_t *)(c.h_io + off_f);
             for (uint32_t q = 0; q < ncol; q++)

@@ -40,6 +40,13 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
 // qpad_scratch: pvs_dense_exact_scratch_bytes() of device memory, reused launch after launch on `s`.
 constexpr uint32_t PVS_DENSE_NQ = 8;  // float rows; int8 rows (the out-of-range fallback) take 4
 uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz);
+// 9..32 queries over float rows in one pass, four rows per lane (pvs_exact_wide.hip)
+constexpr uint32_t PVS_EXACT_WIDE_NQ = 32;
+uint64_t pvs_exact_wide_scratch_bytes(uint32_t stride, uint32_t esz);
+uint32_t pvs_exact_wide_fit(uint32_t stride, uint32_t esz);  // queries per pass for this row pitch: 32, 16 or 0 (too wide for LDS)
+hipError_t pvs_launch_exact_wide(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n, const float *norm2,
+                                 const float *queries, const QInfo *qinfo, uint32_t nq, float *qT_scratch, float *out, uint32_t out_ld, uint32_t out_col,
+                                 uint32_t n_cu, hipStream_t s);
 hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n,
                                   const float *norm2, const void *qexact, const QInfo *qinfo, uint32_t nq, float *qpad_scratch,
                                   float *out, uint32_t out_ld, uint32_t out_col, uint32_t n_cu, hipStream_t s);
@@ -292,7 +299,8 @@ hipError_t pvs_launch_group_aggregate_list(const float *dist, uint32_t ld, uint3
 size_t pvs_gm_rank_work_bytes(uint32_t ncol);
 bool pvs_gm_rank_supported(uint32_t n_groups, uint32_t ncol, uint32_t k);
 hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol, uint32_t k, const int64_t *d_gids, const uint32_t *d_grp_trank,
-                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s);
+                       const uint32_t *d_grp_tinv, void *d_work, int64_t *out_groups, double *out_values, uint32_t *out_flag, hipStream_t s,
+                       bool column_major = false);  // column_major: d_vals_t is [ncol][n_groups]
 // the same for the few sub-groups of a candidate list, all of them in one LDS sort per column (column-major values [ncol][n_sub])
 bool pvs_sub_rank_supported(uint32_t n_sub);
 hipError_t pvs_sub_rank(const double *d_vals, uint32_t n_sub, uint32_t ncol, uint32_t k, const uint32_t *d_sub_slot, const int64_t *d_gids, const uint32_t *d_grp_trank,

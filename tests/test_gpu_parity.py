@@ -471,6 +471,14 @@ def test_dense_exact_packed_pairs_equal_the_scalar_chains(pvs, dtype):
         finally:
             pvs.debug_set("dense_nq4", 0)
         assert np.array_equal(got.view(np.uint32), old.view(np.uint32)), (dtype, metric)
+        # (b = 24 > 8: `got` came from k_exact_wide — 32 chains per pass, query components as scalar operands; the 8-per-pass
+        #  LDS form must agree with it bit for bit too)
+        pvs.debug_set("no_exact_wide", 1)
+        try:
+            old8 = ix.score_batch(queries, metric)
+        finally:
+            pvs.debug_set("no_exact_wide", 0)
+        assert np.array_equal(got.view(np.uint32), old8.view(np.uint32)), (dtype, metric)
         for q in range(b):
             exp = orc.score_all(dt, metric, hc, queries[q])
             assert np.array_equal(np.isnan(got[:, q]), np.isnan(exp)), (dtype, metric, q)
