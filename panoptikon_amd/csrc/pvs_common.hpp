@@ -86,6 +86,7 @@ enum PvsDbg {
     PVS_DBG_NO_FLAG_POLL,          // pvs_search (one-launch route): wait for the stream's completion event instead of polling the kernel's flag words in pinned memory
     PVS_DBG_POLL_LATE_PAGES,       // (a counter) polled searches whose flag word reached host memory before every word of its page had
     PVS_DBG_NO_EXACT_WIDE,         // dense exact path, float rows: 8 queries per pass through LDS (k_dense_exact) also for 9+ queries
+    PVS_DBG_NO_AGG8,               // per-item aggregation of a distance matrix: one thread per (group, column) also when the columns are a multiple of 8
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -36,11 +36,13 @@ struct WideK {
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WIDE_WAVES = 8;  // per workgroup: they share the LDS copy of the queries
 
-template <int DT, int NQ, int METRIC, int R>
+template <int DT, int NQ, int METRIC, int R, int LC>  // LC: 16-byte chunks of a row per load batch (4: half a 128-byte line)
 __global__ __launch_bounds__(64 * WIDE_WAVES) void k_exact_wide(WideK a) {
     constexpr int PER = DT == PVS_F16 ? 8 : 4;  // components per 16-byte chunk
+    constexpr int GRP = 8;                       // independent products in front of their adds
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [qld][NQ]
     for (uint32_t i = threadIdx.x; i < a.qld * (NQ / 4); i += 64 * WIDE_WAVES) ((float4 *)qs)[i] = ((const float4 *)a.qT)[i];
     __syncthreads();
@@ -69,61 +71,98 @@ __global__ __launch_bounds__(64 * WIDE_WAVES) void k_exact_wide(WideK a) {
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int p = 0; p < NQ / 2; p++) acc[r][p] = v2f{0.0f, 0.0f};
-    // A step = one 128-byte line of each of the lane's rows (8 chunks, 8 loads to the same line back to back): a line is fetched
-    // once.  (16 bytes per row and step — the first form — touched each line 8 times, thousands of instructions apart, with 2,048
-    // lines per CU in flight against a 32 KB L1: every touch was a new fetch, 1.3 TB/s of useful bytes.)
+    // A step = one 128-byte line of each of the lane's rows.  (16 bytes per row and step — the first form — touched each line 8
+    // times, thousands of instructions apart, with 2,048 lines per CU in flight against a 32 KB L1: every touch was a new fetch,
+    // 1.3 TB/s of useful bytes.)  The line is held as two halves of LC chunks that are reloaded as soon as they are consumed: the
+    // loads of one half fly under the arithmetic of the other.  (Loading the whole line at the top of a step left every wave of
+    // the chip loading at the same time and then computing at the same time — waves that share a SIMD fall into step — and HBM
+    // idle in between: 64 % of the packed-f32 rate.)
+    static_assert(LC == 4, "two halves of a line, ping-pong");
     const uint32_t n_steps = a.kslabs * 2;
-    uint4 v[R][8];
-#pragma unroll 1
-    for (uint32_t step = 0; step < n_steps; step++) {
-        const uint32_t off = (step >> 1) * 8192u, h8 = (step & 1u) * 8u;
+    u32x4 v[2][R][LC];
+    // The loads are inline assembly and so are their waits: written as plain loads, the compiler hoisted every batch to the top of
+    // the loop body and waited for it there (it schedules by data dependence only, and the reload of a register it can rename
+    // depends on nothing).  A batch is 4R loads; vmcnt counts loads in issue order, so "at most 4R outstanding" behind the issue of
+    // the other half means this half has landed.  The destination registers are read only through the wait statement.
+    auto load_half = [&](int h, uint32_t step) __attribute__((always_inline)) {
+        const uint32_t off = (step >> 1) * 8192u, c0 = (step & 1u) * 8u + (uint32_t)h * LC;
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int c = 0; c < 8; c++) v[r][c] = *(const uint4 *)(wbase + (voff[r] + off + (((h8 + (uint32_t)c) ^ jx) << 4)));
-        // the next step's lines are touched now (one dword per row, the value unused): the registers hold one step only, and a touch
-        // started under this step's arithmetic turns the next step's 8R loads into cache hits
-        uint32_t touch[R];
-        {
-            const uint32_t ns = min(step + 1, n_steps - 1);
-            const uint32_t noff = (ns >> 1) * 8192u + ((((ns & 1u) * 8u) ^ (jx & 8u)) << 4);
+            for (int c = 0; c < LC; c++) {
+                const uint32_t o = voff[r] + off + (((c0 + (uint32_t)c) ^ jx) << 4);
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[h][r][c]) : "v"(o), "s"(wbase));
+            }
+    };
+    auto wait_half = [&](int h, auto all) __attribute__((always_inline)) {  // all but the 4R youngest loads have landed (all: every load)
+        constexpr bool ALL = decltype(all)::value;
+        static_assert(R == 2 || R == 3, "operand lists below");
+#define PVS_W4(r) "+v"(v[h][r][0]), "+v"(v[h][r][1]), "+v"(v[h][r][2]), "+v"(v[h][r][3])
+        if constexpr (R == 2 && ALL)
+            asm volatile("s_waitcnt vmcnt(0)" : PVS_W4(0), PVS_W4(1));
+        else if constexpr (R == 2)
+            asm volatile("s_waitcnt vmcnt(8)" : PVS_W4(0), PVS_W4(1));
+        else if constexpr (ALL)
+            asm volatile("s_waitcnt vmcnt(0)" : PVS_W4(0), PVS_W4(1), PVS_W4(2));
+        else
+            asm volatile("s_waitcnt vmcnt(12)" : PVS_W4(0), PVS_W4(1), PVS_W4(2));
+#undef PVS_W4
+    };
+    auto compute_half = [&](int h, uint32_t step) __attribute__((always_inline)) {
+        const float *qh = qs + ((size_t)step * 8 + (size_t)h * LC) * PER * NQ;
 #pragma unroll
-            for (int r = 0; r < R; r++) touch[r] = *(const uint32_t *)(wbase + (voff[r] + noff));
-        }
-        const float *qstep = qs + (size_t)step * 8 * PER * NQ;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < LC; c++) {
 #pragma unroll
             for (int e = 0; e < PER; e++) {
                 float4 q4[NQ / 4];  // one component of all queries: (q0, q1 | q2, q3) per read, the same address in every lane
 #pragma unroll
-                for (int x = 0; x < NQ / 4; x++) q4[x] = *(const float4 *)(qstep + (c * PER + e) * NQ + 4 * x);
+                for (int x = 0; x < NQ / 4; x++) q4[x] = *(const float4 *)(qh + (c * PER + e) * NQ + 4 * x);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const uint32_t w[4] = {v[r][c].x, v[r][c].y, v[r][c].z, v[r][c].w};
+                    const uint32_t w[4] = {v[h][r][c][0], v[h][r][c][1], v[h][r][c][2], v[h][r][c][3]};
                     float av;
                     if constexpr (DT == PVS_F16)
                         av = h2f((uint16_t)(w[e >> 1] >> ((e & 1) * 16)));
                     else
                         av = __builtin_bit_cast(float, w[e]);
                     const v2f av2 = v2f{av, av};
+                    // (-ffp-contract=off: one rounding per multiply, one per add.)  Groups of 8 independent products, then their 8 adds:
+                    // a packed instruction that reads the result of the one in front of it does not issue back to back.
 #pragma unroll
-                    for (int p = 0; p < NQ / 2; p++) {
-                        const float4 &t4 = q4[p >> 1];
-                        const v2f qv = (p & 1) == 0 ? v2f{t4.x, t4.y} : v2f{t4.z, t4.w};
-                        if (METRIC == PVS_COSINE) {
-                            acc[r][p] = acc[r][p] + av2 * qv;  // (-ffp-contract=off: one rounding per multiply, one per add)
-                        } else {
-                            const v2f t = av2 - qv;
-                            acc[r][p] = acc[r][p] + t * t;
+                    for (int p0 = 0; p0 < NQ / 2; p0 += GRP) {
+                        v2f t[GRP];
+#pragma unroll
+                        for (int i = 0; i < GRP; i++) {
+                            const float4 &t4 = q4[(p0 + i) >> 1];
+                            const v2f qv = (i & 1) == 0 ? v2f{t4.x, t4.y} : v2f{t4.z, t4.w};
+                            if (METRIC == PVS_COSINE) {
+                                t[i] = av2 * qv;
+                            } else {
+                                const v2f d = av2 - qv;
+                                t[i] = d * d;
+                            }
                         }
+#pragma unroll
+                        for (int i = 0; i < GRP; i++) acc[r][p0 + i] = acc[r][p0 + i] + t[i];
                     }
                 }
             }
         }
-#pragma unroll
-        for (int r = 0; r < R; r++) asm volatile("" ::"v"(touch[r]));
+    };
+    load_half(0, 0);
+#pragma unroll 1
+    for (uint32_t step = 0; step < n_steps; step++) {
+        load_half(1, step);
+        wait_half(0, std::false_type{});
+        compute_half(0, step);
+        load_half(0, min(step + 1, n_steps - 1));
+        wait_half(1, std::false_type{});
+        compute_half(1, step);
     }
+    // (the last, redundant reload: its registers must stay reserved until it has landed — the compiler does not know a load is in
+    //  flight into them, and handed them to the arithmetic above as temporaries when nothing named them after the loop: a late
+    //  arrival overwrote an address, found as a memory fault in the f32 instance)
+    wait_half(0, std::true_type{});
     blk = a.n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -153,11 +192,11 @@ __global__ __launch_bounds__(256) void k_transpose_queries(const float *q, uint3
 
 template <int DT, int NQ, int METRIC>
 hipError_t launch_wide_one(const WideK &k, hipStream_t s) {
-    constexpr int WIDE_R = 64 / NQ;  // rows per lane: R x NQ = 64 chains per lane
+    constexpr int WIDE_R = NQ == 32 ? 2 : 3, WIDE_LC = 4;  // rows per lane (R x NQ / 2 accumulator pairs + 8 R registers of row data: four rows at 16 queries spill); chunks per load batch
     const size_t lds = (size_t)k.qld * NQ * 4;
     static std::atomic<bool> configured{false};
     if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_exact_wide<DT, NQ, METRIC, WIDE_R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)k_exact_wide<DT, NQ, METRIC, WIDE_R, WIDE_LC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured.store(true, std::memory_order_release);
     }
@@ -165,7 +204,7 @@ hipError_t launch_wide_one(const WideK &k, hipStream_t s) {
     kk.n_blocks = (uint32_t)((k.n_rows + 64 * WIDE_R - 1) / (64 * WIDE_R));
     const uint32_t grid = std::min<uint32_t>((kk.n_blocks + WIDE_WAVES - 1) / WIDE_WAVES, std::max<uint32_t>(k.n_waves, 1));  // (k.n_waves: the CU count on entry)
     kk.n_waves = grid * WIDE_WAVES;
-    hipLaunchKernelGGL((k_exact_wide<DT, NQ, METRIC, WIDE_R>), dim3(grid), dim3(64 * WIDE_WAVES), lds, s, kk);
+    hipLaunchKernelGGL((k_exact_wide<DT, NQ, METRIC, WIDE_R, WIDE_LC>), dim3(grid), dim3(64 * WIDE_WAVES), lds, s, kk);
     return hipGetLastError();
 }
 template <int DT, int NQ>

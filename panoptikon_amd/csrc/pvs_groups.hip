@@ -192,10 +192,97 @@ __global__ __launch_bounds__(256) void k_group_aggregate(const float *dist, uint
     }
 }
 
+// Many query columns (a multiple of 8), no fan-out: a thread owns one group and EIGHT columns (round 5).  k_group_aggregate gives
+// every (group, column) its own thread — 42M threads for 1.3M files x 32 queries, each a chain of three dependent loads (group
+// offsets, row index, distance): 0.65 ms for a 512 MB matrix, all of it latency.  Here the row indices, weights and flags of a
+// group are read once per 8 columns and a row's 8 distances are two 16-byte loads, up to four rows in flight; lanes of a wave are
+// 64 adjacent groups (their rows lie side by side: the lines are shared), the 4 waves of a workgroup are 4 column blocks, and
+// the column-major output is written 512 bytes per wave and column.  The arithmetic per (group, column) is group_value()'s:
+// SQLite's KBN sums in row order.
+template <int AGG_KIND>  // 0: AVG / weighted (sums), 1: MIN / MAX
+__global__ __launch_bounds__(256) void k_group_aggregate8(const float *dist, uint32_t ld, uint32_t n_cols, const uint32_t *grp_off, const uint32_t *grp_rows,
+                                                          uint32_t n_groups, const float *weights, const uint8_t *exclude, int agg, double *out,
+                                                          uint32_t skip_when) {
+    const uint32_t n_cb = n_cols / 8, cb_per_wg = 4;
+    const uint32_t g = blockIdx.x * 64 + (threadIdx.x & 63u);
+    const uint32_t cb = blockIdx.y * cb_per_wg + (threadIdx.x >> 6);
+    if (g >= n_groups || cb >= n_cb) return;
+    Kbn sum[8], wsum;
+    double ext[8];
+    uint32_t cnt[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        ext[c] = agg == PVS_AGG_MIN ? __builtin_inf() : -__builtin_inf();
+        cnt[c] = 0;
+    }
+    uint64_t joined = 0;
+    const uint32_t e_begin = grp_off[g], e_end = grp_off[g + 1];
+    for (uint32_t e = e_begin; e < e_end; e += 4) {
+        const uint32_t m = e_end - e < 4 ? e_end - e : 4;
+        uint32_t rw[4];
+        float4 d4[4][2];
+        float w4[4];
+        uint8_t ex4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) rw[i] = (uint32_t)i < m ? grp_rows[e + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool on = (uint32_t)i < m;
+            const float4 *p = (const float4 *)(dist + (size_t)rw[i] * ld + cb * 8);
+            d4[i][0] = on ? p[0] : float4{0.f, 0.f, 0.f, 0.f};
+            d4[i][1] = on ? p[1] : float4{0.f, 0.f, 0.f, 0.f};
+            w4[i] = on && weights ? weights[rw[i]] : 1.f;
+            ex4[i] = on && exclude ? exclude[rw[i]] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if ((uint32_t)i >= m) break;
+            if (exclude && (uint32_t)(ex4[i] != 0) == skip_when) continue;
+            joined++;
+            const double w = (double)w4[i];
+            if (weights) wsum.step(w);
+            const float df[8] = {d4[i][0].x, d4[i][0].y, d4[i][0].z, d4[i][0].w, d4[i][1].x, d4[i][1].y, d4[i][1].z, d4[i][1].w};
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (df[c] != df[c]) continue;  // SQL NULL distance
+                const double d = (double)df[c];
+                if constexpr (AGG_KIND == 0)
+                    sum[c].step(weights ? d * w : d);
+                else
+                    ext[c] = agg == PVS_AGG_MIN ? fmin(ext[c], d) : fmax(ext[c], d);
+                cnt[c]++;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        double v;
+        if (joined == 0)
+            v = __builtin_bit_cast(double, PVS_GROUP_ABSENT);
+        else if (cnt[c] == 0)
+            v = __builtin_nan("");
+        else if (weights)
+            v = sum[c].value() / wsum.value();
+        else if (AGG_KIND == 1)
+            v = ext[c];
+        else
+            v = sum[c].value() / (double)cnt[c];
+        out[(size_t)(cb * 8 + c) * n_groups + g] = v;
+    }
+}
+
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
                                       int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when) {
     if (n_groups == 0) return hipSuccess;
+    if (!fanout && !fw.on && n_cols % 8 == 0 && ld % 4 == 0 && ((uintptr_t)dist & 15) == 0 && !pvs_dbg(PVS_DBG_NO_AGG8)) {
+        const dim3 grid((n_groups + 63) / 64, (n_cols / 8 + 3) / 4);
+        if (weights || (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX))
+            hipLaunchKernelGGL(k_group_aggregate8<0>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, n_groups, weights, exclude, agg, out, skip_when);
+        else
+            hipLaunchKernelGGL(k_group_aggregate8<1>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, n_groups, weights, exclude, agg, out, skip_when);
+        return hipGetLastError();
+    }
     const uint32_t ncol_out = fanout ? 1u : n_cols;
     const uint32_t TG = agg_tile_groups(ncol_out);
     hipLaunchKernelGGL(k_group_aggregate, dim3((n_groups + TG - 1) / TG), dim3(256), (size_t)ncol_out * TG * 8, s, dist, ld, n_cols, fanout,

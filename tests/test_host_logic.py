@@ -366,3 +366,22 @@ def test_keyed_merge_of_per_item_pages():
         differs += int(not np.array_equal(pg[q], og[q]))
     assert differs, "the keys must matter in this test"
 
+
+
+def test_exact_wide_instances_use_no_scratch(tmp_path):
+    """k_exact_wide loads its rows by inline assembly into registers the compiler cannot know are still in flight: a spill of one of
+    them would store and reload stale data.  Every instance must compile without scratch (the 16-query instances hold 3 rows per lane
+    for this reason: 4 spilled 12-32 bytes)."""
+    import re
+    import subprocess
+
+    from panoptikon_amd import build as B
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "wide.s"
+    cmd = [B.HIPCC, "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "panoptikon_amd", "csrc"), *B.HIPFLAGS,
+           "--cuda-device-only", "-S", os.path.join(root, "panoptikon_amd", "csrc", "pvs_exact_wide.hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True)
+    found = re.findall(r"\.name:\s+(\S*k_exact_wide\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", out.read_text())
+    assert len(found) == 8, found
+    assert all(int(p) == 0 for _, p in found), found
