@@ -870,6 +870,81 @@ def main():
                 rec["parity"] = {"oracle_rows": n_ref, "ids_and_distances_bit_exact": bool(np.array_equal(hi4[:, :k_ref], ei4) and np.array_equal(hd4[:, :k_ref].view(np.uint32), ed4.view(np.uint32)))}
             secondary.append(rec)
             ixr.close()
+            # (e) the reference's EXACT mode per item (f32 payloads narrowed to f16 here; filters/exact.rs:106-165: every row's distance,
+            # GROUP BY file, AVG, rank): 32 float queries over 4M x 768 rows in 1.33M files — every (row, query) pair is one in-order f32
+            # chain, so the scorer (k_exact_wide, round 5) is bound by the packed-f32 VALU rate, not by HBM: its roofline is that rate
+            n_it, b_it, k_it = 4_000_000, 32, 50
+            ixg = pvs.VectorIndex(pvs.F16, D, device=device, capacity_rows=n_it)
+            stg = pvs.DeviceBuffer(chunk * D * 4, device)
+            rng_g = np.random.default_rng(7)
+            grp_all = []
+            for off in range(0, n_it, chunk):
+                m = min(chunk, n_it - off)
+                L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, off, m, D, stg.ptr))
+                g = np.sort(rng_g.integers(off // 3, (off + m) // 3 + 1, m)).astype(np.int64)  # ~3 adjacent rows per file
+                grp_all.append(g)
+                L.check(lib.pvs_index_add_f32(ixg._h, stg.ptr, m, None, g.ctypes.data, L.DEVICE))
+            stg.free()
+            ixg.sync()
+            qg = np.empty((b_it, D), np.float32)
+            qtmp = pvs.DeviceBuffer(b_it * D * 4, device)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b_it, D, qtmp.ptr))
+            qg[:] = qtmp.to_numpy(np.float32, (b_it, D))
+            qtmp.free()
+            for _ in range(2):
+                ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+            ixg.set_profiling(True)
+            ixg.profile(reset=True)
+            n_calls = 6
+            t_g = time.perf_counter()
+            for _ in range(n_calls):
+                gg, gv, gc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+            el_g = time.perf_counter() - t_g
+            pg_ = ixg.profile()
+            ixg.set_profiling(False)
+            sms_g = pg_.scan_ms / max(pg_.scan_launches, 1)
+            # packed f32 on the vector ALUs: 256 CUs x 128 lane-operations per clock x 2.4 GHz.  The datasheet's 157.3 TFLOP/s counts a fused
+            # multiply-add as two; the reference rounds the product and the sum separately (sqlite-vec's scalar loop), so a multiply and an add
+            # are two instructions here and the instruction rate is the roofline
+            F32_VALU_PEAK_TFLOPS = 78.6
+            ops_g = (2.0 if metric == pvs.COSINE else 3.0) * n_it * D * b_it  # one multiply + one add (L2: + one subtract) per row, component and query, each rounded
+            under_g = None
+            if not args.no_peaks:
+                try:
+                    under_g = sample_clock_and_power(lambda i: ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG), lambda: None, seconds=1.5)
+                except Exception as e:  # noqa: BLE001
+                    under_g = {"error": str(e)}
+            tf_g = ops_g / (sms_g * 1e-3) / 1e12 if pg_.scan_launches else 0.0
+            rec = {"config": {"workload": f"per-item AVG: {n_it}x{D} f16 rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
+                              "batch": b_it, "k": k_it},
+                   "what": "the reference's exact mode per item over FLOAT rows: every (row, query) distance in the reference's f32 order, GROUP BY file, AVG, page",
+                   "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
+                   "dtype": "f32 chains over f16 rows", "data": "synthetic",
+                   "roofline": {"bound": "valu", "achieved": round(tf_g, 1), "peak": F32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf_g / F32_VALU_PEAK_TFLOPS, 4),
+                                "traffic": None, "peak_is": "packed-f32 instruction rate (unfused multiply, add); datasheet FMA peak 157.3",
+                                "kernel": "k_exact_wide<f16, 32 queries> (every row x query exact)", "launches": int(pg_.scan_launches),
+                                "avg_launch_ms": round(sms_g, 4), "algorithmic_flops_per_launch": int(ops_g), "kernel_events": "timed region",
+                                "hbm_frac_of_the_rows_once": round(n_it * D * 2 / (sms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pg_.scan_launches else 0.0,
+                                **({"under_load": under_g} if under_g else {}),
+                                **({"power": {"sclk_mhz": under_g["sclk_mhz"], "socket_power_w": under_g["socket_power_w"], "nominal_sclk_mhz": NOMINAL_SCLK_MHZ,
+                                              "valu_frac_of_clock_scaled_peak": round(tf_g / (F32_VALU_PEAK_TFLOPS * under_g["sclk_mhz"] / NOMINAL_SCLK_MHZ), 4)}}
+                                   if under_g and under_g.get("sclk_mhz") else {})}}
+            if not args.no_verify:  # one column against the oracle over ALL rows (scored chunk by chunk), aggregated and ranked as SQLite does
+                import oracle as orc_g
+
+                t_o = time.time()
+                thr_g = min(os.cpu_count() or 1, 256)
+                omet_g = orc_g.COSINE if metric == pvs.COSINE else orc_g.L2
+                col = b_it - 1
+                dd = np.concatenate([orc_g.score_all(orc_g.F16, omet_g, ixg.read_rows(off, min(args.chunk_rows, n_it - off)), qg[col], threads=thr_g)
+                                     for off in range(0, n_it, args.chunk_rows)])
+                og_, ov_ = orc_g.aggregate(dd, np.concatenate(grp_all), orc_g.AGG_AVG)
+                eg_, ev_ = orc_g._rank_groups(og_, ov_, k_it)
+                rec["parity"] = {"oracle_rows": n_it, "oracle_column": col, "oracle_seconds": round(time.time() - t_o, 1),
+                                 "groups_and_f64_values_bit_exact": bool(int(gc[col]) == len(eg_) and np.array_equal(gg[col, :len(eg_)], eg_)
+                                                                         and np.array_equal(gv[col, :len(eg_)].view(np.uint64), np.asarray(ev_).view(np.uint64)))}
+            secondary.append(rec)
+            ixg.close()
         except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
             secondary.append({"error": str(e)})
         result["secondary"] = secondary
