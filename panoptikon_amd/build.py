@@ -53,7 +53,7 @@ SOURCES = [
     "pvs_score_direct.hip",
     "pvs_sparse.hip", "pvs_rrf_device.hip",
     "pvs_comm.hip",
-    "pvs_multi.hip",
+    "pvs_multi.hip", "pvs_multi_items.hip",
     "pvs_lifecycle.hip",
     "pvs_microbench.hip",
     "pvs_host.cpp",
