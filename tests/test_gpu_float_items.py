@@ -76,3 +76,27 @@ def test_float_per_item_pages_many_queries(pvs, dtype, batch, scattered):
             exp = orc.search_groups(dt, metric, hc[allowed], q[j], grp[allowed], orc.AGG_AVG, k)
             _check_groups((got[0][j], got[1][j], got[2][j]), exp, (dtype, metric, "mask", j))
     ix.close()
+
+
+@pytest.mark.parametrize("dtype,dim,n,b", [("f16", 1280, 700, 40), ("f16", 1288, 333, 33), ("f32", 1280, 450, 64), ("f32", 1536, 257, 35), ("f16", 2600, 131, 20),
+                                              ("f32", 5, 1000, 32), ("f16", 96, 127, 9), ("f32", 768, 64, 17)])
+def test_exact_wide_pitch_boundaries_and_ragged_ends(pvs, dtype, dim, n, b):
+    """k_exact_wide keeps the transposed queries in LDS: 32 per pass up to 1,280 components, 16 up to 2,560, wider rows go back to
+    k_dense_exact's 8 per pass; row counts that are not multiples of a wave's 128 / 192 rows (lanes past the last tile re-read it and
+    write nothing), one-slab rows, batches that end in a 16-query or an 8-query pass.  Every distance against the oracle."""
+    dt = {"f16": pvs.F16, "f32": pvs.F32}[dtype]
+    rows = orc.synth_rows(300 + dim, 0, n, dim)
+    rows[n // 3] = 0.0
+    q = orc.synth_rows(301 + dim, 0, b, dim)
+    ix = pvs.VectorIndex(dt, dim)
+    ix.add_f32(rows)
+    hc = rows.astype(np.float16) if dt == pvs.F16 else rows
+    for metric in (pvs.COSINE, pvs.L2):
+        got = ix.score_batch(q, metric)
+        assert got.shape == (n, b)
+        for j in range(b):
+            exp = orc.score_all(dt, metric, hc, q[j])
+            assert np.array_equal(np.isnan(got[:, j]), np.isnan(exp)), (dtype, dim, metric, j)
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok, j].view(np.uint32), exp[ok].view(np.uint32)), (dtype, dim, metric, j)
+    ix.close()
