@@ -41,7 +41,7 @@ SOURCES = [
     "pvs_scan_f32_mid.hip",
     "pvs_scan_f32_large.hip",
     "pvs_dense.hip",
-    "pvs_dense_exact.hip", "pvs_exact_wide.hip",
+    "pvs_dense_exact.hip", "pvs_dense_exact2.hip", "pvs_exact_wide.hip",
     "pvs_direct.hip",
     "pvs_direct_i8.hip",
     "pvs_direct_f16.hip",

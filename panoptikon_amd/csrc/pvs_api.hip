@@ -27,7 +27,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
     "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
     "direct_unit", "direct_static_pct", "direct_max_nq", "dense_full_sort", "dense_page_first", "no_flag_poll", "poll_late_pages",
-    "no_exact_wide", "no_agg8",
+    "no_exact_wide", "no_agg8", "no_dense2",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;

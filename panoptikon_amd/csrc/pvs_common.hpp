@@ -87,6 +87,7 @@ enum PvsDbg {
     PVS_DBG_POLL_LATE_PAGES,       // (a counter) polled searches whose flag word reached host memory before every word of its page had
     PVS_DBG_NO_EXACT_WIDE,         // dense exact path, float rows: 8 queries per pass through LDS (k_dense_exact) also for 9+ queries
     PVS_DBG_NO_AGG8,               // per-item aggregation of a distance matrix: one thread per (group, column) also when the columns are a multiple of 8
+    PVS_DBG_NO_DENSE2,             // dense exact path, 8 float queries: one row per lane (k_dense_exact) instead of two (k_dense_exact2)
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

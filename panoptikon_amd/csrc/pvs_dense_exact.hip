@@ -336,6 +336,13 @@ hipError_t pvs_launch_dense_exact(int dtype, int metric, const uint8_t *rows, ui
         if (e != hipSuccess) return e;
         k.qinfo = qinfo + q0;
         k.out_col = out_col + q0;
+        if (g == 8 && dtype != PVS_I8 && pvs_dense_exact2_fits(stride, esz) && !pvs_dbg(PVS_DBG_NO_DENSE2)) {
+            // eight float queries: two rows per lane share every query read (pvs_dense_exact2.hip)
+            e = pvs_launch_dense_exact2(dtype, metric, rows, stride, n, norm2, qpad_scratch, k.ctr, k.qinfo, out, out_ld, k.out_col, n_cu, s);
+            if (e != hipSuccess) return e;
+            q0 += g;
+            continue;
+        }
         e = dtype == PVS_I8    ? launch_nq<PVS_I8>(k, g, metric, grid, s)
             : dtype == PVS_F16 ? launch_nq<PVS_F16>(k, g, metric, grid, s)
                                : launch_nq<PVS_F32>(k, g, metric, grid, s);

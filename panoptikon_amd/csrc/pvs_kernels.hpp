@@ -40,6 +40,10 @@ hipError_t pvs_launch_prep_queries(int index_dtype, int qdtype, const void *quer
 // qpad_scratch: pvs_dense_exact_scratch_bytes() of device memory, reused launch after launch on `s`.
 constexpr uint32_t PVS_DENSE_NQ = 8;  // float rows; int8 rows (the out-of-range fallback) take 4
 uint64_t pvs_dense_exact_scratch_bytes(uint32_t stride, uint32_t esz);
+// exactly 8 float queries, two rows per lane (pvs_dense_exact2.hip); qpad / ctr: pvs_launch_dense_exact's scratch, prepared by it
+bool pvs_dense_exact2_fits(uint32_t stride, uint32_t esz);
+hipError_t pvs_launch_dense_exact2(int dtype, int metric, const uint8_t *rows, uint32_t stride, uint64_t n, const float *norm2, const float *qpad, uint32_t *ctr,
+                                   const QInfo *qinfo, float *out, uint32_t out_ld, uint32_t out_col, uint32_t n_cu, hipStream_t s);
 // 9..32 queries over float rows in one pass, four rows per lane (pvs_exact_wide.hip)
 constexpr uint32_t PVS_EXACT_WIDE_NQ = 32;
 uint64_t pvs_exact_wide_scratch_bytes(uint32_t stride, uint32_t esz);

@@ -79,11 +79,14 @@ def test_float_per_item_pages_many_queries(pvs, dtype, batch, scattered):
 
 
 @pytest.mark.parametrize("dtype,dim,n,b", [("f16", 1280, 700, 40), ("f16", 1288, 333, 33), ("f32", 1280, 450, 64), ("f32", 1536, 257, 35), ("f16", 2600, 131, 20),
-                                              ("f32", 5, 1000, 32), ("f16", 96, 127, 9), ("f32", 768, 64, 17)])
+                                              ("f32", 5, 1000, 32), ("f16", 96, 127, 9), ("f32", 768, 64, 17), ("f16", 768, 700, 8), ("f32", 300, 129, 8),
+                                              ("f16", 1024, 333, 8), ("f32", 5, 1000, 8), ("f16", 1030, 200, 8), ("f32", 768, 4097, 48), ("f16", 40, 70000, 8)])
 def test_exact_wide_pitch_boundaries_and_ragged_ends(pvs, dtype, dim, n, b):
     """k_exact_wide keeps the transposed queries in LDS: 32 per pass up to 1,280 components, 16 up to 2,560, wider rows go back to
     k_dense_exact's 8 per pass; row counts that are not multiples of a wave's 128 / 192 rows (lanes past the last tile re-read it and
-    write nothing), one-slab rows, batches that end in a 16-query or an 8-query pass.  Every distance against the oracle."""
+    write nothing), one-slab rows, batches that end in a 16-query or an 8-query pass.  Eight queries take k_dense_exact2 (two rows
+    per lane, half-slab stages gathered by the LDS-DMA) while 8 padded queries fit beside its ring (pitch <= 1,024 components), the
+    one-row form beyond; both must agree.  Every distance against the oracle."""
     dt = {"f16": pvs.F16, "f32": pvs.F32}[dtype]
     rows = orc.synth_rows(300 + dim, 0, n, dim)
     rows[n // 3] = 0.0
@@ -94,6 +97,13 @@ def test_exact_wide_pitch_boundaries_and_ragged_ends(pvs, dtype, dim, n, b):
     for metric in (pvs.COSINE, pvs.L2):
         got = ix.score_batch(q, metric)
         assert got.shape == (n, b)
+        if b % 8 == 0:
+            pvs.debug_set("no_dense2", 1)
+            try:
+                old = ix.score_batch(q, metric)
+            finally:
+                pvs.debug_set("no_dense2", 0)
+            assert np.array_equal(got.view(np.uint32), old.view(np.uint32)), (dtype, dim, metric, "one row per lane")
         for j in range(b):
             exp = orc.score_all(dt, metric, hc, q[j])
             assert np.array_equal(np.isnan(got[:, j]), np.isnan(exp)), (dtype, dim, metric, j)
