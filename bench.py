@@ -945,6 +945,44 @@ def main():
                                                                          and np.array_equal(gv[col, :len(eg_)].view(np.uint64), np.asarray(ev_).view(np.uint64)))}
             secondary.append(rec)
             ixg.close()
+            # (f) similar_to at the reference's measured scale (filters/item_similarity.rs:432-581; its worst performer: 9.5-31 s per call
+            # at ~690k vectors, docs/or-composition-penalty.md:225): the 8 stored vectors of one item against every other row, AVG per
+            # item, page of 100 — int8 rows (quant mode)
+            n_sim, per_item, k_sim = 690_000, 8, 100
+            ixs = pvs.VectorIndex(pvs.I8, D, device=device, capacity_rows=n_sim)
+            ixs.set_scale(scale)
+            sts = pvs.DeviceBuffer(n_sim * D * 4, device)
+            L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, 0, n_sim, D, sts.ptr))
+            g_sim = np.arange(n_sim, dtype=np.int64) // per_item
+            L.check(lib.pvs_index_add_f32(ixs._h, sts.ptr, n_sim, None, g_sim.ctypes.data, L.DEVICE))
+            sts.free()
+            ixs.sync()
+            tg = np.arange(per_item * 1000, per_item * 1001, dtype=np.int64)  # every vector of item 1000 (row ids = row numbers)
+            for _ in range(5):
+                ixs.similar_to(tg, k_sim, metric, pvs.AGG_AVG)
+            lat = []
+            for _ in range(100):
+                t_l = time.perf_counter()
+                sg, sv = ixs.similar_to(tg, k_sim, metric, pvs.AGG_AVG)
+                lat.append(time.perf_counter() - t_l)
+            lat = np.sort(np.array(lat)) * 1e3
+            rec = {"config": {"workload": f"similar_to: {n_sim}x{D} i8 rows, {per_item} vectors per item, {per_item} target vectors, AVG per item, {args.metric}, k={k_sim}",
+                              "rows": n_sim, "dim": D, "targets": per_item, "k": k_sim},
+                   "what": "the reference's similar_to at its measured scale (9.5-31 s per call there): target vectors x every other row, per-item AVG, page",
+                   "metric": "calls_per_sec", "value": round(1e3 / float(lat[50]), 1), "unit": "calls/s", "steps": 100, "ms_per_step": round(float(lat[50]), 4),
+                   "latency_ms": {"p50": round(float(lat[50]), 4), "p99": round(float(lat[98]), 4)}, "dtype": "i8", "data": "synthetic",
+                   "roofline": {"bound": "hbm", "achieved": round(n_sim * D / (float(lat[50]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(n_sim * D / (float(lat[50]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                "kernel": "whole call (gather targets, k_scan MODE 2 scorer, fan-out aggregate, page ranking) against the bytes of the rows once",
+                                "algorithmic_bytes_per_launch": int(n_sim * D)}}
+            if not args.no_verify:
+                import oracle as orc_s
+
+                eg_s, ev_s = orc_s.similar_to(orc_s.I8, orc_s.COSINE if metric == pvs.COSINE else orc_s.L2, ixs.read_rows(0, n_sim), [int(x) for x in tg], g_sim,
+                                              orc_s.AGG_AVG, k_sim)
+                rec["parity"] = {"oracle_rows": n_sim, "groups_and_f64_values_bit_exact": bool(np.array_equal(sg, eg_s) and np.array_equal(np.asarray(sv).view(np.uint64), np.asarray(ev_s).view(np.uint64)))}
+            secondary.append(rec)
+            ixs.close()
         except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
             secondary.append({"error": str(e)})
         result["secondary"] = secondary
