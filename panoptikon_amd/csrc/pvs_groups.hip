@@ -834,10 +834,82 @@ __global__ __launch_bounds__(256) void k_merge_group_pages(const int64_t *g, con
     }
     if (tid == 0) out_c[q] = nout;
 }
-bool pvs_merge_group_pages_supported(uint32_t S, uint32_t k) { return (uint64_t)S * k <= 4096; }
+// Larger unions (4,096 < S * k <= 32,768: pages of thousands of files from 8 shards): every shard's page is already in page order,
+// so an entry's place in the union is its place in its own page plus, for every other shard, the number of that shard's entries in
+// front of it — one binary search per other shard (round 5; until then these pages went to the host).  The pages are staged from the
+// pinned block into device memory first (sortable value bits, inverted key, group, raw value bits): the searches then run in L2.
+struct GPEntry {
+    unsigned long long vb, kb;
+    long long g;
+    unsigned long long raw;
+};
+__global__ __launch_bounds__(256) void k_stage_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch,
+                                                           uint32_t k, GPEntry *st) {
+    const uint32_t q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S * k) return;
+    const uint32_t s = e / k, i = e - s * k;
+    GPEntry o{~0ull, ~0ull, 0x7fffffffffffffffll, 0ull};
+    if (i < min(cnt[(size_t)s * batch + q], k)) {
+        const size_t at = (size_t)s * batch * k + (size_t)q * k + i;
+        const double raw = v[at], val = raw == 0.0 ? 0.0 : raw;  // (-0 and +0 tie)
+        unsigned long long b = (unsigned long long)__double_as_longlong(val);
+        b = val != val ? ~0ull - 1 : ((b >> 63) ? ~b : (b | 0x8000000000000000ull));
+        o.vb = b;
+        o.kb = key ? ~((unsigned long long)key[at] ^ 0x8000000000000000ull) : 0ull;
+        o.g = g[at];
+        o.raw = (unsigned long long)__double_as_longlong(raw);
+    }
+    st[((size_t)q * S + s) * k + i] = o;
+}
+__device__ static inline bool gp_less(const GPEntry &a, const GPEntry &b) { return a.vb != b.vb ? a.vb < b.vb : a.kb != b.kb ? a.kb < b.kb : a.g < b.g; }
+__global__ __launch_bounds__(256) void k_rankmerge_group_pages(const GPEntry *st, const uint32_t *cnt, uint32_t S, uint32_t batch, uint32_t k, int64_t *out_g,
+                                                               double *out_v, uint32_t *out_c) {
+    const uint32_t q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    uint32_t total = 0;
+    for (uint32_t s = 0; s < S; s++) total += min(cnt[(size_t)s * batch + q], k);
+    const uint32_t nout = min(total, k);
+    if (e == 0) out_c[q] = nout;
+    if (e < k && e >= nout) {  // padding behind a short union
+        out_g[(size_t)q * k + e] = -1;
+        out_v[(size_t)q * k + e] = __builtin_nan("");
+    }
+    if (e >= S * k) return;
+    const uint32_t s = e / k, i = e - s * k;
+    if (i >= min(cnt[(size_t)s * batch + q], k)) return;
+    const GPEntry *base = st + (size_t)q * S * k;
+    const GPEntry me = base[(size_t)s * k + i];
+    uint32_t rank = i;
+    for (uint32_t o = 0; o < S && rank < k; o++) {
+        if (o == s) continue;
+        const GPEntry *pg = base + (size_t)o * k;
+        uint32_t lo = 0, hi = min(cnt[(size_t)o * batch + q], k);
+        while (lo < hi) {  // entries of shard o in front of me (groups are disjoint across shards: no ties)
+            const uint32_t mid = (lo + hi) >> 1;
+            if (gp_less(pg[mid], me)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank < k) {
+        out_g[(size_t)q * k + rank] = me.g;
+        out_v[(size_t)q * k + rank] = __longlong_as_double((long long)me.raw);
+    }
+}
+constexpr uint32_t PVS_GROUP_MERGE_LDS = 4096, PVS_GROUP_MERGE_MAX = 32768;
+bool pvs_merge_group_pages_supported(uint32_t S, uint32_t k) { return (uint64_t)S * k <= PVS_GROUP_MERGE_MAX; }
 hipError_t pvs_launch_merge_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch, uint32_t k,
                                         int64_t *out_g, double *out_v, uint32_t *out_c, hipStream_t s) {
     if (batch == 0) return hipSuccess;
+    if ((uint64_t)S * k > PVS_GROUP_MERGE_LDS) {
+        GPEntry *st = nullptr;
+        hipError_t e = pvs_scratch_alloc((void **)&st, (size_t)batch * S * k * sizeof(GPEntry));
+        if (e != hipSuccess) return e;
+        const dim3 grid((S * k + 255) / 256, batch);
+        hipLaunchKernelGGL(k_stage_group_pages, grid, dim3(256), 0, s, g, v, key, cnt, S, batch, k, st);
+        hipLaunchKernelGGL(k_rankmerge_group_pages, grid, dim3(256), 0, s, st, cnt, S, batch, k, out_g, out_v, out_c);
+        e = hipGetLastError();
+        pvs_scratch_free_on(st, s);
+        return e;
+    }
     uint32_t cap = 64;
     while (cap < S * k) cap <<= 1;
     const size_t lds = (size_t)cap * 28;

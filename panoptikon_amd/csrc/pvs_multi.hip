@@ -17,7 +17,7 @@
 // kernel per shard on the source device + a peer copy; candidate masks resident on devices[0] are split there by one gather per
 // shard over the expanded segment table (ensure_shard_rows) and reach the shards by peer copies; the shards write their per-item
 // pages into a pinned block, look up the second sort key of the entries on their own device, and devices[0] merges the pages in
-// one LDS sort per query (k_merge_group_pages; S * k <= 4,096, else the host merge).  Row weights arrive in host memory by the
+// one LDS sort per query (k_merge_group_pages; S * k <= 4,096) or by rank (k_rankmerge_group_pages, <= 32,768; beyond: the host).  Row weights arrive in host memory by the
 // ABI and are split there.
 #include <thread>
 

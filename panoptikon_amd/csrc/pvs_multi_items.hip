@@ -219,7 +219,7 @@ struct GroupPages {
         oc = c + (size_t)S * batch;
     }
 };
-// the shards' pages -> the caller's page: on devices[0] when one LDS sort takes them (S * k <= 4,096), else on the host
+// the shards' pages -> the caller's page: on devices[0] (one LDS sort for S * k <= 4,096, a merge by rank up to 32,768), else on the host
 static pvs_status merge_group_pages(pvs_index *ix, GroupPages &pg, bool keyed, uint32_t S, uint32_t batch, uint32_t k, int64_t *out_groups, double *out_values,
                                     uint32_t *out_count) {
     if (!pvs_merge_group_pages_supported(S, k) || pvs_dbg(PVS_DBG_MULTI_HOST_PAGES)) {

@@ -861,10 +861,22 @@ def test_per_item_work_of_a_multi_device_index_stays_on_the_devices(pvs):
                 else:
                     ei, ed = orc.topk(d[allowed], k, ids=ids[allowed])
                 assert fc[j] == k and np.array_equal(fi[j], ei) and np.array_equal(fd[j].view(np.uint32), ed.view(np.uint32)), (tag, keyed, j, "row page")
-        # k beyond one LDS sort of the merge (S * k > 4,096): the host merge answers, same contract
-        kk = 2100
-        og, ov, oc = ix.search_groups(hq[:1], kk, pvs.L2, pvs.AGG_AVG)
-        eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[0], grp, orc.AGG_AVG, kk, order_keys=keys)
-        assert oc[0] == len(eg) and np.array_equal(og[0, : oc[0]], eg) and np.array_equal(ov[0, : oc[0]].view(np.uint64), ev.view(np.uint64)), tag
+        # k beyond one LDS sort of the merge (4,096 < S * k <= 32,768): the shards' pages are merged by rank on devices[0] (round 5:
+        # every entry's place = its place in its own page + the entries of the other pages in front of it), same contract, and the
+        # same bits as the host merge; a page longer than the union (kk > files) comes back short
+        for kk, agg, oagg in ((2100, pvs.AGG_AVG, orc.AGG_AVG), (2999, pvs.AGG_MAX, orc.AGG_MAX), (4000, pvs.AGG_AVG, orc.AGG_AVG)):
+            got = {}
+            for host_route in (0, 1):
+                pvs.debug_set("multi_host_pages", host_route)
+                try:
+                    got[host_route] = ix.search_groups(hq[:2], kk, pvs.L2, agg)
+                finally:
+                    pvs.debug_set("multi_host_pages", 0)
+            for x, y in zip(got[0], got[1]):
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (tag, kk, agg, "rank merge == host merge")
+            og, ov, oc = got[0]
+            for j in range(2):
+                eg, ev = orc.search_groups(orc.I8, orc.L2, codes, hq[j], grp, oagg, kk, order_keys=keys)
+                assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg) and np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), (tag, kk, agg, j)
         dmask.free()
         ix.close()
