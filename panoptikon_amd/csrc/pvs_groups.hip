@@ -428,14 +428,20 @@ __device__ static inline unsigned long long gm_key(double v) {
     return k;
 }
 // (value of group g in column col: vals[g * gs + col * cs] — group-major gs = ncol, cs = 1; column-major gs = 1, cs = n_groups)
-__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, size_t gs, size_t cs, uint32_t j, unsigned long long *thr) {
+// m: samples taken (2,048 .. GM_M, a power of two: the fewest that put the threshold's rank j at 32 or more — a quarter of the
+// gathers and of the select for 230k files and a page of 10, 20 -> 10 us)
+__global__ __launch_bounds__(GM_SORT_THREADS) void k_gm_thresholds(const double *vals_t, uint32_t n_groups, size_t gs, size_t cs, uint32_t j, uint32_t m,
+                                                                   unsigned long long *thr, uint32_t *count) {
     __shared__ unsigned long long s[GM_M];
     __shared__ uint32_t hist[256], misc[4];
     const uint32_t col = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t i = tid; i < GM_M; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / GM_M) * gs + col * cs]);
+    for (uint32_t i = tid; i < m; i += GM_SORT_THREADS) s[i] = gm_key(vals_t[(size_t)((uint64_t)i * n_groups / m) * gs + col * cs]);
     __syncthreads();
-    const unsigned long long t = wg_radix_kth_u64(s, GM_M, j + 1, hist, misc, 16);  // the sample's j-th smallest (0-based), give or take 16 samples
-    if (tid == 0) thr[col] = t >= ~0ull - 1 ? 0ull : t;  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
+    const unsigned long long t = wg_radix_kth_u64(s, m, j + 1, hist, misc, max(1u, j / 8));  // the sample's j-th smallest (0-based), give or take an eighth
+    if (tid == 0) {
+        thr[col] = t >= ~0ull - 1 ? 0ull : t;  // a threshold among the NULL / absent groups: a page of nothing -> full ranking
+        count[(size_t)col * 32] = 0;            // (the column's page counter for the compaction behind this launch: one fill less per ranking)
+    }
 }
 // grid (row blocks, ceil(ncol / 32)); a workgroup walks `per_wg` consecutive groups, lane = column of its 32-column chunk
 __global__ __launch_bounds__(256) void k_gm_compact(const double *vals_t, uint32_t n_groups, uint32_t ncol, const unsigned long long *thr, uint32_t per_wg,
@@ -648,12 +654,13 @@ hipError_t pvs_gm_rank(const double *d_vals_t, uint32_t n_groups, uint32_t ncol,
     unsigned long long *keys = (unsigned long long *)((uint8_t *)count + (size_t)ncol * 128);
     uint32_t *slots = (uint32_t *)((uint8_t *)keys + (size_t)ncol * GM_CAP * 8);
     const uint64_t target = gm_target(k);
-    const uint32_t j = (uint32_t)std::min<uint64_t>(GM_M - 1, (uint64_t)((double)GM_M * 2.0 * (double)target / (double)n_groups) + 4);
-    hipError_t e = hipMemsetAsync(count, 0, (size_t)ncol * 128, s);
-    if (e != hipSuccess) return e;
+    uint32_t m = 2048;
+    while (m < GM_M && (double)m * 2.0 * (double)target / (double)n_groups < 32.0) m <<= 1;
+    const uint32_t j = (uint32_t)std::min<uint64_t>(m - 1, (uint64_t)((double)m * 2.0 * (double)target / (double)n_groups) + 4);
+    hipError_t e = hipSuccess;
     if (ncol == 1) column_major = true;  // (the same thing)
     hipLaunchKernelGGL(k_gm_thresholds, dim3(ncol), dim3(GM_SORT_THREADS), 0, s, d_vals_t, n_groups, column_major ? (size_t)1 : (size_t)ncol,
-                       column_major ? (size_t)n_groups : (size_t)1, j, thr);
+                       column_major ? (size_t)n_groups : (size_t)1, j, m, thr, count);
     const uint32_t per_wg = 1024;
     if (column_major)
         hipLaunchKernelGGL(k_gm_compact1, dim3((n_groups + 1023) / 1024, ncol), dim3(256), 0, s, d_vals_t, n_groups, thr, count, keys, slots);
