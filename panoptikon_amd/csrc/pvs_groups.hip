@@ -31,6 +31,12 @@ struct Kbn {
 //                w = pow(coalesce(conf_t,1)*coalesce(conf_o,1), cw) * pow(coalesce(lang_o,1)*coalesce(lang_t,1), lw)
 //                (a factor is dropped when its exponent is 0) and the value is SUM(d*w)/SUM(w).
 __device__ static inline double coalesce1(double v) { return v != v ? 1.0 : v; }
+__device__ static inline bool in_left_out_ranges(const FanoutWeights &fw, uint32_t row) {
+    bool in = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) in = in || (i < fw.n_ranges && row >= fw.r_lo[i] && row <= fw.r_hi[i]);
+    return in;
+}
 // One value per (group, output column).  A workgroup owns a tile of TG consecutive groups x all output columns: it walks the
 // tile column-fastest (adjacent lanes read adjacent floats of one row of `dist`) and hands the values to the column-major output
 // through LDS, group-fastest (the direct store — adjacent lanes 8 B apart in columns that lie n_groups * 8 B apart — was one
@@ -103,6 +109,7 @@ __device__ static inline double group_value(const float *dist, uint32_t ld, uint
             for (int i = 0; i < 4; i++) {
                 if ((uint32_t)i >= m) break;
                 if (exclude && (uint32_t)(ex4[i] != 0) == skip_when) continue;
+                if (fw.n_ranges && in_left_out_ranges(fw, rw[i])) continue;
                 const double w = (double)w4[i];
 #pragma unroll
                 for (int c = 0; c < 8; c++) {
@@ -124,6 +131,7 @@ __device__ static inline double group_value(const float *dist, uint32_t ld, uint
     for (uint32_t e = e_slow; e < e_end; e++) {
         const uint32_t row = grp_rows[e];
         if (exclude && (uint32_t)(exclude[row] != 0) == skip_when) continue;  // similar_to: flagged rows; candidate mask: rows it leaves out
+        if (fw.n_ranges && in_left_out_ranges(fw, row)) continue;
         const uint32_t c0 = fanout ? 0u : q, c1 = fanout ? fanout : q + 1;
         for (uint32_t c = c0; c < c1; c++) {
             double w = 1.0;
@@ -275,7 +283,7 @@ hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
                                       int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when) {
     if (n_groups == 0) return hipSuccess;
-    if (!fanout && !fw.on && n_cols % 8 == 0 && ld % 4 == 0 && ((uintptr_t)dist & 15) == 0 && !pvs_dbg(PVS_DBG_NO_AGG8)) {
+    if (!fanout && !fw.on && !fw.n_ranges && n_cols % 8 == 0 && ld % 4 == 0 && ((uintptr_t)dist & 15) == 0 && !pvs_dbg(PVS_DBG_NO_AGG8)) {
         const dim3 grid((n_groups + 63) / 64, (n_cols / 8 + 3) / 4);
         if (weights || (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX))
             hipLaunchKernelGGL(k_group_aggregate8<0>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, n_groups, weights, exclude, agg, out, skip_when);

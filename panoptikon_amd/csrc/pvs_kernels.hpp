@@ -283,6 +283,9 @@ struct FanoutWeights {
     double cw = 0.0, lw = 0.0;
     const uint8_t *kind = nullptr;    // [rows] PVS_KIND_*; gates below apply when set
     uint32_t skip_i2i = 0, skip_t2t = 0;
+    // rows left out of the join (the target item's own rows) as up to four ranges [lo, hi] instead of a byte per row: an item's
+    // vectors are stored side by side, and zeroing + marking a byte map of the whole index cost two fills per similar_to
+    uint32_t n_ranges = 0, r_lo[4] = {0, 0, 0, 0}, r_hi[4] = {0, 0, 0, 0};
 };
 // `exclude` [rows] with skip_when == 1: rows whose byte is non-zero are left out (similar_to: the target's own rows);
 // with skip_when == 0 it is a candidate mask: rows whose byte is zero are left out, and a group without any candidate

@@ -76,16 +76,26 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
         } else {
             HIP_TRY(hipMemcpyAsync(d_q, tg.hq.data(), tg.hq.size(), hipMemcpyHostToDevice, c->stream));
         }
-        HIP_TRY(pvs_scratch_alloc((void **)&d_ex, ix->n + 1));
-        HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
-        {  // one fill per RUN of excluded rows (an item's vectors are stored side by side: eight targets were eight 1-byte fills, 35 us)
+        {  // the rows left out: runs of neighbours (an item's vectors are stored side by side)
             std::vector<uint32_t> ex(excluded);
             std::sort(ex.begin(), ex.end());
+            std::vector<std::pair<uint32_t, uint32_t>> runs;
             for (size_t i = 0; i < ex.size();) {
                 size_t j = i + 1;
                 while (j < ex.size() && ex[j] <= ex[j - 1] + 1) j++;
-                HIP_TRY(hipMemsetAsync(d_ex + ex[i], 1, (size_t)(ex[j - 1] - ex[i]) + 1, c->stream));
+                runs.emplace_back(ex[i], ex[j - 1]);
                 i = j;
+            }
+            if (runs.size() <= 4) {  // ... travel as kernel arguments
+                fw.n_ranges = (uint32_t)runs.size();
+                for (size_t i = 0; i < runs.size(); i++) {
+                    fw.r_lo[i] = runs[i].first;
+                    fw.r_hi[i] = runs[i].second;
+                }
+            } else {  // scattered rows: a byte per row, one fill per run
+                HIP_TRY(pvs_scratch_alloc((void **)&d_ex, ix->n + 1));
+                HIP_TRY(hipMemsetAsync(d_ex, 0, ix->n + 1, c->stream));
+                for (const auto &r : runs) HIP_TRY(hipMemsetAsync(d_ex + r.first, 1, (size_t)(r.second - r.first) + 1, c->stream));
             }
         }
         HIP_TRY(pvs_scratch_alloc((void **)&d_m, std::max<size_t>((size_t)ix->n * n_targets * 4, 4)));
