@@ -326,6 +326,52 @@ pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uin
     return st;
 }
 
+// The device ranking writes its pages into the context's pinned block.  The host does not sleep on the stream for them: it poisons
+// every word the kernels will write (values they never write) and reads the pages when no poisoned word is left — the wake-up through
+// the runtime costs more than the pages' trip over PCIe (as pvs_search's one-launch route, pvs_search_host.hip; round 5).  A column
+// whose flag comes back 0 goes to the full ranking; 20 ms without an answer, profiling and pvs_debug_set("no_flag_poll", 1) wait for the
+// stream.  Whatever earlier kernels of the stream wrote to the pinned block (the scorers' out-of-range flag) is final once a later
+// kernel's page has landed: a kernel's stores are performed before the next kernel of its stream starts.
+namespace {
+constexpr int64_t PAGE_POISON_G = INT64_MIN + 0x5EA1;
+constexpr uint64_t PAGE_POISON_V = 0x7ff85ea15ea15ea1ull;  // (a NaN payload no aggregate produces)
+constexpr uint32_t PAGE_POISON_F = 0xffffffffu;
+bool pages_polled(const pvs_index *ix) { return !ix->profiling && !pvs_dbg(PVS_DBG_NO_FLAG_POLL); }
+void pages_poison(uint8_t *io, size_t off_g, size_t off_v, size_t off_f, uint32_t ncol, uint32_t k) {
+    volatile int64_t *g = (volatile int64_t *)(io + off_g);
+    volatile uint64_t *v = (volatile uint64_t *)(io + off_v);
+    volatile uint32_t *f = (volatile uint32_t *)(io + off_f);
+    for (size_t i = 0; i < (size_t)ncol * k; i++) {
+        g[i] = PAGE_POISON_G;
+        v[i] = PAGE_POISON_V;
+    }
+    for (uint32_t q = 0; q < ncol; q++) f[q] = PAGE_POISON_F;
+    std::atomic_thread_fence(std::memory_order_release);
+}
+// true: every column's flag is there and every page with flag 1 has landed
+bool pages_wait(uint8_t *io, size_t off_g, size_t off_v, size_t off_f, uint32_t ncol, uint32_t k) {
+    volatile int64_t *g = (volatile int64_t *)(io + off_g);
+    volatile uint64_t *v = (volatile uint64_t *)(io + off_v);
+    volatile uint32_t *f = (volatile uint32_t *)(io + off_f);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; spin++) {
+        bool all = true;
+        for (uint32_t q = 0; q < ncol && all; q++) {
+            const uint32_t fl = f[q];
+            all = fl != PAGE_POISON_F;
+            if (all && fl)
+                for (size_t i = (size_t)q * k; i < (size_t)(q + 1) * k && all; i++) all = g[i] != PAGE_POISON_G && v[i] != PAGE_POISON_V;
+        }
+        if (all) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return true;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return false;
+    }
+}
+}  // namespace
+
 // Columns of group values, column-major d_vals [ncol][G] or group-major d_vals_t [G][ncol] (the fused scorer's layout; exactly
 // one of the two is given) -> each column's first k groups on the host.
 static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals, const double *d_vals_t, uint32_t ncol, uint32_t k, int64_t *d_og, double *d_ov,
@@ -348,9 +394,11 @@ static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals,
             PVS_TRY(ctx_pinned_io(c, need));
             HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(ncol)));
             const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+            const bool poll = pages_polled(ix);
+            if (poll) pages_poison(c.h_io, off_g, off_v, off_f, ncol, k);
             HIP_TRY(pvs_gm_rank(d_vals_t, G, ncol, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
                                 (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), c.stream));
-            HIP_TRY(hipStreamSynchronize(c.stream));
+            if (!poll || !pages_wait(c.h_io, off_g, off_v, off_f, ncol, k)) HIP_TRY(hipStreamSynchronize(c.stream));
             const uint32_t *fl = (const uint32_t *)(c.h_io + off_f);
             for (uint32_t q = 0; q < ncol; q++)
                 if (fl[q]) {
@@ -367,9 +415,11 @@ static pvs_status rank_values(pvs_index *ix, SearchCtx &c, const double *d_vals,
             PVS_TRY(ctx_pinned_io(c, need));
             HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(ncol)));
             const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+            const bool poll = pages_polled(ix);
+            if (poll) pages_poison(c.h_io, off_g, off_v, off_f, ncol, k);
             HIP_TRY(pvs_gm_rank(d_vals, G, ncol, k, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
                                 (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), c.stream, true));
-            HIP_TRY(hipStreamSynchronize(c.stream));
+            if (!poll || !pages_wait(c.h_io, off_g, off_v, off_f, ncol, k)) HIP_TRY(hipStreamSynchronize(c.stream));
             const uint32_t *fl = (const uint32_t *)(c.h_io + off_f);
             for (uint32_t q = 0; q < ncol; q++)
                 if (fl[q]) {

@@ -107,7 +107,8 @@ pvs_status similar_core(pvs_index *ix, const SimilarTargets &tg, uint32_t n_targ
         *(volatile uint32_t *)h_flag = 0;
         PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m, h_flag));
         PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, a.agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // (the page has landed — polled in pinned memory or waited for, rank_values — so the scorer's flag, written by an earlier kernel
+        //  of the stream, is final)
         if (*(volatile uint32_t *)h_flag) {
             PVS_TRY(dense_chunk(ix, *c, n_targets, pad, metric, d_m, nullptr, true));
             PVS_TRY(aggregate_and_rank(ix, *c, d_m, n_targets, n_targets, a.agg, nullptr, d_ex, k, out_groups, out_values, out_count, fw));
