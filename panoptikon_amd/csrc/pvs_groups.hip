@@ -859,8 +859,9 @@ struct GPEntry {
     unsigned long long raw;
 };
 __global__ __launch_bounds__(256) void k_stage_group_pages(const int64_t *g, const double *v, const int64_t *key, const uint32_t *cnt, uint32_t S, uint32_t batch,
-                                                           uint32_t k, GPEntry *st) {
+                                                           uint32_t k, GPEntry *st, uint32_t *cnt_dev) {
     const uint32_t q = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e < S) cnt_dev[(size_t)e * batch + q] = cnt[(size_t)e * batch + q];  // (the merge reads the counts many times: not from pinned host memory)
     if (e >= S * k) return;
     const uint32_t s = e / k, i = e - s * k;
     GPEntry o{~0ull, ~0ull, 0x7fffffffffffffffll, 0ull};
@@ -916,11 +917,13 @@ hipError_t pvs_launch_merge_group_pages(const int64_t *g, const double *v, const
     if (batch == 0) return hipSuccess;
     if ((uint64_t)S * k > PVS_GROUP_MERGE_LDS) {
         GPEntry *st = nullptr;
-        hipError_t e = pvs_scratch_alloc((void **)&st, (size_t)batch * S * k * sizeof(GPEntry));
+        const size_t st_bytes = (size_t)batch * S * k * sizeof(GPEntry);
+        hipError_t e = pvs_scratch_alloc((void **)&st, st_bytes + (size_t)S * batch * 4);
         if (e != hipSuccess) return e;
+        uint32_t *cnt_dev = (uint32_t *)((uint8_t *)st + st_bytes);
         const dim3 grid((S * k + 255) / 256, batch);
-        hipLaunchKernelGGL(k_stage_group_pages, grid, dim3(256), 0, s, g, v, key, cnt, S, batch, k, st);
-        hipLaunchKernelGGL(k_rankmerge_group_pages, grid, dim3(256), 0, s, st, cnt, S, batch, k, out_g, out_v, out_c);
+        hipLaunchKernelGGL(k_stage_group_pages, grid, dim3(256), 0, s, g, v, key, cnt, S, batch, k, st, cnt_dev);
+        hipLaunchKernelGGL(k_rankmerge_group_pages, grid, dim3(256), 0, s, st, cnt_dev, S, batch, k, out_g, out_v, out_c);
         e = hipGetLastError();
         pvs_scratch_free_on(st, s);
         return e;
