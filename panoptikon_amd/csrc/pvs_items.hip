@@ -592,6 +592,19 @@ static bool fused_groups_ok(const pvs_index *ix, uint32_t nb, const uint8_t *d_m
 // tile-crossing groups go through.
 static pvs_status fused_group_chunk(pvs_index *ix, SearchCtx &c, uint32_t nb, uint32_t batch_pad, int metric, int agg, const float *d_w, const uint8_t *d_mask,
                                     float *d_m, double *d_vals_t) {
+    if (nb <= 4 && !pvs_dbg(PVS_DBG_NO_DIRECT_SCORE)) {
+        // one to four queries: the v_dot4 stream with the fold in its tile epilogue (pvs_score_direct.hip) — the matrix-core scorer
+        // pads them to 32 and its fold walks a tile's rows serially in every query lane (690k x 768, one query: 125 us against ~90)
+        uint32_t *flag = (uint32_t *)(c.h_io + 32);
+        *(volatile uint32_t *)flag = 0;
+        span_begin(ix, c, 1, ix->n);
+        HIP_TRY(pvs_launch_score_i8_fold(metric, ix->d_rows, ix->stride, ix->dim, ix->n, ix->d_norm2, c.d_qexact, c.d_qinfo, nb, d_m, nb, flag, ix->d_tile_grp, d_w,
+                                         d_mask, d_vals_t, nb, agg, (uint32_t)ix->n_cu, c.stream));
+        span_end(ix, c);
+        HIP_TRY(pvs_launch_group_aggregate_list(d_m, nb, nb, ix->d_grp_off, ix->d_grp_rows, ix->d_straddlers, ix->n_straddlers, d_w, d_mask, agg, d_vals_t, nb,
+                                                c.stream, d_mask ? 0u : 1u));
+        return PVS_OK;
+    }
     ScanArgs a;
     a.dtype = PVS_I8;
     a.metric = metric;

@@ -242,6 +242,10 @@ pvs_status pvs_select_topk(const float *m, uint64_t n, uint32_t ld, uint32_t nq,
 hipError_t pvs_launch_score_i8_direct(int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n_rows, const float *norm2,
                                       const void *qexact, const QInfo *qinfo, uint32_t nb, float *out, uint32_t ld, uint32_t *flag,
                                       uint32_t n_cu, hipStream_t s);
+// ... with the per-item fold in the tile epilogue (the contract of k_scan MODE 3, for 1..4 queries)
+hipError_t pvs_launch_score_i8_fold(int metric, const uint8_t *rows, uint32_t stride, uint32_t dim, uint64_t n_rows, const float *norm2, const void *qexact,
+                                    const QInfo *qinfo, uint32_t nb, float *out, uint32_t ld, uint32_t *flag, const uint4 *tile_grp, const float *weights,
+                                    const uint8_t *mask, double *fold_out, uint32_t fold_ld, int agg, uint32_t n_cu, hipStream_t s);
 // merge of per-shard pages on the device: in [world][batch][k] -> out [batch][k]
 hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_t *counts, uint32_t world,
                             uint32_t batch, uint32_t k, int64_t *out_ids, float *out_dist,

@@ -51,7 +51,7 @@ def test_fused_per_item_scorer_equals_the_oracle(pvs, dim):
     allowed = np.nonzero(mask)[0]
     keys_g = rng.integers(0, 4, len(sizes)).astype(np.int64)
     keys = np.repeat(keys_g, sizes)
-    for nb in (5, 40, 130):
+    for nb in (1, 2, 4, 5, 40, 130):  # (1..4 queries: the v_dot4 scorer with the fold in its tile epilogue; from 5 the matrix-core scorer)
         q = orc.synth_rows(70 + nb, 0, nb, dim)
         hq = orc.quantize_int8(q, scale)
         check = sorted({0, nb // 2, nb - 1})
@@ -69,7 +69,7 @@ def test_fused_per_item_scorer_equals_the_oracle(pvs, dim):
                     for j in check:
                         exp = orc.search_groups(orc.I8, om, codes, hq[j], grp, oagg, k, weights=ww, order_keys=ok)
                         _check((got[0][j], got[1][j], got[2][j]), exp, (dim, nb, keyed, metric, agg, ww is not None, j))
-                    if nb == 40:  # the round-3 route returns the same pages, bit for bit
+                    if nb in (1, 4, 40):  # the round-3 route returns the same pages, bit for bit
                         pvs.debug_set("no_fused_agg", 1)
                         try:
                             old = ix.search_groups(hq, k, metric, agg, row_weights=ww)
@@ -77,7 +77,7 @@ def test_fused_per_item_scorer_equals_the_oracle(pvs, dim):
                             pvs.debug_set("no_fused_agg", 0)
                         assert np.array_equal(old[0], got[0]) and np.array_equal(old[2], got[2])
                         assert np.array_equal(old[1].view(np.uint64), got[1].view(np.uint64))
-                    if nb == 5:  # candidate masks, from host memory and from HBM
+                    if nb in (2, 5):  # candidate masks, from host memory and from HBM
                         mg = ix.search_groups_filtered(hq, k, mask, metric, agg, row_weights=ww)
                         for j in check:
                             exp = orc.search_groups(orc.I8, om, codes[allowed], hq[j], grp[allowed], oagg, k, weights=None if ww is None else ww[allowed],
