@@ -212,8 +212,10 @@ __global__ __launch_bounds__(256) void k_group_aggregate8(const float *dist, uin
                                                           uint32_t n_groups, const float *weights, const uint8_t *exclude, int agg, double *out,
                                                           uint32_t skip_when) {
     const uint32_t n_cb = n_cols / 8, cb_per_wg = 4;
-    const uint32_t g = blockIdx.x * 64 + (threadIdx.x & 63u);
-    const uint32_t cb = blockIdx.y * cb_per_wg + (threadIdx.x >> 6);
+    // four neighbouring lanes take the four column blocks of ONE group: a row's 128 bytes are one request of the four of them (a wave
+    // per column block — 64 lanes reading 32 bytes each of 64 x 3 rows — was bound by the address unit: 16-byte lane requests)
+    const uint32_t g = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const uint32_t cb = blockIdx.y * cb_per_wg + (threadIdx.x & 3u);
     if (g >= n_groups || cb >= n_cb) return;
     Kbn sum[8], wsum;
     double ext[8];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void k_group_aggregate8(const float *dist, uin
         float w4[4];
         uint8_t ex4[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) rw[i] = (uint32_t)i < m ? grp_rows[e + i] : 0u;
+        for (int i = 0; i < 4; i++) rw[i] = (uint32_t)i < m ? (grp_rows ? grp_rows[e + i] : e + (uint32_t)i) : 0u;  // (grp_rows == nullptr: groups are runs of rows, CSR order = row order)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool on = (uint32_t)i < m;
@@ -281,14 +283,14 @@ __global__ __launch_bounds__(256) void k_group_aggregate8(const float *dist, uin
 
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when) {
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw, uint32_t skip_when, bool rows_are_runs) {
     if (n_groups == 0) return hipSuccess;
     if (!fanout && !fw.on && !fw.n_ranges && n_cols % 8 == 0 && ld % 4 == 0 && ((uintptr_t)dist & 15) == 0 && !pvs_dbg(PVS_DBG_NO_AGG8)) {
         const dim3 grid((n_groups + 63) / 64, (n_cols / 8 + 3) / 4);
         if (weights || (agg != PVS_AGG_MIN && agg != PVS_AGG_MAX))
-            hipLaunchKernelGGL(k_group_aggregate8<0>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, n_groups, weights, exclude, agg, out, skip_when);
+            hipLaunchKernelGGL(k_group_aggregate8<0>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, rows_are_runs ? nullptr : grp_rows, n_groups, weights, exclude, agg, out, skip_when);
         else
-            hipLaunchKernelGGL(k_group_aggregate8<1>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, grp_rows, n_groups, weights, exclude, agg, out, skip_when);
+            hipLaunchKernelGGL(k_group_aggregate8<1>, grid, dim3(256), 0, s, dist, ld, n_cols, grp_off, rows_are_runs ? nullptr : grp_rows, n_groups, weights, exclude, agg, out, skip_when);
         return hipGetLastError();
     }
     const uint32_t ncol_out = fanout ? 1u : n_cols;

@@ -318,7 +318,7 @@ pvs_status aggregate_and_rank(pvs_index *ix, SearchCtx &c, const float *d_m, uin
         HIP_TRY(pvs_scratch_alloc((void **)&d_ov, (size_t)k * 8));
         HIP_TRY(pvs_scratch_alloc((void **)&d_oc, 4));
         HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, fanout, ix->d_grp_off, ix->d_grp_rows, G, d_weights, d_exclude, agg, d_vals,
-                                           c.stream, fw, skip_when));
+                                           c.stream, fw, skip_when, ix->groups_are_runs));
         return rank_values(ix, c, d_vals, nullptr, ncol, k, d_og, d_ov, d_oc, out_groups, out_values, out_count);
     };
     pvs_status st = body();

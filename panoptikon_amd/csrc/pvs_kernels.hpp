@@ -297,7 +297,8 @@ struct FanoutWeights {
 constexpr unsigned long long PVS_GROUP_ABSENT = 0x7ff8a5a5a5a5a5a5ull;  // a NaN payload no arithmetic produces
 hipError_t pvs_launch_group_aggregate(const float *dist, uint32_t ld, uint32_t n_cols, uint32_t fanout, const uint32_t *grp_off,
                                       const uint32_t *grp_rows, uint32_t n_groups, const float *weights, const uint8_t *exclude,
-                                      int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1);
+                                      int agg, double *out, hipStream_t s, FanoutWeights fw = FanoutWeights(), uint32_t skip_when = 1,
+                                      bool rows_are_runs = false);  // rows_are_runs: grp_rows[e] == e (the 8-column kernel skips the indirection)
 pvs_status pvs_group_rank(const double *d_vals, const int64_t *d_group_ids, uint32_t n_groups, uint32_t k, GroupWork &w,
                           int64_t *d_out_groups, double *d_out_vals, uint32_t *d_out_count, hipStream_t s, const uint32_t *g_tinv = nullptr);
 // The groups of `list` (indices into the group CSR) only, from the dense matrix, into the group-major output out_t[group][ld_out]:
