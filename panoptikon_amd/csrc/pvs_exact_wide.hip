@@ -42,7 +42,7 @@ constexpr int WIDE_WAVES = 8;  // per workgroup: they share the LDS copy of the 
 template <int DT, int NQ, int METRIC, int R, int LC>  // LC: 16-byte chunks of a row per load batch (4: half a 128-byte line)
 __global__ __launch_bounds__(64 * WIDE_WAVES) void k_exact_wide(WideK a) {
     constexpr int PER = DT == PVS_F16 ? 8 : 4;  // components per 16-byte chunk
-    constexpr int GRP = 8;                       // independent products in front of their adds
+    constexpr int GRP = (DT == PVS_F32 && NQ == 32) ? 4 : 8;  // independent products in front of their adds (the f32 x 32 instance sits at 256 registers)
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [qld][NQ]
     for (uint32_t i = threadIdx.x; i < a.qld * (NQ / 4); i += 64 * WIDE_WAVES) ((float4 *)qs)[i] = ((const float4 *)a.qT)[i];
     __syncthreads();
@@ -174,12 +174,24 @@ __global__ __launch_bounds__(64 * WIDE_WAVES) void k_exact_wide(WideK a) {
         if (row < a.n_rows) {
             const float aa = METRIC == PVS_COSINE ? a.norm2[row] : 0.f;
             float *o = a.out + row * a.out_ld + a.out_col;
+            const bool full = a.nq == (uint32_t)NQ && (((uintptr_t)o) & 15u) == 0;  // a full pass: 16-byte stores (a dword per lane and query was 4x the write requests)
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-                if ((uint32_t)q < a.nq) {
+            for (int q4 = 0; q4 < NQ; q4 += 4) {
+                float d[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int q = q4 + i;
                     const float sum = acc[r][q >> 1][q & 1];
-                    o[q] = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, a.qinfo[q].bb) : ref_l2_finish(sum);
+                    d[i] = METRIC == PVS_COSINE ? ref_cosine_finish(sum, aa, a.qinfo[(uint32_t)q < a.nq ? q : 0].bb) : ref_l2_finish(sum);
                 }
+                if (full) {
+                    *(float4 *)(o + q4) = float4{d[0], d[1], d[2], d[3]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if ((uint32_t)(q4 + i) < a.nq) o[q4 + i] = d[i];
+                }
+            }
         }
     }
     }
