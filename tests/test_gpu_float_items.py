@@ -54,7 +54,7 @@ def test_float_per_item_pages_many_queries(pvs, dtype, batch, scattered):
     for metric in (pvs.COSINE, pvs.L2):
         for agg, oagg, weights in ((pvs.AGG_AVG, orc.AGG_AVG, None), (pvs.AGG_MAX, orc.AGG_MAX, None), (pvs.AGG_AVG, orc.AGG_AVG, w)):
             got = ix.search_groups(q, k, metric, agg, row_weights=weights)
-            for key in ("no_agg8", "no_exact_wide", "no_page_rank"):
+            for key in ("no_agg8", "no_exact_wide", "no_page_rank", "no_flag_poll"):  # (no_flag_poll: the pages waited for on the stream, not polled in pinned memory)
                 pvs.debug_set(key, 1)
                 try:
                     old = ix.search_groups(q, k, metric, agg, row_weights=weights)
