@@ -5,13 +5,13 @@
 // k_dense_exact (pvs_dense_exact.hip) holds 8 queries per pass, one row per lane, and reads the query components from LDS: every
 // packed multiply needs 8 bytes of query per lane, a broadcast ds_read_b128 feeds two of them and costs 8 LDS cycles for the
 // whole CU, so the four SIMDs wait for the one LDS pipe — 4M x 768 f16 rows x 8 queries: 1.9 ms where the packed VALU work is
-// 0.7, and 32 queries are four such passes.  What lowers the LDS traffic per multiply is reuse: here a lane owns R = 4 rows, so
-// a query component read from LDS once feeds four packed multiplies — per component 8 broadcast reads (32 queries) against
-// 4 x 16 x 2 packed instructions: the LDS pipe is half used and the kernel is bound by the packed f32 pipe, which is the chain
-// the reference computes: per row, component and query pair one multiply and one add (cosine) or a subtract, a multiply and an
-// add (L2), each with its own IEEE rounding, in component order.  Rows come straight from HBM (a lane reads 16 bytes of each of
-// its rows per step, one step ahead of the arithmetic; the 8 steps of a 128-byte line follow each other); LDS holds only the
-// transposed, zero-padded queries qT[component][NQ].
+// 0.7, and 32 queries are four such passes.  What lowers the LDS traffic per multiply is reuse: here a lane owns R rows (2 at 32
+// queries, 3 at 16: R x NQ / 2 accumulator pairs + the rows' data must fit 256 registers without a spill), so a query component read
+// from LDS once feeds R packed multiplies and the kernel is bound by the packed f32 pipe, which is the chain the reference computes:
+// per row, component and query pair one multiply and one add (cosine) or a subtract, a multiply and an add (L2), each with its own
+// IEEE rounding, in component order.  Rows come straight from HBM: a lane reads one 128-byte line of each of its rows per step, as
+// two 64-byte halves that are reloaded the moment they are consumed (inline assembly, counted waits: see the loop); LDS holds only
+// the transposed, zero-padded queries qT[component][NQ]; workgroups are persistent and their waves dequeue blocks of 64 R rows.
 // (Tried first: the query components as wave-uniform scalar operands — s_load into SGPR pairs that v_pk_mul_f32 takes directly,
 //  no LDS at all, 76 VGPRs.  The instruction stream was ideal, but a scalar load that misses the 16 KB scalar cache takes ~1,000
 //  cycles, every line of the 96 KB of queries is used once per wave and SMEM returns out of order (lgkmcnt(0) only), so nothing
