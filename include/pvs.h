@@ -55,9 +55,21 @@
  *   - ordering: (distance ascending, row id ascending); NaN distances (SQL NULL in
  *     the reference) sort last.  The id tie-break is the build's addition
  *     (SURVEY.md §8c); the reference leaves ties unspecified.
- *   - threading: pvs_search* / pvs_score_all may be called concurrently from many
- *     host threads on one index (the reference runs up to 16 read connections,
- *     db/connection.rs:235); pvs_index_add / set_scale / destroy are exclusive.
+ *   - threading: every entry point may be called concurrently from many host threads on
+ *     one index, searches AND mutations (the reference runs up to 16 read connections,
+ *     db/connection.rs:235,320-357, beside one writer actor, db/index_writer.rs, under
+ *     SQLite's snapshot isolation).  The library holds a reader / writer gate per index
+ *     (csrc/pvs_gate.hip): pvs_index_add* / remove_rows / replace_rows* / set_order_keys /
+ *     set_streams wait for the calls that read the index, complete the stream-ordered
+ *     searches still in flight on their owners' behalf (the owner's pvs_wait returns the
+ *     parked result), keep new searches out until they are done and cannot be starved by
+ *     them.  A search observes the index before a mutation or after it, never a mix; a
+ *     stream-ordered search enqueued before a mutation answers over the rows as they were.
+ *     Per-row arrays the CALLER keeps (masks, weights) must match the snapshot the caller
+ *     means: serialise those calls with the mutations yourself.  Only pvs_index_destroy
+ *     (and pvs_index_set_scale before the first add) remain the caller's to order.  With
+ *     several ranks (pvs_search_sharded*) mutate collectively: every rank at the same
+ *     point of its program.
  */
 #ifndef PVS_H
 #define PVS_H
@@ -176,8 +188,11 @@ pvs_status pvs_index_add_f32(pvs_index *idx, const float *rows, uint64_t n, cons
  * afterwards is its i-th surviving row — order kept, ids still strictly increasing, later adds append as before.
  * Group ids and order keys the index holds move with their rows; per-row arrays the CALLER keeps (candidate masks,
  * row weights, pvs_similar_opts arrays) follow the same renumbering.  Every search afterwards sees an ordinary index
- * (nothing on a search path tests a row for being alive).  Searches in flight are waited for; exclusive like
- * pvs_index_add.  Multi-device indexes: every shard compacts its rows, the global order is the surviving rows' order.
+ * (nothing on a search path tests a row for being alive).  Safe beside searches (the gate above): calls in flight
+ * are completed first, later ones see the compacted index.  After a removal the next pvs_index_add ascends from the
+ * LAST SURVIVING id (ids that left may come back: item_data.id is not AUTOINCREMENT in the reference).  A removal that
+ * fails after the rows started to move (a HIP error half way) leaves the index unusable: every later call returns
+ * PVS_ERR_STATE; destroy and rebuild it.  Multi-device indexes: every shard compacts its rows, the global order is the surviving rows' order.
  *
  * pvs_index_replace_rows[_f32]: overwrites the vectors of rows the index already holds (same ids, same positions,
  * same groups and keys): rows = dense [n][dim] of the index dtype (or f32, converted like pvs_index_add_f32),
@@ -546,7 +561,11 @@ pvs_status pvs_resolve_vector_quant(pvs_index_mode index, const char *variant, i
 
 /* ------------------------------------------------------------- multi-GPU (RCCL) */
 #define PVS_UNIQUE_ID_BYTES 128
-/* rank 0 creates the id and ships the 128 bytes to the other ranks out of band */
+/* rank 0 creates the id and ships the 128 bytes to the other ranks out of band.  pvs_comm_create is collective and BOUNDED
+ * ("comm_timeout_s"): it returns once every rank has joined AND a one-word all-reduce — the communicator's first collective —
+ * has come back with the right sum, or PVS_ERR_COMM on this rank when the others do not show up in time (hosts agree on the
+ * outcome out of band, as bench.py's make_comm does, before relying on it).  RCCL's diagnostics: NCCL_DEBUG defaults to WARN
+ * (set by the library when the host has not chosen a level). */
 pvs_status pvs_comm_unique_id(uint8_t id[PVS_UNIQUE_ID_BYTES]);
 pvs_status pvs_comm_create(const uint8_t id[PVS_UNIQUE_ID_BYTES], int32_t world, int32_t rank,
                            int32_t device, pvs_comm **out);
@@ -563,7 +582,11 @@ pvs_status pvs_search_sharded(pvs_index *idx, pvs_comm *comm, const void *d_quer
                               int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 /* Stream-ordered form: local search, all-gather and merge are enqueued on one of the index's
  * streams with no host synchronisation in between; pvs_wait(idx, ticket) completes it (and,
- * when any shard handed a query to the dense path, redoes the exchange for the batch). */
+ * when any shard handed a query to the dense path, redoes the exchange for the batch).
+ * Failure semantics across ranks (round 6): a rank that fails LOCALLY before its exchange (out of memory, a HIP error of its
+ * scan) still takes part in the all-gather with a failure record, gets a ticket, and every rank's pvs_wait fails that search —
+ * the failing rank with its own error, the others with PVS_ERR_COMM naming it; nobody is left inside the collective.  A rank
+ * that never arrives at all is bounded by "comm_timeout_s" (pvs_debug_set): PVS_ERR_COMM, communicator aborted. */
 pvs_status pvs_search_sharded_async(pvs_index *idx, pvs_comm *comm, const void *d_queries,
                                     pvs_dtype query_dtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                     int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count,
@@ -655,7 +678,12 @@ pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
  *   "marker_events"           profiling spans as hipEventRecord markers around the kernels instead of events bound to the dispatches
  *   "no_direct_topk"          a single query always takes the filter scan, never the one-launch exact search (pvs_direct.hip)
  *   "direct_max_mb" N         ... takes the one-launch search up to N MB of rows (default 8192)
- *   "direct_queries"          (read-only counter) single queries answered by the one-launch search, process-wide */
+ *   "direct_queries"          (read-only counter) single queries answered by the one-launch search, process-wide
+ *   "comm_timeout_s" N        bound on every wait for the other ranks: communicator creation (ncclCommInitRank + a one-word
+ *                             all-reduce, the communicator's first collective), the shard exchange behind pvs_wait, the control
+ *                             messages of the sharded fusion (default 180 s).  On expiry the communicator is aborted and the call
+ *                             returns PVS_ERR_COMM naming the rank: create a new communicator
+ *   "comm_fail_local" N       tests: the next N pvs_search_sharded_async calls of this process fail before their exchange */
 pvs_status pvs_debug_set(const char *key, int64_t value);
 pvs_status pvs_debug_get(const char *key, int64_t *out_value);
 /* Stage digests of the process' last single-device pvs_rrf_search run under "rrf_digest": out[branch * 4 + stage], stage 0 = the

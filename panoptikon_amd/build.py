@@ -55,6 +55,7 @@ SOURCES = [
     "pvs_comm.hip",
     "pvs_multi.hip", "pvs_multi_items.hip",
     "pvs_lifecycle.hip",
+    "pvs_gate.hip",
     "pvs_microbench.hip",
     "pvs_host.cpp",
 ]

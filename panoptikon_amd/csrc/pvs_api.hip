@@ -27,7 +27,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "scratch_bypass",  "rrf_digest",   "no_sparse",         "sparse_max",           "no_fused_agg",        "no_side_finalize",
     "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
     "direct_unit", "direct_static_pct", "direct_max_nq", "dense_full_sort", "dense_page_first", "no_flag_poll", "poll_late_pages",
-    "no_exact_wide", "no_agg8", "no_dense2",
+    "no_exact_wide", "no_agg8", "no_dense2", "comm_timeout_s", "comm_fail_local",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;
@@ -627,6 +627,7 @@ static pvs_status append_device_rows(pvs_index *ix, const void *rows_dev, bool f
     }
     ix->n += n;
     ix->last_id = last_id;
+    ix->ids_epoch++;
     ix->groups_built_n = UINT64_MAX;
     return PVS_OK;
 }
@@ -638,6 +639,7 @@ pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, 
     if (!rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null rows");
     if (is_multi(ix)) return multi_add(ix, rows, from_f32, n, row_ids, group_ids, space);
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, PVS_POISONED_MSG);
     HIP_TRY(hipSetDevice(ix->device));
     if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set)
         return pvs_fail(PVS_ERR_STATE, "int8 index has no scale artifact: set it before adding f32 rows");
@@ -670,10 +672,12 @@ pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, 
 
 PVS_EXPORT pvs_status pvs_index_add(pvs_index *ix, const void *rows, uint64_t n, const int64_t *row_ids,
                                     const int64_t *group_ids, pvs_space space) {
+    GateExcl gate(ix);  // (searches see the index before or after the append: the rows may move to a larger allocation)
     return add_impl(ix, rows, false, n, row_ids, group_ids, space);
 }
 PVS_EXPORT pvs_status pvs_index_add_f32(pvs_index *ix, const float *rows, uint64_t n, const int64_t *row_ids,
                                         const int64_t *group_ids, pvs_space space) {
+    GateExcl gate(ix);
     return add_impl(ix, rows, true, n, row_ids, group_ids, space);
 }
 
@@ -692,8 +696,8 @@ PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
 }
 PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    GateExcl gate(ix);  // (searches in flight read the tie ranks)
     if (is_multi(ix)) return multi_set_order_keys(ix, keys, n, space);
-    PVS_TRY(pvs_sync(ix));  // (searches in flight read the tie ranks)
     std::lock_guard<std::mutex> lk(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     hipFree(ix->d_trank);
@@ -749,7 +753,7 @@ PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t 
 
 PVS_EXPORT pvs_status pvs_index_set_streams(pvs_index *ix, uint32_t n_streams) {
     if (!ix || n_streams == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "bad stream count");
-    PVS_TRY(pvs_sync(ix));
+    GateExcl gate(ix);  // (no search in flight while the stream mode changes)
     for (pvs_index *sh : ix->shards) sh->multi_stream = n_streams > 1;
     ix->multi_stream = n_streams > 1;
     return PVS_OK;
@@ -831,6 +835,7 @@ PVS_EXPORT pvs_status pvs_device_synchronize(int32_t device) {
 
 PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t n, int64_t *out_row_ids, int64_t *out_group_ids) {
     if (!ix || (n && !out_row_ids)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    GateShared gate(ix);
     if (is_multi(ix)) return multi_read_ids(ix, row0, n, out_row_ids, out_group_ids);
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);
@@ -851,6 +856,7 @@ PVS_EXPORT pvs_status pvs_index_read_ids(pvs_index *ix, uint64_t row0, uint64_t 
 
 PVS_EXPORT pvs_status pvs_index_read_rows(pvs_index *ix, uint64_t row0, uint64_t n, void *out_host) {
     if (!ix || (n && !out_host)) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    GateShared gate(ix);
     if (is_multi(ix)) return multi_read_rows(ix, row0, n, out_host);
     if (row0 + n > ix->n) return pvs_fail(PVS_ERR_INVALID_ARG, "row range [%llu, %llu) exceeds %llu rows", (unsigned long long)row0,
                                           (unsigned long long)(row0 + n), (unsigned long long)ix->n);

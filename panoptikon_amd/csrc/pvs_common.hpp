@@ -88,6 +88,8 @@ enum PvsDbg {
     PVS_DBG_NO_EXACT_WIDE,         // dense exact path, float rows: 8 queries per pass through LDS (k_dense_exact) also for 9+ queries
     PVS_DBG_NO_AGG8,               // per-item aggregation of a distance matrix: one thread per (group, column) also when the columns are a multiple of 8
     PVS_DBG_NO_DENSE2,             // dense exact path, 8 float queries: one row per lane (k_dense_exact) instead of two (k_dense_exact2)
+    PVS_DBG_COMM_TIMEOUT_S,        // bound on every wait for the other ranks (communicator creation, a shard exchange): seconds (0: 180)
+    PVS_DBG_COMM_FAIL_LOCAL,       // tests: the next pvs_search_sharded_async of this process fails locally before its exchange (value = how many)
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -30,6 +30,11 @@ struct SearchCtx {
     hipEvent_t scanned = nullptr;      // recorded behind pass B when pass C runs on the index's side stream
     bool side_finalize = false;        // this search's pass C went to ix->fin_stream (c.done was recorded there)
     bool busy = false;
+    // (under ix->mu) a stream-ordered search whose pvs_wait work is being done right now (by its owner or by a writer draining the
+    // index: pvs_gate.hip), and one a writer completed on its owner's behalf: pvs_wait hands fin_status / fin_err over and releases
+    bool draining = false, finished = false;
+    pvs_status fin_status = PVS_OK;
+    std::string fin_err;
     uint8_t *d_qin = nullptr;     // host-variant query upload [MAX_BATCH][dim*4]
     uint8_t *d_qmat = nullptr;    // [MAX_BATCH][stride]
     float *d_qpad = nullptr;      // dense exact path: PVS_DENSE_NQ zero-padded f32 queries
@@ -77,6 +82,8 @@ struct SearchCtx {
     bool p_fast = false;
     // sharded search: this rank's page, the gathered pages and flags
     pvs_comm *p_comm = nullptr;
+    pvs_status p_local_status = PVS_OK;  // sharded search: this rank failed before the exchange and sent a failure record; pvs_wait returns this
+    std::string p_local_err;
     // this rank's page is ONE record [ids | dist | counts | flags] (pvs_page_record_*: the exchange is a single all-gather);
     // d_loc_ids / d_loc_dist / d_loc_cnt are views into it for the current (batch, k)
     uint8_t *d_loc_rec = nullptr, *d_all_rec = nullptr;
@@ -97,6 +104,9 @@ int pvs_comm_world_(pvs_comm *c);
 int pvs_comm_device_(pvs_comm *c);
 pvs_status pvs_comm_gather_records_(pvs_comm *c, const void *rec, void *all_rec, size_t rec_bytes, hipStream_t s);  // ONE all-gather, rec_bytes per rank
 pvs_status pvs_comm_allreduce_max_(pvs_comm *c, float *d_inout, uint64_t n, hipStream_t s);
+void pvs_comm_abort_(pvs_comm *c);                                               // after a deadline passed: queued collectives fail instead of waiting
+pvs_status pvs_comm_wait_stream_(pvs_comm *c, hipStream_t s, const char *what);  // the same for everything queued on s so far
+pvs_status pvs_comm_wait_event_(pvs_comm *c, hipEvent_t ev, const char *what);    // bounded wait (pvs_debug "comm_timeout_s"); aborts the communicator on expiry
 
 constexpr uint32_t GMAX = 16384;  // group minima per query (pass A grid * RT * 32 <= GMAX)
 constexpr uint32_t NCTX = 16;  // searches in flight per index = the reference's read pool (db/connection.rs:235)
@@ -105,6 +115,9 @@ constexpr uint32_t NCTX = 16;  // searches in flight per index = the reference's
 // shard; a MultiCtx is one search in flight across all of them
 struct MultiCtx {
     bool busy = false, pending = false;
+    bool draining = false, finished = false;  // as in SearchCtx
+    pvs_status fin_status = PVS_OK;
+    std::string fin_err;
     hipStream_t stream = nullptr;  // on the root device (devices[0]): merge + result copies
     hipEvent_t done = nullptr;
     uint8_t *d_all_rec = nullptr;  // root-side gather buffer: one packed page record per shard (pvs_page_record_*)
@@ -144,6 +157,17 @@ struct pvs_index {
     uint32_t dtype = 0, dim = 0, esz = 0, stride = 0;
     uint64_t n = 0, cap = 0;
     int64_t id_base = 0, last_id = INT64_MIN;
+    // Reader / writer gate (pvs_gate.hip; all under mu, waiters on ctx_cv).  The reference mutates while it serves: one writer actor
+    // (db/index_writer.rs, db/extraction_write.rs:574-616, db/vector_quants.rs:1347-1438) beside up to 16 read connections
+    // (db/connection.rs:235,320-357) under SQLite's snapshot isolation.  Here every entry point that reads the rows holds the gate
+    // shared for the duration of the call (stream-ordered searches: for the enqueue; afterwards their context's `pending` flag
+    // stands for them), every entry point that changes rows, ids or keys holds it exclusively: it waits for the shared holders,
+    // completes the stream-ordered searches in flight on their owners' behalf, and keeps new readers out until it is done — a
+    // search observes the index before or after a mutation, never a mix.
+    uint32_t gate_shared = 0, gate_writers_waiting = 0;
+    bool gate_writer_active = false;
+    uint64_t ids_epoch = 0;                     // bumped whenever the id column changes (add, remove): validity of h_ids_cache
+    uint64_t ids_cache_epoch = UINT64_MAX;
     uint8_t *d_rows = nullptr;
     float *d_norm2 = nullptr;   // |a|^2, the reference's aMag (sequential f32)
     float *d_rnorm = nullptr;   // 1/|a|
@@ -207,7 +231,7 @@ struct pvs_index {
     std::vector<PageBlock> page_blocks;
     int64_t *d_grp_key = nullptr;  // per group, in id order: its second sort key (with pvs_index_set_order_keys)
     bool by_group = false;  // multi-device parent: rows are placed by group (group_ids given to every add): per-item operators are shard-local
-    bool poisoned = false;  // multi-device parent: an add failed after some shards took their piece (global row order lost): every later call fails
+    bool poisoned = false;  // an add / removal failed half way (multi-device parent: global row order lost; any index: rows compacted, per-row arrays not): every later call fails
     std::atomic<uint64_t> searches{0}, fast_queries{0}, dense_queries{0}, last_candidates{0};
     std::atomic<uint64_t> direct_queries{0};  // single queries answered by the one-launch search (counted in fast_queries too; pvs_debug_get("direct_queries"))
     std::atomic<uint64_t> flat_reruns{0};  // queries that went through the scan twice (segment overflow -> flat candidate lists)
@@ -245,6 +269,58 @@ struct pvs_index {
 
 
 inline bool is_multi(const pvs_index *ix) { return !ix->shards.empty(); }
+
+// ---- pvs_gate.hip: the reader / writer gate (see pvs_index)
+void pvs_gate_shared_enter(pvs_index *ix);
+void pvs_gate_shared_exit(pvs_index *ix);
+void pvs_gate_excl_enter(pvs_index *ix);  // waits for the shared holders, completes the stream-ordered searches in flight
+void pvs_gate_excl_exit(pvs_index *ix);
+struct GateShared {
+    pvs_index *ix;
+    explicit GateShared(pvs_index *i) : ix(i) {
+        if (ix) pvs_gate_shared_enter(ix);
+    }
+    ~GateShared() {
+        if (ix) pvs_gate_shared_exit(ix);
+    }
+    GateShared(const GateShared &) = delete;
+    GateShared &operator=(const GateShared &) = delete;
+};
+struct GateExcl {
+    pvs_index *ix;
+    explicit GateExcl(pvs_index *i) : ix(i) {
+        if (ix) pvs_gate_excl_enter(ix);
+    }
+    ~GateExcl() {
+        if (ix) pvs_gate_excl_exit(ix);
+    }
+    GateExcl(const GateExcl &) = delete;
+    GateExcl &operator=(const GateExcl &) = delete;
+};
+// several indexes at once (the branches of pvs_rrf_search): entered in address order, each once — two callers that name the same
+// branches in different orders never wait for each other's second index while a writer waits for their first
+struct GateSharedMany {
+    std::vector<pvs_index *> held;
+    template <typename It, typename Fn>
+    GateSharedMany(It first, It last, Fn &&index_of) {
+        for (It it = first; it != last; ++it)
+            if (pvs_index *ix = index_of(*it)) held.push_back(ix);
+        std::sort(held.begin(), held.end());
+        held.erase(std::unique(held.begin(), held.end()), held.end());
+        for (pvs_index *ix : held) pvs_gate_shared_enter(ix);
+    }
+    ~GateSharedMany() {
+        for (size_t i = held.size(); i-- > 0;) pvs_gate_shared_exit(held[i]);
+    }
+    GateSharedMany(const GateSharedMany &) = delete;
+    GateSharedMany &operator=(const GateSharedMany &) = delete;
+};
+// the pvs_wait work of a pending ticket without releasing its context (pvs_search_device.hip / pvs_multi.hip)
+pvs_status pvs_ticket_complete_(pvs_index *ix, uint32_t ticket);
+pvs_status multi_ticket_complete_(pvs_index *ix, uint32_t ticket);
+// (ix->mu held) host copy of the row ids of the index's CURRENT rows in ix->h_ids_cache (keyed on ids_epoch, not on its size)
+pvs_status pvs_host_ids_locked(pvs_index *ix);
+#define PVS_POISONED_MSG "this index was left inconsistent by a mutation that failed half way: destroy and rebuild it"
 
 // ---- pvs_api.hip
 pvs_status use_device(int32_t device, int *resolved);

@@ -199,6 +199,7 @@ static uint32_t dense_chunk_queries(const pvs_index *ix, uint32_t batch) {
 
 PVS_EXPORT pvs_status pvs_score_batch(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, pvs_metric metric,
                                       float *out_dist, pvs_space out_space) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (ix && is_multi(ix)) return multi_score_batch(ix, queries, qdtype, batch, metric, out_dist, out_space);
     PVS_TRY(validate_search(ix, queries, qdtype, batch, 1, metric));
     if (!out_dist) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
@@ -473,10 +474,7 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
     if (kp < std::min<uint64_t>(k, n) || !fast_path_ok(ix, (uint32_t)kp)) return PVS_OK;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
-        if (ix->h_ids_cache.size() != n) {
-            ix->h_ids_cache.resize(n);
-            HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, n * 8, hipMemcpyDeviceToHost));
-        }
+        PVS_TRY(pvs_host_ids_locked(ix));
     }
     std::vector<int64_t> ids;
     std::vector<float> dist;
@@ -561,6 +559,7 @@ static pvs_status groups_min_fast(pvs_index *ix, const void *queries, pvs_dtype 
 PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                         pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                         double *out_values, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!row_weights && coalescing_applies(ix, batch)) {  // (pvs_index_set_coalescing: concurrent callers share one pass)
         PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
         if (!out_groups || !out_values || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
@@ -573,6 +572,7 @@ PVS_EXPORT pvs_status pvs_search_groups(pvs_index *ix, const void *queries, pvs_
 PVS_EXPORT pvs_status pvs_search_groups_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                                  pvs_metric metric, pvs_agg agg, const float *row_weights, const uint8_t *allowed_rows,
                                                  pvs_space mask_space, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
     return search_groups_impl(ix, queries, qdtype, batch, k, metric, agg, row_weights, allowed_rows, mask_space, out_groups, out_values,
                               out_count);
@@ -786,6 +786,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
 PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, const void *queries, pvs_dtype qdtype, uint32_t batch,
                                                 uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups,
                                                 double *out_values, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!comm) return pvs_fail(PVS_ERR_INVALID_ARG, "null communicator");
     if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "a multi-device index shards inside one process: use pvs_search_groups");
     if (ix && pvs_comm_device_(comm) != ix->device) return pvs_fail(PVS_ERR_INVALID_ARG, "index and communicator live on different devices");
@@ -793,14 +794,14 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
     if (batch == 0) return PVS_OK;
     // 1. this shard's page.  Every rank must take part in the exchange below whatever happened locally: a rank
     // that returned early would leave the others inside the all-gather.  A local failure travels as a count of
-    // PVS_PAGE_FAILED and every rank fails after the exchange.
-    constexpr uint32_t PVS_PAGE_FAILED = 0xffffffffu;
+    // GROUP_PAGE_FAILED and every rank fails after the exchange.
+    constexpr uint32_t GROUP_PAGE_FAILED = 0xffffffffu;
     std::vector<int64_t> lg((size_t)batch * k, -1);
     std::vector<double> lv((size_t)batch * k, __builtin_nan(""));
     std::vector<uint32_t> lc(batch, 0);
     const pvs_status local_st = pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, lg.data(), lv.data(), lc.data());
     const std::string local_err = local_st == PVS_OK ? std::string() : std::string(pvs_last_error());
-    if (local_st != PVS_OK) std::fill(lc.begin(), lc.end(), PVS_PAGE_FAILED);
+    if (local_st != PVS_OK) std::fill(lc.begin(), lc.end(), GROUP_PAGE_FAILED);
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t world = (uint32_t)pvs_comm_world_(comm);
     const uint64_t elems = (uint64_t)batch * k;
@@ -834,7 +835,7 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         // 2. one all-gather over xGMI
         PVS_TRY(pvs_comm_gather_records_(comm, d_rec, d_all, rec, s));
         HIP_TRY(hipMemcpyAsync(h_all.data(), d_all, rec * world, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        PVS_TRY(pvs_comm_wait_stream_(comm, s, "per-item shard exchange (all-gather)"));  // bounded: a rank that never arrives is an error, not a hang
         for (uint32_t w = 0; w < world; w++) {
             memcpy(ag.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec, elems * 8);
             memcpy(av.data() + (size_t)w * elems, h_all.data() + (size_t)w * rec + off_v, elems * 8);
@@ -850,7 +851,7 @@ PVS_EXPORT pvs_status pvs_search_groups_sharded(pvs_index *ix, pvs_comm *comm, c
         }
         if (local_st != PVS_OK) return pvs_fail(local_st, "%s", local_err.c_str());
         for (uint32_t w = 0; w < world; w++)
-            if (ac[(size_t)w * batch] == PVS_PAGE_FAILED) return pvs_fail(PVS_ERR_COMM, "rank %u failed its shard of the per-item search", w);
+            if (ac[(size_t)w * batch] == GROUP_PAGE_FAILED) return pvs_fail(PVS_ERR_COMM, "rank %u failed its shard of the per-item search", w);
         // 3. merge on every rank (tiny: world * k entries per query)
         return pvs_merge_group_pages_keyed(ag.data(), av.data(), all_keyed && any_keyed ? ak.data() : nullptr, ac.data(), world, batch, k, out_groups,
                                            out_values, out_count);

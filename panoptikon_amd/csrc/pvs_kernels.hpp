@@ -255,6 +255,9 @@ hipError_t pvs_launch_merge(const int64_t *ids, const float *dist, const uint32_
 // flags[q]: the query's hand-back code (pass C) in the low bits; bit 31 = the keys section is valid (the shard carries
 // pvs_index_set_order_keys keys for all its rows).  The merge breaks distance ties by key DESC when EVERY shard's page says so.
 constexpr uint32_t PVS_PAGE_KEYED = 0x80000000u;
+// a rank that failed locally before the exchange still sends its record, with this bit in every flag word: all ranks fail the
+// search together (0x40404040 is what a byte fill of the flag words with 0x40 leaves; need_dense values are 0..3)
+constexpr uint32_t PVS_PAGE_FAILED = 0x40000000u;
 inline size_t pvs_page_record_off_dist(uint32_t batch, uint32_t k) { return (size_t)batch * k * 8; }
 inline size_t pvs_page_record_off_cnt(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12; }
 inline size_t pvs_page_record_off_flags(uint32_t batch, uint32_t k) { return (size_t)batch * k * 12 + (size_t)batch * 4; }

@@ -35,14 +35,6 @@ __global__ __launch_bounds__(256) void k_rows_move(const uint8_t *rows, uint32_t
     }
 }
 
-pvs_status host_ids(pvs_index *ix) {  // (ix->mu held)
-    if (ix->h_ids_cache.size() != ix->n) {
-        ix->h_ids_cache.resize(ix->n);
-        if (ix->n) HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
-    }
-    return PVS_OK;
-}
-
 // the ids to remove against the index's ids (strictly increasing): alive[pos] = 0, gone[pos] = 1 for every id found
 __global__ __launch_bounds__(256) void k_mark_removed(const int64_t *ids, uint64_t n, const int64_t *rm, uint64_t m, uint8_t *alive, uint8_t *gone) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -80,6 +72,7 @@ void erase_rows(std::vector<T> &v, const std::vector<uint32_t> &dead, uint64_t n
 // from them).  ix->mu is taken here; searches in flight were waited for by the caller.
 pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, uint64_t *out_removed, std::vector<uint32_t> *dead_out) {
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, PVS_POISONED_MSG);
     HIP_TRY(hipSetDevice(ix->device));
     if (out_removed) *out_removed = 0;
     if (dead_out) dead_out->clear();
@@ -95,6 +88,9 @@ pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, 
     void *tmp = nullptr;
     std::vector<uint32_t> dead;
     uint64_t n_new = n_old, r0 = 0;
+    int64_t last_survivor = INT64_MIN;
+    const bool keyed = ix->order_rows == n_old;
+    bool mutating = false;  // the first write to the index's own arrays has been queued: a failure from here on leaves rows, ids and scalars out of step
     auto body = [&]() -> pvs_status {
         HIP_TRY(pvs_scratch_alloc((void **)&d_rm, n_ids * 8));
         HIP_TRY(pvs_scratch_alloc((void **)&d_alive, n_old + 64));
@@ -120,10 +116,22 @@ pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, 
         HIP_TRY(hipStreamSynchronize(s));
         r0 = (uint64_t)dead[0] & ~31ull;  // the first tile that changes
         const uint64_t m_all = n_new > r0 ? n_new - r0 : 0;  // new rows [r0, n_new) get a (possibly new) source
+        const uint64_t chunk = std::max<uint64_t>(32, ((256ull << 20) / ix->stride) & ~31ull);
+        if (m_all) {
+            // EVERY scratch block before the first write to the index (an allocation that failed between the row move and
+            // the per-row arrays left the vectors compacted under unchanged ids and norms)
+            HIP_TRY(pvs_scratch_alloc((void **)&stage, std::min<uint64_t>(chunk, (m_all + 31) & ~31ull) * ix->stride));
+            HIP_TRY(pvs_scratch_alloc(&tmp, m_all * 8));
+        }
+        // the id of the last surviving row (later adds must ascend from IT, not from an id that left: ADVICE r5)
+        if (n_new) {
+            uint32_t src_last = 0;
+            HIP_TRY(hipMemcpy(&src_last, d_src + (n_new - 1), 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&last_survivor, ix->d_ids + src_last, 8, hipMemcpyDeviceToHost));
+        }
+        mutating = true;
         if (m_all) {
             // the rows, chunk by chunk in ascending order through one staging block
-            const uint64_t chunk = std::max<uint64_t>(32, ((256ull << 20) / ix->stride) & ~31ull);
-            HIP_TRY(pvs_scratch_alloc((void **)&stage, std::min<uint64_t>(chunk, (m_all + 31) & ~31ull) * ix->stride));
             for (uint64_t off = 0; off < m_all; off += chunk) {
                 const uint64_t m = std::min(chunk, m_all - off), m32 = (m + 31) & ~31ull;
                 const uint64_t total = m * (ix->stride >> 4);
@@ -134,11 +142,10 @@ pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, 
                 HIP_TRY(hipMemcpyAsync(ix->d_rows + (r0 + off) * ix->stride, stage, m32 * ix->stride, hipMemcpyDeviceToDevice, s));
             }
             // the per-row arrays through the same map
-            HIP_TRY(pvs_scratch_alloc(&tmp, m_all * 8));
             for (int which = 0; which < 4; which++) {
                 void *arr = which == 0 ? (void *)ix->d_norm2 : which == 1 ? (void *)ix->d_rnorm : which == 2 ? (void *)ix->d_ids : (void *)ix->d_order_keys;
                 const uint32_t eb = which < 2 ? 4u : 8u;
-                if (!arr || (which == 3 && ix->order_rows != n_old)) continue;
+                if (!arr || (which == 3 && !keyed)) continue;
                 HIP_TRY(pvs_launch_take_rows(arr, eb, d_src + r0, m_all, tmp, s));
                 HIP_TRY(hipMemcpyAsync((uint8_t *)arr + r0 * eb, tmp, m_all * eb, hipMemcpyDeviceToDevice, s));
             }
@@ -149,25 +156,32 @@ pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, 
         HIP_TRY(pvs_launch_fill_f32(ix->d_rnorm + n_new, n_old - n_new, __builtin_nanf(""), s));
         HIP_TRY(pvs_launch_scan_aux(ix->d_norm2, ix->d_rnorm, r0, n_old - r0, ix->d_scan_cos, ix->d_scan_l2, s));
         HIP_TRY(hipStreamSynchronize(s));
+        // the tie ranks of the surviving rows (their keys moved with them)
+        if (keyed && n_new) PVS_TRY(pvs_build_tie_ranks(ix->d_order_keys, n_new, ix->d_trank, ix->d_tinv, s));
         return PVS_OK;
     };
     pvs_status st = body();
     if (st != PVS_OK) (void)hipStreamSynchronize(s);
     for (void *p : {(void *)d_rm, (void *)d_alive, (void *)d_gone, (void *)d_src, (void *)d_dead, (void *)stage, tmp}) pvs_scratch_free(p);
+    if (st != PVS_OK && mutating) {
+        // vectors, ids, norms and records no longer describe the same rows: serve nothing rather than wrong pages
+        ix->poisoned = true;
+        const std::string why = pvs_last_error();
+        return pvs_fail(st, "row removal failed after the index had started to change (%s): the index is unusable, destroy and rebuild it", why.c_str());
+    }
     PVS_TRY(st);
     if (dead.empty()) return PVS_OK;
     // host mirrors and derived state
+    ix->ids_epoch++;
     ix->h_ids_cache.clear();  // (downloaded again by whoever needs it)
     erase_rows(ix->h_groups, dead, n_old);
-    const bool keyed = ix->order_rows == n_old;
     if (keyed) erase_rows(ix->h_order_keys, dead, n_old);
     ix->n = n_new;
+    ix->last_id = last_survivor;  // (INT64_MIN when nothing is left: any id may come next)
     ix->groups_built_n = UINT64_MAX;
     ix->null_built_n.store(UINT64_MAX, std::memory_order_release);
-    if (keyed) {  // the tie ranks cover the surviving rows (the keys moved with them)
-        ix->order_rows = 0;
+    if (keyed) {
         ix->order_epoch++;
-        if (n_new) PVS_TRY(pvs_build_tie_ranks(ix->d_order_keys, n_new, ix->d_trank, ix->d_tinv, s));
         ix->order_rows = n_new;
     } else if (ix->order_rows) {  // (keys that did not cover every row were unusable anyway)
         ix->order_rows = 0;
@@ -183,11 +197,12 @@ pvs_status remove_single(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, 
 pvs_status replace_single(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, pvs_space space, bool missing_ok,
                           uint64_t *matched) {
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, PVS_POISONED_MSG);
     HIP_TRY(hipSetDevice(ix->device));
     if (matched) *matched = 0;
     if (n == 0) return PVS_OK;
     if (from_f32 && ix->dtype == PVS_I8 && !ix->scale_set) return pvs_fail(PVS_ERR_STATE, "int8 index has no scale artifact: set it before writing f32 rows");
-    PVS_TRY(host_ids(ix));
+    PVS_TRY(pvs_host_ids_locked(ix));
     const std::vector<int64_t> &ids = ix->h_ids_cache;
     std::vector<uint64_t> pos, which;
     for (uint64_t i = 0; i < n; i++) {
@@ -248,7 +263,7 @@ pvs_status multi_remove(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, u
         uint64_t r = 0;
         pvs_status st = remove_single(ix->shards[sh], row_ids, n_ids, &r, &dead[sh]);
         if (st != PVS_OK) {
-            if (total) ix->poisoned = true;  // (some shards compacted, this one did not: the global row order is lost)
+            if (total || ix->shards[sh]->poisoned) ix->poisoned = true;  // (some shards compacted, this one did not — or stopped half way: the global row order is lost)
             return st;
         }
         total += r;
@@ -294,6 +309,13 @@ pvs_status multi_remove(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, u
     }
     ix->n = n_old - total;
     ix->shard_rows_n = UINT64_MAX;  // (the shards' global rows are expanded again on next use)
+    // the id -> row map of the parent (similar_to's targets, the keyed host merge) describes rows that left, and later
+    // adds ascend from the largest id that is still there
+    ix->ids_epoch++;
+    ix->h_ids_cache.clear();
+    ix->last_id = INT64_MIN;
+    for (pvs_index *sh : ix->shards)
+        if (sh->n) ix->last_id = std::max(ix->last_id, sh->last_id);
     return PVS_OK;
 }
 
@@ -317,7 +339,7 @@ pvs_status replace_any(pvs_index *ix, const void *rows, bool from_f32, uint64_t 
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     if (n == 0) return PVS_OK;
     if (!rows || !row_ids) return pvs_fail(PVS_ERR_INVALID_ARG, "null rows / row ids");
-    PVS_TRY(pvs_sync(ix));  // (searches in flight read the rows)
+    GateExcl gate(ix);  // (searches in flight read the rows: they are completed first, new ones wait)
     if (is_multi(ix)) return multi_replace(ix, rows, from_f32, n, row_ids, space);
     return replace_single(ix, rows, from_f32, n, row_ids, space, false, nullptr);
 }
@@ -328,7 +350,7 @@ PVS_EXPORT pvs_status pvs_index_remove_rows(pvs_index *ix, const int64_t *row_id
     if (out_removed) *out_removed = 0;
     if (n == 0) return PVS_OK;
     if (!row_ids) return pvs_fail(PVS_ERR_INVALID_ARG, "null row ids");
-    PVS_TRY(pvs_sync(ix));  // (searches in flight read the rows that move)
+    GateExcl gate(ix);  // (searches in flight read the rows that move: they are completed first, new ones wait)
     if (is_multi(ix)) return multi_remove(ix, row_ids, n, out_removed);
     return remove_single(ix, row_ids, n, out_removed, nullptr);
 }

@@ -55,9 +55,11 @@ void mctx_done(pvs_index *ix, MultiCtx *m) {
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         m->pending = false;
+        m->draining = false;
+        m->finished = false;
         m->busy = false;
     }
-    ix->ctx_cv.notify_one();
+    ix->ctx_cv.notify_all();  // (context waiters and a writer at the gate, pvs_gate.hip)
 }
 
 // the shard contexts a multi search holds are released together with it
@@ -402,6 +404,7 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
         }
         ix->n += n;
         ix->last_id = last;
+        ix->ids_epoch++;
         return PVS_OK;
     }
     const uint64_t base = n / S, rem = n % S;
@@ -447,6 +450,7 @@ pvs_status multi_add(pvs_index *ix, const void *rows, bool from_f32, uint64_t n,
     }
     ix->n += n;
     ix->last_id = last;
+    ix->ids_epoch++;
     return PVS_OK;
 }
 
@@ -465,8 +469,7 @@ pvs_status multi_set_scale(pvs_index *ix, float scale) {
 // orders its own pages with them and attaches the keys to its page records, the root's merge compares (distance, key DESC, id)
 pvs_status multi_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
     if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
-    PVS_TRY(multi_sync(ix));
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk(ix->mu);  // (the caller holds the gate exclusively: no search in flight)
     ix->order_rows = 0;
     ix->h_order_keys.clear();
     if (!keys) {
@@ -561,14 +564,32 @@ pvs_status multi_search_device(pvs_index *ix, const void *d_queries, pvs_dtype q
     return PVS_OK;
 }
 
-pvs_status multi_wait(pvs_index *ix, uint32_t ticket) {
+// the pvs_wait work of a pending multi-device ticket, its shard contexts released; the multi context stays held (pvs_gate.hip)
+pvs_status multi_ticket_complete_(pvs_index *ix, uint32_t ticket) {
     MultiCtx *m = &ix->mctx[ticket];
-    {
-        std::lock_guard<std::mutex> lk(ix->mu);
-        if (!m->busy || !m->pending) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
-    }
     pvs_status st = multi_complete(ix, *m);
     release_shard_ctxs(ix, *m);
+    return st;
+}
+
+pvs_status multi_wait(pvs_index *ix, uint32_t ticket) {
+    MultiCtx *m = &ix->mctx[ticket];
+    pvs_status st = PVS_OK;
+    bool mine = false;
+    {
+        std::unique_lock<std::mutex> lk(ix->mu);
+        if (!m->busy || !(m->pending || m->draining || m->finished)) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+        while (m->draining) ix->ctx_cv.wait(lk);  // a writer is completing it on our behalf
+        if (!m->busy || !(m->pending || m->finished)) return pvs_fail(PVS_ERR_STATE, "ticket %u has no search in flight", ticket);
+        if (m->finished) {
+            st = m->fin_status;
+            if (st != PVS_OK) pvs_fail(st, "%s", m->fin_err.c_str());
+        } else {
+            m->draining = true;
+            mine = true;
+        }
+    }
+    if (mine) st = multi_ticket_complete_(ix, ticket);
     mctx_done(ix, m);
     return st;
 }
@@ -579,7 +600,7 @@ pvs_status multi_sync(pvs_index *ix) {
         bool live;
         {
             std::lock_guard<std::mutex> lk(ix->mu);
-            live = ix->mctx[i].busy && ix->mctx[i].pending;
+            live = ix->mctx[i].busy && (ix->mctx[i].pending || ix->mctx[i].draining || ix->mctx[i].finished);
         }
         if (live) {
             pvs_status s = multi_wait(ix, i);

@@ -90,10 +90,7 @@ static pvs_status merge_row_pages_host(pvs_index *ix, const std::vector<int64_t>
     if (!(ix->order_rows == ix->n && ix->n)) return pvs_merge_topk(ids.data(), dist.data(), cnt.data(), S, batch, k, out_ids, out_dist, out_count);
     {
         std::lock_guard<std::mutex> lk(ix->mu);
-        if (ix->h_ids_cache.size() != ix->n) {
-            ix->h_ids_cache.resize(ix->n);
-            PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
-        }
+        PVS_TRY(pvs_host_ids_locked(ix));
     }
     const size_t elems = (size_t)batch * k;
     std::vector<int64_t> keys(S * elems, 0);

@@ -107,6 +107,7 @@ static pvs_status rrf_score_branch(const pvs_rrf_branch &b, RrfBranchCols *out, 
 PVS_EXPORT pvs_status pvs_rrf_cols_create(const pvs_rrf_branch *branch, pvs_rrf_cols **out) {
     if (!branch || !out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
     pvs_index *ix = branch->idx;
+    GateShared gate(ix);  // (pvs_gate.hip)
     if (ix && is_multi(ix)) return pvs_fail(PVS_ERR_UNSUPPORTED, "one pvs_rrf_cols per single-device shard");
     PVS_TRY(validate_search(ix, branch->query, branch->query_dtype, 1, 1, branch->metric));
     if (!branch->row_weights && branch->agg != PVS_AGG_MIN && branch->agg != PVS_AGG_MAX && branch->agg != PVS_AGG_AVG)
@@ -450,6 +451,8 @@ static pvs_status rrf_search_impl(const pvs_rrf_branch *br, uint32_t nb, uint32_
 // group's key: from the first branch (in branch order) that carries keys and holds the group.
 PVS_EXPORT pvs_status pvs_rrf_search(const pvs_rrf_branch *br, uint32_t nb, uint32_t k, int64_t *out_groups, double *out_scores,
                                      uint32_t *out_count) {
+    const uint32_t nb_ok = br && nb <= (uint32_t)PVS_RRF_MAX_BRANCHES ? nb : 0;
+    GateSharedMany gate(br, br + nb_ok, [](const pvs_rrf_branch &b) { return b.idx; });  // (pvs_gate.hip: every branch's index, in address order)
     bool keyed = false;
     if (br && nb >= 1 && nb <= (uint32_t)PVS_RRF_MAX_BRANCHES)
         for (uint32_t b = 0; b < nb; b++) keyed |= br[b].idx && br[b].idx->order_rows == br[b].idx->n && br[b].idx->n;

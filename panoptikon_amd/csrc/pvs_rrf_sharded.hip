@@ -78,6 +78,7 @@ PVS_EXPORT pvs_status pvs_rrf_search_sharded(const pvs_rrf_branch *branches, uin
                                              pvs_allgather_fn gather, void *gather_ctx, int64_t *out_groups, double *out_scores,
                                              uint32_t *out_count) {
     if (!branches || n_branches < 1 || n_branches > (uint32_t)PVS_RRF_MAX_BRANCHES) return pvs_fail(PVS_ERR_INVALID_ARG, "1..8 branches");
+    GateSharedMany gate(branches, branches + n_branches, [](const pvs_rrf_branch &b) { return b.idx; });  // (pvs_gate.hip)
     if (k < 1 || !out_groups || !out_scores || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "bad page arguments");
     if (comm) world = (uint32_t)pvs_comm_world_(comm);
     if (world < 1 || (world > 1 && !comm && !gather)) return pvs_fail(PVS_ERR_INVALID_ARG, "several ranks need a communicator or an all-gather callback");

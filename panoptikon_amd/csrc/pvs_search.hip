@@ -13,6 +13,7 @@
 pvs_status validate_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                   pvs_metric metric) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
+    if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, PVS_POISONED_MSG);
     if (batch && !queries) return pvs_fail(PVS_ERR_INVALID_ARG, "null queries");
     if (k < 1) return pvs_fail(PVS_ERR_INVALID_ARG, "k must be a positive integer");  // preprocess.rs:441-444
     if (k > (1u << 20)) return pvs_fail(PVS_ERR_INVALID_ARG, "k too large");
@@ -503,7 +504,9 @@ void ctx_done(pvs_index *ix, SearchCtx *c) {
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         c->pending = false;
+        c->draining = false;
+        c->finished = false;
         c->busy = false;
     }
-    ix->ctx_cv.notify_one();
+    ix->ctx_cv.notify_all();  // (context waiters AND a writer waiting at the gate share this condition variable)
 }

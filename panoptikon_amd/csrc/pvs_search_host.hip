@@ -165,6 +165,7 @@ pvs_status coalesce_call(pvs_index *ix, int kind, int agg, const void *queries, 
 
 PVS_EXPORT pvs_status pvs_search(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                  pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (coalescing_applies(ix, batch)) {
         // (arguments are checked before the request is queued: a bad call fails alone)
         PVS_TRY(validate_search(ix, queries, qdtype, batch, k, metric));
@@ -198,6 +199,7 @@ static pvs_status search_page_impl(uint32_t batch, uint64_t offset, uint32_t lim
 }
 PVS_EXPORT pvs_status pvs_search_page(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint64_t offset, uint32_t limit,
                                       pvs_metric metric, int64_t *out_ids, float *out_dist, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (offset == 0) return pvs_search(ix, queries, qdtype, batch, limit, metric, out_ids, out_dist, out_count);
     return search_page_impl<float>(batch, offset, limit, out_ids, out_dist, out_count, __builtin_nanf(""), [&](uint32_t k, int64_t *a, float *b, uint32_t *c) {
         return pvs_search(ix, queries, qdtype, batch, k, metric, a, b, c);
@@ -206,6 +208,7 @@ PVS_EXPORT pvs_status pvs_search_page(pvs_index *ix, const void *queries, pvs_dt
 PVS_EXPORT pvs_status pvs_search_groups_page(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint64_t offset, uint32_t limit,
                                              pvs_metric metric, pvs_agg agg, const float *row_weights, int64_t *out_groups, double *out_values,
                                              uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (offset == 0) return pvs_search_groups(ix, queries, qdtype, batch, limit, metric, agg, row_weights, out_groups, out_values, out_count);
     return search_page_impl<double>(batch, offset, limit, out_groups, out_values, out_count, __builtin_nan(""), [&](uint32_t k, int64_t *a, double *b, uint32_t *c) {
         return pvs_search_groups(ix, queries, qdtype, batch, k, metric, agg, row_weights, a, b, c);
@@ -215,6 +218,7 @@ PVS_EXPORT pvs_status pvs_search_groups_page(pvs_index *ix, const void *queries,
 PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k,
                                           pvs_metric metric, const uint8_t *allowed_rows, pvs_space mask_space, int64_t *out_ids,
                                           float *out_dist, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!allowed_rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate mask");
     if (ix && is_multi(ix)) return multi_search_filtered(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
     return search_host(ix, queries, qdtype, batch, k, metric, allowed_rows, mask_space, out_ids, out_dist, out_count);
@@ -227,6 +231,7 @@ PVS_EXPORT pvs_status pvs_search_filtered(pvs_index *ix, const void *queries, pv
 PVS_EXPORT pvs_status pvs_search_rows(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                       const uint32_t *rows, uint64_t n_listed, pvs_space rows_space, int64_t *out_ids, float *out_dist,
                                       uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     if (n_listed && !rows) return pvs_fail(PVS_ERR_INVALID_ARG, "null candidate rows");
     if (is_multi(ix)) return multi_search_rows(ix, queries, qdtype, batch, k, metric, rows, n_listed, rows_space, out_ids, out_dist, out_count);
@@ -547,6 +552,7 @@ pvs_status search_host(pvs_index *ix, const void *queries, pvs_dtype qdtype, uin
 PVS_EXPORT pvs_status pvs_search_bounded(pvs_index *ix, const void *queries, pvs_dtype qdtype, uint32_t batch, uint32_t k, pvs_metric metric,
                                          int32_t have_gt, double gt, int32_t have_lt, double lt, int64_t *out_ids, float *out_dist,
                                          uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     if (!out_ids || !out_dist || !out_count) return pvs_fail(PVS_ERR_INVALID_ARG, "null output");
     if ((have_gt && gt != gt) || (have_lt && lt != lt)) return pvs_fail(PVS_ERR_INVALID_ARG, "bounds must be numbers");

@@ -130,15 +130,7 @@ pvs_status similar_targets(pvs_index *ix, const int64_t *target_row_ids, uint32_
     trow.resize(n_targets);
     {
         std::lock_guard<std::mutex> lk(ix->mu);
-        if (ix->h_ids_cache.size() != ix->n) {
-            ix->h_ids_cache.resize(ix->n);
-            if (ix->n) {
-                if (is_multi(ix))
-                    PVS_TRY(multi_read_ids(ix, 0, ix->n, ix->h_ids_cache.data(), nullptr));
-                else
-                    HIP_TRY(hipMemcpy(ix->h_ids_cache.data(), ix->d_ids, ix->n * 8, hipMemcpyDeviceToHost));
-            }
-        }
+        PVS_TRY(pvs_host_ids_locked(ix));
         for (uint32_t i = 0; i < n_targets; i++) {  // ids are strictly increasing: binary search
             auto it = std::lower_bound(ix->h_ids_cache.begin(), ix->h_ids_cache.end(), target_row_ids[i]);
             if (it == ix->h_ids_cache.end() || *it != target_row_ids[i])
@@ -211,12 +203,14 @@ static pvs_status similar_to_impl(pvs_index *ix, const int64_t *target_row_ids, 
 
 PVS_EXPORT pvs_status pvs_similar_to(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
                                      pvs_agg agg, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     return similar_to_impl(ix, target_row_ids, n_targets, k, metric, agg, nullptr, nullptr, 0.0, 0.0, nullptr, false, false, out_groups,
                            out_values, out_count);
 }
 
 PVS_EXPORT pvs_status pvs_similar_to_ex(pvs_index *ix, const int64_t *target_row_ids, uint32_t n_targets, uint32_t k, pvs_metric metric,
                                         const pvs_similar_opts *o, int64_t *out_groups, double *out_values, uint32_t *out_count) {
+    GateShared gate(ix);  // (pvs_gate.hip: a mutation waits for this call, a search never sees one half done)
     if (!o || o->struct_size < sizeof(pvs_similar_opts)) return pvs_fail(PVS_ERR_INVALID_ARG, "pvs_similar_opts.struct_size too small");
     if (o->confidence_weight != o->confidence_weight || o->language_confidence_weight != o->language_confidence_weight)
         return pvs_fail(PVS_ERR_INVALID_ARG, "confidence weights must be numbers");

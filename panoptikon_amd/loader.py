@@ -337,7 +337,10 @@ def reconcile_deletions(conn: sqlite3.Connection, li: LoadedIndex, setter_names:
     (`embeddings ... ON DELETE CASCADE` when a file disappears: migrations/index/20250117193000_init.sql:29-33, db/files.rs:175-192),
     remove exactly those rows from the device index (pvs_index_remove_rows: compaction in HBM, milliseconds) instead of reloading
     everything from SQLite.  Returns the number of rows removed, or None when the change is not of that kind and the caller must
-    rebuild.
+    rebuild.  Cost: the device side is milliseconds; the HOST side is O(rows) — every id at or below the anchor is pulled from
+    SQLite (`SELECT d.id ... ORDER BY d.id`, ~1 us per row) and the index's ids and groups are read back — still far below a
+    reload (which also moves and re-ingests every payload), but seconds, not milliseconds, at 10M rows.  IndexCache re-runs the
+    prefix fingerprint (_prefix_intact) afterwards and rebuilds if anything else changed under the same ids.
 
     Safe against reused ids (`item_data.id` is not AUTOINCREMENT, see _prefix_intact): an ANCHOR is needed — the newest row of the
     loaded tail window that is still in the database with the same (id, item_id, payload crc).  Ids at or below the anchor were never
@@ -413,13 +416,20 @@ class IndexCache:
             if profile_name is not None:  # the pair must still be ready, with the scale the codes were made with
                 pair = resolve_ready_pair(conn, profile_name, names)
                 still_ok = pair is not None and np.float32(pair.scale) == np.float32(hit[1].scale) and pair.dim == hit[1].dim
-            if still_ok and append_new_rows(conn, hit[1], names) is not None:
-                self._items[key] = (epoch, hit[1])
-                return hit[1]
-            # rows the index holds were deleted: take exactly those out of HBM, then append what is new
-            if still_ok and reconcile_deletions(conn, hit[1], names) is not None and append_new_rows(conn, hit[1], names) is not None:
-                self._items[key] = (epoch, hit[1])
-                return hit[1]
+            # Any failure of the in-place routes (a PvsError out of an add or a removal, e.g. an id the index refuses) falls through to
+            # the rebuild below, which drops the index: an entry that failed once must not be retried in place on every later get
+            # (before the library lowered last_id after a tail removal, re-added rowids raised here — on EVERY call)
+            try:
+                if still_ok and append_new_rows(conn, hit[1], names) is not None:
+                    self._items[key] = (epoch, hit[1])
+                    return hit[1]
+                # rows the index holds were deleted: take exactly those out of HBM, then append what is new (append_new_rows checks the
+                # whole-prefix fingerprint again first: surviving rows that changed under the same id mean a rebuild)
+                if still_ok and reconcile_deletions(conn, hit[1], names) is not None and append_new_rows(conn, hit[1], names) is not None:
+                    self._items[key] = (epoch, hit[1])
+                    return hit[1]
+            except L.PvsError:
+                pass
         # absent, or the loaded prefix changed: drop every entry of this (database, kind, setters) and rebuild
         for k in [k for k in self._items if k[:3] == key[:3]]:
             self._items.pop(k)[1].index.close()

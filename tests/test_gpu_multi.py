@@ -9,6 +9,7 @@
 * concurrency regressions: searches in flight never share sort scratch; the in-flight limit is an error, not a hang.
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -880,3 +881,78 @@ def test_per_item_work_of_a_multi_device_index_stays_on_the_devices(pvs):
                 assert oc[j] == len(eg) and np.array_equal(og[j, : oc[j]], eg) and np.array_equal(ov[j, : oc[j]].view(np.uint64), ev.view(np.uint64)), (tag, kk, agg, j)
         dmask.free()
         ix.close()
+
+
+def test_a_rank_that_fails_before_the_exchange_fails_the_search_on_every_rank_not_the_job(pvs):
+    """Round 6, RCCL first-run hygiene: a rank that fails LOCALLY before the all-gather of a sharded search still sends a record —
+    every flag word carries PVS_PAGE_FAILED — so the collective completes and every rank's pvs_wait returns an error for THAT
+    search; the communicator and the index keep working.  On a one-GPU box the communicator has one rank (the path is the
+    same: enqueue fails -> failure record -> all-gather -> merge -> pvs_wait reports)."""
+    from panoptikon_amd import _lib as L
+
+    dim, n, k = 64, 20_000, 10
+    rows = orc.synth_rows(81, 0, n, dim)
+    ix = pvs.VectorIndex(pvs.F32, dim)
+    ix.add_f32(rows)
+    uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+    L.check(pvs.lib().pvs_comm_unique_id(uid))
+    comm = C.c_void_p()
+    L.check(pvs.lib().pvs_comm_create(uid, 1, 0, 0, C.byref(comm)))  # (ends with the communicator's first collective: a one-word all-reduce)
+    try:
+        q = orc.synth_rows(82, 0, 4, dim)
+        dq = pvs.DeviceBuffer.from_numpy(q)
+        oi, od, oc = pvs.DeviceBuffer(4 * k * 8), pvs.DeviceBuffer(4 * k * 4), pvs.DeviceBuffer(4 * 4)
+        ei, ed = orc.search(orc.F32, orc.COSINE, rows, q, k)
+
+        def run():
+            L.check(pvs.lib().pvs_search_sharded(ix._h, comm, dq.ptr, L.F32, 4, k, pvs.COSINE, oi.ptr, od.ptr, oc.ptr))
+            return oi.to_numpy(np.int64, (4, k)), od.to_numpy(np.float32, (4, k))
+
+        gi, gd = run()
+        assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+        pvs.debug_set("comm_fail_local", 1)
+        # stream-ordered form: the enqueue hands out a ticket (the failure record is on its way), pvs_wait reports
+        t = C.c_uint32()
+        L.check(pvs.lib().pvs_search_sharded_async(ix._h, comm, dq.ptr, L.F32, 4, k, pvs.COSINE, oi.ptr, od.ptr, oc.ptr, C.byref(t)))
+        with pytest.raises(pvs.PvsError, match="injected local failure"):
+            ix.wait(int(t.value))
+        assert pvs.debug_get("comm_fail_local") == 0
+        gi, gd = run()  # the communicator, the index and the context are all still good
+        assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32))
+    finally:
+        pvs.debug_set("comm_fail_local", 0)
+        pvs.lib().pvs_comm_destroy(comm)
+        ix.close()
+
+
+_NO_SHOW = r"""
+import ctypes as C, sys, time, os
+import panoptikon_amd as pvs
+from panoptikon_amd import _lib as L
+pvs.debug_set("comm_timeout_s", 4)
+uid = (C.c_uint8 * L.UNIQUE_ID_BYTES)()
+L.check(pvs.lib().pvs_comm_unique_id(uid))
+comm = C.c_void_p()
+t0 = time.time()
+rc = pvs.lib().pvs_comm_create(uid, 2, 0, 0, C.byref(comm))   # rank 1 never calls
+print("RESULT", rc, round(time.time() - t0, 1), pvs.lib().pvs_last_error().decode(), flush=True)
+os._exit(0)   # (the helper thread is still inside ncclCommInitRank: leave without running destructors under it)
+"""
+
+
+def test_a_rank_that_never_arrives_is_an_error_not_a_hang(pvs):
+    """pvs_comm_create for a 2-rank communicator whose other rank never calls: PVS_ERR_COMM after the deadline
+    (pvs_debug "comm_timeout_s"), naming the rank — not an 1,800-s driver timeout.  Own process: ncclCommInitRank cannot be
+    cancelled, its helper thread stays behind."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _NO_SHOW], cwd=root, env=dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=120)
+    line = [ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("RESULT")]
+    assert line, (r.stdout[-1500:], r.stderr[-1500:])
+    _, rc, secs, msg = line[0].split(" ", 3)
+    assert int(rc) == 9, line[0]  # PVS_ERR_COMM
+    assert 3.0 <= float(secs) <= 30.0, line[0]
+    assert "rank 0 of 2" in msg and "waited" in msg, msg

@@ -305,7 +305,18 @@ class _StubIndex:
         pass
 
     def add_f32(self, mat, row_ids=None, group_ids=None):
-        self.ids += list(map(int, row_ids))
+        # the library's rule (check_ids, csrc/pvs_api.hip): strictly increasing, ascending from the LAST SURVIVING id — ids that
+        # left with a removal may come back (round 6; ADVICE r5: the stub used to accept anything, which hid that the real
+        # library refused re-added rowids after a tail removal)
+        from panoptikon_amd._lib import PvsError
+
+        new = list(map(int, row_ids))
+        prev = self.ids[-1] if self.ids else None
+        for r in new:
+            if prev is not None and r <= prev:
+                raise PvsError(1, f"row_ids must be strictly increasing ({r} after {prev})")
+            prev = r
+        self.ids += new
         self.grp = getattr(self, "grp", []) + list(map(int, group_ids))
 
     add = add_f32
@@ -375,9 +386,25 @@ def test_deletions_are_reconciled_in_place_and_reused_ids_come_back_as_new_rows(
     and handed out again (item_data.id is not AUTOINCREMENT) sits ABOVE the anchor — the newest loaded row that is still there
     unchanged — so its old row is dropped and append_new_rows brings the new content in; no anchor in the tail window: rebuild."""
     from panoptikon_amd import index as pvs_index
-    from panoptikon_amd import loader
 
     monkeypatch.setattr(pvs_index, "VectorIndex", _StubIndex)
+    _reconcile_scenario(lambda li: list(li.index.ids))
+
+
+@pytest.mark.gpu
+def test_deletions_are_reconciled_in_place_with_the_real_library():
+    """The same scenario against libpvs itself (the stub accepted re-added rowids the library refused — the index
+    now ascends from its last SURVIVING id, csrc/pvs_lifecycle.hip)."""
+    import panoptikon_amd as pvs
+
+    if pvs.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the gpu tests need an MI355X")
+    _reconcile_scenario(lambda li: [int(x) for x in li.index.read_ids(0, int(li.index.stats().rows))])
+
+
+def _reconcile_scenario(ids_of):
+    from panoptikon_amd import loader
+
     conn, good, scale, codes = build_db(ragged=False)
     names = ["clip/m", "tclip/m"]
     for kind in ("exact", "quant"):
@@ -398,8 +425,8 @@ def test_deletions_are_reconciled_in_place_and_reused_ids_come_back_as_new_rows(
                      (all_ids[-1], orc.quantize_int8(vec[None, :], scale)[0].tobytes()))
         assert loader.append_new_rows(conn, li, names) is None
         assert loader.reconcile_deletions(conn, li, names) == 4, kind  # (the reused id's OLD row goes too)
-        assert li.index.ids == [i for i in all_ids if i not in victims] and li.last_id == all_ids[-2]
-        assert loader.append_new_rows(conn, li, names) == 1 and li.index.ids[-1] == all_ids[-1]
+        assert ids_of(li) == [i for i in all_ids if i not in victims] and li.last_id == all_ids[-2]
+        assert loader.append_new_rows(conn, li, names) == 1 and ids_of(li)[-1] == all_ids[-1]
         assert loader._prefix_intact(conn, li, names) and li.rows == len(good) - 3
         # every row of the tail window gone: no anchor, the caller rebuilds
         for v in [t[0] for t in li.tail]:
