@@ -97,6 +97,67 @@ def parse():
     return a
 
 
+def replay_traffic(rows, dim, dtype, batch):
+    """HBM bytes per launch of the dominant kernel of a (rows, dim, dtype, batch) region, REPLAYED from the committed PMC passes
+    (profiles/traffic_table.json: one record per region, written by tools/make_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    runs of the same command; the counters cannot be collected inside a timed run).  Returns (bytes or None, provenance or None)."""
+    recs = []
+    for name in ("traffic_table.json", "traffic_latest.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                j = json.load(open(path))
+                recs += j if isinstance(j, list) else [j]
+            except Exception:  # noqa: BLE001
+                pass
+    for tj in recs:
+        if tj.get("rows") == rows and tj.get("dim") == dim and tj.get("dtype") == dtype and tj.get("batch") == batch:
+            return tj.get("hbm_bytes_per_launch"), (f"replayed from profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this region's command, "
+                                                    f"{tj.get('collected', 'date not recorded')}, kernel {str(tj.get('kernel', ''))[:48]}); not measured in this run")
+    return None, None
+
+
+def summarize_secondary(secondary):
+    """One short record per secondary region: t = tag, ms = ms per step (or per call), f = fraction of the region's roofline (b = which),
+    ok = every parity verdict of the region true (None: the region carries none).  <= ~70 characters each."""
+    out = []
+    for r in secondary:
+        if "error" in r:
+            out.append({"t": "error", "e": str(r["error"])[:60]})
+            continue
+        rl = r.get("roofline", {})
+        par = r.get("parity")
+        ok = None if not par else all(v is True for v in par.values() if isinstance(v, bool))
+        rec = {"t": r.get("tag", "?"), "ms": r.get("ms_per_step"), "b": rl.get("bound"), "f": rl.get("frac"), "ok": ok}
+        if rl.get("mfma", {}).get("frac") and r.get("dtype") == "i8" and r.get("config", {}).get("batch", 0) >= 128:
+            rec["mfma"] = rl["mfma"]["frac"]
+        if r.get("pvs_search_latency_ms"):
+            rec["p50"] = r["pvs_search_latency_ms"]["p50"]
+        if rl.get("traffic") and rl.get("algorithmic_bytes_per_launch"):
+            rec["tr"] = round(rl["traffic"] / rl["algorithmic_bytes_per_launch"], 3)
+        if "fast_frac" in r.get("path", {}):
+            rec["fast"] = r["path"]["fast_frac"]
+        out.append(rec)
+    return out
+
+
+def replay_projected_scaling(rows, dim, dtype, batch):
+    """The shard ladder (tools/shard_ladder.py: this workload at rows/N per GPU for N = 1, 2, 4, 8, each through a 1-rank RCCL
+    communicator so that the all-gather + merge span is in the step) as PROJECTED whole-job q/s — replayed from
+    profiles/projected_scaling_latest.json, never measured on N GPUs here (the driver's SCALE run is the measurement)."""
+    path = os.path.join(ROOT, "profiles", "projected_scaling_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        j = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    if (j.get("rows"), j.get("dim"), j.get("dtype"), j.get("batch")) != (rows, dim, dtype, batch):
+        return None
+    return {"label": "PROJECTED from one-GPU runs at the shard size of each N (rows/N per GPU, 1-rank RCCL exchange in the step); not a measured curve",
+            "collected": j.get("collected"), "by_n_gpus": j.get("by_n_gpus")}
+
+
 def which_config(n, d, dtype, b, k, metric):
     for i, c in CONFIGS.items():
         if (n, d, dtype, b, k, metric) == c:
@@ -627,17 +688,7 @@ def main():
     achieved_gbs = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if prof.scan_launches else 0.0
     ops_per_launch = 2.0 * n_per_gpu * D * B
     mfma_peak = I8_MFMA_PEAK_TOPS if dtype == pvs.I8 else F16_MFMA_PEAK_TFLOPS  # f32 rows run as f16 on the matrix core
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("rows") == n_per_gpu and tj.get("dim") == D and tj.get("dtype") == args.dtype and tj.get("batch") == B:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = ("replayed from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  f"command, {tj.get('collected', 'date not recorded')}); not measured in this run")
-        except Exception:  # noqa: BLE001
-            traffic = None
+    traffic, traffic_source = replay_traffic(n_per_gpu, D, args.dtype, B)
     roofline = {
         "bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -743,10 +794,12 @@ def main():
             # not follow sclk) could do AT THE CLOCK THE BOARD HOLDS under this load
             power = {"sclk_mhz": under["sclk_mhz"], "socket_power_w": under["socket_power_w"], "nominal_sclk_mhz": NOMINAL_SCLK_MHZ,
                      "mfma_frac_of_clock_scaled_peak": round(ops / (sms * 1e-3) / 1e12 / (pk * under["sclk_mhz"] / NOMINAL_SCLK_MHZ), 4) if p.scan_launches else 0.0}
+        tr2, tr2_src = replay_traffic(nrows, D, dt_name, b)
         return {"config": {"workload": f"{nrows}x{D} {dt_name} corpus, batch {b}, {args.metric}, k={K}", "rows": nrows, "dim": D, "batch": b, "k": K},
                 "metric": "knn_queries_per_sec", "value": round(steps * b / el, 1), "unit": "queries/s", "steps": steps, "warmup": warmup,
                 "ms_per_step": round(el / steps * 1e3, 4), "dtype": dt_name, "data": "synthetic",
-                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr2,
+                             **({"traffic_source": tr2_src} if tr2_src else {}),
                              "kernel": (lambda nm: nm if nm.startswith("k_direct_topk") else nm + " (pass B, filter scan)")(ixh.scan_kernel_name(b)), "launches": int(p.scan_launches), "avg_launch_ms": round(sms, 4),
                              "algorithmic_bytes_per_launch": int(by), "kernel_events": "timed region",
                              "mfma": {"achieved": round(ops / (sms * 1e-3) / 1e12, 1) if p.scan_launches else 0.0, "peak": pk,
@@ -761,6 +814,7 @@ def main():
         try:
             # (b) 256 int8 queries per pass over the same corpus: the configuration the int8 MFMA target is reachable on
             rec = timed_region(ix, "i8", 256, 20, 3, load_sample=True)
+            rec["tag"] = "i8x256"
             rec["what"] = "north-star MFMA target shape: 256 int8 queries per corpus pass (k_scan_wide, one workgroup per CU)"
             secondary.append(rec)
             # (a) single query over 10M x 768 f16: the north star's >= 70 % of HBM target
@@ -777,6 +831,7 @@ def main():
                 st16.free()
                 ix16.sync()
                 rec = timed_region(ix16, "f16", 1, 30, 3, load_sample=True)
+                rec["tag"] = "f16x1"
                 rec["what"] = "north-star HBM target shape: single query over 10M x 768 f16 (>= 70 % of the HBM roofline asked)"
                 rec["build_seconds"] = round(time.time() - t_b, 1)
                 if not args.no_verify:  # the page of the timed query against the device's dense path (the reference's algorithm in HBM)
@@ -819,6 +874,7 @@ def main():
             str_.free()
             ixr.sync()
             rec = timed_region(ixr, "i8", 1, 200, 10, K=k_ref)
+            rec["tag"] = "690k_i8x1"
             rec["what"] = "the reference's request shape: one query, page of 10, 690k x 768 int8 (one launch: exact distances + page)"
             qf = np.empty((1, D), np.float32)
             qtmp = pvs.DeviceBuffer(D * 4, device)
@@ -847,6 +903,7 @@ def main():
             # (d) a FEW queries at that scale — a PQL `or` of vector filters over one space (pql/builder.rs:638-661), callers that
             # arrive together (16 read connections, db/connection.rs:235): four queries share the one launch (round 5)
             rec = timed_region(ixr, "i8", 4, 200, 10, K=k_ref)
+            rec["tag"] = "690k_i8x4"
             rec["what"] = "a few queries at the reference's scale: four queries, pages of 10, 690k x 768 int8, ONE launch (k_direct_topk, 4-query instance)"
             qf4 = np.empty((4, D), np.float32)
             qtmp = pvs.DeviceBuffer(4 * D * 4, device)
@@ -915,7 +972,7 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     under_g = {"error": str(e)}
             tf_g = ops_g / (sms_g * 1e-3) / 1e12 if pg_.scan_launches else 0.0
-            rec = {"config": {"workload": f"per-item AVG: {n_it}x{D} f16 rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
+            rec = {"tag": "items_f16x32", "config": {"workload": f"per-item AVG: {n_it}x{D} f16 rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
                               "batch": b_it, "k": k_it},
                    "what": "the reference's exact mode per item over FLOAT rows: every (row, query) distance in the reference's f32 order, GROUP BY file, AVG, page",
                    "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
@@ -966,7 +1023,7 @@ def main():
                 sg, sv = ixs.similar_to(tg, k_sim, metric, pvs.AGG_AVG)
                 lat.append(time.perf_counter() - t_l)
             lat = np.sort(np.array(lat)) * 1e3
-            rec = {"config": {"workload": f"similar_to: {n_sim}x{D} i8 rows, {per_item} vectors per item, {per_item} target vectors, AVG per item, {args.metric}, k={k_sim}",
+            rec = {"tag": "similar_i8", "config": {"workload": f"similar_to: {n_sim}x{D} i8 rows, {per_item} vectors per item, {per_item} target vectors, AVG per item, {args.metric}, k={k_sim}",
                               "rows": n_sim, "dim": D, "targets": per_item, "k": k_sim},
                    "what": "the reference's similar_to at its measured scale (9.5-31 s per call there): target vectors x every other row, per-item AVG, page",
                    "metric": "calls_per_sec", "value": round(1e3 / float(lat[50]), 1), "unit": "calls/s", "steps": 100, "ms_per_step": round(float(lat[50]), 4),
@@ -1095,6 +1152,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"]["sqlite_udf"] = {"error": str(e)}
     if rank == 0:
+        # The driver keeps the LAST 2,000 characters of this line: every secondary region once more, compact (tag, ms per step or per
+        # call, fraction of its roofline, parity verdict), and the projected shard ladder, as the line's final keys.
+        if secondary:
+            result["secondary_summary"] = summarize_secondary(secondary)
+        proj = replay_projected_scaling(N, D, args.dtype, B)
+        if proj and n_gpus == 1 and not args.force_comm:
+            result["projected_scaling"] = proj
         real_stdout.write(json.dumps(result) + "\n")
         real_stdout.flush()
     ctl.barrier()

@@ -75,3 +75,44 @@ def test_one_process_two_shards_on_one_device(pvs):
     rec, err = _bench("single_process_devices_0_0_2Mx768_i8_b128", "--single-process", "--gpus", "2", "--devices", "0,0", "--rows", "2000000", *COMMON)
     assert rec["n_gpus"] == 2 and rec["parity"]["ids_and_distances_bit_exact"] is True and rec["recall_at_k"] == 1.0
     assert "multi-device" in rec["config"]["exchange"]
+
+
+# ---- round 6: the shapes an 8-GPU node runs, at FULL size on the GPU this box has.  Eight rank processes
+# share the device (12.5M-row shards of configs[3]: 76.8 GB of codes in total; file shards of configs[4]); RCCL refuses ranks
+# that share a GPU, so the page exchange goes over the control socket (`--allow-host-gather`, the line says so) — rendezvous,
+# shard ranges, the global int8 scale, 8 concurrent shard builds and searches, the 8-way merge and the oracle parity leg ON
+# EVERY RANK are the code the 8-GPU job runs.
+def _free_gb(pvs):
+    import ctypes as C
+
+    f, t = C.c_uint64(), C.c_uint64()
+    pvs._lib.check(pvs.lib().pvs_device_mem_info(0, C.byref(f), C.byref(t)))
+    return f.value / 2**30
+
+
+@pytest.mark.parametrize("ranks", [8, 4])
+def test_config3_full_size_as_rank_processes(pvs, ranks):
+    """BASELINE configs[3]: 100M x 768 int8 row-sharded, 256 queries per pass, k = 100 — all 100M rows, `ranks` processes."""
+    if _free_gb(pvs) < 150:
+        pytest.skip("needs ~120 GB of free HBM (100M x 768 int8 in shards + staging)")
+    rec, err = _bench(f"gpus{ranks}_ranks_cfg3_100Mx768_i8_b256", "--config", "3", "--gpus", str(ranks), "--allow-host-gather", "--steps", "5", "--warmup", "2",
+                      "--no-peaks", "--no-secondary", "--no-cpu-baseline", "--check-queries", "2" if ranks == 8 else "1", timeout=1500)
+    assert rec["n_gpus"] == ranks and rec["steps"] == 5 and rec["value"] > 0
+    assert rec["config"]["rows"] == 100_000_000 and rec["config"]["batch"] == 256 and "configs[3]" in rec["config"]["workload"]
+    par = rec["parity"]
+    assert par["ids_and_distances_bit_exact"] is True and par["oracle_rows"] == 100_000_000 and rec["recall_at_k"] == 1.0
+    assert par["checked_on"] == f"every one of the {ranks} ranks"
+    want = "rccl-allgather" if pvs.device_count() >= ranks else "ctl-host-gather"
+    assert rec["config"]["exchange"] == want, (rec["config"]["exchange"], err[-1500:])
+
+
+@pytest.mark.parametrize("ranks", [8, 4])
+def test_config4_full_size_as_rank_processes(pvs, ranks):
+    """BASELINE configs[4]: 2 x 25M rows (512-d image + 1024-d text, int8) sharded BY FILE, the PQL or-composition fused by RRF across
+    the ranks (pvs_rrf_search_sharded), checked on every rank by exact global window ranks from the oracle's distances."""
+    if _free_gb(pvs) < 100:
+        pytest.skip("needs ~60 GB of free HBM")
+    rec, err = _bench(f"gpus{ranks}_ranks_cfg4_2x25M_i8", "--config", "4", "--gpus", str(ranks), "--allow-host-gather", "--steps", "5", "--warmup", "2", timeout=1500)
+    assert rec["n_gpus"] == ranks and rec["value"] > 0 and rec["config"]["rows"] == 50_000_000
+    par = rec.get("parity", {})
+    assert par and all(v is True for v in par.values() if isinstance(v, bool)), par

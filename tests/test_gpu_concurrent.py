@@ -206,7 +206,15 @@ def _reader(pvs, ix, w, kind, qs, mask, targets, stop, log, errors, device):
             else:  # "tickets": three stream-ordered searches left in flight for a while, then waited for
                 ts = []
                 for s in range(3):
-                    ts.append((ix.search_device(dq[(j + s) % len(qs)], L.F32, 1, 10, pvs.COSINE, *outs[s]), (j + s) % len(qs), w.completed))
+                    lo_s = w.completed
+                    try:
+                        ts.append((ix.search_device(dq[(j + s) % len(qs)], L.F32, 1, 10, pvs.COSINE, *outs[s]), (j + s) % len(qs), lo_s))
+                    except pvs.PvsError as e:
+                        # every one of the 16 contexts is taken (the reference's pool size): the stream-ordered entry says so instead of
+                        # blocking — its caller may be the thread that has to pvs_wait one.  Wait for what we hold and go on.
+                        if e.status != 5:
+                            raise
+                        break
                 time.sleep(0.0005)
                 for s, (t, jj, lo_s) in enumerate(ts):
                     ix.wait(t)
