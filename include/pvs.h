@@ -679,6 +679,9 @@ pvs_status pvs_microbench(int32_t device, pvs_microbench_result *out);
  *   "no_direct_topk"          a single query always takes the filter scan, never the one-launch exact search (pvs_direct.hip)
  *   "direct_max_mb" N         ... takes the one-launch search up to N MB of rows (default 8192)
  *   "direct_queries"          (read-only counter) single queries answered by the one-launch search, process-wide
+ *   "no_float_certify"        per-item pages over f16 / f32 rows: every (row, query) distance exact (k_exact_wide) instead of the matrix-core
+ *                             brackets + exact rescan of the candidate files (csrc/pvs_items_float.hip; same pages either way)
+ *   "float_certify_queries" / "float_certify_rows"   (read-only counters) queries that route answered; candidate rows it rescanned
  *   "comm_timeout_s" N        bound on every wait for the other ranks: communicator creation (ncclCommInitRank + a one-word
  *                             all-reduce, the communicator's first collective), the shard exchange behind pvs_wait, the control
  *                             messages of the sharded fusion (default 180 s).  On expiry the communicator is aborted and the call

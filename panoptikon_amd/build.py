@@ -25,7 +25,7 @@ SOURCES = [
     "pvs_search.hip",
     "pvs_search_host.hip",
     "pvs_search_device.hip",
-    "pvs_items.hip",
+    "pvs_items.hip", "pvs_items_float.hip",
     "pvs_rrf_search.hip",
     "pvs_similar.hip",
     "pvs_kernels_util.hip",

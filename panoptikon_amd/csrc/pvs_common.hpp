@@ -90,6 +90,9 @@ enum PvsDbg {
     PVS_DBG_NO_DENSE2,             // dense exact path, 8 float queries: one row per lane (k_dense_exact) instead of two (k_dense_exact2)
     PVS_DBG_COMM_TIMEOUT_S,        // bound on every wait for the other ranks (communicator creation, a shard exchange): seconds (0: 180)
     PVS_DBG_COMM_FAIL_LOCAL,       // tests: the next pvs_search_sharded_async of this process fails locally before its exchange (value = how many)
+    PVS_DBG_NO_FLOAT_CERTIFY,      // per-item pages over float rows: every distance exact (k_exact_wide) instead of bound + certify + rescan (pvs_items_float.hip)
+    PVS_DBG_FLOAT_CERTIFY_QUERIES, // (a counter) per-item queries answered by the certified route
+    PVS_DBG_FLOAT_CERTIFY_ROWS,    // (a counter) candidate rows its exact stage rescanned, summed over chunks
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

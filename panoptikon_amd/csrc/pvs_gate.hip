@@ -68,7 +68,9 @@ void pvs_gate_shared_exit(pvs_index *ix) {
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->gate_shared--;
-        wake = ix->gate_shared == 0 && ix->gate_writers_waiting;
+        // (a writer that has announced itself is `waiting` until its turn among writers and `active` while it drains the readers:
+        //  it sleeps on ctx_cv in both states — ctx_done's notify comes BEFORE this decrement, so the last reader out must wake it)
+        wake = ix->gate_shared == 0 && (ix->gate_writers_waiting || ix->gate_writer_active);
     }
     if (wake) ix->ctx_cv.notify_all();
 }

@@ -768,6 +768,28 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
                 d_vt = nullptr;
             }
             if (fused_done) continue;
+            // float rows: bracket every file's aggregate from the matrix-core scan keys, rescan exactly only the files that can reach
+            // the page (pvs_items_float.hip); whatever it cannot certify falls through to the exact-everywhere route below
+            if (ix->n && pvs_float_certify_applies(ix, nb, k)) {
+                bool certified = false;
+                std::vector<uint8_t> redo;
+                PVS_TRY(pvs_float_groups_certified(ix, *c, q_dev, qdtype, q0, nb, pad, k, metric, agg, d_w, dm, d_m, out_groups + (size_t)q0 * k,
+                                                   out_values + (size_t)q0 * k, out_count + q0, &certified, &redo));
+                if (certified) {
+                    // queries nothing can be bracketed for (every distance NULL: a zero query under cosine, a NaN component): one by one
+                    // through the exact-everywhere route
+                    for (uint32_t j = 0; j < nb; j++) {
+                        if (!redo[j]) continue;
+                        PVS_TRY(prep_chunk(ix, *c, q_dev, qdtype, q0 + j, 1, 32, metric));
+                        PVS_TRY(dense_chunk(ix, *c, 1, 32, metric, d_m));
+                        PVS_TRY(aggregate_and_rank(ix, *c, d_m, 1, 0, agg, d_w, dm, k, out_groups + (size_t)(q0 + j) * k, out_values + (size_t)(q0 + j) * k,
+                                                   out_count + q0 + j, FanoutWeights(), dm ? 0u : 1u));
+                        dense_q++;
+                    }
+                    continue;
+                }
+                PVS_TRY(prep_chunk(ix, *c, q_dev, qdtype, q0, nb, pad, metric));  // (the rescan stage prepared the context for its own chunks)
+            }
             dense_q += nb;
             if (ix->n) PVS_TRY(dense_chunk(ix, *c, nb, pad, metric, d_m));
             PVS_TRY(aggregate_and_rank(ix, *c, d_m, nb, 0, agg, d_w, dm, k, out_groups + (size_t)q0 * k, out_values + (size_t)q0 * k,

@@ -102,7 +102,7 @@ struct ScanArgs {
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;
     const QInfo *qinfo;
-    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8), 3 = dense exact folded per group
+    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8), 3 = dense exact folded per group, 4 = dense scan KEYS (float rows: dense_out[row][query] = key, error eA + eR |a|^2)
     float *dense_out = nullptr;       // mode 2: [n_rows][dense_ld]
     uint32_t *dense_flag = nullptr;   // mode 2
     uint32_t dense_ld = 0, batch = 0;

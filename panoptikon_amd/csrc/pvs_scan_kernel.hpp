@@ -691,6 +691,22 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                             }
                         }
                     }
+            } else if constexpr (MODE == 4) {
+                // the scan KEY of every (row, query) pair, dense: dense_out[row][query] = key with |key - kappa| <= eA + eR |a|^2
+                // (kappa = the reference key its distance is a monotone function of, HISTORY.md section 4.2) — what passes A / B
+                // test against thresholds, written out instead: the certified per-item search of float indexes (pvs_items_float.hip)
+                // brackets every row's distance with it, folds the brackets per file, and rescans exactly only the files that can
+                // reach the page.  cosine: key = -dscale acc / |a|; L2: key = |a|^2 + bb - 2 dscale acc (the payload form of MODE 1).
+#pragma unroll
+                for (int g = 0; g < GPW; g++)
+                    if (myq[g] < (int)a.batch && prev_valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const uint32_t row = prev_row_base + (r & 3) + 8 * (r >> 2);
+                            if (row < a.n_rows)
+                                a.dense_out[(size_t)row * a.dense_ld + myq[g]] = COS ? -e.sv[g][r] * qi[g].dscale : e.sv[g][r] + qi[g].bb + qi[g].eR * e.xh[r];
+                        }
+                    }
             } else if constexpr (MODE == 0) {
 #pragma unroll
                 for (int g = 0; g < GPW; g++)
@@ -872,12 +888,14 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
 template <int DT, int KS, int QG>
 static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream_t s) {
     if constexpr (DT == PVS_I8) {
+        if (mode == 4) return hipErrorInvalidValue;  // (int8 distances have a closed form: MODE 2 / 3)
         if (mode == 2)
             return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 2>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 2>(k, s);
         if (mode == 3)
             return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 3>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 3>(k, s);
     } else {
         if (mode == 2 || mode == 3) return hipErrorInvalidValue;  // float order matters: no closed form
+        if (mode == 4) return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 4>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 4>(k, s);
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);

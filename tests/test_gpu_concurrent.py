@@ -259,16 +259,17 @@ def test_sixteen_searching_threads_beside_a_writer(pvs, dtype, devices):
     stop, errors = threading.Event(), []
     logs = [[] for _ in kinds]
     device = devices[0] if devices else 0
-    threads = [threading.Thread(target=_reader, args=(pvs, ix, w, kd, qs, mask, targets, stop, logs[t], errors, device)) for t, kd in enumerate(kinds)]
-    wt = threading.Thread(target=_writer, args=(pvs, ix, w, np.random.default_rng(1), stop, errors, dt, scale))
+    threads = [threading.Thread(target=_reader, args=(pvs, ix, w, kd, qs, mask, targets, stop, logs[t], errors, device), daemon=True) for t, kd in enumerate(kinds)]
+    wt = threading.Thread(target=_writer, args=(pvs, ix, w, np.random.default_rng(1), stop, errors, dt, scale), daemon=True)  # (daemon: a deadlock fails the test instead of hanging the interpreter at exit)
     for t in threads:
         t.start()
     wt.start()
     time.sleep(seconds)
     stop.set()
     for t in threads + [wt]:
-        t.join(timeout=60)
-        assert not t.is_alive(), "a thread did not come back: deadlock at the gate?"
+        t.join(timeout=30)
+    stuck = [kd for t, kd in zip(threads + [wt], kinds + ["writer"]) if t.is_alive()]
+    assert not stuck, f"threads that did not come back (deadlock at the gate?): {stuck}; mutations started {w.started}, completed {w.completed}"
     assert not errors, errors
     n_mut = w.completed
     n_calls = sum(len(lg) for lg in logs)
