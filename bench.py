@@ -41,6 +41,7 @@ NOMINAL_SCLK_MHZ = 2400.0   # the shader clock the datasheet peaks are quoted at
 SEED_CORPUS = 20260928
 SEED_QUERY = 0x5EED0000
 
+CLUSTERED_QUERY_ROW0 = 1 << 40  # queries of the clustered corpus: rows of the same generator far beyond the corpus
 CFG4_ROWS = 25_000_000  # BASELINE configs[4]: 50M rows = a 512-d image-embedding index + a 1024-d text-embedding index (split assumed
                         # even), int8, ~3 vectors per file; the query is the PQL `or` of the two filters fused by RRF
 CONFIGS = {  # BASELINE.json configs[i] -> (rows, dim, dtype, batch, k, metric)
@@ -736,12 +737,16 @@ def main():
     }
 
     # ------------------------------------------------- the north star's other two shapes (own timed regions, headline fields untouched)
-    def timed_region(ixh, dt_name, b, steps, warmup, K=K, load_sample=False):
+    def timed_region(ixh, dt_name, b, steps, warmup, K=K, load_sample=False, clustered=False):
         """`steps` batches of b queries through pvs_search_device on index ixh (one stream), kernel durations from HIP events in the
         timed region: the same measurement as the headline's, as one self-contained record."""
         esz2 = {"i8": 1, "f16": 2, "f32": 4}[dt_name]
         qb = pvs.DeviceBuffer(b * D * 4, device)
-        L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b, D, qb.ptr))
+        if clustered:  # queries of a clustered corpus: the same generator and seed at rows beyond the corpus (they fall into its clusters)
+            L.check(lib.pvs_synth_rows_clustered_f32(device, SEED_CORPUS, CLUSTERED_QUERY_ROW0, b, D, qb.ptr))
+        else:
+            L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b, D, qb.ptr))
+        st0 = ixh.stats()
         o = [(pvs.DeviceBuffer(b * K * 8, device), pvs.DeviceBuffer(b * K * 4, device), pvs.DeviceBuffer(b * 4, device)) for _ in range(2)]
         pend = []
 
@@ -805,7 +810,12 @@ def main():
                              "mfma": {"achieved": round(ops / (sms * 1e-3) / 1e12, 1) if p.scan_launches else 0.0, "peak": pk,
                                       "unit": "TOP/s" if dt_name == "i8" else "TFLOP/s", "frac": round(ops / (sms * 1e-3) / 1e12 / pk, 4) if p.scan_launches else 0.0},
                              **({"under_load": under} if under else {}), **({"power": power} if power else {})},
-                "path": {"fast_queries": int(st2.fast_queries), "dense_queries": int(st2.dense_queries)}}
+                "path": {"fast_queries": int(st2.fast_queries), "dense_queries": int(st2.dense_queries),
+                         # of the queries of this region (warm-up included): answered by the filter scan / the one-launch search, handed to the
+                         # dense path, sent through the scan twice (segment overflow); candidates the last filter scan emitted per query
+                         "fast_frac": round((int(st2.fast_queries) - int(st0.fast_queries)) / max(1, (int(st2.fast_queries) - int(st0.fast_queries)) + (int(st2.dense_queries) - int(st0.dense_queries))), 4),
+                         "rescanned_queries": int(st2.rescanned_queries) - int(st0.rescanned_queries),
+                         "scan_candidates_per_query": round(int(st2.last_candidates) / max(b, 1), 1)}}
 
     secondary = []
     want_secondary = (rank == 0 and world == 1 and not single and not args.force_comm and not args.no_secondary and n_streams == 1
@@ -953,39 +963,50 @@ def main():
             ixg.set_profiling(True)
             ixg.profile(reset=True)
             n_calls = 6
+            cq0, cr0 = pvs.debug_get("float_certify_queries"), pvs.debug_get("float_certify_rows")
             t_g = time.perf_counter()
             for _ in range(n_calls):
                 gg, gv, gc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
             el_g = time.perf_counter() - t_g
+            cert_q, cert_r = pvs.debug_get("float_certify_queries") - cq0, pvs.debug_get("float_certify_rows") - cr0
             pg_ = ixg.profile()
             ixg.set_profiling(False)
             sms_g = pg_.scan_ms / max(pg_.scan_launches, 1)
-            # packed f32 on the vector ALUs: 256 CUs x 128 lane-operations per clock x 2.4 GHz.  The datasheet's 157.3 TFLOP/s counts a fused
-            # multiply-add as two; the reference rounds the product and the sum separately (sqlite-vec's scalar loop), so a multiply and an add
-            # are two instructions here and the instruction rate is the roofline
-            F32_VALU_PEAK_TFLOPS = 78.6
-            ops_g = (2.0 if metric == pvs.COSINE else 3.0) * n_it * D * b_it  # one multiply + one add (L2: + one subtract) per row, component and query, each rounded
+            # Round 6: the page is CERTIFIED, not computed row by row (csrc/pvs_items_float.hip): one matrix-core pass writes the scan key of
+            # every (row, query) pair, per-file brackets of the aggregate pick the files that can reach the page, and the reference's
+            # in-order f32 chain runs on those files only.  The dominant kernel is the scan (k_scan MODE 4): HBM-bound, the rows once.
+            # (Until round 5 every pair ran the exact chain: k_exact_wide, 4.05 ms of a 4.58-ms call, bound by the packed-f32 VALU rate.)
+            by_g = n_it * D * 2
+            gbs_g = by_g / (sms_g * 1e-3) / 1e9 if pg_.scan_launches else 0.0
             under_g = None
             if not args.no_peaks:
                 try:
                     under_g = sample_clock_and_power(lambda i: ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG), lambda: None, seconds=1.5)
                 except Exception as e:  # noqa: BLE001
                     under_g = {"error": str(e)}
-            tf_g = ops_g / (sms_g * 1e-3) / 1e12 if pg_.scan_launches else 0.0
+            # the exact-everywhere route on the same index, for the record (pvs_debug no_float_certify)
+            pvs.debug_set("no_float_certify", 1)
+            try:
+                ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                t_x = time.perf_counter()
+                for _ in range(2):
+                    xg, xv, xc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                ms_exact_everywhere = (time.perf_counter() - t_x) / 2 * 1e3
+            finally:
+                pvs.debug_set("no_float_certify", 0)
             rec = {"tag": "items_f16x32", "config": {"workload": f"per-item AVG: {n_it}x{D} f16 rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
                               "batch": b_it, "k": k_it},
-                   "what": "the reference's exact mode per item over FLOAT rows: every (row, query) distance in the reference's f32 order, GROUP BY file, AVG, page",
+                   "what": "the reference's exact mode per item over FLOAT rows (GROUP BY file, AVG, page): certified — matrix-core brackets per file, exact in-order rescan of the candidate files only",
                    "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
-                   "dtype": "f32 chains over f16 rows", "data": "synthetic",
-                   "roofline": {"bound": "valu", "achieved": round(tf_g, 1), "peak": F32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf_g / F32_VALU_PEAK_TFLOPS, 4),
-                                "traffic": None, "peak_is": "packed-f32 instruction rate (unfused multiply, add); datasheet FMA peak 157.3",
-                                "kernel": "k_exact_wide<f16, 32 queries> (every row x query exact)", "launches": int(pg_.scan_launches),
-                                "avg_launch_ms": round(sms_g, 4), "algorithmic_flops_per_launch": int(ops_g), "kernel_events": "timed region",
-                                "hbm_frac_of_the_rows_once": round(n_it * D * 2 / (sms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pg_.scan_launches else 0.0,
-                                **({"under_load": under_g} if under_g else {}),
-                                **({"power": {"sclk_mhz": under_g["sclk_mhz"], "socket_power_w": under_g["socket_power_w"], "nominal_sclk_mhz": NOMINAL_SCLK_MHZ,
-                                              "valu_frac_of_clock_scaled_peak": round(tf_g / (F32_VALU_PEAK_TFLOPS * under_g["sclk_mhz"] / NOMINAL_SCLK_MHZ), 4)}}
-                                   if under_g and under_g.get("sclk_mhz") else {})}}
+                   "dtype": "f16 rows; brackets from f16 MFMA keys, pages from f32 chains", "data": "synthetic",
+                   "roofline": {"bound": "hbm", "achieved": round(gbs_g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_g / HBM_PEAK_GBS, 4),
+                                "traffic": None, "kernel": "k_scan<f16, 1536 B, 32 queries, MODE 4> (scan keys of every row x query, dense)", "launches": int(pg_.scan_launches),
+                                "avg_launch_ms": round(sms_g, 4), "algorithmic_bytes_per_launch": int(by_g), "kernel_events": "timed region",
+                                "whole_call_frac_of_peak": round(by_g / (el_g / n_calls) / 1e9 / HBM_PEAK_GBS, 4),
+                                **({"under_load": under_g} if under_g else {})},
+                   "certified": {"queries_per_call": cert_q / n_calls, "candidate_rows_per_query": round(cert_r / max(cert_q, 1), 1),
+                                 "exact_everywhere_ms_per_call": round(ms_exact_everywhere, 3),
+                                 "same_pages_as_exact_everywhere": bool(np.array_equal(gg, xg) and np.array_equal(gv.view(np.uint64), xv.view(np.uint64)) and np.array_equal(gc, xc))}}
             if not args.no_verify:  # one column against the oracle over ALL rows (scored chunk by chunk), aggregated and ranked as SQLite does
                 import oracle as orc_g
 
@@ -1040,6 +1061,76 @@ def main():
                 rec["parity"] = {"oracle_rows": n_sim, "groups_and_f64_values_bit_exact": bool(np.array_equal(sg, eg_s) and np.array_equal(np.asarray(sv).view(np.uint64), np.asarray(ev_s).view(np.uint64)))}
             secondary.append(rec)
             ixs.close()
+            # (g) the headline shape and the reference's request shape on a REALISTIC distribution: 2,000 anisotropic clusters with power-law
+            # sizes, runs of near-duplicates, 1 % exact duplicates (pvs_synth_rows_clustered_f32; the reference measures on production
+            # CLIP / mpnet embeddings, docs/vector-int8-quant.md:220-224) — where the sampled threshold of the filter scan is NOT at its
+            # best: q/s, which path answered, candidates per query, parity
+            import oracle as orc_c
+
+            def build_clustered(n_rows):
+                amax_c = 0.0
+                stc = pvs.DeviceBuffer(chunk * D * 4, device)
+                for off in range(0, n_rows, chunk):
+                    m = min(chunk, n_rows - off)
+                    L.check(lib.pvs_synth_rows_clustered_f32(device, SEED_CORPUS, off, m, D, stc.ptr))
+                    outc = L.C.c_float()
+                    L.check(lib.pvs_absmax(stc.ptr, m * D, L.DEVICE, device, L.C.byref(outc)))
+                    amax_c = max(amax_c, float(outc.value))
+                sc = pvs.scale_from_absmax(amax_c)
+                ixc = pvs.VectorIndex(pvs.I8, D, device=device, capacity_rows=n_rows)
+                ixc.set_scale(sc)
+                for off in range(0, n_rows, chunk):
+                    m = min(chunk, n_rows - off)
+                    L.check(lib.pvs_synth_rows_clustered_f32(device, SEED_CORPUS, off, m, D, stc.ptr))
+                    ixc.add_f32((stc, m))
+                stc.free()
+                ixc.sync()
+                return ixc, sc
+
+            def clustered_parity(ixc, sc, n_rows, b, kk, n_oracle):
+                qtmp2 = pvs.DeviceBuffer(b * D * 4, device)
+                L.check(lib.pvs_synth_rows_clustered_f32(device, SEED_CORPUS, CLUSTERED_QUERY_ROW0, b, D, qtmp2.ptr))
+                qc = qtmp2.to_numpy(np.float32, (b, D)).copy()
+                qtmp2.free()
+                fi, fd, fc = ixc.search(qc, kk, metric)
+                ixc.set_path(1)
+                di3, dd3, dc3 = ixc.search(qc, kk, metric)
+                ixc.set_path(0)
+                par = {"queries_vs_device_dense_path": b,
+                       "filter_path_equals_device_dense_path": bool(np.array_equal(fc, dc3) and np.array_equal(fi, di3) and np.array_equal(fd.view(np.uint32), dd3.view(np.uint32)))}
+                qh3 = orc_c.quantize_int8(qc[:n_oracle], sc)
+                om3 = orc_c.COSINE if metric == pvs.COSINE else orc_c.L2
+                acc_i = [np.empty(0, np.int64) for _ in range(n_oracle)]
+                acc_d = [np.empty(0, np.float32) for _ in range(n_oracle)]
+                for off in range(0, n_rows, args.chunk_rows):
+                    m = min(args.chunk_rows, n_rows - off)
+                    ci, cd = orc_c.search(orc_c.I8, om3, ixc.read_rows(off, m), qh3, kk, ids=np.arange(off, off + m, dtype=np.int64), threads=min(os.cpu_count() or 1, 256))
+                    for qq_ in range(n_oracle):
+                        acc_i[qq_], acc_d[qq_] = orc_c.topk(np.concatenate([acc_d[qq_], cd[qq_]]), kk, ids=np.concatenate([acc_i[qq_], ci[qq_]]))
+                par.update({"oracle_rows": n_rows, "oracle_queries": n_oracle,
+                            "ids_and_distances_bit_exact": bool(all(np.array_equal(fi[x, :kk], acc_i[x]) and np.array_equal(fd[x, :kk].view(np.uint32), acc_d[x].view(np.uint32)) for x in range(n_oracle)))})
+                return par
+
+            t_c = time.time()
+            ixc, sc = build_clustered(N)
+            rec = timed_region(ixc, "i8", B, 20, 5, clustered=True)
+            rec["tag"] = "clustered_i8x128"
+            rec["what"] = ("the headline shape on a realistic distribution: 10M x 768 int8, 128 queries, k = 100 over 2,000 anisotropic power-law clusters with "
+                           "near-duplicate runs and 1 % exact duplicates; queries drawn from the same clusters")
+            rec["vs_iid_headline_qps"] = round(rec["value"] / qps, 3)
+            if not args.no_verify:
+                rec["parity"] = clustered_parity(ixc, sc, N, B, K, 2)
+            rec["build_and_check_seconds"] = round(time.time() - t_c, 1)
+            secondary.append(rec)
+            ixc.close()
+            ixc, sc = build_clustered(690_000)
+            rec = timed_region(ixc, "i8", 1, 200, 10, K=10, clustered=True)
+            rec["tag"] = "clustered_690k_i8x1"
+            rec["what"] = "the reference's request shape (one query, page of 10, 690k x 768 int8) on the clustered distribution"
+            if not args.no_verify:
+                rec["parity"] = clustered_parity(ixc, sc, 690_000, 4, 10, 4)
+            secondary.append(rec)
+            ixc.close()
         except Exception as e:  # noqa: BLE001  (the headline line must not depend on the extras)
             secondary.append({"error": str(e)})
         result["secondary"] = secondary

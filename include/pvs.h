@@ -81,7 +81,7 @@
 extern "C" {
 #endif
 
-#define PVS_ABI_VERSION 4
+#define PVS_ABI_VERSION 5
 
 typedef int32_t pvs_status;
 enum {
@@ -646,6 +646,13 @@ pvs_status pvs_memcpy(void *dst, const void *src, size_t bytes, int32_t device);
  * row r, component c is a pure function of (seed, row0 + r, c). */
 pvs_status pvs_synth_rows_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                               float *d_out);
+/* ABI v5 — the same contract over a distribution shaped like production embeddings (the reference measures on CLIP / mpnet
+ * vectors, docs/vector-int8-quant.md:220-224, docs/vector-quant-measurements.md:102-117): 2,000 clusters with power-law sizes,
+ * anisotropic noise inside a cluster, one block of 8 consecutive rows in ten a run of near-duplicates, one row in a hundred an
+ * exact duplicate of a row shortly before it; unit-normalised.  Queries for such a corpus: the same seed at rows beyond the
+ * corpus (they fall into the same clusters). */
+pvs_status pvs_synth_rows_clustered_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
+                                        float *d_out);
 
 /* On-box peaks for the roofline report (SURVEY.md 8d asks for datasheet AND measured peaks): streaming HBM reads with plain
  * 16-byte loads and with the LDS-DMA transport the scan uses, a device-to-device copy (read + write bytes), and the dense

@@ -85,6 +85,9 @@ def lib() -> C.CDLL:
         L.orc_synth_gauss.restype = f
         L.orc_synth_gauss.argtypes = [C.c_uint64, C.c_uint64, u32]
         L.orc_synth_rows.argtypes = [C.c_uint64, C.c_uint64, sz, u32, vp]
+        L.orc_synth_rows_clustered.argtypes = [C.c_uint64, C.c_uint64, sz, u32, vp]
+        L.orc_synth_cluster_of.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_synth_cluster_of.restype = C.c_uint32
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -416,6 +419,17 @@ def synth_rows(seed: int, row0: int, n: int, dim: int) -> np.ndarray:
     out = np.empty((n, dim), np.float32)
     lib().orc_synth_rows(seed, row0, n, dim, _p(out))
     return out
+
+
+def synth_rows_clustered(seed: int, row0: int, n: int, dim: int) -> np.ndarray:
+    """The clustered / anisotropic / duplicate-rich generator (csrc/pvs_kernels_util.hip k_synth_clustered), identical bytes."""
+    out = np.empty((n, dim), np.float32)
+    lib().orc_synth_rows_clustered(seed, row0, n, dim, _p(out))
+    return out
+
+
+def synth_cluster_of(seed: int, row: int) -> int:
+    return int(lib().orc_synth_cluster_of(seed, row))
 
 
 def max_threads() -> int:

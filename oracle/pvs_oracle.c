@@ -733,6 +733,53 @@ ORC_API void orc_synth_rows(uint64_t seed, uint64_t row0, size_t n, uint32_t dim
     }
 }
 
+/* The clustered generator (csrc/pvs_kernels_util.hip: k_synth_clustered — see there for what the distribution models): the same
+ * integer arithmetic, the same final IEEE operations, identical bytes. */
+static uint64_t synth_row_hash(uint64_t seed, uint64_t row) { return splitmix64(seed * 0xA24BAED4963EE407ULL + row * 0x9FB21C651E98DF25ULL + 0x51ED27ULL); }
+static int synth_is_dup(uint64_t seed, uint64_t row) { return row >= 17 && synth_row_hash(seed, row) % 100 == 0; }
+static uint64_t synth_source_row(uint64_t seed, uint64_t row) {
+    if (!synth_is_dup(seed, row)) return row;
+    uint64_t src = row - 1 - ((synth_row_hash(seed, row) >> 8) & 15);
+    return synth_is_dup(seed, src) ? row : src;
+}
+static uint32_t synth_cluster(uint64_t seed, uint64_t row) {
+    uint64_t u = synth_row_hash(seed ^ 0xC1u, row) >> 32;
+    uint64_t u3 = (((u * u) >> 32) * u) >> 32;
+    return (uint32_t)((u3 * 2000u) >> 32);
+}
+static int32_t synth_clustered_raw(uint64_t seed, uint64_t row, uint32_t col) {
+    uint32_t cl = synth_cluster(seed, row);
+    int sh = (int)(splitmix64(seed + 0x77u + (uint64_t)cl * 0x100000001B3ULL + (uint64_t)(col >> 3)) & 3);
+    int32_t centre = synth_raw(seed ^ 0xCE47E5ULL, cl, col);
+    uint64_t block = row >> 3;
+    int near = synth_row_hash(seed ^ 0xB10Cu, block) % 10 == 0;
+    int32_t v = 2 * centre;
+    if (near) {
+        uint32_t cb = synth_cluster(seed, block << 3);
+        int shb = (int)(splitmix64(seed + 0x77u + (uint64_t)cb * 0x100000001B3ULL + (uint64_t)(col >> 3)) & 3);
+        v = 2 * synth_raw(seed ^ 0xCE47E5ULL, cb, col) + (synth_raw(seed ^ 0x5A5AULL, block, col) >> shb) + (synth_raw(seed, row, col) >> (shb + 4));
+    } else {
+        v += synth_raw(seed, row, col) >> sh;
+    }
+    return v;
+}
+ORC_API void orc_synth_rows_clustered(uint64_t seed, uint64_t row0, size_t n, uint32_t dim, float *out) {
+    for (size_t r = 0; r < n; r++) {
+        uint64_t src = synth_source_row(seed, row0 + r);
+        int64_t ss = 0;
+        float *o = out + r * dim;
+        for (uint32_t c = 0; c < dim; c++) {
+            int32_t v = synth_clustered_raw(seed, src, c);
+            o[c] = (float)v * (1.0f / 65536.0f);
+            ss += (int64_t)v * (int64_t)v;
+        }
+        float nrm = (float)sqrt((double)ss * (1.0 / 4294967296.0));
+        if (!(nrm > 0.0f)) nrm = 1.0f;
+        for (uint32_t c = 0; c < dim; c++) o[c] = o[c] / nrm;
+    }
+}
+ORC_API uint32_t orc_synth_cluster_of(uint64_t seed, uint64_t row) { return synth_cluster(seed, synth_source_row(seed, row)); }
+
 ORC_API int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

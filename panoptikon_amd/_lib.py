@@ -164,6 +164,7 @@ SYMBOLS = {
     "pvs_device_free": (_i32, [_i32, _vp]),
     "pvs_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
     "pvs_synth_rows_f32": (_i32, [_i32, _u64, _u64, _u64, _u32, _vp]),
+    "pvs_synth_rows_clustered_f32": (_i32, [_i32, _u64, _u64, _u64, _u32, _vp]),
     "pvs_microbench": (_i32, [_i32, C.POINTER(MicrobenchResult)]),
     "pvs_debug_set": (_i32, [C.c_char_p, _i64]),
     "pvs_debug_get": (_i32, [C.c_char_p, C.POINTER(_i64)]),

@@ -1015,6 +1015,14 @@ PVS_EXPORT pvs_status pvs_synth_rows_f32(int32_t device, uint64_t seed, uint64_t
     return PVS_OK;
 }
 
+PVS_EXPORT pvs_status pvs_synth_rows_clustered_f32(int32_t device, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *d_out) {
+    if (!d_out) return pvs_fail(PVS_ERR_INVALID_ARG, "null argument");
+    PVS_TRY(use_device(device, nullptr));
+    HIP_TRY(pvs_launch_synth_clustered(seed, row0, n, dim, d_out, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return PVS_OK;
+}
+
 // exposed to pvs_comm.hip
 pvs_status pvs_index_internal_(pvs_index *ix, int *device) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");

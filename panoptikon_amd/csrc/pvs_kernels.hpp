@@ -23,6 +23,7 @@ hipError_t pvs_launch_take_rows(const void *in, uint32_t elem_bytes, const uint3
 hipError_t pvs_launch_quantize_flat(const float *src, uint64_t n, float scale, int8_t *dst, hipStream_t s);
 hipError_t pvs_launch_absmax(const float *src, uint64_t n, float *d_out_bits, hipStream_t s);
 hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s);
+hipError_t pvs_launch_synth_clustered(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s);  // clustered, anisotropic, duplicate-rich rows
 hipError_t pvs_launch_iota_ids(int64_t *ids, uint64_t n, int64_t base, hipStream_t s);
 
 // queries: [batch][dim] of qdtype (PVS_F32 or PVS_I8).  Produces, per query:

@@ -321,6 +321,71 @@ hipError_t pvs_launch_synth(uint64_t seed, uint64_t row0, uint64_t n, uint32_t d
     return hipGetLastError();
 }
 
+// ---- a corpus that looks like production embeddings instead of iid Gaussian directions (every timed number was on a
+// distribution where distances concentrate at 1 +- 0.036 and the sampled threshold is at its best).  CLIP / mpnet embeddings are
+// clustered, anisotropic and full of near-duplicates (docs/vector-int8-quant.md:220-224, docs/vector-quant-measurements.md:102-117):
+//   * 2,000 clusters with power-law sizes: cluster = floor(2000 u^3), u uniform — the largest holds ~8 % of the rows;
+//   * row = 2 x centre + noise, the noise ANISOTROPIC: per (cluster, block of 8 dimensions) divided by 1, 2, 4 or 8;
+//   * one block of 8 consecutive rows in ten is a run of NEAR-duplicates (a shared vector + 1/16 of the noise): frames of a video,
+//     crops of an image;
+//   * one row in a hundred is an EXACT duplicate of a row up to 16 positions before it (re-imported files);
+//   * unit-normalised.  Integer arithmetic up to the final IEEE operations, like k_synth: the oracle produces identical bytes.
+__device__ static inline uint64_t synth_row_hash(uint64_t seed, uint64_t row) { return splitmix64(seed * 0xA24BAED4963EE407ULL + row * 0x9FB21C651E98DF25ULL + 0x51ED27ULL); }
+__device__ static inline bool synth_is_dup(uint64_t seed, uint64_t row) { return row >= 17 && synth_row_hash(seed, row) % 100 == 0; }
+// the row whose bytes row r carries (itself, or the earlier row it duplicates — one level: a duplicate of a duplicate is an original)
+__device__ static inline uint64_t synth_source_row(uint64_t seed, uint64_t row) {
+    if (!synth_is_dup(seed, row)) return row;
+    const uint64_t src = row - 1 - ((synth_row_hash(seed, row) >> 8) & 15);
+    return synth_is_dup(seed, src) ? row : src;
+}
+__device__ static inline uint32_t synth_cluster(uint64_t seed, uint64_t row) {
+    const uint64_t u = synth_row_hash(seed ^ 0xC1u, row) >> 32;           // 32 uniform bits
+    const uint64_t u3 = (((u * u) >> 32) * u) >> 32;                       // ~ u^3 / 2^64, < 2^32
+    return (uint32_t)((u3 * 2000u) >> 32);
+}
+__device__ static inline int32_t synth_clustered_raw(uint64_t seed, uint64_t row, uint32_t col) {
+    const uint32_t cl = synth_cluster(seed, row);
+    const int sh = (int)(splitmix64(seed + 0x77u + (uint64_t)cl * 0x100000001B3ULL + (uint64_t)(col >> 3)) & 3);
+    const int32_t centre = synth_raw(seed ^ 0xCE47E5ULL, cl, col);
+    const uint64_t block = row >> 3;
+    const bool near = synth_row_hash(seed ^ 0xB10Cu, block) % 10 == 0;
+    int32_t v = 2 * centre;
+    if (near) {
+        // (the block's rows share the cluster of its first row: a run of near-duplicates lies in one cluster)
+        const uint32_t cb = synth_cluster(seed, block << 3);
+        const int shb = (int)(splitmix64(seed + 0x77u + (uint64_t)cb * 0x100000001B3ULL + (uint64_t)(col >> 3)) & 3);
+        v = 2 * synth_raw(seed ^ 0xCE47E5ULL, cb, col) + (synth_raw(seed ^ 0x5A5AULL, block, col) >> shb) + (synth_raw(seed, row, col) >> (shb + 4));
+    } else {
+        v += synth_raw(seed, row, col) >> sh;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_synth_clustered(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (uint64_t)gridDim.x * 4) {
+        const uint64_t src = synth_source_row(seed, row0 + r);
+        long long ss = 0;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            long long v = synth_clustered_raw(seed, src, c);
+            ss += v * v;
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        float nrm = (float)__dsqrt_rn((double)ss * (1.0 / 4294967296.0));
+        if (!(nrm > 0.0f)) nrm = 1.0f;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            float g = (float)synth_clustered_raw(seed, src, c) * (1.0f / 65536.0f);
+            out[r * dim + c] = __fdiv_rn(g, nrm);
+        }
+    }
+}
+hipError_t pvs_launch_synth_clustered(uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint64_t w = (n + 3) / 4;
+    unsigned g = (unsigned)(w > 65536 ? 65536 : w);
+    hipLaunchKernelGGL(k_synth_clustered, dim3(g), dim3(256), 0, s, seed, row0, n, dim, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------ query prep
 // One workgroup per (padded) query.
 __global__ __launch_bounds__(256) void k_prep_queries(int index_dtype, int qdtype, const void *queries,

@@ -82,6 +82,36 @@ def test_synth_rows_device_bytes_equal_oracle(pvs):
     assert np.array_equal(dev.view(np.uint32), orc.synth_rows(20260928, 1000, n, dim).view(np.uint32))
 
 
+def test_clustered_rows_device_bytes_equal_oracle_and_pages_stay_exact(pvs):
+    """The realistic-distribution generator (round 6: clusters with power-law sizes, anisotropic noise, near-duplicate runs, exact
+    duplicates): device bytes == oracle bytes at several offsets (duplicates reach back across chunk boundaries), and an int8
+    index over such rows answers batches and single queries like the oracle — the exact duplicates tie to the last bit and are
+    ordered by id."""
+    dim = 768
+    for row0, n in ((0, 300), (12_345, 257), ((1 << 40) + 5, 64)):
+        buf = pvs.DeviceBuffer(n * dim * 4)
+        pvs._lib.check(pvs.lib().pvs_synth_rows_clustered_f32(-1, 20260928, row0, n, dim, buf.ptr))
+        assert np.array_equal(buf.to_numpy(np.float32, (n, dim)).view(np.uint32), orc.synth_rows_clustered(20260928, row0, n, dim).view(np.uint32)), row0
+    n, dim = 300_000, 128
+    rows = orc.synth_rows_clustered(7, 0, n, dim)
+    assert len(np.unique(rows[:20_000], axis=0)) < 20_000  # exact duplicates are there
+    scale = orc.compute_int8_scale(rows)
+    ix = pvs.VectorIndex(pvs.I8, dim)
+    ix.set_scale(scale)
+    ix.add_f32(rows)
+    codes = orc.quantize_int8(rows, scale)
+    q = orc.synth_rows_clustered(7, 1 << 40, 40, dim)
+    q[1] = rows[4242]
+    qc = orc.quantize_int8(q, scale)
+    for metric, om in ((pvs.COSINE, orc.COSINE), (pvs.L2, orc.L2)):
+        gi, gd, gc = ix.search(q, 100, metric)
+        ei, ed = orc.search(orc.I8, om, codes, qc, 100, threads=8)
+        assert np.array_equal(gi[:, :100], ei) and np.array_equal(gd[:, :100].view(np.uint32), ed.view(np.uint32)), metric
+        g1, d1, c1 = ix.search(q[1], 10, metric)
+        assert np.array_equal(g1[0, :10], ei[1, :10]) and np.array_equal(d1[0, :10].view(np.uint32), ed[1, :10].view(np.uint32))
+    ix.close()
+
+
 # --------------------------------------------------------------- score_all
 @pytest.mark.parametrize("dtype", ["i8", "f16", "f32"])
 @pytest.mark.parametrize("metric", ["cosine", "l2"])

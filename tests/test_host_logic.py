@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol():
     missing = declared - exported
     assert not missing, f"declared in pvs.h but not exported: {sorted(missing)}"
     assert declared == set(L.SYMBOLS), f"binding drift: {sorted(declared ^ set(L.SYMBOLS))}"
-    assert pvs.lib().pvs_abi_version() == 4
+    assert pvs.lib().pvs_abi_version() == 5
     # the oracle is test infrastructure: the product library must not reference it
     assert "orc_" not in out
     deps = subprocess.check_output(["ldd", L.LIB_PATH], text=True)

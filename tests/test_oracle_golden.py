@@ -364,3 +364,24 @@ def test_oracle_reproduces_the_frozen_fixture_vi():
                     exact = np.linalg.norm(a - qf[qi], axis=1)
                 tol = 1e-4 if name == "i8" else 1e-5
                 assert np.all(np.abs(dist[qi] - exact) <= tol * np.maximum(np.abs(exact), 1e-3) + 1e-6), (name, mname, qi)
+
+
+def test_clustered_generator_has_the_shape_it_claims():
+    """orc_synth_rows_clustered (the realistic-distribution corpus of bench.py's round-6 secondaries; identical bytes on the device,
+    tests/test_gpu_parity.py): unit rows, ~1 % exact duplicates of a row shortly before, power-law cluster sizes, near-duplicate
+    runs, and a pure function of (seed, row): chunked generation equals one call."""
+    n, dim = 30_000, 96
+    r = orc.synth_rows_clustered(99, 0, n, dim)
+    assert np.allclose(np.linalg.norm(r.astype(np.float64), axis=1), 1.0, atol=1e-6)
+    parts = np.concatenate([orc.synth_rows_clustered(99, off, min(7001, n - off), dim) for off in range(0, n, 7001)])
+    assert np.array_equal(parts.view(np.uint32), r.view(np.uint32))
+    uniq = len(np.unique(r, axis=0))
+    assert 0.005 * n < n - uniq < 0.02 * n, (n, uniq)
+    cl = np.array([orc.synth_cluster_of(99, i) for i in range(n)])
+    counts = np.sort(np.bincount(cl, minlength=2000))[::-1]
+    assert counts[0] > 0.05 * n and counts[:20].sum() > 0.15 * n and (counts > 0).sum() > 1500  # a few big clusters, a long tail
+    # rows of one cluster are close, rows of different clusters are not; near-duplicate runs are closer still
+    same = cl[:4000, None] == cl[None, :4000]
+    d = 1.0 - r[:4000].astype(np.float64) @ r[:4000].astype(np.float64).T
+    assert np.median(d[same & ~np.eye(4000, dtype=bool)]) < 0.5 < np.median(d[~same])
+    assert (d[np.triu(np.ones((4000, 4000), bool), 1)] < 0.02).sum() > 100
