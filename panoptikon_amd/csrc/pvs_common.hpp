@@ -93,6 +93,7 @@ enum PvsDbg {
     PVS_DBG_NO_FLOAT_CERTIFY,      // per-item pages over float rows: every distance exact (k_exact_wide) instead of bound + certify + rescan (pvs_items_float.hip)
     PVS_DBG_FLOAT_CERTIFY_QUERIES, // (a counter) per-item queries answered by the certified route
     PVS_DBG_FLOAT_CERTIFY_ROWS,    // (a counter) candidate rows its exact stage rescanned, summed over chunks
+    PVS_DBG_FLOAT_CERTIFY_TRACE,   // the certified route reports its decisions on stderr (candidate rows, bad queries, who answered)
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void k_group_bounds(BoundsK a) {
         const float key = a.keys[(size_t)row * a.ld + q];
         // a row whose distance may be NULL or infinite (zero vector, |a|^2 under / overflow, NaN / inf components), or whose key is
         // not a number: no bracket
-        if (!(aa > 1e-30f && aa < 1e30f) || !(key == key) || fabsf(key) > 1e30f) {
+        // (L2: a zero vector is an ordinary row at distance |q|)
+        if (!((cosine ? aa > 1e-30f : aa >= 0.f) && aa < 1e30f) || !(key == key) || fabsf(key) > 1e30f) {
             forced = true;
             continue;
         }
@@ -254,6 +255,13 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         PVS_TRY(pvs_mask_count(d_flag, ix->n, &m, s));  // (synchronises)
         uint32_t n_bad = 0;
         for (uint32_t q = 0; q < nb; q++) n_bad += h_badq[q] ? 1u : 0u;
+        const bool trace = pvs_dbg(PVS_DBG_FLOAT_CERTIFY_TRACE) != 0;
+        if (trace) {
+            std::vector<float> ht(nb);
+            (void)hipMemcpy(ht.data(), d_thr, (size_t)nb * 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[float certify] n=%llu files=%u nb=%u k=%u metric=%d agg=%d: candidate rows %u, bad queries %u, thresholds %g %g ...\n", (unsigned long long)ix->n, G, nb, k,
+                    metric, agg, m, n_bad, ht[0], ht[nb > 1 ? 1 : 0]);
+        }
         if (n_bad == nb) return PVS_OK;  // (nothing to certify)
         spans_collect(ix, c);
         pvs_dbg_add(PVS_DBG_FLOAT_CERTIFY_ROWS, m);
@@ -267,6 +275,7 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         bool done = false;
         PVS_TRY(pvs_sparse_search_groups(ix, c, (const uint8_t *)d_queries + (size_t)q0 * qbytes, qdtype, nb, k, metric, agg, d_w, d_list, m, out_groups, out_values,
                                          out_count, &done));
+        if (trace) fprintf(stderr, "[float certify] exact stage over %u rows: %s\n", m, done ? "answered" : "handed back");
         if (done) {
             ix->sparse_queries -= nb;  // (counted there as mask-driven sparse searches; these are not)
             pvs_dbg_add(PVS_DBG_FLOAT_CERTIFY_QUERIES, nb - n_bad);
