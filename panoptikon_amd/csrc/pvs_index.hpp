@@ -391,6 +391,9 @@ static inline size_t pvs_group_pages_bytes(uint32_t chunk, uint32_t k) { return 
 pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, int agg,
                                     const float *d_weights, const uint32_t *d_list, uint32_t m, int64_t *out_groups, double *out_values, uint32_t *out_count,
                                     bool *handled);
+pvs_status pvs_sparse_groups_of_files(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t nb, uint32_t k, int metric, int agg, const float *d_weights,
+                                      const uint8_t *d_mask, const uint32_t *d_files, uint32_t m_f, uint32_t m_rows, const uint8_t *skip, int64_t *out_groups,
+                                      double *out_values, uint32_t *out_count, bool *handled);
 pvs_status pvs_sparse_search(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t batch, uint32_t k, int metric, const uint32_t *d_list,
                              uint32_t m, int64_t *d_out_ids, float *d_out_dist, uint32_t *d_out_count);
 // ---- pvs_items.hip

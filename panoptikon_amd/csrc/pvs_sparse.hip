@@ -278,6 +278,48 @@ __global__ void k_sub_slots(const uint32_t *key_s, const uint32_t *sub_off, uint
     if (j == 0) *sub_off_end = m;  // the CSR's closing offset
 }
 
+// Candidate FILES (group slots, any order, m_f <= 8,192) -> the row list grouped by file with its CSR: one workgroup.  A file's rows
+// keep their row order (grp_rows lists them so: SQLite's aggregates are order dependent); rows the mask leaves out are dropped.
+__global__ __launch_bounds__(1024) void k_files_layout(const uint32_t *files, uint32_t m_f, const uint32_t *grp_off, const uint32_t *grp_rows, const uint8_t *mask,
+                                                       const float *weights, uint32_t *sub_off, uint32_t *sub_slot, uint32_t *list, uint32_t *pos, float *w_sub, uint32_t list_cap) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (m_f + 1023) / 1024;
+    const uint32_t i0 = tid * per, i1 = min(i0 + per, m_f);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t f = files[i];
+        uint32_t c = 0;
+        for (uint32_t e = grp_off[f]; e < grp_off[f + 1]; e++) c += (!mask || mask[grp_rows[e]]) ? 1u : 0u;
+        mine += c;
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive scan of the threads' totals
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t at = s_part[tid] - mine;
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t f = files[i];
+        sub_off[i] = at;
+        sub_slot[i] = f;
+        for (uint32_t e = grp_off[f]; e < grp_off[f + 1]; e++) {
+            const uint32_t row = grp_rows[e];
+            if (mask && !mask[row]) continue;
+            if (at < list_cap) {
+                list[at] = row;
+                pos[at] = at;
+                if (w_sub) w_sub[at] = weights[row];
+            }
+            at++;
+        }
+    }
+    if (tid == 1023) sub_off[m_f] = s_part[1023];
+}
+
 constexpr uint32_t SPARSE_SORT_MAX = 8192;  // rows one in-LDS sort takes (64 KiB of records)
 constexpr uint32_t SPARSE_SELECT_KMAX = 8192;  // pvs_select.hip's largest page
 }  // namespace
@@ -647,5 +689,76 @@ pvs_status pvs_sparse_search_groups(pvs_index *ix, SearchCtx &c, const void *d_q
                     (void *)d_m, (void *)d_vals, tmp, d_work})
         pvs_scratch_free(p);
     if (st == PVS_OK && *handled) ix->sparse_queries += batch;
+    return st;
+}
+
+
+// The per-item pages of `nb` queries over the rows of m_f candidate FILES (d_files: group slots, any order, no duplicates; m_rows =
+// their rows the mask allows): the lean form of pvs_sparse_search_groups for the certified float route (pvs_items_float.hip) — the
+// list is laid out grouped by file by one workgroup (no sort, no select, one synchronisation), then gather-and-score with the
+// reference's in-order chain, SQLite's aggregates per file, one LDS ranking per query column.  *handled = false: more files than
+// one LDS ranking takes, or massive ties at a page's edge.  skip[q] != 0: that column's verdict is not looked at (its page is
+// garbage the caller overwrites).  Outputs: host arrays [nb][k].
+pvs_status pvs_sparse_groups_of_files(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t nb, uint32_t k, int metric, int agg, const float *d_weights,
+                                      const uint8_t *d_mask, const uint32_t *d_files, uint32_t m_f, uint32_t m_rows, const uint8_t *skip, int64_t *out_groups,
+                                      double *out_values, uint32_t *out_count, bool *handled) {
+    *handled = false;
+    hipStream_t s = c.stream;
+    if (m_f == 0 || m_rows == 0 || !pvs_sub_rank_supported(m_f) || nb > PVS_MAX_BATCH) return PVS_OK;
+    uint32_t *d_sub_off = nullptr, *d_sub_slot = nullptr, *d_list = nullptr, *d_pos = nullptr;
+    float *d_wsub = nullptr, *d_m = nullptr;
+    double *d_vals = nullptr;
+    void *d_work = nullptr;
+    const bool keyed = ix->d_grp_tinv && ix->d_grp_trank;
+    auto body = [&]() -> pvs_status {
+        HIP_TRY(pvs_scratch_alloc((void **)&d_sub_off, ((size_t)m_f + 1) * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_sub_slot, (size_t)m_f * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_list, (size_t)m_rows * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_pos, (size_t)m_rows * 4));
+        if (d_weights) HIP_TRY(pvs_scratch_alloc((void **)&d_wsub, (size_t)m_rows * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_m, (size_t)m_rows * nb * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_vals, (size_t)m_f * nb * 8));
+        HIP_TRY(pvs_scratch_alloc(&d_work, pvs_gm_rank_work_bytes(nb)));
+        hipLaunchKernelGGL(k_files_layout, dim3(1), dim3(1024), 0, s, d_files, m_f, ix->d_grp_off, ix->d_grp_rows, d_mask, d_weights, d_sub_off, d_sub_slot, d_list, d_pos, d_wsub, m_rows);
+        HIP_TRY(hipGetLastError());
+        const size_t off_g = 64, off_v = off_g + (size_t)nb * k * 8, off_f = off_v + (size_t)nb * k * 8, off_c = off_f + (size_t)nb * 4, need = off_c + (size_t)nb * 4;
+        if (need != pvs_group_pages_bytes(nb, k)) return pvs_fail(PVS_ERR_STATE, "per-item page layout and pvs_group_pages_bytes disagree");
+        PVS_TRY(ctx_pinned_io(c, need));
+        const uint32_t qbytes = ix->dim * (ix->dtype == PVS_I8 ? 1u : 4u), qpad = (qbytes + 63u) & ~63u;
+        const uint32_t pad = nb <= 32 ? 32 : nb <= 64 ? 64 : 128;
+        PVS_TRY(prep_chunk(ix, c, d_queries, qdtype, 0, nb, pad, metric));
+        uint32_t qt = 1;
+        while (qt * 2 <= nb && qt * 2 * qpad <= 32768 && qt * 2 <= 64) qt *= 2;
+        const dim3 g((m_rows + 256 / qt - 1) / (256 / qt), (nb + qt - 1) / qt);
+        const size_t lds = (size_t)qt * qpad;
+        // (the scorer's list-validity words: this list is grouped by file, not ascending — its "unsorted" word is not looked at; every
+        //  row comes out of the index's own CSR, none lies beyond the index)
+#define PVS_SPARSE_SCORE(DT)                                                                                                                                       \
+    hipLaunchKernelGGL(k_sparse_score<DT>, g, dim3(256), lds, s, ix->d_rows, ix->stride, (int)ix->dim, metric, ix->d_norm2, d_list, m_rows, ix->n, c.d_qexact, c.d_qinfo, \
+                       nb, qt, qpad, d_m, nb, (uint32_t *)c.h_io)
+        if (ix->dtype == PVS_I8)
+            PVS_SPARSE_SCORE(PVS_I8);
+        else if (ix->dtype == PVS_F16)
+            PVS_SPARSE_SCORE(PVS_F16);
+        else
+            PVS_SPARSE_SCORE(PVS_F32);
+#undef PVS_SPARSE_SCORE
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(pvs_launch_group_aggregate(d_m, nb, nb, 0, d_sub_off, d_pos, m_f, d_wsub, nullptr, agg, d_vals, s));
+        HIP_TRY(pvs_sub_rank(d_vals, m_f, nb, k, d_sub_slot, ix->d_grp_ids, keyed ? ix->d_grp_trank : nullptr, keyed ? ix->d_grp_tinv : nullptr, d_work,
+                             (int64_t *)(c.h_io + off_g), (double *)(c.h_io + off_v), (uint32_t *)(c.h_io + off_f), (uint32_t *)(c.h_io + off_c), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t *fl = (const uint32_t *)(c.h_io + off_f), *cn = (const uint32_t *)(c.h_io + off_c);
+        for (uint32_t q = 0; q < nb; q++)
+            if (!fl[q] && !(skip && skip[q])) return PVS_OK;  // (not handled: the caller's corpus pass answers the chunk)
+        memcpy(out_groups, c.h_io + off_g, (size_t)nb * k * 8);
+        memcpy(out_values, c.h_io + off_v, (size_t)nb * k * 8);
+        memcpy(out_count, cn, (size_t)nb * 4);
+        *handled = true;
+        return PVS_OK;
+    };
+    pvs_status st = body();
+    if (st != PVS_OK) (void)hipStreamSynchronize(s);
+    for (void *p : {(void *)d_sub_off, (void *)d_sub_slot, (void *)d_list, (void *)d_pos, (void *)d_wsub, (void *)d_m, (void *)d_vals, d_work}) pvs_scratch_free(p);
     return st;
 }
