@@ -413,7 +413,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
 // ---- pvs_items_float.hip: per-item pages over float rows by bound + certify + exact rescan of the candidates
 bool pvs_float_certify_applies(const pvs_index *ix, uint32_t nb, uint32_t k);
 pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t q0, uint32_t nb, uint32_t batch_pad, uint32_t k,
-                                      int metric, int agg, const float *d_w, const uint8_t *d_mask, float *d_keys, int64_t *out_groups, double *out_values,
+                                      int metric, int agg, const float *d_w, const uint8_t *d_mask, int64_t *out_groups, double *out_values,
                                       uint32_t *out_count, bool *handled, std::vector<uint8_t> *redo);
 struct SimilarArgs {  // similar_to's options; the row_* arrays are host arrays over the rows of the index they are passed with
     pvs_agg agg;

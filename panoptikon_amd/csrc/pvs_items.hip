@@ -773,7 +773,7 @@ pvs_status search_groups_impl(pvs_index *ix, const void *queries, pvs_dtype qdty
             if (ix->n && pvs_float_certify_applies(ix, nb, k)) {
                 bool certified = false;
                 std::vector<uint8_t> redo;
-                PVS_TRY(pvs_float_groups_certified(ix, *c, q_dev, qdtype, q0, nb, pad, k, metric, agg, d_w, dm, d_m, out_groups + (size_t)q0 * k,
+                PVS_TRY(pvs_float_groups_certified(ix, *c, q_dev, qdtype, q0, nb, pad, k, metric, agg, d_w, dm, out_groups + (size_t)q0 * k,
                                                    out_values + (size_t)q0 * k, out_count + q0, &certified, &redo));
                 if (certified) {
                     // queries nothing can be bracketed for (every distance NULL: a zero query under cosine, a NaN component): one by one

@@ -34,106 +34,117 @@ constexpr uint32_t BUCKETS = 16384;  // per query: minima of U over disjoint set
 
 struct BoundsK {
     const float *keys;       // [n][ld]
-    uint32_t ld, nb;
+    uint32_t ld, nb;         // ld = nb rounded up to a multiple of 4 (16-byte lines); lo and bucket_min share it
     const QInfo *qinfo;
     const float *norm2;      // [n] |a|^2 (sequential f32: the reference's aMag)
     const uint32_t *grp_off, *grp_rows;
     uint32_t n_groups;
     const float *weights;    // optional [n]
     const uint8_t *mask;     // optional [n]: 0 = the row takes part in nothing
+    bool rows_are_runs;      // grp_rows[e] == e: every file is one run of consecutive rows (no indirection)
     int metric, agg;
-    float *lo;               // [n_groups][nb]
-    uint32_t *bucket_min;    // [nb][BUCKETS] bit patterns of non-negative floats
+    float *lo;               // [n_groups][ld]
+    uint32_t *bucket_min;    // [BUCKETS][ld] bit patterns of non-negative floats (query-minor: the lanes of a file touch one line; k_kth reads the transpose)
     uint32_t *bad_query;     // [nb] 1: nothing of this query can be bracketed (every distance NULL, a non-finite norm): it names no candidate
                              // and the caller answers it through the exact-everywhere route
 };
 
-// one thread per (file, query), query fastest: the 32 keys of a row are one 128-byte line.  Per-row arithmetic in f32 (every
-// operation's rounding is inside the 1e-6 (1 + |d|) the brackets are widened by: five operations of 6e-8 each plus the half ulp of the
-// reference's own f32 distance), sums of brackets in f64; no division or square root in f64 (42 M threads: 0.95 ms with them, round 6).
-__global__ __launch_bounds__(256) void k_group_bounds(BoundsK a) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t q = (uint32_t)(t % a.nb);
-    const uint64_t f = t / a.nb;
-    if (f >= a.n_groups) return;
+constexpr uint32_t QCAP = 1024;   // candidate files one query may name before it counts as "cannot be certified" (ties with everything)
+constexpr uint32_t UCAP = 8192;   // files in the union of a chunk's candidates (one LDS ranking per query column: pvs_sub_rank)
+constexpr int RUN_ROWS = 16;      // rows a thread of k_run_bounds loads at once
+
+// The bracket of one row's distance from its key (f32: every rounding — five operations of 6e-8, the half ulp of the reference's own
+// f32 distance — is inside the 1e-6 (1 + |d|) the bracket is widened by) folded into a file's accumulators.
+struct FileAcc {
+    double s_lo, s_hi, s_w;
+    float x_lo, x_hi;
+    uint32_t cnt;
+    bool forced;
+    __device__ void reset(bool want_min) {
+        s_lo = s_hi = s_w = 0.0;
+        x_lo = x_hi = want_min ? __builtin_inff() : -__builtin_inff();
+        cnt = 0;
+        forced = false;
+    }
+};
+struct QConst {
+    float eA, eR, inv_sb;
+    bool ok, cosine, weighted, want_min, want_max;
+};
+__device__ static inline QConst q_const(const BoundsK &a, uint32_t q) {
     const QInfo qi = a.qinfo[q];
-    const bool cosine = a.metric == PVS_COSINE;
+    QConst c;
+    c.cosine = a.metric == PVS_COSINE;
     // a query whose distances are all NULL, or whose norm is not finite: nothing can be bracketed — it names no candidate here and is
     // answered by the exact-everywhere route (its page is the first k files in (order key, id) order, all NULL, or worse)
-    const bool q_ok = qi.bb == qi.bb && qi.bb < __builtin_inff() && (!cosine || qi.bb > 0.f) && qi.dscale > 0.f;
-    if (f == 0) a.bad_query[q] = q_ok ? 0u : 1u;
-    if (!q_ok) {
-        a.lo[f * a.nb + q] = __builtin_nanf("");  // (compares false against any threshold, +inf included)
+    c.ok = qi.bb == qi.bb && qi.bb < __builtin_inff() && (!c.cosine || qi.bb > 0.f) && qi.dscale > 0.f;
+    c.eA = qi.eA;
+    c.eR = qi.eR;
+    c.inv_sb = c.cosine && c.ok ? 1.0f / sqrtf(qi.bb) : 0.f;  // (two roundings: inside the margin)
+    c.weighted = a.weights != nullptr;
+    c.want_min = a.agg == PVS_AGG_MIN && !c.weighted;
+    c.want_max = a.agg == PVS_AGG_MAX && !c.weighted;
+    return c;
+}
+__device__ static inline void acc_row(FileAcc &f, const QConst &c, float key, float aa, float w) {
+    f.cnt++;
+    // a row whose distance may be NULL or infinite (cosine: zero vector, |a|^2 under / overflow; NaN / inf components), or whose key
+    // is not a number: no bracket.  (L2: a zero vector is an ordinary row at distance |q|.)
+    if (!((c.cosine ? aa > 1e-30f : aa >= 0.f) && aa < 1e30f) || !(fabsf(key) <= 1e30f)) {
+        f.forced = true;
         return;
     }
-    const float inv_sb = cosine ? 1.0f / sqrtf(qi.bb) : 0.f;  // (two roundings: inside the margin)
-    const uint32_t e0 = a.grp_off[f], e1 = a.grp_off[f + 1];
-    const bool weighted = a.weights != nullptr;
-    const bool want_min = a.agg == PVS_AGG_MIN, want_max = a.agg == PVS_AGG_MAX;
-    double s_lo = 0.0, s_hi = 0.0, s_w = 0.0;
-    float x_lo = want_min ? __builtin_inff() : -__builtin_inff(), x_hi = x_lo;
-    uint32_t cnt = 0;
-    bool forced = false;
-    for (uint32_t e = e0; e < e1; e++) {
-        const uint32_t row = a.grp_rows[e];
-        if (a.mask && !a.mask[row]) continue;
-        cnt++;
-        const float aa = a.norm2[row];
-        const float key = a.keys[(size_t)row * a.ld + q];
-        // a row whose distance may be NULL or infinite (cosine: zero vector, |a|^2 under / overflow; NaN / inf components), or whose
-        // key is not a number: no bracket.  (L2: a zero vector is an ordinary row at distance |q|.)
-        if (!((cosine ? aa > 1e-30f : aa >= 0.f) && aa < 1e30f) || !(key == key) || fabsf(key) > 1e30f) {
-            forced = true;
-            continue;
-        }
-        float lo, hi;
-        if (cosine) {
-            lo = 1.0f + (key - qi.eA) * inv_sb;
-            hi = 1.0f + (key + qi.eA) * inv_sb;
-        } else {
-            const float err = qi.eA + qi.eR * aa;
-            lo = sqrtf(fmaxf(key - err, 0.f));
-            hi = sqrtf(fmaxf(key + err, 0.f));
-        }
-        lo -= 1e-6f * (1.0f + fabsf(lo));
-        hi += 1e-6f * (1.0f + fabsf(hi));
-        if (weighted) {
-            const float w = a.weights[row];
-            if (!(w > 0.f && w < 1e30f)) {
-                forced = true;
-                continue;
-            }
-            s_lo += (double)lo * (double)w;
-            s_hi += (double)hi * (double)w;
-            s_w += (double)w;
-        } else if (want_min) {
-            x_lo = fminf(x_lo, lo);
-            x_hi = fminf(x_hi, hi);
-        } else if (want_max) {
-            x_lo = fmaxf(x_lo, lo);
-            x_hi = fmaxf(x_hi, hi);
-        } else {
-            s_lo += (double)lo;
-            s_hi += (double)hi;
-        }
+    float lo, hi;
+    if (c.cosine) {
+        lo = 1.0f + (key - c.eA) * c.inv_sb;
+        hi = 1.0f + (key + c.eA) * c.inv_sb;
+    } else {
+        const float err = c.eA + c.eR * aa;
+        lo = sqrtf(fmaxf(key - err, 0.f));
+        hi = sqrtf(fmaxf(key + err, 0.f));
     }
+    lo -= 1e-6f * (1.0f + fabsf(lo));
+    hi += 1e-6f * (1.0f + fabsf(hi));
+    if (c.weighted) {
+        if (!(w > 0.f && w < 1e30f)) {
+            f.forced = true;
+            return;
+        }
+        f.s_lo += (double)lo * (double)w;
+        f.s_hi += (double)hi * (double)w;
+        f.s_w += (double)w;
+    } else if (c.want_min) {
+        f.x_lo = fminf(f.x_lo, lo);
+        f.x_hi = fminf(f.x_hi, hi);
+    } else if (c.want_max) {
+        f.x_lo = fmaxf(f.x_lo, lo);
+        f.x_hi = fmaxf(f.x_hi, hi);
+    } else {
+        f.s_lo += (double)lo;
+        f.s_hi += (double)hi;
+    }
+}
+// a file's bracket [L, U] -> lo[file][q], and U into its bucket
+__device__ static inline void emit_file(const BoundsK &a, const QConst &c, const FileAcc &f, uint64_t file, uint32_t q) {
     float L, U;
-    if (cnt == 0) {  // no candidate row: the file is not part of the result at all
-        L = __builtin_inff();
+    if (!c.ok) {
+        L = __builtin_nanf("");  // (compares false against any threshold, +inf included)
         U = __builtin_inff();
-    } else if (forced) {
+    } else if (f.cnt == 0) {  // no candidate row: the file is not part of the result at all
+        L = U = __builtin_inff();
+    } else if (f.forced) {
         L = -__builtin_inff();
         U = __builtin_inff();
     } else {
-        if (want_min || want_max) {
-            L = x_lo;
-            U = x_hi;
+        if (c.want_min || c.want_max) {
+            L = f.x_lo;
+            U = f.x_hi;
         } else {
             // (the f64 sums are exact to 1e-16 relative per term, SQLite's compensated sum within an ulp of the true one; the f32
             //  reciprocal, product and conversion: three roundings — 1e-6 relative covers all of it many times over)
-            const float inv = 1.0f / (weighted ? (float)s_w : (float)cnt);
-            L = (float)s_lo * inv;
-            U = (float)s_hi * inv;
+            const float inv = 1.0f / (c.weighted ? (float)f.s_w : (float)f.cnt);
+            L = (float)f.s_lo * inv;
+            U = (float)f.s_hi * inv;
             L -= 1e-6f * (1.0f + fabsf(L));
             U += 1e-6f * (1.0f + fabsf(U));
         }
@@ -142,27 +153,127 @@ __global__ __launch_bounds__(256) void k_group_bounds(BoundsK a) {
             U = __builtin_inff();
         }
     }
-    a.lo[f * a.nb + q] = L;
+    a.lo[file * a.ld + q] = L;
     if (U < __builtin_inff()) {
         if (U < 0.f) U = 0.f;  // (raising an upper bound keeps it one; non-negative floats order like their bit patterns)
-        uint32_t *slot = a.bucket_min + (size_t)q * BUCKETS + (uint32_t)(f % BUCKETS);
+        uint32_t *slot = a.bucket_min + (size_t)(file % BUCKETS) * a.ld + q;
         const uint32_t ub = __builtin_bit_cast(uint32_t, U);
-        if (ub < *(volatile uint32_t *)slot) atomicMin(slot, ub);  // (the minimum settles after a few files per bucket: most threads only look)
+        // (the minimum settles after a few files per bucket: most threads only look — with a device-scope load the L2 serves; a
+        //  `volatile` read compiles to a system-scope load that goes out to the fabric: 42 M of them were most of this kernel's time)
+        if (ub < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, ub);
     }
 }
 
-constexpr uint32_t QCAP = 1024;   // candidate files one query may name before it counts as "cannot be certified" (ties with everything)
-constexpr uint32_t UCAP = 8192;   // files in the union of a chunk's candidates (one LDS ranking per query column: pvs_sub_rank)
+// Files that are RUNS of consecutive rows (the reference's loader streams ORDER BY item_data.id: a file's vectors are adjacent): a
+// thread takes RUN_ROWS consecutive rows of one query — file slot, |a|^2, key (+ weight, mask) of all of them loaded before any is
+// used: ~50 independent loads in flight per thread, the keys of a row one 128-byte line across the 32 query lanes — and folds them
+// file by file.  A file belongs to the thread that holds its FIRST row: rows at the start of the block that continue a file from
+// the block before are skipped, a file that runs past the block's end is followed to its end.  (A thread per (file, query) walked
+// file -> row -> key one dependent load at a time: 0.44-0.95 ms for 0.7 GB in three variants — latency, not bandwidth; a thread
+// per file with the queries in registers: 1.5 ms — 16 bytes per lane and line.)
+__global__ __launch_bounds__(256) void k_run_bounds(BoundsK a, const uint32_t *row_gidx, uint64_t n_rows, uint32_t nbp, uint32_t nbp_log2) {
+    const uint32_t q = threadIdx.x & (nbp - 1u);
+    if (q >= a.nb) return;
+    const QConst c = q_const(a, q);
+    if (blockIdx.x == 0 && threadIdx.x < nbp) a.bad_query[q] = c.ok ? 0u : 1u;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * (256u / nbp) + (threadIdx.x >> nbp_log2)) * RUN_ROWS;
+    if (r0 >= n_rows) return;
+    uint32_t g[RUN_ROWS];
+    float key[RUN_ROWS], aa[RUN_ROWS], w[RUN_ROWS];
+    uint8_t use[RUN_ROWS];
+    const uint32_t g_before = r0 ? row_gidx[r0 - 1] : 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < RUN_ROWS; i++) {
+        const uint64_t r = r0 + i < n_rows ? r0 + i : n_rows - 1;
+        g[i] = row_gidx[r];
+        aa[i] = a.norm2[r];
+        key[i] = a.keys[r * a.ld + q];
+        w[i] = c.weighted ? a.weights[r] : 1.0f;
+        use[i] = a.mask ? a.mask[r] : (uint8_t)1;
+    }
+    FileAcc f;
+    f.reset(c.want_min);
+    uint32_t cur = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < RUN_ROWS; i++) {
+        if (r0 + i >= n_rows || g[i] == g_before) continue;  // (beyond the index / the tail of a file an earlier thread owns)
+        if (g[i] != cur) {
+            if (cur != 0xffffffffu) emit_file(a, c, f, cur, q);
+            cur = g[i];
+            f.reset(c.want_min);
+        }
+        if (use[i]) acc_row(f, c, key[i], aa[i], w[i]);
+    }
+    if (cur == 0xffffffffu) return;
+    for (uint64_t r = r0 + RUN_ROWS; r < n_rows && row_gidx[r] == cur; r++)  // the last file runs on into the next block(s)
+        if (!a.mask || a.mask[r]) acc_row(f, c, a.keys[r * a.ld + q], a.norm2[r], c.weighted ? a.weights[r] : 1.0f);
+    emit_file(a, c, f, cur, q);
+}
 
-// one thread per (file, query): a candidate (L <= T) is appended to its query's list
-__global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t n_groups, const float *thr, uint32_t *qcnt, uint32_t *qlist) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (uint64_t)n_groups * nb) return;
-    const uint32_t q = (uint32_t)(t % nb);
-    if (!(lo[t] <= thr[q])) return;
-    if (*(volatile uint32_t *)(qcnt + q) > 4 * QCAP) return;  // (already beyond saving: the count only has to say so)
-    const uint32_t slot = atomicAdd(qcnt + q, 1u);
-    if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)(t / nb);
+// Files whose rows lie anywhere: one thread per (file, query) walks the file's rows through the CSR (the scattered case: dependent
+// loads, several times slower than the run form above)
+__global__ __launch_bounds__(256) void k_group_bounds(BoundsK a, uint32_t nbp, uint32_t nbp_log2) {
+    const uint32_t q = threadIdx.x & (nbp - 1u);
+    if (q >= a.nb) return;
+    const QConst c = q_const(a, q);
+    if (blockIdx.x == 0 && threadIdx.x < nbp) a.bad_query[q] = c.ok ? 0u : 1u;
+    const uint64_t file = (uint64_t)blockIdx.x * (256u / nbp) + (threadIdx.x >> nbp_log2);
+    if (file >= a.n_groups) return;
+    FileAcc f;
+    f.reset(c.want_min);
+    const uint32_t e0 = a.grp_off[file], e1 = a.grp_off[file + 1];
+    for (uint32_t e = e0; e < e1; e += 4) {
+        uint32_t row[4];
+        bool in[4];
+        float aa4[4], key4[4], w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            in[i] = e + i < e1;
+            row[i] = in[i] ? a.grp_rows[e + i] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            aa4[i] = a.norm2[row[i]];
+            key4[i] = a.keys[(size_t)row[i] * a.ld + q];
+            w4[i] = c.weighted ? a.weights[row[i]] : 1.0f;
+            if (a.mask) in[i] = in[i] && a.mask[row[i]] != 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (in[i]) acc_row(f, c, key4[i], aa4[i], w4[i]);
+    }
+    emit_file(a, c, f, file, q);
+}
+
+// one thread per (file, query), 8 files per thread (their loads issued before the first compare): a candidate (L <= T) is appended
+// to its query's list
+__global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t ld, uint32_t nbp, uint32_t nbp_log2, uint32_t n_groups, const float *thr,
+                                                    uint32_t *qcnt, uint32_t *qlist) {
+    const uint32_t q = threadIdx.x & (nbp - 1u);
+    if (q >= nb) return;
+    const float t = thr[q];
+    const uint32_t fpb = 256u / nbp;
+    float v[8];
+#pragma unroll
+    for (uint32_t it = 0; it < 8; it++) {
+        const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> nbp_log2);
+        v[it] = f < n_groups ? lo[f * ld + q] : __builtin_nanf("");
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 8; it++) {
+        if (!(v[it] <= t)) continue;
+        const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> nbp_log2);
+        if (__hip_atomic_load(qcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 * QCAP) return;  // (already beyond saving: the count only has to say so)
+        const uint32_t slot = atomicAdd(qcnt + q, 1u);
+        if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)f;
+    }
+}
+// bucket minima [BUCKETS][ld] -> [nb][BUCKETS] (what k_kth reads)
+__global__ __launch_bounds__(256) void k_bucket_transpose(const uint32_t *in, uint32_t nb, uint32_t ld, uint32_t *out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb * BUCKETS) return;
+    const uint32_t q = i / BUCKETS, b = i % BUCKETS;
+    out[i] = in[(size_t)b * ld + q];
 }
 // the union of the lists of the queries that stayed below QCAP: a file enters once (a bit per file), with its allowed rows counted
 __global__ __launch_bounds__(256) void k_union(const uint32_t *qcnt, const uint32_t *qlist, uint32_t nb, uint32_t *bits, const uint32_t *grp_off, const uint32_t *grp_rows,
@@ -192,24 +303,26 @@ bool pvs_float_certify_applies(const pvs_index *ix, uint32_t nb, uint32_t k) {
     return ix->n >= 16384;
 }
 
-// The queries [q0, q0 + nb) of d_queries were prepared in c (prep_chunk with batch_pad).  d_keys: scratch of >= n * nb floats.
+// The queries [q0, q0 + nb) of d_queries were prepared in c (prep_chunk with batch_pad).
 // *handled: the pages of the chunk are in out_*; (*redo)[q] != 0: except this query's, which the caller answers through the
 // exact-everywhere route (nothing of it can be bracketed, or it ties with more than QCAP files).
 pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d_queries, int qdtype, uint32_t q0, uint32_t nb, uint32_t batch_pad, uint32_t k,
-                                      int metric, int agg, const float *d_w, const uint8_t *d_mask, float *d_keys, int64_t *out_groups, double *out_values,
+                                      int metric, int agg, const float *d_w, const uint8_t *d_mask, int64_t *out_groups, double *out_values,
                                       uint32_t *out_count, bool *handled, std::vector<uint8_t> *redo) {
     *handled = false;
     redo->assign(nb, 0);
     hipStream_t s = c.stream;
     const uint32_t G = ix->n_groups;
-    float *d_lo = nullptr, *d_thr = nullptr;
+    const uint32_t ld = (nb + 3u) & ~3u;  // keys, lower bounds and bucket minima in 16-byte lines
+    float *d_keys = nullptr, *d_lo = nullptr, *d_thr = nullptr;
     uint32_t *d_bmin = nullptr, *d_small = nullptr, *d_qlist = nullptr, *d_bits = nullptr, *d_ufiles = nullptr;
     // d_small: [bad query flags nb | candidate counts nb | union files, union rows] — one copy to the host
     std::vector<uint32_t> h_small(2 * (size_t)nb + 2, 0);
     const size_t bits_bytes = ((size_t)G + 31) / 32 * 4;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(pvs_scratch_alloc((void **)&d_lo, (size_t)G * nb * 4));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, (size_t)nb * BUCKETS * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_keys, (size_t)ix->n * ld * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_lo, (size_t)G * ld * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, ((size_t)ld + nb) * BUCKETS * 4));  // (query-minor minima, then their transpose)
         HIP_TRY(pvs_scratch_alloc((void **)&d_thr, (size_t)nb * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_small, h_small.size() * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_qlist, (size_t)nb * QCAP * 4));
@@ -237,9 +350,9 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs));
         a.dense_out = d_keys;
-        a.dense_ld = nb;
+        a.dense_ld = ld;
         a.batch = nb;
-        HIP_TRY(pvs_launch_fill_f32((float *)d_bmin, (uint64_t)nb * BUCKETS, __builtin_inff(), s));
+        HIP_TRY(pvs_launch_fill_f32((float *)d_bmin, (uint64_t)ld * BUCKETS, __builtin_inff(), s));
         HIP_TRY(hipMemsetAsync(d_small, 0, h_small.size() * 4, s));
         HIP_TRY(hipMemsetAsync(d_bits, 0, bits_bytes, s));
         if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop)) a.ev_start = a.ev_stop = nullptr;
@@ -247,7 +360,7 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         // 2. brackets per (file, query)
         BoundsK b;
         b.keys = d_keys;
-        b.ld = nb;
+        b.ld = ld;
         b.nb = nb;
         b.qinfo = c.d_qinfo;
         b.norm2 = ix->d_norm2;
@@ -256,17 +369,28 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         b.n_groups = G;
         b.weights = d_w;
         b.mask = d_mask;
+        b.rows_are_runs = ix->groups_are_runs;
         b.metric = metric;
         b.agg = agg;
         b.lo = d_lo;
         b.bucket_min = d_bmin;
         b.bad_query = d_badq;
-        const uint64_t threads = (uint64_t)G * nb;
-        hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, b);
+        uint32_t nbp = 1, nbp_log2 = 0;
+        while (nbp < nb) nbp <<= 1, nbp_log2++;
+        const uint32_t lanes_rows = 256u / nbp;  // row blocks (run form) or files (CSR form) per workgroup
+        if (ix->groups_are_runs && ix->d_row_gidx) {
+            const uint64_t blocks = (ix->n + RUN_ROWS - 1) / RUN_ROWS;
+            hipLaunchKernelGGL(k_run_bounds, dim3((unsigned)((blocks + lanes_rows - 1) / lanes_rows)), dim3(256), 0, s, b, ix->d_row_gidx, ix->n, nbp, nbp_log2);
+        } else {
+            hipLaunchKernelGGL(k_group_bounds, dim3((unsigned)(((uint64_t)G + lanes_rows - 1) / lanes_rows)), dim3(256), 0, s, b, nbp, nbp_log2);
+        }
         HIP_TRY(hipGetLastError());
         // 3. the thresholds, 4. every query's candidate files and their union
-        HIP_TRY(pvs_launch_kth((const float *)d_bmin, BUCKETS, nb, k, d_thr, s));
-        hipLaunchKernelGGL(k_candidates, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_lo, nb, G, d_thr, d_qcnt, d_qlist);
+        uint32_t *d_bmin_t = d_bmin + (size_t)ld * BUCKETS;
+        hipLaunchKernelGGL(k_bucket_transpose, dim3((nb * BUCKETS + 255) / 256), dim3(256), 0, s, d_bmin, nb, ld, d_bmin_t);
+        HIP_TRY(pvs_launch_kth((const float *)d_bmin_t, BUCKETS, nb, k, d_thr, s));
+        hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)G + lanes_rows * 8 - 1) / (lanes_rows * 8))), dim3(256), 0, s, d_lo, nb, ld, nbp, nbp_log2, G, d_thr, d_qcnt,
+                           d_qlist);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_union, dim3(QCAP / 256, nb), dim3(256), 0, s, d_qcnt, d_qlist, nb, d_bits, ix->d_grp_off, ix->d_grp_rows, d_mask, d_ucnt, d_ufiles);
         HIP_TRY(hipGetLastError());
@@ -307,6 +431,6 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
     };
     pvs_status st = body();
     if (st != PVS_OK) (void)hipStreamSynchronize(s);
-    for (void *p : {(void *)d_lo, (void *)d_bmin, (void *)d_thr, (void *)d_small, (void *)d_qlist, (void *)d_bits, (void *)d_ufiles}) pvs_scratch_free_on(p, s);
+    for (void *p : {(void *)d_keys, (void *)d_lo, (void *)d_bmin, (void *)d_thr, (void *)d_small, (void *)d_qlist, (void *)d_bits, (void *)d_ufiles}) pvs_scratch_free_on(p, s);
     return st;
 }
