@@ -648,6 +648,14 @@ def main():
     step = step_single if (world == 1 and not args.force_comm) else step_sharded
 
     # ----------------------------------------------------------------- timing
+    # Every in-flight slot owns a search context whose buffers (and, on a multi-device index, every shard's) are allocated by its first
+    # search: with fewer warm-up steps than slots the timed region pays those allocations (round 5: `--single-process --devices 0,0`
+    # at --steps 5 --warmup 2 reported 4.76 ms/step where the steady state is 0.39 — profiles/r06_single_process_0_0_timeline.md).
+    # The untimed priming steps below touch every slot once; the W warm-up steps follow as asked.
+    priming = max(0, (slots if (world == 1 or comm is not None) else 1) + 1 - args.warmup)
+    for i in range(priming):
+        step(i)
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
@@ -729,7 +737,7 @@ def main():
         "config": {"workload": f"{N}x{D} {args.dtype} corpus, batch {B}, {args.metric}, k={K} ({which_config(N, D, args.dtype, B, K, args.metric)})",
                    "rows": N, "dim": D, "batch": B, "k": K, "metric": args.metric,
                    "parallelism": f"row-shard x{n_gpus}" + (" (one process)" if single else f" ({world} rank{'s' if world > 1 else ''})"),
-                   "exchange": gather_mode, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1,
+                   "exchange": gather_mode, "priming_steps_before_warmup": priming, "streams": n_streams, "inflight": slots if (world == 1 or comm is not None) else 1,
                    **({"debug_knobs": args.debug} if args.debug else {})},
         "roofline": roofline,
         "path": {"fast_queries": int(st.fast_queries), "dense_queries": int(st.dense_queries),

@@ -28,7 +28,7 @@ const char *const g_dbg_names[PVS_DBG_COUNT] = {
     "rrf_host_rounds", "multi_host_pages", "prelude_stream", "dense_nq4", "marker_events", "no_direct_topk", "direct_max_mb", "direct_queries",
     "direct_unit", "direct_static_pct", "direct_max_nq", "dense_full_sort", "dense_page_first", "no_flag_poll", "poll_late_pages",
     "no_exact_wide", "no_agg8", "no_dense2", "comm_timeout_s", "comm_fail_local",
-    "no_float_certify", "float_certify_queries", "float_certify_rows", "float_certify_trace",
+    "no_float_certify", "float_certify_queries", "float_certify_rows", "float_certify_trace", "float_certify_no_fold",
 };
 int dbg_key(const char *key) {
     if (!key) return -1;

@@ -94,6 +94,7 @@ enum PvsDbg {
     PVS_DBG_FLOAT_CERTIFY_QUERIES, // (a counter) per-item queries answered by the certified route
     PVS_DBG_FLOAT_CERTIFY_ROWS,    // (a counter) candidate rows its exact stage rescanned, summed over chunks
     PVS_DBG_FLOAT_CERTIFY_TRACE,   // the certified route reports its decisions on stderr (candidate rows, bad queries, who answered)
+    PVS_DBG_FLOAT_CERTIFY_NO_FOLD, // the certified route writes the key matrix (k_scan MODE 4) and folds in a second kernel also when the files are runs
     PVS_DBG_COUNT
 };
 int64_t pvs_dbg(PvsDbg key);

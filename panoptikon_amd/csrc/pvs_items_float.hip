@@ -30,7 +30,7 @@
 #include "pvs_index.hpp"
 
 namespace {
-constexpr uint32_t BUCKETS = 16384;  // per query: minima of U over disjoint sets of files (file index mod BUCKETS) -> k_kth
+constexpr uint32_t BUCKETS = PVS_FLOAT_BUCKETS;  // per query: minima of U over disjoint sets of files (file index mod BUCKETS) -> k_kth
 
 struct BoundsK {
     const float *keys;       // [n][ld]
@@ -245,6 +245,86 @@ __global__ __launch_bounds__(256) void k_group_bounds(BoundsK a, uint32_t nbp, u
     emit_file(a, c, f, file, q);
 }
 
+// MODE 5 leaves the row brackets of the files that cross a 32-row tile boundary in two sparse matrices: one thread per (such
+// file, query) folds them (a few percent of the files)
+__global__ __launch_bounds__(256) void k_spill_bounds(BoundsK a, const uint32_t *list, uint32_t n_list, const float *lo_rows, const float *hi_rows, uint32_t nbp, uint32_t nbp_log2) {
+    const uint32_t q = threadIdx.x & (nbp - 1u);
+    if (q >= a.nb) return;
+    const QConst c = q_const(a, q);
+    const uint64_t li = (uint64_t)blockIdx.x * (256u / nbp) + (threadIdx.x >> nbp_log2);
+    if (li >= n_list) return;
+    const uint32_t file = list[li];
+    const uint32_t e0 = a.grp_off[file], e1 = a.grp_off[file + 1];
+    float s_lo = 0.f, s_hi = 0.f, s_w = 0.f;
+    float x_lo = c.want_min ? __builtin_inff() : -__builtin_inff(), x_hi = x_lo;
+    uint32_t cnt = 0;
+    bool forced = false;
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t row = a.rows_are_runs ? e : a.grp_rows[e];
+        if (a.mask && !a.mask[row]) continue;
+        cnt++;
+        const float lo = lo_rows[(size_t)row * a.ld + q], hi = hi_rows[(size_t)row * a.ld + q];
+        if (!(lo == lo) || !(hi == hi)) forced = true;
+        if (c.weighted) {
+            const float w = a.weights[row];
+            if (!(w > 0.f && w < 1e30f)) forced = true;
+            s_lo += lo * w;
+            s_hi += hi * w;
+            s_w += w;
+        } else if (c.want_min) {
+            x_lo = fminf(x_lo, lo);
+            x_hi = fminf(x_hi, hi);
+        } else if (c.want_max) {
+            x_lo = fmaxf(x_lo, lo);
+            x_hi = fmaxf(x_hi, hi);
+        } else {
+            s_lo += lo;
+            s_hi += hi;
+        }
+    }
+    float L, U;
+    if (!c.ok) {
+        L = __builtin_nanf("");
+        U = __builtin_inff();
+    } else if (cnt == 0) {
+        L = U = __builtin_inff();
+    } else if (forced) {
+        L = -__builtin_inff();
+        U = __builtin_inff();
+    } else {
+        float l, u;
+        if (c.want_min || c.want_max) {
+            l = x_lo;
+            u = x_hi;
+        } else {
+            const float inv = 1.0f / (c.weighted ? s_w : (float)cnt);
+            l = s_lo * inv;
+            u = s_hi * inv;
+        }
+        // (f32 sums over the rows of one file: cnt roundings of 6e-8 each — a file of more than a few thousand rows is not worth a
+        //  bracket: forced)
+        const float mg = 1e-6f + 1.5e-7f * (float)cnt;
+        L = l - mg * (1.0f + fabsf(l));
+        U = u + mg * (1.0f + fabsf(u));
+        if (!(L == L) || !(U == U) || cnt > 4096) {
+            L = -__builtin_inff();
+            U = __builtin_inff();
+        }
+    }
+    a.lo[(size_t)file * a.ld + q] = L;
+    if (U < __builtin_inff()) {
+        if (U < 0.f) U = 0.f;
+        // (the scan's lanes own buckets [0, BUCKETS / 2): k_scan MODE 5 writes grid x RT x 8 <= 8,192 of them; these files take the rest)
+        uint32_t *slot = a.bucket_min + (size_t)(BUCKETS / 2 + file % (BUCKETS / 2)) * a.ld + q;
+        const uint32_t ub = __builtin_bit_cast(uint32_t, U);
+        if (ub < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, ub);
+    }
+}
+__global__ void k_query_flags(BoundsK a) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < a.nb) a.bad_query[q] = q_const(a, q).ok ? 0u : 1u;
+}
+
 // one thread per (file, query), 8 files per thread (their loads issued before the first compare): a candidate (L <= T) is appended
 // to its query's list
 __global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t ld, uint32_t nbp, uint32_t nbp_log2, uint32_t n_groups, const float *thr,
@@ -320,7 +400,6 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
     std::vector<uint32_t> h_small(2 * (size_t)nb + 2, 0);
     const size_t bits_bytes = ((size_t)G + 31) / 32 * 4;
     auto body = [&]() -> pvs_status {
-        HIP_TRY(pvs_scratch_alloc((void **)&d_keys, (size_t)ix->n * ld * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_lo, (size_t)G * ld * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, ((size_t)ld + nb) * BUCKETS * 4));  // (query-minor minima, then their transpose)
         HIP_TRY(pvs_scratch_alloc((void **)&d_thr, (size_t)nb * 4));
@@ -329,37 +408,11 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         HIP_TRY(pvs_scratch_alloc((void **)&d_bits, bits_bytes));
         HIP_TRY(pvs_scratch_alloc((void **)&d_ufiles, (size_t)UCAP * 4));
         uint32_t *d_badq = d_small, *d_qcnt = d_small + nb, *d_ucnt = d_small + 2 * (size_t)nb;
-        // 1. the scan keys of every (row, query) pair: one corpus pass on the matrix cores
-        ScanArgs a;
-        a.dtype = (int)ix->dtype;
-        a.metric = metric;
-        a.kslabs = ix->stride / PVS_KSLAB_BYTES;
-        a.qgroups = batch_pad / 32;
-        a.rows = ix->d_rows;
-        a.aux = metric == PVS_COSINE ? ix->d_scan_cos : ix->d_scan_l2;
-        a.stride = ix->stride;
-        a.n_rows = ix->n;
-        a.qmat = c.d_qmat;
-        a.qinfo = c.d_qinfo;
-        a.thr = c.d_thr;
-        a.gmin = c.d_gmin;
-        a.groups_per_query = 0;
-        a.mode = 4;
-        a.tile_step = 1;
-        const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);
-        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
-        a.grid = std::min<uint32_t>(n_wgtiles, (uint32_t)ix->n_cu * pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs));
-        a.dense_out = d_keys;
-        a.dense_ld = ld;
-        a.batch = nb;
-        HIP_TRY(pvs_launch_fill_f32((float *)d_bmin, (uint64_t)ld * BUCKETS, __builtin_inff(), s));
-        HIP_TRY(hipMemsetAsync(d_small, 0, h_small.size() * 4, s));
-        HIP_TRY(hipMemsetAsync(d_bits, 0, bits_bytes, s));
-        if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop)) a.ev_start = a.ev_stop = nullptr;
-        HIP_TRY(pvs_launch_scan(a, s));
-        // 2. brackets per (file, query)
+        // 1. + 2. one corpus pass on the matrix cores.  Files that are runs of rows (the loader's order): the brackets are folded per
+        // file in the scan's epilogue (k_scan MODE 5) and only the rows of tile-crossing files leave it; otherwise the scan writes
+        // the key of every (row, query) pair (MODE 4) and a second kernel walks the files.
         BoundsK b;
-        b.keys = d_keys;
+        b.keys = nullptr;
         b.ld = ld;
         b.nb = nb;
         b.qinfo = c.d_qinfo;
@@ -377,8 +430,56 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         b.bad_query = d_badq;
         uint32_t nbp = 1, nbp_log2 = 0;
         while (nbp < nb) nbp <<= 1, nbp_log2++;
-        const uint32_t lanes_rows = 256u / nbp;  // row blocks (run form) or files (CSR form) per workgroup
-        if (ix->groups_are_runs && ix->d_row_gidx) {
+        const uint32_t lanes_rows = 256u / nbp;  // row blocks (run form), files (CSR form) or listed files per workgroup
+        const bool fold_in_scan = ix->groups_are_runs && ix->d_tile_grp && !(((uintptr_t)d_mask & 3u) || ((uintptr_t)d_w & 3u)) && !pvs_dbg(PVS_DBG_FLOAT_CERTIFY_NO_FOLD);
+        ScanArgs a;
+        a.dtype = (int)ix->dtype;
+        a.metric = metric;
+        a.kslabs = ix->stride / PVS_KSLAB_BYTES;
+        a.qgroups = batch_pad / 32;
+        a.rows = ix->d_rows;
+        a.aux = metric == PVS_COSINE ? ix->d_scan_cos : ix->d_scan_l2;
+        a.stride = ix->stride;
+        a.n_rows = ix->n;
+        a.qmat = c.d_qmat;
+        a.qinfo = c.d_qinfo;
+        a.thr = c.d_thr;
+        a.gmin = c.d_gmin;
+        a.groups_per_query = 0;
+        a.mode = fold_in_scan ? 5 : 4;
+        a.tile_step = 1;
+        const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);
+        const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
+        // (MODE 5: one workgroup per CU; its lanes own 8 buckets each: grid x RT x 8 <= BUCKETS / 2)
+        a.grid = std::min<uint32_t>(n_wgtiles, fold_in_scan ? std::min<uint32_t>((uint32_t)ix->n_cu, BUCKETS / 2 / (8u * pvs_scan_row_tiles(a.qgroups)))
+                                                            : (uint32_t)ix->n_cu * pvs_scan_wg_per_cu(a.dtype, a.qgroups, a.kslabs));
+        const size_t mat = (size_t)pvs_round_up(ix->n, 32) * ld;  // floats of one [rows][ld] matrix
+        HIP_TRY(pvs_scratch_alloc((void **)&d_keys, mat * 4 * (fold_in_scan ? 2 : 1)));
+        a.dense_out = d_keys;
+        a.dense_ld = ld;
+        a.batch = nb;
+        if (fold_in_scan) {
+            a.tile_grp = ix->d_tile_grp;
+            a.fold_weights = d_w;
+            a.fold_mask = d_mask;
+            a.fold_out = (double *)d_lo;  // (MODE 5: a float matrix)
+            a.fold_ld = ld;
+            a.fold_agg = agg;
+            a.fold_bucket = d_bmin;
+            a.fold_hi_off = mat;
+        }
+        HIP_TRY(pvs_launch_fill_f32((float *)d_bmin, (uint64_t)ld * BUCKETS, __builtin_inff(), s));
+        HIP_TRY(hipMemsetAsync(d_small, 0, h_small.size() * 4, s));
+        HIP_TRY(hipMemsetAsync(d_bits, 0, bits_bytes, s));
+        if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop)) a.ev_start = a.ev_stop = nullptr;
+        HIP_TRY(pvs_launch_scan(a, s));
+        b.keys = d_keys;
+        if (fold_in_scan) {
+            hipLaunchKernelGGL(k_query_flags, dim3(1), dim3(128), 0, s, b);
+            if (ix->n_straddlers)
+                hipLaunchKernelGGL(k_spill_bounds, dim3((ix->n_straddlers + lanes_rows - 1) / lanes_rows), dim3(256), 0, s, b, ix->d_straddlers, ix->n_straddlers, d_keys,
+                                   d_keys + mat, nbp, nbp_log2);
+        } else if (ix->groups_are_runs && ix->d_row_gidx) {
             const uint64_t blocks = (ix->n + RUN_ROWS - 1) / RUN_ROWS;
             hipLaunchKernelGGL(k_run_bounds, dim3((unsigned)((blocks + lanes_rows - 1) / lanes_rows)), dim3(256), 0, s, b, ix->d_row_gidx, ix->n, nbp, nbp_log2);
         } else {

@@ -93,6 +93,7 @@ uint64_t pvs_direct_work_bytes(uint32_t n_cu);
 hipError_t pvs_launch_direct_topk(const DirectArgs &d, hipStream_t s);
 
 // ---- filter scan (pvs_kernels_scan.hip)
+constexpr uint32_t PVS_FLOAT_BUCKETS = 16384;  // per query: minima of the files' upper bounds over disjoint sets of files (file slot mod this) -> k_kth
 struct ScanArgs {
     int dtype, metric;
     uint32_t kslabs;        // stride / 256
@@ -103,7 +104,7 @@ struct ScanArgs {
     uint64_t n_rows;        // valid rows
     const uint8_t *qmat;
     const QInfo *qinfo;
-    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8), 3 = dense exact folded per group, 4 = dense scan KEYS (float rows: dense_out[row][query] = key, error eA + eR |a|^2)
+    int mode;               // 0 = group minima of the upper bound (threshold pass), 1 = filter, 2 = dense exact (int8), 3 = dense exact folded per group, 4 = dense scan KEYS (float rows: dense_out[row][query] = key, error eA + eR |a|^2), 5 = brackets of the distances folded per file (float rows, files that are runs)
     float *dense_out = nullptr;       // mode 2: [n_rows][dense_ld]
     uint32_t *dense_flag = nullptr;   // mode 2
     uint32_t dense_ld = 0, batch = 0;
@@ -128,6 +129,8 @@ struct ScanArgs {
     double *fold_out = nullptr;
     uint32_t fold_ld = 0;
     int fold_agg = 0;
+    uint32_t *fold_bucket = nullptr;  // mode 5 (see ScanK)
+    uint64_t fold_hi_off = 0;
     // optional events bound to the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of THIS kernel, and something a
     // second stream can wait for, without a marker packet in the queue)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

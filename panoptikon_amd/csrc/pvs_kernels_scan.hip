@@ -76,6 +76,8 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.fold_out = a.fold_out;
     k.fold_ld = a.fold_ld;
     k.fold_agg = a.fold_agg;
+    k.fold_bucket = a.fold_bucket;
+    k.fold_hi_off = a.fold_hi_off;
     k.ev_start = a.ev_start;
     k.ev_stop = a.ev_stop;
     hipError_t e = hipErrorInvalidValue;

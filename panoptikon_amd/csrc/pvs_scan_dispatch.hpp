@@ -37,6 +37,11 @@ struct ScanK {
     double *fold_out;           // [n_groups][fold_ld]
     uint32_t fold_ld;
     int fold_agg;               // PVS_AGG_MIN / MAX / AVG (ignored with weights)
+    // MODE 5 (float rows, brackets folded per file: pvs_items_float.hip): fold_out is a float matrix [n_groups][fold_ld] of lower
+    // bounds, fold_bucket the minima of the upper bounds [PVS_FLOAT_BUCKETS][fold_ld], fold_hi_off the distance in floats from
+    // dense_out (lower ends of the rows of tile-crossing files) to the matrix of their upper ends
+    uint32_t *fold_bucket;
+    uint64_t fold_hi_off;
     // host side only (16 bytes of kernel argument nobody reads): events bound to THIS dispatch by hipExtLaunchKernelGGL — the kernel's
     // start / stop timestamps come from its own completion signal, no marker packet goes into the queue (two hipEventRecord around
     // every kernel of a search cost 30-45 us of a 1.29-ms step at configs[2])

@@ -143,7 +143,7 @@ struct Geo {
 
 // (MODE 3 — the per-group fold — holds 32 distances and the f64 sum state on top of the query fragments: one wave per SIMD beyond 768-B rows)
 constexpr int scan_waves_per_simd(int QG, int KSLABS, int MODE) {
-    return scan_fold2(QG, KSLABS, MODE) ? 2 : (QG == 1 || KSLABS > 4 || (MODE == 3 && KSLABS > 3)) ? 1 : 2;
+    return scan_fold2(QG, KSLABS, MODE) ? 2 : (QG == 1 || KSLABS > 4 || (MODE == 3 && KSLABS > 3) || MODE == 5) ? 1 : 2;  // (MODE 5 holds 64 bracket ends per lane on top of the query fragments)
 }
 
 template <int DT, int KSLABS, int QG, int METRIC, int MODE>
@@ -183,6 +183,12 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
 #pragma unroll
         for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
+    // MODE 5: minima of the files' upper bounds this lane has seen, over FOLD_SLOTS disjoint sets of files (file slot mod FOLD_SLOTS):
+    // its share of the per-query buckets the threshold select reads — registers, written once at the end of the kernel
+    constexpr int FOLD_SLOTS = 8;
+    float umin[MODE == 5 ? FOLD_SLOTS : 1];
+#pragma unroll
+    for (int i = 0; i < (MODE == 5 ? FOLD_SLOTS : 1); i++) umin[i] = __builtin_inff();
     // Candidate emission (MODE 1).  Every (workgroup row stream, half-wave, query) triple owns a SEGMENT of a.seg_cap slots in
     // HBM, written by exactly one LANE (lane (j, h) holds query column j and the rows of half h), so the fill count is a
     // register of that lane: no staging list, no flush, no atomic of any kind.  A segment that overflows is reported through
@@ -665,6 +671,189 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 }
             }
         };
+        // MODE 5 — the certified per-item search of FLOAT indexes (pvs_items_float.hip) folded into the scan's epilogue: the previous
+        // tile's 32 rows x 32 queries of this wave become per-row BRACKETS of the reference's distance (from the scan key and its
+        // rigorous error eA + eR |a|^2, HISTORY.md section 4.2), the brackets of every file that lies inside the tile are folded (AVG: sums,
+        // MIN / MAX: extremes, positive weights: weighted sums — f32: at most 32 rows, the roundings are inside the margin) and
+        // the file's bracket [L, U] leaves as L -> fold_out[file][query] and U -> an atomic minimum in its bucket.  No key matrix is
+        // written or read (MODE 4 + k_run_bounds: 0.5 GB out, 0.5 GB back, 0.5 ms at 4M x 768 x 32).  Same control structure as
+        // MODE 3's fold: tile record, weights and mask through the scalar cache, wave-uniform branches; the row brackets of files
+        // that CROSS a tile boundary go to two sparse matrices (dense_out: lower ends, dense_out + fold_hi_off: upper ends) and are
+        // folded by k_spill_bounds afterwards.  A row that may be NULL (norm zero / not finite, key not a number) poisons its file
+        // (NaN bracket -> forced candidate).
+        auto fold_brackets = [&](Epi &e) {
+            if constexpr (MODE == 5) {
+                typedef const __attribute__((address_space(4))) uint32_t *cptr32;
+                const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(prev_row_base >> 5));
+                const uint64_t row0 = (uint64_t)tile_u * 32u;
+                if (row0 >= a.n_rows) return;
+                const bool q_ok = qi[0].bb == qi[0].bb && qi[0].bb < __builtin_inff() && (!COS || qi[0].bb > 0.f) && qi[0].dscale > 0.f;
+                const float inv_sb = COS && q_ok ? 1.0f / sqrtf(qi[0].bb) : 0.f;
+                float lo16[16], hi16[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float x = e.xh[r];  // cosine: 1/|a|, L2: |a|^2
+                    const float key = COS ? -e.sv[0][r] * qi[0].dscale : e.sv[0][r] + qi[0].bb + qi[0].eR * x;
+                    const bool valid = (COS ? (x > 1e-15f && x < 1e15f) : (x >= 0.f && x < 1e30f)) && fabsf(key) <= 1e30f;
+                    float lo, hi;
+                    if (COS) {
+                        lo = 1.0f + (key - qi[0].eA) * inv_sb;
+                        hi = 1.0f + (key + qi[0].eA) * inv_sb;
+                    } else {
+                        const float err = qi[0].eA + qi[0].eR * x;
+                        lo = sqrtf(fmaxf(key - err, 0.f));
+                        hi = sqrtf(fmaxf(key + err, 0.f));
+                    }
+                    lo -= 1e-6f * (1.0f + fabsf(lo));
+                    hi += 1e-6f * (1.0f + fabsf(hi));
+                    lo16[r] = valid ? lo : __builtin_nanf("");
+                    hi16[r] = valid ? hi : __builtin_nanf("");
+                }
+                float LO[32], HI[32];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float ol = __shfl_xor(lo16[r], 32, 64), oh = __shfl_xor(hi16[r], 32, 64);
+                    const int t = (r & 3) + 8 * (r >> 2);
+                    LO[t] = h ? ol : lo16[r];
+                    HI[t] = h ? oh : hi16[r];
+                    LO[t + 4] = h ? lo16[r] : ol;
+                    HI[t + 4] = h ? hi16[r] : oh;
+                }
+                cptr32 tg = (cptr32)(uintptr_t)(a.tile_grp + tile_u);
+                uint32_t g_run = tg[0];
+                const uint32_t m_last = tg[1], m_spill = tg[2];
+                uint32_t m_allow = 0xffffffffu;
+                if (a.fold_mask) {
+                    cptr32 mk = (cptr32)(uintptr_t)(a.fold_mask + row0);
+                    m_allow = 0;
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; w8++) {
+                        const uint32_t v = mk[w8];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) m_allow |= ((v >> (8 * b)) & 0xffu) ? (1u << (4 * w8 + b)) : 0u;
+                    }
+                }
+                const uint32_t n_here = a.n_rows - row0 >= 32u ? 32u : (uint32_t)(a.n_rows - row0);
+                const uint32_t m_rows = n_here == 32u ? 0xffffffffu : ((1u << n_here) - 1u);
+                const uint32_t m_use = m_allow & ~m_spill & m_rows;
+                const uint32_t m_sp = m_spill & m_rows;
+                const uint32_t m_end = m_last & m_rows;
+                const int q = myq[0];
+                const bool mine = h == 0 && q < (int)a.batch;
+                if (m_sp != 0) {
+#pragma unroll
+                    for (int i = 0; i < 32; i++)
+                        if (((m_sp >> i) & 1u) && mine) {
+                            a.dense_out[(row0 + (uint64_t)i) * a.dense_ld + (uint32_t)q] = LO[i];
+                            a.dense_out[a.fold_hi_off + (row0 + (uint64_t)i) * a.dense_ld + (uint32_t)q] = HI[i];
+                        }
+                }
+                float *lo_out = (float *)a.fold_out;
+                auto emit = [&](float l, float u, uint32_t cnt, bool forced) {
+                    float L, U;
+                    if (!q_ok) {
+                        L = __builtin_nanf("");
+                        U = __builtin_inff();
+                    } else if (cnt == 0) {
+                        L = U = __builtin_inff();
+                    } else if (forced || !(l == l) || !(u == u)) {
+                        L = -__builtin_inff();
+                        U = __builtin_inff();
+                    } else {
+                        const float mg = 1e-6f + 1.5e-7f * (float)cnt;
+                        L = l - mg * (1.0f + fabsf(l));
+                        U = u + mg * (1.0f + fabsf(u));
+                    }
+                    if (mine) lo_out[(size_t)g_run * a.fold_ld + (uint32_t)q] = L;
+                    // (no memory round trip here — a load or a returning atomic per file stalled the one wave per SIMD for its whole
+                    //  latency, ~10 files per tile: +0.39 ms at 4M x 768 x 32 — the minimum goes into one of the lane's registers,
+                    //  picked by the wave-uniform file slot)
+                    const uint32_t sl = g_run & (uint32_t)(FOLD_SLOTS - 1);
+                    const float uu = U < 0.f ? 0.f : U;  // (raising an upper bound keeps it one; non-negative floats order like their bit patterns)
+#pragma unroll
+                    for (int i = 0; i < FOLD_SLOTS; i++) umin[i] = sl == (uint32_t)i ? fminf(umin[i], uu) : umin[i];
+                    g_run++;
+                };
+                if (a.fold_weights) {
+                    cptr32 wp = (cptr32)(uintptr_t)(a.fold_weights + row0);
+                    uint32_t wb[32];
+#pragma unroll
+                    for (int i = 0; i < 32; i++) wb[i] = wp[i];
+                    float s_lo = 0.f, s_hi = 0.f, s_w = 0.f;
+                    uint32_t cnt = 0;
+                    bool forced = false;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;  // uniform
+                        const float w = __builtin_bit_cast(float, wb[i]);
+                        if (use) {
+                            cnt++;
+                            forced |= !(w > 0.f && w < 1e30f) || !(LO[i] == LO[i]);
+                            s_lo += LO[i] * w;
+                            s_hi += HI[i] * w;
+                            s_w += w;
+                        }
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u)) {
+                                const float inv = 1.0f / s_w;
+                                emit(s_lo * inv, s_hi * inv, cnt, forced);
+                            } else {
+                                g_run++;
+                            }
+                            s_lo = s_hi = s_w = 0.f;
+                            cnt = 0;
+                            forced = false;
+                        }
+                    }
+                } else if (a.fold_agg == PVS_AGG_AVG) {
+                    float s_lo = 0.f, s_hi = 0.f;
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;
+                        if (use) {
+                            cnt++;
+                            s_lo += LO[i];  // (a NaN bracket poisons the sums: forced below)
+                            s_hi += HI[i];
+                        }
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u)) {
+                                const float inv = 1.0f / (float)(cnt ? cnt : 1u);
+                                emit(s_lo * inv, s_hi * inv, cnt, false);
+                            } else {
+                                g_run++;
+                            }
+                            s_lo = s_hi = 0.f;
+                            cnt = 0;
+                        }
+                    }
+                } else {
+                    const bool want_min = a.fold_agg == PVS_AGG_MIN;
+                    float x_lo = want_min ? __builtin_inff() : -__builtin_inff(), x_hi = x_lo;
+                    uint32_t cnt = 0;
+                    bool forced = false;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) {
+                        const bool use = (m_use >> i) & 1u;
+                        if (use) {
+                            cnt++;
+                            forced |= !(LO[i] == LO[i]);  // (fmin / fmax drop a NaN: remember it)
+                            x_lo = want_min ? fminf(x_lo, LO[i]) : fmaxf(x_lo, LO[i]);
+                            x_hi = want_min ? fminf(x_hi, HI[i]) : fmaxf(x_hi, HI[i]);
+                        }
+                        if ((m_end >> i) & 1u) {
+                            if (!((m_sp >> i) & 1u))
+                                emit(x_lo, x_hi, cnt, forced);
+                            else
+                                g_run++;
+                            x_lo = x_hi = want_min ? __builtin_inff() : -__builtin_inff();
+                            cnt = 0;
+                            forced = false;
+                        }
+                    }
+                }
+            }
+        };
         auto epi_rest = [&](Epi &e, auto &&pv) {
             if constexpr (MODE == 3) {
                 if (prev_valid) fold_groups(e, pv);
@@ -691,6 +880,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                             }
                         }
                     }
+            } else if constexpr (MODE == 5) {
+                if (prev_valid) fold_brackets(e);
             } else if constexpr (MODE == 4) {
                 // the scan KEY of every (row, query) pair, dense: dense_out[row][query] = key with |key - kappa| <= eA + eR |a|^2
                 // (kappa = the reference key its distance is a monotone function of, HISTORY.md section 4.2) — what passes A / B
@@ -851,6 +1042,12 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = mycnt[g];
     }
 
+    if (MODE == 5 && sid < nstreams && h == 0 && myq[0] < (int)a.batch) {
+        // this lane's FOLD_SLOTS bucket minima: buckets [(sid * RT + rt) * FOLD_SLOTS, +FOLD_SLOTS) of its query, query-minor rows
+#pragma unroll
+        for (int i = 0; i < FOLD_SLOTS; i++)
+            a.fold_bucket[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = __builtin_bit_cast(uint32_t, umin[i]);
+    }
     if (MODE == 0 && sid < nstreams) {
         // Each lane holds 16 minima per query (one per accumulator row slot) = 16 disjoint row groups of its query.
         // The threshold only needs a few times k groups per query; folding to a.gmin_per_lane (a power of two)
@@ -888,7 +1085,7 @@ static hipError_t scan_launch_one(const ScanK &k, hipStream_t s) {
 template <int DT, int KS, int QG>
 static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream_t s) {
     if constexpr (DT == PVS_I8) {
-        if (mode == 4) return hipErrorInvalidValue;  // (int8 distances have a closed form: MODE 2 / 3)
+        if (mode == 4 || mode == 5) return hipErrorInvalidValue;  // (int8 distances have a closed form: MODE 2 / 3)
         if (mode == 2)
             return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 2>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 2>(k, s);
         if (mode == 3)
@@ -896,6 +1093,7 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     } else {
         if (mode == 2 || mode == 3) return hipErrorInvalidValue;  // float order matters: no closed form
         if (mode == 4) return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 4>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 4>(k, s);
+        if (mode == 5) return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 5>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 5>(k, s);
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);

@@ -78,6 +78,14 @@ def test_certified_pages_equal_exact_everywhere_and_the_oracle(pvs, dtype, scatt
             got, nq, nr, old = _both_routes(pvs, lambda: ix.search_groups(q, k, metric, agg, row_weights=weights))
             tag = (dtype, scattered, metric, agg, weights is not None)
             assert _same(got, old), tag
+            # the brackets folded in the scan's epilogue (k_scan MODE 5: files that are runs) against the key matrix + a second kernel
+            # (MODE 4 + k_run_bounds): the same pages
+            pvs.debug_set("float_certify_no_fold", 1)
+            try:
+                two_pass = ix.search_groups(q, k, metric, agg, row_weights=weights)
+            finally:
+                pvs.debug_set("float_certify_no_fold", 0)
+            assert _same(got, two_pass), (tag, "fold in the scan vs key matrix")
             if agg != pvs.AGG_MIN:  # (MIN pages come from row pages of the filter scan first)
                 # (q[3] = 0: under cosine nothing of it can be bracketed; under L2 every unit row is at distance 1 from it — a MAX that ties
                 #  with every file is set aside too; each is answered by the exact-everywhere route, the rest of the chunk certified)

@@ -119,6 +119,25 @@ def test_config4_two_25M_row_indexes_or_composition_rrf(pvs, monkeypatch):
         assert pvs.lib().pvs_rrf_last_path() == 2
         assert np.array_equal(g1, g2) and np.array_equal(s1.view(np.uint64), s2.view(np.uint64)), k
         assert (np.diff(s1) <= 0).all()
+    # ... and the ORACLE's literal composition over all 2 x 25M rows for this query (round 6; until then this test compared the
+    # bounded fusion with the device's own full ranking only): every row scored on the CPU (chunk by chunk, read back from HBM), MIN
+    # per file, row_number over ALL files of each branch, UNION, RRF, ORDER BY score DESC, file id — 100 files and their f64 scores
+    cols = []
+    for ixb, qv, om, dim, sc, gstride in ((img, qi, orc.COSINE, 512, 0.00185, 1), (txt, qt, orc.L2, 1024, 0.0013, 2)):
+        qh = orc.quantize_int8(qv[None, :], np.float32(ixb.stats().scale))[0]
+        dcol = np.empty(n, np.float32)
+        for off in range(0, n, 1_000_000):
+            dcol[off:off + 1_000_000] = orc.score_all(orc.I8, om, ixb.read_rows(off, 1_000_000), qh, threads=orc.max_threads())
+        grp = (np.arange(n, dtype=np.int64) // 3) * gstride
+        cols.append(orc.aggregate(dcol, grp, orc.AGG_MIN))
+    allg = np.union1d(cols[0][0], cols[1][0])
+    ranks = np.full((2, len(allg)), -1, np.int64)
+    for j, (g, v) in enumerate(cols):
+        ranks[j, np.searchsorted(allg, g)] = orc.row_number(v, g)
+    score = pvs.rrf_fuse(ranks, [5, 10], [1.0, 0.7])  # (host arithmetic of the C ABI = orc.rrf_score: tests/test_host_logic.py)
+    order = np.lexsort((allg, -score))[:100]
+    g100, s100 = pvs.rrf_search(brs, 100)
+    assert np.array_equal(g100, allg[order]) and np.array_equal(s100.view(np.uint64), score[order].view(np.uint64)), "configs[4] vs the oracle's literal composition over 2 x 25M rows"
     # each branch alone: the per-file page of the filter scan = the head of that branch's window
     gg, gv, gc = img.search_groups(qi[None, :], 50, pvs.COSINE, pvs.AGG_MIN)
     g_single, s_single = pvs.rrf_search(brs[:1], 50)

@@ -1152,18 +1152,20 @@ def test_full_size_properties(pvs, dtype, n, b):
         assert np.array_equal(col[gi[0]].view(np.uint32), gd[0].view(np.uint32))
         assert (col >= gd[0, -1]).sum() >= n - k  # nothing outside the page beats its last entry
         if dt == pvs.I8 and metric == pvs.COSINE:
-            # the CPU oracle over the WHOLE corpus for the first and the last query of the batch (the last one lives in the last
-            # wave of the 128- / 256-query kernel): ids and int8 distances bit for bit
+            # the CPU oracle over the WHOLE corpus for EIGHT queries spread over the batch — one per wave of the 128- / 256-query
+            # kernel, the first and the last of the batch among them (round 6; two until then): ids and int8 distances bit for bit
             scale = ix.stats().scale
-            qc = orc.quantize_int8(q[[0, b - 1]], scale)
-            acc_i = [np.empty(0, np.int64), np.empty(0, np.int64)]
-            acc_d = [np.empty(0, np.float32), np.empty(0, np.float32)]
+            which = sorted({0, b - 1, *[(t * b) // 7 + (t % 3) for t in range(1, 7)]})[:8]
+            which = [min(x, b - 1) for x in which]
+            qc = orc.quantize_int8(q[which], scale)
+            acc_i = [np.empty(0, np.int64) for _ in which]
+            acc_d = [np.empty(0, np.float32) for _ in which]
             for off in range(0, n, 1_000_000):
                 slab = ix.read_rows(off, 1_000_000)
                 ci, cd = orc.search(orc.I8, orc.COSINE, slab, qc, k, ids=np.arange(off, off + 1_000_000, dtype=np.int64), threads=orc.max_threads())
-                for t in range(2):
+                for t in range(len(which)):
                     acc_i[t], acc_d[t] = orc.topk(np.concatenate([acc_d[t], cd[t]]), k, ids=np.concatenate([acc_i[t], ci[t]]))
-            for t, qi in enumerate((0, b - 1)):
+            for t, qi in enumerate(which):
                 assert np.array_equal(gi[qi], acc_i[t]) and np.array_equal(gd[qi].view(np.uint32), acc_d[t].view(np.uint32)), f"query {qi} vs the oracle over {n} rows"
         if dt != pvs.I8 and n == 1_000_000:
             # configs[1] (1M x 768 f16 x 32) and its f32 form: the CPU oracle over the WHOLE corpus (sequential-f32 restatement of
