@@ -155,8 +155,11 @@ def replay_projected_scaling(rows, dim, dtype, batch):
         return None
     if (j.get("rows"), j.get("dim"), j.get("dtype"), j.get("batch")) != (rows, dim, dtype, batch):
         return None
-    return {"label": "PROJECTED from one-GPU runs at the shard size of each N (rows/N per GPU, 1-rank RCCL exchange in the step); not a measured curve",
-            "collected": j.get("collected"), "by_n_gpus": j.get("by_n_gpus")}
+    # (compact: the driver keeps the last 2,000 characters of the line; the full rungs are profiles/bench_r06_ladder_*.json)
+    return {"label": "PROJECTED, not measured on N GPUs: one-GPU runs at rows/N per GPU with a 1-rank RCCL exchange in the step (tools/shard_ladder.py)",
+            "collected": j.get("collected"),
+            "by_n_gpus": {n: {"ms": r.get("ms_per_step"), "qps": r.get("projected_qps"), "scan_frac": r.get("scan_hbm_frac"), "xchg_ms": r.get("exchange_ms"),
+                              "eff": r.get("efficiency")} for n, r in (j.get("by_n_gpus") or {}).items()}}
 
 
 def which_config(n, d, dtype, b, k, metric):
@@ -1008,7 +1011,8 @@ def main():
                    "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
                    "dtype": "f16 rows; brackets from f16 MFMA keys, pages from f32 chains", "data": "synthetic",
                    "roofline": {"bound": "hbm", "achieved": round(gbs_g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_g / HBM_PEAK_GBS, 4),
-                                "traffic": None, "kernel": "k_scan<f16, 1536 B, 32 queries, MODE 4> (scan keys of every row x query, dense)", "launches": int(pg_.scan_launches),
+                                "traffic": replay_traffic(n_it, D, "f16", b_it)[0], "traffic_source": replay_traffic(n_it, D, "f16", b_it)[1],
+                                "kernel": "k_scan<f16, 1536 B, 32 queries, MODE 5> (per-row brackets of the distance folded per file in the epilogue)", "launches": int(pg_.scan_launches),
                                 "avg_launch_ms": round(sms_g, 4), "algorithmic_bytes_per_launch": int(by_g), "kernel_events": "timed region",
                                 "whole_call_frac_of_peak": round(by_g / (el_g / n_calls) / 1e9 / HBM_PEAK_GBS, 4),
                                 **({"under_load": under_g} if under_g else {})},

@@ -6,7 +6,7 @@ import panoptikon_amd as pvs
 from panoptikon_amd import _lib as L
 lib = pvs.lib()
 dt = sys.argv[1] if len(sys.argv) > 1 else "f16"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 32
 N, D = 4_000_000, 768
 rng = np.random.default_rng(1)
 ix = pvs.VectorIndex(pvs.F16 if dt == "f16" else pvs.F32, D, capacity_rows=N)
@@ -20,3 +20,7 @@ q = rng.standard_normal((B, D)).astype(np.float32)
 for i in range(5):
     ix.search_groups(q, 50, pvs.COSINE, pvs.AGG_AVG)
 ix.close()
+if "--json" in sys.argv:  # (what tools/make_traffic.py reads: the region's shape and the algorithmic bytes of its dominant kernel)
+    import json
+    esz = 2 if dt == "f16" else 4
+    print(json.dumps({"dtype": dt, "config": {"rows": N, "dim": D, "batch": B}, "roofline": {"algorithmic_bytes_per_launch": N * D * esz}}))
