@@ -431,7 +431,7 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         uint32_t nbp = 1, nbp_log2 = 0;
         while (nbp < nb) nbp <<= 1, nbp_log2++;
         const uint32_t lanes_rows = 256u / nbp;  // row blocks (run form), files (CSR form) or listed files per workgroup
-        const bool fold_in_scan = ix->groups_are_runs && ix->d_tile_grp && !(((uintptr_t)d_mask & 3u) || ((uintptr_t)d_w & 3u)) && !pvs_dbg(PVS_DBG_FLOAT_CERTIFY_NO_FOLD);
+        const bool fold_in_scan = ix->groups_are_runs && ix->d_tile_grp && pvs_scan_fold5_supported((int)ix->dtype, ix->stride / PVS_KSLAB_BYTES) && !(((uintptr_t)d_mask & 3u) || ((uintptr_t)d_w & 3u)) && !pvs_dbg(PVS_DBG_FLOAT_CERTIFY_NO_FOLD);
         ScanArgs a;
         a.dtype = (int)ix->dtype;
         a.metric = metric;

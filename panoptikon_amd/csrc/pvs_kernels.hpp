@@ -136,6 +136,7 @@ struct ScanArgs {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
 bool pvs_scan_supported(int dtype, uint32_t kslabs);
+bool pvs_scan_fold5_supported(int dtype, uint32_t kslabs);  // mode 5 has an instance for this pitch
 // geometry of the filter passes (modes 0 / 1) of a shape — it depends on which kernel serves them (pvs_scan_is_wide)
 bool pvs_scan_is_wide(int dtype, uint32_t qgroups, uint32_t kslabs);
 uint32_t pvs_scan_wg_rows(int dtype, uint32_t qgroups, uint32_t kslabs);  // rows per workgroup tile

@@ -41,6 +41,13 @@ uint32_t pvs_scan_wg_per_cu(int dtype, uint32_t qgroups, uint32_t kslabs) {
 }
 uint32_t pvs_scan_max_batch(int dtype, uint32_t kslabs) { return dtype == PVS_I8 && kslabs >= 1 && kslabs <= 4 ? 256u : 128u; }  // (8-wave instances: pitch <= 1 KiB)
 
+// MODE 5 (brackets folded in the epilogue) exists for the pitches whose query fragments leave room for 64 more registers per lane:
+// f16 up to 2,048-B rows (1,024-d), f32 up to 4,096-B rows (1,024-d)
+bool pvs_scan_fold5_supported(int dtype, uint32_t kslabs) {
+    if (dtype == PVS_I8 || !pvs_scan_supported(dtype, kslabs)) return false;
+    return kslabs * (dtype == PVS_F32 ? 4u : 8u) <= 64u;
+}
+
 hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     ScanK k;
     k.rows = a.rows;

@@ -1093,7 +1093,14 @@ static hipError_t scan_launch_mm(const ScanK &k, int metric, int mode, hipStream
     } else {
         if (mode == 2 || mode == 3) return hipErrorInvalidValue;  // float order matters: no closed form
         if (mode == 4) return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 4>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 4>(k, s);
-        if (mode == 5) return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 5>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 5>(k, s);
+        if (mode == 5) {
+            // (the widest pitches keep 384 VGPRs of query fragments: 64 bracket ends on top of them spill — pvs_scan_fold5_supported
+            //  sends those shapes through MODE 4 and the second kernel; tools/check_scratch.py)
+            if constexpr (KS * steps_per_slab<DT>() <= 64)
+                return metric == PVS_COSINE ? scan_launch_one<DT, KS, QG, PVS_COSINE, 5>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 5>(k, s);
+            else
+                return hipErrorInvalidValue;
+        }
     }
     if (metric == PVS_COSINE) return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_COSINE, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_COSINE, 1>(k, s);
     return mode == 0 ? scan_launch_one<DT, KS, QG, PVS_L2, 0>(k, s) : scan_launch_one<DT, KS, QG, PVS_L2, 1>(k, s);
