@@ -418,8 +418,38 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         // ---- epilogue of the previous tile, cut into micro-steps the main loop drops between MFMAs, plus a rest.
         //  PRETEST: 8 steps per group (v_max3 fold of two accumulators each) — no row scalar is touched;
         //  otherwise 16 steps per group (8 score pairs, 8 folds), row scalars in xh.
+        // MODE 5: per-query constants of the bracket arithmetic, and the NEXT fold's tile record (+ candidate-mask bits), loaded through
+        // the scalar cache at the end of the tile before — the record of the tile a fold works on was asked for one whole tile
+        // earlier (asked for at the fold itself, its ~1 us of latency stalled the one wave per SIMD once per tile)
+        const bool f5_ok = qi[0].bb == qi[0].bb && qi[0].bb < __builtin_inff() && (!COS || qi[0].bb > 0.f) && qi[0].dscale > 0.f;
+        const float f5_inv_sb = COS && f5_ok ? 1.0f / sqrtf(qi[0].bb) : 0.f;
+        uint32_t f5_g = 0, f5_last = 0, f5_spill = 0, f5_allow = 0xffffffffu;
+        auto fold_prefetch = [&](uint32_t row_base) {
+            if constexpr (MODE == 5) {
+                typedef const __attribute__((address_space(4))) uint32_t *cptr32;
+                const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row_base >> 5));
+                if ((uint64_t)tile_u * 32u >= a.n_rows) return;
+                cptr32 tg = (cptr32)(uintptr_t)(a.tile_grp + tile_u);
+                f5_g = tg[0];
+                f5_last = tg[1];
+                f5_spill = tg[2];
+                f5_allow = 0xffffffffu;
+                if (a.fold_mask) {
+                    cptr32 mk = (cptr32)(uintptr_t)(a.fold_mask + (uint64_t)tile_u * 32u);
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int w8 = 0; w8 < 8; w8++) {
+                        const uint32_t v = mk[w8];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) m |= ((v >> (8 * b)) & 0xffu) ? (1u << (4 * w8 + b)) : 0u;
+                    }
+                    f5_allow = m;
+                }
+            }
+        };
         struct Epi {
             float xh[16];
+            float lo16[MODE == 5 ? 16 : 1], hi16[MODE == 5 ? 16 : 1];  // MODE 5: the lane's 16 row brackets (computed in the MFMAs' shadow)
             float sv[GPW][16];
             float best[GPW];
             elem_t mx[GPW];
@@ -484,6 +514,28 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 if (i < 8) {
                     e.sv[g][2 * i] = score(g, undo_f32((float)pv(g, 2 * i), e.xh[2 * i]), e.xh[2 * i]);
                     e.sv[g][2 * i + 1] = score(g, undo_f32((float)pv(g, 2 * i + 1), e.xh[2 * i + 1]), e.xh[2 * i + 1]);
+                } else if constexpr (MODE == 5) {
+                    // the brackets of two rows: [D(key - err), D(key + err)] widened by 1e-6 (1 + |d|); NaN for a row whose distance may
+                    // be NULL (norm zero / not finite, key not a number): it poisons its file (forced candidate)
+#pragma unroll
+                    for (int rr = (i - 8) * 2; rr < (i - 8) * 2 + 2; rr++) {
+                        const float x = e.xh[rr];  // cosine: 1/|a|, L2: |a|^2
+                        const float key = COS ? -e.sv[0][rr] * qi[0].dscale : e.sv[0][rr] + qi[0].bb + qi[0].eR * x;
+                        const bool valid = (COS ? (x > 1e-15f && x < 1e15f) : (x >= 0.f && x < 1e30f)) && fabsf(key) <= 1e30f;
+                        float lo, hi;
+                        if (COS) {
+                            lo = 1.0f + (key - qi[0].eA) * f5_inv_sb;
+                            hi = 1.0f + (key + qi[0].eA) * f5_inv_sb;
+                        } else {
+                            const float err = qi[0].eA + qi[0].eR * x;
+                            lo = sqrtf(fmaxf(key - err, 0.f));
+                            hi = sqrtf(fmaxf(key + err, 0.f));
+                        }
+                        lo -= 1e-6f * (1.0f + fabsf(lo));
+                        hi += 1e-6f * (1.0f + fabsf(hi));
+                        e.lo16[rr] = valid ? lo : __builtin_nanf("");
+                        e.hi16[rr] = valid ? hi : __builtin_nanf("");
+                    }
                 } else {
                     const int r = (i - 8) * 2;
                     // NaN (padding / zero-norm rows) never wins a fmax/fmin
@@ -687,52 +739,19 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(prev_row_base >> 5));
                 const uint64_t row0 = (uint64_t)tile_u * 32u;
                 if (row0 >= a.n_rows) return;
-                const bool q_ok = qi[0].bb == qi[0].bb && qi[0].bb < __builtin_inff() && (!COS || qi[0].bb > 0.f) && qi[0].dscale > 0.f;
-                const float inv_sb = COS && q_ok ? 1.0f / sqrtf(qi[0].bb) : 0.f;
-                float lo16[16], hi16[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float x = e.xh[r];  // cosine: 1/|a|, L2: |a|^2
-                    const float key = COS ? -e.sv[0][r] * qi[0].dscale : e.sv[0][r] + qi[0].bb + qi[0].eR * x;
-                    const bool valid = (COS ? (x > 1e-15f && x < 1e15f) : (x >= 0.f && x < 1e30f)) && fabsf(key) <= 1e30f;
-                    float lo, hi;
-                    if (COS) {
-                        lo = 1.0f + (key - qi[0].eA) * inv_sb;
-                        hi = 1.0f + (key + qi[0].eA) * inv_sb;
-                    } else {
-                        const float err = qi[0].eA + qi[0].eR * x;
-                        lo = sqrtf(fmaxf(key - err, 0.f));
-                        hi = sqrtf(fmaxf(key + err, 0.f));
-                    }
-                    lo -= 1e-6f * (1.0f + fabsf(lo));
-                    hi += 1e-6f * (1.0f + fabsf(hi));
-                    lo16[r] = valid ? lo : __builtin_nanf("");
-                    hi16[r] = valid ? hi : __builtin_nanf("");
-                }
+                const bool q_ok = f5_ok;
                 float LO[32], HI[32];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float ol = __shfl_xor(lo16[r], 32, 64), oh = __shfl_xor(hi16[r], 32, 64);
+                    const float ol = __shfl_xor(e.lo16[r], 32, 64), oh = __shfl_xor(e.hi16[r], 32, 64);
                     const int t = (r & 3) + 8 * (r >> 2);
-                    LO[t] = h ? ol : lo16[r];
-                    HI[t] = h ? oh : hi16[r];
-                    LO[t + 4] = h ? lo16[r] : ol;
-                    HI[t + 4] = h ? hi16[r] : oh;
+                    LO[t] = h ? ol : e.lo16[r];
+                    HI[t] = h ? oh : e.hi16[r];
+                    LO[t + 4] = h ? e.lo16[r] : ol;
+                    HI[t + 4] = h ? e.hi16[r] : oh;
                 }
-                cptr32 tg = (cptr32)(uintptr_t)(a.tile_grp + tile_u);
-                uint32_t g_run = tg[0];
-                const uint32_t m_last = tg[1], m_spill = tg[2];
-                uint32_t m_allow = 0xffffffffu;
-                if (a.fold_mask) {
-                    cptr32 mk = (cptr32)(uintptr_t)(a.fold_mask + row0);
-                    m_allow = 0;
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; w8++) {
-                        const uint32_t v = mk[w8];
-#pragma unroll
-                        for (int b = 0; b < 4; b++) m_allow |= ((v >> (8 * b)) & 0xffu) ? (1u << (4 * w8 + b)) : 0u;
-                    }
-                }
+                uint32_t g_run = f5_g;  // (the record asked for at the end of the tile before: fold_prefetch)
+                const uint32_t m_last = f5_last, m_spill = f5_spill, m_allow = f5_allow;
                 const uint32_t n_here = a.n_rows - row0 >= 32u ? 32u : (uint32_t)(a.n_rows - row0);
                 const uint32_t m_rows = n_here == 32u ? 0xffffffffu : ((1u << n_here) - 1u);
                 const uint32_t m_use = m_allow & ~m_spill & m_rows;
@@ -1023,6 +1042,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
             for (int r = 0; r < 16; r++) hold[0][r] = A::sum2(acc[0], acc1, r);  // i8: exact integers; floats: within the error budget
             prev_row_base = (uint32_t)((sid + (uint32_t)tl * nstreams) * a.tile_step * SLAB_ROWS) + rt * 32 + 4 * h;
             prev_valid = true;
+            fold_prefetch(prev_row_base);
         };
         // The last tile's epilogue runs inside one extra "ghost" tile (the DMA stream already re-reads the last tile past
         // the end to keep vmcnt uniform; its sums are never looked at): 1/n_my more work, but the epilogue — the bulk of the
