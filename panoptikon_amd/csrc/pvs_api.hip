@@ -674,11 +674,13 @@ pvs_status add_impl(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, 
 PVS_EXPORT pvs_status pvs_index_add(pvs_index *ix, const void *rows, uint64_t n, const int64_t *row_ids,
                                     const int64_t *group_ids, pvs_space space) {
     GateExcl gate(ix);  // (searches see the index before or after the append: the rows may move to a larger allocation)
+    PVS_GATE_REFUSED(gate);
     return add_impl(ix, rows, false, n, row_ids, group_ids, space);
 }
 PVS_EXPORT pvs_status pvs_index_add_f32(pvs_index *ix, const float *rows, uint64_t n, const int64_t *row_ids,
                                         const int64_t *group_ids, pvs_space space) {
     GateExcl gate(ix);
+    PVS_GATE_REFUSED(gate);
     return add_impl(ix, rows, true, n, row_ids, group_ids, space);
 }
 
@@ -698,6 +700,7 @@ PVS_EXPORT pvs_status pvs_index_set_scale(pvs_index *ix, float scale) {
 PVS_EXPORT pvs_status pvs_index_set_order_keys(pvs_index *ix, const int64_t *keys, uint64_t n, pvs_space space) {
     if (!ix) return pvs_fail(PVS_ERR_INVALID_ARG, "null index");
     GateExcl gate(ix);  // (searches in flight read the tie ranks)
+    PVS_GATE_REFUSED(gate);
     if (is_multi(ix)) return multi_set_order_keys(ix, keys, n, space);
     std::lock_guard<std::mutex> lk(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
@@ -755,6 +758,7 @@ PVS_EXPORT pvs_status pvs_index_set_scale_artifact(pvs_index *ix, const uint8_t 
 PVS_EXPORT pvs_status pvs_index_set_streams(pvs_index *ix, uint32_t n_streams) {
     if (!ix || n_streams == 0) return pvs_fail(PVS_ERR_INVALID_ARG, "bad stream count");
     GateExcl gate(ix);  // (no search in flight while the stream mode changes)
+    PVS_GATE_REFUSED(gate);
     for (pvs_index *sh : ix->shards) sh->multi_stream = n_streams > 1;
     ix->multi_stream = n_streams > 1;
     return PVS_OK;

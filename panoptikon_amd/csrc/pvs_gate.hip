@@ -75,15 +75,15 @@ void pvs_gate_shared_exit(pvs_index *ix) {
     if (wake) ix->ctx_cv.notify_all();
 }
 
-void pvs_gate_excl_enter(pvs_index *ix) {
+bool pvs_gate_excl_enter(pvs_index *ix) {
     if (Held *h = held_find(ix)) {
         if (h->excl) {  // nested mutation by the writer itself
             h->excl++;
-            return;
+            return true;
         }
-        // a thread that holds the gate shared and asks for it exclusively would wait for itself: no entry point does that
-        fprintf(stderr, "libpvs: exclusive gate requested inside a shared hold of the same index (bug)\n");
-        abort();
+        // a thread that holds the gate shared and asks for it exclusively would wait for itself (no entry point of the library does
+        // that; a host callback running inside a search might): refused, the caller returns PVS_ERR_STATE
+        return false;
     }
     const bool multi = is_multi(ix);
     std::unique_lock<std::mutex> lk(ix->mu);
@@ -125,6 +125,7 @@ void pvs_gate_excl_enter(pvs_index *ix) {
     }
     lk.unlock();
     t_held.push_back({ix, 0, 1});
+    return true;
 }
 
 void pvs_gate_excl_exit(pvs_index *ix) {

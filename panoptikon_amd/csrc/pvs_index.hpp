@@ -273,7 +273,7 @@ inline bool is_multi(const pvs_index *ix) { return !ix->shards.empty(); }
 // ---- pvs_gate.hip: the reader / writer gate (see pvs_index)
 void pvs_gate_shared_enter(pvs_index *ix);
 void pvs_gate_shared_exit(pvs_index *ix);
-void pvs_gate_excl_enter(pvs_index *ix);  // waits for the shared holders, completes the stream-ordered searches in flight
+bool pvs_gate_excl_enter(pvs_index *ix);  // waits for the shared holders, completes the stream-ordered searches in flight; false: this thread holds the gate shared (refused)
 void pvs_gate_excl_exit(pvs_index *ix);
 struct GateShared {
     pvs_index *ix;
@@ -288,11 +288,12 @@ struct GateShared {
 };
 struct GateExcl {
     pvs_index *ix;
+    bool ok = true;  // false: the calling thread is inside a search of this index (a mutation there would wait for itself)
     explicit GateExcl(pvs_index *i) : ix(i) {
-        if (ix) pvs_gate_excl_enter(ix);
+        if (ix) ok = pvs_gate_excl_enter(ix);
     }
     ~GateExcl() {
-        if (ix) pvs_gate_excl_exit(ix);
+        if (ix && ok) pvs_gate_excl_exit(ix);
     }
     GateExcl(const GateExcl &) = delete;
     GateExcl &operator=(const GateExcl &) = delete;
@@ -320,6 +321,8 @@ pvs_status pvs_ticket_complete_(pvs_index *ix, uint32_t ticket);
 pvs_status multi_ticket_complete_(pvs_index *ix, uint32_t ticket);
 // (ix->mu held) host copy of the row ids of the index's CURRENT rows in ix->h_ids_cache (keyed on ids_epoch, not on its size)
 pvs_status pvs_host_ids_locked(pvs_index *ix);
+#define PVS_GATE_REFUSED(gate) \
+    if (!(gate).ok) return pvs_fail(PVS_ERR_STATE, "a mutation was requested by a thread that is inside a search of the same index")
 #define PVS_POISONED_MSG "this index was left inconsistent by a mutation that failed half way: destroy and rebuild it"
 
 // ---- pvs_api.hip

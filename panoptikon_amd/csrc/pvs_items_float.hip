@@ -325,34 +325,27 @@ __global__ void k_query_flags(BoundsK a) {
     if (q < a.nb) a.bad_query[q] = q_const(a, q).ok ? 0u : 1u;
 }
 
-// one thread per (file, FOUR queries), 8 files per thread, their 16-byte loads issued before the first compare (a dword per lane kept
-// ~32 KB in flight per CU: 170 MB of lower bounds took 0.09 ms): a candidate (L <= T) is appended to its query's list
-__global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t ld, uint32_t l4p, uint32_t l4p_log2, uint32_t n_groups, const float *thr,
+// one thread per (file, query), 8 files per thread (their loads issued before the first compare): a candidate (L <= T) is appended
+// to its query's list.  (170 MB of lower bounds in 0.09 ms = 1.8 TB/s; 16-byte loads per lane measured no better: 0.107 ms.)
+__global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t ld, uint32_t nbp, uint32_t nbp_log2, uint32_t n_groups, const float *thr,
                                                     uint32_t *qcnt, uint32_t *qlist) {
-    const uint32_t q4 = threadIdx.x & (l4p - 1u);  // this lane's block of four query columns
-    if (4 * q4 >= ld) return;
-    float t[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) t[c] = 4 * q4 + c < nb ? thr[4 * q4 + c] : -__builtin_inff();
-    const uint32_t fpb = 256u / l4p;
-    float4 v[8];
+    const uint32_t q = threadIdx.x & (nbp - 1u);
+    if (q >= nb) return;
+    const float t = thr[q];
+    const uint32_t fpb = 256u / nbp;
+    float v[8];
 #pragma unroll
     for (uint32_t it = 0; it < 8; it++) {
-        const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> l4p_log2);
-        v[it] = f < n_groups ? *(const float4 *)(lo + f * ld + 4 * q4) : make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> nbp_log2);
+        v[it] = f < n_groups ? lo[f * ld + q] : __builtin_nanf("");
     }
 #pragma unroll
     for (uint32_t it = 0; it < 8; it++) {
-        const float l[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (!(l[c] <= t[c])) continue;
-            const uint32_t q = 4 * q4 + c;
-            const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> l4p_log2);
-            if (__hip_atomic_load(qcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 * QCAP) continue;  // (already beyond saving: the count only has to say so)
-            const uint32_t slot = atomicAdd(qcnt + q, 1u);
-            if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)f;
-        }
+        if (!(v[it] <= t)) continue;
+        const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> nbp_log2);
+        if (__hip_atomic_load(qcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 * QCAP) return;  // (already beyond saving: the count only has to say so)
+        const uint32_t slot = atomicAdd(qcnt + q, 1u);
+        if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)f;
     }
 }
 // bucket minima [BUCKETS][ld] -> [nb][BUCKETS] (what k_kth reads)
@@ -497,13 +490,8 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         uint32_t *d_bmin_t = d_bmin + (size_t)ld * BUCKETS;
         hipLaunchKernelGGL(k_bucket_transpose, dim3((nb * BUCKETS + 255) / 256), dim3(256), 0, s, d_bmin, nb, ld, d_bmin_t);
         HIP_TRY(pvs_launch_kth((const float *)d_bmin_t, BUCKETS, nb, k, d_thr, s));
-        {
-            uint32_t l4p = 1, l4p_log2 = 0;
-            while (l4p < ld / 4) l4p <<= 1, l4p_log2++;
-            const uint32_t files_per_block = (256u / l4p) * 8u;
-            hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)G + files_per_block - 1) / files_per_block)), dim3(256), 0, s, d_lo, nb, ld, l4p, l4p_log2, G, d_thr,
-                               d_qcnt, d_qlist);
-        }
+        hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)G + lanes_rows * 8 - 1) / (lanes_rows * 8))), dim3(256), 0, s, d_lo, nb, ld, nbp, nbp_log2, G, d_thr, d_qcnt,
+                           d_qlist);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_union, dim3(QCAP / 256, nb), dim3(256), 0, s, d_qcnt, d_qlist, nb, d_bits, ix->d_grp_off, ix->d_grp_rows, d_mask, d_ucnt, d_ufiles);
         HIP_TRY(hipGetLastError());

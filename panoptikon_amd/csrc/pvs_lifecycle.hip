@@ -340,6 +340,7 @@ pvs_status replace_any(pvs_index *ix, const void *rows, bool from_f32, uint64_t 
     if (n == 0) return PVS_OK;
     if (!rows || !row_ids) return pvs_fail(PVS_ERR_INVALID_ARG, "null rows / row ids");
     GateExcl gate(ix);  // (searches in flight read the rows: they are completed first, new ones wait)
+    PVS_GATE_REFUSED(gate);
     if (is_multi(ix)) return multi_replace(ix, rows, from_f32, n, row_ids, space);
     return replace_single(ix, rows, from_f32, n, row_ids, space, false, nullptr);
 }
@@ -351,6 +352,7 @@ PVS_EXPORT pvs_status pvs_index_remove_rows(pvs_index *ix, const int64_t *row_id
     if (n == 0) return PVS_OK;
     if (!row_ids) return pvs_fail(PVS_ERR_INVALID_ARG, "null row ids");
     GateExcl gate(ix);  // (searches in flight read the rows that move: they are completed first, new ones wait)
+    PVS_GATE_REFUSED(gate);
     if (is_multi(ix)) return multi_remove(ix, row_ids, n, out_removed);
     return remove_single(ix, row_ids, n, out_removed, nullptr);
 }
