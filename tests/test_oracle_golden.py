@@ -385,3 +385,38 @@ def test_clustered_generator_has_the_shape_it_claims():
     d = 1.0 - r[:4000].astype(np.float64) @ r[:4000].astype(np.float64).T
     assert np.median(d[same & ~np.eye(4000, dtype=bool)]) < 0.5 < np.median(d[~same])
     assert (d[np.triu(np.ones((4000, 4000), bool), 1)] < 0.02).sum() > 100
+
+
+def test_oracle_distances_equal_an_independent_numpy_restatement():
+    """A second, independent restatement of sqlite-vec 0.1.9's scalar loops (the oracle's C is the first; neither is the reference's
+    binary — its source is not in the image): sequential f32 accumulation in component order, written with numpy
+    primitives whose rounding is defined — an f32 multiply per element, `np.cumsum` over float32 (a strictly sequential f32 running
+    sum, no pairwise tree) — then sqrt / divide in double and one narrowing to f32.  Bit for bit equal to the oracle for f32, f16
+    (widened) and int8 rows, cosine and L2, over dimensions that are and are not multiples of anything."""
+    rng = np.random.default_rng(123)
+
+    def seq_sum(x):  # sequential f32 sum in order
+        return np.float32(0.0) if x.size == 0 else np.cumsum(x.astype(np.float32), dtype=np.float32)[-1]
+
+    def np_cosine(a, b):
+        a, b = a.astype(np.float32), b.astype(np.float32)
+        dot, aa, bb = seq_sum(a * b), seq_sum(a * a), seq_sum(b * b)
+        with np.errstate(all="ignore"):
+            return np.float32(1.0 - np.float64(dot) / (np.sqrt(np.float64(aa)) * np.sqrt(np.float64(bb))))
+
+    def np_l2(a, b):
+        a, b = a.astype(np.float32), b.astype(np.float32)
+        d = a - b
+        return np.float32(np.sqrt(np.float64(seq_sum(d * d))))
+
+    for dim in (1, 3, 8, 100, 512, 768, 1027):
+        rows = (rng.standard_normal((40, dim)) * rng.choice([1e-3, 1.0, 50.0], (40, 1))).astype(np.float32)
+        q = rng.standard_normal(dim).astype(np.float32)
+        for dt, data, query in ((orc.F32, rows, q), (orc.F16, rows.astype(np.float16), q),
+                                (orc.I8, rng.integers(-128, 128, (40, dim)).astype(np.int8), rng.integers(-128, 128, dim).astype(np.int8))):
+            wide = data.astype(np.float32)
+            qw = query.astype(np.float32)
+            for metric, fn in ((orc.COSINE, np_cosine), (orc.L2, np_l2)):
+                got = orc.score_all(dt, metric, data, query)
+                exp = np.array([fn(wide[i], qw) for i in range(len(wide))], np.float32)
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (dim, dt, metric)
