@@ -197,7 +197,7 @@ pvs_status pvs_index_add_f32(pvs_index *idx, const float *rows, uint64_t n, cons
  * pvs_index_replace_rows[_f32]: overwrites the vectors of rows the index already holds (same ids, same positions,
  * same groups and keys): rows = dense [n][dim] of the index dtype (or f32, converted like pvs_index_add_f32),
  * row_ids strictly increasing, every id must be in the index (PVS_ERR_INVALID_ARG otherwise).  Multi-device
- * indexes take host rows. */
+ * indexes stage device-space rows through the host once (every shard picks the rows it holds). */
 pvs_status pvs_index_remove_rows(pvs_index *idx, const int64_t *row_ids, uint64_t n, uint64_t *out_removed);
 pvs_status pvs_index_replace_rows(pvs_index *idx, const void *rows, uint64_t n, const int64_t *row_ids, pvs_space rows_space);
 pvs_status pvs_index_replace_rows_f32(pvs_index *idx, const float *rows, uint64_t n, const int64_t *row_ids, pvs_space rows_space);

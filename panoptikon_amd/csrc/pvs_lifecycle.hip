@@ -321,7 +321,20 @@ pvs_status multi_remove(pvs_index *ix, const int64_t *row_ids, uint64_t n_ids, u
 
 pvs_status multi_replace(pvs_index *ix, const void *rows, bool from_f32, uint64_t n, const int64_t *row_ids, pvs_space space) {
     if (ix->poisoned) return pvs_fail(PVS_ERR_STATE, "this multi-device index lost its row order in a failed pvs_index_add: destroy and rebuild it");
-    if (space != PVS_HOST) return pvs_fail(PVS_ERR_UNSUPPORTED, "pvs_index_replace_rows on a multi-device index takes host rows (every shard picks the rows it holds)");
+    std::vector<uint8_t> staged;
+    if (space != PVS_HOST) {
+        // device-space rows: staged through the host once (every shard picks the rows it holds: placement is a scatter, as in
+        // pvs_index_add on a multi-device index) — replacements are a few rows per call
+        const size_t bytes = (size_t)n * ix->dim * (from_f32 ? 4 : pvs_esz(ix->dtype));
+        try {
+            staged.resize(bytes);
+        } catch (const std::bad_alloc &) {
+            return pvs_fail(PVS_ERR_OOM, "out of host memory staging %llu replacement rows", (unsigned long long)n);
+        }
+        HIP_TRY(hipMemcpy(staged.data(), rows, bytes, hipMemcpyDeviceToHost));
+        rows = staged.data();
+        space = PVS_HOST;
+    }
     std::lock_guard<std::mutex> lk(ix->mu);
     for (uint64_t i = 1; i < n; i++)
         if (row_ids[i] <= row_ids[i - 1]) return pvs_fail(PVS_ERR_INVALID_ARG, "row ids of a replacement must be strictly increasing");

@@ -153,6 +153,11 @@ class VectorIndex:
     def replace_rows(self, rows, row_ids):
         """pvs_index_replace_rows[_f32]: new vectors for rows the index already holds (f32 rows are converted like add_f32)."""
         ids = np.ascontiguousarray(row_ids, np.int64).ravel()
+        if isinstance(rows, tuple):  # (DeviceBuffer, "f32" | "native"): rows already in HBM
+            buf, kind = rows
+            fn = L.lib().pvs_index_replace_rows_f32 if kind == "f32" else L.lib().pvs_index_replace_rows
+            L.check(fn(self._h, buf.ptr, int(ids.size), _ptr(ids), L.DEVICE))
+            return
         rows = np.ascontiguousarray(rows)
         if rows.ndim != 2 or rows.shape[1] != self.dim or rows.shape[0] != ids.size:
             raise ValueError("rows must be [len(row_ids)][dim]")

@@ -184,6 +184,8 @@ def test_random_interleavings_of_add_remove_replace(pvs, dtype, devices):
             rows[3] = 0.0
             if dt == pvs.I8 and rng.random() < 0.5:
                 ix.replace_rows(orc.quantize_int8(rows, scale), ids)  # codes as they are
+            elif rng.random() < 0.5:  # rows already in HBM (a multi-device index stages them through the host once)
+                ix.replace_rows((pvs.DeviceBuffer.from_numpy(np.ascontiguousarray(rows, np.float32)), "f32"), ids)
             else:
                 ix.replace_rows(rows, ids)
             m.replace(rows, ids)
