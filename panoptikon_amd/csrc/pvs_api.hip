@@ -362,6 +362,7 @@ void ctx_release(SearchCtx &c) {
     if (c.h_all_flags) hipHostFree(c.h_all_flags);
     if (c.own_stream) hipStreamDestroy(c.own_stream);
     if (c.h_io) hipHostFree(c.h_io);
+    if (c.h_cert) hipHostFree(c.h_cert);
     c = SearchCtx();
 }
 

@@ -348,6 +348,14 @@ __global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb
         if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)f;
     }
 }
+// what a chunk starts from, in one launch (three fills cost five: ~26 us in front of every scan): bucket minima +inf, counters and
+// the union's bits 0
+__global__ __launch_bounds__(256) void k_certify_init(uint32_t *bmin, uint32_t n_bmin, uint32_t *small, uint32_t n_small, uint32_t *bits, uint32_t n_bits) {
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_bmin; i += stride) bmin[i] = 0x7f800000u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_bits; i += stride) bits[i] = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_small; i += stride) small[i] = 0;
+}
 // bucket minima [BUCKETS][ld] -> [nb][BUCKETS] (what k_kth reads)
 __global__ __launch_bounds__(256) void k_bucket_transpose(const uint32_t *in, uint32_t nb, uint32_t ld, uint32_t *out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -397,13 +405,15 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
     float *d_keys = nullptr, *d_lo = nullptr, *d_thr = nullptr;
     uint32_t *d_bmin = nullptr, *d_small = nullptr, *d_qlist = nullptr, *d_bits = nullptr, *d_ufiles = nullptr;
     // d_small: [bad query flags nb | candidate counts nb | union files, union rows] — one copy to the host
-    std::vector<uint32_t> h_small(2 * (size_t)nb + 2, 0);
+    const size_t n_small = 2 * (size_t)nb + 2;
+    if (!c.h_cert) HIP_TRY(hipHostMalloc((void **)&c.h_cert, (2 * (size_t)PVS_SCAN_MAX_BATCH + 2) * 4, hipHostMallocDefault));
+    const uint32_t *h_small = c.h_cert;  // (pinned: the copy is one DMA, not a staged one behind a synchronisation of its own)
     const size_t bits_bytes = ((size_t)G + 31) / 32 * 4;
     auto body = [&]() -> pvs_status {
         HIP_TRY(pvs_scratch_alloc((void **)&d_lo, (size_t)G * ld * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, ((size_t)ld + nb) * BUCKETS * 4));  // (query-minor minima, then their transpose)
         HIP_TRY(pvs_scratch_alloc((void **)&d_thr, (size_t)nb * 4));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_small, h_small.size() * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_small, n_small * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_qlist, (size_t)nb * QCAP * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_bits, bits_bytes));
         HIP_TRY(pvs_scratch_alloc((void **)&d_ufiles, (size_t)UCAP * 4));
@@ -468,9 +478,8 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
             a.fold_bucket = d_bmin;
             a.fold_hi_off = mat;
         }
-        HIP_TRY(pvs_launch_fill_f32((float *)d_bmin, (uint64_t)ld * BUCKETS, __builtin_inff(), s));
-        HIP_TRY(hipMemsetAsync(d_small, 0, h_small.size() * 4, s));
-        HIP_TRY(hipMemsetAsync(d_bits, 0, bits_bytes, s));
+        hipLaunchKernelGGL(k_certify_init, dim3(512), dim3(256), 0, s, d_bmin, ld * BUCKETS, d_small, (uint32_t)n_small, d_bits, (uint32_t)(bits_bytes / 4));
+        HIP_TRY(hipGetLastError());
         if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop)) a.ev_start = a.ev_stop = nullptr;
         HIP_TRY(pvs_launch_scan(a, s));
         b.keys = d_keys;
@@ -495,7 +504,7 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_union, dim3(QCAP / 256, nb), dim3(256), 0, s, d_qcnt, d_qlist, nb, d_bits, ix->d_grp_off, ix->d_grp_rows, d_mask, d_ucnt, d_ufiles);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_small.data(), d_small, h_small.size() * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(c.h_cert, d_small, n_small * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         spans_collect(ix, c);
         uint32_t n_redo = 0;

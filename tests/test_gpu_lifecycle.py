@@ -224,12 +224,16 @@ def test_removing_one_percent_of_ten_million_rows(pvs):
     rng = np.random.default_rng(5)
     gone = np.sort(rng.choice(n, 100_000, replace=False)).astype(np.int64)
     gone[:50] = bi[0, :100:2]  # half of the first query's best hundred among them
-    gone = np.unique(gone)
-    ix.remove_rows(np.array([n + 5], np.int64))  # (first call: scratch blocks are allocated)
+    first = np.array([7], np.int64)
+    gone = np.setdiff1d(np.unique(gone), first)
+    # (the first removal of a process allocates its scratch blocks — a staging block of 256 MiB, the survivors' map: ~90 ms once,
+    #  whatever ran before in this process — so one row near the front goes first and is not timed)
+    assert ix.remove_rows(first) == 1
     t = time.perf_counter()
     removed = ix.remove_rows(gone)
     dt_remove = time.perf_counter() - t
-    assert removed == len(gone) and ix.stats().rows == n - len(gone)
+    assert removed == len(gone) and ix.stats().rows == n - len(gone) - 1
+    gone = np.union1d(gone, first)
     print(f"removed {removed} of {n} rows in {dt_remove * 1e3:.1f} ms")
     assert dt_remove < 0.05, f"removal took {dt_remove * 1e3:.1f} ms"
     ai, ad, ac = ix.search(q[:4], 100, pvs.COSINE)

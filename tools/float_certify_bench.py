@@ -10,7 +10,7 @@ lib = pvs.lib()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 quick = "--quick" in sys.argv
 dt = args[0] if len(args) > 0 else "f16"
-N = int(args[1]) if len(args) > 1 else 4_000_000
+N = int(args[1]) if len(args) > 1 and args[1].isdigit() else 4_000_000
 D, K = 768, 50
 ix = pvs.VectorIndex(pvs.F16 if dt == "f16" else pvs.F32, D, capacity_rows=N)
 stage = pvs.DeviceBuffer(1_000_000 * D * 4)
