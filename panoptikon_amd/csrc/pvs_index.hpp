@@ -69,7 +69,7 @@ struct SearchCtx {
     // from it and write their page into it — no staging copies, one synchronisation per call
     uint8_t *h_io = nullptr;
     size_t h_io_cap = 0;
-    uint32_t *h_cert = nullptr;   // pinned: the counters of a certified per-item chunk come back here (pvs_items_float.hip), 2 * PVS_SCAN_MAX_BATCH + 2 words
+    uint32_t *h_cert = nullptr;   // pinned: the counters of a certified per-item chunk come back here (pvs_items_float.hip), 2 * PVS_SCAN_MAX_BATCH + 3 words
     DenseWork dense;
     GroupWork gwork;              // per-context sort scratch of pvs_group_rank (searches in flight never share it)
     // deferred fallback bookkeeping (device variant)

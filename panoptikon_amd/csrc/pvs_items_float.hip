@@ -51,6 +51,7 @@ struct BoundsK {
 
 constexpr uint32_t QCAP = 1024;   // candidate files one query may name before it counts as "cannot be certified" (ties with everything)
 constexpr uint32_t UCAP = 8192;   // files in the union of a chunk's candidates (one LDS ranking per query column: pvs_sub_rank)
+constexpr uint32_t QCS = 32;      // words between two queries' candidate counters: a 128-byte line each
 constexpr int RUN_ROWS = 16;      // rows a thread of k_run_bounds loads at once
 
 // The bracket of one row's distance from its key (f32: every rounding — five operations of 6e-8, the half ulp of the reference's own
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void k_group_bounds(BoundsK a, uint32_t nbp, u
 
 // MODE 5 leaves the row brackets of the files that cross a 32-row tile boundary in two sparse matrices: one thread per (such
 // file, query) folds them (a few percent of the files)
-__global__ __launch_bounds__(256) void k_spill_bounds(BoundsK a, const uint32_t *list, uint32_t n_list, const float *lo_rows, const float *hi_rows, uint32_t nbp, uint32_t nbp_log2) {
+__global__ __launch_bounds__(256) void k_spill_bounds(BoundsK a, const uint32_t *list, uint32_t n_list, const float *lo_rows, const float *hi_rows, uint32_t nbp, uint32_t nbp_log2,
+                                                      float *lo_list) {
     const uint32_t q = threadIdx.x & (nbp - 1u);
     if (q >= a.nb) return;
     const QConst c = q_const(a, q);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void k_spill_bounds(BoundsK a, const uint32_t 
             U = __builtin_inff();
         }
     }
-    a.lo[(size_t)file * a.ld + q] = L;
+    lo_list[li * a.ld + q] = L;  // (compact, in list order: k_candidates reads these files' lower bounds as one dense matrix)
     if (U < __builtin_inff()) {
         if (U < 0.f) U = 0.f;
         // (the scan's lanes own buckets [0, BUCKETS / 2): k_scan MODE 5 writes grid x RT x 8 <= 8,192 of them; these files take the rest)
@@ -328,7 +330,7 @@ __global__ void k_query_flags(BoundsK a) {
 // one thread per (file, query), 8 files per thread (their loads issued before the first compare): a candidate (L <= T) is appended
 // to its query's list.  (170 MB of lower bounds in 0.09 ms = 1.8 TB/s; 16-byte loads per lane measured no better: 0.107 ms.)
 __global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb, uint32_t ld, uint32_t nbp, uint32_t nbp_log2, uint32_t n_groups, const float *thr,
-                                                    uint32_t *qcnt, uint32_t *qlist) {
+                                                    uint32_t *qcnt, uint32_t *qlist, const uint32_t *file_of) {
     const uint32_t q = threadIdx.x & (nbp - 1u);
     if (q >= nb) return;
     const float t = thr[q];
@@ -343,9 +345,75 @@ __global__ __launch_bounds__(256) void k_candidates(const float *lo, uint32_t nb
     for (uint32_t it = 0; it < 8; it++) {
         if (!(v[it] <= t)) continue;
         const uint64_t f = ((uint64_t)blockIdx.x * 8 + it) * fpb + (threadIdx.x >> nbp_log2);
-        if (__hip_atomic_load(qcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 * QCAP) return;  // (already beyond saving: the count only has to say so)
-        const uint32_t slot = atomicAdd(qcnt + q, 1u);
-        if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = (uint32_t)f;
+        if (__hip_atomic_load(qcnt + q * QCS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 4 * QCAP) return;  // (already beyond saving: the count only has to say so)
+        const uint32_t slot = atomicAdd(qcnt + q * QCS, 1u);
+        if (slot < QCAP) qlist[(size_t)q * QCAP + slot] = file_of ? file_of[f] : (uint32_t)f;
+    }
+}
+// After k_scan MODE 5: the lower bounds of the files folded in the scan are never read as a matrix.  The scan's lanes kept, beside
+// the minima of the upper bounds, the minima of the LOWER bounds of the same buckets (bucket = (wave of the scan, number of the
+// wave's tile mod 8): the files that end in those tiles); a bucket whose minimum is above the query's threshold holds no candidate —
+// all but ~60 of 8,192 per query.  One workgroup per scan wave: its (slot, query) pairs at or below the threshold are collected, then
+// its threads visit the tiles of those slots (the tile records name the files that end in a tile, in order) and look at the lower
+// bounds of their files.
+// (170 MB of lower bounds read at 1.8 TB/s: 0.09 ms; this: a 1-MB matrix of minima and a few thousand 4-byte reads.)
+__global__ __launch_bounds__(256) void k_candidates_tiles(const float *lmin, const float *lo, uint32_t nb, uint32_t ld, const float *thr, const uint4 *tile_grp, uint64_t n_rows,
+                                                          uint32_t RT, uint32_t nstreams, uint32_t n_wgtiles, uint32_t *qcnt, uint32_t *qlist, uint32_t *visits) {
+    __shared__ uint32_t s_pairs[8 * PVS_MAX_BATCH];
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_dead[PVS_MAX_BATCH];  // the query already names more files than it may (ties with everything): stop adding to it
+    const uint32_t w = blockIdx.x, sid = w / RT, rt = w % RT;
+    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x < nb) s_dead[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < 8u * nb; p += 256u) {
+        const uint32_t slot = p / nb, q = p % nb;
+        if (lmin[(size_t)(w * 8u + slot) * ld + q] <= thr[q]) s_pairs[atomicAdd(&s_n, 1u)] = p;
+    }
+    __syncthreads();
+    const uint32_t np = s_n;
+    if (np == 0 || sid >= n_wgtiles) return;
+    if (visits && threadIdx.x == 0) atomicAdd(visits, np);
+    const uint32_t n_my = (n_wgtiles - sid + nstreams - 1) / nstreams, n8 = (n_my + 7u) / 8u;
+    // one item per (pair, tile of the pair's slot: this wave's tiles number slot, slot + 8, ...): the record, then the lower bounds of
+    // the files that end in the tile, eight loads at a time.  (A thread per tile that walked the pairs and the files one dependent
+    // load after the other: 45 us on the slowest workgroup's chain.)
+    for (uint32_t it = threadIdx.x; it < np * n8; it += 256u) {
+        const uint32_t ip = it / n8, j = s_pairs[ip] / nb + 8u * (it - ip * n8);
+        const uint32_t q = s_pairs[ip] % nb;
+        if (j >= n_my || *(volatile uint32_t *)&s_dead[q]) continue;
+        const uint64_t u = (uint64_t)(sid + j * nstreams) * RT + rt, row0 = u * 32u;
+        if (row0 >= n_rows) continue;
+        const uint4 rec = tile_grp[u];
+        const uint32_t n_here = n_rows - row0 >= 32u ? 32u : (uint32_t)(n_rows - row0);
+        const uint32_t m_rows = n_here == 32u ? 0xffffffffu : ((1u << n_here) - 1u);
+        const uint32_t m_end = rec.y & m_rows;
+        // bit o of em: the o-th file that ends in this tile was folded by the scan (does not cross a tile boundary)
+        uint32_t em = 0, o = 0, m = m_end;
+        while (m) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            em |= ((rec.z >> i) & 1u) ? 0u : (1u << o);
+            o++;
+        }
+        const float t = thr[q];
+        while (em) {
+            float v[8];
+            uint32_t off[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; k8++) {
+                off[k8] = em ? (uint32_t)__builtin_ctz(em) : 0u;
+                v[k8] = em ? lo[(size_t)(rec.x + off[k8]) * ld + q] : __builtin_nanf("");
+                em &= em - 1u;  // (0 stays 0)
+            }
+#pragma unroll
+            for (int k8 = 0; k8 < 8; k8++) {
+                if (!(v[k8] <= t)) continue;
+                const uint32_t at = atomicAdd(qcnt + q * QCS, 1u);
+                if (at < QCAP) qlist[(size_t)q * QCAP + at] = rec.x + off[k8];
+                if (at > 4 * QCAP) s_dead[q] = 1;
+            }
+        }
     }
 }
 // what a chunk starts from, in one launch (three fills cost five: ~26 us in front of every scan): bucket minima +inf, counters and
@@ -365,9 +433,10 @@ __global__ __launch_bounds__(256) void k_bucket_transpose(const uint32_t *in, ui
 }
 // the union of the lists of the queries that stayed below QCAP: a file enters once (a bit per file), with its allowed rows counted
 __global__ __launch_bounds__(256) void k_union(const uint32_t *qcnt, const uint32_t *qlist, uint32_t nb, uint32_t *bits, const uint32_t *grp_off, const uint32_t *grp_rows,
-                                               const uint8_t *mask, uint32_t *ucnt, uint32_t *ufiles) {
+                                               const uint8_t *mask, uint32_t *ucnt, uint32_t *ufiles, uint32_t *qtot) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
-    const uint32_t c = qcnt[q];
+    const uint32_t c = qcnt[q * QCS];
+    if (i == 0) qtot[q] = c;  // (what the host reads: the padded counters stay on the device)
     if (c > QCAP || i >= c) return;
     const uint32_t f = qlist[(size_t)q * QCAP + i];
     const uint32_t bit = 1u << (f & 31u);
@@ -402,22 +471,25 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
     hipStream_t s = c.stream;
     const uint32_t G = ix->n_groups;
     const uint32_t ld = (nb + 3u) & ~3u;  // keys, lower bounds and bucket minima in 16-byte lines
-    float *d_keys = nullptr, *d_lo = nullptr, *d_thr = nullptr;
+    float *d_keys = nullptr, *d_lo = nullptr, *d_thr = nullptr, *d_lo_list = nullptr, *d_lmin = nullptr;
     uint32_t *d_bmin = nullptr, *d_small = nullptr, *d_qlist = nullptr, *d_bits = nullptr, *d_ufiles = nullptr;
     // d_small: [bad query flags nb | candidate counts nb | union files, union rows] — one copy to the host
-    const size_t n_small = 2 * (size_t)nb + 2;
-    if (!c.h_cert) HIP_TRY(hipHostMalloc((void **)&c.h_cert, (2 * (size_t)PVS_SCAN_MAX_BATCH + 2) * 4, hipHostMallocDefault));
+    const size_t n_small = 2 * (size_t)nb + 3;  // bad-query flags, candidate totals, union files, union rows, (trace) bucket visits; behind them the padded counters
+    const size_t n_pad = (size_t)nb * QCS;
+    if (!c.h_cert) HIP_TRY(hipHostMalloc((void **)&c.h_cert, (2 * (size_t)PVS_SCAN_MAX_BATCH + 3) * 4, hipHostMallocDefault));
     const uint32_t *h_small = c.h_cert;  // (pinned: the copy is one DMA, not a staged one behind a synchronisation of its own)
     const size_t bits_bytes = ((size_t)G + 31) / 32 * 4;
     auto body = [&]() -> pvs_status {
         HIP_TRY(pvs_scratch_alloc((void **)&d_lo, (size_t)G * ld * 4));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, ((size_t)ld + nb) * BUCKETS * 4));  // (query-minor minima, then their transpose)
+        // (query-minor minima of the upper bounds, their transpose, the scan's minima of the lower bounds [BUCKETS / 2][ld])
+        HIP_TRY(pvs_scratch_alloc((void **)&d_bmin, (((size_t)ld + nb) * BUCKETS + (size_t)ld * (BUCKETS / 2)) * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_thr, (size_t)nb * 4));
-        HIP_TRY(pvs_scratch_alloc((void **)&d_small, n_small * 4));
+        HIP_TRY(pvs_scratch_alloc((void **)&d_small, (n_small + n_pad) * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_qlist, (size_t)nb * QCAP * 4));
         HIP_TRY(pvs_scratch_alloc((void **)&d_bits, bits_bytes));
         HIP_TRY(pvs_scratch_alloc((void **)&d_ufiles, (size_t)UCAP * 4));
-        uint32_t *d_badq = d_small, *d_qcnt = d_small + nb, *d_ucnt = d_small + 2 * (size_t)nb;
+        d_lmin = (float *)(d_bmin + ((size_t)ld + nb) * BUCKETS);
+        uint32_t *d_badq = d_small, *d_qtot = d_small + nb, *d_ucnt = d_small + 2 * (size_t)nb, *d_qcnt = d_small + n_small;
         // 1. + 2. one corpus pass on the matrix cores.  Files that are runs of rows (the loader's order): the brackets are folded per
         // file in the scan's epilogue (k_scan MODE 5) and only the rows of tile-crossing files leave it; otherwise the scan writes
         // the key of every (row, query) pair (MODE 4) and a second kernel walks the files.
@@ -458,7 +530,8 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         a.groups_per_query = 0;
         a.mode = fold_in_scan ? 5 : 4;
         a.tile_step = 1;
-        const uint32_t wg_rows = 32u * pvs_scan_row_tiles(a.qgroups);
+        const uint32_t rt_scan = pvs_scan_row_tiles(a.qgroups);
+        const uint32_t wg_rows = 32u * rt_scan;
         const uint32_t n_wgtiles = (uint32_t)((ix->n + wg_rows - 1) / wg_rows);
         // (MODE 5: one workgroup per CU; its lanes own 8 buckets each: grid x RT x 8 <= BUCKETS / 2)
         a.grid = std::min<uint32_t>(n_wgtiles, fold_in_scan ? std::min<uint32_t>((uint32_t)ix->n_cu, BUCKETS / 2 / (8u * pvs_scan_row_tiles(a.qgroups)))
@@ -477,8 +550,10 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
             a.fold_agg = agg;
             a.fold_bucket = d_bmin;
             a.fold_hi_off = mat;
+            a.fold_bucket_lo = d_lmin;
+            if (ix->n_straddlers) HIP_TRY(pvs_scratch_alloc((void **)&d_lo_list, (size_t)ix->n_straddlers * ld * 4));
         }
-        hipLaunchKernelGGL(k_certify_init, dim3(512), dim3(256), 0, s, d_bmin, ld * BUCKETS, d_small, (uint32_t)n_small, d_bits, (uint32_t)(bits_bytes / 4));
+        hipLaunchKernelGGL(k_certify_init, dim3(512), dim3(256), 0, s, d_bmin, (ld + nb) * BUCKETS + ld * (BUCKETS / 2), d_small, (uint32_t)(n_small + n_pad), d_bits, (uint32_t)(bits_bytes / 4));
         HIP_TRY(hipGetLastError());
         if (!span_bound(ix, c, 1, ix->n, &a.ev_start, &a.ev_stop)) a.ev_start = a.ev_stop = nullptr;
         HIP_TRY(pvs_launch_scan(a, s));
@@ -487,7 +562,7 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
             hipLaunchKernelGGL(k_query_flags, dim3(1), dim3(128), 0, s, b);
             if (ix->n_straddlers)
                 hipLaunchKernelGGL(k_spill_bounds, dim3((ix->n_straddlers + lanes_rows - 1) / lanes_rows), dim3(256), 0, s, b, ix->d_straddlers, ix->n_straddlers, d_keys,
-                                   d_keys + mat, nbp, nbp_log2);
+                                   d_keys + mat, nbp, nbp_log2, d_lo_list);
         } else if (ix->groups_are_runs && ix->d_row_gidx) {
             const uint64_t blocks = (ix->n + RUN_ROWS - 1) / RUN_ROWS;
             hipLaunchKernelGGL(k_run_bounds, dim3((unsigned)((blocks + lanes_rows - 1) / lanes_rows)), dim3(256), 0, s, b, ix->d_row_gidx, ix->n, nbp, nbp_log2);
@@ -499,10 +574,20 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         uint32_t *d_bmin_t = d_bmin + (size_t)ld * BUCKETS;
         hipLaunchKernelGGL(k_bucket_transpose, dim3((nb * BUCKETS + 255) / 256), dim3(256), 0, s, d_bmin, nb, ld, d_bmin_t);
         HIP_TRY(pvs_launch_kth((const float *)d_bmin_t, BUCKETS, nb, k, d_thr, s));
-        hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)G + lanes_rows * 8 - 1) / (lanes_rows * 8))), dim3(256), 0, s, d_lo, nb, ld, nbp, nbp_log2, G, d_thr, d_qcnt,
-                           d_qlist);
+        if (fold_in_scan) {
+            // (the files folded in the scan: only the buckets whose smallest lower bound is at or below the threshold; the tile-crossing
+            //  files: their compact matrix)
+            hipLaunchKernelGGL(k_candidates_tiles, dim3(a.grid * rt_scan), dim3(256), 0, s, d_lmin, d_lo, nb, ld, d_thr, ix->d_tile_grp, ix->n, rt_scan, a.grid, n_wgtiles, d_qcnt,
+                               d_qlist, pvs_dbg(PVS_DBG_FLOAT_CERTIFY_TRACE) ? d_ucnt + 2 : (uint32_t *)nullptr);
+            if (ix->n_straddlers)
+                hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)ix->n_straddlers + lanes_rows * 8 - 1) / (lanes_rows * 8))), dim3(256), 0, s, d_lo_list, nb, ld, nbp,
+                                   nbp_log2, ix->n_straddlers, d_thr, d_qcnt, d_qlist, ix->d_straddlers);
+        } else {
+            hipLaunchKernelGGL(k_candidates, dim3((unsigned)(((uint64_t)G + lanes_rows * 8 - 1) / (lanes_rows * 8))), dim3(256), 0, s, d_lo, nb, ld, nbp, nbp_log2, G, d_thr, d_qcnt,
+                               d_qlist, (const uint32_t *)nullptr);
+        }
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_union, dim3(QCAP / 256, nb), dim3(256), 0, s, d_qcnt, d_qlist, nb, d_bits, ix->d_grp_off, ix->d_grp_rows, d_mask, d_ucnt, d_ufiles);
+        hipLaunchKernelGGL(k_union, dim3(QCAP / 256, nb), dim3(256), 0, s, d_qcnt, d_qlist, nb, d_bits, ix->d_grp_off, ix->d_grp_rows, d_mask, d_ucnt, d_ufiles, d_qtot);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c.h_cert, d_small, n_small * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -513,13 +598,14 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
             skip[q] = (h_small[q] || h_small[nb + q] > QCAP) ? 1 : 0;
             n_redo += skip[q];
         }
-        const uint32_t m_f = h_small[2 * (size_t)nb], m_rows = h_small[2 * (size_t)nb + 1];
+        const uint32_t *h_u = h_small + 2 * (size_t)nb;
+        const uint32_t m_f = h_u[0], m_rows = h_u[1];
         const bool trace = pvs_dbg(PVS_DBG_FLOAT_CERTIFY_TRACE) != 0;
         if (trace) {
             std::vector<float> ht(nb);
             (void)hipMemcpy(ht.data(), d_thr, (size_t)nb * 4, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[float certify] n=%llu files=%u nb=%u k=%u metric=%d agg=%d: union of %u candidate files (%u rows), %u queries not certifiable, candidates of q0 %u, thresholds %g %g ...\n",
-                    (unsigned long long)ix->n, G, nb, k, metric, agg, m_f, m_rows, n_redo, h_small[nb], ht[0], ht[nb > 1 ? 1 : 0]);
+            fprintf(stderr, "[float certify] n=%llu files=%u nb=%u k=%u metric=%d agg=%d: union of %u candidate files (%u rows), %u queries not certifiable, candidates of q0 %u, thresholds %g %g ..., %u buckets visited\n",
+                    (unsigned long long)ix->n, G, nb, k, metric, agg, m_f, m_rows, n_redo, h_small[nb], ht[0], ht[nb > 1 ? 1 : 0], h_u[2]);
         }
         // Not worth it, or not possible: every query uncertifiable; more than a couple of them (each one is a corpus pass of its own
         // through the exact route: the whole chunk through k_exact_wide is cheaper); more files than one LDS ranking takes; so many
@@ -541,6 +627,6 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
     };
     pvs_status st = body();
     if (st != PVS_OK) (void)hipStreamSynchronize(s);
-    for (void *p : {(void *)d_keys, (void *)d_lo, (void *)d_bmin, (void *)d_thr, (void *)d_small, (void *)d_qlist, (void *)d_bits, (void *)d_ufiles}) pvs_scratch_free_on(p, s);
+    for (void *p : {(void *)d_keys, (void *)d_lo, (void *)d_bmin, (void *)d_thr, (void *)d_small, (void *)d_qlist, (void *)d_bits, (void *)d_ufiles, (void *)d_lo_list}) pvs_scratch_free_on(p, s);
     return st;
 }

@@ -131,6 +131,7 @@ struct ScanArgs {
     int fold_agg = 0;
     uint32_t *fold_bucket = nullptr;  // mode 5 (see ScanK)
     uint64_t fold_hi_off = 0;
+    float *fold_bucket_lo = nullptr;  // mode 5: the minima of the LOWER bounds over the same buckets [PVS_FLOAT_BUCKETS / 2][fold_ld] (which buckets can hold a candidate)
     // optional events bound to the dispatch itself (hipExtLaunchKernelGGL: start / stop timestamps of THIS kernel, and something a
     // second stream can wait for, without a marker packet in the queue)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;

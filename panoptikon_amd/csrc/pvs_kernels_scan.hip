@@ -85,6 +85,7 @@ hipError_t pvs_launch_scan(const ScanArgs &a, hipStream_t s) {
     k.fold_agg = a.fold_agg;
     k.fold_bucket = a.fold_bucket;
     k.fold_hi_off = a.fold_hi_off;
+    k.fold_bucket_lo = a.fold_bucket_lo;
     k.ev_start = a.ev_start;
     k.ev_stop = a.ev_stop;
     hipError_t e = hipErrorInvalidValue;

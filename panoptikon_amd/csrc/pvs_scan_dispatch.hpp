@@ -42,6 +42,7 @@ struct ScanK {
     // dense_out (lower ends of the rows of tile-crossing files) to the matrix of their upper ends
     uint32_t *fold_bucket;
     uint64_t fold_hi_off;
+    float *fold_bucket_lo;  // minima of the lower bounds over the same buckets: k_candidates_tiles visits only buckets with one at or below the threshold
     // host side only (16 bytes of kernel argument nobody reads): events bound to THIS dispatch by hipExtLaunchKernelGGL — the kernel's
     // start / stop timestamps come from its own completion signal, no marker packet goes into the queue (two hipEventRecord around
     // every kernel of a search cost 30-45 us of a 1.29-ms step at configs[2])

@@ -183,12 +183,13 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
 #pragma unroll
         for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
-    // MODE 5: minima of the files' upper bounds this lane has seen, over FOLD_SLOTS disjoint sets of files (file slot mod FOLD_SLOTS):
+    // MODE 5: minima of the files' upper (and lower) bounds this lane has seen, over FOLD_SLOTS disjoint sets of files (the files that end in
+    // this wave's tiles number s, s + FOLD_SLOTS, ...):
     // its share of the per-query buckets the threshold select reads — registers, written once at the end of the kernel
     constexpr int FOLD_SLOTS = 8;
-    float umin[MODE == 5 ? FOLD_SLOTS : 1];
+    float umin[MODE == 5 ? FOLD_SLOTS : 1], lmin[MODE == 5 ? FOLD_SLOTS : 1];
 #pragma unroll
-    for (int i = 0; i < (MODE == 5 ? FOLD_SLOTS : 1); i++) umin[i] = __builtin_inff();
+    for (int i = 0; i < (MODE == 5 ? FOLD_SLOTS : 1); i++) umin[i] = lmin[i] = __builtin_inff();
     // Candidate emission (MODE 1).  Every (workgroup row stream, half-wave, query) triple owns a SEGMENT of a.seg_cap slots in
     // HBM, written by exactly one LANE (lane (j, h) holds query column j and the rows of half h), so the fill count is a
     // register of that lane: no staging list, no flush, no atomic of any kind.  A segment that overflows is reported through
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         // earlier (asked for at the fold itself, its ~1 us of latency stalled the one wave per SIMD once per tile)
         const bool f5_ok = qi[0].bb == qi[0].bb && qi[0].bb < __builtin_inff() && (!COS || qi[0].bb > 0.f) && qi[0].dscale > 0.f;
         const float f5_inv_sb = COS && f5_ok ? 1.0f / sqrtf(qi[0].bb) : 0.f;
-        uint32_t f5_g = 0, f5_last = 0, f5_spill = 0, f5_allow = 0xffffffffu;
+        uint32_t f5_g = 0, f5_last = 0, f5_spill = 0, f5_allow = 0xffffffffu, f5_seq = 0;
         auto fold_prefetch = [&](uint32_t row_base) {
             if constexpr (MODE == 5) {
                 typedef const __attribute__((address_space(4))) uint32_t *cptr32;
@@ -738,8 +739,10 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 typedef const __attribute__((address_space(4))) uint32_t *cptr32;
                 const uint32_t tile_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(prev_row_base >> 5));
                 const uint64_t row0 = (uint64_t)tile_u * 32u;
+                const uint32_t t_slot = (f5_seq++) & (uint32_t)(FOLD_SLOTS - 1);  // the bucket of this tile's files: (this wave, tile number mod FOLD_SLOTS)
                 if (row0 >= a.n_rows) return;
                 const bool q_ok = f5_ok;
+                float t_u = __builtin_inff(), t_l = __builtin_inff();
                 float LO[32], HI[32];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
@@ -785,12 +788,11 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                     }
                     if (mine) lo_out[(size_t)g_run * a.fold_ld + (uint32_t)q] = L;
                     // (no memory round trip here — a load or a returning atomic per file stalled the one wave per SIMD for its whole
-                    //  latency, ~10 files per tile: +0.39 ms at 4M x 768 x 32 — the minimum goes into one of the lane's registers,
-                    //  picked by the wave-uniform file slot)
-                    const uint32_t sl = g_run & (uint32_t)(FOLD_SLOTS - 1);
+                    //  latency, ~10 files per tile: +0.39 ms at 4M x 768 x 32 — and no slot logic per file either: the files of one tile
+                    //  share a bucket, the tile's two minima go into the lane's registers once per tile)
                     const float uu = U < 0.f ? 0.f : U;  // (raising an upper bound keeps it one; non-negative floats order like their bit patterns)
-#pragma unroll
-                    for (int i = 0; i < FOLD_SLOTS; i++) umin[i] = sl == (uint32_t)i ? fminf(umin[i], uu) : umin[i];
+                    t_u = fminf(t_u, uu);
+                    t_l = fminf(t_l, L);  // (a NaN lower bound — nothing of this query can be bracketed — leaves it: no bucket names a candidate)
                     g_run++;
                 };
                 if (a.fold_weights) {
@@ -870,6 +872,11 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                             forced = false;
                         }
                     }
+                }
+#pragma unroll
+                for (int i = 0; i < FOLD_SLOTS; i++) {
+                    umin[i] = t_slot == (uint32_t)i ? fminf(umin[i], t_u) : umin[i];
+                    lmin[i] = t_slot == (uint32_t)i ? fminf(lmin[i], t_l) : lmin[i];
                 }
             }
         };
@@ -1066,7 +1073,10 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         // this lane's FOLD_SLOTS bucket minima: buckets [(sid * RT + rt) * FOLD_SLOTS, +FOLD_SLOTS) of its query, query-minor rows
 #pragma unroll
         for (int i = 0; i < FOLD_SLOTS; i++)
+        {
             a.fold_bucket[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = __builtin_bit_cast(uint32_t, umin[i]);
+            a.fold_bucket_lo[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = lmin[i];
+        }
     }
     if (MODE == 0 && sid < nstreams) {
         // Each lane holds 16 minima per query (one per accumulator row slot) = 16 disjoint row groups of its query.
