@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
 #pragma unroll
         for (int r = 0; r < (MODE == 0 ? 16 : 1); r++) mins[g][r] = __builtin_inff();
 
-    // MODE 5: minima of the files' upper (and lower) bounds this lane has seen, over FOLD_SLOTS disjoint sets of files (the files that end in
-    // this wave's tiles number s, s + FOLD_SLOTS, ...):
+    // MODE 5: minima of the files' upper bounds (lanes of half 1) / lower bounds (half 0) this lane has seen, over FOLD_SLOTS disjoint sets
+    // of files (the files that end in this wave's tiles number s, s + FOLD_SLOTS, ...):
     // its share of the per-query buckets the threshold select reads — registers, written once at the end of the kernel
     constexpr int FOLD_SLOTS = 8;
-    float umin[MODE == 5 ? FOLD_SLOTS : 1], lmin[MODE == 5 ? FOLD_SLOTS : 1];
+    float xmin[MODE == 5 ? FOLD_SLOTS : 1];
 #pragma unroll
-    for (int i = 0; i < (MODE == 5 ? FOLD_SLOTS : 1); i++) umin[i] = lmin[i] = __builtin_inff();
+    for (int i = 0; i < (MODE == 5 ? FOLD_SLOTS : 1); i++) xmin[i] = __builtin_inff();
     // Candidate emission (MODE 1).  Every (workgroup row stream, half-wave, query) triple owns a SEGMENT of a.seg_cap slots in
     // HBM, written by exactly one LANE (lane (j, h) holds query column j and the rows of half h), so the fill count is a
     // register of that lane: no staging list, no flush, no atomic of any kind.  A segment that overflows is reported through
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                     e.sv[g][2 * i] = score(g, undo_f32((float)pv(g, 2 * i), e.xh[2 * i]), e.xh[2 * i]);
                     e.sv[g][2 * i + 1] = score(g, undo_f32((float)pv(g, 2 * i + 1), e.xh[2 * i + 1]), e.xh[2 * i + 1]);
                 } else if constexpr (MODE == 5) {
-                    // the brackets of two rows: [D(key - err), D(key + err)] widened by 1e-6 (1 + |d|); NaN for a row whose distance may
-                    // be NULL (norm zero / not finite, key not a number): it poisons its file (forced candidate)
+                    // the brackets of two rows: [D(key - err), D(key + err)] widened by 1e-6 (1 + |d|); [-inf, +inf] for a row whose distance
+                    // may be NULL (norm zero / not finite, key not a number): it poisons its file's sums (forced candidate)
 #pragma unroll
                     for (int rr = (i - 8) * 2; rr < (i - 8) * 2 + 2; rr++) {
                         const float x = e.xh[rr];  // cosine: 1/|a|, L2: |a|^2
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                         }
                         lo -= 1e-6f * (1.0f + fabsf(lo));
                         hi += 1e-6f * (1.0f + fabsf(hi));
-                        e.lo16[rr] = valid ? lo : __builtin_nanf("");
-                        e.hi16[rr] = valid ? hi : __builtin_nanf("");
+                        e.lo16[rr] = valid ? lo : -__builtin_inff();
+                        e.hi16[rr] = valid ? hi : __builtin_inff();
                     }
                 } else {
                     const int r = (i - 8) * 2;
@@ -741,18 +741,29 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 const uint64_t row0 = (uint64_t)tile_u * 32u;
                 const uint32_t t_slot = (f5_seq++) & (uint32_t)(FOLD_SLOTS - 1);  // the bucket of this tile's files: (this wave, tile number mod FOLD_SLOTS)
                 if (row0 >= a.n_rows) return;
-                const bool q_ok = f5_ok;
-                float t_u = __builtin_inff(), t_l = __builtin_inff();
-                float LO[32], HI[32];
+                const int q = myq[0];
+                if (q >= (int)a.batch) return;  // (padding queries: nothing of theirs leaves the kernel)
+                // The halves of the wave split the work: after ONE v_permlane32_swap per pair of rows the lanes of half 0 hold the LOWER ends
+                // of all 32 rows of their query, the lanes of half 1 the UPPER ends — the same instruction stream folds both (a sum, an
+                // extreme), widens away from the value (sgn) and keeps one running minimum: of the lower bounds in half 0 (which buckets
+                // can hold a candidate), of the upper bounds in half 1 (the threshold).  (Both ends in every lane, exchanged by 32
+                // shuffles and 64 selects, every minimum through fminf's canonicalisation, an IEEE division per file: ~1,600 instructions
+                // per tile on the one wave per SIMD — 0.39 of the scan's 1.30 ms at 4M x 768 x 32.)
+                float X[32];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float ol = __shfl_xor(e.lo16[r], 32, 64), oh = __shfl_xor(e.hi16[r], 32, 64);
+                    // (inline asm: with __builtin_amdgcn_permlane32_swap hipcc 7.2 used the FIRST result for both — rows t + 4 got the
+                    //  values of rows t (tools/probe/permlane32_swap_test.hip shows the instruction itself does what the ISA says); the
+                    //  nops are the VALU-write -> permlane hazard the compiler would have covered)
+                    float xa = e.lo16[r], xb = e.hi16[r];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(xa), "+v"(xb));
                     const int t = (r & 3) + 8 * (r >> 2);
-                    LO[t] = h ? ol : e.lo16[r];
-                    HI[t] = h ? oh : e.hi16[r];
-                    LO[t + 4] = h ? e.lo16[r] : ol;
-                    HI[t + 4] = h ? e.hi16[r] : oh;
+                    X[t] = xa;      // half 0: lo of row t (its own),        half 1: hi of row t (half 0's)
+                    X[t + 4] = xb;  // half 0: lo of row t + 4 (half 1's),   half 1: hi of row t + 4 (its own)
                 }
+                const float sgn = h ? 1.0f : -1.0f;
+                const float far = h ? __builtin_inff() : -__builtin_inff();  // the end of a bracket that says nothing
+                const float bad = f5_ok ? 0.f : __builtin_nanf("");           // nothing of this query can be bracketed: NaN ends (compare false everywhere)
                 uint32_t g_run = f5_g;  // (the record asked for at the end of the tile before: fold_prefetch)
                 const uint32_t m_last = f5_last, m_spill = f5_spill, m_allow = f5_allow;
                 const uint32_t n_here = a.n_rows - row0 >= 32u ? 32u : (uint32_t)(a.n_rows - row0);
@@ -760,39 +771,28 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                 const uint32_t m_use = m_allow & ~m_spill & m_rows;
                 const uint32_t m_sp = m_spill & m_rows;
                 const uint32_t m_end = m_last & m_rows;
-                const int q = myq[0];
-                const bool mine = h == 0 && q < (int)a.batch;
                 if (m_sp != 0) {
+                    float *sp_out = a.dense_out + (h ? a.fold_hi_off : 0) + row0 * a.dense_ld + (uint32_t)q;
 #pragma unroll
                     for (int i = 0; i < 32; i++)
-                        if (((m_sp >> i) & 1u) && mine) {
-                            a.dense_out[(row0 + (uint64_t)i) * a.dense_ld + (uint32_t)q] = LO[i];
-                            a.dense_out[a.fold_hi_off + (row0 + (uint64_t)i) * a.dense_ld + (uint32_t)q] = HI[i];
-                        }
+                        if ((m_sp >> i) & 1u) sp_out[(size_t)i * a.dense_ld] = X[i];
                 }
-                float *lo_out = (float *)a.fold_out;
-                auto emit = [&](float l, float u, uint32_t cnt, bool forced) {
-                    float L, U;
-                    if (!q_ok) {
-                        L = __builtin_nanf("");
-                        U = __builtin_inff();
-                    } else if (cnt == 0) {
-                        L = U = __builtin_inff();
-                    } else if (forced || !(l == l) || !(u == u)) {
-                        L = -__builtin_inff();
-                        U = __builtin_inff();
+                float *lo_out = (float *)a.fold_out + (uint32_t)q;
+                float t_m = __builtin_inff();  // this tile's minimum of the ends this lane folds
+                // val: the file's aggregate of this lane's ends; cnt rows took part; forced: a weight that says nothing
+                auto emit = [&](float val, uint32_t cnt, bool forced) {
+                    float v;
+                    if (cnt == 0) {
+                        v = __builtin_inff();  // no candidate row: the file is not part of the result at all
+                    } else if (forced) {
+                        v = far;
                     } else {
-                        const float mg = 1e-6f + 1.5e-7f * (float)cnt;
-                        L = l - mg * (1.0f + fabsf(l));
-                        U = u + mg * (1.0f + fabsf(u));
+                        const float mg = sgn * (1e-6f + 1.5e-7f * (float)cnt);
+                        v = __builtin_fmaf(mg, 1.0f + __builtin_fabsf(val), val);  // (an infinite end stays where it is)
                     }
-                    if (mine) lo_out[(size_t)g_run * a.fold_ld + (uint32_t)q] = L;
-                    // (no memory round trip here — a load or a returning atomic per file stalled the one wave per SIMD for its whole
-                    //  latency, ~10 files per tile: +0.39 ms at 4M x 768 x 32 — and no slot logic per file either: the files of one tile
-                    //  share a bucket, the tile's two minima go into the lane's registers once per tile)
-                    const float uu = U < 0.f ? 0.f : U;  // (raising an upper bound keeps it one; non-negative floats order like their bit patterns)
-                    t_u = fminf(t_u, uu);
-                    t_l = fminf(t_l, L);  // (a NaN lower bound — nothing of this query can be bracketed — leaves it: no bucket names a candidate)
+                    v += bad;
+                    if (h == 0) lo_out[(size_t)g_run * a.fold_ld] = v;
+                    t_m = v < t_m ? v : t_m;
                     g_run++;
                 };
                 if (a.fold_weights) {
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                     uint32_t wb[32];
 #pragma unroll
                     for (int i = 0; i < 32; i++) wb[i] = wp[i];
-                    float s_lo = 0.f, s_hi = 0.f, s_w = 0.f;
+                    float s = 0.f, s_w = 0.f;
                     uint32_t cnt = 0;
                     bool forced = false;
 #pragma unroll
@@ -809,75 +809,63 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                         const float w = __builtin_bit_cast(float, wb[i]);
                         if (use) {
                             cnt++;
-                            forced |= !(w > 0.f && w < 1e30f) || !(LO[i] == LO[i]);
-                            s_lo += LO[i] * w;
-                            s_hi += HI[i] * w;
+                            forced |= !(w > 0.f && w < 1e30f);
+                            s = __builtin_fmaf(X[i], w, s);
                             s_w += w;
                         }
                         if ((m_end >> i) & 1u) {
-                            if (!((m_sp >> i) & 1u)) {
-                                const float inv = 1.0f / s_w;
-                                emit(s_lo * inv, s_hi * inv, cnt, forced);
-                            } else {
+                            if (!((m_sp >> i) & 1u))
+                                emit(s * __builtin_amdgcn_rcpf(s_w), cnt, forced);  // (1 ulp: inside the margin)
+                            else
                                 g_run++;
-                            }
-                            s_lo = s_hi = s_w = 0.f;
+                            s = s_w = 0.f;
                             cnt = 0;
                             forced = false;
                         }
                     }
                 } else if (a.fold_agg == PVS_AGG_AVG) {
-                    float s_lo = 0.f, s_hi = 0.f;
+                    float s = 0.f;
                     uint32_t cnt = 0;
 #pragma unroll
                     for (int i = 0; i < 32; i++) {
-                        const bool use = (m_use >> i) & 1u;
-                        if (use) {
+                        if ((m_use >> i) & 1u) {
                             cnt++;
-                            s_lo += LO[i];  // (a NaN bracket poisons the sums: forced below)
-                            s_hi += HI[i];
+                            s += X[i];  // (a row whose distance may be NULL carries -inf / +inf: the sum says nothing, as it must)
                         }
                         if ((m_end >> i) & 1u) {
-                            if (!((m_sp >> i) & 1u)) {
-                                const float inv = 1.0f / (float)(cnt ? cnt : 1u);
-                                emit(s_lo * inv, s_hi * inv, cnt, false);
-                            } else {
+                            if (!((m_sp >> i) & 1u))
+                                emit(s * __builtin_amdgcn_rcpf((float)(cnt ? cnt : 1u)), cnt, false);
+                            else
                                 g_run++;
-                            }
-                            s_lo = s_hi = 0.f;
+                            s = 0.f;
                             cnt = 0;
                         }
                     }
                 } else {
+                    // MIN: the smallest lower / upper end (a NULL-able row: -inf below, ignored above — MIN skips a NULL, and a row that
+                    // is not NULL can only lower it); MAX: the mirror image
                     const bool want_min = a.fold_agg == PVS_AGG_MIN;
-                    float x_lo = want_min ? __builtin_inff() : -__builtin_inff(), x_hi = x_lo;
+                    float x = want_min ? __builtin_inff() : -__builtin_inff();
                     uint32_t cnt = 0;
-                    bool forced = false;
 #pragma unroll
                     for (int i = 0; i < 32; i++) {
-                        const bool use = (m_use >> i) & 1u;
-                        if (use) {
+                        if ((m_use >> i) & 1u) {
                             cnt++;
-                            forced |= !(LO[i] == LO[i]);  // (fmin / fmax drop a NaN: remember it)
-                            x_lo = want_min ? fminf(x_lo, LO[i]) : fmaxf(x_lo, LO[i]);
-                            x_hi = want_min ? fminf(x_hi, HI[i]) : fmaxf(x_hi, HI[i]);
+                            const bool take = want_min ? X[i] < x : X[i] > x;
+                            x = take ? X[i] : x;
                         }
                         if ((m_end >> i) & 1u) {
                             if (!((m_sp >> i) & 1u))
-                                emit(x_lo, x_hi, cnt, forced);
+                                emit(x, cnt, false);
                             else
                                 g_run++;
-                            x_lo = x_hi = want_min ? __builtin_inff() : -__builtin_inff();
+                            x = want_min ? __builtin_inff() : -__builtin_inff();
                             cnt = 0;
-                            forced = false;
                         }
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < FOLD_SLOTS; i++) {
-                    umin[i] = t_slot == (uint32_t)i ? fminf(umin[i], t_u) : umin[i];
-                    lmin[i] = t_slot == (uint32_t)i ? fminf(lmin[i], t_l) : lmin[i];
-                }
+                for (int i = 0; i < FOLD_SLOTS; i++) xmin[i] = (t_slot == (uint32_t)i && t_m < xmin[i]) ? t_m : xmin[i];
             }
         };
         auto epi_rest = [&](Epi &e, auto &&pv) {
@@ -1069,13 +1057,15 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
         for (int g = 0; g < GPW; g++) a.seg_cnt[(size_t)myq[g] * a.seg_stride + seg] = mycnt[g];
     }
 
-    if (MODE == 5 && sid < nstreams && h == 0 && myq[0] < (int)a.batch) {
-        // this lane's FOLD_SLOTS bucket minima: buckets [(sid * RT + rt) * FOLD_SLOTS, +FOLD_SLOTS) of its query, query-minor rows
+    if (MODE == 5 && sid < nstreams && myq[0] < (int)a.batch) {
+        // this lane's FOLD_SLOTS bucket minima: buckets [(sid * RT + rt) * FOLD_SLOTS, +FOLD_SLOTS) of its query, query-minor rows — half 1:
+        // of the upper bounds (raised to 0: raising an upper bound keeps it one; non-negative floats order like their bit patterns),
+        // half 0: of the lower bounds
+        float *out = h ? (float *)a.fold_bucket : a.fold_bucket_lo;
 #pragma unroll
-        for (int i = 0; i < FOLD_SLOTS; i++)
-        {
-            a.fold_bucket[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = __builtin_bit_cast(uint32_t, umin[i]);
-            a.fold_bucket_lo[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = lmin[i];
+        for (int i = 0; i < FOLD_SLOTS; i++) {
+            const float v = xmin[i];
+            out[(size_t)((sid * RT + rt) * FOLD_SLOTS + i) * a.fold_ld + (uint32_t)myq[0]] = (h && v < 0.f) ? 0.f : v;
         }
     }
     if (MODE == 0 && sid < nstreams) {
