@@ -41,6 +41,7 @@
 //   * 256 queries (int8, row pitch <= 1 KiB) run on k_scan_wide (pvs_scan_wide.hpp), not here.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "pvs_lds_dma.hpp"
 #include "pvs_scan_dispatch.hpp"
@@ -824,44 +825,66 @@ __global__ __launch_bounds__(256, scan_waves_per_simd(QG, KSLABS, MODE)) void k_
                         }
                     }
                 } else if (a.fold_agg == PVS_AGG_AVG) {
-                    float s = 0.f;
-                    uint32_t cnt = 0;
+                    // (ALL: no candidate mask, a full tile — the rows of tile-crossing files may be added like any other, what they are added
+                    //  to is never emitted: one scalar branch per row instead of two)
+                    auto rows = [&](auto all_rows) {
+                        float s = 0.f;
+                        uint32_t cnt = 0;
 #pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        if ((m_use >> i) & 1u) {
-                            cnt++;
-                            s += X[i];  // (a row whose distance may be NULL carries -inf / +inf: the sum says nothing, as it must)
+                        for (int i = 0; i < 32; i++) {
+                            if (decltype(all_rows)::value || ((m_use >> i) & 1u)) {
+                                cnt++;
+                                s += X[i];  // (a row whose distance may be NULL carries -inf / +inf: the sum says nothing, as it must)
+                            }
+                            if ((m_end >> i) & 1u) {
+                                if (!((m_sp >> i) & 1u))
+                                    emit(s * __builtin_amdgcn_rcpf((float)(cnt ? cnt : 1u)), cnt, false);
+                                else
+                                    g_run++;
+                                s = 0.f;
+                                cnt = 0;
+                            }
                         }
-                        if ((m_end >> i) & 1u) {
-                            if (!((m_sp >> i) & 1u))
-                                emit(s * __builtin_amdgcn_rcpf((float)(cnt ? cnt : 1u)), cnt, false);
-                            else
-                                g_run++;
-                            s = 0.f;
-                            cnt = 0;
-                        }
-                    }
+                    };
+                    if ((m_allow & m_rows) == 0xffffffffu)
+                        rows(std::true_type{});
+                    else
+                        rows(std::false_type{});
                 } else {
                     // MIN: the smallest lower / upper end (a NULL-able row: -inf below, ignored above — MIN skips a NULL, and a row that
                     // is not NULL can only lower it); MAX: the mirror image
-                    const bool want_min = a.fold_agg == PVS_AGG_MIN;
-                    float x = want_min ? __builtin_inff() : -__builtin_inff();
-                    uint32_t cnt = 0;
+                    auto rows = [&](auto all_rows, auto want_min) {
+                        constexpr bool MN = decltype(want_min)::value;
+                        float x = MN ? __builtin_inff() : -__builtin_inff();
+                        uint32_t cnt = 0;
 #pragma unroll
-                    for (int i = 0; i < 32; i++) {
-                        if ((m_use >> i) & 1u) {
-                            cnt++;
-                            const bool take = want_min ? X[i] < x : X[i] > x;
-                            x = take ? X[i] : x;
+                        for (int i = 0; i < 32; i++) {
+                            if (decltype(all_rows)::value || ((m_use >> i) & 1u)) {
+                                cnt++;
+                                const bool take = MN ? X[i] < x : X[i] > x;
+                                x = take ? X[i] : x;
+                            }
+                            if ((m_end >> i) & 1u) {
+                                if (!((m_sp >> i) & 1u))
+                                    emit(x, cnt, false);
+                                else
+                                    g_run++;
+                                x = MN ? __builtin_inff() : -__builtin_inff();
+                                cnt = 0;
+                            }
                         }
-                        if ((m_end >> i) & 1u) {
-                            if (!((m_sp >> i) & 1u))
-                                emit(x, cnt, false);
-                            else
-                                g_run++;
-                            x = want_min ? __builtin_inff() : -__builtin_inff();
-                            cnt = 0;
-                        }
+                    };
+                    const bool all = (m_allow & m_rows) == 0xffffffffu;
+                    if (a.fold_agg == PVS_AGG_MIN) {
+                        if (all)
+                            rows(std::true_type{}, std::true_type{});
+                        else
+                            rows(std::false_type{}, std::true_type{});
+                    } else {
+                        if (all)
+                            rows(std::true_type{}, std::false_type{});
+                        else
+                            rows(std::false_type{}, std::false_type{});
                     }
                 }
 #pragma unroll
