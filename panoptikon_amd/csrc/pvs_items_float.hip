@@ -7,16 +7,20 @@
 // 98 M exact chains to return 32 pages of 100 files).  The row search never did that: it filters on the matrix cores with
 // rigorous error bounds and rescans only survivors.  This file does the same for per-item pages:
 //
-//   1. k_scan MODE 4 (pvs_scan_kernel.hpp): one corpus pass on the matrix cores writes the scan KEY of every (row, query) pair,
+//   1. one corpus pass on the matrix cores (pvs_scan_kernel.hpp) yields the scan KEY of every (row, query) pair,
 //      |key - kappa| <= err = eA + eR |a|^2, kappa = the reference key the distance D is a monotone function of (cosine:
-//      D = fl32(1 + kappa / sqrt(bb)); L2: D = fl32(sqrt(kappa)); HISTORY.md section 4.2 — the algebra passes A/B/C rest on);
-//   2. k_group_bounds: per (file, query) the bracket [lo_i, hi_i] of every row's distance is folded into a bracket [L, U] of the
+//      D = fl32(1 + kappa / sqrt(bb)); L2: D = fl32(sqrt(kappa)); HISTORY.md section 4.2 — the algebra passes A/B/C rest on).
+//      Files that are runs of rows: k_scan MODE 5 folds steps 1 + 2 in its epilogue (no key matrix), only the
+//      rows of tile-crossing files leave it (k_spill_bounds); otherwise MODE 4 writes the keys and k_run_bounds / k_group_bounds fold;
+//   2. per (file, query) the bracket [lo_i, hi_i] of every row's distance is folded into a bracket [L, U] of the
 //      file's aggregate — AVG: means of the brackets; MIN / MAX: min / max of the ends; SUM(d w)/SUM(w) with positive weights: the
 //      weighted means — widened for every rounding on the way.  A file with a row whose distance may be NULL (zero / non-finite
 //      norm, non-finite key) or a non-positive weight is FORCED: L = -inf, it never lowers the threshold.  U goes into one of
-//      16,384 per-query buckets (atomic minimum); L is stored;
+//      16,384 per-query buckets (a minimum per bucket: registers of the scan's lanes in MODE 5, atomics otherwise); L is stored, and
+//      MODE 5 keeps the buckets' minima of L as well;
 //   3. k_kth (pass A's select): T = the k-th smallest bucket minimum >= the k-th smallest U >= the k-th smallest exact value;
-//   4. k_candidates / k_union: every file with L <= T for a query is that query's candidate (every file of its true page is one:
+//   4. k_candidates_tiles (after MODE 5: only the buckets whose smallest L is at or below T are looked into) / k_candidates (the dense
+//      form) / k_union: every file with L <= T for a query is that query's candidate (every file of its true page is one:
 //      exact value <= the k-th exact value <= T, and L <= exact); a query that names more than 1,024 ties with everything and is
 //      set aside; the union of the others' candidates is the file list of the chunk;
 //   5. pvs_sparse_groups_of_files (pvs_sparse.hip): the exact in-order chain on the rows of those files only, SQLite's KBN sums per
