@@ -265,27 +265,45 @@ __global__ __launch_bounds__(256) void k_spill_bounds(BoundsK a, const uint32_t 
     float x_lo = c.want_min ? __builtin_inff() : -__builtin_inff(), x_hi = x_lo;
     uint32_t cnt = 0;
     bool forced = false;
-    for (uint32_t e = e0; e < e1; e++) {
-        const uint32_t row = a.rows_are_runs ? e : a.grp_rows[e];
-        if (a.mask && !a.mask[row]) continue;
-        cnt++;
-        const float lo = lo_rows[(size_t)row * a.ld + q], hi = hi_rows[(size_t)row * a.ld + q];
-        if (!(lo == lo) || !(hi == hi)) forced = true;
-        if (c.weighted) {
-            const float w = a.weights[row];
-            if (!(w > 0.f && w < 1e30f)) forced = true;
-            s_lo += lo * w;
-            s_hi += hi * w;
-            s_w += w;
-        } else if (c.want_min) {
-            x_lo = fminf(x_lo, lo);
-            x_hi = fminf(x_hi, hi);
-        } else if (c.want_max) {
-            x_lo = fmaxf(x_lo, lo);
-            x_hi = fmaxf(x_hi, hi);
-        } else {
-            s_lo += lo;
-            s_hi += hi;
+    // (four rows at a time, their loads issued together: a row after the other was one memory round trip per row and end)
+    for (uint32_t e = e0; e < e1; e += 4) {
+        uint32_t row[4];
+        bool in[4];
+        float lo4[4], hi4[4], w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            in[i] = e + i < e1;
+            row[i] = in[i] ? (a.rows_are_runs ? e + i : a.grp_rows[e + i]) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lo4[i] = in[i] ? lo_rows[(size_t)row[i] * a.ld + q] : 0.f;
+            hi4[i] = in[i] ? hi_rows[(size_t)row[i] * a.ld + q] : 0.f;
+            w4[i] = (in[i] && c.weighted) ? a.weights[row[i]] : 1.0f;
+            if (a.mask) in[i] = in[i] && a.mask[row[i]] != 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!in[i]) continue;
+            cnt++;
+            const float lo = lo4[i], hi = hi4[i];
+            if (!(lo == lo) || !(hi == hi)) forced = true;
+            if (c.weighted) {
+                const float w = w4[i];
+                if (!(w > 0.f && w < 1e30f)) forced = true;
+                s_lo += lo * w;
+                s_hi += hi * w;
+                s_w += w;
+            } else if (c.want_min) {
+                x_lo = fminf(x_lo, lo);
+                x_hi = fminf(x_hi, hi);
+            } else if (c.want_max) {
+                x_lo = fmaxf(x_lo, lo);
+                x_hi = fmaxf(x_hi, hi);
+            } else {
+                s_lo += lo;
+                s_hi += hi;
+            }
         }
     }
     float L, U;
