@@ -446,12 +446,17 @@ __global__ __launch_bounds__(256) void k_certify_init(uint32_t *bmin, uint32_t n
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_bits; i += stride) bits[i] = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_small; i += stride) small[i] = 0;
 }
-// bucket minima [BUCKETS][ld] -> [nb][BUCKETS] (what k_kth reads)
-__global__ __launch_bounds__(256) void k_bucket_transpose(const uint32_t *in, uint32_t nb, uint32_t ld, uint32_t *out) {
+// bucket minima [BUCKETS][ld] -> [nb][BUCKETS / merge] (what k_kth reads): `merge` neighbouring buckets become one (the union of
+// disjoint sets of files is one; a page of k <= 256 files does not need 16,384 buckets to resolve its k-th smallest upper bound, and
+// the select over 4,096 values takes a third of the time)
+__global__ __launch_bounds__(256) void k_bucket_transpose(const uint32_t *in, uint32_t nb, uint32_t ld, uint32_t *out, uint32_t merge) {
+    const uint32_t per = BUCKETS / merge;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nb * BUCKETS) return;
-    const uint32_t q = i / BUCKETS, b = i % BUCKETS;
-    out[i] = in[(size_t)b * ld + q];
+    if (i >= nb * per) return;
+    const uint32_t q = i / per, b = i % per;
+    uint32_t m = 0xffffffffu;  // (bit patterns of non-negative floats, +inf included: unsigned order)
+    for (uint32_t j = 0; j < merge; j++) m = min(m, in[(size_t)(b * merge + j) * ld + q]);
+    out[i] = m;
 }
 // the union of the lists of the queries that stayed below QCAP: a file enters once (a bit per file), with its allowed rows counted
 __global__ __launch_bounds__(256) void k_union(const uint32_t *qcnt, const uint32_t *qlist, uint32_t nb, uint32_t *bits, const uint32_t *grp_off, const uint32_t *grp_rows,
@@ -594,8 +599,9 @@ pvs_status pvs_float_groups_certified(pvs_index *ix, SearchCtx &c, const void *d
         HIP_TRY(hipGetLastError());
         // 3. the thresholds, 4. every query's candidate files and their union
         uint32_t *d_bmin_t = d_bmin + (size_t)ld * BUCKETS;
-        hipLaunchKernelGGL(k_bucket_transpose, dim3((nb * BUCKETS + 255) / 256), dim3(256), 0, s, d_bmin, nb, ld, d_bmin_t);
-        HIP_TRY(pvs_launch_kth((const float *)d_bmin_t, BUCKETS, nb, k, d_thr, s));
+        const uint32_t merge = k <= 256 ? 4u : (k <= 512 ? 2u : 1u);  // (>= 16 buckets per page entry stay)
+        hipLaunchKernelGGL(k_bucket_transpose, dim3((nb * (BUCKETS / merge) + 255) / 256), dim3(256), 0, s, d_bmin, nb, ld, d_bmin_t, merge);
+        HIP_TRY(pvs_launch_kth((const float *)d_bmin_t, BUCKETS / merge, nb, k, d_thr, s));
         if (fold_in_scan) {
             // (the files folded in the scan: only the buckets whose smallest lower bound is at or below the threshold; the tile-crossing
             //  files: their compact matrix)
