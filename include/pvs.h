@@ -376,7 +376,10 @@ pvs_status pvs_score_batch(pvs_index *idx, const void *queries, pvs_dtype query_
  * filters/exact.rs:67-80), rank the groups (value asc, group id asc, NULL last) and
  * return page 1 of size k.  Groups are the group_ids given to pvs_index_add (identity
  * when none were given).  out_groups/out_values: [batch][k] host buffers; values are the
- * f64 SQLite would produce (Kahan-Babuska-Neumaier sums in row order). */
+ * f64 SQLite would produce (Kahan-Babuska-Neumaier sums in row order).
+ * "Score every row" is the contract, not always the work: over f16 / f32 rows the page is CERTIFIED (matrix-core brackets of every
+ * file's aggregate, the exact in-order chain on the files that can reach the page only; whatever cannot be certified is scored
+ * exactly as before) — the same page and values bit for bit; pvs_debug_set("no_float_certify", 1) forces the exact-everywhere route. */
 pvs_status pvs_search_groups(pvs_index *idx, const void *queries, pvs_dtype query_dtype, uint32_t batch,
                              uint32_t k, pvs_metric metric, pvs_agg agg, const float *row_weights,
                              int64_t *out_groups, double *out_values, uint32_t *out_count);
