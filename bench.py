@@ -952,89 +952,90 @@ def main():
             # GROUP BY file, AVG, rank): 32 float queries over 4M x 768 rows in 1.33M files — every (row, query) pair is one in-order f32
             # chain, so the scorer (k_exact_wide, round 5) is bound by the packed-f32 VALU rate, not by HBM: its roofline is that rate
             n_it, b_it, k_it = 4_000_000, 32, 50
-            ixg = pvs.VectorIndex(pvs.F16, D, device=device, capacity_rows=n_it)
-            stg = pvs.DeviceBuffer(chunk * D * 4, device)
-            rng_g = np.random.default_rng(7)
-            grp_all = []
-            for off in range(0, n_it, chunk):
-                m = min(chunk, n_it - off)
-                L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, off, m, D, stg.ptr))
-                g = np.sort(rng_g.integers(off // 3, (off + m) // 3 + 1, m)).astype(np.int64)  # ~3 adjacent rows per file
-                grp_all.append(g)
-                L.check(lib.pvs_index_add_f32(ixg._h, stg.ptr, m, None, g.ctypes.data, L.DEVICE))
-            stg.free()
-            ixg.sync()
-            qg = np.empty((b_it, D), np.float32)
-            qtmp = pvs.DeviceBuffer(b_it * D * 4, device)
-            L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b_it, D, qtmp.ptr))
-            qg[:] = qtmp.to_numpy(np.float32, (b_it, D))
-            qtmp.free()
-            for _ in range(2):
-                ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
-            ixg.set_profiling(True)
-            ixg.profile(reset=True)
-            n_calls = 6
-            cq0, cr0 = pvs.debug_get("float_certify_queries"), pvs.debug_get("float_certify_rows")
-            t_g = time.perf_counter()
-            for _ in range(n_calls):
-                gg, gv, gc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
-            el_g = time.perf_counter() - t_g
-            cert_q, cert_r = pvs.debug_get("float_certify_queries") - cq0, pvs.debug_get("float_certify_rows") - cr0
-            pg_ = ixg.profile()
-            ixg.set_profiling(False)
-            sms_g = pg_.scan_ms / max(pg_.scan_launches, 1)
-            # Round 6: the page is CERTIFIED, not computed row by row (csrc/pvs_items_float.hip): one matrix-core pass writes the scan key of
-            # every (row, query) pair, per-file brackets of the aggregate pick the files that can reach the page, and the reference's
-            # in-order f32 chain runs on those files only.  The dominant kernel is the scan (k_scan MODE 4): HBM-bound, the rows once.
-            # (Until round 5 every pair ran the exact chain: k_exact_wide, 4.05 ms of a 4.58-ms call, bound by the packed-f32 VALU rate.)
-            by_g = n_it * D * 2
-            gbs_g = by_g / (sms_g * 1e-3) / 1e9 if pg_.scan_launches else 0.0
-            under_g = None
-            if not args.no_peaks:
-                try:
-                    under_g = sample_clock_and_power(lambda i: ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG), lambda: None, seconds=1.5)
-                except Exception as e:  # noqa: BLE001
-                    under_g = {"error": str(e)}
-            # the exact-everywhere route on the same index, for the record (pvs_debug no_float_certify)
-            pvs.debug_set("no_float_certify", 1)
-            try:
-                ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
-                t_x = time.perf_counter()
+            for it_name, it_dt, it_esz, it_orc in (("f16", pvs.F16, 2, "F16"), ("f32", pvs.F32, 4, "F32")):  # (round 6, end: the reference's exact mode IS f32 — its line is driver-visible too)
+                ixg = pvs.VectorIndex(it_dt, D, device=device, capacity_rows=n_it)
+                stg = pvs.DeviceBuffer(chunk * D * 4, device)
+                rng_g = np.random.default_rng(7)
+                grp_all = []
+                for off in range(0, n_it, chunk):
+                    m = min(chunk, n_it - off)
+                    L.check(lib.pvs_synth_rows_f32(device, SEED_CORPUS, off, m, D, stg.ptr))
+                    g = np.sort(rng_g.integers(off // 3, (off + m) // 3 + 1, m)).astype(np.int64)  # ~3 adjacent rows per file
+                    grp_all.append(g)
+                    L.check(lib.pvs_index_add_f32(ixg._h, stg.ptr, m, None, g.ctypes.data, L.DEVICE))
+                stg.free()
+                ixg.sync()
+                qg = np.empty((b_it, D), np.float32)
+                qtmp = pvs.DeviceBuffer(b_it * D * 4, device)
+                L.check(lib.pvs_synth_rows_f32(device, SEED_QUERY, 0, b_it, D, qtmp.ptr))
+                qg[:] = qtmp.to_numpy(np.float32, (b_it, D))
+                qtmp.free()
                 for _ in range(2):
-                    xg, xv, xc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
-                ms_exact_everywhere = (time.perf_counter() - t_x) / 2 * 1e3
-            finally:
-                pvs.debug_set("no_float_certify", 0)
-            rec = {"tag": "items_f16x32", "config": {"workload": f"per-item AVG: {n_it}x{D} f16 rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
-                              "batch": b_it, "k": k_it},
-                   "what": "the reference's exact mode per item over FLOAT rows (GROUP BY file, AVG, page): certified — matrix-core brackets per file, exact in-order rescan of the candidate files only",
-                   "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
-                   "dtype": "f16 rows; brackets from f16 MFMA keys, pages from f32 chains", "data": "synthetic",
-                   "roofline": {"bound": "hbm", "achieved": round(gbs_g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_g / HBM_PEAK_GBS, 4),
-                                "traffic": replay_traffic(n_it, D, "f16", b_it)[0], "traffic_source": replay_traffic(n_it, D, "f16", b_it)[1],
-                                "kernel": "k_scan<f16, 1536 B, 32 queries, MODE 5> (per-row brackets of the distance folded per file in the epilogue)", "launches": int(pg_.scan_launches),
-                                "avg_launch_ms": round(sms_g, 4), "algorithmic_bytes_per_launch": int(by_g), "kernel_events": "timed region",
-                                "whole_call_frac_of_peak": round(by_g / (el_g / n_calls) / 1e9 / HBM_PEAK_GBS, 4),
-                                **({"under_load": under_g} if under_g else {})},
-                   "certified": {"queries_per_call": cert_q / n_calls, "candidate_rows_per_query": round(cert_r / max(cert_q, 1), 1),
-                                 "exact_everywhere_ms_per_call": round(ms_exact_everywhere, 3),
-                                 "same_pages_as_exact_everywhere": bool(np.array_equal(gg, xg) and np.array_equal(gv.view(np.uint64), xv.view(np.uint64)) and np.array_equal(gc, xc))}}
-            if not args.no_verify:  # one column against the oracle over ALL rows (scored chunk by chunk), aggregated and ranked as SQLite does
-                import oracle as orc_g
+                    ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                ixg.set_profiling(True)
+                ixg.profile(reset=True)
+                n_calls = 6
+                cq0, cr0 = pvs.debug_get("float_certify_queries"), pvs.debug_get("float_certify_rows")
+                t_g = time.perf_counter()
+                for _ in range(n_calls):
+                    gg, gv, gc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                el_g = time.perf_counter() - t_g
+                cert_q, cert_r = pvs.debug_get("float_certify_queries") - cq0, pvs.debug_get("float_certify_rows") - cr0
+                pg_ = ixg.profile()
+                ixg.set_profiling(False)
+                sms_g = pg_.scan_ms / max(pg_.scan_launches, 1)
+                # Round 6: the page is CERTIFIED, not computed row by row (csrc/pvs_items_float.hip): one matrix-core pass writes the scan key of
+                # every (row, query) pair, per-file brackets of the aggregate pick the files that can reach the page, and the reference's
+                # in-order f32 chain runs on those files only.  The dominant kernel is the scan (k_scan MODE 4): HBM-bound, the rows once.
+                # (Until round 5 every pair ran the exact chain: k_exact_wide, 4.05 ms of a 4.58-ms call, bound by the packed-f32 VALU rate.)
+                by_g = n_it * D * it_esz
+                gbs_g = by_g / (sms_g * 1e-3) / 1e9 if pg_.scan_launches else 0.0
+                under_g = None
+                if not args.no_peaks:
+                    try:
+                        under_g = sample_clock_and_power(lambda i: ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG), lambda: None, seconds=1.5)
+                    except Exception as e:  # noqa: BLE001
+                        under_g = {"error": str(e)}
+                # the exact-everywhere route on the same index, for the record (pvs_debug no_float_certify)
+                pvs.debug_set("no_float_certify", 1)
+                try:
+                    ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                    t_x = time.perf_counter()
+                    for _ in range(2):
+                        xg, xv, xc = ixg.search_groups(qg, k_it, metric, pvs.AGG_AVG)
+                    ms_exact_everywhere = (time.perf_counter() - t_x) / 2 * 1e3
+                finally:
+                    pvs.debug_set("no_float_certify", 0)
+                rec = {"tag": f"items_{it_name}x32", "config": {"workload": f"per-item AVG: {n_it}x{D} {it_name} rows in ~{n_it // 3} files, batch {b_it}, {args.metric}, k={k_it}", "rows": n_it, "dim": D,
+                                  "batch": b_it, "k": k_it},
+                       "what": "the reference's exact mode per item over FLOAT rows (GROUP BY file, AVG, page): certified — matrix-core brackets per file, exact in-order rescan of the candidate files only",
+                       "metric": "knn_queries_per_sec", "value": round(n_calls * b_it / el_g, 1), "unit": "queries/s", "steps": n_calls, "ms_per_step": round(el_g / n_calls * 1e3, 4),
+                       "dtype": f"{it_name} rows; brackets from f16 MFMA keys, pages from f32 chains", "data": "synthetic",
+                       "roofline": {"bound": "hbm", "achieved": round(gbs_g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_g / HBM_PEAK_GBS, 4),
+                                    "traffic": replay_traffic(n_it, D, it_name, b_it)[0], "traffic_source": replay_traffic(n_it, D, it_name, b_it)[1],
+                                    "kernel": f"k_scan<{it_name}, {D * it_esz} B, 32 queries, MODE 5> (per-row brackets of the distance folded per file in the epilogue)", "launches": int(pg_.scan_launches),
+                                    "avg_launch_ms": round(sms_g, 4), "algorithmic_bytes_per_launch": int(by_g), "kernel_events": "timed region",
+                                    "whole_call_frac_of_peak": round(by_g / (el_g / n_calls) / 1e9 / HBM_PEAK_GBS, 4),
+                                    **({"under_load": under_g} if under_g else {})},
+                       "certified": {"queries_per_call": cert_q / n_calls, "candidate_rows_per_query": round(cert_r / max(cert_q, 1), 1),
+                                     "exact_everywhere_ms_per_call": round(ms_exact_everywhere, 3),
+                                     "same_pages_as_exact_everywhere": bool(np.array_equal(gg, xg) and np.array_equal(gv.view(np.uint64), xv.view(np.uint64)) and np.array_equal(gc, xc))}}
+                if not args.no_verify:  # one column against the oracle over ALL rows (scored chunk by chunk), aggregated and ranked as SQLite does
+                    import oracle as orc_g
 
-                t_o = time.time()
-                thr_g = min(os.cpu_count() or 1, 256)
-                omet_g = orc_g.COSINE if metric == pvs.COSINE else orc_g.L2
-                col = b_it - 1
-                dd = np.concatenate([orc_g.score_all(orc_g.F16, omet_g, ixg.read_rows(off, min(args.chunk_rows, n_it - off)), qg[col], threads=thr_g)
-                                     for off in range(0, n_it, args.chunk_rows)])
-                og_, ov_ = orc_g.aggregate(dd, np.concatenate(grp_all), orc_g.AGG_AVG)
-                eg_, ev_ = orc_g._rank_groups(og_, ov_, k_it)
-                rec["parity"] = {"oracle_rows": n_it, "oracle_column": col, "oracle_seconds": round(time.time() - t_o, 1),
-                                 "groups_and_f64_values_bit_exact": bool(int(gc[col]) == len(eg_) and np.array_equal(gg[col, :len(eg_)], eg_)
-                                                                         and np.array_equal(gv[col, :len(eg_)].view(np.uint64), np.asarray(ev_).view(np.uint64)))}
-            secondary.append(rec)
-            ixg.close()
+                    t_o = time.time()
+                    thr_g = min(os.cpu_count() or 1, 256)
+                    omet_g = orc_g.COSINE if metric == pvs.COSINE else orc_g.L2
+                    col = b_it - 1
+                    dd = np.concatenate([orc_g.score_all(getattr(orc_g, it_orc), omet_g, ixg.read_rows(off, min(args.chunk_rows, n_it - off)), qg[col], threads=thr_g)
+                                         for off in range(0, n_it, args.chunk_rows)])
+                    og_, ov_ = orc_g.aggregate(dd, np.concatenate(grp_all), orc_g.AGG_AVG)
+                    eg_, ev_ = orc_g._rank_groups(og_, ov_, k_it)
+                    rec["parity"] = {"oracle_rows": n_it, "oracle_column": col, "oracle_seconds": round(time.time() - t_o, 1),
+                                     "groups_and_f64_values_bit_exact": bool(int(gc[col]) == len(eg_) and np.array_equal(gg[col, :len(eg_)], eg_)
+                                                                             and np.array_equal(gv[col, :len(eg_)].view(np.uint64), np.asarray(ev_).view(np.uint64)))}
+                secondary.append(rec)
+                ixg.close()
             # (f) similar_to at the reference's measured scale (filters/item_similarity.rs:432-581; its worst performer: 9.5-31 s per call
             # at ~690k vectors, docs/or-composition-penalty.md:225): the 8 stored vectors of one item against every other row, AVG per
             # item, page of 100 — int8 rows (quant mode)
